@@ -1,0 +1,256 @@
+"""CPU oracle for the sdfest hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+numpy front-end over ``oracle/libsdfr_oracle.so`` (built by ``oracle/Makefile``
+from ``sdfr_oracle.c`` / ``sdfr_oracle_impl.h``).  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package; nothing under ``sdfest_amd/`` does.
+
+Parity status: pinned against golden vectors captured from the reference's own
+importable code (``tools/make_goldens.py``; see ``tests/test_oracle_golden.py``).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsdfr_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (no GPU, no reference sources involved)."""
+    src = [os.path.join(_HERE, f) for f in ("sdfr_oracle.c", "sdfr_oracle_impl.h")]
+    stale = not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libsdfr_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+    return _lib
+
+
+def _sfx(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return "_f32", ctypes.c_float
+    if dtype == np.float64:
+        return "_f64", ctypes.c_double
+    raise TypeError(f"oracle supports float32/float64, got {dtype}")
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _pose(position, orientation, inv_scale, dtype):
+    pos = _c(position, dtype).reshape(-1, 3)
+    quat = _c(orientation, dtype).reshape(-1, 4)
+    isc = _c(inv_scale, dtype).reshape(-1)
+    B = pos.shape[0]
+    assert quat.shape[0] == B and isc.shape[0] == B
+    return pos, quat, isc, B
+
+
+def render_forward(sdf, position, orientation, inv_scale, width, height, cx, cy, fx, fy,
+                   threshold, dtype=np.float32, max_steps=0, with_aux=False):
+    """Depth render of B poses of one SDF.  cx, cy are pixel-centre-0.5 intrinsics.
+
+    Returns depth (B,H,W); with_aux=True also returns (steps int32, margin).
+    """
+    sfx, _ = _sfx(dtype)
+    sdf = _c(sdf, dtype)
+    R = sdf.shape[0]
+    pos, quat, isc, B = _pose(position, orientation, inv_scale, dtype)
+    depth = np.empty((B, height, width), dtype=dtype)
+    steps = np.empty((B, height, width), dtype=np.int32) if with_aux else None
+    margin = np.empty((B, height, width), dtype=dtype) if with_aux else None
+    fn = getattr(lib(), "sdfo_render_forward" + sfx)
+    fn.restype = None
+    fn(_p(sdf), ctypes.c_int(R), _p(pos), _p(quat), _p(isc), ctypes.c_int(B),
+       ctypes.c_int(width), ctypes.c_int(height), ctypes.c_double(cx), ctypes.c_double(cy),
+       ctypes.c_double(fx), ctypes.c_double(fy), ctypes.c_double(threshold), _p(depth),
+       _p(steps), _p(margin), ctypes.c_int(max_steps))
+    if with_aux:
+        return depth, steps, margin
+    return depth
+
+
+def render_backward(grad_depth, depth, sdf, position, orientation, inv_scale, cx, cy, fx, fy,
+                    dtype=np.float32, sdf_grad_mode=0):
+    """Returns (g_sdf (R,R,R) summed over views, g_pos (B,3), g_quat (B,4), g_inv_scale (B,))."""
+    sfx, _ = _sfx(dtype)
+    sdf = _c(sdf, dtype)
+    R = sdf.shape[0]
+    pos, quat, isc, B = _pose(position, orientation, inv_scale, dtype)
+    depth = _c(depth, dtype).reshape(B, *np.shape(depth)[-2:])
+    H, W = depth.shape[-2:]
+    grad_depth = _c(grad_depth, dtype).reshape(B, H, W)
+    g_sdf = np.empty((R, R, R), dtype=dtype)
+    g_pos = np.empty((B, 3), dtype=dtype)
+    g_quat = np.empty((B, 4), dtype=dtype)
+    g_isc = np.empty((B,), dtype=dtype)
+    fn = getattr(lib(), "sdfo_render_backward" + sfx)
+    fn.restype = None
+    fn(_p(grad_depth), _p(depth), _p(sdf), ctypes.c_int(R), _p(pos), _p(quat), _p(isc),
+       ctypes.c_int(B), ctypes.c_int(W), ctypes.c_int(H), ctypes.c_double(cx),
+       ctypes.c_double(cy), ctypes.c_double(fx), ctypes.c_double(fy),
+       ctypes.c_int(sdf_grad_mode), _p(g_sdf), _p(g_pos), _p(g_quat), _p(g_isc))
+    return g_sdf, g_pos, g_quat, g_isc
+
+
+def render_derivative_images(depth, sdf, position, orientation, inv_scale, cx, cy, fx, fy,
+                             dtype=np.float64):
+    """(B,H,W,8) per-pixel d depth / d (px,py,pz,qx,qy,qz,qw,inv_scale)."""
+    sfx, _ = _sfx(dtype)
+    sdf = _c(sdf, dtype)
+    R = sdf.shape[0]
+    pos, quat, isc, B = _pose(position, orientation, inv_scale, dtype)
+    depth = _c(depth, dtype).reshape(B, *np.shape(depth)[-2:])
+    H, W = depth.shape[-2:]
+    out = np.empty((B, H, W, 8), dtype=dtype)
+    fn = getattr(lib(), "sdfo_render_derivative_images" + sfx)
+    fn.restype = None
+    fn(_p(depth), _p(sdf), ctypes.c_int(R), _p(pos), _p(quat), _p(isc), ctypes.c_int(B),
+       ctypes.c_int(W), ctypes.c_int(H), ctypes.c_double(cx), ctypes.c_double(cy),
+       ctypes.c_double(fx), ctypes.c_double(fy), _p(out))
+    return out
+
+
+def pc_loss_forward(points, position, orientation, scale, sdf, dtype=np.float32):
+    sfx, _ = _sfx(dtype)
+    sdf = _c(sdf, dtype)
+    pts = _c(points, dtype).reshape(-1, 3)
+    pos, quat, sc = _c(position, dtype), _c(orientation, dtype), _c(scale, dtype).reshape(1)
+    out = np.empty((pts.shape[0],), dtype=dtype)
+    fn = getattr(lib(), "sdfo_pc_loss_forward" + sfx)
+    fn.restype = None
+    fn(_p(pts), ctypes.c_int(pts.shape[0]), _p(pos), _p(quat), _p(sc), _p(sdf),
+       ctypes.c_int(sdf.shape[0]), _p(out))
+    return out
+
+
+def pc_loss_backward(grad_out, points, position, orientation, scale, sdf, dtype=np.float32):
+    """Returns (g_sdf, g_pos (3,), g_quat (4,), g_scale ())."""
+    sfx, _ = _sfx(dtype)
+    sdf = _c(sdf, dtype)
+    R = sdf.shape[0]
+    pts = _c(points, dtype).reshape(-1, 3)
+    go = _c(grad_out, dtype).reshape(-1)
+    pos, quat, sc = _c(position, dtype), _c(orientation, dtype), _c(scale, dtype).reshape(1)
+    g_sdf = np.empty((R, R, R), dtype=dtype)
+    g_pos = np.empty(3, dtype=dtype)
+    g_quat = np.empty(4, dtype=dtype)
+    g_scale = np.empty(1, dtype=dtype)
+    fn = getattr(lib(), "sdfo_pc_loss_backward" + sfx)
+    fn.restype = None
+    fn(_p(go), _p(pts), ctypes.c_int(pts.shape[0]), _p(pos), _p(quat), _p(sc), _p(sdf),
+       ctypes.c_int(R), _p(g_sdf), _p(g_pos), _p(g_quat), _p(g_scale))
+    return g_sdf, g_pos, g_quat, g_scale[0]
+
+
+def decoder_forward(params, config, z, dtype=np.float32, enforce_tsdf=False):
+    """config: the reference's vae yaml dict (keys latent_size, decoder{fc_layers,conv_layers}, tsdf).
+
+    params: flat array in state_dict order (see pack_decoder_params)."""
+    sfx, _ = _sfx(dtype)
+    dec = config["decoder"]
+    fc_out = np.array([l["out"] for l in dec["fc_layers"]], dtype=np.int32)
+    conv = dec["conv_layers"]
+    ins = np.array([l["in_size"] for l in conv], dtype=np.int32)
+    cin = np.array([l["in_channels"] for l in conv], dtype=np.int32)
+    cout = np.array([l["out_channels"] for l in conv], dtype=np.int32)
+    ks = np.array([l["kernel_size"] for l in conv], dtype=np.int32)
+    relu = np.array([1 if l["relu"] else 0 for l in conv], dtype=np.int32)
+    volume = int(config.get("sdf_size", 64))
+    tsdf = config.get("tsdf", False)
+    tsdf = float(tsdf) if tsdf is not False else 0.0
+    z = _c(z, dtype).reshape(-1, config["latent_size"])
+    params = _c(params, dtype)
+    out = np.empty((z.shape[0], 1, volume, volume, volume), dtype=dtype)
+    fn = getattr(lib(), "sdfo_decoder_forward" + sfx)
+    fn.restype = ctypes.c_int
+    rc = fn(_p(params), ctypes.c_int(config["latent_size"]), ctypes.c_int(len(fc_out)),
+            _p(fc_out), ctypes.c_int(len(conv)), _p(ins), _p(cin), _p(cout), _p(ks), _p(relu),
+            ctypes.c_int(volume), ctypes.c_double(tsdf), ctypes.c_int(int(enforce_tsdf)), _p(z),
+            ctypes.c_int(z.shape[0]), _p(out))
+    if rc != 0:
+        raise ValueError(f"decoder layer description inconsistent (code {rc})")
+    return out
+
+
+def pack_decoder_params(state, n_fc, n_conv, prefix="decoder."):
+    """Flatten a state-dict-like mapping (name -> array) into the oracle/product order."""
+    parts = []
+    for i in range(n_fc):
+        parts += [state[f"{prefix}_fc_layers.{i}.weight"], state[f"{prefix}_fc_layers.{i}.bias"]]
+    for i in range(n_conv):
+        parts += [state[f"{prefix}_conv_layers.{i}.weight"], state[f"{prefix}_conv_layers.{i}.bias"]]
+    return np.concatenate([np.asarray(p, dtype=np.float32).reshape(-1) for p in parts])
+
+
+def depth_to_pointcloud(depth, fx, fy, cx0, cy0, dtype=np.float32):
+    """cx0, cy0: pixel-centre-0 intrinsics (Camera.get_pinhole_camera_parameters(0.0))."""
+    sfx, _ = _sfx(dtype)
+    depth = _c(depth, dtype)
+    H, W = depth.shape
+    pts = np.empty((H * W, 3), dtype=dtype)
+    fn = getattr(lib(), "sdfo_depth_to_pointcloud" + sfx)
+    fn.restype = ctypes.c_int
+    n = fn(_p(depth), ctypes.c_int(W), ctypes.c_int(H), ctypes.c_double(fx), ctypes.c_double(fy),
+           ctypes.c_double(cx0), ctypes.c_double(cy0), _p(pts))
+    return pts[:n].copy()
+
+
+# --- synthetic inputs shared by tests and bench ---------------------
+
+def blobs_sdf(seed=0, R=64, K=8):
+    """Union of K seeded spheres on linspace(-1,1,R)^3, indexing 'ij', float32."""
+    rng = np.random.default_rng(seed)
+    centers = rng.uniform(-0.45, 0.45, (K, 3))
+    radii = rng.uniform(0.15, 0.35, K)
+    g = np.linspace(-1, 1, R)
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    d = np.full((R, R, R), np.inf)
+    for c, r in zip(centers, radii):
+        d = np.minimum(d, np.sqrt((X - c[0]) ** 2 + (Y - c[1]) ** 2 + (Z - c[2]) ** 2) - r)
+    return d.astype(np.float32)
+
+
+def sphere_sdf(radius=0.5, R=64):
+    g = np.linspace(-1, 1, R)
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    return (np.sqrt(X * X + Y * Y + Z * Z) - radius).astype(np.float32)
+
+
+def random_poses(B, seed=1, width=640, height=480, f=320.0):
+    """C3/C4 pose generator: Shoemake-uniform q, z~U(1.2,2), centre pixel in the
+    central 50% of the image, scale~U(0.4,0.6).  Returns pos(B,3), quat(B,4), inv_scale(B)."""
+    rng = np.random.default_rng(seed)
+    u1, u2, u3 = rng.uniform(size=(3, B))
+    quat = np.stack([
+        np.sqrt(1 - u1) * np.sin(2 * np.pi * u2),
+        np.sqrt(1 - u1) * np.cos(2 * np.pi * u2),
+        np.sqrt(u1) * np.sin(2 * np.pi * u3),
+        np.sqrt(u1) * np.cos(2 * np.pi * u3),
+    ], axis=1)
+    z = rng.uniform(1.2, 2.0, B)
+    cx, cy = width / 2, height / 2
+    u = rng.uniform(0.25 * width, 0.75 * width, B)
+    v = rng.uniform(0.25 * height, 0.75 * height, B)
+    pos = np.stack([(u - cx) * z / f, -(v - cy) * z / f, -z], axis=1)
+    scale = rng.uniform(0.4, 0.6, B)
+    return pos.astype(np.float32), quat.astype(np.float32), (1.0 / scale).astype(np.float32)

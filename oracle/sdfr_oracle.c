@@ -1,0 +1,42 @@
+/*
+ * oracle/sdfr_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Instantiates the CPU restatement in sdfr_oracle_impl.h for float (_f32) and
+ * double (_f64).  Built by oracle/Makefile into oracle/libsdfr_oracle.so and
+ * loaded only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline.
+ *
+ * Parity status: PINNED against golden vectors captured by importing the
+ * reference's numpy renderer, torch pc_loss and torch SDFDecoder in the build
+ * container (tools/make_goldens.py -> tests/golden/ npz files).  The reference's
+ * native CUDA path cannot be compiled here (no nvcc; CUDA-only sources), so
+ * there is no oracle/_ref build; see DESIGN.md "Oracle".
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <stddef.h>
+
+#define REAL float
+#define SUFFIX _f32
+#define SQRT sqrtf
+#define FABS fabsf
+#define FLOOR floorf
+#include "sdfr_oracle_impl.h"
+#undef REAL
+#undef SUFFIX
+#undef SQRT
+#undef FABS
+#undef FLOOR
+
+#define REAL double
+#define SUFFIX _f64
+#define SQRT sqrt
+#define FABS fabs
+#define FLOOR floor
+#include "sdfr_oracle_impl.h"
+#undef REAL
+#undef SUFFIX
+#undef SQRT
+#undef FABS
+#undef FLOOR
+
+int sdfo_version(void) { return 1; }

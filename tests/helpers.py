@@ -1,0 +1,44 @@
+"""Shared helpers for the parity tests (test-side only)."""
+import glob
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+POSE_NAMES = ["px", "py", "pz", "qx", "qy", "qz", "qw", "inv_scale"]
+
+
+def render_cases():
+    return sorted(os.path.basename(p)[len("render_"):-len(".npz")]
+                  for p in glob.glob(os.path.join(GOLDEN, "render_*.npz")))
+
+
+def load_render_case(name):
+    d = np.load(os.path.join(GOLDEN, f"render_{name}.npz"))
+    c = {k: d[k] for k in d.files}
+    from oracle import blobs_sdf, sphere_sdf
+    c["sdf"] = {"sphere": lambda: sphere_sdf(0.5), "blobs0": lambda: blobs_sdf(0)}[str(c["sdf_kind"])]()
+    for k in ("W", "H"):
+        c[k] = int(c[k])
+    for k in ("fov", "thr", "inv_scale", "fx", "fy", "cx", "cy"):
+        c[k] = float(c[k])
+    return c
+
+
+def dense_from_sparse(idx, val, R=64):
+    g = np.zeros((R, R, R), dtype=np.float64)
+    if len(idx):
+        g[tuple(np.asarray(idx).T)] = val
+    return g
+
+
+def rel_err(a, b, floor=None):
+    """max |a-b| / max(|b|, floor); floor defaults to max|b| (tensor-relative)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if floor is None:
+        floor = np.max(np.abs(b)) if b.size else 1.0
+    floor = max(float(floor), 1e-300)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor))) if a.size else 0.0
