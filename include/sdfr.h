@@ -1,0 +1,108 @@
+/*
+ * sdfr.h -- C ABI of libsdfr_hip.so: the MI355X (gfx950) implementation of
+ * sdfest's differentiable-renderer hot path.
+ *
+ * This is the drop-in boundary.  It replaces the two entry points of the
+ * reference's pybind module `sdf_renderer_cpp`
+ *     forward (sdfest/differentiable_renderer/csrc/sdf_renderer.cpp:42-61)
+ *     backward(sdfest/differentiable_renderer/csrc/sdf_renderer.cpp:63-86)
+ * and, for the render-and-compare loop around them, the torch-op
+ * implementations of
+ *     losses.pc_loss          (sdfest/estimation/losses.py:32-135)
+ *     SDFDecoder.forward      (sdfest/vae/sdf_vae.py:217-259)
+ *
+ * Rules of the boundary
+ *   - plain C, no torch types.  Every pointer is a DEVICE pointer owned by the
+ *     caller unless its name starts with `h_`.  All tensors are fp32,
+ *     C-contiguous.
+ *   - the library allocates nothing and never synchronises the host: all work
+ *     is enqueued on `stream` (a hipStream_t; NULL = the default stream), so a
+ *     call sequence can be captured into a hipGraph.  Scratch memory comes from
+ *     the caller (`*_workspace_bytes`).
+ *   - re-entrant and thread-safe: the reference's backward runs on a PyTorch
+ *     autograd worker thread; every call does hipSetDevice(device) itself
+ *     (reference: OptionalCUDAGuard, sdf_renderer.cpp:57-58, :82).
+ *   - return 0 on success, a negative SDFR_E_* for argument errors, or a
+ *     positive hipError_t.  sdfr_last_error() gives the thread's last message.
+ *
+ * Data layout
+ *   sdf      [R][R][R]   index order sdf[x][y][z]
+ *   pos      [B][3]      object position in the camera frame (OpenGL: -z forward)
+ *   quat     [B][4]      object orientation, (x, y, z, w) scalar-last, unit norm
+ *   inv_scale[B]         1 / half-width of the SDF volume
+ *   depth    [B][H][W]   row 0 = top; 0 = no hit
+ *   cx, cy               principal point in the pixel-centre-0.5 convention
+ *                        (Camera.get_pinhole_camera_parameters(0.5),
+ *                        sdf_renderer.py:116-133)
+ *   B views share one SDF (sdf_view_stride = 0) or have one each
+ *   (sdf_view_stride = R*R*R elements).
+ */
+#ifndef SDFR_H_
+#define SDFR_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDFR_VERSION 100 /* 0.1.0 */
+#define SDFR_API __attribute__((visibility("default")))
+
+#define SDFR_E_INVALID (-1)   /* bad shape / size / flag */
+#define SDFR_E_NULL (-2)      /* required pointer is NULL */
+#define SDFR_E_WORKSPACE (-3) /* workspace too small */
+
+/* ray-march safety cap.  The reference loop (sdf_renderer_cuda.cu:283-293) is
+ * unbounded and spins forever for threshold == 0 on an exactly-zero sample; a
+ * ray that needs more evaluations than this is reported as a miss (depth 0). */
+#define SDFR_MAX_MARCH_STEPS 4096
+
+/* d depth / d sdf weight assignment */
+#define SDFR_SDF_GRAD_EXACT 0       /* trilinear weights (simple_renderer.py:399-408) */
+#define SDFR_SDF_GRAD_CUDA_COMPAT 1 /* the permutation in sdf_renderer_cuda.cu:373-388 */
+
+SDFR_API int sdfr_version(void);
+SDFR_API const char* sdfr_last_error(void);
+
+/* ---- sphere-tracing depth render -------------------------------------------------------- */
+
+/* Scratch for sdfr_render_forward (per-view set-up records). */
+SDFR_API size_t sdfr_render_forward_workspace_bytes(int B, int W, int H);
+
+/* Replaces sdf_renderer_cpp.forward (sdf_renderer.cpp:42-61 ->
+ * sdf_renderer_cuda.cu:472-510, kernel :241-298), extended by a leading batch
+ * dimension: view b of the output equals one reference call with pose b.
+ * `depth` is fully overwritten (the reference zero-fills with torch::zeros). */
+SDFR_API int sdfr_render_forward(const float* sdf, int R, long long sdf_view_stride,
+                        const float* pos, const float* quat, const float* inv_scale, int B,
+                        int W, int H, float cx, float cy, float fx, float fy, float threshold,
+                        float* depth, void* workspace, size_t workspace_bytes, int device,
+                        void* stream);
+
+/* Scratch for sdfr_render_backward (set-up records + per-tile partial sums). */
+SDFR_API size_t sdfr_render_backward_workspace_bytes(int B, int W, int H);
+
+/* Replaces sdf_renderer_cpp.backward (sdf_renderer.cpp:63-86 ->
+ * sdf_renderer_cuda.cu:512-556, kernel :300-468), batched like the forward.
+ *   depth        the forward's output for the SAME poses (pixels with depth != 0
+ *                are differentiated, :334)
+ *   g_sdf        overwritten.  g_sdf_view_stride = 0: [R][R][R], the sum over
+ *                the B views (what autograd would accumulate for a shared SDF);
+ *                R*R*R: one gradient volume per view.
+ *   g_pos [B][3], g_quat [B][4] (x,y,z,w), g_inv_scale [B]: overwritten.
+ * Pose gradients are reduced in a fixed order (bitwise reproducible); g_sdf uses
+ * float atomics across workgroups (last-bit run-to-run variation, as in the
+ * reference). */
+SDFR_API int sdfr_render_backward(const float* grad_depth, const float* depth, const float* sdf, int R,
+                         long long sdf_view_stride, const float* pos, const float* quat,
+                         const float* inv_scale, int B, int W, int H, float cx, float cy,
+                         float fx, float fy, int sdf_grad_mode, float* g_sdf,
+                         long long g_sdf_view_stride, float* g_pos, float* g_quat,
+                         float* g_inv_scale, void* workspace, size_t workspace_bytes, int device,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDFR_H_ */

@@ -1,0 +1,10 @@
+"""sdfest_amd -- MI355X-native implementation of sdfest's render-and-compare hot path.
+
+Public surface mirrors the reference's ``sdfest.differentiable_renderer``
+(``Camera``, ``render_depth_gpu``) so that ``SDFPipeline.render`` can bind to it
+unchanged; see INTEGRATION.md.
+"""
+from .differentiable_renderer import (Camera, SDFRendererFunctionGPU, render_depth_batch,
+                                      render_depth_gpu)
+
+__all__ = ["Camera", "SDFRendererFunctionGPU", "render_depth_gpu", "render_depth_batch"]

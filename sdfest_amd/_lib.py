@@ -1,0 +1,63 @@
+"""ctypes binding of libsdfr_hip.so (the C ABI declared in include/sdfr.h).
+
+The shared library is built in-tree by ``sdfest_amd/csrc/Makefile`` (see
+``__graft_entry__.build``).  There is NO fallback: if the library is missing
+or a call fails, the error is raised -- the product never computes on the CPU.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsdfr_hip.so")
+_lib = None
+
+c_fp = ctypes.c_void_p
+c_int = ctypes.c_int
+c_ll = ctypes.c_longlong
+c_f = ctypes.c_float
+c_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/sdfr.h declaration by declaration
+SIGNATURES = {
+    "sdfr_version": (c_int, []),
+    "sdfr_last_error": (ctypes.c_char_p, []),
+    "sdfr_render_forward_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
+    "sdfr_render_forward": (c_int, [c_fp, c_int, c_ll, c_fp, c_fp, c_fp, c_int, c_int, c_int,
+                                    c_f, c_f, c_f, c_f, c_f, c_fp, c_fp, c_sz, c_int, c_fp]),
+    "sdfr_render_backward_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
+    "sdfr_render_backward": (c_int, [c_fp, c_fp, c_fp, c_int, c_ll, c_fp, c_fp, c_fp, c_int,
+                                     c_int, c_int, c_f, c_f, c_f, c_f, c_int, c_fp, c_ll, c_fp,
+                                     c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),
+}
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc")]
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `make -C sdfest_amd/csrc` "
+                "(or __graft_entry__.build()); sdfest_amd has no CPU fallback")
+        import torch  # noqa: F401  loads torch's libamdhip64 first so both share one HIP runtime
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().sdfr_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,229 @@
+"""PyTorch interface of the HIP depth renderer.
+
+Host-side mirror of ``sdfest/differentiable_renderer/sdf_renderer.py``: same
+``Camera`` (:31-133), same ``SDFRendererFunctionGPU`` (:267-357) and
+``render_depth_gpu`` (:360-424) signatures, argument meaning and exceptions.
+Tensors are only buffers here: the work happens in ``libsdfr_hip.so`` through
+the C ABI of ``include/sdfr.h``.
+"""
+import math
+import threading
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+class Camera:
+    """Pinhole camera parameters (reference: sdf_renderer.py:31-133).
+
+    ``pixel_center`` states where, inside a pixel, the principal point's
+    coordinate system puts the pixel centre (0 = computer vision, 0.5 = graphics).
+    """
+
+    def __init__(self, width: int, height: int, fx: float, fy: float, cx: float, cy: float,
+                 s: float = 0.0, pixel_center: float = 0.0):
+        self.fx = fx
+        self.fy = fy
+        self.cx = cx
+        self.cy = cy
+        self.pixel_center = pixel_center
+        self.s = s
+        self.width = width
+        self.height = height
+
+    def get_pinhole_camera_parameters(self, pixel_center: float) -> Tuple:
+        """(fx, fy, cx, cy, s) with the principal point re-expressed for `pixel_center`."""
+        shift = pixel_center - self.pixel_center
+        return self.fx, self.fy, self.cx + shift, self.cy + shift, self.s
+
+
+_ws_lock = threading.Lock()
+_ws_cache = {}
+
+
+def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """Per (device, thread) scratch buffer, grown on demand.  Forward runs on the caller's
+    thread and backward on an autograd worker thread; keying by thread keeps them apart."""
+    key = (device.index, threading.get_ident())
+    with _ws_lock:
+        buf = _ws_cache.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
+            _ws_cache[key] = buf
+    return buf
+
+
+def _check_input(t: torch.Tensor, name: str) -> None:
+    # reference: CHECK_CUDA / CHECK_CONTIGUOUS (sdf_renderer.cpp:9-13) raise RuntimeError
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def forward_raw(sdf, position, orientation, inv_scale, width, height, cx, cy, fx, fy, threshold):
+    """Equivalent of ``sdf_renderer_cpp.forward`` (sdf_renderer.cpp:42-61), batched.
+
+    sdf (R,R,R) shared by all views or (B,R,R,R); position (B,3); orientation (B,4);
+    inv_scale (B,).  Returns depth (B,H,W).
+    """
+    for t, n in ((sdf, "sdf"), (position, "position"), (orientation, "orientation"),
+                 (inv_scale, "inv_scale")):
+        _check_input(t, n)
+    B = position.shape[0]
+    if position.shape != (B, 3) or orientation.shape != (B, 4) or inv_scale.shape != (B,):
+        raise RuntimeError("expected position (B,3), orientation (B,4), inv_scale (B,)")
+    R = sdf.shape[-1]
+    if sdf.dim() == 3:
+        stride = 0
+    elif sdf.dim() == 4 and sdf.shape[0] == B:
+        stride = R * R * R
+    else:
+        raise RuntimeError("sdf must be (R,R,R) or (B,R,R,R)")
+    if tuple(sdf.shape[-3:]) != (R, R, R):
+        raise RuntimeError("sdf must be cubic")
+    dev = sdf.device
+    depth = torch.empty((B, height, width), dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    nbytes = L.sdfr_render_forward_workspace_bytes(B, width, height)
+    ws = _workspace(dev, nbytes)
+    rc = L.sdfr_render_forward(_ptr(sdf), R, stride, _ptr(position), _ptr(orientation),
+                               _ptr(inv_scale), B, width, height, cx, cy, fx, fy, threshold,
+                               _ptr(depth), _ptr(ws), ws.numel(), dev.index, _stream(dev))
+    _lib.check(rc, "sdfr_render_forward")
+    return depth
+
+
+def backward_raw(grad_depth, depth, sdf, position, orientation, inv_scale, width, height, cx, cy,
+                 fx, fy, sdf_grad_mode=0):
+    """Equivalent of ``sdf_renderer_cpp.backward`` (sdf_renderer.cpp:63-86), batched.
+
+    Returns (g_sdf like sdf, g_position (B,3), g_orientation (B,4), g_inv_scale (B,)).
+    """
+    for t, n in ((grad_depth, "grad_depth_image"), (depth, "depth_image"), (sdf, "sdf"),
+                 (position, "position"), (orientation, "orientation"), (inv_scale, "inv_scale")):
+        _check_input(t, n)
+    B = position.shape[0]
+    R = sdf.shape[-1]
+    per_view = sdf.dim() == 4
+    stride = R * R * R if per_view else 0
+    dev = sdf.device
+    g_sdf = torch.empty_like(sdf)
+    g_pos = torch.empty_like(position)
+    g_quat = torch.empty_like(orientation)
+    g_isc = torch.empty_like(inv_scale)
+    L = _lib.lib()
+    nbytes = L.sdfr_render_backward_workspace_bytes(B, width, height)
+    ws = _workspace(dev, nbytes)
+    rc = L.sdfr_render_backward(_ptr(grad_depth), _ptr(depth), _ptr(sdf), R, stride,
+                                _ptr(position), _ptr(orientation), _ptr(inv_scale), B, width,
+                                height, cx, cy, fx, fy, sdf_grad_mode, _ptr(g_sdf), stride,
+                                _ptr(g_pos), _ptr(g_quat), _ptr(g_isc), _ptr(ws), ws.numel(),
+                                dev.index, _stream(dev))
+    _lib.check(rc, "sdfr_render_backward")
+    return g_sdf, g_pos, g_quat, g_isc
+
+
+class _RenderBatch(torch.autograd.Function):
+    """Batched renderer: B poses of one SDF (or of B SDFs) in one launch."""
+
+    @staticmethod
+    def forward(ctx, sdf, position, orientation, inv_scale, threshold, camera, sdf_grad_mode):
+        fx, fy, cx, cy, _ = camera.get_pinhole_camera_parameters(0.5)
+        sdf_c = sdf.detach().contiguous()
+        pos = position.detach().contiguous()
+        quat = orientation.detach().contiguous()
+        isc = inv_scale.detach().contiguous()
+        image = forward_raw(sdf_c, pos, quat, isc, camera.width, camera.height, cx, cy, fx, fy,
+                            threshold)
+        ctx.save_for_backward(image, sdf_c, pos, quat, isc)
+        ctx.cam = (camera.width, camera.height, cx, cy, fx, fy)
+        ctx.sdf_grad_mode = sdf_grad_mode
+        return image
+
+    @staticmethod
+    def backward(ctx, grad_depth_image):
+        image, sdf, pos, quat, isc = ctx.saved_tensors
+        w, h, cx, cy, fx, fy = ctx.cam
+        g_sdf, g_p, g_q, g_is = backward_raw(grad_depth_image.contiguous(), image, sdf, pos, quat,
+                                             isc, w, h, cx, cy, fx, fy, ctx.sdf_grad_mode)
+        return g_sdf, g_p, g_q, g_is, None, None, None
+
+
+class SDFRendererFunctionGPU(torch.autograd.Function):
+    """Single-view renderer function; signature of sdf_renderer.py:267-357."""
+
+    @staticmethod
+    def forward(ctx, sdf: torch.Tensor, position: torch.Tensor, orientation: torch.Tensor,
+                inv_scale: torch.Tensor, threshold: Optional[float] = 0.0,
+                camera: Optional[Camera] = None) -> torch.Tensor:
+        for t, n in ((sdf, "sdf"), (position, "position"), (orientation, "orientation"),
+                     (inv_scale, "inv_scale")):
+            _check_input(t, n)
+        fx, fy, cx, cy, _ = camera.get_pinhole_camera_parameters(0.5)
+        image = forward_raw(sdf, position.reshape(1, 3), orientation.reshape(1, 4),
+                            inv_scale.reshape(1), camera.width, camera.height, cx, cy, fx, fy,
+                            threshold)[0]
+        ctx.save_for_backward(image, sdf, position, orientation, inv_scale)
+        ctx.cam = (camera.width, camera.height, cx, cy, fx, fy)
+        return image
+
+    @staticmethod
+    def backward(ctx, grad_depth_image: torch.Tensor):
+        image, sdf, position, orientation, inv_scale = ctx.saved_tensors
+        w, h, cx, cy, fx, fy = ctx.cam
+        g_sdf, g_p, g_q, g_is = backward_raw(
+            grad_depth_image.contiguous().reshape(1, h, w), image.reshape(1, h, w), sdf,
+            position.reshape(1, 3), orientation.reshape(1, 4), inv_scale.reshape(1), w, h, cx, cy,
+            fx, fy, render_depth_gpu.sdf_grad_mode)
+        # gradients come back in the shape of the inputs ((4,) or (1,4); () or (1,))
+        return (g_sdf, g_p.reshape(position.shape), g_q.reshape(orientation.shape),
+                g_is.reshape(inv_scale.shape), None, None)
+
+
+def render_depth_gpu(sdf: torch.Tensor, position: torch.Tensor, orientation: torch.Tensor,
+                     inv_scale: torch.Tensor, width: Optional[int] = None,
+                     height: Optional[int] = None, fov_deg: Optional[float] = None,
+                     threshold: Optional[float] = 0.0, camera: Optional[Camera] = None):
+    """Render a depth image of a 7-DOF discrete SDF (drop-in for sdf_renderer.py:360-424).
+
+    The SDF pose is given in the camera frame under the OpenGL convention; the first image
+    row is up.  Give either ``camera`` or ``width``+``height``+``fov_deg`` (horizontal fov,
+    square pixels).  Differentiable w.r.t. sdf, position, orientation and inv_scale.
+    """
+    if None not in [width, height, fov_deg] and camera is not None:
+        raise ValueError("Either width+height+fov_dev or camera must be provided.")
+    if camera is None:
+        f = width / math.tan(fov_deg * math.pi / 180.0 / 2.0) / 2
+        camera = Camera(width, height, f, f, width / 2, height / 2, pixel_center=0.5)
+    return SDFRendererFunctionGPU.apply(sdf, position, orientation, inv_scale, threshold, camera)
+
+
+# d depth / d sdf weights: 0 = exact (numpy twin), 1 = the CUDA kernel's permutation
+render_depth_gpu.sdf_grad_mode = 0
+
+
+def render_depth_batch(sdf: torch.Tensor, positions: torch.Tensor, orientations: torch.Tensor,
+                       inv_scales: torch.Tensor, threshold: float, camera: Camera,
+                       sdf_grad_mode: int = 0) -> torch.Tensor:
+    """B views in one launch: view b equals render_depth_gpu(sdf, positions[b], ...).
+
+    The reference loops over views in Python (estimation/simple_setup.py:420-446); this is
+    the same arithmetic with the loop moved onto the GPU.  sdf: (R,R,R) shared or (B,R,R,R).
+    """
+    return _RenderBatch.apply(sdf, positions, orientations, inv_scales, threshold, camera,
+                              sdf_grad_mode)

@@ -1,0 +1,79 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol that
+include/sdfr.h declares (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from helpers import ROOT
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    from sdfest_amd import _lib
+    _lib.build()
+    assert os.path.exists(_lib.LIB_PATH)
+    return _lib.LIB_PATH
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sdfr.h")).read()
+    return sorted(set(re.findall(r"SDFR_API\s+[\w\s\*]+?\b(sdfr_\w+)\s*\(", text)))
+
+
+def test_header_declares_entry_points():
+    syms = declared_symbols()
+    for s in ("sdfr_version", "sdfr_last_error", "sdfr_render_forward", "sdfr_render_backward"):
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol(libpath):
+    h = ctypes.CDLL(libpath)
+    for s in declared_symbols():
+        assert hasattr(h, s), f"{s} declared in include/sdfr.h but not exported"
+
+
+def test_binding_table_matches_header(libpath):
+    from sdfest_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+    text = open(os.path.join(ROOT, "include", "sdfr.h")).read()
+    # argument counts of the ctypes signatures equal the header's
+    for name, (_, args) in _lib.SIGNATURES.items():
+        m = re.search(r"SDFR_API[^;]*?\b%s\s*\(([^;]*?)\);" % name, text, re.S)
+        assert m, name
+        params = m.group(1).strip()
+        n = 0 if params in ("", "void") else len(params.split(","))
+        assert n == len(args), (name, n, len(args))
+
+
+def test_version_and_error_string(libpath):
+    from sdfest_amd import _lib
+    L = _lib.lib()
+    assert L.sdfr_version() == 100
+    assert isinstance(L.sdfr_last_error(), bytes)
+
+
+def test_argument_errors_without_gpu(libpath):
+    """Argument validation happens before any HIP call, so it is testable on CPU."""
+    from sdfest_amd import _lib
+    L = _lib.lib()
+    rc = L.sdfr_render_forward(None, 1, 0, None, None, None, 1, 8, 8, 4.0, 4.0, 4.0, 4.0, 0.01,
+                               None, None, 0, 0, None)
+    assert rc == -1 and b"R=1" in L.sdfr_last_error()
+    rc = L.sdfr_render_forward(None, 64, 0, None, None, None, 1, 8, 8, 4.0, 4.0, 4.0, 4.0, 0.01,
+                               None, None, 0, 0, None)
+    assert rc == -2
+    assert L.sdfr_render_forward_workspace_bytes(3, 640, 480) == 3 * 128
+    assert L.sdfr_render_backward_workspace_bytes(2, 640, 480) == 2 * 128 + 2 * 20 * 60 * 32
+
+
+def test_product_does_not_import_oracle():
+    """The product package must never route through the oracle (or any CPU fallback)."""
+    pkg = os.path.join(ROOT, "sdfest_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "sdfr_oracle" not in src, f
