@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: sphere-tracing depth render forward + backward.
+
+Metric (BASELINE.json): depth renders/sec fwd+bwd, 640x480 @ 64^3 SDF.
+
+Workload per GPU ("C3", BASELINE.json configs[2]): 256 seeded random
+poses of the synthetic blobs(0) 64^3 SDF at 640x480, threshold 0.005, upstream gradient
+U(-1,1).  One step = forward of the 256 views + backward of the 256 views (+ the RCCL
+all-reduce of the shared d/dSDF when N > 1).  N GPUs = N shards of 256 views of one
+256*N-view batch (configs[3] at N=8), so scaling is weak.  Everything is resident in HBM
+before the timed region.  `--batch 1` gives configs[1] (one view per launch).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md: 8 TB/s; 6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="views per GPU per step")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="views in the CPU sample (0 = auto)")
+    return ap.parse_args()
+
+
+def synthetic_inputs(B_total, rank, B, W, H, device):
+    """blobs(0) SDF and this rank's contiguous shard of the seeded pose list."""
+    import oracle  # input generators only (numpy); nothing of the oracle is timed here
+    sdf = oracle.blobs_sdf(0)
+    pos, quat, isc = oracle.random_poses(B_total, seed=1, width=W, height=H, f=W / 2.0)
+    sl = slice(rank * B, (rank + 1) * B)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234 + rank)
+    g = torch.rand((B, H, W), device=device, generator=gen) * 2 - 1
+    return sdf, (pos[sl], quat[sl], isc[sl]), t(sdf), t(pos[sl]), t(quat[sl]), t(isc[sl]), g
+
+
+def _time_oracle(lib, sdf, pos, quat, isc, W, H, thr, threads, budget_cpu_s):
+    """renders/s of the oracle's fwd+bwd on len(pos) views with `threads` OpenMP threads."""
+    import ctypes
+    S = pos.shape[0]
+    depth = np.empty((S, H, W), np.float32)
+    g = np.random.default_rng(0).uniform(-1, 1, (S, H, W)).astype(np.float32)
+    gs = np.empty((64, 64, 64), np.float32)
+    gp, gq, gi = np.empty((S, 3), np.float32), np.empty((S, 4), np.float32), np.empty(S, np.float32)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    cd, ci = ctypes.c_double, ctypes.c_int
+    f = W / 2.0
+
+    def once():
+        lib.sdfo_render_forward_f32(P(sdf), ci(64), P(pos), P(quat), P(isc), ci(S), ci(W), ci(H),
+                                    cd(W / 2), cd(H / 2), cd(f), cd(f), cd(thr), P(depth), None,
+                                    None, ci(0))
+        lib.sdfo_render_backward_f32(P(g), P(depth), P(sdf), ci(64), P(pos), P(quat), P(isc), ci(S),
+                                     ci(W), ci(H), cd(W / 2), cd(H / 2), cd(f), cd(f), ci(0), P(gs),
+                                     P(gp), P(gq), P(gi))
+
+    lib.sdfo_set_threads(ci(threads))
+    once()  # warm-up (page faults, thread pool)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        once()
+        reps += 1
+        el = time.perf_counter() - t0
+        if el * threads >= budget_cpu_s or el >= 15.0 or reps >= 50:
+            break
+    return S * reps / el, reps
+
+
+def cpu_baseline(sdf, poses, W, H, thr, sample):
+    """The oracle (a CPU port of the same algorithm) timed on this host's cores, on a bounded
+    sample of the SAME workload: all cores on `sample` views, and one core on 16 of them."""
+    import ctypes
+    import subprocess
+    here = os.path.join(ROOT, "oracle")
+    subprocess.check_call(["make", "-C", here, "libsdfr_oracle_native.so"], stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(os.path.join(here, "libsdfr_oracle_native.so"))
+    pos, quat, isc = (np.ascontiguousarray(a[:sample], dtype=np.float32) for a in poses)
+    sdf = np.ascontiguousarray(sdf, dtype=np.float32)
+    ncpu = os.cpu_count() or 1
+    v_all, reps_all = _time_oracle(lib, sdf, pos, quat, isc, W, H, thr, ncpu, 15.0)
+    n1 = min(16, pos.shape[0])
+    v_one, _ = _time_oracle(lib, sdf, pos[:n1].copy(), quat[:n1].copy(), isc[:n1].copy(), W, H, thr,
+                            1, 4.0)
+    use_all = v_all >= v_one
+    return {"value": round(v_all if use_all else v_one, 2), "unit": "renders/s",
+            "cores": ncpu if use_all else 1, "kind": "port",
+            "sample": f"{pos.shape[0]} views of the same workload (first poses of the seeded list), "
+                      f"fwd+bwd x{reps_all}, oracle built as libsdfr_oracle_native.so "
+                      f"(gcc -O3 -march=native -fopenmp); host has {ncpu} logical cores",
+            "value_1thread": round(v_one, 2), "value_allthreads": round(v_all, 2)}
+
+
+def load_traffic():
+    """HBM bytes per forward launch from the committed rocprofv3 --pmc passes (profiles/)."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p))
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    args = parse()
+    N = args.gpus
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != N:
+        if world == 1 and N > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        N = world
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if N > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=N, device_id=device)
+
+    from sdfest_amd import BatchRenderPlan, Camera
+    from sdfest_amd.parallel import allreduce_shared_gradients
+
+    W, H, B, thr = args.width, args.height, args.batch, 0.005
+    sdf_np, poses_np, sdf, pos, quat, isc, g = synthetic_inputs(B * N, rank, B, W, H, device)
+    cam = Camera(W, H, W / 2.0, W / 2.0, W / 2.0, H / 2.0, pixel_center=0.5)
+    plan = BatchRenderPlan(64, B, cam, device=device)
+
+    def step(ev=None):
+        if ev:
+            ev[0].record()
+        plan.forward(sdf, pos, quat, isc, thr)
+        if ev:
+            ev[1].record()
+        plan.backward(g, sdf, pos, quat, isc)
+        if ev:
+            ev[2].record()
+        if N > 1:
+            allreduce_shared_gradients(plan.g_sdf)
+
+    def barrier():
+        if N > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if N > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
+    bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
+    hits = int((plan.depth > 0).sum().item())
+
+    if rank == 0:
+        views = B * N * args.steps
+        value = views / elapsed
+        R3 = 64 ** 3
+        bytes_per_view = 12 * W * H + 12 * R3 / B + 32          # fwd+bwd
+        fwd_bytes = B * (4 * W * H + 16) + 4 * R3               # forward launch: depth out, sdf in
+        bwd_bytes = B * (8 * W * H + 16) + 8 * R3               # backward launch: 2 images in, sdf in, g_sdf out
+        dominant = "render_forward_kernel" if fwd_ms >= bwd_ms else "render_backward_kernel"
+        k_bytes, k_ms = (fwd_bytes, fwd_ms) if fwd_ms >= bwd_ms else (bwd_bytes, bwd_ms)
+        achieved = k_bytes / (k_ms * 1e-3) / 1e9
+        traffic = load_traffic()
+        line = {
+            "metric": "depth renders/sec fwd+bwd, 640x480 @ 64^3 SDF",
+            "value": round(value, 1),
+            "unit": "renders/s",
+            "n_gpus": N,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"C3: {B} seeded random poses per GPU of the blobs(0) 64^3 SDF, "
+                                   f"{W}x{H}, threshold 0.005, forward+backward"
+                                   + (", RCCL all-reduce of dSDF" if N > 1 else ""),
+                       "views_per_gpu": B, "width": W, "height": H, "sdf_resolution": 64,
+                       "parallelism": f"views sharded over {N} GPU(s)",
+                       "hit_pixels_rank0": hits},
+            "roofline": {"bound": "hbm", "kernel": dominant,
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": round(achieved * 1e9 / HBM_PEAK, 5),
+                         "traffic": (traffic or {}).get(dominant),
+                         "algorithmic_bytes_per_launch": int(k_bytes),
+                         "avg_launch_ms": round(k_ms, 4)},
+            "roofline_step": {"bytes_per_view": bytes_per_view,
+                              "achieved": round(bytes_per_view * value / N / 1e9, 2),
+                              "unit": "GB/s per GPU",
+                              "frac": round(bytes_per_view * value / N / HBM_PEAK, 5)},
+            "kernel_ms": {"forward_call": round(fwd_ms, 4), "backward_call": round(bwd_ms, 4)},
+        }
+        if N == 1 and not args.no_cpu_baseline:
+            sample = args.cpu_sample or min(B, 256)
+            line["cpu_baseline"] = cpu_baseline(sdf_np, poses_np, W, H, thr, sample)
+            line["speedup_vs_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line), flush=True)
+    if N > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,8 +67,9 @@ SDFR_API const char* sdfr_last_error(void);
 
 /* ---- sphere-tracing depth render -------------------------------------------------------- */
 
-/* Scratch for sdfr_render_forward (per-view set-up records). */
-SDFR_API size_t sdfr_render_forward_workspace_bytes(int B, int W, int H);
+/* Scratch for sdfr_render_forward (per-view set-up records + the re-packed grid, see
+ * render.hip "cell records"). */
+SDFR_API size_t sdfr_render_forward_workspace_bytes(int R, int B, int W, int H);
 
 /* Replaces sdf_renderer_cpp.forward (sdf_renderer.cpp:42-61 ->
  * sdf_renderer_cuda.cu:472-510, kernel :241-298), extended by a leading batch
@@ -81,7 +82,7 @@ SDFR_API int sdfr_render_forward(const float* sdf, int R, long long sdf_view_str
                         void* stream);
 
 /* Scratch for sdfr_render_backward (set-up records + per-tile partial sums). */
-SDFR_API size_t sdfr_render_backward_workspace_bytes(int B, int W, int H);
+SDFR_API size_t sdfr_render_backward_workspace_bytes(int R, int B, int W, int H);
 
 /* Replaces sdf_renderer_cpp.backward (sdf_renderer.cpp:63-86 ->
  * sdf_renderer_cuda.cu:512-556, kernel :300-468), batched like the forward.

@@ -39,6 +39,15 @@ def lib():
     return _lib
 
 
+def set_threads(n: int) -> None:
+    """OpenMP threads used by the oracle (for the cpu_baseline timing)."""
+    lib().sdfo_set_threads(ctypes.c_int(int(n)))
+
+
+def max_threads() -> int:
+    return int(lib().sdfo_max_threads())
+
+
 def _sfx(dtype):
     dtype = np.dtype(dtype)
     if dtype == np.float32:

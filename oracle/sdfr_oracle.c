@@ -40,3 +40,12 @@
 #undef FLOOR
 
 int sdfo_version(void) { return 1; }
+
+#ifdef _OPENMP
+#include <omp.h>
+void sdfo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int sdfo_max_threads(void) { return omp_get_max_threads(); }
+#else
+void sdfo_set_threads(int n) { (void)n; }
+int sdfo_max_threads(void) { return 1; }
+#endif

@@ -182,16 +182,16 @@ void FN(sdfo_render_forward)(const REAL* sdf, int R, const REAL* pos, const REAL
                              const REAL* inv_scale, int B, int W, int H, double cx, double cy,
                              double fx, double fy, double threshold, REAL* depth, int* steps,
                              REAL* margin, int max_steps) {
+  const REAL thr = (REAL)threshold;
+#pragma omp parallel for collapse(2) schedule(dynamic, 8)
   for (int b = 0; b < B; ++b) {
-    const REAL isc = inv_scale[b];
-    const REAL scale = (REAL)1 / isc;
-    REAL rot[3][3];
-    FN(quat_matrix)(quat + 4 * b, rot);
-    const FN(v3) p = FN(v3_make)(pos[3 * b], pos[3 * b + 1], pos[3 * b + 2]);
-    const FN(v3) org = FN(mat_apply_t)(rot, FN(v3_make)(-p.x, -p.y, -p.z));
-    const REAL thr = (REAL)threshold;
-#pragma omp parallel for schedule(dynamic, 4)
     for (int row = 0; row < H; ++row) {
+      const REAL isc = inv_scale[b];
+      const REAL scale = (REAL)1 / isc;
+      REAL rot[3][3];
+      FN(quat_matrix)(quat + 4 * b, rot);
+      const FN(v3) p = FN(v3_make)(pos[3 * b], pos[3 * b + 1], pos[3 * b + 2]);
+      const FN(v3) org = FN(mat_apply_t)(rot, FN(v3_make)(-p.x, -p.y, -p.z));
       for (int col = 0; col < W; ++col) {
         const size_t pix = ((size_t)b * H + row) * W + col;
         REAL out = 0, mg = (REAL)1e30;
@@ -293,6 +293,9 @@ void FN(sdfo_render_backward)(const REAL* grad_depth, const REAL* depth, const R
   const size_t nvox = (size_t)R * R * R;
   const size_t RR = (size_t)R * R;
   double* acc_sdf = (double*)calloc(nvox, sizeof(double));
+  /* views in parallel; pose sums are per view and sequential in pixel order, voxel sums use
+   * atomics on doubles (order-dependent only at the 1e-16 level) */
+#pragma omp parallel for schedule(dynamic, 1)
   for (int b = 0; b < B; ++b) {
     REAL rot[3][3];
     FN(quat_matrix)(quat + 4 * b, rot);
@@ -311,10 +314,12 @@ void FN(sdfo_render_backward)(const REAL* grad_depth, const REAL* depth, const R
         for (int k = 0; k < 8; ++k) acc[k] += (double)(dz[k] * go);
         FN(corner_weights)(c.off, sdf_grad_mode, wgt);
         double* a = acc_sdf + c.base[0] * RR + (size_t)c.base[1] * R + c.base[2];
-        a[0] += (double)(go * wgt[0] * f);          a[1] += (double)(go * wgt[1] * f);
-        a[R] += (double)(go * wgt[2] * f);          a[R + 1] += (double)(go * wgt[3] * f);
-        a[RR] += (double)(go * wgt[4] * f);         a[RR + 1] += (double)(go * wgt[5] * f);
-        a[RR + R] += (double)(go * wgt[6] * f);     a[RR + R + 1] += (double)(go * wgt[7] * f);
+        const size_t offs[8] = {0, 1, (size_t)R, (size_t)R + 1, RR, RR + 1, RR + R, RR + R + 1};
+        for (int k = 0; k < 8; ++k) {
+          const double contrib = (double)(go * wgt[k] * f);
+#pragma omp atomic
+          a[offs[k]] += contrib;
+        }
       }
     }
     g_pos[3 * b] = (REAL)acc[0]; g_pos[3 * b + 1] = (REAL)acc[1]; g_pos[3 * b + 2] = (REAL)acc[2];

@@ -4,7 +4,8 @@ Public surface mirrors the reference's ``sdfest.differentiable_renderer``
 (``Camera``, ``render_depth_gpu``) so that ``SDFPipeline.render`` can bind to it
 unchanged; see INTEGRATION.md.
 """
-from .differentiable_renderer import (Camera, SDFRendererFunctionGPU, render_depth_batch,
+from .differentiable_renderer import (BatchRenderPlan, Camera, SDFRendererFunctionGPU,
+                                      render_depth_batch,
                                       render_depth_gpu)
 
-__all__ = ["Camera", "SDFRendererFunctionGPU", "render_depth_gpu", "render_depth_batch"]
+__all__ = ["BatchRenderPlan", "Camera", "SDFRendererFunctionGPU", "render_depth_gpu", "render_depth_batch"]

@@ -22,10 +22,10 @@ c_sz = ctypes.c_size_t
 SIGNATURES = {
     "sdfr_version": (c_int, []),
     "sdfr_last_error": (ctypes.c_char_p, []),
-    "sdfr_render_forward_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
+    "sdfr_render_forward_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
     "sdfr_render_forward": (c_int, [c_fp, c_int, c_ll, c_fp, c_fp, c_fp, c_int, c_int, c_int,
                                     c_f, c_f, c_f, c_f, c_f, c_fp, c_fp, c_sz, c_int, c_fp]),
-    "sdfr_render_backward_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
+    "sdfr_render_backward_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
     "sdfr_render_backward": (c_int, [c_fp, c_fp, c_fp, c_int, c_ll, c_fp, c_fp, c_fp, c_int,
                                      c_int, c_int, c_f, c_f, c_f, c_f, c_int, c_fp, c_ll, c_fp,
                                      c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),

@@ -50,8 +50,17 @@ struct alignas(128) ViewSetup {
 };
 static_assert(sizeof(ViewSetup) == 128, "ViewSetup must stay 128 bytes");
 
-constexpr int kTileW = 32;  // workgroup tile: 32 x 8 pixels = 4 waves of 8 x 8
-constexpr int kTileH = 8;
+// A workgroup (4 waves) owns a 64 x 32 pixel macro-tile and walks its eight 32 x 8 sub-tiles;
+// inside a sub-tile each wave is an 8 x 8 pixel patch.
+constexpr int kTileW = 64;
+constexpr int kTileH = 32;
+constexpr int kSubW = 32;
+constexpr int kSubH = 8;
+constexpr int kSubs = (kTileW / kSubW) * (kTileH / kSubH);  // 8
+
+// packed cell records are used for a grid shared by >= kPackedMinViews views, up to kPackedMaxR
+constexpr int kPackedMinViews = 4;
+constexpr int kPackedMaxR = 128;
 
 inline int tiles_x(int W) { return (W + kTileW - 1) / kTileW; }
 inline int tiles_y(int H) { return (H + kTileH - 1) / kTileH; }

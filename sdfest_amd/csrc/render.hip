@@ -8,17 +8,22 @@
 //   * a set-up kernel turns each pose into a 128-byte record (rotation, object-frame camera
 //     position, grid-space ray origin, conservative screen rectangle of the bounding cube);
 //     the image kernels read it through the scalar cache instead of re-deriving it per pixel;
-//   * tiles outside the rectangle only store zeros (forward) or exit without touching memory
-//     (backward): in realistic scenes that is most of the frame;
+//   * a workgroup owns a 64x32-pixel macro-tile (8 sub-tiles of 32x8, a wave = an 8x8 patch):
+//     macro-tiles outside the rectangle only stream float4 zeros (forward) or exit without
+//     touching memory (backward) -- in realistic scenes that is most of the frame -- and a
+//     256-view batch is 38k workgroups instead of 307k;
 //   * the slab test and the march run in the object frame / in grid coordinates, so one step
 //     is 3 FMAs + floor/clamp instead of the reference's scale-normalise-index-denormalise chain;
-//   * a wave is an 8x8 pixel patch (neighbouring lanes gather neighbouring voxels, which the
-//     64x64x64 grid (1 MiB) serves from L1/L2 -- it cannot live in the 160 KiB LDS);
-//   * the 8 pose-gradient sums go wave-shuffle -> LDS -> one 32-byte partial per tile -> a fixed-
-//     order reduction kernel (bitwise reproducible); the reference issues 8 same-address float
-//     atomics per hit pixel (sdf_renderer_cuda.cu:459-466);
-//   * d/dsdf contributions of a tile are pre-summed in an LDS brick around the tile's surface
-//     patch before one global float atomic per touched voxel.
+//   * the 64^3 grid (1 MiB) cannot live in the 160 KiB LDS and a per-corner gather costs ~28
+//     L1 tag look-ups per load instruction (measured: the L1, not HBM or the VALU, bounded v1),
+//     so a pre-pass re-packs the grid into 32-byte cell records (the 8 corners of a cell side by
+//     side): one march step is two 16-byte loads from one 32-byte-aligned record;
+//   * the 8 pose-gradient sums stay in registers across a macro-tile, then wave-shuffle -> LDS ->
+//     one 32-byte partial per macro-tile -> a fixed-order reduction kernel (bitwise
+//     reproducible); the reference issues 8 same-address float atomics per hit pixel
+//     (sdf_renderer_cuda.cu:459-466);
+//   * d/dsdf contributions of a macro-tile are pre-summed in an LDS hash of 8-voxel z-runs and
+//     flushed as 32-byte runs of global float atomics (one per touched voxel per macro-tile).
 #include "common.hpp"
 
 namespace sdfr {
@@ -87,24 +92,25 @@ __global__ void view_setup_kernel(const float* __restrict__ pos, const float* __
 }
 
 // ---------------------------------------------------------------------------------------------
-// shared device pieces
+// cell records: rec[lin] = the 8 corners of the cell whose corner 000 has linear index lin,
+// as two float4: (v000, v001, v010, v011), (v100, v101, v110, v111).  R^3 records (the last
+// layer along each axis is never addressed: cell indices are clamped to R-2).
 // ---------------------------------------------------------------------------------------------
-struct Pixel {
-  int row, col;
-  bool inside;  // inside the image
-};
-
-// 32x8 tile, 4 waves, each wave an 8x8 patch
-__device__ __forceinline__ Pixel tile_pixel(int tile_x, int tile_y, int W, int H) {
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  Pixel px;
-  px.col = tile_x * kTileW + wave * 8 + (lane & 7);
-  px.row = tile_y * kTileH + (lane >> 3);
-  px.inside = (px.col < W) && (px.row < H);
-  return px;
+__global__ __launch_bounds__(256) void pack_cells_kernel(const float* __restrict__ sdf, int R,
+                                                         float4* __restrict__ cells) {
+  const int lin = blockIdx.x * blockDim.x + threadIdx.x;
+  const int RR = R * R;
+  if (lin >= RR * R) return;
+  const int z = lin % R, y = (lin / R) % R, x = lin / RR;
+  if (x >= R - 1 || y >= R - 1 || z >= R - 1) return;
+  const float* p = sdf + lin;
+  cells[2 * (size_t)lin] = make_float4(p[0], p[1], p[R], p[R + 1]);
+  cells[2 * (size_t)lin + 1] = make_float4(p[RR], p[RR + 1], p[RR + R], p[RR + R + 1]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// shared device pieces
+// ---------------------------------------------------------------------------------------------
 // unit ray through a pixel centre (camera frame, OpenGL).  sdf_renderer_cuda.cu:137-154.
 __device__ __forceinline__ V3 pixel_ray(int row, int col, float cx, float cy, float rfx, float rfy) {
   const float dx = ((float)col + 0.5f - cx) * rfx;
@@ -135,11 +141,11 @@ struct Cell {
   int lin;  // linear index of corner 000
 };
 
-// Locate the cell of a grid-space point and gather its 8 corners (4 z-pair loads).
-// Same cell choice and the same un-clamped (extrapolating) cell coordinate as
-// sdf_renderer_cuda.cu:196-239.
-template <int RT>
-__device__ __forceinline__ void gather_cell(const float* __restrict__ sdf, int R, float gx,
+// Locate the cell of a grid-space point and fetch its 8 corners.  Same cell choice and the
+// same un-clamped (extrapolating) cell coordinate as sdf_renderer_cuda.cu:196-239.
+// PACKED: `src` is the cell-record array (two 16-byte loads); else the plain grid (4 z-pair loads).
+template <int RT, bool PACKED>
+__device__ __forceinline__ void gather_cell(const float* __restrict__ src, int R, float gx,
                                             float gy, float gz, Cell& c) {
   const int Rr = RT > 0 ? RT : R;
   const float top = (float)(Rr - 2);
@@ -149,13 +155,20 @@ __device__ __forceinline__ void gather_cell(const float* __restrict__ sdf, int R
   c.ox = gx - bx; c.oy = gy - by; c.oz = gz - bz;
   const int lin = ((int)bx * Rr + (int)by) * Rr + (int)bz;
   c.lin = lin;
-  const float* base = sdf + lin;
-  const ZPair p00 = *reinterpret_cast<const ZPair*>(base);
-  const ZPair p01 = *reinterpret_cast<const ZPair*>(base + Rr);
-  const ZPair p10 = *reinterpret_cast<const ZPair*>(base + Rr * Rr);
-  const ZPair p11 = *reinterpret_cast<const ZPair*>(base + Rr * Rr + Rr);
-  c.v[0] = p00.lo; c.v[1] = p00.hi; c.v[2] = p01.lo; c.v[3] = p01.hi;
-  c.v[4] = p10.lo; c.v[5] = p10.hi; c.v[6] = p11.lo; c.v[7] = p11.hi;
+  if (PACKED) {
+    const float4* rec = reinterpret_cast<const float4*>(src) + 2 * (size_t)(unsigned)lin;
+    const float4 a = rec[0], b = rec[1];
+    c.v[0] = a.x; c.v[1] = a.y; c.v[2] = a.z; c.v[3] = a.w;
+    c.v[4] = b.x; c.v[5] = b.y; c.v[6] = b.z; c.v[7] = b.w;
+  } else {
+    const float* base = src + lin;
+    const ZPair p00 = *reinterpret_cast<const ZPair*>(base);
+    const ZPair p01 = *reinterpret_cast<const ZPair*>(base + Rr);
+    const ZPair p10 = *reinterpret_cast<const ZPair*>(base + Rr * Rr);
+    const ZPair p11 = *reinterpret_cast<const ZPair*>(base + Rr * Rr + Rr);
+    c.v[0] = p00.lo; c.v[1] = p00.hi; c.v[2] = p01.lo; c.v[3] = p01.hi;
+    c.v[4] = p10.lo; c.v[5] = p10.hi; c.v[6] = p11.lo; c.v[7] = p11.hi;
+  }
 }
 
 // trilinear value, lerp order x, y, z (sdf_renderer_cuda.cu:231-238)
@@ -170,79 +183,101 @@ __device__ __forceinline__ float trilerp(const Cell& c) {
   return fmaf(c1, c.oz, c0 * az);
 }
 
-// ---------------------------------------------------------------------------------------------
-// forward
-// ---------------------------------------------------------------------------------------------
-template <int RT>
-__global__ __launch_bounds__(kBlock) void render_forward_kernel(
-    const float* __restrict__ sdf, int R, long long sdf_view_stride,
-    const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, float cx, float cy,
-    float rfx, float rfy, float threshold, float* __restrict__ depth) {
-  const int tiles_per_view = ntx * nty;
-  const int b = blockIdx.x / tiles_per_view;
-  const int t_in_view = blockIdx.x - b * tiles_per_view;
-  const int tile_y = t_in_view / ntx, tile_x = t_in_view - tile_y * ntx;
-  const ViewSetup& s = setup[b];
-  const Pixel px = tile_pixel(tile_x, tile_y, W, H);
-  float* out = depth + ((size_t)b * H + px.row) * W + px.col;
-
-  // tile against the cube's screen rectangle (wave-uniform)
-  const int x0 = s.rect[0], y0 = s.rect[1], x1 = s.rect[2], y1 = s.rect[3];
-  const bool tile_live = (tile_x * kTileW < x1) && (tile_x * kTileW + kTileW > x0) &&
-                         (tile_y * kTileH < y1) && (tile_y * kTileH + kTileH > y0);
-  if (!tile_live) {
-    if (px.inside) *out = 0.0f;
-    return;
-  }
-  float result = 0.0f;
-  const bool in_rect = px.inside && px.col >= x0 && px.col < x1 && px.row >= y0 && px.row < y1;
-  if (in_rect) {
-    const V3 d = pixel_ray(px.row, px.col, cx, cy, rfx, rfy);
-    const V3 dobj = rot_t(s, d);
-    // slab test in the object frame: axis i of the cube is e_i, the cube centre is at +e
-    // relative to the ray origin, f_i = dobj_i.  sdf_renderer_cuda.cu:156-194.
-    const float scale = s.scale;
-    float t_near = -1e-10f, t_far = 1e10f;
-    bool hit_box = true;
-    const float dv[3] = {dobj.x, dobj.y, dobj.z};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float e = s.e[a], f = dv[a];
-      if (fabsf(f) > 1e-20f) {
-        const float inv = __builtin_amdgcn_rcpf(f);
-        const float ta = (e + scale) * inv, tb = (e - scale) * inv;
-        t_near = fmaxf(t_near, fminf(ta, tb));
-        t_far = fminf(t_far, fmaxf(ta, tb));
-      } else if (-e > scale || -e < -scale) {
-        hit_box = false;
-      }
-    }
-    hit_box = hit_box && !(t_near > t_far) && !(t_far < 0.0f);
-    if (hit_box) {
-      const float* vol = sdf + (size_t)b * sdf_view_stride;
-      const float k = s.isc * (0.5f * (float)((RT > 0 ? RT : R) - 1));
-      const float dgx = dobj.x * k, dgy = dobj.y * k, dgz = dobj.z * k;
-      const float ogx = s.og[0], ogy = s.og[1], ogz = s.og[2];
-      float t = fmaxf(t_near, 0.0f);
-      int n = 0;
-      while (t < t_far && n < SDFR_MAX_MARCH_STEPS) {
-        Cell c;
-        gather_cell<RT>(vol, R, fmaf(t, dgx, ogx), fmaf(t, dgy, ogy), fmaf(t, dgz, ogz), c);
-        const float dist = trilerp(c) * scale;
-        if (dist < threshold * t) {
-          result = -t * d.z;
-          break;
-        }
-        t += dist;
-        ++n;
-      }
-    }
-  }
-  if (px.inside) *out = result;
+struct Rect {
+  int x0, y0, x1, y1;
+};
+__device__ __forceinline__ bool overlaps(const Rect& r, int px, int py, int w, int h) {
+  return (px < r.x1) && (px + w > r.x0) && (py < r.y1) && (py + h > r.y0);
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward
+// forward.  grid = (macro-tiles x, macro-tiles y, views)
+// ---------------------------------------------------------------------------------------------
+template <int RT, bool PACKED>
+__global__ __launch_bounds__(kBlock) void render_forward_kernel(
+    const float* __restrict__ src, int R, long long src_view_stride,
+    const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx, float rfy,
+    float threshold, int vec_ok, float* __restrict__ depth) {
+  const int b = blockIdx.z;
+  const int px0 = blockIdx.x * kTileW, py0 = blockIdx.y * kTileH;
+  const ViewSetup& s = setup[b];
+  const Rect rc{s.rect[0], s.rect[1], s.rect[2], s.rect[3]};
+  float* img = depth + (size_t)b * H * W;
+  const int tid = threadIdx.x;
+
+  if (!overlaps(rc, px0, py0, kTileW, kTileH)) {
+    // nothing of the cube projects here: stream zeros
+    if (vec_ok) {
+#pragma unroll
+      for (int i = tid; i < kTileW * kTileH / 4; i += kBlock) {
+        const int row = py0 + (i >> 4), col = px0 + (i & 15) * 4;
+        if (row < H && col < W) *reinterpret_cast<float4*>(img + (size_t)row * W + col) = make_float4(0, 0, 0, 0);
+      }
+    } else {
+      for (int i = tid; i < kTileW * kTileH; i += kBlock) {
+        const int row = py0 + (i >> 6), col = px0 + (i & 63);
+        if (row < H && col < W) img[(size_t)row * W + col] = 0.0f;
+      }
+    }
+    return;
+  }
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int Rr = RT > 0 ? RT : R;
+  const float scale = s.scale;
+  const float kgrid = s.isc * (0.5f * (float)(Rr - 1));
+  const float ogx = s.og[0], ogy = s.og[1], ogz = s.og[2];
+  const float* vol = src + (size_t)b * src_view_stride;
+
+  for (int sub = 0; sub < kSubs; ++sub) {
+    const int sx = px0 + (sub & 1) * kSubW, sy = py0 + (sub >> 1) * kSubH;
+    const int col = sx + wave * 8 + (lane & 7), row = sy + (lane >> 3);
+    const bool inside = (col < W) && (row < H);
+    float result = 0.0f;
+    // wave-uniform: does this wave's 8x8 patch touch the rectangle at all?
+    if (overlaps(rc, sx + wave * 8, sy, 8, 8)) {
+      const bool in_rect = inside && col >= rc.x0 && col < rc.x1 && row >= rc.y0 && row < rc.y1;
+      const V3 d = pixel_ray(row, col, cx, cy, rfx, rfy);
+      const V3 dobj = rot_t(s, d);
+      // slab test in the object frame: the cube is axis-aligned there, its centre is at +e
+      // from the ray origin and f_i = dobj_i.  sdf_renderer_cuda.cu:156-194, branch-free.
+      float t_near = -1e-10f, t_far = 1e10f;
+      bool miss = !in_rect;
+      const float dv[3] = {dobj.x, dobj.y, dobj.z};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float e = s.e[a], f = dv[a];
+        const bool big = fabsf(f) > 1e-20f;
+        const float inv = __builtin_amdgcn_rcpf(f);
+        const float ta = (e + scale) * inv, tb = (e - scale) * inv;
+        t_near = big ? fmaxf(t_near, fminf(ta, tb)) : t_near;
+        t_far = big ? fminf(t_far, fmaxf(ta, tb)) : t_far;
+        miss = miss || (!big && (-e > scale || -e < -scale));
+      }
+      miss = miss || (t_near > t_far) || (t_far < 0.0f);
+      if (!miss) {
+        const float dgx = dobj.x * kgrid, dgy = dobj.y * kgrid, dgz = dobj.z * kgrid;
+        float t = fmaxf(t_near, 0.0f);
+        int n = 0;
+        while (t < t_far && n < SDFR_MAX_MARCH_STEPS) {
+          Cell c;
+          gather_cell<RT, PACKED>(vol, R, fmaf(t, dgx, ogx), fmaf(t, dgy, ogy), fmaf(t, dgz, ogz), c);
+          const float dist = trilerp(c) * scale;
+          if (dist < threshold * t) {
+            result = -t * d.z;
+            break;
+          }
+          t += dist;
+          ++n;
+        }
+      }
+    }
+    if (inside) img[(size_t)row * W + col] = result;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward.  grid = (macro-tiles x, macro-tiles y, views)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -250,63 +285,91 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-constexpr int kBrick = 4096;  // floats of LDS used to pre-sum a tile's d/dsdf contributions
+// LDS hash of 8-voxel runs (32 bytes of the gradient volume): key = linear voxel index >> 3.
+constexpr int kRunSlots = 1024;
+constexpr int kRunLen = 8;
+
+__device__ __forceinline__ int run_slot(int* keys, int key) {
+  unsigned h = ((unsigned)key * 2654435761u) >> 22;  // 10 bits
+#pragma unroll 1
+  for (int probe = 0; probe < 24; ++probe) {
+    const int old = atomicCAS(&keys[h], -1, key);
+    if (old == -1 || old == key) return (int)h;
+    h = (h + 1) & (kRunSlots - 1);
+  }
+  return -1;
+}
+
+// add (w_lo, w_hi) to voxels lin, lin+1 (a z-pair) of the gradient volume through the hash
+__device__ __forceinline__ void add_zpair(int* keys, float* vals, float* __restrict__ gvol, int lin,
+                                          float w_lo, float w_hi) {
+  const int k0 = lin >> 3, k1 = (lin + 1) >> 3;
+  const int s0 = run_slot(keys, k0);
+  if (s0 >= 0) atomicAdd(&vals[s0 * kRunLen + (lin & 7)], w_lo); else atomicAdd(gvol + lin, w_lo);
+  const int s1 = (k1 == k0) ? s0 : run_slot(keys, k1);
+  if (s1 >= 0) atomicAdd(&vals[s1 * kRunLen + ((lin + 1) & 7)], w_hi); else atomicAdd(gvol + lin + 1, w_hi);
+}
 
 template <int RT>
 __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     const float* __restrict__ grad_depth, const float* __restrict__ depth,
     const float* __restrict__ sdf, int R, long long sdf_view_stride,
-    const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, float cx, float cy,
-    float rfx, float rfy, int sdf_grad_mode, float* __restrict__ g_sdf,
-    long long g_sdf_view_stride, float* __restrict__ partials) {
-  __shared__ float brick[kBrick];
+    const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx, float rfy,
+    int sdf_grad_mode, float* __restrict__ g_sdf, long long g_sdf_view_stride,
+    float* __restrict__ partials) {
+  __shared__ int run_key[kRunSlots];
+  __shared__ float run_val[kRunSlots * kRunLen];
   __shared__ float wave_part[4][8];
-  __shared__ int box_lo[3], box_hi[3];
 
   const int Rr = RT > 0 ? RT : R;
-  const int tiles_per_view = ntx * nty;
-  const int b = blockIdx.x / tiles_per_view;
-  const int t_in_view = blockIdx.x - b * tiles_per_view;
-  const int tile_y = t_in_view / ntx, tile_x = t_in_view - tile_y * ntx;
+  const int b = blockIdx.z;
+  const int px0 = blockIdx.x * kTileW, py0 = blockIdx.y * kTileH;
   const ViewSetup& s = setup[b];
-  const int x0 = s.rect[0], y0 = s.rect[1], x1 = s.rect[2], y1 = s.rect[3];
-  const bool tile_live = (tile_x * kTileW < x1) && (tile_x * kTileW + kTileW > x0) &&
-                         (tile_y * kTileH < y1) && (tile_y * kTileH + kTileH > y0);
-  if (!tile_live) return;  // depth is 0 there by construction of the forward: nothing to do
+  const Rect rc{s.rect[0], s.rect[1], s.rect[2], s.rect[3]};
+  if (!overlaps(rc, px0, py0, kTileW, kTileH)) return;  // depth is 0 there by construction
 
-  const int tid = threadIdx.x;
-  const Pixel px = tile_pixel(tile_x, tile_y, W, H);
-  const size_t pix = ((size_t)b * H + px.row) * W + px.col;
-  float z = 0.0f, go = 0.0f;
-  if (px.inside) {
-    z = depth[pix];
-    go = grad_depth[pix];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float* zimg = depth + (size_t)b * H * W;
+  const float* gimg = grad_depth + (size_t)b * H * W;
+  float* part = partials + ((size_t)b * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+
+  // all depth reads of the macro-tile up front (independent loads)
+  float zs[kSubs];
+  bool any_hit = false;
+#pragma unroll
+  for (int sub = 0; sub < kSubs; ++sub) {
+    const int col = px0 + (sub & 1) * kSubW + wave * 8 + (lane & 7);
+    const int row = py0 + (sub >> 1) * kSubH + (lane >> 3);
+    zs[sub] = (col < W && row < H) ? zimg[(size_t)row * W + col] : 0.0f;
+    any_hit = any_hit || (zs[sub] != 0.0f);
   }
-  const bool hit = z != 0.0f;
-  float* part = partials + ((size_t)b * tiles_per_view + t_in_view) * 8;
-  if (!__syncthreads_or(hit)) {
+  if (!__syncthreads_or(any_hit)) {
     if (tid < 8) part[tid] = 0.0f;
     return;
   }
-  if (tid < 3) {
-    box_lo[tid] = 1 << 30;
-    box_hi[tid] = -1;
-  }
+  for (int i = tid; i < kRunSlots; i += kBlock) run_key[i] = -1;
+  for (int i = tid; i < kRunSlots * kRunLen; i += kBlock) run_val[i] = 0.0f;
   __syncthreads();
 
-  float dz[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  float wgt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int bx = 0, by = 0, bz = 0;
-  if (hit) {
-    const V3 d = pixel_ray(px.row, px.col, cx, cy, rfx, rfy);
+  const float* vol = sdf + (size_t)b * sdf_view_stride;
+  float* gvol = g_sdf + (size_t)b * g_sdf_view_stride;
+  const float h = 0.5f * (float)(Rr - 1);
+  const float scale = s.scale, isc = s.isc;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+#pragma unroll 1
+  for (int sub = 0; sub < kSubs; ++sub) {
+    const float z = zs[sub];
+    if (z == 0.0f) continue;
+    const int col = px0 + (sub & 1) * kSubW + wave * 8 + (lane & 7);
+    const int row = py0 + (sub >> 1) * kSubH + (lane >> 3);
+    const float go = gimg[(size_t)row * W + col];
+    const V3 d = pixel_ray(row, col, cx, cy, rfx, rfy);
     const V3 dobj = rot_t(s, d);
-    const float h = 0.5f * (float)(Rr - 1);
-    const float scale = s.scale, isc = s.isc;
     const float t = z * __builtin_amdgcn_rcpf(-d.z);  // -z / d.z   (cu:339)
     const V3 o = mk(fmaf(t, dobj.x, -s.e[0]), fmaf(t, dobj.y, -s.e[1]), fmaf(t, dobj.z, -s.e[2]));
-    const float* vol = sdf + (size_t)b * sdf_view_stride;
     Cell c;
-    gather_cell<RT>(vol, R, fmaf(o.x * isc, h, h), fmaf(o.y * isc, h, h), fmaf(o.z * isc, h, h), c);
+    gather_cell<RT, false>(vol, R, fmaf(o.x * isc, h, h), fmaf(o.y * isc, h, h), fmaf(o.z * isc, h, h), c);
     const float tri = trilerp(c);
     // gradient of the trilinear value w.r.t. the cell coordinate
     const float ax = 1.0f - c.ox, ay = 1.0f - c.oy, az = 1.0f - c.oz;
@@ -319,12 +382,12 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     G.z = fmaf(c11, c.oy, c01 * ay) - fmaf(c10, c.oy, c00 * ay);
 
     const float adz = fabsf(d.z);
-    const float f = scale * adz;      // cu:372
-    const float sg = isc * h;         // s = inv_scale / grid_size (cu:391)
-    const float kf = f * sg * go;     // common factor of the pose terms, times upstream grad
+    const float f = scale * adz;   // cu:372
+    const float sg = isc * h;      // s = inv_scale / grid_size (cu:391)
+    const float kf = f * sg * go;  // common factor of the pose terms, times upstream grad
     // position: dc/dp_j = -s * R[j][:]
     const V3 RG = rot_f(s, G);
-    dz[0] = -kf * RG.x; dz[1] = -kf * RG.y; dz[2] = -kf * RG.z;
+    acc[0] -= kf * RG.x; acc[1] -= kf * RG.y; acc[2] -= kf * RG.z;
     // quaternion: dc/dq_k = s * (d/dq_k[Rhom^T v] - 2 q_k o), v = t d - p
     const V3 v = mk(fmaf(t, d.x, -s.p[0]), fmaf(t, d.y, -s.p[1]), fmaf(t, d.z, -s.p[2]));
     const V3 u = mk(s.q[0], s.q[1], s.q[2]);
@@ -332,80 +395,52 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     const float udv = dot(u, v);
     const V3 uxv = cross(u, v);
     const float Gv = dot(G, v), Go = dot(G, o), Gu = dot(G, u);
-    // G . (e_k x v) = (v x G)_k
-    const V3 vxG = cross(v, G);
+    const V3 vxG = cross(v, G);  // G . (e_k x v) = (v x G)_k
     // d/du_k: -2 u_k v + 2 e_k (u.v) + 2 u v_k - 2 w (e_k x v) - 2 u_k o
-    dz[3] = kf * 2.0f * (-u.x * Gv + udv * G.x + v.x * Gu - w * vxG.x - u.x * Go);
-    dz[4] = kf * 2.0f * (-u.y * Gv + udv * G.y + v.y * Gu - w * vxG.y - u.y * Go);
-    dz[5] = kf * 2.0f * (-u.z * Gv + udv * G.z + v.z * Gu - w * vxG.z - u.z * Go);
+    acc[3] += kf * 2.0f * (-u.x * Gv + udv * G.x + v.x * Gu - w * vxG.x - u.x * Go);
+    acc[4] += kf * 2.0f * (-u.y * Gv + udv * G.y + v.y * Gu - w * vxG.y - u.y * Go);
+    acc[5] += kf * 2.0f * (-u.z * Gv + udv * G.z + v.z * Gu - w * vxG.z - u.z * Go);
     // d/dw: 2 w v - 2 (u x v) - 2 w o
-    dz[6] = kf * 2.0f * (w * Gv - dot(G, uxv) - w * Go);
+    acc[6] += kf * 2.0f * (w * Gv - dot(G, uxv) - w * Go);
     // inverse scale: dc/ds^-1 = o / g, plus the product rule on scale (cu:439, :457)
-    dz[7] = go * (f * h * Go - tri * scale * scale * adz);
+    acc[7] += go * (f * h * Go - tri * scale * scale * adz);
 
     const float gf = go * f;
-    const float x1w = c.ox, y1w = c.oy, z1w = c.oz;
+    const float x1w = c.ox * gf, x0w = ax * gf;
+    float w0, w1, w2, w3, w4, w5, w6, w7;
     if (sdf_grad_mode == SDFR_SDF_GRAD_EXACT) {
-      wgt[0] = ax * ay * az;  wgt[1] = ax * ay * z1w;  wgt[2] = ax * y1w * az;  wgt[3] = ax * y1w * z1w;
-      wgt[4] = x1w * ay * az; wgt[5] = x1w * ay * z1w; wgt[6] = x1w * y1w * az; wgt[7] = x1w * y1w * z1w;
+      w0 = x0w * ay * az;   w1 = x0w * ay * c.oz;   w2 = x0w * c.oy * az;   w3 = x0w * c.oy * c.oz;
+      w4 = x1w * ay * az;   w5 = x1w * ay * c.oz;   w6 = x1w * c.oy * az;   w7 = x1w * c.oy * c.oz;
     } else {  // the weights the CUDA kernel really adds (cu:373-388)
-      wgt[0] = ax * ay * z1w;  wgt[1] = ax * y1w * az;  wgt[2] = ax * y1w * z1w; wgt[3] = x1w * ay * az;
-      wgt[4] = x1w * ay * z1w; wgt[5] = x1w * ay * z1w; wgt[6] = x1w * y1w * az; wgt[7] = x1w * y1w * z1w;
+      w0 = x0w * ay * c.oz; w1 = x0w * c.oy * az;   w2 = x0w * c.oy * c.oz; w3 = x1w * ay * az;
+      w4 = x1w * ay * c.oz; w5 = x1w * ay * c.oz;   w6 = x1w * c.oy * az;   w7 = x1w * c.oy * c.oz;
     }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) wgt[k] *= gf;
-    bz = c.lin % Rr;
-    by = (c.lin / Rr) % Rr;
-    bx = c.lin / (Rr * Rr);
-    atomicMin(&box_lo[0], bx); atomicMax(&box_hi[0], bx);
-    atomicMin(&box_lo[1], by); atomicMax(&box_hi[1], by);
-    atomicMin(&box_lo[2], bz); atomicMax(&box_hi[2], bz);
+    add_zpair(run_key, run_val, gvol, c.lin, w0, w1);
+    add_zpair(run_key, run_val, gvol, c.lin + Rr, w2, w3);
+    add_zpair(run_key, run_val, gvol, c.lin + Rr * Rr, w4, w5);
+    add_zpair(run_key, run_val, gvol, c.lin + Rr * Rr + Rr, w6, w7);
   }
 
-  // pose sums: wave shuffle -> LDS -> tile partial
-  const int wave = tid >> 6, lane = tid & 63;
+  // pose sums: registers -> wave shuffle -> LDS -> macro-tile partial
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const float sk = wave_sum(dz[k]);
+    const float sk = wave_sum(acc[k]);
     if (lane == 0) wave_part[wave][k] = sk;
   }
   __syncthreads();
   if (tid < 8) part[tid] = (wave_part[0][tid] + wave_part[1][tid]) + (wave_part[2][tid] + wave_part[3][tid]);
 
-  // d/dsdf: pre-sum the tile's contributions in an LDS brick spanning the voxel bounding box of
-  // its hit cells (a surface patch is compact), then one global atomic per touched voxel.
-  float* gvol = g_sdf + (size_t)b * g_sdf_view_stride;
-  const int lx = box_lo[0], ly = box_lo[1], lz = box_lo[2];
-  const int nx = box_hi[0] - lx + 2, ny = box_hi[1] - ly + 2, nz = box_hi[2] - lz + 2;
-  const int vol_n = nx * ny * nz;
-  if (vol_n <= kBrick) {
-    for (int i = tid; i < vol_n; i += kBlock) brick[i] = 0.0f;
-    __syncthreads();
-    if (hit) {
-      const int o0 = ((bx - lx) * ny + (by - ly)) * nz + (bz - lz);
-      atomicAdd(&brick[o0], wgt[0]);                atomicAdd(&brick[o0 + 1], wgt[1]);
-      atomicAdd(&brick[o0 + nz], wgt[2]);           atomicAdd(&brick[o0 + nz + 1], wgt[3]);
-      atomicAdd(&brick[o0 + ny * nz], wgt[4]);      atomicAdd(&brick[o0 + ny * nz + 1], wgt[5]);
-      atomicAdd(&brick[o0 + ny * nz + nz], wgt[6]); atomicAdd(&brick[o0 + ny * nz + nz + 1], wgt[7]);
-    }
-    __syncthreads();
-    for (int i = tid; i < vol_n; i += kBlock) {
-      const float val = brick[i];
-      if (val != 0.0f) {
-        const int iz = i % nz, iy = (i / nz) % ny, ix = i / (nz * ny);
-        atomicAdd(&gvol[((size_t)(lx + ix) * Rr + (ly + iy)) * Rr + (lz + iz)], val);
-      }
-    }
-  } else if (hit) {  // patch too spread out for the brick (rare): straight to global
-    float* g0 = gvol + ((size_t)bx * Rr + by) * Rr + bz;
-    atomicAdd(g0, wgt[0]);                atomicAdd(g0 + 1, wgt[1]);
-    atomicAdd(g0 + Rr, wgt[2]);           atomicAdd(g0 + Rr + 1, wgt[3]);
-    atomicAdd(g0 + Rr * Rr, wgt[4]);      atomicAdd(g0 + Rr * Rr + 1, wgt[5]);
-    atomicAdd(g0 + Rr * Rr + Rr, wgt[6]); atomicAdd(g0 + Rr * Rr + Rr + 1, wgt[7]);
+  // flush the runs: lane j of an 8-lane group writes element j of one run (32 contiguous bytes)
+  const int nvox = Rr * Rr * Rr;
+  for (int i = tid; i < kRunSlots * kRunLen; i += kBlock) {
+    const int key = run_key[i >> 3];
+    const float val = run_val[i];
+    const int lin = key * kRunLen + (i & 7);
+    if (key >= 0 && val != 0.0f && lin < nvox) atomicAdd(gvol + lin, val);
   }
 }
 
-// Fixed-order sum of a view's tile partials: one wave per view.
+// Fixed-order sum of a view's macro-tile partials: one wave per view.
 __global__ __launch_bounds__(64) void pose_reduce_kernel(const float* __restrict__ partials,
                                                          const ViewSetup* __restrict__ setup,
                                                          int ntx, int nty,
@@ -415,7 +450,7 @@ __global__ __launch_bounds__(64) void pose_reduce_kernel(const float* __restrict
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
   const ViewSetup& s = setup[b];
-  // live tile range of this view (same predicate as the image kernels)
+  // live macro-tile range of this view (same predicate as the image kernels)
   const int x0 = s.rect[0], y0 = s.rect[1], x1 = s.rect[2], y1 = s.rect[3];
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (x1 > x0 && y1 > y0) {
@@ -446,25 +481,37 @@ __global__ __launch_bounds__(64) void pose_reduce_kernel(const float* __restrict
 int check_common(int R, int B, int W, int H, float fx, float fy) {
   if (R < 2 || R > 1024) return fail(SDFR_E_INVALID, "R=%d out of range [2,1024]", R);
   if (B < 0 || W < 0 || H < 0) return fail(SDFR_E_INVALID, "negative size B=%d W=%d H=%d", B, W, H);
+  if (B > 65535) return fail(SDFR_E_INVALID, "B=%d exceeds 65535 views per call", B);
+  if (tiles_y(H) > 65535) return fail(SDFR_E_INVALID, "H=%d too large", H);
+  if ((long long)W * H * (long long)(B > 0 ? B : 1) > (1LL << 40))
+    return fail(SDFR_E_INVALID, "image batch too large");
   if (!(fx != 0.0f) || !(fy != 0.0f)) return fail(SDFR_E_INVALID, "focal length must be non-zero");
-  const long long tiles = (long long)tiles_x(W) * tiles_y(H) * (long long)B;
-  if (tiles > 0x7fffffffLL) return fail(SDFR_E_INVALID, "B*tiles = %lld exceeds the grid limit", tiles);
   return 0;
 }
 
 size_t setup_bytes(int B) { return (size_t)(B > 0 ? B : 0) * sizeof(ViewSetup); }
+
+// The packed-record march pays a re-pack of the grid per call (R^3 x 32 bytes written); worth it
+// when the grid is shared by several views and small enough to stay cache resident.
+bool use_packed(int R, int B, long long sdf_view_stride) {
+  return sdf_view_stride == 0 && B >= kPackedMinViews && R <= kPackedMaxR;
+}
+size_t packed_bytes(int R) { return (size_t)R * R * R * 8 * sizeof(float); }
 
 }  // namespace
 }  // namespace sdfr
 
 using namespace sdfr;
 
-extern "C" size_t sdfr_render_forward_workspace_bytes(int B, int W, int H) {
+extern "C" size_t sdfr_render_forward_workspace_bytes(int R, int B, int W, int H) {
   (void)W; (void)H;
-  return setup_bytes(B);
+  size_t n = setup_bytes(B);
+  if (R >= 2 && R <= kPackedMaxR) n += packed_bytes(R);
+  return n;
 }
 
-extern "C" size_t sdfr_render_backward_workspace_bytes(int B, int W, int H) {
+extern "C" size_t sdfr_render_backward_workspace_bytes(int R, int B, int W, int H) {
+  (void)R;
   if (B <= 0 || W <= 0 || H <= 0) return setup_bytes(B);
   return setup_bytes(B) + (size_t)B * tiles_x(W) * tiles_y(H) * 8 * sizeof(float);
 }
@@ -480,25 +527,35 @@ extern "C" int sdfr_render_forward(const float* sdf, int R, long long sdf_view_s
   if (B == 0 || W == 0 || H == 0) return 0;
   if (!sdf || !pos || !quat || !inv_scale || !depth || !workspace)
     return fail(SDFR_E_NULL, "sdfr_render_forward: NULL pointer argument");
-  if (workspace_bytes < sdfr_render_forward_workspace_bytes(B, W, H))
+  if (workspace_bytes < sdfr_render_forward_workspace_bytes(R, B, W, H))
     return fail(SDFR_E_WORKSPACE, "sdfr_render_forward: workspace %zu < %zu bytes", workspace_bytes,
-                sdfr_render_forward_workspace_bytes(B, W, H));
+                sdfr_render_forward_workspace_bytes(R, B, W, H));
   if ((uintptr_t)workspace % alignof(ViewSetup))
     return fail(SDFR_E_INVALID, "workspace must be %zu-byte aligned", alignof(ViewSetup));
   SDFR_HIP_TRY(hipSetDevice(device));
   hipStream_t st = (hipStream_t)stream;
   ViewSetup* setup = (ViewSetup*)workspace;
+  float* cells = (float*)((char*)workspace + setup_bytes(B));  // 128-byte aligned
   hipLaunchKernelGGL(view_setup_kernel, dim3((B + 63) / 64), dim3(64), 0, st, pos, quat, inv_scale,
                      B, R, W, H, cx, cy, fx, fy, setup);
-  const int ntx = tiles_x(W), nty = tiles_y(H);
-  const dim3 grid((unsigned)(ntx * nty * B));
+  const bool packed = use_packed(R, B, sdf_view_stride);
+  if (packed) {
+    const int n = R * R * R;
+    hipLaunchKernelGGL(pack_cells_kernel, dim3((n + 255) / 256), dim3(256), 0, st, sdf, R,
+                       (float4*)cells);
+  }
+  const dim3 grid((unsigned)tiles_x(W), (unsigned)tiles_y(H), (unsigned)B);
   const float rfx = (float)(1.0 / (double)fx), rfy = (float)(1.0 / (double)fy);
-  if (R == 64)
-    hipLaunchKernelGGL(render_forward_kernel<64>, grid, dim3(kBlock), 0, st, sdf, R, sdf_view_stride,
-                       setup, W, H, ntx, nty, cx, cy, rfx, rfy, threshold, depth);
-  else
-    hipLaunchKernelGGL(render_forward_kernel<0>, grid, dim3(kBlock), 0, st, sdf, R, sdf_view_stride,
-                       setup, W, H, ntx, nty, cx, cy, rfx, rfy, threshold, depth);
+  const int vec_ok = (W % 4 == 0) && ((uintptr_t)depth % 16 == 0);
+#define SDFR_LAUNCH_FWD(RT, PK, SRC, STRIDE)                                                         \
+  hipLaunchKernelGGL((render_forward_kernel<RT, PK>), grid, dim3(kBlock), 0, st, SRC, R, STRIDE,     \
+                     setup, W, H, cx, cy, rfx, rfy, threshold, vec_ok, depth)
+  if (packed) {
+    if (R == 64) SDFR_LAUNCH_FWD(64, true, cells, 0LL); else SDFR_LAUNCH_FWD(0, true, cells, 0LL);
+  } else {
+    if (R == 64) SDFR_LAUNCH_FWD(64, false, sdf, sdf_view_stride); else SDFR_LAUNCH_FWD(0, false, sdf, sdf_view_stride);
+  }
+#undef SDFR_LAUNCH_FWD
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -534,9 +591,9 @@ extern "C" int sdfr_render_backward(const float* grad_depth, const float* depth,
   }
   if (!grad_depth || !depth || !sdf || !workspace)
     return fail(SDFR_E_NULL, "sdfr_render_backward: NULL pointer argument");
-  if (workspace_bytes < sdfr_render_backward_workspace_bytes(B, W, H))
+  if (workspace_bytes < sdfr_render_backward_workspace_bytes(R, B, W, H))
     return fail(SDFR_E_WORKSPACE, "sdfr_render_backward: workspace %zu < %zu bytes", workspace_bytes,
-                sdfr_render_backward_workspace_bytes(B, W, H));
+                sdfr_render_backward_workspace_bytes(R, B, W, H));
   if ((uintptr_t)workspace % alignof(ViewSetup))
     return fail(SDFR_E_INVALID, "workspace must be %zu-byte aligned", alignof(ViewSetup));
   ViewSetup* setup = (ViewSetup*)workspace;
@@ -544,16 +601,16 @@ extern "C" int sdfr_render_backward(const float* grad_depth, const float* depth,
   hipLaunchKernelGGL(view_setup_kernel, dim3((B + 63) / 64), dim3(64), 0, st, pos, quat, inv_scale,
                      B, R, W, H, cx, cy, fx, fy, setup);
   const int ntx = tiles_x(W), nty = tiles_y(H);
-  const dim3 grid((unsigned)(ntx * nty * B));
+  const dim3 grid((unsigned)ntx, (unsigned)nty, (unsigned)B);
   const float rfx = (float)(1.0 / (double)fx), rfy = (float)(1.0 / (double)fy);
   if (R == 64)
     hipLaunchKernelGGL(render_backward_kernel<64>, grid, dim3(kBlock), 0, st, grad_depth, depth, sdf,
-                       R, sdf_view_stride, setup, W, H, ntx, nty, cx, cy, rfx, rfy, sdf_grad_mode,
-                       g_sdf, g_sdf_view_stride, partials);
+                       R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf,
+                       g_sdf_view_stride, partials);
   else
     hipLaunchKernelGGL(render_backward_kernel<0>, grid, dim3(kBlock), 0, st, grad_depth, depth, sdf,
-                       R, sdf_view_stride, setup, W, H, ntx, nty, cx, cy, rfx, rfy, sdf_grad_mode,
-                       g_sdf, g_sdf_view_stride, partials);
+                       R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf,
+                       g_sdf_view_stride, partials);
   hipLaunchKernelGGL(pose_reduce_kernel, dim3(B), dim3(64), 0, st, partials, setup, ntx, nty, g_pos,
                      g_quat, g_inv_scale);
   SDFR_HIP_TRY(hipGetLastError());

@@ -99,7 +99,7 @@ def forward_raw(sdf, position, orientation, inv_scale, width, height, cx, cy, fx
     dev = sdf.device
     depth = torch.empty((B, height, width), dtype=torch.float32, device=dev)
     L = _lib.lib()
-    nbytes = L.sdfr_render_forward_workspace_bytes(B, width, height)
+    nbytes = L.sdfr_render_forward_workspace_bytes(R, B, width, height)
     ws = _workspace(dev, nbytes)
     rc = L.sdfr_render_forward(_ptr(sdf), R, stride, _ptr(position), _ptr(orientation),
                                _ptr(inv_scale), B, width, height, cx, cy, fx, fy, threshold,
@@ -127,7 +127,7 @@ def backward_raw(grad_depth, depth, sdf, position, orientation, inv_scale, width
     g_quat = torch.empty_like(orientation)
     g_isc = torch.empty_like(inv_scale)
     L = _lib.lib()
-    nbytes = L.sdfr_render_backward_workspace_bytes(B, width, height)
+    nbytes = L.sdfr_render_backward_workspace_bytes(R, B, width, height)
     ws = _workspace(dev, nbytes)
     rc = L.sdfr_render_backward(_ptr(grad_depth), _ptr(depth), _ptr(sdf), R, stride,
                                 _ptr(position), _ptr(orientation), _ptr(inv_scale), B, width,
@@ -227,3 +227,54 @@ def render_depth_batch(sdf: torch.Tensor, positions: torch.Tensor, orientations:
     """
     return _RenderBatch.apply(sdf, positions, orientations, inv_scales, threshold, camera,
                               sdf_grad_mode)
+
+
+class BatchRenderPlan:
+    """Pre-allocated buffers for repeated forward+backward of B views (no per-call allocation).
+
+    This is how a production loop drives the C ABI: every output and the workspace are
+    allocated once, each step is a fixed sequence of launches on one stream, so the step can
+    be captured into a hipGraph (``capture()``).
+    """
+
+    def __init__(self, R: int, B: int, camera: Camera, device="cuda", per_view_sdf: bool = False,
+                 sdf_grad_mode: int = 0):
+        self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.R, self.B, self.camera = R, B, camera
+        self.fx, self.fy, self.cx, self.cy, _ = camera.get_pinhole_camera_parameters(0.5)
+        self.W, self.H = camera.width, camera.height
+        self.sdf_stride = R * R * R if per_view_sdf else 0
+        self.sdf_grad_mode = sdf_grad_mode
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.depth = torch.empty((B, self.H, self.W), **f32)
+        self.g_sdf = torch.empty((B, R, R, R) if per_view_sdf else (R, R, R), **f32)
+        self.g_pos = torch.empty((B, 3), **f32)
+        self.g_quat = torch.empty((B, 4), **f32)
+        self.g_inv_scale = torch.empty((B,), **f32)
+        L = _lib.lib()
+        nbytes = max(L.sdfr_render_forward_workspace_bytes(R, B, self.W, self.H),
+                     L.sdfr_render_backward_workspace_bytes(R, B, self.W, self.H), 256)
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self._L = L
+
+    def forward(self, sdf, pos, quat, inv_scale, threshold: float) -> torch.Tensor:
+        rc = self._L.sdfr_render_forward(
+            sdf.data_ptr(), self.R, self.sdf_stride, pos.data_ptr(), quat.data_ptr(),
+            inv_scale.data_ptr(), self.B, self.W, self.H, self.cx, self.cy, self.fx, self.fy,
+            threshold, self.depth.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(),
+            self.device.index, _stream(self.device))
+        _lib.check(rc, "sdfr_render_forward")
+        return self.depth
+
+    def backward(self, grad_depth, sdf, pos, quat, inv_scale):
+        rc = self._L.sdfr_render_backward(
+            grad_depth.data_ptr(), self.depth.data_ptr(), sdf.data_ptr(), self.R, self.sdf_stride,
+            pos.data_ptr(), quat.data_ptr(), inv_scale.data_ptr(), self.B, self.W, self.H,
+            self.cx, self.cy, self.fx, self.fy, self.sdf_grad_mode, self.g_sdf.data_ptr(),
+            self.sdf_stride, self.g_pos.data_ptr(), self.g_quat.data_ptr(),
+            self.g_inv_scale.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(),
+            self.device.index, _stream(self.device))
+        _lib.check(rc, "sdfr_render_backward")
+        return self.g_sdf, self.g_pos, self.g_quat, self.g_inv_scale
