@@ -59,7 +59,10 @@ constexpr int kSubH = 8;
 constexpr int kSubs = (kTileW / kSubW) * (kTileH / kSubH);  // 8
 
 // packed cell records are used for a grid shared by >= kPackedMinViews views, up to kPackedMaxR
-constexpr int kPackedMinViews = 4;
+#ifndef SDFR_PACKED_MIN_VIEWS
+#define SDFR_PACKED_MIN_VIEWS 4
+#endif
+constexpr int kPackedMinViews = SDFR_PACKED_MIN_VIEWS;
 constexpr int kPackedMaxR = 128;
 
 inline int tiles_x(int W) { return (W + kTileW - 1) / kTileW; }

@@ -26,10 +26,15 @@
 //     flushed as 32-byte runs of global float atomics (one per touched voxel per macro-tile).
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace sdfr {
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef SDFR_RAYS_PER_LANE
+#define SDFR_RAYS_PER_LANE 1
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // set-up: one thread per view
@@ -96,6 +101,8 @@ __global__ void view_setup_kernel(const float* __restrict__ pos, const float* __
 // as two float4: (v000, v001, v010, v011), (v100, v101, v110, v111).  R^3 records (the last
 // layer along each axis is never addressed: cell indices are clamped to R-2).
 // ---------------------------------------------------------------------------------------------
+// (A 2x2x2-blocked record order was measured: +10 integer ops per step, no gain -- the march is
+// bound by dependent-load latency, not by lines per access.  Records stay in grid order.)
 __global__ __launch_bounds__(256) void pack_cells_kernel(const float* __restrict__ sdf, int R,
                                                          float4* __restrict__ cells) {
   const int lin = blockIdx.x * blockDim.x + threadIdx.x;
@@ -104,8 +111,9 @@ __global__ __launch_bounds__(256) void pack_cells_kernel(const float* __restrict
   const int z = lin % R, y = (lin / R) % R, x = lin / RR;
   if (x >= R - 1 || y >= R - 1 || z >= R - 1) return;
   const float* p = sdf + lin;
-  cells[2 * (size_t)lin] = make_float4(p[0], p[1], p[R], p[R + 1]);
-  cells[2 * (size_t)lin + 1] = make_float4(p[RR], p[RR + 1], p[RR + R], p[RR + R + 1]);
+  const size_t rec = (size_t)lin;
+  cells[2 * rec] = make_float4(p[0], p[1], p[R], p[R + 1]);
+  cells[2 * rec + 1] = make_float4(p[RR], p[RR + 1], p[RR + R], p[RR + R + 1]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -183,6 +191,12 @@ __device__ __forceinline__ float trilerp(const Cell& c) {
   return fmaf(c1, c.oz, c0 * az);
 }
 
+// lane -> pixel of the wave's 8x8 patch, in Morton order: 4 consecutive lanes are a 2x2 pixel
+// block, 16 lanes a 4x4 block.  The texture-address unit handles a 16-byte-per-lane load four
+// lanes at a time; four lanes that sit in one 2x2 block mostly hit one record (one cache line).
+__device__ __forceinline__ int patch_x(int lane) { return (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4); }
+__device__ __forceinline__ int patch_y(int lane) { return ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4); }
+
 struct Rect {
   int x0, y0, x1, y1;
 };
@@ -193,11 +207,17 @@ __device__ __forceinline__ bool overlaps(const Rect& r, int px, int py, int w, i
 // ---------------------------------------------------------------------------------------------
 // forward.  grid = (macro-tiles x, macro-tiles y, views)
 // ---------------------------------------------------------------------------------------------
-template <int RT, bool PACKED>
+// One lane marches K rays at once (the pixels it owns in K consecutive sub-tiles): the march is
+// a chain of dependent gathers (address -> 32-byte record -> lerp -> next t), so with one ray
+// per lane a wave sits idle for a full cache round trip per step; K independent chains keep K
+// record loads in flight per lane.  All K rays start together, so the step number of every
+// active ray equals the iteration count `n` and one counter enforces SDFR_MAX_MARCH_STEPS.
+template <int RT, bool PACKED, int K>
 __global__ __launch_bounds__(kBlock) void render_forward_kernel(
     const float* __restrict__ src, int R, long long src_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx, float rfy,
     float threshold, int vec_ok, float* __restrict__ depth) {
+  static_assert(kSubs % K == 0, "K must divide the sub-tiles of a macro-tile");
   const int b = blockIdx.z;
   const int px0 = blockIdx.x * kTileW, py0 = blockIdx.y * kTileH;
   const ViewSetup& s = setup[b];
@@ -229,50 +249,76 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
   const float ogx = s.og[0], ogy = s.og[1], ogz = s.og[2];
   const float* vol = src + (size_t)b * src_view_stride;
 
-  for (int sub = 0; sub < kSubs; ++sub) {
-    const int sx = px0 + (sub & 1) * kSubW, sy = py0 + (sub >> 1) * kSubH;
-    const int col = sx + wave * 8 + (lane & 7), row = sy + (lane >> 3);
-    const bool inside = (col < W) && (row < H);
-    float result = 0.0f;
-    // wave-uniform: does this wave's 8x8 patch touch the rectangle at all?
-    if (overlaps(rc, sx + wave * 8, sy, 8, 8)) {
-      const bool in_rect = inside && col >= rc.x0 && col < rc.x1 && row >= rc.y0 && row < rc.y1;
-      const V3 d = pixel_ray(row, col, cx, cy, rfx, rfy);
-      const V3 dobj = rot_t(s, d);
-      // slab test in the object frame: the cube is axis-aligned there, its centre is at +e
-      // from the ray origin and f_i = dobj_i.  sdf_renderer_cuda.cu:156-194, branch-free.
-      float t_near = -1e-10f, t_far = 1e10f;
-      bool miss = !in_rect;
-      const float dv[3] = {dobj.x, dobj.y, dobj.z};
+  for (int grp = 0; grp < kSubs; grp += K) {
+    float t[K], t_far[K], dgx[K], dgy[K], dgz[K], ndz[K], result[K];
+    bool active[K];
+    int pix[K];  // row * W + col, or -1 outside the image
+    bool any = false;
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const float e = s.e[a], f = dv[a];
-        const bool big = fabsf(f) > 1e-20f;
-        const float inv = __builtin_amdgcn_rcpf(f);
-        const float ta = (e + scale) * inv, tb = (e - scale) * inv;
-        t_near = big ? fmaxf(t_near, fminf(ta, tb)) : t_near;
-        t_far = big ? fminf(t_far, fmaxf(ta, tb)) : t_far;
-        miss = miss || (!big && (-e > scale || -e < -scale));
-      }
-      miss = miss || (t_near > t_far) || (t_far < 0.0f);
-      if (!miss) {
-        const float dgx = dobj.x * kgrid, dgy = dobj.y * kgrid, dgz = dobj.z * kgrid;
-        float t = fmaxf(t_near, 0.0f);
-        int n = 0;
-        while (t < t_far && n < SDFR_MAX_MARCH_STEPS) {
-          Cell c;
-          gather_cell<RT, PACKED>(vol, R, fmaf(t, dgx, ogx), fmaf(t, dgy, ogy), fmaf(t, dgz, ogz), c);
-          const float dist = trilerp(c) * scale;
-          if (dist < threshold * t) {
-            result = -t * d.z;
-            break;
-          }
-          t += dist;
-          ++n;
+    for (int k = 0; k < K; ++k) {
+      const int sub = grp + k;
+      const int sx = px0 + (sub & 1) * kSubW, sy = py0 + (sub >> 1) * kSubH;
+      const int col = sx + wave * 8 + patch_x(lane), row = sy + patch_y(lane);
+      const bool inside = (col < W) && (row < H);
+      pix[k] = inside ? row * W + col : -1;
+      result[k] = 0.0f;
+      active[k] = false;
+      t[k] = 0.0f; t_far[k] = 0.0f; dgx[k] = dgy[k] = dgz[k] = 0.0f; ndz[k] = 0.0f;
+      // wave-uniform: does this wave's 8x8 patch touch the rectangle at all?
+      if (overlaps(rc, sx + wave * 8, sy, 8, 8)) {
+        const bool in_rect = inside && col >= rc.x0 && col < rc.x1 && row >= rc.y0 && row < rc.y1;
+        const V3 d = pixel_ray(row, col, cx, cy, rfx, rfy);
+        const V3 dobj = rot_t(s, d);
+        // slab test in the object frame: the cube is axis-aligned there, its centre is at +e
+        // from the ray origin and f_i = dobj_i.  sdf_renderer_cuda.cu:156-194, branch-free.
+        float t_near = -1e-10f, tf = 1e10f;
+        bool miss = !in_rect;
+        const float dv[3] = {dobj.x, dobj.y, dobj.z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const float e = s.e[a], f = dv[a];
+          const bool big = fabsf(f) > 1e-20f;
+          const float inv = __builtin_amdgcn_rcpf(f);
+          const float ta = (e + scale) * inv, tb = (e - scale) * inv;
+          t_near = big ? fmaxf(t_near, fminf(ta, tb)) : t_near;
+          tf = big ? fminf(tf, fmaxf(ta, tb)) : tf;
+          miss = miss || (!big && (-e > scale || -e < -scale));
         }
+        miss = miss || (t_near > tf) || (tf < 0.0f);
+        t[k] = fmaxf(t_near, 0.0f);
+        t_far[k] = tf;
+        dgx[k] = dobj.x * kgrid; dgy[k] = dobj.y * kgrid; dgz[k] = dobj.z * kgrid;
+        ndz[k] = -d.z;
+        active[k] = !miss && (t[k] < tf);
+        any = any || active[k];
       }
     }
-    if (inside) img[(size_t)row * W + col] = result;
+    int n = 0;
+    while (any) {
+      Cell c[K];
+      // issue every ray's record loads before touching any of the data; a finished ray is
+      // parked on its last (valid) point and its result is ignored
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        gather_cell<RT, PACKED>(vol, R, fmaf(t[k], dgx[k], ogx), fmaf(t[k], dgy[k], ogy),
+                                fmaf(t[k], dgz[k], ogz), c[k]);
+      ++n;
+      any = false;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float dist = trilerp(c[k]) * scale;
+        const bool hit = active[k] && (dist < threshold * t[k]);
+        result[k] = hit ? t[k] * ndz[k] : result[k];
+        const float tn = t[k] + dist;
+        const bool go_on = active[k] && !hit && (tn < t_far[k]) && (n < SDFR_MAX_MARCH_STEPS);
+        t[k] = go_on ? tn : t[k];
+        active[k] = go_on;
+        any = any || go_on;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (pix[k] >= 0) img[pix[k]] = result[k];
   }
 }
 
@@ -286,13 +332,23 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // LDS hash of 8-voxel runs (32 bytes of the gradient volume): key = linear voxel index >> 3.
-constexpr int kRunSlots = 1024;
+//
+// Sums are kept in 64-bit FIXED POINT, not float: on gfx950 ds_add_f32 executes one lane at a
+// time (~185 cycles per wave-instruction even without conflicts, measured), ds_add_u64 takes ~8.
+// Every contribution of a macro-tile is bounded by M = max|grad_depth| * scale over its hit
+// pixels (trilinear weights <= 1, |d.z| <= 1), a voxel receives at most 2048 pixels x 8 corners of
+// them, so with 2^-e >= M the integers round(c * 2^(44-e)) sum to less than 2^58 in magnitude.
+// The scale is a power of two (exact in float), every float contribution is represented exactly
+// (24 significant bits), and integer addition is associative: a macro-tile's sums are exact and
+// independent of the order in which its lanes arrive.
+constexpr int kRunSlots = 512;
 constexpr int kRunLen = 8;
+constexpr int kFixedBits = 44;
 
 __device__ __forceinline__ int run_slot(int* keys, int key) {
-  unsigned h = ((unsigned)key * 2654435761u) >> 22;  // 10 bits
+  unsigned h = ((unsigned)key * 2654435761u) >> 23;  // 9 bits
 #pragma unroll 1
-  for (int probe = 0; probe < 24; ++probe) {
+  for (int probe = 0; probe < 32; ++probe) {
     const int old = atomicCAS(&keys[h], -1, key);
     if (old == -1 || old == key) return (int)h;
     h = (h + 1) & (kRunSlots - 1);
@@ -300,14 +356,24 @@ __device__ __forceinline__ int run_slot(int* keys, int key) {
   return -1;
 }
 
-// add (w_lo, w_hi) to voxels lin, lin+1 (a z-pair) of the gradient volume through the hash
-__device__ __forceinline__ void add_zpair(int* keys, float* vals, float* __restrict__ gvol, int lin,
-                                          float w_lo, float w_hi) {
+// add (w_lo, w_hi) to voxels lin, lin+1 (a z-pair) of the gradient volume through the hash.
+// to_fixed: power-of-two factor into the fixed-point domain.
+__device__ __forceinline__ void add_zpair(int* keys, unsigned long long* vals,
+                                          float* __restrict__ gvol, int lin, float w_lo, float w_hi,
+                                          float to_fixed) {
   const int k0 = lin >> 3, k1 = (lin + 1) >> 3;
   const int s0 = run_slot(keys, k0);
-  if (s0 >= 0) atomicAdd(&vals[s0 * kRunLen + (lin & 7)], w_lo); else atomicAdd(gvol + lin, w_lo);
+  if (s0 >= 0) atomicAdd(&vals[s0 * kRunLen + (lin & 7)], (unsigned long long)(long long)(w_lo * to_fixed));
+  else atomicAdd(gvol + lin, w_lo);
   const int s1 = (k1 == k0) ? s0 : run_slot(keys, k1);
-  if (s1 >= 0) atomicAdd(&vals[s1 * kRunLen + ((lin + 1) & 7)], w_hi); else atomicAdd(gvol + lin + 1, w_hi);
+  if (s1 >= 0) atomicAdd(&vals[s1 * kRunLen + ((lin + 1) & 7)], (unsigned long long)(long long)(w_hi * to_fixed));
+  else atomicAdd(gvol + lin + 1, w_hi);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
 }
 
 template <int RT>
@@ -317,9 +383,10 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx, float rfy,
     int sdf_grad_mode, float* __restrict__ g_sdf, long long g_sdf_view_stride,
     float* __restrict__ partials) {
+  __shared__ unsigned long long run_val[kRunSlots * kRunLen];
   __shared__ int run_key[kRunSlots];
-  __shared__ float run_val[kRunSlots * kRunLen];
   __shared__ float wave_part[4][8];
+  __shared__ int tile_max_bits;
 
   const int Rr = RT > 0 ? RT : R;
   const int b = blockIdx.z;
@@ -333,37 +400,58 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
   const float* gimg = grad_depth + (size_t)b * H * W;
   float* part = partials + ((size_t)b * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
 
-  // all depth reads of the macro-tile up front (independent loads)
-  float zs[kSubs];
+  // all depth reads of the macro-tile up front (independent loads), then the upstream
+  // gradient of the hit pixels only
+  float zs[kSubs], gos[kSubs];
   bool any_hit = false;
 #pragma unroll
   for (int sub = 0; sub < kSubs; ++sub) {
-    const int col = px0 + (sub & 1) * kSubW + wave * 8 + (lane & 7);
-    const int row = py0 + (sub >> 1) * kSubH + (lane >> 3);
+    const int col = px0 + (sub & 1) * kSubW + wave * 8 + patch_x(lane);
+    const int row = py0 + (sub >> 1) * kSubH + patch_y(lane);
     zs[sub] = (col < W && row < H) ? zimg[(size_t)row * W + col] : 0.0f;
-    any_hit = any_hit || (zs[sub] != 0.0f);
+  }
+  float gmax = 0.0f;
+#pragma unroll
+  for (int sub = 0; sub < kSubs; ++sub) {
+    const int col = px0 + (sub & 1) * kSubW + wave * 8 + patch_x(lane);
+    const int row = py0 + (sub >> 1) * kSubH + patch_y(lane);
+    const bool hit = zs[sub] != 0.0f;
+    gos[sub] = hit ? gimg[(size_t)row * W + col] : 0.0f;
+    gmax = fmaxf(gmax, fabsf(gos[sub]));
+    any_hit = any_hit || hit;
   }
   if (!__syncthreads_or(any_hit)) {
     if (tid < 8) part[tid] = 0.0f;
     return;
   }
   for (int i = tid; i < kRunSlots; i += kBlock) run_key[i] = -1;
-  for (int i = tid; i < kRunSlots * kRunLen; i += kBlock) run_val[i] = 0.0f;
+  for (int i = tid; i < kRunSlots * kRunLen; i += kBlock) run_val[i] = 0ull;
+  if (tid == 0) tile_max_bits = 0;
+  __syncthreads();
+  gmax = wave_max(gmax);
+  if (lane == 0) atomicMax(&tile_max_bits, __float_as_int(gmax));  // non-negative floats order as ints
   __syncthreads();
 
   const float* vol = sdf + (size_t)b * sdf_view_stride;
   float* gvol = g_sdf + (size_t)b * g_sdf_view_stride;
   const float h = 0.5f * (float)(Rr - 1);
   const float scale = s.scale, isc = s.isc;
+  // fixed-point scale: 2^(kFixedBits - e) with 2^e >= 2 * max|go| * scale  (power of two)
+  const float bound = 2.0f * __int_as_float(tile_max_bits) * fabsf(scale);
+  int e2;
+  (void)frexpf(bound, &e2);  // bound = m * 2^e2, m in [0.5, 1)  ->  2^e2 > bound
+  const bool fixed_ok = (bound > 0.0f) && (bound < 1e30f) && (e2 > -80);
+  const float to_fixed = fixed_ok ? ldexpf(1.0f, kFixedBits - e2) : 0.0f;
+  const float from_fixed = fixed_ok ? ldexpf(1.0f, e2 - kFixedBits) : 0.0f;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
-#pragma unroll 1
+#pragma unroll
   for (int sub = 0; sub < kSubs; ++sub) {
     const float z = zs[sub];
     if (z == 0.0f) continue;
-    const int col = px0 + (sub & 1) * kSubW + wave * 8 + (lane & 7);
-    const int row = py0 + (sub >> 1) * kSubH + (lane >> 3);
-    const float go = gimg[(size_t)row * W + col];
+    const int col = px0 + (sub & 1) * kSubW + wave * 8 + patch_x(lane);
+    const int row = py0 + (sub >> 1) * kSubH + patch_y(lane);
+    const float go = gos[sub];
     const V3 d = pixel_ray(row, col, cx, cy, rfx, rfy);
     const V3 dobj = rot_t(s, d);
     const float t = z * __builtin_amdgcn_rcpf(-d.z);  // -z / d.z   (cu:339)
@@ -415,10 +503,23 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
       w0 = x0w * ay * c.oz; w1 = x0w * c.oy * az;   w2 = x0w * c.oy * c.oz; w3 = x1w * ay * az;
       w4 = x1w * ay * c.oz; w5 = x1w * ay * c.oz;   w6 = x1w * c.oy * az;   w7 = x1w * c.oy * c.oz;
     }
-    add_zpair(run_key, run_val, gvol, c.lin, w0, w1);
-    add_zpair(run_key, run_val, gvol, c.lin + Rr, w2, w3);
-    add_zpair(run_key, run_val, gvol, c.lin + Rr * Rr, w4, w5);
-    add_zpair(run_key, run_val, gvol, c.lin + Rr * Rr + Rr, w6, w7);
+    // Outside [0,1] cell coordinates (extrapolation) a weight can exceed the bound the fixed-
+    // point scale assumes; such a pixel (never the case for a hit inside the volume) and the
+    // degenerate-scale case go straight to global float atomics.
+    const float wmax = fmaxf(fmaxf(fmaxf(fabsf(w0), fabsf(w1)), fmaxf(fabsf(w2), fabsf(w3))),
+                             fmaxf(fmaxf(fabsf(w4), fabsf(w5)), fmaxf(fabsf(w6), fabsf(w7))));
+    if (fixed_ok && wmax * to_fixed < 3.5e13f /* 2^45 */) {
+      add_zpair(run_key, run_val, gvol, c.lin, w0, w1, to_fixed);
+      add_zpair(run_key, run_val, gvol, c.lin + Rr, w2, w3, to_fixed);
+      add_zpair(run_key, run_val, gvol, c.lin + Rr * Rr, w4, w5, to_fixed);
+      add_zpair(run_key, run_val, gvol, c.lin + Rr * Rr + Rr, w6, w7, to_fixed);
+    } else {
+      float* g0 = gvol + c.lin;
+      atomicAdd(g0, w0);                atomicAdd(g0 + 1, w1);
+      atomicAdd(g0 + Rr, w2);           atomicAdd(g0 + Rr + 1, w3);
+      atomicAdd(g0 + Rr * Rr, w4);      atomicAdd(g0 + Rr * Rr + 1, w5);
+      atomicAdd(g0 + Rr * Rr + Rr, w6); atomicAdd(g0 + Rr * Rr + Rr + 1, w7);
+    }
   }
 
   // pose sums: registers -> wave shuffle -> LDS -> macro-tile partial
@@ -434,9 +535,9 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
   const int nvox = Rr * Rr * Rr;
   for (int i = tid; i < kRunSlots * kRunLen; i += kBlock) {
     const int key = run_key[i >> 3];
-    const float val = run_val[i];
+    const long long q = (long long)run_val[i];
     const int lin = key * kRunLen + (i & 7);
-    if (key >= 0 && val != 0.0f && lin < nvox) atomicAdd(gvol + lin, val);
+    if (key >= 0 && q != 0 && lin < nvox) atomicAdd(gvol + lin, (float)q * from_fixed);
   }
 }
 
@@ -547,9 +648,11 @@ extern "C" int sdfr_render_forward(const float* sdf, int R, long long sdf_view_s
   const dim3 grid((unsigned)tiles_x(W), (unsigned)tiles_y(H), (unsigned)B);
   const float rfx = (float)(1.0 / (double)fx), rfy = (float)(1.0 / (double)fy);
   const int vec_ok = (W % 4 == 0) && ((uintptr_t)depth % 16 == 0);
+  const char* lds_env = getenv("SDFR_DEBUG_FWD_LDS");  // experiment knob: caps workgroups per CU
+  const unsigned dyn_lds = lds_env ? (unsigned)atoi(lds_env) : 0u;
 #define SDFR_LAUNCH_FWD(RT, PK, SRC, STRIDE)                                                         \
-  hipLaunchKernelGGL((render_forward_kernel<RT, PK>), grid, dim3(kBlock), 0, st, SRC, R, STRIDE,     \
-                     setup, W, H, cx, cy, rfx, rfy, threshold, vec_ok, depth)
+  hipLaunchKernelGGL((render_forward_kernel<RT, PK, SDFR_RAYS_PER_LANE>), grid, dim3(kBlock), dyn_lds, st, \
+                     SRC, R, STRIDE, setup, W, H, cx, cy, rfx, rfy, threshold, vec_ok, depth)
   if (packed) {
     if (R == 64) SDFR_LAUNCH_FWD(64, true, cells, 0LL); else SDFR_LAUNCH_FWD(0, true, cells, 0LL);
   } else {
