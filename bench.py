@@ -97,18 +97,26 @@ def cpu_baseline(sdf, poses, W, H, thr, sample):
     lib = ctypes.CDLL(os.path.join(here, "libsdfr_oracle_native.so"))
     pos, quat, isc = (np.ascontiguousarray(a[:sample], dtype=np.float32) for a in poses)
     sdf = np.ascontiguousarray(sdf, dtype=np.float32)
-    ncpu = os.cpu_count() or 1
-    v_all, reps_all = _time_oracle(lib, sdf, pos, quat, isc, W, H, thr, ncpu, 15.0)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    # OpenMP scaling on a shared many-core host is far from linear: try a few thread counts on
+    # the same sample and report the best, with the count that achieved it.
     n1 = min(16, pos.shape[0])
     v_one, _ = _time_oracle(lib, sdf, pos[:n1].copy(), quat[:n1].copy(), isc[:n1].copy(), W, H, thr,
-                            1, 4.0)
-    use_all = v_all >= v_one
-    return {"value": round(v_all if use_all else v_one, 2), "unit": "renders/s",
-            "cores": ncpu if use_all else 1, "kind": "port",
+                            1, 3.0)
+    sweep = {1: v_one}
+    reps = {}
+    for threads in sorted({t for t in (8, 32, 64, 128, ncpu) if 1 < t <= ncpu}):
+        sweep[threads], reps[threads] = _time_oracle(lib, sdf, pos, quat, isc, W, H, thr, threads, 6.0)
+    best = max(sweep, key=lambda k: sweep[k])
+    return {"value": round(sweep[best], 2), "unit": "renders/s", "cores": best, "kind": "port",
             "sample": f"{pos.shape[0]} views of the same workload (first poses of the seeded list), "
-                      f"fwd+bwd x{reps_all}, oracle built as libsdfr_oracle_native.so "
-                      f"(gcc -O3 -march=native -fopenmp); host has {ncpu} logical cores",
-            "value_1thread": round(v_one, 2), "value_allthreads": round(v_all, 2)}
+                      f"fwd+bwd, x{reps.get(best, 1)} repeats; oracle built as libsdfr_oracle_native.so "
+                      f"(gcc -O3 -march=native -fopenmp); host offers {ncpu} logical cores; "
+                      f"thread sweep renders/s: " + ", ".join(f"{k}:{v:.0f}" for k, v in sorted(sweep.items())),
+            "value_1thread": round(v_one, 2)}
 
 
 def load_traffic():

@@ -50,13 +50,32 @@ struct alignas(128) ViewSetup {
 };
 static_assert(sizeof(ViewSetup) == 128, "ViewSetup must stay 128 bytes");
 
-// A workgroup (4 waves) owns a 64 x 32 pixel macro-tile and walks its eight 32 x 8 sub-tiles;
-// inside a sub-tile each wave is an 8 x 8 pixel patch.
-constexpr int kTileW = 64;
-constexpr int kTileH = 32;
+// A workgroup (4 waves) owns a tile of SX x SY sub-tiles of 32 x 8 pixels and walks them; inside
+// a sub-tile each wave is an 8 x 8 pixel patch.  Two geometries are compiled: the 64 x 32
+// macro-tile (2 x 4 sub-tiles) for batches, and the single 32 x 8 sub-tile when a call has too
+// few macro-tiles to fill 256 CUs (single-view calls of the drop-in autograd path).
 constexpr int kSubW = 32;
 constexpr int kSubH = 8;
-constexpr int kSubs = (kTileW / kSubW) * (kTileH / kSubH);  // 8
+struct TileGeom {
+  int sx, sy;  // sub-tiles per tile
+  int w() const { return sx * kSubW; }
+  int h() const { return sy * kSubH; }
+  int nx(int W) const { return (W + w() - 1) / w(); }
+  int ny(int H) const { return (H + h() - 1) / h(); }
+};
+constexpr TileGeom kMacroTile{2, 4};
+constexpr TileGeom kSmallTile{1, 1};
+// Measured on MI355X (640x480, blobs scene): the forward is as fast or faster with small tiles
+// at every batch size (B=1: 14 vs 46 us, B=256: 303 vs 310 us), so it always uses them.  The
+// backward gains from macro-tiles only when there are enough of them (B=64: 128 vs 141 us with
+// small tiles, B=256: 421 vs 265 us): more LDS pre-summation per global atomic, fewer brick
+// initialisations.
+constexpr long long kBackwardMacroMinTiles = 16384;
+inline TileGeom forward_geom(int, int, int) { return kSmallTile; }
+inline TileGeom backward_geom(int B, int W, int H) {
+  return ((long long)B * kMacroTile.nx(W) * kMacroTile.ny(H) >= kBackwardMacroMinTiles) ? kMacroTile
+                                                                                         : kSmallTile;
+}
 
 // packed cell records are used for a grid shared by >= kPackedMinViews views, up to kPackedMaxR
 #ifndef SDFR_PACKED_MIN_VIEWS
@@ -65,7 +84,5 @@ constexpr int kSubs = (kTileW / kSubW) * (kTileH / kSubH);  // 8
 constexpr int kPackedMinViews = SDFR_PACKED_MIN_VIEWS;
 constexpr int kPackedMaxR = 128;
 
-inline int tiles_x(int W) { return (W + kTileW - 1) / kTileW; }
-inline int tiles_y(int H) { return (H + kTileH - 1) / kTileH; }
 
 }  // namespace sdfr

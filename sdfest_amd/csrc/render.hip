@@ -26,15 +26,12 @@
 //     flushed as 32-byte runs of global float atomics (one per touched voxel per macro-tile).
 #include "common.hpp"
 
-#include <cstdlib>
 
 namespace sdfr {
 namespace {
 
 constexpr int kBlock = 256;
-#ifndef SDFR_RAYS_PER_LANE
-#define SDFR_RAYS_PER_LANE 1
-#endif
+
 
 // ---------------------------------------------------------------------------------------------
 // set-up: one thread per view
@@ -212,12 +209,13 @@ __device__ __forceinline__ bool overlaps(const Rect& r, int px, int py, int w, i
 // per lane a wave sits idle for a full cache round trip per step; K independent chains keep K
 // record loads in flight per lane.  All K rays start together, so the step number of every
 // active ray equals the iteration count `n` and one counter enforces SDFR_MAX_MARCH_STEPS.
-template <int RT, bool PACKED, int K>
+template <int RT, bool PACKED, int K, int SX, int SY>
 __global__ __launch_bounds__(kBlock) void render_forward_kernel(
     const float* __restrict__ src, int R, long long src_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx, float rfy,
     float threshold, int vec_ok, float* __restrict__ depth) {
-  static_assert(kSubs % K == 0, "K must divide the sub-tiles of a macro-tile");
+  constexpr int kSubs = SX * SY, kTileW = SX * kSubW, kTileH = SY * kSubH;
+  static_assert(kSubs % K == 0, "K must divide the sub-tiles of a tile");
   const int b = blockIdx.z;
   const int px0 = blockIdx.x * kTileW, py0 = blockIdx.y * kTileH;
   const ViewSetup& s = setup[b];
@@ -226,16 +224,17 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
   const int tid = threadIdx.x;
 
   if (!overlaps(rc, px0, py0, kTileW, kTileH)) {
-    // nothing of the cube projects here: stream zeros
+    // nothing of the cube projects here: stream zeros.  (Non-temporal stores were measured: same
+    // time, +28 % WRITE_SIZE -- partial lines no longer combine in L2.)
     if (vec_ok) {
 #pragma unroll
       for (int i = tid; i < kTileW * kTileH / 4; i += kBlock) {
-        const int row = py0 + (i >> 4), col = px0 + (i & 15) * 4;
+        const int row = py0 + i / (kTileW / 4), col = px0 + (i % (kTileW / 4)) * 4;
         if (row < H && col < W) *reinterpret_cast<float4*>(img + (size_t)row * W + col) = make_float4(0, 0, 0, 0);
       }
     } else {
       for (int i = tid; i < kTileW * kTileH; i += kBlock) {
-        const int row = py0 + (i >> 6), col = px0 + (i & 63);
+        const int row = py0 + i / kTileW, col = px0 + i % kTileW;
         if (row < H && col < W) img[(size_t)row * W + col] = 0.0f;
       }
     }
@@ -257,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int sub = grp + k;
-      const int sx = px0 + (sub & 1) * kSubW, sy = py0 + (sub >> 1) * kSubH;
+      const int sx = px0 + (sub % SX) * kSubW, sy = py0 + (sub / SX) * kSubH;
       const int col = sx + wave * 8 + patch_x(lane), row = sy + patch_y(lane);
       const bool inside = (col < W) && (row < H);
       pix[k] = inside ? row * W + col : -1;
@@ -376,7 +375,7 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-template <int RT>
+template <int RT, int SX, int SY>
 __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     const float* __restrict__ grad_depth, const float* __restrict__ depth,
     const float* __restrict__ sdf, int R, long long sdf_view_stride,
@@ -388,6 +387,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
   __shared__ float wave_part[4][8];
   __shared__ int tile_max_bits;
 
+  constexpr int kSubs = SX * SY, kTileW = SX * kSubW, kTileH = SY * kSubH;
   const int Rr = RT > 0 ? RT : R;
   const int b = blockIdx.z;
   const int px0 = blockIdx.x * kTileW, py0 = blockIdx.y * kTileH;
@@ -406,15 +406,15 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
   bool any_hit = false;
 #pragma unroll
   for (int sub = 0; sub < kSubs; ++sub) {
-    const int col = px0 + (sub & 1) * kSubW + wave * 8 + patch_x(lane);
-    const int row = py0 + (sub >> 1) * kSubH + patch_y(lane);
+    const int col = px0 + (sub % SX) * kSubW + wave * 8 + patch_x(lane);
+    const int row = py0 + (sub / SX) * kSubH + patch_y(lane);
     zs[sub] = (col < W && row < H) ? zimg[(size_t)row * W + col] : 0.0f;
   }
   float gmax = 0.0f;
 #pragma unroll
   for (int sub = 0; sub < kSubs; ++sub) {
-    const int col = px0 + (sub & 1) * kSubW + wave * 8 + patch_x(lane);
-    const int row = py0 + (sub >> 1) * kSubH + patch_y(lane);
+    const int col = px0 + (sub % SX) * kSubW + wave * 8 + patch_x(lane);
+    const int row = py0 + (sub / SX) * kSubH + patch_y(lane);
     const bool hit = zs[sub] != 0.0f;
     gos[sub] = hit ? gimg[(size_t)row * W + col] : 0.0f;
     gmax = fmaxf(gmax, fabsf(gos[sub]));
@@ -449,8 +449,8 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
   for (int sub = 0; sub < kSubs; ++sub) {
     const float z = zs[sub];
     if (z == 0.0f) continue;
-    const int col = px0 + (sub & 1) * kSubW + wave * 8 + patch_x(lane);
-    const int row = py0 + (sub >> 1) * kSubH + patch_y(lane);
+    const int col = px0 + (sub % SX) * kSubW + wave * 8 + patch_x(lane);
+    const int row = py0 + (sub / SX) * kSubH + patch_y(lane);
     const float go = gos[sub];
     const V3 d = pixel_ray(row, col, cx, cy, rfx, rfy);
     const V3 dobj = rot_t(s, d);
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
 // Fixed-order sum of a view's macro-tile partials: one wave per view.
 __global__ __launch_bounds__(64) void pose_reduce_kernel(const float* __restrict__ partials,
                                                          const ViewSetup* __restrict__ setup,
-                                                         int ntx, int nty,
+                                                         int ntx, int nty, int tile_w, int tile_h,
                                                          float* __restrict__ g_pos,
                                                          float* __restrict__ g_quat,
                                                          float* __restrict__ g_inv_scale) {
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(64) void pose_reduce_kernel(const float* __restrict
   const int x0 = s.rect[0], y0 = s.rect[1], x1 = s.rect[2], y1 = s.rect[3];
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (x1 > x0 && y1 > y0) {
-    const int tx0 = x0 / kTileW, tx1 = (x1 - 1) / kTileW, ty0 = y0 / kTileH, ty1 = (y1 - 1) / kTileH;
+    const int tx0 = x0 / tile_w, tx1 = (x1 - 1) / tile_w, ty0 = y0 / tile_h, ty1 = (y1 - 1) / tile_h;
     const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1);
     const float* base = partials + (size_t)b * ntx * nty * 8;
     for (int i = lane; i < n; i += 64) {
@@ -583,7 +583,7 @@ int check_common(int R, int B, int W, int H, float fx, float fy) {
   if (R < 2 || R > 1024) return fail(SDFR_E_INVALID, "R=%d out of range [2,1024]", R);
   if (B < 0 || W < 0 || H < 0) return fail(SDFR_E_INVALID, "negative size B=%d W=%d H=%d", B, W, H);
   if (B > 65535) return fail(SDFR_E_INVALID, "B=%d exceeds 65535 views per call", B);
-  if (tiles_y(H) > 65535) return fail(SDFR_E_INVALID, "H=%d too large", H);
+  if (kSmallTile.ny(H) > 65535) return fail(SDFR_E_INVALID, "H=%d too large", H);
   if ((long long)W * H * (long long)(B > 0 ? B : 1) > (1LL << 40))
     return fail(SDFR_E_INVALID, "image batch too large");
   if (!(fx != 0.0f) || !(fy != 0.0f)) return fail(SDFR_E_INVALID, "focal length must be non-zero");
@@ -614,7 +614,8 @@ extern "C" size_t sdfr_render_forward_workspace_bytes(int R, int B, int W, int H
 extern "C" size_t sdfr_render_backward_workspace_bytes(int R, int B, int W, int H) {
   (void)R;
   if (B <= 0 || W <= 0 || H <= 0) return setup_bytes(B);
-  return setup_bytes(B) + (size_t)B * tiles_x(W) * tiles_y(H) * 8 * sizeof(float);
+  // partial sums: one 32-byte record per tile of the finer geometry
+  return setup_bytes(B) + (size_t)B * kSmallTile.nx(W) * kSmallTile.ny(H) * 8 * sizeof(float);
 }
 
 extern "C" int sdfr_render_forward(const float* sdf, int R, long long sdf_view_stride,
@@ -645,20 +646,26 @@ extern "C" int sdfr_render_forward(const float* sdf, int R, long long sdf_view_s
     hipLaunchKernelGGL(pack_cells_kernel, dim3((n + 255) / 256), dim3(256), 0, st, sdf, R,
                        (float4*)cells);
   }
-  const dim3 grid((unsigned)tiles_x(W), (unsigned)tiles_y(H), (unsigned)B);
+  const TileGeom geom = forward_geom(B, W, H);
+  const bool macro = geom.sx == kMacroTile.sx;
+  const dim3 grid((unsigned)geom.nx(W), (unsigned)geom.ny(H), (unsigned)B);
   const float rfx = (float)(1.0 / (double)fx), rfy = (float)(1.0 / (double)fy);
   const int vec_ok = (W % 4 == 0) && ((uintptr_t)depth % 16 == 0);
-  const char* lds_env = getenv("SDFR_DEBUG_FWD_LDS");  // experiment knob: caps workgroups per CU
-  const unsigned dyn_lds = lds_env ? (unsigned)atoi(lds_env) : 0u;
+#define SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, SX, SY)                                               \
+  hipLaunchKernelGGL((render_forward_kernel<RT, PK, 1, SX, SY>), grid, dim3(kBlock), 0, st, SRC, R,  \
+                     STRIDE, setup, W, H, cx, cy, rfx, rfy, threshold, vec_ok, depth)
 #define SDFR_LAUNCH_FWD(RT, PK, SRC, STRIDE)                                                         \
-  hipLaunchKernelGGL((render_forward_kernel<RT, PK, SDFR_RAYS_PER_LANE>), grid, dim3(kBlock), dyn_lds, st, \
-                     SRC, R, STRIDE, setup, W, H, cx, cy, rfx, rfy, threshold, vec_ok, depth)
+  do {                                                                                               \
+    if (macro) SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, 2, 4);                                         \
+    else SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, 1, 1);                                               \
+  } while (0)
   if (packed) {
     if (R == 64) SDFR_LAUNCH_FWD(64, true, cells, 0LL); else SDFR_LAUNCH_FWD(0, true, cells, 0LL);
   } else {
     if (R == 64) SDFR_LAUNCH_FWD(64, false, sdf, sdf_view_stride); else SDFR_LAUNCH_FWD(0, false, sdf, sdf_view_stride);
   }
 #undef SDFR_LAUNCH_FWD
+#undef SDFR_LAUNCH_FWD_G
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -703,19 +710,23 @@ extern "C" int sdfr_render_backward(const float* grad_depth, const float* depth,
   float* partials = (float*)((char*)workspace + setup_bytes(B));
   hipLaunchKernelGGL(view_setup_kernel, dim3((B + 63) / 64), dim3(64), 0, st, pos, quat, inv_scale,
                      B, R, W, H, cx, cy, fx, fy, setup);
-  const int ntx = tiles_x(W), nty = tiles_y(H);
+  const TileGeom geom = backward_geom(B, W, H);
+  const bool macro = geom.sx == kMacroTile.sx;
+  const int ntx = geom.nx(W), nty = geom.ny(H);
   const dim3 grid((unsigned)ntx, (unsigned)nty, (unsigned)B);
   const float rfx = (float)(1.0 / (double)fx), rfy = (float)(1.0 / (double)fy);
-  if (R == 64)
-    hipLaunchKernelGGL(render_backward_kernel<64>, grid, dim3(kBlock), 0, st, grad_depth, depth, sdf,
-                       R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf,
-                       g_sdf_view_stride, partials);
-  else
-    hipLaunchKernelGGL(render_backward_kernel<0>, grid, dim3(kBlock), 0, st, grad_depth, depth, sdf,
-                       R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf,
-                       g_sdf_view_stride, partials);
-  hipLaunchKernelGGL(pose_reduce_kernel, dim3(B), dim3(64), 0, st, partials, setup, ntx, nty, g_pos,
-                     g_quat, g_inv_scale);
+#define SDFR_LAUNCH_BWD(RT, SX, SY)                                                                  \
+  hipLaunchKernelGGL((render_backward_kernel<RT, SX, SY>), grid, dim3(kBlock), 0, st, grad_depth,    \
+                     depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode,   \
+                     g_sdf, g_sdf_view_stride, partials)
+  if (R == 64) {
+    if (macro) SDFR_LAUNCH_BWD(64, 2, 4); else SDFR_LAUNCH_BWD(64, 1, 1);
+  } else {
+    if (macro) SDFR_LAUNCH_BWD(0, 2, 4); else SDFR_LAUNCH_BWD(0, 1, 1);
+  }
+#undef SDFR_LAUNCH_BWD
+  hipLaunchKernelGGL(pose_reduce_kernel, dim3(B), dim3(64), 0, st, partials, setup, ntx, nty,
+                     geom.w(), geom.h(), g_pos, g_quat, g_inv_scale);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }
