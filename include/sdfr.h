@@ -103,6 +103,33 @@ SDFR_API int sdfr_render_backward(const float* grad_depth, const float* depth, c
                          float* g_inv_scale, void* workspace, size_t workspace_bytes, int device,
                          void* stream);
 
+/* ---- trilinear SDF sampler of the point-cloud loss --------------------------------------- */
+
+/* Replaces losses.pc_loss (sdfest/estimation/losses.py:32-135), for all views of a step at once.
+ *   points  [N][3]   camera-frame points; view v owns [offsets[v], offsets[v+1])
+ *   offsets [B+1]    DEVICE int array; NULL is allowed for B == 1 and means [0, max_view_points)
+ *   max_view_points  host-side upper bound of the longest segment (sizes the grid)
+ *   pos [B][3], quat [B][4] (need not be normalised: the kernel normalises like the reference,
+ *   :58), scale [B] (half-width, NOT its inverse)
+ *   out     [N]      interpolated distance * scale, 0 for points outside the volume (:92-94,:134) */
+SDFR_API int sdfr_pc_loss_forward(const float* points, const int* offsets, int B, int max_view_points,
+                         const float* pos, const float* quat, const float* scale,
+                         const float* sdf, int R, long long sdf_view_stride, float* out,
+                         int device, void* stream);
+
+SDFR_API size_t sdfr_pc_loss_backward_workspace_bytes(int B, int max_view_points);
+
+/* VJP of the above for upstream grad_out[N]; equals torch autograd through losses.py:32-135
+ * (the q normalisation is differentiated through; outside points get no gradient).
+ * g_sdf is overwritten (stride 0: summed over the views; R^3: per view); g_pos [B][3],
+ * g_quat [B][4], g_scale [B] are overwritten, reduced in a fixed order. */
+SDFR_API int sdfr_pc_loss_backward(const float* grad_out, const float* points, const int* offsets, int B,
+                          int max_view_points, const float* pos, const float* quat,
+                          const float* scale, const float* sdf, int R, long long sdf_view_stride,
+                          float* g_sdf, long long g_sdf_view_stride, float* g_pos, float* g_quat,
+                          float* g_scale, void* workspace, size_t workspace_bytes, int device,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,4 +8,6 @@ from .differentiable_renderer import (BatchRenderPlan, Camera, SDFRendererFuncti
                                       render_depth_batch,
                                       render_depth_gpu)
 
-__all__ = ["BatchRenderPlan", "Camera", "SDFRendererFunctionGPU", "render_depth_gpu", "render_depth_batch"]
+from .losses import pc_loss, pc_loss_batch
+
+__all__ = ["pc_loss", "pc_loss_batch", "BatchRenderPlan", "Camera", "SDFRendererFunctionGPU", "render_depth_gpu", "render_depth_batch"]

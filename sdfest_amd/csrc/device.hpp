@@ -1,0 +1,143 @@
+// device.hpp -- device-side pieces shared by the render and sampler kernels (gfx950 only).
+#pragma once
+
+#include "common.hpp"
+
+namespace sdfr {
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// shared device pieces
+// ---------------------------------------------------------------------------------------------
+// unit ray through a pixel centre (camera frame, OpenGL).  sdf_renderer_cuda.cu:137-154.
+__device__ __forceinline__ V3 pixel_ray(int row, int col, float cx, float cy, float rfx, float rfy) {
+  const float dx = ((float)col + 0.5f - cx) * rfx;
+  const float dy = -((float)row + 0.5f - cy) * rfy;
+  const float inv_len = __builtin_amdgcn_rsqf(fmaf(dx, dx, fmaf(dy, dy, 1.0f)));
+  return mk(dx * inv_len, dy * inv_len, -inv_len);
+}
+
+__device__ __forceinline__ V3 rot_t(const ViewSetup& s, V3 v) {  // R^T v
+  return mk(fmaf(s.rot[0], v.x, fmaf(s.rot[3], v.y, s.rot[6] * v.z)),
+            fmaf(s.rot[1], v.x, fmaf(s.rot[4], v.y, s.rot[7] * v.z)),
+            fmaf(s.rot[2], v.x, fmaf(s.rot[5], v.y, s.rot[8] * v.z)));
+}
+__device__ __forceinline__ V3 rot_f(const ViewSetup& s, V3 v) {  // R v
+  return mk(fmaf(s.rot[0], v.x, fmaf(s.rot[1], v.y, s.rot[2] * v.z)),
+            fmaf(s.rot[3], v.x, fmaf(s.rot[4], v.y, s.rot[5] * v.z)),
+            fmaf(s.rot[6], v.x, fmaf(s.rot[7], v.y, s.rot[8] * v.z)));
+}
+
+// z-adjacent corner pair: 8-byte load at 4-byte alignment (global memory allows it)
+struct __attribute__((packed, aligned(4))) ZPair {
+  float lo, hi;
+};
+
+struct Cell {
+  float v[8];  // corner values, index 4*ix + 2*iy + iz
+  float ox, oy, oz;
+  int lin;  // linear index of corner 000
+};
+
+// Locate the cell of a grid-space point and fetch its 8 corners.  Same cell choice and the
+// same un-clamped (extrapolating) cell coordinate as sdf_renderer_cuda.cu:196-239.
+// PACKED: `src` is the cell-record array (two 16-byte loads); else the plain grid (4 z-pair loads).
+template <int RT, bool PACKED>
+__device__ __forceinline__ void gather_cell(const float* __restrict__ src, int R, float gx,
+                                            float gy, float gz, Cell& c) {
+  const int Rr = RT > 0 ? RT : R;
+  const float top = (float)(Rr - 2);
+  const float bx = fminf(fmaxf(floorf(gx), 0.0f), top);
+  const float by = fminf(fmaxf(floorf(gy), 0.0f), top);
+  const float bz = fminf(fmaxf(floorf(gz), 0.0f), top);
+  c.ox = gx - bx; c.oy = gy - by; c.oz = gz - bz;
+  const int lin = ((int)bx * Rr + (int)by) * Rr + (int)bz;
+  c.lin = lin;
+  if (PACKED) {
+    const float4* rec = reinterpret_cast<const float4*>(src) + 2 * (size_t)(unsigned)lin;
+    const float4 a = rec[0], b = rec[1];
+    c.v[0] = a.x; c.v[1] = a.y; c.v[2] = a.z; c.v[3] = a.w;
+    c.v[4] = b.x; c.v[5] = b.y; c.v[6] = b.z; c.v[7] = b.w;
+  } else {
+    const float* base = src + lin;
+    const ZPair p00 = *reinterpret_cast<const ZPair*>(base);
+    const ZPair p01 = *reinterpret_cast<const ZPair*>(base + Rr);
+    const ZPair p10 = *reinterpret_cast<const ZPair*>(base + Rr * Rr);
+    const ZPair p11 = *reinterpret_cast<const ZPair*>(base + Rr * Rr + Rr);
+    c.v[0] = p00.lo; c.v[1] = p00.hi; c.v[2] = p01.lo; c.v[3] = p01.hi;
+    c.v[4] = p10.lo; c.v[5] = p10.hi; c.v[6] = p11.lo; c.v[7] = p11.hi;
+  }
+}
+
+// trilinear value, lerp order x, y, z (sdf_renderer_cuda.cu:231-238)
+__device__ __forceinline__ float trilerp(const Cell& c) {
+  const float ax = 1.0f - c.ox, ay = 1.0f - c.oy, az = 1.0f - c.oz;
+  const float c00 = fmaf(c.v[4], c.ox, c.v[0] * ax);
+  const float c01 = fmaf(c.v[5], c.ox, c.v[1] * ax);
+  const float c10 = fmaf(c.v[6], c.ox, c.v[2] * ax);
+  const float c11 = fmaf(c.v[7], c.ox, c.v[3] * ax);
+  const float c0 = fmaf(c10, c.oy, c00 * ay);
+  const float c1 = fmaf(c11, c.oy, c01 * ay);
+  return fmaf(c1, c.oz, c0 * az);
+}
+
+// lane -> pixel of the wave's 8x8 patch, in Morton order: 4 consecutive lanes are a 2x2 pixel
+// block, 16 lanes a 4x4 block.  The texture-address unit handles a 16-byte-per-lane load four
+// lanes at a time; four lanes that sit in one 2x2 block mostly hit one record (one cache line).
+__device__ __forceinline__ int patch_x(int lane) { return (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4); }
+__device__ __forceinline__ int patch_y(int lane) { return ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// LDS hash of 8-voxel runs (32 bytes of the gradient volume): key = linear voxel index >> 3.
+//
+// Sums are kept in 64-bit FIXED POINT, not float: on gfx950 ds_add_f32 executes one lane at a
+// time (~185 cycles per wave-instruction even without conflicts, measured), ds_add_u64 takes ~8.
+// Every contribution of a macro-tile is bounded by M = max|grad_depth| * scale over its hit
+// pixels (trilinear weights <= 1, |d.z| <= 1), a voxel receives at most 2048 pixels x 8 corners of
+// them, so with 2^-e >= M the integers round(c * 2^(44-e)) sum to less than 2^58 in magnitude.
+// The scale is a power of two (exact in float), every float contribution is represented exactly
+// (24 significant bits), and integer addition is associative: a macro-tile's sums are exact and
+// independent of the order in which its lanes arrive.
+constexpr int kRunSlots = 512;
+constexpr int kRunLen = 8;
+constexpr int kFixedBits = 44;
+
+__device__ __forceinline__ int run_slot(int* keys, int key) {
+  unsigned h = ((unsigned)key * 2654435761u) >> 23;  // 9 bits
+#pragma unroll 1
+  for (int probe = 0; probe < 32; ++probe) {
+    const int old = atomicCAS(&keys[h], -1, key);
+    if (old == -1 || old == key) return (int)h;
+    h = (h + 1) & (kRunSlots - 1);
+  }
+  return -1;
+}
+
+// add (w_lo, w_hi) to voxels lin, lin+1 (a z-pair) of the gradient volume through the hash.
+// to_fixed: power-of-two factor into the fixed-point domain.
+__device__ __forceinline__ void add_zpair(int* keys, unsigned long long* vals,
+                                          float* __restrict__ gvol, int lin, float w_lo, float w_hi,
+                                          float to_fixed) {
+  const int k0 = lin >> 3, k1 = (lin + 1) >> 3;
+  const int s0 = run_slot(keys, k0);
+  if (s0 >= 0) atomicAdd(&vals[s0 * kRunLen + (lin & 7)], (unsigned long long)(long long)(w_lo * to_fixed));
+  else atomicAdd(gvol + lin, w_lo);
+  const int s1 = (k1 == k0) ? s0 : run_slot(keys, k1);
+  if (s1 >= 0) atomicAdd(&vals[s1 * kRunLen + ((lin + 1) & 7)], (unsigned long long)(long long)(w_hi * to_fixed));
+  else atomicAdd(gvol + lin + 1, w_hi);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+
+}  // namespace
+}  // namespace sdfr
