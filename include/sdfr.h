@@ -130,6 +130,28 @@ SDFR_API int sdfr_pc_loss_backward(const float* grad_out, const float* points, c
                           float* g_scale, void* workspace, size_t workspace_bytes, int device,
                           void* stream);
 
+/* ---- VAE decoder forward ------------------------------------------------------------------ */
+
+/* Replaces SDFDecoder.forward / SDFVAE.decode (sdfest/vae/sdf_vae.py:217-259, :79-87).
+ * The handle owns a device copy of the weights (re-laid-out for the kernels); creation is the
+ * only call of this library that allocates device memory and synchronises.
+ *   h_params   HOST pointer: the decoder's tensors flattened in state_dict order
+ *              (decoder._fc_layers.{i}.weight [out][in], .bias, ..., decoder._conv_layers.{i}
+ *              .weight [cout][cin][k][k][k], .bias)
+ *   the five conv_* arrays and fc_out are the yaml's decoder.conv_layers / fc_layers entries
+ *   volume     sdf_size (64); tsdf: truncation value or 0 for "False" */
+typedef struct sdfr_decoder sdfr_decoder;
+SDFR_API int sdfr_decoder_create(const float* h_params, size_t n_params, int latent, int n_fc,
+                        const int* fc_out, int n_conv, const int* conv_in_size,
+                        const int* conv_cin, const int* conv_cout, const int* conv_k,
+                        const int* conv_relu, int volume, float tsdf, int device,
+                        sdfr_decoder** out_handle);
+SDFR_API void sdfr_decoder_destroy(sdfr_decoder* decoder);
+SDFR_API size_t sdfr_decoder_workspace_bytes(const sdfr_decoder* decoder, int N);
+/* z [N][latent] -> out [N][volume^3] (the reference returns (N,1,D,D,D)); on the decoder's device */
+SDFR_API int sdfr_decoder_forward(const sdfr_decoder* decoder, const float* z, int N, int enforce_tsdf,
+                         float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,5 +9,6 @@ from .differentiable_renderer import (BatchRenderPlan, Camera, SDFRendererFuncti
                                       render_depth_gpu)
 
 from .losses import pc_loss, pc_loss_batch
+from .vae import SDFDecoder
 
-__all__ = ["pc_loss", "pc_loss_batch", "BatchRenderPlan", "Camera", "SDFRendererFunctionGPU", "render_depth_gpu", "render_depth_batch"]
+__all__ = ["SDFDecoder", "pc_loss", "pc_loss_batch", "BatchRenderPlan", "Camera", "SDFRendererFunctionGPU", "render_depth_gpu", "render_depth_batch"]

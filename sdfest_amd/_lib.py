@@ -34,6 +34,11 @@ SIGNATURES = {
     "sdfr_pc_loss_backward_workspace_bytes": (c_sz, [c_int, c_int]),
     "sdfr_pc_loss_backward": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_int,
                                       c_ll, c_fp, c_ll, c_fp, c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),
+    "sdfr_decoder_create": (c_int, [c_fp, c_sz, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_fp,
+                                    c_fp, c_int, c_f, c_int, c_fp]),
+    "sdfr_decoder_destroy": (None, [c_fp]),
+    "sdfr_decoder_workspace_bytes": (c_sz, [c_fp, c_int]),
+    "sdfr_decoder_forward": (c_int, [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_sz, c_fp]),
 }
 
 

@@ -1,0 +1,109 @@
+"""VAE decoder: host-side mirror of ``sdfest/vae/sdf_vae.py::SDFDecoder`` (:171-259).
+
+Built from the reference's own config dict (``decoder: {fc_layers, conv_layers}``,
+``latent_size``, ``tsdf``) and a state dict with the reference's parameter names
+(``decoder._fc_layers.{i}.weight`` ...).  ``forward`` / ``decode`` run in ``libsdfr_hip.so``
+(decoder.hip): one launch for the Linear stack, one MFMA launch per Conv3d, one per resize.
+"""
+import ctypes
+from typing import Mapping, Optional, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _flatten_state(state: Mapping, n_fc: int, n_conv: int, prefix: str) -> np.ndarray:
+    def get(name):
+        t = state[name]
+        if isinstance(t, torch.Tensor):
+            t = t.detach().cpu().numpy()
+        return np.asarray(t, dtype=np.float32).reshape(-1)
+
+    parts = []
+    for i in range(n_fc):
+        parts += [get(f"{prefix}_fc_layers.{i}.weight"), get(f"{prefix}_fc_layers.{i}.bias")]
+    for i in range(n_conv):
+        parts += [get(f"{prefix}_conv_layers.{i}.weight"), get(f"{prefix}_conv_layers.{i}.bias")]
+    return np.ascontiguousarray(np.concatenate(parts))
+
+
+class SDFDecoder:
+    """Decoder of the SDF VAE (reference: SDFDecoder.__init__ sdf_vae.py:171-205)."""
+
+    def __init__(self, volume_size: int, latent_size: int, fc_layers: list, conv_layers: list,
+                 tsdf: Optional[Union[bool, float]] = False, state_dict: Optional[Mapping] = None,
+                 device="cuda", prefix: str = "decoder."):
+        # reference: SDFDecoder.sanity_check (sdf_vae.py:207-215)
+        assert fc_layers[-1]["out"] == conv_layers[0]["in_channels"] * conv_layers[0]["in_size"] ** 3
+        for a, b in zip(conv_layers[:-1], conv_layers[1:]):
+            assert a["out_channels"] == b["in_channels"]
+        assert conv_layers[-1]["out_channels"] == 1
+        if state_dict is None:
+            raise ValueError("state_dict with the decoder parameters is required")
+        self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self._volume_size = volume_size
+        self.latent_size = latent_size
+        self._tsdf = tsdf
+        if not any(k.startswith(prefix) for k in state_dict):
+            prefix = ""
+        params = _flatten_state(state_dict, len(fc_layers), len(conv_layers), prefix)
+        arr = lambda v: np.ascontiguousarray(v, dtype=np.int32)
+        fc_out = arr([l["out"] for l in fc_layers])
+        ins = arr([l["in_size"] for l in conv_layers])
+        cin = arr([l["in_channels"] for l in conv_layers])
+        cout = arr([l["out_channels"] for l in conv_layers])
+        ks = arr([l["kernel_size"] for l in conv_layers])
+        relu = arr([1 if l["relu"] else 0 for l in conv_layers])
+        L = _lib.lib()
+        handle = ctypes.c_void_p()
+        P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        rc = L.sdfr_decoder_create(P(params), params.size, latent_size, len(fc_layers), P(fc_out),
+                                   len(conv_layers), P(ins), P(cin), P(cout), P(ks), P(relu),
+                                   volume_size, float(tsdf) if tsdf is not False else 0.0,
+                                   self.device.index, ctypes.byref(handle))
+        _lib.check(rc, "sdfr_decoder_create")
+        self._L, self._h = L, handle
+        self._ws = None
+
+    @classmethod
+    def from_config(cls, config: Mapping, state_dict: Mapping, device="cuda", sdf_size: int = 64):
+        """config: the reference's vae config (keys latent_size, decoder, tsdf)."""
+        return cls(sdf_size, config["latent_size"], config["decoder"]["fc_layers"],
+                   config["decoder"]["conv_layers"], config.get("tsdf", False), state_dict, device)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.sdfr_decoder_destroy(h)
+            self._h = None
+
+    def forward(self, z: torch.Tensor, enforce_tsdf: bool = False) -> torch.Tensor:
+        """z (N, latent_size) -> (N, 1, D, D, D), like SDFDecoder.forward (sdf_vae.py:217-259)."""
+        if not z.is_cuda or z.dtype != torch.float32:
+            raise RuntimeError("z must be a float32 CUDA tensor")
+        if z.dim() != 2 or z.shape[1] != self.latent_size:
+            raise RuntimeError(f"z must have shape (N, {self.latent_size})")
+        if z.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError(
+                "decoder backward (VJP to the latent) is not built yet: call under torch.no_grad()")
+        zc = z.detach().contiguous()
+        N, D = zc.shape[0], self._volume_size
+        out = torch.empty((N, 1, D, D, D), dtype=torch.float32, device=self.device)
+        need = self._L.sdfr_decoder_workspace_bytes(self._h, N)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        rc = self._L.sdfr_decoder_forward(self._h, zc.data_ptr(), N, int(bool(enforce_tsdf)),
+                                          out.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                                          torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(rc, "sdfr_decoder_forward")
+        return out
+
+    __call__ = forward
+
+    def decode(self, z: torch.Tensor, enforce_tsdf: bool = False) -> torch.Tensor:
+        """Same as SDFVAE.decode (sdf_vae.py:79-87)."""
+        return self.forward(z, enforce_tsdf)
