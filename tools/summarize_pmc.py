@@ -66,6 +66,14 @@ def main():
     os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
     open(os.path.join(root, "profiles", name + ".md"), "w").write("\n".join(lines) + "\n")
     json.dump(out, open(os.path.join(root, "profiles", name + ".json"), "w"), indent=1)
+    # what bench.py reports as roofline.traffic: HBM bytes per launch of the two image kernels
+    traffic = {"source": f"profiles/{name}.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; "
+                         "2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"}
+    for k, v in out.items():
+        if "hbm_bytes" in v:
+            traffic[k.split("<")[0]] = int(v["hbm_bytes"])
+    if len(traffic) > 1:
+        json.dump(traffic, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
     print("\n".join(lines))
 
 
