@@ -63,15 +63,27 @@ struct TileGeom {
   int nx(int W) const { return (W + w() - 1) / w(); }
   int ny(int H) const { return (H + h() - 1) / h(); }
 };
-constexpr TileGeom kMacroTile{2, 4};
+#ifndef SDFR_MACRO_SX
+#define SDFR_MACRO_SX 2
+#define SDFR_MACRO_SY 1
+#endif
+constexpr TileGeom kMacroTile{SDFR_MACRO_SX, SDFR_MACRO_SY};
 constexpr TileGeom kSmallTile{1, 1};
 // Measured on MI355X (640x480, blobs scene): the forward is as fast or faster with small tiles
 // at every batch size (B=1: 14 vs 46 us, B=256: 303 vs 310 us), so it always uses them.  The
 // backward gains from macro-tiles only when there are enough of them (B=64: 128 vs 141 us with
 // small tiles, B=256: 421 vs 265 us): more LDS pre-summation per global atomic, fewer brick
 // initialisations.
-constexpr long long kBackwardMacroMinTiles = 16384;
-inline TileGeom forward_geom(int, int, int) { return kSmallTile; }
+#ifndef SDFR_BWD_MACRO_MIN
+#define SDFR_BWD_MACRO_MIN 16384
+#endif
+constexpr long long kBackwardMacroMinTiles = SDFR_BWD_MACRO_MIN;
+#ifndef SDFR_FWD_MACRO_MIN
+#define SDFR_FWD_MACRO_MIN 16384
+#endif
+inline TileGeom forward_geom(int B, int W, int H) {
+  return ((long long)B * kMacroTile.nx(W) * kMacroTile.ny(H) >= SDFR_FWD_MACRO_MIN) ? kMacroTile : kSmallTile;
+}
 inline TileGeom backward_geom(int B, int W, int H) {
   return ((long long)B * kMacroTile.nx(W) * kMacroTile.ny(H) >= kBackwardMacroMinTiles) ? kMacroTile
                                                                                          : kSmallTile;

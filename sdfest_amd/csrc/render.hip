@@ -8,16 +8,17 @@
 //   * a set-up kernel turns each pose into a 128-byte record (rotation, object-frame camera
 //     position, grid-space ray origin, conservative screen rectangle of the bounding cube);
 //     the image kernels read it through the scalar cache instead of re-deriving it per pixel;
-//   * a workgroup owns a 64x32-pixel macro-tile (8 sub-tiles of 32x8, a wave = an 8x8 patch):
-//     macro-tiles outside the rectangle only stream float4 zeros (forward) or exit without
-//     touching memory (backward) -- in realistic scenes that is most of the frame -- and a
-//     256-view batch is 38k workgroups instead of 307k;
+//   * a workgroup owns a 64x8-pixel tile (2 sub-tiles of 32x8, a wave = an 8x8 patch; 32x8 for
+//     small batches): tiles outside the rectangle only stream float4 zeros (forward) or exit
+//     without touching memory (backward) -- in realistic scenes that is most of the frame.
+//     (A persistent grid walking the tile list with a stride was measured: 40 us less dispatch,
+//     but 100+ us more tail -- the hardware dispatcher balances the very uneven tiles better.)
 //   * the slab test and the march run in the object frame / in grid coordinates, so one step
 //     is 3 FMAs + floor/clamp instead of the reference's scale-normalise-index-denormalise chain;
 //   * the 64^3 grid (1 MiB) cannot live in the 160 KiB LDS and a per-corner gather costs ~28
 //     L1 tag look-ups per load instruction (measured: the L1, not HBM or the VALU, bounded v1),
-//     so a pre-pass re-packs the grid into 32-byte cell records (the 8 corners of a cell side by
-//     side): one march step is two 16-byte loads from one 32-byte-aligned record;
+//     so a pre-pass re-packs the grid into 16-byte face records (4 corners side by side): one
+//     march step is two 16-byte loads;
 //   * the 8 pose-gradient sums stay in registers across a macro-tile, then wave-shuffle -> LDS ->
 //     one 32-byte partial per macro-tile -> a fixed-order reduction kernel (bitwise
 //     reproducible); the reference issues 8 same-address float atomics per hit pixel
@@ -95,9 +96,11 @@ __global__ void view_setup_kernel(const float* __restrict__ pos, const float* __
 }
 
 // ---------------------------------------------------------------------------------------------
-// cell records: rec[lin] = the 8 corners of the cell whose corner 000 has linear index lin,
-// as two float4: (v000, v001, v010, v011), (v100, v101, v110, v111).  R^3 records (the last
-// layer along each axis is never addressed: cell indices are clamped to R-2).
+// face records: rec[lin] = the 4 corners of the cell face x = const whose corner 00 is voxel lin:
+// (v(x,y,z), v(x,y,z+1), v(x,y+1,z), v(x,y+1,z+1)) as one float4.  A cell is the two records
+// rec[lin] and rec[lin + R^2]: two 16-byte loads per march step instead of four 8-byte z-pair
+// loads.  R^3 records = 4 MiB at R = 64 (a full 32-byte cell record per voxel was measured too:
+// 8 MiB, 2.5 % slower -- it overflows the 4 MiB per-XCD L2).
 // ---------------------------------------------------------------------------------------------
 // (A 2x2x2-blocked record order was measured: +10 integer ops per step, no gain -- the march is
 // bound by dependent-load latency, not by lines per access.  Records stay in grid order.)
@@ -106,12 +109,10 @@ __global__ __launch_bounds__(256) void pack_cells_kernel(const float* __restrict
   const int lin = blockIdx.x * blockDim.x + threadIdx.x;
   const int RR = R * R;
   if (lin >= RR * R) return;
-  const int z = lin % R, y = (lin / R) % R, x = lin / RR;
-  if (x >= R - 1 || y >= R - 1 || z >= R - 1) return;
+  const int z = lin % R, y = (lin / R) % R;
+  if (y >= R - 1 || z >= R - 1) return;
   const float* p = sdf + lin;
-  const size_t rec = (size_t)lin;
-  cells[2 * rec] = make_float4(p[0], p[1], p[R], p[R + 1]);
-  cells[2 * rec + 1] = make_float4(p[RR], p[RR + 1], p[RR + R], p[RR + R + 1]);
+  cells[lin] = make_float4(p[0], p[1], p[R], p[R + 1]);
 }
 
 struct Rect {
@@ -378,10 +379,8 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     const float wmax = fmaxf(fmaxf(fmaxf(fabsf(w0), fabsf(w1)), fmaxf(fabsf(w2), fabsf(w3))),
                              fmaxf(fmaxf(fabsf(w4), fabsf(w5)), fmaxf(fabsf(w6), fabsf(w7))));
     if (fixed_ok && wmax * to_fixed < 3.5e13f /* 2^45 */) {
-      add_zpair(run_key, run_val, gvol, c.lin, w0, w1, to_fixed);
-      add_zpair(run_key, run_val, gvol, c.lin + Rr, w2, w3, to_fixed);
-      add_zpair(run_key, run_val, gvol, c.lin + Rr * Rr, w4, w5, to_fixed);
-      add_zpair(run_key, run_val, gvol, c.lin + Rr * Rr + Rr, w6, w7, to_fixed);
+      const float wk[8] = {w0, w1, w2, w3, w4, w5, w6, w7};
+      add_cell(run_key, run_val, gvol, c.lin, Rr, wk, to_fixed);
     } else {
       float* g0 = gvol + c.lin;
       atomicAdd(g0, w0);                atomicAdd(g0 + 1, w1);
@@ -466,7 +465,7 @@ size_t setup_bytes(int B) { return (size_t)(B > 0 ? B : 0) * sizeof(ViewSetup); 
 bool use_packed(int R, int B, long long sdf_view_stride) {
   return sdf_view_stride == 0 && B >= kPackedMinViews && R <= kPackedMaxR;
 }
-size_t packed_bytes(int R) { return (size_t)R * R * R * 8 * sizeof(float); }
+size_t packed_bytes(int R) { return (size_t)R * R * R * 4 * sizeof(float); }
 
 }  // namespace
 }  // namespace sdfr
@@ -525,7 +524,7 @@ extern "C" int sdfr_render_forward(const float* sdf, int R, long long sdf_view_s
                      STRIDE, setup, W, H, cx, cy, rfx, rfy, threshold, vec_ok, depth)
 #define SDFR_LAUNCH_FWD(RT, PK, SRC, STRIDE)                                                         \
   do {                                                                                               \
-    if (macro) SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, 2, 4);                                         \
+    if (macro) SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, SDFR_MACRO_SX, SDFR_MACRO_SY);                                         \
     else SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, 1, 1);                                               \
   } while (0)
   if (packed) {
@@ -589,9 +588,9 @@ extern "C" int sdfr_render_backward(const float* grad_depth, const float* depth,
                      depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode,   \
                      g_sdf, g_sdf_view_stride, partials)
   if (R == 64) {
-    if (macro) SDFR_LAUNCH_BWD(64, 2, 4); else SDFR_LAUNCH_BWD(64, 1, 1);
+    if (macro) SDFR_LAUNCH_BWD(64, SDFR_MACRO_SX, SDFR_MACRO_SY); else SDFR_LAUNCH_BWD(64, 1, 1);
   } else {
-    if (macro) SDFR_LAUNCH_BWD(0, 2, 4); else SDFR_LAUNCH_BWD(0, 1, 1);
+    if (macro) SDFR_LAUNCH_BWD(0, SDFR_MACRO_SX, SDFR_MACRO_SY); else SDFR_LAUNCH_BWD(0, 1, 1);
   }
 #undef SDFR_LAUNCH_BWD
   hipLaunchKernelGGL(pose_reduce_kernel, dim3(B), dim3(64), 0, st, partials, setup, ntx, nty,

@@ -169,10 +169,8 @@ __global__ __launch_bounds__(kPts) void pc_loss_backward_kernel(
     const float w0 = x0w * ay * az, w1 = x0w * ay * c.oz, w2 = x0w * c.oy * az, w3 = x0w * c.oy * c.oz;
     const float w4 = x1w * ay * az, w5 = x1w * ay * c.oz, w6 = x1w * c.oy * az, w7 = x1w * c.oy * c.oz;
     if (fixed_ok) {
-      add_zpair(run_key, run_val, gvol, c.lin, w0, w1, to_fixed);
-      add_zpair(run_key, run_val, gvol, c.lin + Rr, w2, w3, to_fixed);
-      add_zpair(run_key, run_val, gvol, c.lin + Rr * Rr, w4, w5, to_fixed);
-      add_zpair(run_key, run_val, gvol, c.lin + Rr * Rr + Rr, w6, w7, to_fixed);
+      const float wk[8] = {w0, w1, w2, w3, w4, w5, w6, w7};
+      add_cell(run_key, run_val, gvol, c.lin, Rr, wk, to_fixed);
     } else if (go != 0.0f) {
       float* g0 = gvol + c.lin;
       atomicAdd(g0, w0);                atomicAdd(g0 + 1, w1);
