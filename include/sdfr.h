@@ -148,9 +148,23 @@ SDFR_API int sdfr_decoder_create(const float* h_params, size_t n_params, int lat
                         sdfr_decoder** out_handle);
 SDFR_API void sdfr_decoder_destroy(sdfr_decoder* decoder);
 SDFR_API size_t sdfr_decoder_workspace_bytes(const sdfr_decoder* decoder, int N);
-/* z [N][latent] -> out [N][volume^3] (the reference returns (N,1,D,D,D)); on the decoder's device */
+/* z [N][latent] -> out [N][volume^3] (the reference returns (N,1,D,D,D)); on the decoder's device.
+ * tape: NULL for inference; otherwise sdfr_decoder_tape_bytes(decoder, N) bytes that receive the
+ * post-ReLU layer outputs a later sdfr_decoder_backward_latent needs. */
+SDFR_API size_t sdfr_decoder_tape_bytes(const sdfr_decoder* decoder, int N);
 SDFR_API int sdfr_decoder_forward(const sdfr_decoder* decoder, const float* z, int N, int enforce_tsdf,
-                         float* out, void* workspace, size_t workspace_bytes, void* stream);
+                         float* out, float* tape, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+/* Vector-Jacobian product of the decoder w.r.t. the latent, weights held constant: what
+ * loss.backward() propagates to latent_shape in SDFPipeline.__call__
+ * (sdfest/estimation/simple_setup.py:413-414, :456) through SDFDecoder.forward
+ * (sdfest/vae/sdf_vae.py:217-259).  grad_out [N][volume^3] -> g_z [N][latent].
+ * `tape` comes from the forward of the same z with enforce_tsdf = 0.  Deterministic (no atomics). */
+SDFR_API size_t sdfr_decoder_backward_workspace_bytes(const sdfr_decoder* decoder, int N);
+SDFR_API int sdfr_decoder_backward_latent(const sdfr_decoder* decoder, const float* z, const float* tape,
+                                 const float* grad_out, int N, float* g_z, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

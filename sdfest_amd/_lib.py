@@ -38,7 +38,10 @@ SIGNATURES = {
                                     c_fp, c_int, c_f, c_int, c_fp]),
     "sdfr_decoder_destroy": (None, [c_fp]),
     "sdfr_decoder_workspace_bytes": (c_sz, [c_fp, c_int]),
-    "sdfr_decoder_forward": (c_int, [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_sz, c_fp]),
+    "sdfr_decoder_tape_bytes": (c_sz, [c_fp, c_int]),
+    "sdfr_decoder_forward": (c_int, [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_sz, c_fp]),
+    "sdfr_decoder_backward_workspace_bytes": (c_sz, [c_fp, c_int]),
+    "sdfr_decoder_backward_latent": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_sz, c_fp]),
 }
 
 

@@ -33,6 +33,15 @@ struct sdfr_decoder {
   std::vector<size_t> fc_w_off, fc_b_off;  // fc weights: [out][in] except the last: [in][out]
   std::vector<size_t> conv_w_off, conv_b_off, conv_tab_off;  // conv weights: [Kpad][16]
   size_t max_act = 0;                      // floats of the largest intermediate tensor
+  // backward (VJP to the latent): transposed/flipped conv matrices, their tap tables, zero bias
+  std::vector<size_t> bwd_w_off, bwd_tab_off;
+  std::vector<int> bwd_kpad;
+  size_t zero_bias_off = 0;
+  size_t max_bwd = 0;                      // floats of the largest gradient tensor (incl. padding)
+  // tape: post-ReLU outputs kept by a forward that will be differentiated
+  size_t tape_fc_off = 0;                  // per-sample float offsets
+  std::vector<size_t> tape_conv_off;
+  size_t tape_floats = 0;                  // per sample
 };
 
 namespace sdfr {
@@ -181,6 +190,152 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
   }
 }
 
+
+// ---- backward (VJP to the latent; weights are constants) -------------------------------------
+
+// out[N][C][np^3] = zero-padded (by `pad` on every side) copy of g[N][C][m^3], multiplied by the
+// ReLU mask of the layer's forward output when `act` is given.  The padded tensor turns the
+// data-gradient of a valid convolution into another valid convolution (with flipped weights).
+__global__ __launch_bounds__(256) void pad_mask_kernel(const float* __restrict__ g,
+                                                       const float* __restrict__ act, int C, int m,
+                                                       int pad, float* __restrict__ out) {
+  const int np = m + 2 * pad;
+  const size_t vp = (size_t)np * np * np, vm = (size_t)m * m * m;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)C * vp) return;
+  const int n = blockIdx.y;
+  const int c = (int)(idx / vp);
+  const int r = (int)(idx - (size_t)c * vp);
+  const int z = r % np - pad, y = (r / np) % np - pad, x = r / (np * np) - pad;
+  float v = 0.0f;
+  if (x >= 0 && x < m && y >= 0 && y < m && z >= 0 && z < m) {
+    const size_t src = ((size_t)n * C + c) * vm + ((size_t)x * m + y) * m + z;
+    v = g[src];
+    if (act && !(act[src] > 0.0f)) v = 0.0f;
+  }
+  out[((size_t)n * C + c) * vp + r] = v;
+}
+
+// weight of output index d on input index i along one axis of the trilinear resize
+__device__ __forceinline__ float resize_weight(int d, int i, float ratio, int n_in) {
+  int i0, i1;
+  float l1;
+  resize_axis(d, ratio, n_in, i0, i1, l1);
+  return (i0 == i ? 1.0f - l1 : 0.0f) + (i1 == i ? l1 : 0.0f);
+}
+
+// Transpose of resize3_kernel in gather form (deterministic, no atomics):
+// g_in[c][x][y][z] = sum over the few outputs (dx,dy,dz) that interpolate from (x,y,z).
+constexpr int kMaxSpan = 16;
+__global__ __launch_bounds__(256) void resize3_backward_kernel(const float* __restrict__ g_out, int C,
+                                                               int n_in, int n_out,
+                                                               float* __restrict__ g_in) {
+  const size_t vo = (size_t)n_out * n_out * n_out, vi = (size_t)n_in * n_in * n_in;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)C * vi) return;
+  const int n = blockIdx.y;
+  const int c = (int)(idx / vi);
+  const int r = (int)(idx - (size_t)c * vi);
+  const int z = r % n_in, y = (r / n_in) % n_in, x = r / (n_in * n_in);
+  const float ratio = (float)n_in / (float)n_out;
+  const float inv = (float)n_out / (float)n_in;
+  int lo[3], cnt[3];
+  float w[3][kMaxSpan];
+  const int ix[3] = {x, y, z};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    int d0 = (int)floorf(((float)ix[a] - 0.5f) * inv - 0.5f) - 1;
+    int d1 = (int)ceilf(((float)ix[a] + 1.5f) * inv - 0.5f) + 1;
+    d0 = max(d0, 0);
+    d1 = min(d1, n_out - 1);
+    if (d1 - d0 + 1 > kMaxSpan) d1 = d0 + kMaxSpan - 1;  // host guarantees this never truncates
+    lo[a] = d0;
+    cnt[a] = d1 - d0 + 1;
+    for (int k = 0; k < kMaxSpan; ++k) w[a][k] = (k < cnt[a]) ? resize_weight(d0 + k, ix[a], ratio, n_in) : 0.0f;
+  }
+  const float* p = g_out + ((size_t)n * C + c) * vo;
+  float acc = 0.0f;
+  for (int a = 0; a < cnt[0]; ++a) {
+    if (w[0][a] == 0.0f) continue;
+    float sy = 0.0f;
+    for (int b = 0; b < cnt[1]; ++b) {
+      if (w[1][b] == 0.0f) continue;
+      const float* row = p + ((size_t)(lo[0] + a) * n_out + (lo[1] + b)) * n_out + lo[2];
+      float sz = 0.0f;
+      for (int k = 0; k < cnt[2]; ++k) sz = fmaf(w[2][k], row[k], sz);
+      sy = fmaf(w[1][b], sz, sy);
+    }
+    acc = fmaf(w[0][a], sy, acc);
+  }
+  g_in[((size_t)n * C + c) * vi + r] = acc;
+}
+
+// g[i] = 0 where the forward activation was not positive (ReLU'), in place
+__global__ void relu_mask_kernel(float* __restrict__ g, const float* __restrict__ act, size_t count) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < count && !(act[i] > 0.0f)) g[i] = 0.0f;
+}
+
+// Backward of the Linear stack, one workgroup per sample: g_last (already ReLU-masked, width
+// of the last layer) -> g_z.  Hidden activations are recomputed in LDS as in the forward.
+__global__ __launch_bounds__(kFcBlock) void fc_stack_backward_kernel(const float* __restrict__ params,
+                                                                     FcDesc d,
+                                                                     const float* __restrict__ z,
+                                                                     const float* __restrict__ g_last,
+                                                                     float* __restrict__ g_z) {
+  __shared__ float act[8][kMaxHidden];   // act[l] = input of layer l (act[0] = z)
+  __shared__ float gbuf[2][kMaxHidden];
+  __shared__ float red[kFcBlock / 64];
+  const int tid = threadIdx.x, n = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < d.width[0]; i += kFcBlock) act[0][i] = z[(size_t)n * d.width[0] + i];
+  __syncthreads();
+  for (int l = 0; l < d.n_fc - 1; ++l) {
+    const int win = d.width[l], wout = d.width[l + 1];
+    const float* w = params + d.w_off[l];
+    const float* b = params + d.b_off[l];
+    for (int o = tid; o < wout; o += kFcBlock) {
+      float acc = b[o];
+      for (int i = 0; i < win; ++i) acc = fmaf(w[(size_t)o * win + i], act[l][i], acc);
+      act[l + 1][o] = fmaxf(acc, 0.0f);
+    }
+    __syncthreads();
+  }
+  // last layer (weights stored transposed [in][out]): g_h[i] = sum_o Wt[i][o] * g_last[o]
+  int cur = 0;
+  {
+    const int l = d.n_fc - 1, win = d.width[l], wout = d.width[l + 1];
+    const float* wt = params + d.w_off[l];
+    const float* g = g_last + (size_t)n * wout;
+    for (int i = 0; i < win; ++i) {
+      float part = 0.0f;
+      for (int o = tid; o < wout; o += kFcBlock) part = fmaf(wt[(size_t)i * wout + o], g[o], part);
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+      if (lane == 0) red[wave] = part;
+      __syncthreads();
+      if (tid == 0) {
+        float t = 0.0f;
+        for (int k = 0; k < kFcBlock / 64; ++k) t += red[k];
+        // ReLU' of the layer that produced act[l] (l >= 1); the latent itself has no ReLU
+        gbuf[cur][i] = (l == 0 || act[l][i] > 0.0f) ? t : 0.0f;
+      }
+      __syncthreads();
+    }
+  }
+  for (int l = d.n_fc - 2; l >= 0; --l) {
+    const int win = d.width[l], wout = d.width[l + 1];
+    const float* w = params + d.w_off[l];  // [out][in]
+    for (int i = tid; i < win; i += kFcBlock) {
+      float t = 0.0f;
+      for (int o = 0; o < wout; ++o) t = fmaf(w[(size_t)o * win + i], gbuf[cur][o], t);
+      gbuf[cur ^ 1][i] = (l == 0 || act[l][i] > 0.0f) ? t : 0.0f;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  for (int i = tid; i < d.width[0]; i += kFcBlock) g_z[(size_t)n * d.width[0] + i] = gbuf[cur][i];
+}
+
 }  // namespace
 }  // namespace sdfr
 
@@ -293,6 +448,66 @@ extern "C" int sdfr_decoder_create(const float* h_params, size_t n_params, int l
     d->max_act = std::max(d->max_act, (size_t)co_n * m * m * m);
   }
   d->max_act = std::max(d->max_act, (size_t)volume * volume * volume);
+  // backward: data-gradient of conv l = valid conv of the zero-padded output gradient with
+  //   Wb[kk = co*k^3 + (a*k+b)*k + c][ci] = W[co][ci][k-1-a][k-1-b][k-1-c]
+  {
+    const float* q = h_params;
+    int wdt = latent;
+    for (int l = 0; l < n_fc; ++l) { q += (size_t)fc_out[l] * wdt + fc_out[l]; wdt = fc_out[l]; }
+    int prev_n = conv_in_size[0];
+    d->max_bwd = (size_t)volume * volume * volume;
+    size_t tape = 0;
+    d->tape_fc_off = tape;
+    tape += (size_t)fc_out[n_fc - 1];
+    for (int l = 0; l < n_conv; ++l) {
+      const int k = conv_k[l], ci_n = conv_cin[l], co_n = conv_cout[l], n = conv_in_size[l];
+      const int m = n - k + 1, np = m + 2 * (k - 1), k3 = k * k * k;
+      const int Kb = co_n * k3, kpad = (Kb + 3) / 4 * 4, ci_tiles = (ci_n + 15) / 16;
+      if ((size_t)kpad * 17 * sizeof(float) > 64 * 1024) {
+        delete d;
+        return fail(SDFR_E_INVALID, "conv layer %d: Cout*k^3 too large for the backward weight tile", l);
+      }
+      d->bwd_kpad.push_back(kpad);
+      align();
+      d->bwd_w_off.push_back(img.size());
+      for (int ct = 0; ct < ci_tiles; ++ct)
+        for (int kk = 0; kk < kpad; ++kk)
+          for (int j = 0; j < 16; ++j) {
+            const int ci = ct * 16 + j;
+            float v = 0.0f;
+            if (kk < Kb && ci < ci_n) {
+              const int co = kk / k3, r = kk % k3, a = r / (k * k), b = (r / k) % k, c = r % k;
+              v = q[(((size_t)co * ci_n + ci) * k + (k - 1 - a)) * k * k + (size_t)(k - 1 - b) * k + (k - 1 - c)];
+            }
+            img.push_back(v);
+          }
+      align();
+      d->bwd_tab_off.push_back(img.size());
+      for (int kk = 0; kk < kpad; ++kk) {
+        int off = 0;
+        if (kk < Kb) {
+          const int co = kk / k3, r = kk % k3, a = r / (k * k), b = (r / k) % k, c = r % k;
+          off = co * np * np * np + (a * np + b) * np + c;
+        }
+        float f;
+        memcpy(&f, &off, sizeof(f));
+        img.push_back(f);
+      }
+      q += (size_t)co_n * ci_n * k3 + co_n;
+      d->max_bwd = std::max(d->max_bwd, (size_t)co_n * np * np * np);
+      d->max_bwd = std::max(d->max_bwd, (size_t)ci_n * n * n * n);
+      d->max_bwd = std::max(d->max_bwd, (size_t)ci_n * prev_n * prev_n * prev_n);
+      d->tape_conv_off.push_back(tape);
+      tape += (size_t)co_n * m * m * m;
+      prev_n = m;
+    }
+    d->tape_floats = tape;
+    align();
+    d->zero_bias_off = img.size();
+    int max_c = 16;
+    for (int l = 0; l < n_conv; ++l) max_c = std::max(max_c, conv_cin[l]);
+    img.insert(img.end(), (size_t)max_c, 0.0f);
+  }
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipMalloc((void**)&d->d_params, img.size() * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(d->d_params, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -319,9 +534,14 @@ extern "C" size_t sdfr_decoder_workspace_bytes(const sdfr_decoder* d, int N) {
   return 2 * (size_t)N * d->max_act * sizeof(float) + 512;
 }
 
+extern "C" size_t sdfr_decoder_tape_bytes(const sdfr_decoder* d, int N) {
+  if (!d || N <= 0) return 0;
+  return (size_t)N * d->tape_floats * sizeof(float);
+}
+
 extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N, int enforce_tsdf,
-                                    float* out, void* workspace, size_t workspace_bytes,
-                                    void* stream) {
+                                    float* out, float* tape, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
   if (!d) return fail(SDFR_E_NULL, "sdfr_decoder_forward: NULL decoder");
   if (N < 0 || N > 65535) return fail(SDFR_E_INVALID, "N=%d out of range", N);
   if (N == 0) return 0;
@@ -344,8 +564,14 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
     fd.b_off[l] = (long long)d->fc_b_off[l];
   }
   const int last = d->fc_out[d->n_fc - 1];
-  hipLaunchKernelGGL(fc_stack_kernel, dim3((last + kFcBlock - 1) / kFcBlock, N), dim3(kFcBlock), 0, st,
-                     d->d_params, fd, z, buf[cur]);
+  // with a tape, every ReLU'd layer output goes to its own slot (and is read from there)
+  const float* act_in;
+  {
+    float* fc_dst = tape ? tape + (size_t)N * d->tape_fc_off : buf[cur];
+    hipLaunchKernelGGL(fc_stack_kernel, dim3((last + kFcBlock - 1) / kFcBlock, N), dim3(kFcBlock), 0, st,
+                       d->d_params, fd, z, fc_dst);
+    act_in = fc_dst;
+  }
 
   const float clampv = (enforce_tsdf && d->tsdf > 0.0f) ? d->tsdf : 0.0f;
   int c = d->conv_cin[0], n = d->conv_in_size[0];
@@ -354,8 +580,9 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
       const int no = d->conv_in_size[l];
       const size_t cnt = (size_t)c * no * no * no;
       hipLaunchKernelGGL(resize3_kernel, dim3((unsigned)((cnt + 255) / 256), N), dim3(256), 0, st,
-                         buf[cur], c, n, no, 0.0f, buf[cur ^ 1]);
+                         act_in, c, n, no, 0.0f, buf[cur ^ 1]);
       cur ^= 1;
+      act_in = buf[cur];
       n = no;
     }
     const int k = d->conv_k[l], co_n = d->conv_cout[l], m = n - k + 1, kpad = d->conv_kpad[l];
@@ -364,21 +591,23 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
     const int blocks = (n_tiles + 4 * tpw - 1) / (4 * tpw);
     const size_t lds = (size_t)kpad * 17 * sizeof(float);
     const bool is_last = (l == d->n_conv - 1);
-    float* dst = (is_last && m == d->volume && clampv == 0.0f) ? out : buf[cur ^ 1];
+    float* dst = (is_last && m == d->volume && clampv == 0.0f) ? out
+                 : (tape ? tape + (size_t)N * d->tape_conv_off[l] : buf[cur ^ 1]);
     hipLaunchKernelGGL(conv3d_mfma_kernel, dim3(blocks, (co_n + 15) / 16, N), dim3(256), lds, st,
-                       buf[cur], d->d_params + d->conv_w_off[l],
+                       act_in, d->d_params + d->conv_w_off[l],
                        reinterpret_cast<const int*>(d->d_params + d->conv_tab_off[l]),
                        d->d_params + d->conv_b_off[l], dst, c, co_n, n, m, kpad, d->conv_relu[l], tpw);
-    if (dst != out) cur ^= 1;
+    if (dst != out && !tape) cur ^= 1;
+    act_in = dst;
     c = co_n;
     n = m;
     if (is_last) {
       const size_t vox = (size_t)d->volume * d->volume * d->volume;
       if (n != d->volume) {
         hipLaunchKernelGGL(resize3_kernel, dim3((unsigned)((vox + 255) / 256), N), dim3(256), 0, st,
-                           buf[cur], 1, n, d->volume, clampv, out);
+                           act_in, 1, n, d->volume, clampv, out);
       } else if (dst != out) {
-        SDFR_HIP_TRY(hipMemcpyAsync(out, buf[cur], (size_t)N * vox * sizeof(float),
+        SDFR_HIP_TRY(hipMemcpyAsync(out, act_in, (size_t)N * vox * sizeof(float),
                                     hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(clamp_kernel, dim3((unsigned)(((size_t)N * vox + 255) / 256)), dim3(256), 0, st,
                            out, (size_t)N * vox, clampv);
@@ -386,5 +615,99 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
     }
   }
   SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" size_t sdfr_decoder_backward_workspace_bytes(const sdfr_decoder* d, int N) {
+  if (!d || N <= 0) return 0;
+  return 2 * (size_t)N * d->max_bwd * sizeof(float) + 512;
+}
+
+extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* z, const float* tape,
+                                            const float* grad_out, int N, float* g_z,
+                                            void* workspace, size_t workspace_bytes, void* stream) {
+  if (!d) return fail(SDFR_E_NULL, "sdfr_decoder_backward_latent: NULL decoder");
+  if (N < 0 || N > 65535) return fail(SDFR_E_INVALID, "N=%d out of range", N);
+  if (N == 0) return 0;
+  if (!z || !tape || !grad_out || !g_z || !workspace)
+    return fail(SDFR_E_NULL, "sdfr_decoder_backward_latent: NULL pointer argument");
+  if (workspace_bytes < sdfr_decoder_backward_workspace_bytes(d, N))
+    return fail(SDFR_E_WORKSPACE, "sdfr_decoder_backward_latent: workspace %zu < %zu bytes",
+                workspace_bytes, sdfr_decoder_backward_workspace_bytes(d, N));
+  SDFR_HIP_TRY(hipSetDevice(d->device));
+  hipStream_t st = (hipStream_t)stream;
+  uintptr_t wsp = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+  float* buf[2] = {(float*)wsp, (float*)wsp + (size_t)N * d->max_bwd};
+  int cur = 0;
+  const float* g = grad_out;  // gradient w.r.t. the current tensor, [N][c][n^3]
+
+  // sizes of the tensor each conv layer produces
+  std::vector<int> out_n(d->n_conv);
+  for (int l = 0; l < d->n_conv; ++l) out_n[l] = d->conv_in_size[l] - d->conv_k[l] + 1;
+  auto check_span = [&](int n_in, int n_out) {
+    return (int)(2.0f * (float)n_out / (float)n_in) + 5 <= kMaxSpan;
+  };
+  int n = d->volume;
+  if (out_n[d->n_conv - 1] != d->volume) {  // final resize
+    const int ni = out_n[d->n_conv - 1];
+    if (!check_span(ni, d->volume)) return fail(SDFR_E_INVALID, "resize ratio %d->%d unsupported in backward", ni, d->volume);
+    const size_t cnt = (size_t)ni * ni * ni;
+    hipLaunchKernelGGL(resize3_backward_kernel, dim3((unsigned)((cnt + 255) / 256), N), dim3(256), 0, st,
+                       g, 1, ni, d->volume, buf[cur]);
+    g = buf[cur];
+    cur ^= 1;
+    n = ni;
+  }
+  for (int l = d->n_conv - 1; l >= 0; --l) {
+    const int k = d->conv_k[l], ci_n = d->conv_cin[l], co_n = d->conv_cout[l];
+    const int nin = d->conv_in_size[l], m = out_n[l], np = m + 2 * (k - 1);
+    // 1. ReLU' and zero padding of the output gradient
+    const float* act = d->conv_relu[l] ? tape + (size_t)N * d->tape_conv_off[l] : nullptr;
+    const size_t cntp = (size_t)co_n * np * np * np;
+    hipLaunchKernelGGL(pad_mask_kernel, dim3((unsigned)((cntp + 255) / 256), N), dim3(256), 0, st, g, act,
+                       co_n, m, k - 1, buf[cur]);
+    g = buf[cur];
+    cur ^= 1;
+    // 2. data gradient = valid conv (kernel k) of the padded tensor with the flipped weights
+    const int kpad = d->bwd_kpad[l];
+    const int n_tiles = (nin * nin * nin + 15) / 16;
+    const int tpw = n_tiles >= 4096 ? 4 : 1;
+    const int blocks = (n_tiles + 4 * tpw - 1) / (4 * tpw);
+    hipLaunchKernelGGL(conv3d_mfma_kernel, dim3(blocks, (ci_n + 15) / 16, N), dim3(256),
+                       (size_t)kpad * 17 * sizeof(float), st, g, d->d_params + d->bwd_w_off[l],
+                       reinterpret_cast<const int*>(d->d_params + d->bwd_tab_off[l]),
+                       d->d_params + d->zero_bias_off, buf[cur], co_n, ci_n, np, nin, kpad, 0, tpw);
+    g = buf[cur];
+    cur ^= 1;
+    n = nin;
+    // 3. the resize in front of this layer, if any
+    const int prev = (l == 0) ? d->conv_in_size[0] : out_n[l - 1];
+    if (prev != nin) {
+      if (!check_span(prev, nin)) return fail(SDFR_E_INVALID, "resize ratio %d->%d unsupported in backward", prev, nin);
+      const size_t cnt = (size_t)ci_n * prev * prev * prev;
+      hipLaunchKernelGGL(resize3_backward_kernel, dim3((unsigned)((cnt + 255) / 256), N), dim3(256), 0, st,
+                         g, ci_n, prev, nin, buf[cur]);
+      g = buf[cur];
+      cur ^= 1;
+      n = prev;
+    }
+  }
+  // g is now the gradient w.r.t. the (ReLU'd) output of the Linear stack
+  const int last = d->fc_out[d->n_fc - 1];
+  float* gl = buf[cur];
+  SDFR_HIP_TRY(hipMemcpyAsync(gl, g, (size_t)N * last * sizeof(float), hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)(((size_t)N * last + 255) / 256)), dim3(256), 0, st,
+                     gl, tape + (size_t)N * d->tape_fc_off, (size_t)N * last);
+  FcDesc fd;
+  fd.n_fc = d->n_fc;
+  fd.width[0] = d->latent;
+  for (int l = 0; l < d->n_fc; ++l) {
+    fd.width[l + 1] = d->fc_out[l];
+    fd.w_off[l] = (long long)d->fc_w_off[l];
+    fd.b_off[l] = (long long)d->fc_b_off[l];
+  }
+  hipLaunchKernelGGL(fc_stack_backward_kernel, dim3(N), dim3(kFcBlock), 0, st, d->d_params, fd, z, gl, g_z);
+  SDFR_HIP_TRY(hipGetLastError());
+  (void)n;
   return 0;
 }

@@ -29,6 +29,23 @@ def _flatten_state(state: Mapping, n_fc: int, n_conv: int, prefix: str) -> np.nd
     return np.ascontiguousarray(np.concatenate(parts))
 
 
+class _DecodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, dec):
+        zc = z.detach().contiguous()
+        nbytes = dec._L.sdfr_decoder_tape_bytes(dec._h, zc.shape[0])
+        tape = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dec.device)
+        out = dec._forward_raw(zc, False, tape)
+        ctx.save_for_backward(zc, tape)
+        ctx.dec = dec
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        zc, tape = ctx.saved_tensors
+        return ctx.dec._backward_raw(zc, tape, grad_out.contiguous()), None
+
+
 class SDFDecoder:
     """Decoder of the SDF VAE (reference: SDFDecoder.__init__ sdf_vae.py:171-205)."""
 
@@ -81,26 +98,47 @@ class SDFDecoder:
             self._L.sdfr_decoder_destroy(h)
             self._h = None
 
+    def _scratch(self, need: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _forward_raw(self, zc: torch.Tensor, enforce_tsdf: bool, tape: Optional[torch.Tensor]):
+        N, D = zc.shape[0], self._volume_size
+        out = torch.empty((N, 1, D, D, D), dtype=torch.float32, device=self.device)
+        ws = self._scratch(self._L.sdfr_decoder_workspace_bytes(self._h, N))
+        rc = self._L.sdfr_decoder_forward(self._h, zc.data_ptr(), N, int(bool(enforce_tsdf)),
+                                          out.data_ptr(), None if tape is None else tape.data_ptr(),
+                                          ws.data_ptr(), ws.numel(),
+                                          torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(rc, "sdfr_decoder_forward")
+        return out
+
+    def _backward_raw(self, zc: torch.Tensor, tape: torch.Tensor, grad_out: torch.Tensor):
+        N = zc.shape[0]
+        g_z = torch.empty_like(zc)
+        ws = self._scratch(self._L.sdfr_decoder_backward_workspace_bytes(self._h, N))
+        rc = self._L.sdfr_decoder_backward_latent(self._h, zc.data_ptr(), tape.data_ptr(),
+                                                  grad_out.data_ptr(), N, g_z.data_ptr(),
+                                                  ws.data_ptr(), ws.numel(),
+                                                  torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(rc, "sdfr_decoder_backward_latent")
+        return g_z
+
     def forward(self, z: torch.Tensor, enforce_tsdf: bool = False) -> torch.Tensor:
-        """z (N, latent_size) -> (N, 1, D, D, D), like SDFDecoder.forward (sdf_vae.py:217-259)."""
+        """z (N, latent_size) -> (N, 1, D, D, D), like SDFDecoder.forward (sdf_vae.py:217-259).
+
+        Differentiable w.r.t. z (the weights are constants, as in the estimation loop where only
+        the latent is optimised, simple_setup.py:400-406)."""
         if not z.is_cuda or z.dtype != torch.float32:
             raise RuntimeError("z must be a float32 CUDA tensor")
         if z.dim() != 2 or z.shape[1] != self.latent_size:
             raise RuntimeError(f"z must have shape (N, {self.latent_size})")
         if z.requires_grad and torch.is_grad_enabled():
-            raise NotImplementedError(
-                "decoder backward (VJP to the latent) is not built yet: call under torch.no_grad()")
-        zc = z.detach().contiguous()
-        N, D = zc.shape[0], self._volume_size
-        out = torch.empty((N, 1, D, D, D), dtype=torch.float32, device=self.device)
-        need = self._L.sdfr_decoder_workspace_bytes(self._h, N)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        rc = self._L.sdfr_decoder_forward(self._h, zc.data_ptr(), N, int(bool(enforce_tsdf)),
-                                          out.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
-                                          torch.cuda.current_stream(self.device).cuda_stream)
-        _lib.check(rc, "sdfr_decoder_forward")
-        return out
+            if enforce_tsdf and self._tsdf is not False:
+                raise NotImplementedError("gradient through the tsdf clamp is not supported")
+            return _DecodeFn.apply(z, self)
+        return self._forward_raw(z.detach().contiguous(), enforce_tsdf, None)
 
     __call__ = forward
 

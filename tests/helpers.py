@@ -42,3 +42,10 @@ def rel_err(a, b, floor=None):
         floor = np.max(np.abs(b)) if b.size else 1.0
     floor = max(float(floor), 1e-300)
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor))) if a.size else 0.0
+
+
+def decoder_probe_G(n=64):
+    """The deterministic upstream gradient used by tools/make_goldens.py for the decoder VJP."""
+    a = np.arange(n, dtype=np.float64)
+    X, Y, Z = np.meshgrid(a, a, a, indexing="ij")
+    return (np.sin(0.37 * X + 0.11) * np.cos(0.23 * Y - 0.4) + 0.5 * np.sin(0.05 * Z * X * 0.1 + 0.3 * Y)).astype(np.float32)
