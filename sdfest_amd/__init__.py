@@ -10,5 +10,6 @@ from .differentiable_renderer import (BatchRenderPlan, Camera, SDFRendererFuncti
 
 from .losses import pc_loss, pc_loss_batch
 from .vae import SDFDecoder
+from .pipeline import RenderAndCompare
 
-__all__ = ["SDFDecoder", "pc_loss", "pc_loss_batch", "BatchRenderPlan", "Camera", "SDFRendererFunctionGPU", "render_depth_gpu", "render_depth_batch"]
+__all__ = ["RenderAndCompare", "SDFDecoder", "pc_loss", "pc_loss_batch", "BatchRenderPlan", "Camera", "SDFRendererFunctionGPU", "render_depth_gpu", "render_depth_batch"]

@@ -1,0 +1,38 @@
+"""CPU: loop glue (quaternion helpers, depth -> point cloud) against goldens captured from the
+reference's quaternion_utils and against the oracle."""
+import os
+
+import numpy as np
+import torch
+
+import oracle
+from helpers import GOLDEN
+from sdfest_amd.differentiable_renderer import Camera
+from sdfest_amd.pipeline import (depth_to_pointcloud, quaternion_apply, quaternion_invert,
+                                 quaternion_multiply)
+
+
+def test_quaternion_helpers_match_reference_goldens():
+    d = np.load(os.path.join(GOLDEN, "quaternion.npz"))
+    t = lambda a: torch.tensor(a, dtype=torch.float64)
+    assert np.allclose(quaternion_multiply(t(d["q1"]), t(d["q2"])).numpy(), d["mul"], atol=1e-14)
+    assert np.allclose(quaternion_apply(t(d["q1"]), t(d["pts"])).numpy(), d["apply"], atol=1e-14)
+    assert np.allclose(quaternion_invert(t(d["q1"])).numpy(), d["inv"], atol=0)
+    # the reference's own known-answer tests (tests/initilization/test_quaternion.py:8-50)
+    q = torch.tensor([0.0, 0.0, np.sin(np.pi / 4), np.cos(np.pi / 4)], dtype=torch.float64)  # 90 deg about z
+    assert np.allclose(quaternion_apply(q, torch.tensor([1.0, 0.0, 0.0], dtype=torch.float64)).numpy(),
+                       [0.0, 1.0, 0.0], atol=1e-12)
+    assert np.allclose(quaternion_multiply(q, quaternion_invert(q)).numpy(), [0, 0, 0, 1], atol=1e-12)
+
+
+def test_depth_to_pointcloud_matches_oracle_and_convention():
+    rng = np.random.default_rng(0)
+    depth = rng.uniform(0.5, 2.0, (48, 64)).astype(np.float32)
+    depth[rng.uniform(size=depth.shape) < 0.6] = 0.0
+    cam = Camera(64, 48, 40.0, 42.0, 32.0, 24.0, pixel_center=0.5)
+    fx, fy, cx0, cy0, _ = cam.get_pinhole_camera_parameters(0.0)
+    assert (cx0, cy0) == (31.5, 23.5)
+    pts = depth_to_pointcloud(torch.tensor(depth), cam).numpy()
+    ref = oracle.depth_to_pointcloud(depth, fx, fy, cx0, cy0)
+    assert pts.shape == ref.shape == (int((depth != 0).sum()), 3)
+    assert np.allclose(pts, ref, rtol=1e-6, atol=1e-7)

@@ -1,0 +1,170 @@
+"""GPU: the render-and-compare iteration (SDFPipeline.__call__ hot loop) against a numpy restatement
+built from the oracle's render / sampler forward+backward, and the C5 convergence run."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def qmul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+
+
+def qinv(q):
+    return q * np.array([-1, -1, -1, 1.0])
+
+
+def qrot(q, v):
+    return qmul(qmul(q, np.append(v, 0.0)), qinv(q))[:3]
+
+
+def left_mul_matrix(a):
+    """M with qmul(a, b) = M @ b."""
+    ax, ay, az, aw = a
+    return np.array([[aw, -az, ay, ax], [az, aw, -ax, ay], [-ay, ax, aw, az], [-ax, -ay, -az, aw]])
+
+
+class NumpyAdam:
+    def __init__(self, lrs):
+        self.lrs, self.m, self.v, self.t = lrs, [0.0] * len(lrs), [0.0] * len(lrs), 0
+
+    def step(self, params, grads):
+        self.t += 1
+        out = []
+        for i, (p, g) in enumerate(zip(params, grads)):
+            self.m[i] = 0.9 * self.m[i] + 0.1 * g
+            self.v[i] = 0.999 * self.v[i] + 0.001 * g * g
+            mh = self.m[i] / (1 - 0.9 ** self.t)
+            vh = self.v[i] / (1 - 0.999 ** self.t)
+            out.append(p - self.lrs[i] * mh / (np.sqrt(vh) + 1e-8))
+        return out
+
+
+def oracle_loop(sdf, depth_images, cam, cam_pos, cam_quat, p, q, s, thr, iters, wd, wpc):
+    """numpy float64 restatement of simple_setup.py:408-462 with shape_optimization=False."""
+    W, H, fx, fy, cx, cy = cam
+    V = depth_images.shape[0]
+    clouds = [oracle.depth_to_pointcloud(d, fx, fy, cx - 0.5, cy - 0.5, dtype=np.float64) for d in depth_images]
+    adam = NumpyAdam([1e-3, 1e-2, 1e-3])
+    traj = []
+    for _ in range(iters):
+        nq = q / np.linalg.norm(q)
+        gp, gnq, gs = np.zeros(3), np.zeros(4), 0.0
+        for v in range(V):
+            qw2c = qinv(cam_quat[v])
+            Rw2c = np.stack([qrot(qw2c, e) for e in np.eye(3)], axis=1)
+            pc = Rw2c @ (p - cam_pos[v])
+            qc = qmul(qw2c, nq)
+            est = oracle.render_forward(sdf, pc, qc, [1.0 / s], W, H, cx, cy, fx, fy, thr, dtype=np.float64)[0]
+            mask = (depth_images[v] > 0) & (est > 0)
+            gimg = wd * np.sign(est - depth_images[v]) * mask / mask.sum()
+            _, g_pc, g_qc, g_is = oracle.render_backward(gimg, est, sdf, pc, qc, [1.0 / s], cx, cy, fx, fy,
+                                                         dtype=np.float64)
+            val = oracle.pc_loss_forward(clouds[v], pc, qc, s, sdf, dtype=np.float64)
+            go = wpc * np.sign(val) / len(val)
+            _, g_pc2, g_qc2, g_s2 = oracle.pc_loss_backward(go, clouds[v], pc, qc, s, sdf, dtype=np.float64)
+            gp += Rw2c.T @ (g_pc[0] + g_pc2)
+            gnq += left_mul_matrix(qw2c).T @ (g_qc[0] + g_qc2)
+            gs += -g_is[0] / s ** 2 + g_s2
+        n = np.linalg.norm(q)
+        gq = (gnq - nq * (nq @ gnq)) / n
+        p, q, s = adam.step([p, q, np.array(s)], [gp, gq, np.array(gs)])
+        s = float(s)
+        q = q / np.linalg.norm(q)
+        traj.append((p.copy(), q.copy(), s))
+    return traj
+
+
+@pytest.fixture(scope="module")
+def mug_decoder():
+    from sdfest_amd import SDFDecoder
+    from test_decoder_gpu import mug_config
+    d = np.load(os.path.join(GOLDEN, "decoder_mug.npz"))
+    w = np.load(os.path.join(GOLDEN, "mug_decoder_weights.npz"))
+    return SDFDecoder.from_config(mug_config(d), {k: w[k] for k in w.files}), d
+
+
+def test_iteration_matches_numpy_restatement(mug_decoder):
+    """5 Adam iterations, 2 cameras with non-trivial extrinsics, 64x48, mug shape at z=0 (pose only,
+    shape_optimization=False): parameter trajectory vs the oracle-based loop."""
+    from sdfest_amd import Camera
+    from sdfest_amd.pipeline import RenderAndCompare
+    dec, d = mug_decoder
+    sdf = d["z0_full"].astype(np.float64)
+    W, H, f = 64, 48, 60.0
+    cam = Camera(W, H, f, f, W / 2, H / 2, pixel_center=0.5)
+    camt = (W, H, f, f, W / 2, H / 2)
+    cam_pos = np.array([[0.0, 0.0, 0.0], [0.25, 0.05, 0.02]])
+    cq = np.array([0.02, 0.27, 0.01, 1.0]); cq /= np.linalg.norm(cq)
+    cam_quat = np.stack([np.array([0.0, 0, 0, 1.0]), cq])
+    p_true = np.array([0.01, -0.015, -0.45]); s_true = 0.11
+    q_true = np.array([0.3, 0.5, -0.1, 0.8]); q_true /= np.linalg.norm(q_true)
+    obs = []
+    for v in range(2):
+        qw2c = qinv(cam_quat[v])
+        obs.append(oracle.render_forward(sdf, qrot(qw2c, p_true - cam_pos[v]), qmul(qw2c, q_true), [1 / s_true],
+                                         W, H, W / 2, H / 2, f, f, 0.005, dtype=np.float64)[0])
+    obs = np.stack(obs)
+    assert (obs > 0).sum(axis=(1, 2)).min() > 150
+    p0 = p_true + np.array([0.008, -0.006, 0.01]); s0 = 0.12
+    q0 = q_true + np.array([0.04, -0.03, 0.02, 0.01])
+    cfg = {"threshold": 0.005, "max_iterations": 5, "depth_weight": 1.0, "pc_weight": 3.0}
+    ref = oracle_loop(sdf, obs, camt, cam_pos, cam_quat, p0.copy(), q0.copy(), s0, 0.005, 5, 1.0, 3.0)
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device="cuda")
+    hist = []
+    loop = RenderAndCompare(dec, cam, cfg)
+    loop(t(obs), t(p0[None]), t(q0[None]), t([s0]), torch.zeros(1, 8, device="cuda"),
+         camera_positions=t(cam_pos), camera_orientations=t(cam_quat), shape_optimization=False,
+         history=hist)
+    for it, (rp, rq, rs) in enumerate(ref):
+        hp = hist[it]["position"].cpu().numpy()[0]
+        hq = hist[it]["orientation"].cpu().numpy()[0]
+        hs = hist[it]["scale"].item()
+        # Adam normalises the gradient, so steps are ~lr; agree to a small fraction of a step
+        assert np.max(np.abs(hp - rp)) < 2e-4 * (it + 1), (it, hp, rp)
+        assert np.max(np.abs(hq - rq)) < 2e-3 * (it + 1), (it, hq, rq)
+        assert abs(hs - rs) < 2e-4 * (it + 1), (it, hs, rs)
+    # and the steps really moved the parameters
+    assert np.linalg.norm(ref[-1][0] - p0) > 2e-3
+
+
+def test_c5_full_loop_converges(mug_decoder):
+    """BASELINE configs[4]: decoder(z) -> 64^3 SDF -> render, 50 Adam steps on a synthetic depth
+    image, mug config, 640x480, shape optimisation on."""
+    from sdfest_amd import Camera, render_depth_gpu
+    from sdfest_amd.pipeline import RenderAndCompare
+    dec, d = mug_decoder
+    cam = Camera(640, 480, 320.0, 320.0, 320.0, 240.0, pixel_center=0.5)
+    dev = "cuda"
+    z_true = torch.tensor(d["z"][9:10], device=dev) * 0.5
+    p_true = torch.tensor([[0.02, -0.01, -0.5]], device=dev)
+    q_true = torch.tensor([[0.2, 0.6, -0.15, 0.75]], device=dev)
+    q_true = q_true / q_true.norm()
+    s_true = torch.tensor([0.055], device=dev)
+    with torch.no_grad():
+        target = render_depth_gpu(dec.decode(z_true)[0, 0], p_true[0], q_true[0], 1 / s_true[0], None, None,
+                                  None, 0.005, cam)
+    assert (target > 0).sum() > 2000
+    cfg = {"threshold": 0.005, "max_iterations": 50, "depth_weight": 1.0, "pc_weight": 3.0}
+    hist = []
+    p0 = p_true + torch.tensor([[0.01, 0.01, 0.01]], device=dev)
+    q0 = q_true + torch.tensor([[0.06, -0.05, 0.04, 0.0]], device=dev)
+    out = RenderAndCompare(dec, cam, cfg)(target[None], p0, q0 / q0.norm(), torch.tensor([0.06], device=dev),
+                                          torch.zeros(1, 8, device=dev), history=hist)
+    losses = [h["loss"].item() for h in hist]
+    assert all(np.isfinite(losses))
+    assert min(losses[-5:]) < 0.5 * losses[0], losses
+    pos_err0 = (p0 - p_true).norm().item()
+    pos_err = (out[0] - p_true).norm().item()
+    assert pos_err < 0.6 * pos_err0, (pos_err0, pos_err)
+    assert abs(out[2].item() - 0.055) < abs(0.06 - 0.055)
+    assert hist[-1]["latent"].abs().max().item() > 1e-3      # the latent really was optimised
