@@ -33,6 +33,10 @@ namespace sdfr {
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef SDFR_GROUP_X   // tiles per workgroup in batch mode (GX x GY tiles of 64 x 8 pixels)
+#define SDFR_GROUP_X 1
+#define SDFR_GROUP_Y 1
+#endif
 
 
 // ---------------------------------------------------------------------------------------------
@@ -131,14 +135,13 @@ __device__ __forceinline__ bool overlaps(const Rect& r, int px, int py, int w, i
 // record loads in flight per lane.  All K rays start together, so the step number of every
 // active ray equals the iteration count `n` and one counter enforces SDFR_MAX_MARCH_STEPS.
 template <int RT, bool PACKED, int K, int SX, int SY>
-__global__ __launch_bounds__(kBlock) void render_forward_kernel(
-    const float* __restrict__ src, int R, long long src_view_stride,
+__device__ __forceinline__ void forward_tile(
+    int tile_x, int tile_y, int b, const float* __restrict__ src, int R, long long src_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx, float rfy,
     float threshold, int vec_ok, float* __restrict__ depth) {
   constexpr int kSubs = SX * SY, kTileW = SX * kSubW, kTileH = SY * kSubH;
   static_assert(kSubs % K == 0, "K must divide the sub-tiles of a tile");
-  const int b = blockIdx.z;
-  const int px0 = blockIdx.x * kTileW, py0 = blockIdx.y * kTileH;
+  const int px0 = tile_x * kTileW, py0 = tile_y * kTileH;
   const ViewSetup& s = setup[b];
   const Rect rc{s.rect[0], s.rect[1], s.rect[2], s.rect[3]};
   float* img = depth + (size_t)b * H * W;
@@ -242,25 +245,55 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
   }
 }
 
+// A workgroup can walk a GX x GY group of tiles.  More than half of the tiles of a batch only
+// store zeros (or, in the backward, do nothing) and an all-culled launch of 153 600 workgroups
+// takes 40 us, so fewer, fatter workgroups looked attractive -- measured, every grouping loses
+// (B=256, forward/backward us: 1x1 257/211, 1x2 264/311, 1x4 270/317, 2x4 295/363; a persistent
+// grid striding over the whole tile list: 377/472): the dispatcher hides the very uneven tile
+// costs only when it has many independent workgroups.  GX = GY = 1 is what ships.
+template <int RT, bool PACKED, int K, int SX, int SY, int GX, int GY>
+__global__ __launch_bounds__(kBlock) void render_forward_kernel(
+    const float* __restrict__ src, int R, long long src_view_stride,
+    const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, float cx, float cy,
+    float rfx, float rfy, float threshold, int vec_ok, float* __restrict__ depth) {
+  const int b = blockIdx.z;
+#pragma unroll 1
+  for (int g = 0; g < GX * GY; ++g) {
+    const int tx = blockIdx.x * GX + g % GX, ty = blockIdx.y * GY + g / GX;
+    if (tx < ntx && ty < nty)
+      forward_tile<RT, PACKED, K, SX, SY>(tx, ty, b, src, R, src_view_stride, setup, W, H, cx, cy, rfx,
+                                          rfy, threshold, vec_ok, depth);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // backward.  grid = (macro-tiles x, macro-tiles y, views)
 // ---------------------------------------------------------------------------------------------
+struct BackwardLds {
+  unsigned long long run_val[kRunSlots * kRunLen];
+  int run_key[kRunSlots];
+  float wave_part[4][8];
+  int tile_max_bits;
+};
+
+// One tile of the backward.  Every return is workgroup-uniform; the caller puts a barrier
+// between tiles (the LDS tables are reused).
 template <int RT, int SX, int SY>
-__global__ __launch_bounds__(kBlock) void render_backward_kernel(
+__device__ __forceinline__ void backward_tile(
+    BackwardLds& lds, int tile_x, int tile_y, int ntx, int nty, int b,
     const float* __restrict__ grad_depth, const float* __restrict__ depth,
     const float* __restrict__ sdf, int R, long long sdf_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx, float rfy,
     int sdf_grad_mode, float* __restrict__ g_sdf, long long g_sdf_view_stride,
     float* __restrict__ partials) {
-  __shared__ unsigned long long run_val[kRunSlots * kRunLen];
-  __shared__ int run_key[kRunSlots];
-  __shared__ float wave_part[4][8];
-  __shared__ int tile_max_bits;
+  unsigned long long* run_val = lds.run_val;
+  int* run_key = lds.run_key;
+  float (*wave_part)[8] = lds.wave_part;
+  int& tile_max_bits = lds.tile_max_bits;
 
   constexpr int kSubs = SX * SY, kTileW = SX * kSubW, kTileH = SY * kSubH;
   const int Rr = RT > 0 ? RT : R;
-  const int b = blockIdx.z;
-  const int px0 = blockIdx.x * kTileW, py0 = blockIdx.y * kTileH;
+  const int px0 = tile_x * kTileW, py0 = tile_y * kTileH;
   const ViewSetup& s = setup[b];
   const Rect rc{s.rect[0], s.rect[1], s.rect[2], s.rect[3]};
   if (!overlaps(rc, px0, py0, kTileW, kTileH)) return;  // depth is 0 there by construction
@@ -268,7 +301,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const float* zimg = depth + (size_t)b * H * W;
   const float* gimg = grad_depth + (size_t)b * H * W;
-  float* part = partials + ((size_t)b * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+  float* part = partials + (((size_t)b * nty + tile_y) * ntx + tile_x) * 8;
 
   // all depth reads of the macro-tile up front (independent loads), then the upstream
   // gradient of the hit pixels only
@@ -380,7 +413,11 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
                              fmaxf(fmaxf(fabsf(w4), fabsf(w5)), fmaxf(fabsf(w6), fabsf(w7))));
     if (fixed_ok && wmax * to_fixed < 3.5e13f /* 2^45 */) {
       const float wk[8] = {w0, w1, w2, w3, w4, w5, w6, w7};
+#ifdef SDFR_ABLATE_NO_SCATTER  // timing-only build
+      acc[7] += 1e-30f * (w0 + w1 + w2 + w3 + w4 + w5 + w6 + w7 + to_fixed);
+#else
       add_cell(run_key, run_val, gvol, c.lin, Rr, wk, to_fixed);
+#endif
     } else {
       float* g0 = gvol + c.lin;
       atomicAdd(g0, w0);                atomicAdd(g0 + 1, w1);
@@ -406,6 +443,27 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     const long long q = (long long)run_val[i];
     const int lin = key * kRunLen + (i & 7);
     if (key >= 0 && q != 0 && lin < nvox) atomicAdd(gvol + lin, (float)q * from_fixed);
+  }
+}
+
+template <int RT, int SX, int SY, int GX, int GY>
+__global__ __launch_bounds__(kBlock) void render_backward_kernel(
+    const float* __restrict__ grad_depth, const float* __restrict__ depth,
+    const float* __restrict__ sdf, int R, long long sdf_view_stride,
+    const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, float cx, float cy,
+    float rfx, float rfy, int sdf_grad_mode, float* __restrict__ g_sdf,
+    long long g_sdf_view_stride, float* __restrict__ partials) {
+  __shared__ BackwardLds lds;
+  const int b = blockIdx.z;
+#pragma unroll 1
+  for (int g = 0; g < GX * GY; ++g) {  // a group of tiles per workgroup, as in the forward
+    const int tx = blockIdx.x * GX + g % GX, ty = blockIdx.y * GY + g / GX;
+    if (tx < ntx && ty < nty) {
+      backward_tile<RT, SX, SY>(lds, tx, ty, ntx, nty, b, grad_depth, depth, sdf, R, sdf_view_stride,
+                                setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride,
+                                partials);
+      __syncthreads();
+    }
   }
 }
 
@@ -516,16 +574,22 @@ extern "C" int sdfr_render_forward(const float* sdf, int R, long long sdf_view_s
   }
   const TileGeom geom = forward_geom(B, W, H);
   const bool macro = geom.sx == kMacroTile.sx;
-  const dim3 grid((unsigned)geom.nx(W), (unsigned)geom.ny(H), (unsigned)B);
+  const int ntx = geom.nx(W), nty = geom.ny(H);
+  const dim3 grid_tile((unsigned)ntx, (unsigned)nty, (unsigned)B);
+  const dim3 grid_group((unsigned)((ntx + SDFR_GROUP_X - 1) / SDFR_GROUP_X),
+                        (unsigned)((nty + SDFR_GROUP_Y - 1) / SDFR_GROUP_Y), (unsigned)B);
   const float rfx = (float)(1.0 / (double)fx), rfy = (float)(1.0 / (double)fy);
   const int vec_ok = (W % 4 == 0) && ((uintptr_t)depth % 16 == 0);
-#define SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, SX, SY)                                               \
-  hipLaunchKernelGGL((render_forward_kernel<RT, PK, 1, SX, SY>), grid, dim3(kBlock), 0, st, SRC, R,  \
-                     STRIDE, setup, W, H, cx, cy, rfx, rfy, threshold, vec_ok, depth)
+#define SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, SX, SY, GX, GY, GRID)                                 \
+  hipLaunchKernelGGL((render_forward_kernel<RT, PK, 1, SX, SY, GX, GY>), GRID, dim3(kBlock), 0, st,  \
+                     SRC, R, STRIDE, setup, W, H, ntx, nty, cx, cy, rfx, rfy, threshold, vec_ok, depth)
 #define SDFR_LAUNCH_FWD(RT, PK, SRC, STRIDE)                                                         \
   do {                                                                                               \
-    if (macro) SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, SDFR_MACRO_SX, SDFR_MACRO_SY);                                         \
-    else SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, 1, 1);                                               \
+    if (macro)                                                                                       \
+      SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, SDFR_MACRO_SX, SDFR_MACRO_SY, SDFR_GROUP_X,             \
+                        SDFR_GROUP_Y, grid_group);                                                   \
+    else                                                                                             \
+      SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, 1, 1, 1, 1, grid_tile);                                 \
   } while (0)
   if (packed) {
     if (R == 64) SDFR_LAUNCH_FWD(64, true, cells, 0LL); else SDFR_LAUNCH_FWD(0, true, cells, 0LL);
@@ -581,16 +645,20 @@ extern "C" int sdfr_render_backward(const float* grad_depth, const float* depth,
   const TileGeom geom = backward_geom(B, W, H);
   const bool macro = geom.sx == kMacroTile.sx;
   const int ntx = geom.nx(W), nty = geom.ny(H);
-  const dim3 grid((unsigned)ntx, (unsigned)nty, (unsigned)B);
+  const dim3 grid_tile((unsigned)ntx, (unsigned)nty, (unsigned)B);
+  const dim3 grid_group((unsigned)((ntx + SDFR_GROUP_X - 1) / SDFR_GROUP_X),
+                        (unsigned)((nty + SDFR_GROUP_Y - 1) / SDFR_GROUP_Y), (unsigned)B);
   const float rfx = (float)(1.0 / (double)fx), rfy = (float)(1.0 / (double)fy);
-#define SDFR_LAUNCH_BWD(RT, SX, SY)                                                                  \
-  hipLaunchKernelGGL((render_backward_kernel<RT, SX, SY>), grid, dim3(kBlock), 0, st, grad_depth,    \
-                     depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode,   \
-                     g_sdf, g_sdf_view_stride, partials)
+#define SDFR_LAUNCH_BWD(RT, SX, SY, GX, GY, GRID)                                                    \
+  hipLaunchKernelGGL((render_backward_kernel<RT, SX, SY, GX, GY>), GRID, dim3(kBlock), 0, st,        \
+                     grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, ntx, nty, cx, cy, rfx, \
+                     rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials)
   if (R == 64) {
-    if (macro) SDFR_LAUNCH_BWD(64, SDFR_MACRO_SX, SDFR_MACRO_SY); else SDFR_LAUNCH_BWD(64, 1, 1);
+    if (macro) SDFR_LAUNCH_BWD(64, SDFR_MACRO_SX, SDFR_MACRO_SY, SDFR_GROUP_X, SDFR_GROUP_Y, grid_group);
+    else SDFR_LAUNCH_BWD(64, 1, 1, 1, 1, grid_tile);
   } else {
-    if (macro) SDFR_LAUNCH_BWD(0, SDFR_MACRO_SX, SDFR_MACRO_SY); else SDFR_LAUNCH_BWD(0, 1, 1);
+    if (macro) SDFR_LAUNCH_BWD(0, SDFR_MACRO_SX, SDFR_MACRO_SY, SDFR_GROUP_X, SDFR_GROUP_Y, grid_group);
+    else SDFR_LAUNCH_BWD(0, 1, 1, 1, 1, grid_tile);
   }
 #undef SDFR_LAUNCH_BWD
   hipLaunchKernelGGL(pose_reduce_kernel, dim3(B), dim3(64), 0, st, partials, setup, ntx, nty,
