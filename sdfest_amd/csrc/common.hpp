@@ -36,7 +36,7 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) {
 }
 
 // Per-view record written once by the set-up kernel and then read through the
-// scalar cache by every workgroup of that view (128 bytes = one s_load_dwordx16 x2).
+// scalar cache by every workgroup of that view.
 struct alignas(128) ViewSetup {
   float rot[9];   // R(q), row-major: object -> camera
   float e[3];     // R^T p  (object-frame position of the camera origin is -e)
@@ -46,9 +46,12 @@ struct alignas(128) ViewSetup {
   float scale;    // 1 / inv_scale
   float isc;      // inv_scale
   int rect[4];    // conservative screen bounds of the OBB: x0, y0, x1, y1 (pixels, half-open)
-  float pad[4];
+  float ep[3];    // e + scale  (slab planes, object frame)
+  float em[3];    // e - scale
+  float dgk;      // inv_scale * (R-1)/2: object-frame direction -> grid-space direction
+  float pad[29];
 };
-static_assert(sizeof(ViewSetup) == 128, "ViewSetup must stay 128 bytes");
+static_assert(sizeof(ViewSetup) == 256, "ViewSetup must stay 256 bytes");
 
 // A workgroup (4 waves) owns a tile of SX x SY sub-tiles of 32 x 8 pixels and walks them; inside
 // a sub-tile each wave is an 8 x 8 pixel patch.  Two geometries are compiled: the 64 x 32

@@ -51,7 +51,9 @@ __device__ __forceinline__ void gather_cell(const float* __restrict__ src, int R
   const float by = fminf(fmaxf(floorf(gy), 0.0f), top);
   const float bz = fminf(fmaxf(floorf(gz), 0.0f), top);
   c.ox = gx - bx; c.oy = gy - by; c.oz = gz - bz;
-  const int lin = ((int)bx * Rr + (int)by) * Rr + (int)bz;
+  // linear index formed in float (exact: < 2^24 for R <= 256) -- one conversion instead of three
+  const int lin = (Rr <= 256) ? (int)fmaf(fmaf(bx, (float)Rr, by), (float)Rr, bz)
+                              : ((int)bx * Rr + (int)by) * Rr + (int)bz;
   c.lin = lin;
   if (PACKED) {
     const float4* rec = reinterpret_cast<const float4*>(src) + (size_t)(unsigned)lin;
@@ -67,6 +69,28 @@ __device__ __forceinline__ void gather_cell(const float* __restrict__ src, int R
     c.v[0] = p00.lo; c.v[1] = p00.hi; c.v[2] = p01.lo; c.v[3] = p01.hi;
     c.v[4] = p10.lo; c.v[5] = p10.hi; c.v[6] = p11.lo; c.v[7] = p11.hi;
   }
+}
+
+// The march's fetch: the two face records of the cell through a buffer descriptor -- one 32-bit
+// byte offset per lane, the second record R^2 records further on as a scalar offset, and the
+// hardware range check (an out-of-range offset reads 0 instead of faulting).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <int RT>
+__device__ __forceinline__ void gather_cell_records(__amdgpu_buffer_rsrc_t recs, int R, float gx,
+                                                    float gy, float gz, Cell& c) {
+  const int Rr = RT > 0 ? RT : R;
+  const float top = (float)(Rr - 2);
+  const float bx = fminf(fmaxf(floorf(gx), 0.0f), top);
+  const float by = fminf(fmaxf(floorf(gy), 0.0f), top);
+  const float bz = fminf(fmaxf(floorf(gz), 0.0f), top);
+  c.ox = gx - bx; c.oy = gy - by; c.oz = gz - bz;
+  const int lin = (Rr <= 256) ? (int)fmaf(fmaf(bx, (float)Rr, by), (float)Rr, bz)
+                              : ((int)bx * Rr + (int)by) * Rr + (int)bz;
+  c.lin = lin;
+  const i32x4 a = __builtin_amdgcn_raw_buffer_load_b128(recs, lin * 16, 0, 0);
+  const i32x4 b = __builtin_amdgcn_raw_buffer_load_b128(recs, lin * 16, Rr * Rr * 16, 0);
+  c.v[0] = __int_as_float(a.x); c.v[1] = __int_as_float(a.y); c.v[2] = __int_as_float(a.z); c.v[3] = __int_as_float(a.w);
+  c.v[4] = __int_as_float(b.x); c.v[5] = __int_as_float(b.y); c.v[6] = __int_as_float(b.z); c.v[7] = __int_as_float(b.w);
 }
 
 // trilinear value, lerp order x, y, z (sdf_renderer_cuda.cu:231-238)

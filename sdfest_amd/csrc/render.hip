@@ -95,7 +95,12 @@ __global__ void view_setup_kernel(const float* __restrict__ pos, const float* __
     x0 = (int)fx0; x1 = (int)fx1; y0 = (int)fy0; y1 = (int)fy1;
   }
   s.rect[0] = x0; s.rect[1] = y0; s.rect[2] = x1; s.rect[3] = y1;
-  s.pad[0] = s.pad[1] = s.pad[2] = s.pad[3] = 0.0f;
+  for (int k = 0; k < 3; ++k) {
+    s.ep[k] = s.e[k] + scale;
+    s.em[k] = s.e[k] - scale;
+  }
+  s.dgk = isc * h;
+  for (int k = 0; k < 29; ++k) s.pad[k] = 0.0f;
   out[b] = s;
 }
 
@@ -166,11 +171,14 @@ __device__ __forceinline__ void forward_tile(
   }
 
   const int wave = tid >> 6, lane = tid & 63;
-  const int Rr = RT > 0 ? RT : R;
   const float scale = s.scale;
-  const float kgrid = s.isc * (0.5f * (float)(Rr - 1));
+  const float kgrid = s.dgk;
   const float ogx = s.og[0], ogy = s.og[1], ogz = s.og[2];
   const float* vol = src + (size_t)b * src_view_stride;
+  const int Rr = RT > 0 ? RT : R;
+  // record array as a buffer resource (PACKED only; R <= 128 so the size fits 32 bits)
+  const __amdgpu_buffer_rsrc_t recs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(vol), 0, PACKED ? Rr * Rr * Rr * 16 : 0, 0x00020000);
 
   for (int grp = 0; grp < kSubs; grp += K) {
     float t[K], t_far[K], dgx[K], dgy[K], dgz[K], ndz[K], result[K];
@@ -189,29 +197,33 @@ __device__ __forceinline__ void forward_tile(
       t[k] = 0.0f; t_far[k] = 0.0f; dgx[k] = dgy[k] = dgz[k] = 0.0f; ndz[k] = 0.0f;
       // wave-uniform: does this wave's 8x8 patch touch the rectangle at all?
       if (overlaps(rc, sx + wave * 8, sy, 8, 8)) {
-        const bool in_rect = inside && col >= rc.x0 && col < rc.x1 && row >= rc.y0 && row < rc.y1;
-        const V3 d = pixel_ray(row, col, cx, cy, rfx, rfy);
-        const V3 dobj = rot_t(s, d);
-        // slab test in the object frame: the cube is axis-aligned there, its centre is at +e
-        // from the ray origin and f_i = dobj_i.  sdf_renderer_cuda.cu:156-194, branch-free.
+        // unit ray (cu:137-154), rotated into the object frame with d.z = -1 folded in
+        const float dx = ((float)col + 0.5f - cx) * rfx;
+        const float dy = -((float)row + 0.5f - cy) * rfy;
+        const float inv_len = __builtin_amdgcn_rsqf(fmaf(dx, dx, fmaf(dy, dy, 1.0f)));
+        const float ux = fmaf(s.rot[0], dx, fmaf(s.rot[3], dy, -s.rot[6]));
+        const float uy = fmaf(s.rot[1], dx, fmaf(s.rot[4], dy, -s.rot[7]));
+        const float uz = fmaf(s.rot[2], dx, fmaf(s.rot[5], dy, -s.rot[8]));
+        const float dv[3] = {ux * inv_len, uy * inv_len, uz * inv_len};
+        // Slab test in the object frame (the cube is axis-aligned there, its centre at +e from
+        // the ray origin, f_i = dobj_i): same accept/reject as cu:156-194.  A ray parallel to a
+        // slab (f = 0) needs no special case: 1/f = +-inf puts both plane distances at the same
+        // infinity when the origin is outside the slab (-> t_near > t_far or t_far < 0) and at
+        // opposite infinities when it is inside (-> the axis does not constrain the interval).
+        // Pixels outside the screen rectangle fail this test by construction of the rectangle.
         float t_near = -1e-10f, tf = 1e10f;
-        bool miss = !in_rect;
-        const float dv[3] = {dobj.x, dobj.y, dobj.z};
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-          const float e = s.e[a], f = dv[a];
-          const bool big = fabsf(f) > 1e-20f;
-          const float inv = __builtin_amdgcn_rcpf(f);
-          const float ta = (e + scale) * inv, tb = (e - scale) * inv;
-          t_near = big ? fmaxf(t_near, fminf(ta, tb)) : t_near;
-          tf = big ? fminf(tf, fmaxf(ta, tb)) : tf;
-          miss = miss || (!big && (-e > scale || -e < -scale));
+          const float inv = __builtin_amdgcn_rcpf(dv[a]);
+          const float ta = s.ep[a] * inv, tb = s.em[a] * inv;
+          t_near = fmaxf(t_near, fminf(ta, tb));
+          tf = fminf(tf, fmaxf(ta, tb));
         }
-        miss = miss || (t_near > tf) || (tf < 0.0f);
+        const bool miss = !inside || (t_near > tf) || (tf < 0.0f);
         t[k] = fmaxf(t_near, 0.0f);
         t_far[k] = tf;
-        dgx[k] = dobj.x * kgrid; dgy[k] = dobj.y * kgrid; dgz[k] = dobj.z * kgrid;
-        ndz[k] = -d.z;
+        dgx[k] = dv[0] * kgrid; dgy[k] = dv[1] * kgrid; dgz[k] = dv[2] * kgrid;
+        ndz[k] = inv_len;  // -d.z
         active[k] = !miss && (t[k] < tf);
         any = any || active[k];
       }
@@ -222,9 +234,14 @@ __device__ __forceinline__ void forward_tile(
       // issue every ray's record loads before touching any of the data; a finished ray is
       // parked on its last (valid) point and its result is ignored
 #pragma unroll
-      for (int k = 0; k < K; ++k)
-        gather_cell<RT, PACKED>(vol, R, fmaf(t[k], dgx[k], ogx), fmaf(t[k], dgy[k], ogy),
-                                fmaf(t[k], dgz[k], ogz), c[k]);
+      for (int k = 0; k < K; ++k) {
+        if (PACKED)
+          gather_cell_records<RT>(recs, R, fmaf(t[k], dgx[k], ogx), fmaf(t[k], dgy[k], ogy),
+                                  fmaf(t[k], dgz[k], ogz), c[k]);
+        else
+          gather_cell<RT, false>(vol, R, fmaf(t[k], dgx[k], ogx), fmaf(t[k], dgy[k], ogy),
+                                 fmaf(t[k], dgz[k], ogz), c[k]);
+      }
       ++n;
       any = false;
 #pragma unroll
