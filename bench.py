@@ -143,9 +143,13 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if N > 1:
+    # under torch.distributed.run (RANK set) the collective path is taken even at world size 1,
+    # so a 1-GPU torchrun exercises exactly the code the multi-GPU runs execute
+    use_dist = N > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=N, device_id=device)
 
     from sdfest_amd import BatchRenderPlan, Camera
@@ -165,11 +169,11 @@ def main():
         plan.backward(g, sdf, pos, quat, isc)
         if ev:
             ev[2].record()
-        if N > 1:
-            allreduce_shared_gradients(plan.g_sdf)
+        if use_dist:
+            allreduce_shared_gradients(plan.g_sdf)   # the one exchange of the step (RCCL)
 
     def barrier():
-        if N > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -183,7 +187,7 @@ def main():
         step(events[k])
     barrier()
     elapsed = time.perf_counter() - t0
-    if N > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -240,7 +244,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(sdf_np, poses_np, W, H, thr, sample)
             line["speedup_vs_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
-    if N > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

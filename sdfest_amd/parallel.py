@@ -36,7 +36,7 @@ def allreduce_shared_gradients(g_sdf: torch.Tensor,
     ride in the same bucket so the step has exactly one collective.
     """
     dist = _dist()
-    if dist is None or dist.get_world_size(group) == 1:
+    if dist is None:
         return g_sdf
     if not extra:
         dist.all_reduce(g_sdf, op=dist.ReduceOp.SUM, group=group)
