@@ -166,6 +166,47 @@ SDFR_API int sdfr_decoder_backward_latent(const sdfr_decoder* decoder, const flo
                                  const float* grad_out, int N, float* g_z, void* workspace,
                                  size_t workspace_bytes, void* stream);
 
+/* ---- glue of one render-and-compare iteration (SDFPipeline.__call__, simple_setup.py:408-470) --- */
+/* Small kernels that replace the reference's per-iteration torch-op soup so that a whole
+ * iteration is a fixed launch sequence (graph-capturable).  All pointers are device pointers. */
+
+/* :411, :424-430 -- world-frame pose (position[3], orientation[4] un-normalised, scale[1]) to
+ * the V camera frames: pos_c [V][3], quat_c [V][4], inv_scale [V] (= 1/scale), scale_v [V]. */
+SDFR_API int sdfr_pose_to_views(const float* position, const float* orientation, const float* scale,
+                       const float* cam_pos, const float* cam_quat, int V, float* pos_c,
+                       float* quat_c, float* inv_scale, float* scale_v, int device, void* stream);
+
+/* reverse of the above: per-view gradients from the renderer (ga_*: w.r.t. pos_c, quat_c,
+ * inv_scale) and from the sampler (gb_*: w.r.t. pos_c, quat_c, scale), any of which may be NULL,
+ * to g_position[3], g_orientation[4] (through the normalisation), g_scale[1]. */
+SDFR_API int sdfr_views_to_pose_grad(const float* orientation, const float* scale, const float* cam_quat,
+                            int V, const float* ga_pos, const float* ga_quat,
+                            const float* ga_inv_scale, const float* gb_pos, const float* gb_quat,
+                            const float* gb_scale, float* g_position, float* g_orientation,
+                            float* g_scale, int device, void* stream);
+
+/* :125-131 -- loss[v] = mean |estimate - target| over (target > 0) & (estimate > 0) (NaN when the
+ * overlap is empty, like torch.mean of an empty selection); grad_estimate = weight * d loss / d
+ * estimate.  Deterministic two-pass reduction. */
+SDFR_API size_t sdfr_depth_l1_workspace_bytes(int V, int W, int H);
+SDFR_API int sdfr_depth_l1_loss(const float* estimate, const float* target, int V, int W, int H,
+                       float weight, float* loss, float* grad_estimate, void* workspace,
+                       size_t workspace_bytes, int device, void* stream);
+
+/* :144 -- loss[v] = mean |values| over view v's points, grad_values = weight * sign / M_v */
+SDFR_API int sdfr_pc_l1_loss(const float* values, const int* offsets, int V, int max_view_points,
+                    float weight, float* loss, float* grad_values, int device, void* stream);
+
+/* a += b  (sums the renderer's and the sampler's d/dSDF) */
+SDFR_API int sdfr_add_inplace(float* a, const float* b, size_t n, int device, void* stream);
+
+/* :400-406, :458-462 -- one torch.optim.Adam step (default betas/eps) on params laid out
+ * [position 3 | orientation 4 | scale 1 | latent ...], then orientation /= |orientation|.
+ * step[0] (device int) is the number of steps taken so far and is incremented. */
+SDFR_API int sdfr_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                   int* step, int n_params, float lr_position, float lr_orientation,
+                   float lr_scale, float lr_latent, int update_latent, int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,14 @@ SIGNATURES = {
     "sdfr_decoder_forward": (c_int, [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_sz, c_fp]),
     "sdfr_decoder_backward_workspace_bytes": (c_sz, [c_fp, c_int]),
     "sdfr_decoder_backward_latent": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_sz, c_fp]),
+    "sdfr_pose_to_views": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp]),
+    "sdfr_views_to_pose_grad": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                        c_fp, c_fp, c_fp, c_int, c_fp]),
+    "sdfr_depth_l1_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
+    "sdfr_depth_l1_loss": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_f, c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),
+    "sdfr_pc_l1_loss": (c_int, [c_fp, c_fp, c_int, c_int, c_f, c_fp, c_fp, c_int, c_fp]),
+    "sdfr_add_inplace": (c_int, [c_fp, c_fp, c_sz, c_int, c_fp]),
+    "sdfr_adam_step": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_f, c_f, c_f, c_f, c_int, c_int, c_fp]),
 }
 
 

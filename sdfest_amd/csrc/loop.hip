@@ -1,0 +1,324 @@
+// loop.hip -- the glue of one render-and-compare iteration as a handful of tiny kernels, so that
+// the whole iteration (decoder, batched render, batched sampler, losses, gradient chain, Adam) is
+// a fixed sequence of launches on one stream with no host round trip and can be replayed as a
+// hipGraph.  What it restates (sdfest/estimation/simple_setup.py):
+//   :411          norm_orientation = orientation / |orientation|
+//   :424-430      per view: q_w2c = conj(camera_orientation); position_c = R(q_w2c)(position -
+//                 camera_position); orientation_c = q_w2c * norm_orientation
+//   :125-131      loss_depth = mean |estimate - input| over (input > 0) & (estimate > 0)
+//   :144          loss_pc = mean |pc_loss(...)|
+//   :448-454      loss = depth_weight * sum_v loss_depth + pc_weight * sum_v loss_pc
+//   :400-406,:458 Adam (torch defaults) with lr 1e-3 / 1e-2 / 1e-3 / 1e-2 for position /
+//                 orientation / scale / latent;  :462 orientation /= |orientation|
+// and the reverse-mode chain of the first two items (what autograd does in the reference).
+#include "common.hpp"
+#include "device.hpp"
+
+namespace sdfr {
+namespace {
+
+__device__ __forceinline__ void quat_mul(const float* a, const float* b, float* o) {
+  const float ax = a[0], ay = a[1], az = a[2], aw = a[3], bx = b[0], by = b[1], bz = b[2], bw = b[3];
+  o[0] = aw * bx + ax * bw + ay * bz - az * by;
+  o[1] = aw * by - ax * bz + ay * bw + az * bx;
+  o[2] = aw * bz + ax * by - ay * bx + az * bw;
+  o[3] = aw * bw - ax * bx - ay * by - az * bz;
+}
+
+// rotation matrix of a unit quaternion (row-major)
+__device__ __forceinline__ void quat_matrix(const float* q, float* m) {
+  const float x = q[0], y = q[1], z = q[2], w = q[3];
+  m[0] = 1 - 2 * (y * y + z * z); m[1] = 2 * (x * y - w * z);     m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z);     m[4] = 1 - 2 * (x * x + z * z); m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y);     m[7] = 2 * (y * z + w * x);     m[8] = 1 - 2 * (x * x + y * y);
+}
+
+// The reference rotates with quaternion_apply = q * (v,0) * conj(q) (quaternion_utils.py:36-54),
+// which for a non-unit q scales by |q|^2; camera orientations are unit quaternions, for which
+// this equals the matrix product.  The gradient chain below assumes unit camera quaternions.
+__global__ void pose_to_views_kernel(const float* __restrict__ position,
+                                     const float* __restrict__ orientation,
+                                     const float* __restrict__ scale,
+                                     const float* __restrict__ cam_pos,
+                                     const float* __restrict__ cam_quat, int V,
+                                     float* __restrict__ pos_c, float* __restrict__ quat_c,
+                                     float* __restrict__ inv_scale, float* __restrict__ scale_v) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const float q[4] = {orientation[0], orientation[1], orientation[2], orientation[3]};
+  const float inv_n = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const float nq[4] = {q[0] * inv_n, q[1] * inv_n, q[2] * inv_n, q[3] * inv_n};
+  const float qc[4] = {-cam_quat[4 * v], -cam_quat[4 * v + 1], -cam_quat[4 * v + 2], cam_quat[4 * v + 3]};
+  float m[9];
+  quat_matrix(qc, m);
+  const float dx = position[0] - cam_pos[3 * v], dy = position[1] - cam_pos[3 * v + 1],
+              dz = position[2] - cam_pos[3 * v + 2];
+  pos_c[3 * v] = m[0] * dx + m[1] * dy + m[2] * dz;
+  pos_c[3 * v + 1] = m[3] * dx + m[4] * dy + m[5] * dz;
+  pos_c[3 * v + 2] = m[6] * dx + m[7] * dy + m[8] * dz;
+  quat_mul(qc, nq, quat_c + 4 * v);
+  inv_scale[v] = 1.0f / scale[0];
+  scale_v[v] = scale[0];
+}
+
+// one thread: sum the per-view gradients back to the world-frame parameters
+__global__ void views_to_pose_grad_kernel(const float* __restrict__ orientation,
+                                          const float* __restrict__ scale,
+                                          const float* __restrict__ cam_quat, int V,
+                                          const float* __restrict__ ga_pos,
+                                          const float* __restrict__ ga_quat,
+                                          const float* __restrict__ ga_inv_scale,
+                                          const float* __restrict__ gb_pos,
+                                          const float* __restrict__ gb_quat,
+                                          const float* __restrict__ gb_scale,
+                                          float* __restrict__ g_position,
+                                          float* __restrict__ g_orientation,
+                                          float* __restrict__ g_scale) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const float q[4] = {orientation[0], orientation[1], orientation[2], orientation[3]};
+  const float inv_n = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const float nq[4] = {q[0] * inv_n, q[1] * inv_n, q[2] * inv_n, q[3] * inv_n};
+  float gp[3] = {0, 0, 0}, gn[4] = {0, 0, 0, 0}, gs = 0.0f;
+  const float s = scale[0];
+  for (int v = 0; v < V; ++v) {
+    const float a[4] = {-cam_quat[4 * v], -cam_quat[4 * v + 1], -cam_quat[4 * v + 2], cam_quat[4 * v + 3]};
+    float m[9];
+    quat_matrix(a, m);
+    float gpc[3], gqc[4];
+    for (int k = 0; k < 3; ++k) gpc[k] = (ga_pos ? ga_pos[3 * v + k] : 0.0f) + (gb_pos ? gb_pos[3 * v + k] : 0.0f);
+    for (int k = 0; k < 4; ++k) gqc[k] = (ga_quat ? ga_quat[4 * v + k] : 0.0f) + (gb_quat ? gb_quat[4 * v + k] : 0.0f);
+    // position_c = M (p - c):  g_p += M^T g
+    gp[0] += m[0] * gpc[0] + m[3] * gpc[1] + m[6] * gpc[2];
+    gp[1] += m[1] * gpc[0] + m[4] * gpc[1] + m[7] * gpc[2];
+    gp[2] += m[2] * gpc[0] + m[5] * gpc[1] + m[8] * gpc[2];
+    // orientation_c = a * nq = L(a) nq:  g_nq += L(a)^T g
+    const float ax = a[0], ay = a[1], az = a[2], aw = a[3];
+    gn[0] += aw * gqc[0] + az * gqc[1] - ay * gqc[2] - ax * gqc[3];
+    gn[1] += -az * gqc[0] + aw * gqc[1] + ax * gqc[2] - ay * gqc[3];
+    gn[2] += ay * gqc[0] - ax * gqc[1] + aw * gqc[2] - az * gqc[3];
+    gn[3] += ax * gqc[0] + ay * gqc[1] + az * gqc[2] + aw * gqc[3];
+    // inv_scale = 1/scale (render), scale itself (sampler)
+    gs += (ga_inv_scale ? -ga_inv_scale[v] / (s * s) : 0.0f) + (gb_scale ? gb_scale[v] : 0.0f);
+  }
+  const float d = nq[0] * gn[0] + nq[1] * gn[1] + nq[2] * gn[2] + nq[3] * gn[3];
+  for (int k = 0; k < 3; ++k) g_position[k] = gp[k];
+  for (int k = 0; k < 4; ++k) g_orientation[k] = (gn[k] - nq[k] * d) * inv_n;
+  g_scale[0] = gs;
+}
+
+constexpr int kLossChunk = 4096;  // pixels per workgroup of the depth-loss reduction
+
+// pass 1: per (view, chunk) the sum of |est - tgt| and the count over the overlap mask
+__global__ __launch_bounds__(256) void depth_l1_partial_kernel(const float* __restrict__ est,
+                                                               const float* __restrict__ tgt,
+                                                               int npix, int nchunk,
+                                                               float* __restrict__ partial) {
+  __shared__ float ssum[4], scnt[4];
+  const int v = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const size_t base = (size_t)v * npix;
+  float sum = 0.0f, cnt = 0.0f;
+  for (int i = chunk * kLossChunk + tid; i < min(npix, (chunk + 1) * kLossChunk); i += 256) {
+    const float e = est[base + i], t = tgt[base + i];
+    if (t > 0.0f && e > 0.0f) {
+      sum += fabsf(e - t);
+      cnt += 1.0f;
+    }
+  }
+  sum = wave_sum(sum);
+  cnt = wave_sum(cnt);
+  if ((tid & 63) == 0) { ssum[tid >> 6] = sum; scnt[tid >> 6] = cnt; }
+  __syncthreads();
+  if (tid == 0) {
+    partial[((size_t)v * nchunk + chunk) * 2] = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+    partial[((size_t)v * nchunk + chunk) * 2 + 1] = (scnt[0] + scnt[1]) + (scnt[2] + scnt[3]);
+  }
+}
+
+// pass 2: loss[v] = sum / count (NaN for an empty overlap, as torch.mean of an empty selection);
+// grad_est = weight * sign(est - tgt) / count on the overlap, 0 elsewhere
+__global__ __launch_bounds__(256) void depth_l1_grad_kernel(const float* __restrict__ est,
+                                                            const float* __restrict__ tgt, int npix,
+                                                            int nchunk,
+                                                            const float* __restrict__ partial,
+                                                            float weight, float* __restrict__ loss,
+                                                            float* __restrict__ grad) {
+  const int v = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  float sum = 0.0f, cnt = 0.0f;
+  for (int c = 0; c < nchunk; ++c) {  // same order in every thread: one value per view
+    sum += partial[((size_t)v * nchunk + c) * 2];
+    cnt += partial[((size_t)v * nchunk + c) * 2 + 1];
+  }
+  if (chunk == 0 && tid == 0) loss[v] = sum / cnt;
+  const float k = cnt > 0.0f ? weight / cnt : 0.0f;
+  const size_t base = (size_t)v * npix;
+  for (int i = chunk * kLossChunk + tid; i < min(npix, (chunk + 1) * kLossChunk); i += 256) {
+    const float e = est[base + i], t = tgt[base + i];
+    float g = 0.0f;
+    if (t > 0.0f && e > 0.0f) g = (e > t) ? k : ((e < t) ? -k : 0.0f);
+    grad[base + i] = g;
+  }
+}
+
+// one workgroup per view: loss[v] = mean |val| over the view's points; grad = weight*sign/M_v
+__global__ __launch_bounds__(256) void pc_l1_kernel(const float* __restrict__ val,
+                                                    const int* __restrict__ offsets, int n_single,
+                                                    float weight, float* __restrict__ loss,
+                                                    float* __restrict__ grad) {
+  __shared__ float ssum[4];
+  const int v = blockIdx.x, tid = threadIdx.x;
+  const int begin = offsets ? offsets[v] : 0, end = offsets ? offsets[v + 1] : n_single;
+  float sum = 0.0f;
+  for (int i = begin + tid; i < end; i += 256) sum += fabsf(val[i]);
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) ssum[tid >> 6] = sum;
+  __syncthreads();
+  const float m = (float)(end - begin);
+  if (tid == 0) loss[v] = ((ssum[0] + ssum[1]) + (ssum[2] + ssum[3])) / m;
+  const float k = weight / m;
+  for (int i = begin + tid; i < end; i += 256) {
+    const float x = val[i];
+    grad[i] = x > 0.0f ? k : (x < 0.0f ? -k : 0.0f);
+  }
+}
+
+__global__ void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) a[i] += b[i];
+}
+
+// Adam with torch.optim.Adam's defaults (betas 0.9/0.999, eps 1e-8, no weight decay, no amsgrad):
+//   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// One thread per scalar of the four groups laid out [position 3 | orientation 4 | scale 1 | latent L];
+// `step` lives on the device so that a captured graph advances it on every replay.
+__global__ void adam_step_kernel(float* __restrict__ params, const float* __restrict__ grads,
+                                 float* __restrict__ m, float* __restrict__ v,
+                                 int* __restrict__ step, int n, float lr_pos, float lr_quat,
+                                 float lr_scale, float lr_latent, int update_latent) {
+  __shared__ float qnorm2;
+  const int i = threadIdx.x;
+  const int t = step[0] + 1;
+  if (i == 0) qnorm2 = 0.0f;
+  __syncthreads();
+  float p = 0.0f;
+  if (i < n && (i < 8 || update_latent)) {
+    const float lr = i < 3 ? lr_pos : (i < 7 ? lr_quat : (i < 8 ? lr_scale : lr_latent));
+    const float g = grads[i];
+    const float mi = 0.9f * m[i] + 0.1f * g;
+    const float vi = 0.999f * v[i] + 0.001f * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    const float bc1 = 1.0f - powf(0.9f, (float)t), bc2 = 1.0f - powf(0.999f, (float)t);
+    p = params[i] - (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + 1e-8f);
+    if (i >= 3 && i < 7) atomicAdd(&qnorm2, p * p);
+  } else if (i < n) {
+    p = params[i];
+  }
+  __syncthreads();
+  if (i < n) params[i] = (i >= 3 && i < 7) ? p / sqrtf(qnorm2) : p;  // :462 renormalise the quaternion
+  if (i == 0) step[0] = t;
+}
+
+}  // namespace
+}  // namespace sdfr
+
+using namespace sdfr;
+
+extern "C" int sdfr_pose_to_views(const float* position, const float* orientation, const float* scale,
+                                  const float* cam_pos, const float* cam_quat, int V, float* pos_c,
+                                  float* quat_c, float* inv_scale, float* scale_v, int device,
+                                  void* stream) {
+  if (V < 0) return fail(SDFR_E_INVALID, "V=%d is negative", V);
+  if (V == 0) return 0;
+  if (!position || !orientation || !scale || !cam_pos || !cam_quat || !pos_c || !quat_c || !inv_scale || !scale_v)
+    return fail(SDFR_E_NULL, "sdfr_pose_to_views: NULL pointer argument");
+  SDFR_HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(pose_to_views_kernel, dim3((V + 63) / 64), dim3(64), 0, (hipStream_t)stream, position,
+                     orientation, scale, cam_pos, cam_quat, V, pos_c, quat_c, inv_scale, scale_v);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfr_views_to_pose_grad(const float* orientation, const float* scale,
+                                       const float* cam_quat, int V, const float* ga_pos,
+                                       const float* ga_quat, const float* ga_inv_scale,
+                                       const float* gb_pos, const float* gb_quat,
+                                       const float* gb_scale, float* g_position,
+                                       float* g_orientation, float* g_scale, int device,
+                                       void* stream) {
+  if (V < 0) return fail(SDFR_E_INVALID, "V=%d is negative", V);
+  if (!orientation || !scale || !cam_quat || !g_position || !g_orientation || !g_scale)
+    return fail(SDFR_E_NULL, "sdfr_views_to_pose_grad: NULL pointer argument");
+  SDFR_HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(views_to_pose_grad_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, orientation,
+                     scale, cam_quat, V, ga_pos, ga_quat, ga_inv_scale, gb_pos, gb_quat, gb_scale,
+                     g_position, g_orientation, g_scale);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" size_t sdfr_depth_l1_workspace_bytes(int V, int W, int H) {
+  if (V <= 0 || W <= 0 || H <= 0) return 0;
+  const int nchunk = (W * H + kLossChunk - 1) / kLossChunk;
+  return (size_t)V * nchunk * 2 * sizeof(float);
+}
+
+extern "C" int sdfr_depth_l1_loss(const float* estimate, const float* target, int V, int W, int H,
+                                  float weight, float* loss, float* grad_estimate, void* workspace,
+                                  size_t workspace_bytes, int device, void* stream) {
+  if (V < 0 || W < 0 || H < 0 || V > 65535 || (long long)W * H > 0x7fffffffLL)
+    return fail(SDFR_E_INVALID, "sdfr_depth_l1_loss: bad sizes");
+  if (V == 0 || W == 0 || H == 0) return 0;
+  if (!estimate || !target || !loss || !grad_estimate || !workspace)
+    return fail(SDFR_E_NULL, "sdfr_depth_l1_loss: NULL pointer argument");
+  if (workspace_bytes < sdfr_depth_l1_workspace_bytes(V, W, H))
+    return fail(SDFR_E_WORKSPACE, "sdfr_depth_l1_loss: workspace too small");
+  SDFR_HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  const int npix = W * H, nchunk = (npix + kLossChunk - 1) / kLossChunk;
+  hipLaunchKernelGGL(depth_l1_partial_kernel, dim3(nchunk, V), dim3(256), 0, st, estimate, target, npix,
+                     nchunk, (float*)workspace);
+  hipLaunchKernelGGL(depth_l1_grad_kernel, dim3(nchunk, V), dim3(256), 0, st, estimate, target, npix,
+                     nchunk, (const float*)workspace, weight, loss, grad_estimate);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfr_pc_l1_loss(const float* values, const int* offsets, int V, int max_view_points,
+                               float weight, float* loss, float* grad_values, int device,
+                               void* stream) {
+  if (V < 0 || V > 65535 || max_view_points < 0) return fail(SDFR_E_INVALID, "sdfr_pc_l1_loss: bad sizes");
+  if (!offsets && V > 1) return fail(SDFR_E_NULL, "offsets may be NULL only for a single view");
+  if (V == 0) return 0;
+  if (!loss || (max_view_points > 0 && (!values || !grad_values)))
+    return fail(SDFR_E_NULL, "sdfr_pc_l1_loss: NULL pointer argument");
+  SDFR_HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(pc_l1_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, values, offsets,
+                     max_view_points, weight, loss, grad_values);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfr_add_inplace(float* a, const float* b, size_t n, int device, void* stream) {
+  if (n == 0) return 0;
+  if (!a || !b) return fail(SDFR_E_NULL, "sdfr_add_inplace: NULL pointer argument");
+  SDFR_HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, a, b, n);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfr_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                              int* step, int n_params, float lr_position, float lr_orientation,
+                              float lr_scale, float lr_latent, int update_latent, int device,
+                              void* stream) {
+  if (n_params < 8 || n_params > 1024) return fail(SDFR_E_INVALID, "n_params=%d out of range [8,1024]", n_params);
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !step)
+    return fail(SDFR_E_NULL, "sdfr_adam_step: NULL pointer argument");
+  SDFR_HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(adam_step_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, params, grads, exp_avg,
+                     exp_avg_sq, step, n_params, lr_position, lr_orientation, lr_scale, lr_latent,
+                     update_latent);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}

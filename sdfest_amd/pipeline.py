@@ -135,3 +135,194 @@ class RenderAndCompare:
                                 "orientation": orientation.detach().clone(),
                                 "scale": scale.detach().clone(), "latent": latent.detach().clone()})
         return position.detach(), orientation.detach(), scale.detach(), latent.detach()
+
+
+class FusedRenderAndCompare:
+    """The same optimisation as :class:`RenderAndCompare`, without autograd and without Python in
+    the loop: every iteration is one fixed sequence of launches of ``libsdfr_hip.so`` (decoder with
+    tape, pose chain, batched render, losses, batched sampler, both backward passes, gradient
+    chain, decoder VJP, Adam) captured once into a hipGraph and replayed.
+
+    Parameters live in one device buffer ``[position 3 | orientation 4 | scale 1 | latent L]``.
+    """
+
+    def __init__(self, decoder, camera: Camera, config: Dict, depth_images: torch.Tensor,
+                 camera_positions: Optional[torch.Tensor] = None,
+                 camera_orientations: Optional[torch.Tensor] = None,
+                 shape_optimization: bool = True, device="cuda"):
+        from . import _lib
+        from .differentiable_renderer import BatchRenderPlan
+        self.L = _lib.lib()
+        self.check = _lib.check
+        self.dec = decoder
+        self.cam = camera
+        self.cfg = config
+        self.dev = torch.device(device)
+        if self.dev.index is None:
+            self.dev = torch.device("cuda", torch.cuda.current_device())
+        self.shape_opt = bool(shape_optimization)
+        V, H, W = depth_images.shape
+        self.V, self.H, self.W = V, H, W
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.target = depth_images.to(**f32).contiguous()
+        self.cam_pos = (torch.zeros((V, 3), **f32) if camera_positions is None
+                        else camera_positions.to(**f32).contiguous())
+        self.cam_quat = (torch.tensor([0.0, 0.0, 0.0, 1.0], **f32).repeat(V, 1) if camera_orientations is None
+                         else camera_orientations.to(**f32).contiguous())
+        helper = RenderAndCompare(decoder, camera, config, self.dev)
+        self.points, self.offsets, lens = helper.prepare_views(self.target)
+        self.max_pts = max(lens) if lens else 0
+        self.Lz = decoder.latent_size
+        n = 8 + self.Lz
+        self.params = torch.zeros(n, **f32)
+        self.grads = torch.zeros(n, **f32)
+        self.m = torch.zeros(n, **f32)
+        self.v = torch.zeros(n, **f32)
+        self.step = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        R = decoder._volume_size
+        self.R = R
+        self.plan = BatchRenderPlan(R, V, camera, device=self.dev)
+        self.pos_c = torch.empty((V, 3), **f32)
+        self.quat_c = torch.empty((V, 4), **f32)
+        self.inv_scale = torch.empty((V,), **f32)
+        self.scale_v = torch.empty((V,), **f32)
+        self.grad_est = torch.empty((V, H, W), **f32)
+        self.loss_depth = torch.zeros((V,), **f32)
+        self.loss_pc = torch.zeros((V,), **f32)
+        N = self.points.shape[0]
+        self.vals = torch.empty((max(N, 1),), **f32)
+        self.grad_vals = torch.empty((max(N, 1),), **f32)
+        self.g_sdf_pc = torch.empty((R, R, R), **f32)
+        self.g_pos_pc = torch.empty((V, 3), **f32)
+        self.g_quat_pc = torch.empty((V, 4), **f32)
+        self.g_scale_pc = torch.empty((V,), **f32)
+        self.sdf = torch.empty((1, 1, R, R, R), **f32)
+        u8 = dict(dtype=torch.uint8, device=self.dev)
+        self.tape = torch.empty(max(self.L.sdfr_decoder_tape_bytes(decoder._h, 1), 256), **u8)
+        self.ws_dec = torch.empty(max(self.L.sdfr_decoder_workspace_bytes(decoder._h, 1),
+                                      self.L.sdfr_decoder_backward_workspace_bytes(decoder._h, 1), 256), **u8)
+        self.ws_loss = torch.empty(max(self.L.sdfr_depth_l1_workspace_bytes(V, W, H), 256), **u8)
+        self.ws_pc = torch.empty(max(self.L.sdfr_pc_loss_backward_workspace_bytes(V, self.max_pts), 256), **u8)
+        self.graph = None
+
+    # views of the parameter buffer
+    @property
+    def position(self):
+        return self.params[0:3]
+
+    @property
+    def orientation(self):
+        return self.params[3:7]
+
+    @property
+    def scale(self):
+        return self.params[7:8]
+
+    @property
+    def latent(self):
+        return self.params[8:]
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def _decode(self, st, with_tape):
+        rc = self.L.sdfr_decoder_forward(self.dec._h, self.latent.data_ptr(), 1, 0, self.sdf.data_ptr(),
+                                         self.tape.data_ptr() if with_tape else None, self.ws_dec.data_ptr(),
+                                         self.ws_dec.numel(), st)
+        self.check(rc, "sdfr_decoder_forward")
+
+    def iteration(self):
+        """One iteration of simple_setup.py:408-462 as a launch sequence on the current stream."""
+        L, d, st = self.L, self.dev.index, self._stream()
+        p = self.params.data_ptr()
+        pos, quat, scale = p, p + 12, p + 28
+        g = self.grads.data_ptr()
+        if self.shape_opt:
+            self._decode(st, True)
+        self.check(L.sdfr_pose_to_views(pos, quat, scale, self.cam_pos.data_ptr(), self.cam_quat.data_ptr(),
+                                        self.V, self.pos_c.data_ptr(), self.quat_c.data_ptr(),
+                                        self.inv_scale.data_ptr(), self.scale_v.data_ptr(), d, st),
+                   "sdfr_pose_to_views")
+        sdf = self.sdf[0, 0]
+        est = self.plan.forward(sdf, self.pos_c, self.quat_c, self.inv_scale, self.cfg["threshold"])
+        self.check(L.sdfr_depth_l1_loss(est.data_ptr(), self.target.data_ptr(), self.V, self.W, self.H,
+                                        self.cfg["depth_weight"], self.loss_depth.data_ptr(),
+                                        self.grad_est.data_ptr(), self.ws_loss.data_ptr(),
+                                        self.ws_loss.numel(), d, st), "sdfr_depth_l1_loss")
+        g_sdf, g_pos, g_quat, g_is = self.plan.backward(self.grad_est, sdf, self.pos_c, self.quat_c,
+                                                        self.inv_scale)
+        have_pts = self.max_pts > 0
+        if have_pts:
+            self.check(L.sdfr_pc_loss_forward(self.points.data_ptr(), self.offsets.data_ptr(), self.V,
+                                              self.max_pts, self.pos_c.data_ptr(), self.quat_c.data_ptr(),
+                                              self.scale_v.data_ptr(), sdf.data_ptr(), self.R, 0,
+                                              self.vals.data_ptr(), d, st), "sdfr_pc_loss_forward")
+            self.check(L.sdfr_pc_l1_loss(self.vals.data_ptr(), self.offsets.data_ptr(), self.V, self.max_pts,
+                                         self.cfg["pc_weight"], self.loss_pc.data_ptr(),
+                                         self.grad_vals.data_ptr(), d, st), "sdfr_pc_l1_loss")
+            self.check(L.sdfr_pc_loss_backward(self.grad_vals.data_ptr(), self.points.data_ptr(),
+                                               self.offsets.data_ptr(), self.V, self.max_pts,
+                                               self.pos_c.data_ptr(), self.quat_c.data_ptr(),
+                                               self.scale_v.data_ptr(), sdf.data_ptr(), self.R, 0,
+                                               self.g_sdf_pc.data_ptr(), 0, self.g_pos_pc.data_ptr(),
+                                               self.g_quat_pc.data_ptr(), self.g_scale_pc.data_ptr(),
+                                               self.ws_pc.data_ptr(), self.ws_pc.numel(), d, st),
+                       "sdfr_pc_loss_backward")
+        self.check(L.sdfr_views_to_pose_grad(quat, scale, self.cam_quat.data_ptr(), self.V, g_pos.data_ptr(),
+                                             g_quat.data_ptr(), g_is.data_ptr(),
+                                             self.g_pos_pc.data_ptr() if have_pts else None,
+                                             self.g_quat_pc.data_ptr() if have_pts else None,
+                                             self.g_scale_pc.data_ptr() if have_pts else None,
+                                             g, g + 12, g + 28, d, st), "sdfr_views_to_pose_grad")
+        if self.shape_opt:
+            if have_pts:
+                self.check(L.sdfr_add_inplace(g_sdf.data_ptr(), self.g_sdf_pc.data_ptr(), g_sdf.numel(), d, st),
+                           "sdfr_add_inplace")
+            self.check(L.sdfr_decoder_backward_latent(self.dec._h, self.latent.data_ptr(), self.tape.data_ptr(),
+                                                      g_sdf.data_ptr(), 1, g + 32, self.ws_dec.data_ptr(),
+                                                      self.ws_dec.numel(), st), "sdfr_decoder_backward_latent")
+        self.check(L.sdfr_adam_step(p, g, self.m.data_ptr(), self.v.data_ptr(), self.step.data_ptr(),
+                                    8 + self.Lz, 1e-3, 1e-2, 1e-3, 1e-2, int(self.shape_opt), d, st),
+                   "sdfr_adam_step")
+
+    def __call__(self, position, orientation, scale, latent, use_graph: bool = True,
+                 history: Optional[List] = None):
+        """Run config['max_iterations'] iterations from the given initial estimate; returns
+        (position (1,3), orientation (1,4), scale (1,), latent (1,L))."""
+        with torch.no_grad():
+            self.params[0:3] = position.reshape(3)
+            self.params[3:7] = orientation.reshape(4)
+            self.params[7:8] = scale.reshape(1)
+            self.params[8:] = latent.reshape(-1)
+            self.m.zero_(); self.v.zero_(); self.step.zero_(); self.grads.zero_()
+        if not self.shape_opt:
+            self._decode(self._stream(), False)
+        n_iter = self.cfg["max_iterations"]
+        if use_graph and self.graph is None:
+            # warm up on a side stream (lazy module loads), restore the state, then capture
+            saved = [t.clone() for t in (self.params, self.m, self.v, self.step)]
+            s = torch.cuda.Stream(self.dev)
+            s.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(s):
+                self.iteration()
+            torch.cuda.current_stream(self.dev).wait_stream(s)
+            for t, c in zip((self.params, self.m, self.v, self.step), saved):
+                t.copy_(c)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.iteration()
+            for t, c in zip((self.params, self.m, self.v, self.step), saved):
+                t.copy_(c)   # the capture itself does not execute, but keep the state explicit
+        for _ in range(n_iter):
+            if use_graph:
+                self.graph.replay()
+            else:
+                self.iteration()
+            if history is not None:
+                history.append({"loss": (self.cfg["depth_weight"] * self.loss_depth.sum()
+                                         + self.cfg["pc_weight"] * self.loss_pc.sum()).clone(),
+                                "position": self.position.clone()[None],
+                                "orientation": self.orientation.clone()[None],
+                                "scale": self.scale.clone(), "latent": self.latent.clone()[None]})
+        return (self.position.clone()[None], self.orientation.clone()[None], self.scale.clone(),
+                self.latent.clone()[None])

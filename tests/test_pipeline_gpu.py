@@ -168,3 +168,49 @@ def test_c5_full_loop_converges(mug_decoder):
     assert pos_err < 0.6 * pos_err0, (pos_err0, pos_err)
     assert abs(out[2].item() - 0.055) < abs(0.06 - 0.055)
     assert hist[-1]["latent"].abs().max().item() > 1e-3      # the latent really was optimised
+
+
+@pytest.mark.parametrize("shape_opt", [False, True])
+def test_fused_graph_loop_matches_autograd_loop(mug_decoder, shape_opt):
+    """The launch-sequence / hipGraph iteration against the autograd-driven one: same parameter
+    trajectory (2 cameras, 160x120, 8 iterations), eager and graph-replayed."""
+    from sdfest_amd import Camera
+    from sdfest_amd.pipeline import FusedRenderAndCompare, RenderAndCompare
+    dec, d = mug_decoder
+    W, H, f = 160, 120, 150.0
+    cam = Camera(W, H, f, f, W / 2, H / 2, pixel_center=0.5)
+    dev = "cuda"
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device=dev)
+    cam_pos = t([[0.0, 0.0, 0.0], [0.25, 0.05, 0.02]])
+    cq = np.array([0.02, 0.27, 0.01, 1.0]); cq /= np.linalg.norm(cq)
+    cam_quat = t([[0, 0, 0, 1.0], cq])
+    p_true = t([[0.01, -0.015, -0.45]]); s_true = t([0.11])
+    q_true = t([[0.3, 0.5, -0.1, 0.8]]); q_true = q_true / q_true.norm()
+    z_true = t(d["z"][10:11]) * 0.3
+    cfg = {"threshold": 0.005, "max_iterations": 8, "depth_weight": 1.0, "pc_weight": 3.0}
+    ref_loop = RenderAndCompare(dec, cam, cfg)
+    with torch.no_grad():
+        sdf = dec.decode(z_true)[0, 0]
+        _, _, obs = ref_loop.losses(torch.ones((2, H, W), device=dev), torch.zeros((0, 3), device=dev),
+                                    None, [], cam_pos, cam_quat, p_true, q_true, s_true, sdf)
+    obs = obs.contiguous()
+    assert (obs > 0).sum(dim=(1, 2)).min() > 1000
+    p0 = p_true + t([[0.008, -0.006, 0.01]]); s0 = t([0.12])
+    q0 = q_true + t([[0.04, -0.03, 0.02, 0.01]]); z0 = torch.zeros(1, 8, device=dev)
+    h_ref = []
+    ref_loop(obs, p0, q0, s0, z0, camera_positions=cam_pos, camera_orientations=cam_quat,
+             shape_optimization=shape_opt, history=h_ref)
+    fused = FusedRenderAndCompare(dec, cam, cfg, obs, cam_pos, cam_quat, shape_optimization=shape_opt)
+    for use_graph in (False, True, True):
+        h = []
+        out = fused(p0, q0, s0, z0, use_graph=use_graph, history=h)
+        for it in range(cfg["max_iterations"]):
+            for key, tol in (("position", 2e-5), ("orientation", 2e-4), ("scale", 2e-5), ("latent", 5e-4)):
+                a, b = h[it][key].reshape(-1), h_ref[it][key].reshape(-1)
+                assert (a - b).abs().max().item() <= tol * (it + 1), (use_graph, it, key, a, b)
+            assert abs(h[it]["loss"].item() - h_ref[it]["loss"].item()) <= 2e-3 * abs(h_ref[it]["loss"].item())
+        assert torch.equal(out[0], h[-1]["position"])
+    if shape_opt:
+        assert h[-1]["latent"].abs().max().item() > 1e-3
+    else:
+        assert h[-1]["latent"].abs().max().item() == 0.0
