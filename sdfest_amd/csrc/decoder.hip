@@ -171,11 +171,23 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
     const int z = pos % m, y = (pos / m) % m, x = pos / (m * m);
     const float* base = src + ((size_t)x * n + y) * n + z;
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int kk0 = 0; kk0 < kpad; kk0 += 4) {
+    // the gathers of 8 K-steps are issued together and only then consumed: the loop is a chain of
+    // dependent (LDS tap -> global gather -> MFMA) round trips otherwise
+    int kk0 = 0;
+    for (; kk0 + 32 <= kpad; kk0 += 32) {
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int kk = kk0 + 4 * u + kq;
+        a[u] = base[tap_l[kk]];
+        b[u] = w_l[kk * 16 + row];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+    }
+    for (; kk0 < kpad; kk0 += 4) {
       const int kk = kk0 + kq;
-      const float a = base[tap_l[kk]];
-      const float b = w_l[kk * 16 + row];
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(base[tap_l[kk]], w_l[kk * 16 + row], acc, 0, 0, 0);
     }
     if (co < Cout) {
       float* dst = out + ((size_t)nb * Cout + co) * mv;
@@ -224,50 +236,30 @@ __device__ __forceinline__ float resize_weight(int d, int i, float ratio, int n_
   return (i0 == i ? 1.0f - l1 : 0.0f) + (i1 == i ? l1 : 0.0f);
 }
 
-// Transpose of resize3_kernel in gather form (deterministic, no atomics):
-// g_in[c][x][y][z] = sum over the few outputs (dx,dy,dz) that interpolate from (x,y,z).
-constexpr int kMaxSpan = 16;
-__global__ __launch_bounds__(256) void resize3_backward_kernel(const float* __restrict__ g_out, int C,
-                                                               int n_in, int n_out,
-                                                               float* __restrict__ g_in) {
-  const size_t vo = (size_t)n_out * n_out * n_out, vi = (size_t)n_in * n_in * n_in;
+// Transpose of resize3_kernel, one axis per launch (the interpolation is separable), in gather
+// form: deterministic, no atomics.  The tensor is viewed as [outer][n_out][inner] -> [outer][n_in][inner]:
+//   g_in[o][i][r] = sum over the few d with i0(d) == i or i1(d) == i of w(d -> i) * g_out[o][d][r]
+__global__ __launch_bounds__(256) void resize_axis_backward_kernel(const float* __restrict__ g_out,
+                                                                   size_t outer, int n_in, int n_out,
+                                                                   size_t inner,
+                                                                   float* __restrict__ g_in) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)C * vi) return;
-  const int n = blockIdx.y;
-  const int c = (int)(idx / vi);
-  const int r = (int)(idx - (size_t)c * vi);
-  const int z = r % n_in, y = (r / n_in) % n_in, x = r / (n_in * n_in);
-  const float ratio = (float)n_in / (float)n_out;
-  const float inv = (float)n_out / (float)n_in;
-  int lo[3], cnt[3];
-  float w[3][kMaxSpan];
-  const int ix[3] = {x, y, z};
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    int d0 = (int)floorf(((float)ix[a] - 0.5f) * inv - 0.5f) - 1;
-    int d1 = (int)ceilf(((float)ix[a] + 1.5f) * inv - 0.5f) + 1;
-    d0 = max(d0, 0);
-    d1 = min(d1, n_out - 1);
-    if (d1 - d0 + 1 > kMaxSpan) d1 = d0 + kMaxSpan - 1;  // host guarantees this never truncates
-    lo[a] = d0;
-    cnt[a] = d1 - d0 + 1;
-    for (int k = 0; k < kMaxSpan; ++k) w[a][k] = (k < cnt[a]) ? resize_weight(d0 + k, ix[a], ratio, n_in) : 0.0f;
-  }
-  const float* p = g_out + ((size_t)n * C + c) * vo;
+  if (idx >= outer * n_in * inner) return;
+  const size_t r = idx % inner;
+  const int i = (int)((idx / inner) % n_in);
+  const size_t o = idx / (inner * n_in);
+  const float ratio = (float)n_in / (float)n_out, inv = (float)n_out / (float)n_in;
+  int d0 = (int)floorf(((float)i - 0.5f) * inv - 0.5f) - 1;
+  int d1 = (int)ceilf(((float)i + 1.5f) * inv - 0.5f) + 1;
+  d0 = max(d0, 0);
+  d1 = min(d1, n_out - 1);
+  const float* p = g_out + (o * n_out) * inner + r;
   float acc = 0.0f;
-  for (int a = 0; a < cnt[0]; ++a) {
-    if (w[0][a] == 0.0f) continue;
-    float sy = 0.0f;
-    for (int b = 0; b < cnt[1]; ++b) {
-      if (w[1][b] == 0.0f) continue;
-      const float* row = p + ((size_t)(lo[0] + a) * n_out + (lo[1] + b)) * n_out + lo[2];
-      float sz = 0.0f;
-      for (int k = 0; k < cnt[2]; ++k) sz = fmaf(w[2][k], row[k], sz);
-      sy = fmaf(w[1][b], sz, sy);
-    }
-    acc = fmaf(w[0][a], sy, acc);
+  for (int d = d0; d <= d1; ++d) {
+    const float w = resize_weight(d, i, ratio, n_in);
+    if (w != 0.0f) acc = fmaf(w, p[(size_t)d * inner], acc);
   }
-  g_in[((size_t)n * C + c) * vi + r] = acc;
+  g_in[idx] = acc;
 }
 
 // g[i] = 0 where the forward activation was not positive (ReLU'), in place
@@ -276,17 +268,40 @@ __global__ void relu_mask_kernel(float* __restrict__ g, const float* __restrict_
   if (i < count && !(act[i] > 0.0f)) g[i] = 0.0f;
 }
 
-// Backward of the Linear stack, one workgroup per sample: g_last (already ReLU-masked, width
-// of the last layer) -> g_z.  Hidden activations are recomputed in LDS as in the forward.
+// Backward of the last (wide) Linear layer: t[n][i] = sum_o Wt[i][o] * g_last[n][o], one workgroup
+// per (i, sample) -- a 50 x 8192 GEMV spread over 50 workgroups instead of one.
+__global__ __launch_bounds__(kFcBlock) void fc_last_backward_kernel(const float* __restrict__ params,
+                                                                    FcDesc d,
+                                                                    const float* __restrict__ g_last,
+                                                                    float* __restrict__ t_out) {
+  __shared__ float red[kFcBlock / 64];
+  const int i = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int l = d.n_fc - 1, win = d.width[l], wout = d.width[l + 1];
+  const float* wt = params + d.w_off[l] + (size_t)i * wout;
+  const float* g = g_last + (size_t)n * wout;
+  float part = 0.0f;
+  for (int o = tid; o < wout; o += kFcBlock) part = fmaf(wt[o], g[o], part);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = part;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.0f;
+    for (int k = 0; k < kFcBlock / 64; ++k) t += red[k];
+    t_out[(size_t)n * win + i] = t;
+  }
+}
+
+// Backward of the small leading layers, one workgroup per sample: t (gradient w.r.t. the input of
+// the last layer, not yet ReLU-masked) -> g_z.  Hidden activations are recomputed in LDS.
 __global__ __launch_bounds__(kFcBlock) void fc_stack_backward_kernel(const float* __restrict__ params,
                                                                      FcDesc d,
                                                                      const float* __restrict__ z,
-                                                                     const float* __restrict__ g_last,
+                                                                     const float* __restrict__ t_in,
                                                                      float* __restrict__ g_z) {
   __shared__ float act[8][kMaxHidden];   // act[l] = input of layer l (act[0] = z)
   __shared__ float gbuf[2][kMaxHidden];
-  __shared__ float red[kFcBlock / 64];
-  const int tid = threadIdx.x, n = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, n = blockIdx.x;
   for (int i = tid; i < d.width[0]; i += kFcBlock) act[0][i] = z[(size_t)n * d.width[0] + i];
   __syncthreads();
   for (int l = 0; l < d.n_fc - 1; ++l) {
@@ -300,27 +315,15 @@ __global__ __launch_bounds__(kFcBlock) void fc_stack_backward_kernel(const float
     }
     __syncthreads();
   }
-  // last layer (weights stored transposed [in][out]): g_h[i] = sum_o Wt[i][o] * g_last[o]
   int cur = 0;
   {
-    const int l = d.n_fc - 1, win = d.width[l], wout = d.width[l + 1];
-    const float* wt = params + d.w_off[l];
-    const float* g = g_last + (size_t)n * wout;
-    for (int i = 0; i < win; ++i) {
-      float part = 0.0f;
-      for (int o = tid; o < wout; o += kFcBlock) part = fmaf(wt[(size_t)i * wout + o], g[o], part);
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
-      if (lane == 0) red[wave] = part;
-      __syncthreads();
-      if (tid == 0) {
-        float t = 0.0f;
-        for (int k = 0; k < kFcBlock / 64; ++k) t += red[k];
-        // ReLU' of the layer that produced act[l] (l >= 1); the latent itself has no ReLU
-        gbuf[cur][i] = (l == 0 || act[l][i] > 0.0f) ? t : 0.0f;
-      }
-      __syncthreads();
+    const int l = d.n_fc - 1, win = d.width[l];
+    // ReLU' of the layer that produced act[l] (l >= 1); the latent itself has no ReLU
+    for (int i = tid; i < win; i += kFcBlock) {
+      const float t = t_in[(size_t)n * win + i];
+      gbuf[cur][i] = (l == 0 || act[l][i] > 0.0f) ? t : 0.0f;
     }
+    __syncthreads();
   }
   for (int l = d.n_fc - 2; l >= 0; --l) {
     const int win = d.width[l], wout = d.width[l + 1];
@@ -587,7 +590,7 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
     }
     const int k = d->conv_k[l], co_n = d->conv_cout[l], m = n - k + 1, kpad = d->conv_kpad[l];
     const int n_tiles = (m * m * m + 15) / 16;
-    const int tpw = n_tiles >= 4096 ? 4 : 1;
+    const int tpw = n_tiles >= 32768 ? 4 : 1;
     const int blocks = (n_tiles + 4 * tpw - 1) / (4 * tpw);
     const size_t lds = (size_t)kpad * 17 * sizeof(float);
     const bool is_last = (l == d->n_conv - 1);
@@ -644,18 +647,25 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
   // sizes of the tensor each conv layer produces
   std::vector<int> out_n(d->n_conv);
   for (int l = 0; l < d->n_conv; ++l) out_n[l] = d->conv_in_size[l] - d->conv_k[l] + 1;
-  auto check_span = [&](int n_in, int n_out) {
-    return (int)(2.0f * (float)n_out / (float)n_in) + 5 <= kMaxSpan;
+  // transpose of a trilinear resize of [N*C] volumes n_out^3 -> n_in^3: z, then y, then x
+  auto resize_backward = [&](int C, int n_in, int n_out) {
+    const size_t nc = (size_t)N * C;
+    struct Pass { size_t outer; size_t inner; } passes[3] = {
+        {nc * n_out * n_out, 1},                  // z:  [nc][no][no][no] -> [nc][no][no][ni]
+        {nc * n_out, (size_t)n_in},               // y:  [nc][no][no][ni] -> [nc][no][ni][ni]
+        {nc, (size_t)n_in * n_in}};               // x:  [nc][no][ni][ni] -> [nc][ni][ni][ni]
+    for (int a = 0; a < 3; ++a) {
+      const size_t cnt = passes[a].outer * n_in * passes[a].inner;
+      hipLaunchKernelGGL(resize_axis_backward_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st,
+                         g, passes[a].outer, n_in, n_out, passes[a].inner, buf[cur]);
+      g = buf[cur];
+      cur ^= 1;
+    }
   };
   int n = d->volume;
   if (out_n[d->n_conv - 1] != d->volume) {  // final resize
     const int ni = out_n[d->n_conv - 1];
-    if (!check_span(ni, d->volume)) return fail(SDFR_E_INVALID, "resize ratio %d->%d unsupported in backward", ni, d->volume);
-    const size_t cnt = (size_t)ni * ni * ni;
-    hipLaunchKernelGGL(resize3_backward_kernel, dim3((unsigned)((cnt + 255) / 256), N), dim3(256), 0, st,
-                       g, 1, ni, d->volume, buf[cur]);
-    g = buf[cur];
-    cur ^= 1;
+    resize_backward(1, ni, d->volume);
     n = ni;
   }
   for (int l = d->n_conv - 1; l >= 0; --l) {
@@ -671,7 +681,7 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
     // 2. data gradient = valid conv (kernel k) of the padded tensor with the flipped weights
     const int kpad = d->bwd_kpad[l];
     const int n_tiles = (nin * nin * nin + 15) / 16;
-    const int tpw = n_tiles >= 4096 ? 4 : 1;
+    const int tpw = n_tiles >= 32768 ? 4 : 1;
     const int blocks = (n_tiles + 4 * tpw - 1) / (4 * tpw);
     hipLaunchKernelGGL(conv3d_mfma_kernel, dim3(blocks, (ci_n + 15) / 16, N), dim3(256),
                        (size_t)kpad * 17 * sizeof(float), st, g, d->d_params + d->bwd_w_off[l],
@@ -683,12 +693,7 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
     // 3. the resize in front of this layer, if any
     const int prev = (l == 0) ? d->conv_in_size[0] : out_n[l - 1];
     if (prev != nin) {
-      if (!check_span(prev, nin)) return fail(SDFR_E_INVALID, "resize ratio %d->%d unsupported in backward", prev, nin);
-      const size_t cnt = (size_t)ci_n * prev * prev * prev;
-      hipLaunchKernelGGL(resize3_backward_kernel, dim3((unsigned)((cnt + 255) / 256), N), dim3(256), 0, st,
-                         g, ci_n, prev, nin, buf[cur]);
-      g = buf[cur];
-      cur ^= 1;
+      resize_backward(ci_n, prev, nin);
       n = prev;
     }
   }
@@ -706,7 +711,10 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
     fd.w_off[l] = (long long)d->fc_w_off[l];
     fd.b_off[l] = (long long)d->fc_b_off[l];
   }
-  hipLaunchKernelGGL(fc_stack_backward_kernel, dim3(N), dim3(kFcBlock), 0, st, d->d_params, fd, z, gl, g_z);
+  float* t_mid = buf[cur ^ 1];
+  hipLaunchKernelGGL(fc_last_backward_kernel, dim3(fd.width[d->n_fc - 1], N), dim3(kFcBlock), 0, st,
+                     d->d_params, fd, gl, t_mid);
+  hipLaunchKernelGGL(fc_stack_backward_kernel, dim3(N), dim3(kFcBlock), 0, st, d->d_params, fd, z, t_mid, g_z);
   SDFR_HIP_TRY(hipGetLastError());
   (void)n;
   return 0;
