@@ -1,0 +1,61 @@
+"""Time forward/backward of several builds of the library (ablation / variant .so files)."""
+import ctypes, os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oracle
+from sdfest_amd import _lib
+
+def load(path):
+    h = ctypes.CDLL(path)
+    for name, (res, args) in _lib.SIGNATURES.items():
+        fn = getattr(h, name); fn.restype = res; fn.argtypes = args
+    return h
+
+def main():
+    B, W, H = int(os.environ.get("B", 256)), 640, 480
+    dev = torch.device("cuda:0")
+    sdf = torch.tensor(oracle.blobs_sdf(0), device=dev)
+    pos, quat, isc = (torch.tensor(a, device=dev) for a in oracle.random_poses(B, seed=1))
+    g = torch.rand((B, H, W), device=dev) * 2 - 1
+    depth = torch.empty((B, H, W), device=dev)
+    gs = torch.empty((64, 64, 64), device=dev); gp = torch.empty((B, 3), device=dev)
+    gq = torch.empty((B, 4), device=dev); gi = torch.empty((B,), device=dev)
+    mode = os.environ.get("MODE", "")
+    thr = float(os.environ.get("THR", "0.005"))
+    if mode == "offscreen":
+        pos = pos.clone(); pos[:, 0] += 100.0
+    libs = []
+    for path in sys.argv[1:]:
+        L = load(path)
+        nb = max(L.sdfr_render_forward_workspace_bytes(64, B, W, H), L.sdfr_render_backward_workspace_bytes(64, B, W, H))
+        libs.append((path, L, torch.empty(nb + 256, dtype=torch.uint8, device=dev)))
+    st = torch.cuda.current_stream().cuda_stream
+    def fwd(L, ws):
+        rc = L.sdfr_render_forward(sdf.data_ptr(), 64, 0, pos.data_ptr(), quat.data_ptr(), isc.data_ptr(), B, W, H,
+                              320.0, 240.0, 320.0, 320.0, thr, depth.data_ptr(), ws.data_ptr(), ws.numel(), 0, st)
+        assert rc == 0, L.sdfr_last_error()
+    def bwd(L, ws):
+        rc = L.sdfr_render_backward(g.data_ptr(), depth.data_ptr(), sdf.data_ptr(), 64, 0, pos.data_ptr(), quat.data_ptr(),
+                               isc.data_ptr(), B, W, H, 320.0, 240.0, 320.0, 320.0, 0, gs.data_ptr(), 0, gp.data_ptr(),
+                               gq.data_ptr(), gi.data_ptr(), ws.data_ptr(), ws.numel(), 0, st)
+        assert rc == 0, L.sdfr_last_error()
+    rounds = int(os.environ.get("ROUNDS", 7))
+    res = {path: {"fwd": [], "bwd": []} for path, _, _ in libs}
+    for r in range(rounds + 1):
+        for path, L, ws in libs:
+            for name, fn in (("fwd", fwd), ("bwd", bwd)):
+                fn(L, ws); torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                n = 10
+                e0.record()
+                for _ in range(n): fn(L, ws)
+                e1.record(); torch.cuda.synchronize()
+                if r > 0: res[path][name].append(e0.elapsed_time(e1) / n * 1e3)
+    hits = int((depth > 0).sum())
+    for path, _, _ in libs:
+        f = float(np.median(res[path]["fwd"])); b = float(np.median(res[path]["bwd"]))
+        print(f"{os.path.basename(path):40s} B={B} fwd {f:8.1f} us  bwd {b:8.1f} us  hits={hits} "
+              f"-> {B/((f+b)*1e-6):,.0f} renders/s  (median of {rounds} interleaved rounds; "
+              f"fwd min {min(res[path]['fwd']):.1f} bwd min {min(res[path]['bwd']):.1f})", flush=True)
+main()
