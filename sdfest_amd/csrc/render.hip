@@ -107,9 +107,10 @@ __global__ void view_setup_kernel(const float* __restrict__ pos, const float* __
 // ---------------------------------------------------------------------------------------------
 // face records: rec[lin] = the 4 corners of the cell face x = const whose corner 00 is voxel lin:
 // (v(x,y,z), v(x,y,z+1), v(x,y+1,z), v(x,y+1,z+1)) as one float4.  A cell is the two records
-// rec[lin] and rec[lin + R^2]: two 16-byte loads per march step instead of four 8-byte z-pair
-// loads.  R^3 records = 4 MiB at R = 64 (a full 32-byte cell record per voxel was measured too:
-// 8 MiB, 2.5 % slower -- it overflows the 4 MiB per-XCD L2).
+// the record of (x,y,z) and the record of (x+1,y,z): two 16-byte loads per march step instead of
+// four 8-byte z-pair loads.  4 MiB at R = 64 (a full 32-byte cell record per voxel was measured
+// too: 8 MiB, 2.5 % slower -- it overflows the 4 MiB per-XCD L2).  Storage order: device.hpp,
+// record_index.
 // ---------------------------------------------------------------------------------------------
 // (A 2x2x2-blocked record order was measured: +10 integer ops per step, no gain -- the march is
 // bound by dependent-load latency, not by lines per access.  Records stay in grid order.)
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void pack_cells_kernel(const float* __restrict
   const int z = lin % R, y = (lin / R) % R;
   if (y >= R - 1 || z >= R - 1) return;
   const float* p = sdf + lin;
-  cells[lin] = make_float4(p[0], p[1], p[R], p[R + 1]);
+  cells[record_index(lin / RR, y, z, (R + 1) >> 1)] = make_float4(p[0], p[1], p[R], p[R + 1]);
 }
 
 struct Rect {
@@ -178,7 +179,7 @@ __device__ __forceinline__ void forward_tile(
   const int Rr = RT > 0 ? RT : R;
   // record array as a buffer resource (PACKED only; R <= 128 so the size fits 32 bits)
   const __amdgpu_buffer_rsrc_t recs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(vol), 0, PACKED ? Rr * Rr * Rr * 16 : 0, 0x00020000);
+      const_cast<float*>(vol), 0, PACKED ? Rr * record_slab(Rr) * 16 : 0, 0x00020000);
 
   for (int grp = 0; grp < kSubs; grp += K) {
     float t[K], t_far[K], dgx[K], dgy[K], dgz[K], ndz[K], result[K];
@@ -540,7 +541,7 @@ size_t setup_bytes(int B) { return (size_t)(B > 0 ? B : 0) * sizeof(ViewSetup); 
 bool use_packed(int R, int B, long long sdf_view_stride) {
   return sdf_view_stride == 0 && B >= kPackedMinViews && R <= kPackedMaxR;
 }
-size_t packed_bytes(int R) { return (size_t)R * R * R * 4 * sizeof(float); }
+size_t packed_bytes(int R) { return (size_t)R * record_slab(R) * 4 * sizeof(float); }
 
 }  // namespace
 }  // namespace sdfr

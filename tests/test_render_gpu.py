@@ -292,3 +292,20 @@ def check_depth_count(d_hip, d_ref, margin):
         # (the oracle's own fp32 and fp64 builds disagree by > 1e-4 on 0.9 % of these pixels)
         assert np.mean(err > 1e-4) < 0.05 and np.median(err) < 5e-6
     return int((mism & robust).sum()) + int(mism.sum())
+
+
+def test_packed_record_path_generic_and_odd_resolution(R):
+    """B >= 4 views sharing a grid take the face-record march; exercise it at R != 64 incl. an odd R
+    (padded 2x2 blocks) and check it equals the per-view (plain-grid) launches bit for bit."""
+    for Rn in (33, 48, 7):
+        sdf = oracle.sphere_sdf(0.55, R=Rn)
+        pos, quat, isc = oracle.random_poses(5, seed=Rn, width=96, height=72, f=60.0)
+        cam = (96, 72, 48.0, 36.0, 60.0, 60.0)
+        d = hip_forward(R, sdf, pos, quat, isc, *cam, 0.01)
+        for b in range(5):
+            d1 = hip_forward(R, sdf, pos[b], quat[b], isc[b:b + 1], *cam, 0.01)[0]
+            assert np.array_equal(d1, d[b]), (Rn, b)
+        do, _, m = oracle.render_forward(sdf, pos, quat, isc, *cam, 0.01, dtype=np.float32, with_aux=True)
+        for b in range(5):
+            check_depth(d[b], do[b], m[b], f"R{Rn}/view{b}")
+        assert (d > 0).sum() > 200
