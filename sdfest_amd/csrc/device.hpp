@@ -75,6 +75,9 @@ __device__ __forceinline__ void gather_cell(const float* __restrict__ src, int R
 // holds the faces of a 2 x 2 neighbourhood, so the cells a wave touches in one step fall into fewer
 // chunks -- the gather unit costs ~2 cycles per distinct 64-byte chunk per load
 // (tools/microbench/gather_bench.hip).  Measured: forward 247.5 -> 232.3 us per 256 random views.
+// (Three arrays -- faces perpendicular to x, y, z, each view marching the one for its dominant
+// viewing axis so that the 2 x 2 blocks lie in the plane its rays sweep -- were built and measured:
+// 261 us.  12 MiB of records no longer fit the 4 MiB per-XCD L2.)
 // Hb = ceil(R/2) blocks per axis; one x-slab = 4 Hb^2 records.
 __host__ __device__ __forceinline__ int record_slab(int R) { return 4 * ((R + 1) >> 1) * ((R + 1) >> 1); }
 __device__ __forceinline__ int record_index(int x, int y, int z, int Hb) {
