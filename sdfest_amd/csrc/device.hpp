@@ -119,11 +119,13 @@ __device__ __forceinline__ float trilerp(const Cell& c) {
   return fmaf(c1, c.oz, c0 * az);
 }
 
-// lane -> pixel of the wave's 8x8 patch, in Morton order: 4 consecutive lanes are a 2x2 pixel
-// block, 16 lanes a 4x4 block.  The texture-address unit handles a 16-byte-per-lane load four
-// lanes at a time; four lanes that sit in one 2x2 block mostly hit one record (one cache line).
-__device__ __forceinline__ int patch_x(int lane) { return (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4); }
-__device__ __forceinline__ int patch_y(int lane) { return ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4); }
+// lane -> pixel of the wave's 8x8 patch, row-major: a row of 8 pixels is one 32-byte segment for
+// the image loads and stores.  (A Morton order -- 2x2 pixel blocks per lane quad, hoping that quad
+// lanes share a record -- was measured: no gain for the gathers, whose cost follows the distinct
+// 64-byte chunks of the whole wave, and 2-4 % slower because the image accesses split into 8-byte
+// pieces.)
+__device__ __forceinline__ int patch_x(int lane) { return lane & 7; }
+__device__ __forceinline__ int patch_y(int lane) { return lane >> 3; }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
