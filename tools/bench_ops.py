@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Side benchmarks of the other ops of the path (sampler, decoder, per-view-SDF render)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def timeit(fn, n=50):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3  # us
+
+
+def main():
+    import oracle
+    from sdfest_amd import BatchRenderPlan, Camera, SDFDecoder
+    from sdfest_amd.losses import _backward_raw, _forward_raw
+    dev = torch.device("cuda", 0)
+    out = {}
+    # sampler: V views x M points each (M = hit pixels of a typical mug view .. every pixel)
+    sdf = torch.tensor(oracle.blobs_sdf(0), device=dev)
+    rng = np.random.default_rng(0)
+    for V, M in ((1, 5000), (8, 5000), (1, 307200), (64, 20000)):
+        pts = torch.tensor(rng.uniform(-0.6, 0.6, (V * M, 3)).astype(np.float32) + np.array([0, 0, -1.0], np.float32), device=dev)
+        offs = torch.arange(0, V * M + 1, M, dtype=torch.int32, device=dev)
+        pos = torch.tensor([[0.0, 0.0, -1.0]], device=dev).repeat(V, 1)
+        quat = torch.tensor([[0.1, -0.2, 0.3, 0.9]], device=dev).repeat(V, 1)
+        sc = torch.full((V,), 0.5, device=dev)
+        go = torch.rand(V * M, device=dev) * 2 - 1
+        tf = timeit(lambda: _forward_raw(pts, offs, M, pos, quat, sc, sdf))
+        tb = timeit(lambda: _backward_raw(go, pts, offs, M, pos, quat, sc, sdf))
+        out[f"pc_loss V={V} M={M}"] = {"forward_us": round(tf, 1), "backward_us": round(tb, 1),
+                                       "Mpoints_per_s_fwd+bwd": round(V * M / (tf + tb), 1)}
+    # decoder
+    g = os.path.join(ROOT, "tests", "golden")
+    d = np.load(os.path.join(g, "decoder_mug.npz"))
+    w = np.load(os.path.join(g, "mug_decoder_weights.npz"))
+    cfg = {"latent_size": int(d["latent_size"]), "tsdf": False, "decoder": {
+        "fc_layers": [{"out": int(o)} for o in d["fc_out"]],
+        "conv_layers": [{"in_size": int(a), "in_channels": int(b), "out_channels": int(c), "kernel_size": int(k),
+                         "relu": bool(r)} for a, b, c, k, r in zip(d["conv_in_size"], d["conv_cin"], d["conv_cout"],
+                                                                   d["conv_k"], d["conv_relu"])]}}
+    dec = SDFDecoder.from_config(cfg, {k: w[k] for k in w.files})
+    for N in (1, 16, 256):
+        z = torch.randn(N, 8, device=dev)
+        with torch.no_grad():
+            t = timeit(lambda: dec.decode(z), 20)
+        zg = z.clone().requires_grad_()
+        G = torch.randn(N, 1, 64, 64, 64, device=dev)
+
+        def fb():
+            zg.grad = None
+            dec.decode(zg).backward(G)
+        t2 = timeit(fb, 10)
+        out[f"decoder N={N}"] = {"forward_us": round(t, 1), "forward+vjp_us": round(t2, 1),
+                                 "decodes_per_s": round(N / t * 1e6, 1)}
+    # render with one SDF per view (the dataset-generation caller: generated_dataset.py:247-342)
+    B = 64
+    with torch.no_grad():
+        sdfs = dec.decode(torch.randn(B, 8, device=dev) * 0.5)[:, 0].contiguous()
+    pos, quat, isc = (torch.tensor(a, device=dev) for a in oracle.random_poses(B, seed=3))
+    pos = pos * torch.tensor([0.3, 0.3, 0.3], device=dev)   # mug-sized scene: z in [0.36, 0.6]
+    isc = torch.full((B,), 1 / 0.08, device=dev)
+    cam = Camera(640, 480, 320.0, 320.0, 320.0, 240.0, pixel_center=0.5)
+    plan = BatchRenderPlan(64, B, cam, device=dev, per_view_sdf=True)
+    t = timeit(lambda: plan.forward(sdfs, pos, quat, isc, 0.005), 20)
+    out[f"render forward, one SDF per view, B={B}"] = {"us": round(t, 1), "views_per_s": round(B / t * 1e6, 1),
+                                                         "hit_pixels": int((plan.depth > 0).sum())}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
