@@ -1,0 +1,91 @@
+"""GPU: error behaviour of the C ABI and of the Python mirror (reference: TORCH_CHECK -> RuntimeError,
+sdf_renderer.cpp:9-13; ValueError for a double camera spec, sdf_renderer.py:416-417)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c_abi_rejects_bad_arguments_without_touching_memory():
+    from sdfest_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    sdf = torch.zeros((64, 64, 64), device=dev)
+    pos = torch.zeros((2, 3), device=dev); quat = torch.zeros((2, 4), device=dev); isc = torch.ones(2, device=dev)
+    depth = torch.full((2, 48, 64), 7.0, device=dev)
+    ws = torch.empty(1 << 24, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    args = lambda **kw: [kw.get("sdf", sdf.data_ptr()), kw.get("R", 64), kw.get("stride", 0), pos.data_ptr(),
+                         quat.data_ptr(), isc.data_ptr(), kw.get("B", 2), 64, 48, 32.0, 24.0, kw.get("fx", 40.0), 40.0,
+                         0.01, depth.data_ptr(), kw.get("ws", ws.data_ptr()), kw.get("wsn", ws.numel()), 0, st]
+    assert L.sdfr_render_forward(*args(R=1)) == -1
+    assert L.sdfr_render_forward(*args(B=-1)) == -1
+    assert L.sdfr_render_forward(*args(fx=0.0)) == -1
+    assert L.sdfr_render_forward(*args(stride=5)) == -1
+    assert L.sdfr_render_forward(*args(sdf=None)) == -2
+    assert L.sdfr_render_forward(*args(wsn=64)) == -3 and b"workspace" in L.sdfr_last_error()
+    assert L.sdfr_render_forward(*args(ws=ws.data_ptr() + 4)) == -1   # misaligned workspace
+    assert L.sdfr_render_forward(*args(B=0)) == 0
+    torch.cuda.synchronize()
+    assert torch.all(depth == 7.0)                 # none of the rejected calls launched anything
+    assert L.sdfr_render_forward(*args()) == 0
+    torch.cuda.synchronize()
+    assert torch.all(depth == 0.0)                 # zero quaternion / position: nothing hit, all written
+
+
+def test_python_mirror_raises_like_the_reference():
+    from sdfest_amd import Camera, SDFDecoder, pc_loss, render_depth_gpu
+    dev = "cuda"
+    sdf = torch.tensor(oracle.sphere_sdf(0.5), device=dev)
+    p = torch.tensor([0.0, 0.0, -2.0], device=dev); q = torch.tensor([0.0, 0.0, 0.0, 1.0], device=dev)
+    s = torch.tensor(1.0, device=dev)
+    cam = Camera(32, 24, 16.0, 16.0, 16.0, 12.0, pixel_center=0.5)
+    with pytest.raises(ValueError):
+        render_depth_gpu(sdf, p, q, s, 32, 24, 90.0, 0.01, cam)
+    with pytest.raises(RuntimeError, match="CUDA"):
+        render_depth_gpu(sdf.cpu(), p, q, s, None, None, None, 0.01, cam)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        render_depth_gpu(sdf.permute(2, 1, 0), p, q, s, None, None, None, 0.01, cam)
+    with pytest.raises(RuntimeError, match="float32"):
+        render_depth_gpu(sdf.double(), p, q, s, None, None, None, 0.01, cam)
+    with pytest.raises(RuntimeError):
+        pc_loss(torch.zeros((4, 3)), p, q, s, sdf)            # CPU points
+    with pytest.raises(ValueError):
+        SDFDecoder(64, 8, [{"out": 8}], [dict(in_size=2, in_channels=1, out_channels=1, kernel_size=1, relu=False)])
+    with pytest.raises(AssertionError):                       # SDFDecoder.sanity_check (sdf_vae.py:207-215)
+        SDFDecoder(64, 8, [{"out": 9}], [dict(in_size=2, in_channels=1, out_channels=1, kernel_size=1, relu=False)],
+                   state_dict={})
+
+
+def test_calls_from_other_threads_and_streams():
+    """backward runs on an autograd worker thread in the reference; the library must not depend on
+    thread-local HIP state.  Also a non-default stream."""
+    import threading
+    from sdfest_amd import Camera, render_depth_gpu
+    dev = "cuda"
+    sdf = torch.tensor(oracle.blobs_sdf(0), device=dev)
+    cam = Camera(160, 120, 80.0, 80.0, 80.0, 60.0, pixel_center=0.5)
+    results = {}
+
+    def work(i):
+        torch.cuda.set_device(0)
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            p = torch.tensor([0.0, 0.0, -1.5], device=dev, requires_grad=True)
+            q = torch.tensor([0.0, 0.0, 0.0, 1.0], device=dev)
+            d = render_depth_gpu(sdf, p, q, torch.tensor(2.0, device=dev), None, None, None, 0.005, cam)
+            d.sum().backward()
+            st.synchronize()
+            results[i] = (int((d > 0).sum()), p.grad.clone())
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert all(results[i][0] == 948 for i in range(4))
+    for i in range(1, 4):
+        assert torch.equal(results[i][1], results[0][1])      # pose gradients are order-independent
