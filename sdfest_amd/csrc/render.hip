@@ -451,11 +451,16 @@ __device__ __forceinline__ void backward_tile(
     }
   }
 
-  // pose sums: registers -> wave shuffle -> LDS -> macro-tile partial
+  // pose sums: registers -> wave shuffle -> LDS -> macro-tile partial (a wave without a hit pixel
+  // has nothing to reduce)
+  if (__ballot(any_hit) != 0ull) {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const float sk = wave_sum(acc[k]);
-    if (lane == 0) wave_part[wave][k] = sk;
+    for (int k = 0; k < 8; ++k) {
+      const float sk = wave_sum(acc[k]);
+      if (lane == 0) wave_part[wave][k] = sk;
+    }
+  } else if (lane < 8) {
+    wave_part[wave][lane] = 0.0f;
   }
   __syncthreads();
   if (tid < 8) part[tid] = (wave_part[0][tid] + wave_part[1][tid]) + (wave_part[2][tid] + wave_part[3][tid]);
@@ -464,9 +469,10 @@ __device__ __forceinline__ void backward_tile(
   const int nvox = Rr * Rr * Rr;
   for (int i = tid; i < kRunSlots * kRunLen; i += kBlock) {
     const int key = run_key[i >> 3];
+    if (key < 0) continue;  // most slots of a tile stay empty
     const long long q = (long long)run_val[i];
     const int lin = key * kRunLen + (i & 7);
-    if (key >= 0 && q != 0 && lin < nvox) atomicAdd(gvol + lin, (float)q * from_fixed);
+    if (q != 0 && lin < nvox) atomicAdd(gvol + lin, (float)q * from_fixed);
   }
 }
 

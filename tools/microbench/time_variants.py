@@ -23,6 +23,12 @@ def main():
     gq = torch.empty((B, 4), device=dev); gi = torch.empty((B,), device=dev)
     mode = os.environ.get("MODE", "")
     thr = float(os.environ.get("THR", "0.005"))
+    if mode == "samepose":
+        pos = torch.tensor([[0.0, 0.0, -1.5]], device=dev).repeat(B, 1).contiguous()
+        quat = torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=dev).repeat(B, 1).contiguous()
+        isc = torch.full((B,), 2.0, device=dev)
+    if mode == "nosurface":
+        sdf = torch.ones_like(sdf)
     if mode == "offscreen":
         pos = pos.clone(); pos[:, 0] += 100.0
     libs = []
