@@ -89,3 +89,23 @@ def test_calls_from_other_threads_and_streams():
     assert all(results[i][0] == 948 for i in range(4))
     for i in range(1, 4):
         assert torch.equal(results[i][1], results[0][1])      # pose gradients are order-independent
+
+
+def test_march_step_cap_terminates_where_the_reference_hangs():
+    """threshold = 0 on an exactly-zero field: the reference loop (cu:283-293) never terminates
+    (dist == 0 is not < 0 and t does not advance); the step cap returns a miss instead."""
+    import sdfest_amd.differentiable_renderer as r
+    dev = "cuda"
+    sdf = torch.zeros((64, 64, 64), device=dev)
+    pos = torch.tensor([[0.0, 0.0, -2.0]] * 5, device=dev)
+    quat = torch.tensor([[0.0, 0.0, 0.0, 1.0]] * 5, device=dev)
+    isc = torch.ones(5, device=dev)
+    for batch in (1, 5):     # plain-grid and face-record march
+        d = r.forward_raw(sdf, pos[:batch].contiguous(), quat[:batch].contiguous(), isc[:batch].contiguous(),
+                          64, 48, 32.0, 24.0, 40.0, 40.0, 0.0)
+        torch.cuda.synchronize()
+        assert torch.all(d == 0)
+    # with a positive threshold the same field is a hit at the cube face
+    d = r.forward_raw(sdf, pos[:1].contiguous(), quat[:1].contiguous(), isc[:1].contiguous(), 64, 48, 32.0, 24.0,
+                      40.0, 40.0, 0.01)
+    assert (d > 0).sum() > 100 and abs(d[d > 0].min().item() - 1.0) < 1e-5
