@@ -142,73 +142,101 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// LDS hash of 8-voxel runs (32 bytes of the gradient volume): key = linear voxel index >> 3.
+// LDS hash of short z-runs of the gradient volume: key = linear voxel index >> SHIFT.
 //
 // Sums are kept in 64-bit FIXED POINT, not float: on gfx950 ds_add_f32 executes one lane at a
 // time (~185 cycles per wave-instruction even without conflicts, measured), ds_add_u64 takes ~8.
-// Every contribution of a macro-tile is bounded by M = max|grad_depth| * scale over its hit
-// pixels (trilinear weights <= 1, |d.z| <= 1), a voxel receives at most 2048 pixels x 8 corners of
-// them, so with 2^-e >= M the integers round(c * 2^(44-e)) sum to less than 2^58 in magnitude.
+// Every contribution of a tile is bounded by M = max|grad_depth| * scale over its hit pixels
+// (trilinear weights <= 1, |d.z| <= 1), a voxel receives at most 512 pixels x 8 corners of them,
+// so with 2^-e >= M the integers round(c * 2^(44-e)) sum to less than 2^58 in magnitude.
 // The scale is a power of two (exact in float), every float contribution is represented exactly
-// (24 significant bits), and integer addition is associative: a macro-tile's sums are exact and
+// (24 significant bits), and integer addition is associative: a tile's sums are exact and
 // independent of the order in which its lanes arrive.
-#ifndef SDFR_RUN_SLOTS
-#define SDFR_RUN_SLOTS 256
-#endif
-constexpr int kRunSlots = SDFR_RUN_SLOTS;
-constexpr int kRunLen = 8;
+//
+// Geometry (measured, backward of 256 views / of one 160x120 view):  8-voxel runs x 256 slots
+// 188 us / 47 us;  4 x 512: 180 / 39;  2 x 1024: 227 / 20;  4 x 1024: 278 / 20.  A table that
+// overflows falls back to global float atomics (slow: low-resolution views touch a new cell with
+// every pixel), a big table costs occupancy.  Batches use 4 x 512, small calls 2 x 1024.
 constexpr int kFixedBits = 44;
 
-// Slot of run `key`: a plain LDS read first -- once a run has been installed (by an earlier lane
-// or sub-tile; ~9 pixels share a cell) the look-up needs no atomic at all -- and a compare-and-swap
-// only on an empty slot.  Keys are never changed once written, so a stale read can only be "empty".
-// (Measured: CAS on every look-up cost 96 of the backward's 267 us.)
-__device__ __forceinline__ int run_slot(int* keys, int key) {
-  unsigned h = (((unsigned)key * 2654435761u) >> 16) & (kRunSlots - 1);
+template <int SHIFT, int SLOTS>
+struct RunHash {
+  static constexpr int kShift = SHIFT, kSlots = SLOTS, kLen = 1 << SHIFT;
+  unsigned long long vals[SLOTS << SHIFT];
+  int keys[SLOTS];
+
+  __device__ __forceinline__ void clear(int tid, int nthreads) {
+    for (int i = tid; i < SLOTS; i += nthreads) keys[i] = -1;
+    for (int i = tid; i < (SLOTS << SHIFT); i += nthreads) vals[i] = 0ull;
+  }
+
+  // Slot of run `key`: a plain LDS read first -- once a run has been installed (by an earlier lane
+  // or sub-tile; several pixels share a cell) the look-up needs no atomic at all -- and a compare-
+  // and-swap only on an empty slot.  Keys never change once written, so a stale read can only be
+  // "empty".  (Measured: CAS on every look-up cost 96 of the backward's 267 us.)
+  __device__ __forceinline__ int slot_of(int key) {
+    unsigned h = (((unsigned)key * 2654435761u) >> 16) & (SLOTS - 1);
 #pragma unroll 1
-  for (int probe = 0; probe < 32; ++probe) {
-    int cur = __builtin_nontemporal_load(&keys[h]);  // not cached in a register across probes
-    if (cur == -1) cur = atomicCAS(&keys[h], -1, key);
-    if (cur == -1 || cur == key) return (int)h;
-    h = (h + 1) & (kRunSlots - 1);
+    for (int probe = 0; probe < 32; ++probe) {
+      int cur = __builtin_nontemporal_load(&keys[h]);  // not cached in a register across probes
+      if (cur == -1) cur = atomicCAS(&keys[h], -1, key);
+      if (cur == -1 || cur == key) return (int)h;
+      h = (h + 1) & (SLOTS - 1);
+    }
+    return -1;
   }
-  return -1;
-}
 
-// one fixed-point add into a resolved slot, or a global float atomic when the table is crowded
-__device__ __forceinline__ void add_one(unsigned long long* vals, float* __restrict__ gvol, int slot,
-                                        int lin, float w, float to_fixed) {
-  if (slot >= 0) atomicAdd(&vals[slot * kRunLen + (lin & 7)], (unsigned long long)(long long)(w * to_fixed));
-  else atomicAdd(gvol + lin, w);
-}
+  // one fixed-point add into a resolved slot, or a global float atomic when the table is crowded
+  __device__ __forceinline__ void add_one(float* __restrict__ gvol, int slot, int lin, float w,
+                                          float to_fixed) {
+    if (slot >= 0)
+      atomicAdd(&vals[(slot << SHIFT) + (lin & (kLen - 1))], (unsigned long long)(long long)(w * to_fixed));
+    else
+      atomicAdd(gvol + lin, w);
+  }
 
-// Add the 8 corner contributions of the cell at `lin` (corner order 000,001,010,011,100,...).
-// The four z-pairs live in four runs (two when z & 7 == 7 splits a pair): their first-probe key
-// reads are issued together and waited for once; only a miss takes the probing loop.  The
-// look-ups are a latency chain per lane (LDS round trip each), so overlapping them matters more
-// than the atomic's own cost.
-__device__ __forceinline__ void add_cell(int* keys, unsigned long long* vals, float* __restrict__ gvol,
-                                         int lin, int Rr, const float (&w)[8], float to_fixed) {
-  const int col[4] = {lin, lin + Rr, lin + Rr * Rr, lin + Rr * Rr + Rr};
-  int key[4], cur[4];
-  unsigned h[4];
+  // Add the 8 corner contributions of the cell at `lin` (corner order 000,001,010,011,100,...).
+  // The four z-pairs live in four runs (more when a pair straddles two runs): their first-probe key
+  // reads are issued together and waited for once; only a miss takes the probing loop.  The
+  // look-ups are a latency chain per lane (LDS round trip each), so overlapping them matters more
+  // than the atomic's own cost.
+  __device__ __forceinline__ void add_cell(float* __restrict__ gvol, int lin, int Rr,
+                                           const float (&w)[8], float to_fixed) {
+    const int col[4] = {lin, lin + Rr, lin + Rr * Rr, lin + Rr * Rr + Rr};
+    int key[4], cur[4];
+    unsigned h[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    key[j] = col[j] >> 3;
-    h[j] = (((unsigned)key[j] * 2654435761u) >> 16) & (kRunSlots - 1);
-    cur[j] = __builtin_nontemporal_load(&keys[h[j]]);
+    for (int j = 0; j < 4; ++j) {
+      key[j] = col[j] >> SHIFT;
+      h[j] = (((unsigned)key[j] * 2654435761u) >> 16) & (SLOTS - 1);
+      cur[j] = __builtin_nontemporal_load(&keys[h[j]]);
+    }
+    int slot[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) slot[j] = (cur[j] == key[j]) ? (int)h[j] : slot_of(key[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      add_one(gvol, slot[j], col[j], w[2 * j], to_fixed);
+      const bool split = (col[j] & (kLen - 1)) == kLen - 1;  // the +z corner starts the next run
+      const int s_hi = split ? slot_of(key[j] + 1) : slot[j];
+      add_one(gvol, s_hi, col[j] + 1, w[2 * j + 1], to_fixed);
+    }
   }
-  int slot[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) slot[j] = (cur[j] == key[j]) ? (int)h[j] : run_slot(keys, key[j]);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    add_one(vals, gvol, slot[j], col[j], w[2 * j], to_fixed);
-    const bool split = (col[j] & 7) == 7;  // the +z corner starts the next run
-    const int s_hi = split ? run_slot(keys, key[j] + 1) : slot[j];
-    add_one(vals, gvol, s_hi, col[j] + 1, w[2 * j + 1], to_fixed);
+
+  // flush: consecutive lanes write consecutive voxels of a run (contiguous global float atomics)
+  __device__ __forceinline__ void flush(float* __restrict__ gvol, int nvox, float from_fixed, int tid,
+                                        int nthreads) {
+    for (int i = tid; i < (SLOTS << SHIFT); i += nthreads) {
+      const int key = keys[i >> SHIFT];
+      if (key < 0) continue;  // most slots of a tile stay empty
+      const long long q = (long long)vals[i];
+      const int lin = (key << SHIFT) + (i & (kLen - 1));
+      if (q != 0 && lin < nvox) atomicAdd(gvol + lin, (float)q * from_fixed);
+    }
   }
-}
+};
+using BatchHash = RunHash<2, 512>;    // 64 x 8-pixel tiles of a batch
+using SmallHash = RunHash<1, 1024>;   // 32 x 8-pixel tiles of small calls, any resolution
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -25,6 +25,8 @@
 //     (sdf_renderer_cuda.cu:459-466);
 //   * d/dsdf contributions of a macro-tile are pre-summed in an LDS hash of 8-voxel z-runs and
 //     flushed as 32-byte runs of global float atomics (one per touched voxel per macro-tile).
+#include <type_traits>
+
 #include "common.hpp"
 #include "device.hpp"
 
@@ -292,25 +294,24 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
 // ---------------------------------------------------------------------------------------------
 // backward.  grid = (macro-tiles x, macro-tiles y, views)
 // ---------------------------------------------------------------------------------------------
+template <typename Hash>
 struct BackwardLds {
-  unsigned long long run_val[kRunSlots * kRunLen];
-  int run_key[kRunSlots];
+  Hash hash;
   float wave_part[4][8];
   int tile_max_bits;
 };
 
 // One tile of the backward.  Every return is workgroup-uniform; the caller puts a barrier
 // between tiles (the LDS tables are reused).
-template <int RT, int SX, int SY>
+template <int RT, int SX, int SY, typename Hash>
 __device__ __forceinline__ void backward_tile(
-    BackwardLds& lds, int tile_x, int tile_y, int ntx, int nty, int b,
+    BackwardLds<Hash>& lds, int tile_x, int tile_y, int ntx, int nty, int b,
     const float* __restrict__ grad_depth, const float* __restrict__ depth,
     const float* __restrict__ sdf, int R, long long sdf_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx, float rfy,
     int sdf_grad_mode, float* __restrict__ g_sdf, long long g_sdf_view_stride,
     float* __restrict__ partials) {
-  unsigned long long* run_val = lds.run_val;
-  int* run_key = lds.run_key;
+  Hash& hash = lds.hash;
   float (*wave_part)[8] = lds.wave_part;
   int& tile_max_bits = lds.tile_max_bits;
 
@@ -351,8 +352,7 @@ __device__ __forceinline__ void backward_tile(
     if (tid < 8) part[tid] = 0.0f;
     return;
   }
-  for (int i = tid; i < kRunSlots; i += kBlock) run_key[i] = -1;
-  for (int i = tid; i < kRunSlots * kRunLen; i += kBlock) run_val[i] = 0ull;
+  hash.clear(tid, kBlock);
   if (tid == 0) tile_max_bits = 0;
   __syncthreads();
   gmax = wave_max(gmax);
@@ -440,7 +440,7 @@ __device__ __forceinline__ void backward_tile(
 #ifdef SDFR_ABLATE_NO_SCATTER  // timing-only build
       acc[7] += 1e-30f * (w0 + w1 + w2 + w3 + w4 + w5 + w6 + w7 + to_fixed);
 #else
-      add_cell(run_key, run_val, gvol, c.lin, Rr, wk, to_fixed);
+      hash.add_cell(gvol, c.lin, Rr, wk, to_fixed);
 #endif
     } else {
       float* g0 = gvol + c.lin;
@@ -465,15 +465,7 @@ __device__ __forceinline__ void backward_tile(
   __syncthreads();
   if (tid < 8) part[tid] = (wave_part[0][tid] + wave_part[1][tid]) + (wave_part[2][tid] + wave_part[3][tid]);
 
-  // flush the runs: lane j of an 8-lane group writes element j of one run (32 contiguous bytes)
-  const int nvox = Rr * Rr * Rr;
-  for (int i = tid; i < kRunSlots * kRunLen; i += kBlock) {
-    const int key = run_key[i >> 3];
-    if (key < 0) continue;  // most slots of a tile stay empty
-    const long long q = (long long)run_val[i];
-    const int lin = key * kRunLen + (i & 7);
-    if (q != 0 && lin < nvox) atomicAdd(gvol + lin, (float)q * from_fixed);
-  }
+  hash.flush(gvol, Rr * Rr * Rr, from_fixed, tid, kBlock);
 }
 
 template <int RT, int SX, int SY, int GX, int GY>
@@ -483,13 +475,14 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, float cx, float cy,
     float rfx, float rfy, int sdf_grad_mode, float* __restrict__ g_sdf,
     long long g_sdf_view_stride, float* __restrict__ partials) {
-  __shared__ BackwardLds lds;
+  using Hash = typename std::conditional<(SX * SY > 1), BatchHash, SmallHash>::type;
+  __shared__ BackwardLds<Hash> lds;
   const int b = blockIdx.z;
 #pragma unroll 1
   for (int g = 0; g < GX * GY; ++g) {  // a group of tiles per workgroup, as in the forward
     const int tx = blockIdx.x * GX + g % GX, ty = blockIdx.y * GY + g / GX;
     if (tx < ntx && ty < nty) {
-      backward_tile<RT, SX, SY>(lds, tx, ty, ntx, nty, b, grad_depth, depth, sdf, R, sdf_view_stride,
+      backward_tile<RT, SX, SY, Hash>(lds, tx, ty, ntx, nty, b, grad_depth, depth, sdf, R, sdf_view_stride,
                                 setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride,
                                 partials);
       __syncthreads();

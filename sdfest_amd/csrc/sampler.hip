@@ -90,8 +90,7 @@ __global__ __launch_bounds__(kPts) void pc_loss_backward_kernel(
     const float* __restrict__ quat, const float* __restrict__ scale, const float* __restrict__ sdf,
     int R, long long sdf_view_stride, float* __restrict__ g_sdf, long long g_sdf_view_stride,
     float* __restrict__ partials, int nblk) {
-  __shared__ unsigned long long run_val[kRunSlots * kRunLen];
-  __shared__ int run_key[kRunSlots];
+  __shared__ SmallHash hash;   // point clouds of any density
   __shared__ float wave_part[kPts / 64][8];
   __shared__ int blk_max_bits;
 
@@ -106,8 +105,7 @@ __global__ __launch_bounds__(kPts) void pc_loss_backward_kernel(
   const float* vol = sdf + (size_t)v * sdf_view_stride;
   float* gvol = g_sdf + (size_t)v * g_sdf_view_stride;
 
-  for (int k = tid; k < kRunSlots; k += kPts) run_key[k] = -1;
-  for (int k = tid; k < kRunSlots * kRunLen; k += kPts) run_val[k] = 0ull;
+  hash.clear(tid, kPts);
   if (tid == 0) blk_max_bits = 0;
 
   bool live = false;
@@ -170,7 +168,7 @@ __global__ __launch_bounds__(kPts) void pc_loss_backward_kernel(
     const float w4 = x1w * ay * az, w5 = x1w * ay * c.oz, w6 = x1w * c.oy * az, w7 = x1w * c.oy * c.oz;
     if (fixed_ok) {
       const float wk[8] = {w0, w1, w2, w3, w4, w5, w6, w7};
-      add_cell(run_key, run_val, gvol, c.lin, Rr, wk, to_fixed);
+      hash.add_cell(gvol, c.lin, Rr, wk, to_fixed);
     } else if (go != 0.0f) {
       float* g0 = gvol + c.lin;
       atomicAdd(g0, w0);                atomicAdd(g0 + 1, w1);
@@ -195,13 +193,7 @@ __global__ __launch_bounds__(kPts) void pc_loss_backward_kernel(
   int e2;
   (void)frexpf(bound, &e2);
   const float from_fixed = ldexpf(1.0f, e2 - kFixedBits);
-  const int nvox = Rr * Rr * Rr;
-  for (int k = tid; k < kRunSlots * kRunLen; k += kPts) {
-    const int key = run_key[k >> 3];
-    const long long q = (long long)run_val[k];
-    const int lin = key * kRunLen + (k & 7);
-    if (key >= 0 && q != 0 && lin < nvox) atomicAdd(gvol + lin, (float)q * from_fixed);
-  }
+  hash.flush(gvol, Rr * Rr * Rr, from_fixed, tid, kPts);
 }
 
 // one wave per view: fixed-order sum of the block partials, then the Jacobian of q^ = q/|q|
