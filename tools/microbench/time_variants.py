@@ -1,7 +1,7 @@
 """Time forward/backward of several builds of the library (ablation / variant .so files)."""
 import ctypes, os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import oracle
 from sdfest_amd import _lib
@@ -27,6 +27,9 @@ def main():
         pos = torch.tensor([[0.0, 0.0, -1.5]], device=dev).repeat(B, 1).contiguous()
         quat = torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=dev).repeat(B, 1).contiguous()
         isc = torch.full((B,), 2.0, device=dev)
+    if mode == "mug":   # mug-sized objects at 0.4-0.6 m: ~1.1 pixels per voxel
+        pos = pos * torch.tensor([0.3, 0.3, 0.3], device=dev)
+        isc = torch.full((B,), 1 / 0.055, device=dev)
     if mode == "nosurface":
         sdf = torch.ones_like(sdf)
     if mode == "offscreen":
