@@ -79,8 +79,15 @@ __device__ __forceinline__ void gather_cell(const float* __restrict__ src, int R
 // viewing axis so that the 2 x 2 blocks lie in the plane its rays sweep -- were built and measured:
 // 261 us.  12 MiB of records no longer fit the 4 MiB per-XCD L2.)
 // Hb = ceil(R/2) blocks per axis; one x-slab = 4 Hb^2 records.
-__host__ __device__ __forceinline__ int record_slab(int R) { return 4 * ((R + 1) >> 1) * ((R + 1) >> 1); }
+#ifndef SDFR_RECORD_ORDER_LINEAR
+#define SDFR_RECORD_ORDER_LINEAR 0  // 1: records in grid order (timing experiments)
+#endif
+constexpr bool kRecordsBlocked = !SDFR_RECORD_ORDER_LINEAR;
+__host__ __device__ __forceinline__ int record_slab(int R) {
+  return kRecordsBlocked ? 4 * ((R + 1) >> 1) * ((R + 1) >> 1) : R * R;
+}
 __device__ __forceinline__ int record_index(int x, int y, int z, int Hb) {
+  if (!kRecordsBlocked) return (x * (2 * Hb) + y) * (2 * Hb) + z;  // timing only: even R
   return (((x * Hb + (y >> 1)) * Hb + (z >> 1)) << 2) | ((y & 1) << 1) | (z & 1);
 }
 
@@ -105,6 +112,75 @@ __device__ __forceinline__ void gather_cell_records(__amdgpu_buffer_rsrc_t recs,
   const i32x4 b = __builtin_amdgcn_raw_buffer_load_b128(recs, rix * 16, record_slab(Rr) * 16, 0);
   c.v[0] = __int_as_float(a.x); c.v[1] = __int_as_float(a.y); c.v[2] = __int_as_float(a.z); c.v[3] = __int_as_float(a.w);
   c.v[4] = __int_as_float(b.x); c.v[5] = __int_as_float(b.y); c.v[6] = __int_as_float(b.z); c.v[7] = __int_as_float(b.w);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The march's sample: trilinear SDF value at a grid-space point, written for the VALU.
+//
+// rocprofv3 showed the forward kernel issuing VALU instructions in ~97 % of its SIMD cycles
+// (SQ_ACTIVE_INST_VALU x 4 vs. busy cycles): at 8 waves per SIMD the record loads are hidden and
+// the march is bound by its instruction count, 49 VALU per step.  This version does the same
+// arithmetic, bit for bit (same floor/clamp, same (1-f)*a + f*b lerps in the order x, y, z), in
+// 2-wide packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 run two fp32 lanes per issue
+// slot on gfx950) and forms the record index in float (exact below 2^24) with a bit permute
+// instead of three conversions and ten integer ops.
+// `src`: buffer descriptor of the face records (PACKED) or of the plain grid.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+__host__ __device__ __forceinline__ constexpr bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+template <int RT, bool PACKED>
+__device__ __forceinline__ float march_sample(__amdgpu_buffer_rsrc_t src, int R, f32x2 gxy, float gz) {
+  const int Rr = RT > 0 ? RT : R;
+  const float top = (float)(Rr - 2), fR = (float)Rr;
+  const f32x2 bxy = {fminf(fmaxf(floorf(gxy.x), 0.0f), top), fminf(fmaxf(floorf(gxy.y), 0.0f), top)};
+  const float bz = fminf(fmaxf(floorf(gz), 0.0f), top);
+  const f32x2 oxy = gxy - bxy, axy = 1.0f - oxy;
+  const float oz = gz - bz, az = 1.0f - oz;
+  // linear index of corner 000, formed in float where that is exact (R^3 <= 2^24)
+  const int lin = (Rr <= 256) ? (int)fmaf(fmaf(bxy.x, fR, bxy.y), fR, bz)
+                              : ((int)bxy.x * Rr + (int)bxy.y) * Rr + (int)bz;
+  f32x2 a01, a23, b01, b23;  // corner pairs (z, z+1) at (x,y), (x,y+1), (x+1,y), (x+1,y+1)
+  if (PACKED) {
+    int rix;
+    if (!kRecordsBlocked) {
+      rix = lin;
+    } else if (RT > 0 && is_pow2(RT) && RT >= 4) {
+      // lin = [x | y5..y1 y0 | z5..z1 z0]  ->  record_index = [x | y5..y1 | z5..z1 | y0 | z0]
+      // as two bit-field inserts (the compiler expands the C form into and/and/and/or3)
+      constexpr int L = __builtin_ctz(RT > 0 ? RT : 2);
+      constexpr int zhi = ((1 << L) - 2) << 1;  // where z5..z1 land
+      int t;
+      asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(t) : "s"(zhi), "v"(lin << 1), "v"(lin));  // VOP3: no literals
+      asm("v_bfi_b32 %0, 2, %1, %2" : "=v"(rix) : "v"(lin >> (L - 1)), "v"(t));
+    } else {
+      rix = record_index((int)bxy.x, (int)bxy.y, (int)bz, (Rr + 1) >> 1);
+    }
+    const i32x4 a = __builtin_amdgcn_raw_buffer_load_b128(src, rix * 16, 0, 0);
+    const i32x4 b = __builtin_amdgcn_raw_buffer_load_b128(src, rix * 16, record_slab(Rr) * 16, 0);
+    a01 = f32x2{__int_as_float(a.x), __int_as_float(a.y)};
+    a23 = f32x2{__int_as_float(a.z), __int_as_float(a.w)};
+    b01 = f32x2{__int_as_float(b.x), __int_as_float(b.y)};
+    b23 = f32x2{__int_as_float(b.z), __int_as_float(b.w)};
+  } else {
+    // plain grid: four z-pairs, 8-byte loads at 4-byte alignment
+    const int off = lin * 4;
+    const i32x2 p00 = __builtin_amdgcn_raw_buffer_load_b64(src, off, 0, 0);
+    const i32x2 p01 = __builtin_amdgcn_raw_buffer_load_b64(src, off, Rr * 4, 0);
+    const i32x2 p10 = __builtin_amdgcn_raw_buffer_load_b64(src, off, Rr * Rr * 4, 0);
+    const i32x2 p11 = __builtin_amdgcn_raw_buffer_load_b64(src, off, (Rr * Rr + Rr) * 4, 0);
+    a01 = f32x2{__int_as_float(p00.x), __int_as_float(p00.y)};
+    a23 = f32x2{__int_as_float(p01.x), __int_as_float(p01.y)};
+    b01 = f32x2{__int_as_float(p10.x), __int_as_float(p10.y)};
+    b23 = f32x2{__int_as_float(p11.x), __int_as_float(p11.y)};
+  }
+  // lerp x (both z of the y and the y+1 edge), then y, then z: sdf_renderer_cuda.cu:231-238
+  const f32x2 ox2 = {oxy.x, oxy.x}, ax2 = {axy.x, axy.x}, oy2 = {oxy.y, oxy.y}, ay2 = {axy.y, axy.y};
+  const f32x2 c0 = __builtin_elementwise_fma(b01, ox2, a01 * ax2);
+  const f32x2 c1 = __builtin_elementwise_fma(b23, ox2, a23 * ax2);
+  const f32x2 c = __builtin_elementwise_fma(c1, oy2, c0 * ay2);
+  return fmaf(c.y, oz, c.x * az);
 }
 
 // trilinear value, lerp order x, y, z (sdf_renderer_cuda.cu:231-238)

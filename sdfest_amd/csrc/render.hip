@@ -137,18 +137,16 @@ __device__ __forceinline__ bool overlaps(const Rect& r, int px, int py, int w, i
 // ---------------------------------------------------------------------------------------------
 // forward.  grid = (macro-tiles x, macro-tiles y, views)
 // ---------------------------------------------------------------------------------------------
-// One lane marches K rays at once (the pixels it owns in K consecutive sub-tiles): the march is
-// a chain of dependent gathers (address -> 32-byte record -> lerp -> next t), so with one ray
-// per lane a wave sits idle for a full cache round trip per step; K independent chains keep K
-// record loads in flight per lane.  All K rays start together, so the step number of every
-// active ray equals the iteration count `n` and one counter enforces SDFR_MAX_MARCH_STEPS.
-template <int RT, bool PACKED, int K, int SX, int SY>
+// One ray per lane.  (K rays per lane -- K independent load chains to hide the gather latency --
+// was built and measured: slower at every K; the march is bound by its VALU
+// instruction count, so the loop below is written for that: packed fp32 in march_sample, and a
+// loop whose only per-step bookkeeping is two compares and one add.)
+template <int RT, bool PACKED, int SX, int SY>
 __device__ __forceinline__ void forward_tile(
     int tile_x, int tile_y, int b, const float* __restrict__ src, int R, long long src_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx, float rfy,
     float threshold, int vec_ok, float* __restrict__ depth) {
   constexpr int kSubs = SX * SY, kTileW = SX * kSubW, kTileH = SY * kSubH;
-  static_assert(kSubs % K == 0, "K must divide the sub-tiles of a tile");
   using PF = Patch<kPatchWFwd>;
   const int px0 = tile_x * kTileW, py0 = tile_y * kTileH;
   const ViewSetup& s = setup[b];
@@ -157,8 +155,7 @@ __device__ __forceinline__ void forward_tile(
   const int tid = threadIdx.x;
 
   if (!overlaps(rc, px0, py0, kTileW, kTileH)) {
-    // nothing of the cube projects here: stream zeros.  (Non-temporal stores were measured: same
-    // time, +28 % WRITE_SIZE -- partial lines no longer combine in L2.)
+    // nothing of the cube projects here: stream zeros.
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     if (vec_ok) {
@@ -181,92 +178,70 @@ __device__ __forceinline__ void forward_tile(
   const int wave = tid >> 6, lane = tid & 63;
   const float scale = s.scale;
   const float kgrid = s.dgk;
-  const float ogx = s.og[0], ogy = s.og[1], ogz = s.og[2];
+  const f32x2 ogxy = {s.og[0], s.og[1]};
+  const float ogz = s.og[2];
   const float* vol = src + (size_t)b * src_view_stride;
   const int Rr = RT > 0 ? RT : R;
-  // record array as a buffer resource (PACKED only; R <= 128 so the size fits 32 bits)
-  const __amdgpu_buffer_rsrc_t recs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(vol), 0, PACKED ? Rr * record_slab(Rr) * 16 : 0, 0x00020000);
+  // the record array / the grid as a buffer resource: 32-bit byte offsets, hardware range check
+  const unsigned src_bytes = PACKED ? (unsigned)Rr * record_slab(Rr) * 16u : (unsigned)Rr * Rr * Rr * 4u;
+  const __amdgpu_buffer_rsrc_t vsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vol), 0, (int)src_bytes, 0x00020000);
 
-  for (int grp = 0; grp < kSubs; grp += K) {
-    float t[K], t_far[K], dgx[K], dgy[K], dgz[K], ndz[K], result[K];
-    bool active[K];
-    int pix[K];  // row * W + col, or -1 outside the image
-    bool any = false;
+  for (int sub = 0; sub < kSubs; ++sub) {
+    const int sx = px0 + (sub % SX) * kSubW, sy = py0 + (sub / SX) * kSubH;
+    const int col = sx + PF::ox(wave) + PF::x(lane), row = sy + PF::oy(wave) + PF::y(lane);
+    const bool inside = (col < W) && (row < H);
+    float result = 0.0f;
+    // wave-uniform: does this wave's 8x8 patch touch the rectangle at all?
+    if (overlaps(rc, sx + PF::ox(wave), sy + PF::oy(wave), PF::W, PF::H)) {
+      // unit ray (cu:137-154), rotated into the object frame with d.z = -1 folded in
+      const float dx = ((float)col + 0.5f - cx) * rfx;
+      const float dy = -((float)row + 0.5f - cy) * rfy;
+      const float inv_len = __builtin_amdgcn_rsqf(fmaf(dx, dx, fmaf(dy, dy, 1.0f)));
+      const float ux = fmaf(s.rot[0], dx, fmaf(s.rot[3], dy, -s.rot[6]));
+      const float uy = fmaf(s.rot[1], dx, fmaf(s.rot[4], dy, -s.rot[7]));
+      const float uz = fmaf(s.rot[2], dx, fmaf(s.rot[5], dy, -s.rot[8]));
+      const float dv[3] = {ux * inv_len, uy * inv_len, uz * inv_len};
+      // Slab test in the object frame (the cube is axis-aligned there, its centre at +e from
+      // the ray origin, f_i = dobj_i): same accept/reject as cu:156-194.  A ray parallel to a
+      // slab (f = 0) needs no special case: 1/f = +-inf puts both plane distances at the same
+      // infinity when the origin is outside the slab (-> t_near > t_far or t_far < 0) and at
+      // opposite infinities when it is inside (-> the axis does not constrain the interval).
+      // Pixels outside the screen rectangle fail this test by construction of the rectangle.
+      float t_near = -1e-10f, tf = 1e10f;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int sub = grp + k;
-      const int sx = px0 + (sub % SX) * kSubW, sy = py0 + (sub / SX) * kSubH;
-      const int col = sx + PF::ox(wave) + PF::x(lane), row = sy + PF::oy(wave) + PF::y(lane);
-      const bool inside = (col < W) && (row < H);
-      pix[k] = inside ? row * W + col : -1;
-      result[k] = 0.0f;
-      active[k] = false;
-      t[k] = 0.0f; t_far[k] = 0.0f; dgx[k] = dgy[k] = dgz[k] = 0.0f; ndz[k] = 0.0f;
-      // wave-uniform: does this wave's 8x8 patch touch the rectangle at all?
-      if (overlaps(rc, sx + PF::ox(wave), sy + PF::oy(wave), PF::W, PF::H)) {
-        // unit ray (cu:137-154), rotated into the object frame with d.z = -1 folded in
-        const float dx = ((float)col + 0.5f - cx) * rfx;
-        const float dy = -((float)row + 0.5f - cy) * rfy;
-        const float inv_len = __builtin_amdgcn_rsqf(fmaf(dx, dx, fmaf(dy, dy, 1.0f)));
-        const float ux = fmaf(s.rot[0], dx, fmaf(s.rot[3], dy, -s.rot[6]));
-        const float uy = fmaf(s.rot[1], dx, fmaf(s.rot[4], dy, -s.rot[7]));
-        const float uz = fmaf(s.rot[2], dx, fmaf(s.rot[5], dy, -s.rot[8]));
-        const float dv[3] = {ux * inv_len, uy * inv_len, uz * inv_len};
-        // Slab test in the object frame (the cube is axis-aligned there, its centre at +e from
-        // the ray origin, f_i = dobj_i): same accept/reject as cu:156-194.  A ray parallel to a
-        // slab (f = 0) needs no special case: 1/f = +-inf puts both plane distances at the same
-        // infinity when the origin is outside the slab (-> t_near > t_far or t_far < 0) and at
-        // opposite infinities when it is inside (-> the axis does not constrain the interval).
-        // Pixels outside the screen rectangle fail this test by construction of the rectangle.
-        float t_near = -1e-10f, tf = 1e10f;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          const float inv = __builtin_amdgcn_rcpf(dv[a]);
-          const float ta = s.ep[a] * inv, tb = s.em[a] * inv;
-          t_near = fmaxf(t_near, fminf(ta, tb));
-          tf = fminf(tf, fmaxf(ta, tb));
+      for (int a = 0; a < 3; ++a) {
+        const float inv = __builtin_amdgcn_rcpf(dv[a]);
+        const float ta = s.ep[a] * inv, tb = s.em[a] * inv;
+        t_near = fmaxf(t_near, fminf(ta, tb));
+        tf = fminf(tf, fmaxf(ta, tb));
+      }
+      const bool miss = !inside || (t_near > tf) || (tf < 0.0f);
+      float t = fmaxf(t_near, 0.0f);
+      if (!miss && (t < tf)) {
+        const f32x2 dgxy = {dv[0] * kgrid, dv[1] * kgrid};
+        const float dgz = dv[2] * kgrid;
+        // sphere tracing, cu:196-260: sample, hit if dist < threshold * t (t = the sample's own
+        // t), else advance by dist and stop at the far plane or at the step cap.  A lane that
+        // leaves keeps its t: the depth of a hit is formed once, after the loop.
+        bool hit;
+        int n = 0;  // samples taken; the same for every lane still in the loop
+        for (;;) {
+          ++n;
+          const f32x2 t2 = {t, t};
+          const float value = march_sample<RT, PACKED>(vsrc, R, __builtin_elementwise_fma(t2, dgxy, ogxy),
+                                                       fmaf(t, dgz, ogz));
+          const float dist = value * scale;
+          hit = dist < threshold * t;
+          if (hit) break;
+          const float tn = t + dist;
+          if (!(tn < tf) || n >= SDFR_MAX_MARCH_STEPS) break;
+          t = tn;
         }
-        const bool miss = !inside || (t_near > tf) || (tf < 0.0f);
-        t[k] = fmaxf(t_near, 0.0f);
-        t_far[k] = tf;
-        dgx[k] = dv[0] * kgrid; dgy[k] = dv[1] * kgrid; dgz[k] = dv[2] * kgrid;
-        ndz[k] = inv_len;  // -d.z
-        active[k] = !miss && (t[k] < tf);
-        any = any || active[k];
+        result = hit ? t * inv_len : 0.0f;  // inv_len = -d.z of the unit ray
       }
     }
-    int n = 0;
-    while (any) {
-      Cell c[K];
-      // issue every ray's record loads before touching any of the data; a finished ray is
-      // parked on its last (valid) point and its result is ignored
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        if (PACKED)
-          gather_cell_records<RT>(recs, R, fmaf(t[k], dgx[k], ogx), fmaf(t[k], dgy[k], ogy),
-                                  fmaf(t[k], dgz[k], ogz), c[k]);
-        else
-          gather_cell<RT, false>(vol, R, fmaf(t[k], dgx[k], ogx), fmaf(t[k], dgy[k], ogy),
-                                 fmaf(t[k], dgz[k], ogz), c[k]);
-      }
-      ++n;
-      any = false;
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const float dist = trilerp(c[k]) * scale;
-        const bool hit = active[k] && (dist < threshold * t[k]);
-        result[k] = hit ? t[k] * ndz[k] : result[k];
-        const float tn = t[k] + dist;
-        const bool go_on = active[k] && !hit && (tn < t_far[k]) && (n < SDFR_MAX_MARCH_STEPS);
-        t[k] = go_on ? tn : t[k];
-        active[k] = go_on;
-        any = any || go_on;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k)
-      if (pix[k] >= 0) img[pix[k]] = result[k];
+    if (inside) img[row * W + col] = result;
   }
 }
 
@@ -276,7 +251,7 @@ __device__ __forceinline__ void forward_tile(
 // (B=256, forward/backward us: 1x1 257/211, 1x2 264/311, 1x4 270/317, 2x4 295/363; a persistent
 // grid striding over the whole tile list: 377/472): the dispatcher hides the very uneven tile
 // costs only when it has many independent workgroups.  GX = GY = 1 is what ships.
-template <int RT, bool PACKED, int K, int SX, int SY, int GX, int GY>
+template <int RT, bool PACKED, int SX, int SY, int GX, int GY>
 __global__ __launch_bounds__(kBlock) void render_forward_kernel(
     const float* __restrict__ src, int R, long long src_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, float cx, float cy,
@@ -286,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
   for (int g = 0; g < GX * GY; ++g) {
     const int tx = blockIdx.x * GX + g % GX, ty = blockIdx.y * GY + g / GX;
     if (tx < ntx && ty < nty)
-      forward_tile<RT, PACKED, K, SX, SY>(tx, ty, b, src, R, src_view_stride, setup, W, H, cx, cy, rfx,
+      forward_tile<RT, PACKED, SX, SY>(tx, ty, b, src, R, src_view_stride, setup, W, H, cx, cy, rfx,
                                           rfy, threshold, vec_ok, depth);
   }
 }
@@ -529,7 +504,7 @@ __global__ __launch_bounds__(64) void pose_reduce_kernel(const float* __restrict
 // host side
 // ---------------------------------------------------------------------------------------------
 int check_common(int R, int B, int W, int H, float fx, float fy) {
-  if (R < 2 || R > 1024) return fail(SDFR_E_INVALID, "R=%d out of range [2,1024]", R);
+  if (R < 2 || R > 1023) return fail(SDFR_E_INVALID, "R=%d out of range [2,1023]", R);
   if (B < 0 || W < 0 || H < 0) return fail(SDFR_E_INVALID, "negative size B=%d W=%d H=%d", B, W, H);
   if (B > 65535) return fail(SDFR_E_INVALID, "B=%d exceeds 65535 views per call", B);
   if (kSmallTile.ny(H) > 65535) return fail(SDFR_E_INVALID, "H=%d too large", H);
@@ -604,7 +579,7 @@ extern "C" int sdfr_render_forward(const float* sdf, int R, long long sdf_view_s
   const float rfx = (float)(1.0 / (double)fx), rfy = (float)(1.0 / (double)fy);
   const int vec_ok = (W % 4 == 0) && ((uintptr_t)depth % 16 == 0);
 #define SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, SX, SY, GX, GY, GRID)                                 \
-  hipLaunchKernelGGL((render_forward_kernel<RT, PK, 1, SX, SY, GX, GY>), GRID, dim3(kBlock), 0, st,  \
+  hipLaunchKernelGGL((render_forward_kernel<RT, PK, SX, SY, GX, GY>), GRID, dim3(kBlock), 0, st,  \
                      SRC, R, STRIDE, setup, W, H, ntx, nty, cx, cy, rfx, rfy, threshold, vec_ok, depth)
 #define SDFR_LAUNCH_FWD(RT, PK, SRC, STRIDE)                                                         \
   do {                                                                                               \
