@@ -103,6 +103,37 @@ SDFR_API int sdfr_render_backward(const float* grad_depth, const float* depth, c
                          float* g_inv_scale, void* workspace, size_t workspace_bytes, int device,
                          void* stream);
 
+/* ---- render + masked depth-L1 in one pass ------------------------------------ */
+
+/* The depth term of SDFPipeline._compute_view_losses (sdfest/estimation/simple_setup.py:129-135)
+ * folded into the renderer, so that neither the loss kernel nor the gradient image exists:
+ *     overlap = (target > 0) & (depth > 0);   loss[b] = mean |depth - target| over overlap
+ * sdfr_render_forward_l1 = sdfr_render_forward + loss[b] (NaN for an empty overlap, like
+ * torch.mean of an empty selection) + loss_stats[b] = {sum |depth - target|, count} (2 floats per
+ * view, consumed by the backward).  Sums are reduced in a fixed order (bitwise reproducible).
+ *   target [B][H][W]  the observed depth images (read at hit pixels only). */
+SDFR_API size_t sdfr_render_forward_l1_workspace_bytes(int R, int B, int W, int H);
+SDFR_API int sdfr_render_forward_l1(const float* sdf, int R, long long sdf_view_stride,
+                           const float* pos, const float* quat, const float* inv_scale, int B,
+                           int W, int H, float cx, float cy, float fx, float fy, float threshold,
+                           const float* target, float* depth, float* loss, float* loss_stats,
+                           void* workspace, size_t workspace_bytes, int device, void* stream);
+
+/* sdfr_render_backward with the upstream gradient image formed in the kernel:
+ *     grad_depth = k_b * sign(depth - target) on the overlap, 0 elsewhere,
+ *     k_b = loss_weight * (loss_grad ? loss_grad[b] : 1) / count_b      (0 for an empty overlap)
+ * i.e. the gradient of sum_b loss_weight * loss_grad[b] * loss[b].  Results are identical to
+ * sdfr_depth_l1_loss followed by sdfr_render_backward.  Workspace: sdfr_render_backward_workspace_bytes.
+ *   loss_grad [B] DEVICE array or NULL;  loss_stats [B][2] from sdfr_render_forward_l1. */
+SDFR_API int sdfr_render_backward_l1(const float* loss_grad, float loss_weight, const float* loss_stats,
+                            const float* target, const float* depth, const float* sdf, int R,
+                            long long sdf_view_stride, const float* pos, const float* quat,
+                            const float* inv_scale, int B, int W, int H, float cx, float cy,
+                            float fx, float fy, int sdf_grad_mode, float* g_sdf,
+                            long long g_sdf_view_stride, float* g_pos, float* g_quat,
+                            float* g_inv_scale, void* workspace, size_t workspace_bytes, int device,
+                            void* stream);
+
 /* ---- trilinear SDF sampler of the point-cloud loss --------------------------------------- */
 
 /* Replaces losses.pc_loss (sdfest/estimation/losses.py:32-135), for all views of a step at once.

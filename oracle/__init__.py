@@ -224,6 +224,25 @@ def depth_to_pointcloud(depth, fx, fy, cx0, cy0, dtype=np.float32):
     return pts[:n].copy()
 
 
+def depth_l1(estimate, target, weight=1.0):
+    """Masked depth-L1 of SDFPipeline._compute_view_losses (estimation/simple_setup.py:129-135) and
+    its gradient w.r.t. the estimate, float64: overlap = (target > 0) & (estimate > 0),
+    loss = mean |estimate - target| over overlap (nan if empty; torch.mean of an empty selection),
+    grad = weight * sign(estimate - target) / count on the overlap (torch.abs has gradient 0 at 0).
+    Works on one image (H,W) or a stack (B,H,W) -> per-view loss."""
+    e = np.asarray(estimate, dtype=np.float64)
+    t = np.asarray(target, dtype=np.float64)
+    single = e.ndim == 2
+    e3, t3 = (e[None], t[None]) if single else (e, t)
+    mask = (t3 > 0) & (e3 > 0)
+    cnt = mask.sum(axis=(1, 2)).astype(np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        loss = np.where(mask, np.abs(e3 - t3), 0.0).sum(axis=(1, 2)) / cnt
+        k = np.where(cnt > 0, weight / cnt, 0.0)
+    grad = np.where(mask, np.sign(e3 - t3), 0.0) * k[:, None, None]
+    return (loss[0], grad[0]) if single else (loss, grad)
+
+
 # --- synthetic inputs shared by tests and bench (SURVEY.md section 8d) ---------------------
 
 def blobs_sdf(seed=0, R=64, K=8):

@@ -5,11 +5,11 @@ Public surface mirrors the reference's ``sdfest.differentiable_renderer``
 unchanged; see INTEGRATION.md.
 """
 from .differentiable_renderer import (BatchRenderPlan, Camera, SDFRendererFunctionGPU,
-                                      render_depth_batch,
+                                      render_depth_batch, render_depth_l1_batch,
                                       render_depth_gpu)
 
 from .losses import pc_loss, pc_loss_batch
 from .vae import SDFDecoder
 from .pipeline import RenderAndCompare
 
-__all__ = ["RenderAndCompare", "SDFDecoder", "pc_loss", "pc_loss_batch", "BatchRenderPlan", "Camera", "SDFRendererFunctionGPU", "render_depth_gpu", "render_depth_batch"]
+__all__ = ["RenderAndCompare", "SDFDecoder", "pc_loss", "pc_loss_batch", "BatchRenderPlan", "Camera", "SDFRendererFunctionGPU", "render_depth_gpu", "render_depth_batch", "render_depth_l1_batch"]

@@ -29,6 +29,13 @@ SIGNATURES = {
     "sdfr_render_backward": (c_int, [c_fp, c_fp, c_fp, c_int, c_ll, c_fp, c_fp, c_fp, c_int,
                                      c_int, c_int, c_f, c_f, c_f, c_f, c_int, c_fp, c_ll, c_fp,
                                      c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),
+    "sdfr_render_forward_l1_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
+    "sdfr_render_forward_l1": (c_int, [c_fp, c_int, c_ll, c_fp, c_fp, c_fp, c_int, c_int, c_int,
+                                       c_f, c_f, c_f, c_f, c_f, c_fp, c_fp, c_fp, c_fp, c_fp, c_sz,
+                                       c_int, c_fp]),
+    "sdfr_render_backward_l1": (c_int, [c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_int, c_ll, c_fp, c_fp,
+                                        c_fp, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_int, c_fp,
+                                        c_ll, c_fp, c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),
     "sdfr_pc_loss_forward": (c_int, [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_ll,
                                      c_fp, c_int, c_fp]),
     "sdfr_pc_loss_backward_workspace_bytes": (c_sz, [c_int, c_int]),

@@ -141,11 +141,17 @@ __device__ __forceinline__ bool overlaps(const Rect& r, int px, int py, int w, i
 // was built and measured: slower at every K; the march is bound by its VALU
 // instruction count, so the loop below is written for that: packed fp32 in march_sample, and a
 // loop whose only per-step bookkeeping is two compares and one add.)
-template <int RT, bool PACKED, int SX, int SY>
+//
+// LOSS: the masked depth-L1 of simple_setup.py:129-135 is folded in: a hit pixel
+// also reads the observed depth and the tile leaves (sum |est - obs|, count) over the overlap
+// mask (obs > 0) & (est > 0) in `loss_part`; est = 0 off the object, so only hit pixels can be in
+// the mask and culled tiles never touch the observed image.
+template <int RT, bool PACKED, int SX, int SY, bool LOSS>
 __device__ __forceinline__ void forward_tile(
-    int tile_x, int tile_y, int b, const float* __restrict__ src, int R, long long src_view_stride,
-    const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx, float rfy,
-    float threshold, int vec_ok, float* __restrict__ depth) {
+    int tile_x, int tile_y, int ntx, int nty, int b, const float* __restrict__ src, int R,
+    long long src_view_stride, const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy,
+    float rfx, float rfy, float threshold, int vec_ok, float* __restrict__ depth,
+    const float* __restrict__ target, float* __restrict__ loss_part) {
   constexpr int kSubs = SX * SY, kTileW = SX * kSubW, kTileH = SY * kSubH;
   using PF = Patch<kPatchWFwd>;
   const int px0 = tile_x * kTileW, py0 = tile_y * kTileH;
@@ -187,6 +193,8 @@ __device__ __forceinline__ void forward_tile(
   const __amdgpu_buffer_rsrc_t vsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vol), 0, (int)src_bytes, 0x00020000);
 
+  float l_sum = 0.0f, l_cnt = 0.0f;  // LOSS: this lane's share of the tile's (sum, count)
+  const float* obs = LOSS ? target + (size_t)b * H * W : nullptr;
   for (int sub = 0; sub < kSubs; ++sub) {
     const int sx = px0 + (sub % SX) * kSubW, sy = py0 + (sub / SX) * kSubH;
     const int col = sx + PF::ox(wave) + PF::x(lane), row = sy + PF::oy(wave) + PF::y(lane);
@@ -239,9 +247,27 @@ __device__ __forceinline__ void forward_tile(
           t = tn;
         }
         result = hit ? t * inv_len : 0.0f;  // inv_len = -d.z of the unit ray
+        if (LOSS && result > 0.0f) {
+          const float o = obs[row * W + col];
+          if (o > 0.0f) {
+            l_sum += fabsf(result - o);
+            l_cnt += 1.0f;
+          }
+        }
       }
     }
     if (inside) img[row * W + col] = result;
+  }
+  if (LOSS) {
+    // fixed-order tile sum: lanes (butterfly) -> waves -> one record per tile
+    __shared__ float wave_loss[4][2];
+    l_sum = wave_sum(l_sum);
+    l_cnt = wave_sum(l_cnt);
+    if (lane == 0) { wave_loss[wave][0] = l_sum; wave_loss[wave][1] = l_cnt; }
+    __syncthreads();
+    if (tid < 2)
+      loss_part[(((size_t)b * nty + tile_y) * ntx + tile_x) * 2 + tid] =
+          (wave_loss[0][tid] + wave_loss[1][tid]) + (wave_loss[2][tid] + wave_loss[3][tid]);
   }
 }
 
@@ -251,18 +277,19 @@ __device__ __forceinline__ void forward_tile(
 // (B=256, forward/backward us: 1x1 257/211, 1x2 264/311, 1x4 270/317, 2x4 295/363; a persistent
 // grid striding over the whole tile list: 377/472): the dispatcher hides the very uneven tile
 // costs only when it has many independent workgroups.  GX = GY = 1 is what ships.
-template <int RT, bool PACKED, int SX, int SY, int GX, int GY>
+template <int RT, bool PACKED, int SX, int SY, int GX, int GY, bool LOSS>
 __global__ __launch_bounds__(kBlock) void render_forward_kernel(
     const float* __restrict__ src, int R, long long src_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, float cx, float cy,
-    float rfx, float rfy, float threshold, int vec_ok, float* __restrict__ depth) {
+    float rfx, float rfy, float threshold, int vec_ok, float* __restrict__ depth,
+    const float* __restrict__ target, float* __restrict__ loss_part) {
   const int b = blockIdx.z;
 #pragma unroll 1
   for (int g = 0; g < GX * GY; ++g) {
     const int tx = blockIdx.x * GX + g % GX, ty = blockIdx.y * GY + g / GX;
     if (tx < ntx && ty < nty)
-      forward_tile<RT, PACKED, SX, SY>(tx, ty, b, src, R, src_view_stride, setup, W, H, cx, cy, rfx,
-                                          rfy, threshold, vec_ok, depth);
+      forward_tile<RT, PACKED, SX, SY, LOSS>(tx, ty, ntx, nty, b, src, R, src_view_stride, setup, W, H, cx,
+                                             cy, rfx, rfy, threshold, vec_ok, depth, target, loss_part);
   }
 }
 
@@ -278,9 +305,12 @@ struct BackwardLds {
 
 // One tile of the backward.  Every return is workgroup-uniform; the caller puts a barrier
 // between tiles (the LDS tables are reused).
-template <int RT, int SX, int SY, typename Hash>
+// LOSS: `grad_depth` is the OBSERVED depth image and the upstream gradient is formed on the fly,
+// go = +-k on the overlap mask (obs > 0) & (est > 0), k = weight * dL/dloss_b / count_b
+// (the gradient of simple_setup.py:129-135's masked mean of |est - obs|; 0 where est == obs).
+template <int RT, int SX, int SY, typename Hash, bool LOSS>
 __device__ __forceinline__ void backward_tile(
-    BackwardLds<Hash>& lds, int tile_x, int tile_y, int ntx, int nty, int b,
+    BackwardLds<Hash>& lds, int tile_x, int tile_y, int ntx, int nty, int b, float loss_k,
     const float* __restrict__ grad_depth, const float* __restrict__ depth,
     const float* __restrict__ sdf, int R, long long sdf_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx, float rfy,
@@ -320,6 +350,10 @@ __device__ __forceinline__ void backward_tile(
     const int row = py0 + (sub / SX) * kSubH + PB::oy(wave) + PB::y(lane);
     const bool hit = zs[sub] != 0.0f;
     gos[sub] = hit ? gimg[(size_t)row * W + col] : 0.0f;
+    if (LOSS) {
+      const float e = zs[sub], o = gos[sub];
+      gos[sub] = (e > 0.0f && o > 0.0f) ? ((e > o) ? loss_k : ((e < o) ? -loss_k : 0.0f)) : 0.0f;
+    }
     gmax = fmaxf(gmax, fabsf(gos[sub]));
     any_hit = any_hit || hit;
   }
@@ -443,21 +477,28 @@ __device__ __forceinline__ void backward_tile(
   hash.flush(gvol, Rr * Rr * Rr, from_fixed, tid, kBlock);
 }
 
-template <int RT, int SX, int SY, int GX, int GY>
+template <int RT, int SX, int SY, int GX, int GY, bool LOSS>
 __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     const float* __restrict__ grad_depth, const float* __restrict__ depth,
     const float* __restrict__ sdf, int R, long long sdf_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, float cx, float cy,
     float rfx, float rfy, int sdf_grad_mode, float* __restrict__ g_sdf,
-    long long g_sdf_view_stride, float* __restrict__ partials) {
+    long long g_sdf_view_stride, float* __restrict__ partials, const float* __restrict__ loss_grad,
+    const float* __restrict__ loss_stats, float loss_weight) {
   using Hash = typename std::conditional<(SX * SY > 1), BatchHash, SmallHash>::type;
   __shared__ BackwardLds<Hash> lds;
   const int b = blockIdx.z;
+  float loss_k = 0.0f;
+  if (LOSS) {  // same expression as depth_l1_grad_kernel (loop.hip): k = weight / count, 0 if empty
+    const float cnt = loss_stats[2 * b + 1];
+    const float w = loss_grad ? loss_weight * loss_grad[b] : loss_weight;
+    loss_k = cnt > 0.0f ? w / cnt : 0.0f;
+  }
 #pragma unroll 1
   for (int g = 0; g < GX * GY; ++g) {  // a group of tiles per workgroup, as in the forward
     const int tx = blockIdx.x * GX + g % GX, ty = blockIdx.y * GY + g / GX;
     if (tx < ntx && ty < nty) {
-      backward_tile<RT, SX, SY, Hash>(lds, tx, ty, ntx, nty, b, grad_depth, depth, sdf, R, sdf_view_stride,
+      backward_tile<RT, SX, SY, Hash, LOSS>(lds, tx, ty, ntx, nty, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride,
                                 setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride,
                                 partials);
       __syncthreads();
@@ -500,6 +541,36 @@ __global__ __launch_bounds__(64) void pose_reduce_kernel(const float* __restrict
   }
 }
 
+// Fixed-order sum of a view's per-tile (sum, count) records: one wave per view.
+// loss[b] = sum / count (NaN for an empty overlap, like torch.mean of an empty selection).
+__global__ __launch_bounds__(64) void loss_reduce_kernel(const float* __restrict__ loss_part,
+                                                         const ViewSetup* __restrict__ setup,
+                                                         int ntx, int nty, int tile_w, int tile_h,
+                                                         float* __restrict__ loss,
+                                                         float* __restrict__ stats) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const ViewSetup& s = setup[b];
+  const int x0 = s.rect[0], y0 = s.rect[1], x1 = s.rect[2], y1 = s.rect[3];
+  float sum = 0.0f, cnt = 0.0f;
+  if (x1 > x0 && y1 > y0) {
+    const int tx0 = x0 / tile_w, tx1 = (x1 - 1) / tile_w, ty0 = y0 / tile_h, ty1 = (y1 - 1) / tile_h;
+    const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1);
+    const float2* base = reinterpret_cast<const float2*>(loss_part) + (size_t)b * ntx * nty;
+    for (int i = lane; i < n; i += 64) {
+      const float2 p = base[(size_t)(ty0 + i / nx) * ntx + tx0 + i % nx];
+      sum += p.x;
+      cnt += p.y;
+    }
+  }
+  sum = wave_sum(sum);
+  cnt = wave_sum(cnt);
+  if (lane == 0) {
+    loss[b] = sum / cnt;
+    stats[2 * b] = sum;
+    stats[2 * b + 1] = cnt;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -535,6 +606,13 @@ extern "C" size_t sdfr_render_forward_workspace_bytes(int R, int B, int W, int H
   return n;
 }
 
+extern "C" size_t sdfr_render_forward_l1_workspace_bytes(int R, int B, int W, int H) {
+  size_t n = (sdfr_render_forward_workspace_bytes(R, B, W, H) + 127) & ~(size_t)127;
+  // one (sum, count) record per tile of the finer geometry
+  if (B > 0 && W > 0 && H > 0) n += (size_t)B * kSmallTile.nx(W) * kSmallTile.ny(H) * 2 * sizeof(float);
+  return n;
+}
+
 extern "C" size_t sdfr_render_backward_workspace_bytes(int R, int B, int W, int H) {
   (void)R;
   if (B <= 0 || W <= 0 || H <= 0) return setup_bytes(B);
@@ -542,26 +620,32 @@ extern "C" size_t sdfr_render_backward_workspace_bytes(int R, int B, int W, int 
   return setup_bytes(B) + (size_t)B * kSmallTile.nx(W) * kSmallTile.ny(H) * 8 * sizeof(float);
 }
 
-extern "C" int sdfr_render_forward(const float* sdf, int R, long long sdf_view_stride,
-                                   const float* pos, const float* quat, const float* inv_scale,
-                                   int B, int W, int H, float cx, float cy, float fx, float fy,
-                                   float threshold, float* depth, void* workspace,
-                                   size_t workspace_bytes, int device, void* stream) {
+namespace {
+// target == nullptr: the plain forward.  Otherwise the forward with the depth-L1 folded in.
+int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_stride, const float* pos,
+                 const float* quat, const float* inv_scale, int B, int W, int H, float cx, float cy,
+                 float fx, float fy, float threshold, float* depth, const float* target, float* loss,
+                 float* loss_stats, void* workspace, size_t workspace_bytes, int device,
+                 void* stream) {
+  const bool with_loss = target != nullptr;
+  const size_t need = with_loss ? sdfr_render_forward_l1_workspace_bytes(R, B, W, H)
+                                : sdfr_render_forward_workspace_bytes(R, B, W, H);
   if (int rc = check_common(R, B, W, H, fx, fy)) return rc;
   if (sdf_view_stride != 0 && sdf_view_stride < (long long)R * R * R)
     return fail(SDFR_E_INVALID, "sdf_view_stride must be 0 or >= R^3");
   if (B == 0 || W == 0 || H == 0) return 0;
   if (!sdf || !pos || !quat || !inv_scale || !depth || !workspace)
-    return fail(SDFR_E_NULL, "sdfr_render_forward: NULL pointer argument");
-  if (workspace_bytes < sdfr_render_forward_workspace_bytes(R, B, W, H))
-    return fail(SDFR_E_WORKSPACE, "sdfr_render_forward: workspace %zu < %zu bytes", workspace_bytes,
-                sdfr_render_forward_workspace_bytes(R, B, W, H));
+    return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
+  if (workspace_bytes < need)
+    return fail(SDFR_E_WORKSPACE, "%s: workspace %zu < %zu bytes", fn, workspace_bytes, need);
   if ((uintptr_t)workspace % alignof(ViewSetup))
     return fail(SDFR_E_INVALID, "workspace must be %zu-byte aligned", alignof(ViewSetup));
   SDFR_HIP_TRY(hipSetDevice(device));
   hipStream_t st = (hipStream_t)stream;
   ViewSetup* setup = (ViewSetup*)workspace;
   float* cells = (float*)((char*)workspace + setup_bytes(B));  // 128-byte aligned
+  float* loss_part = (float*)((char*)workspace +
+                              ((sdfr_render_forward_workspace_bytes(R, B, W, H) + 127) & ~(size_t)127));
   hipLaunchKernelGGL(view_setup_kernel, dim3((B + 63) / 64), dim3(64), 0, st, pos, quat, inv_scale,
                      B, R, W, H, cx, cy, fx, fy, setup);
   const bool packed = use_packed(R, B, sdf_view_stride);
@@ -578,9 +662,15 @@ extern "C" int sdfr_render_forward(const float* sdf, int R, long long sdf_view_s
                         (unsigned)((nty + SDFR_GROUP_Y - 1) / SDFR_GROUP_Y), (unsigned)B);
   const float rfx = (float)(1.0 / (double)fx), rfy = (float)(1.0 / (double)fy);
   const int vec_ok = (W % 4 == 0) && ((uintptr_t)depth % 16 == 0);
+#define SDFR_LAUNCH_FWD_L(RT, PK, SRC, STRIDE, SX, SY, GX, GY, GRID, LOSS)                           \
+  hipLaunchKernelGGL((render_forward_kernel<RT, PK, SX, SY, GX, GY, LOSS>), GRID, dim3(kBlock), 0,  \
+                     st, SRC, R, STRIDE, setup, W, H, ntx, nty, cx, cy, rfx, rfy, threshold, vec_ok,  \
+                     depth, target, loss_part)
 #define SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, SX, SY, GX, GY, GRID)                                 \
-  hipLaunchKernelGGL((render_forward_kernel<RT, PK, SX, SY, GX, GY>), GRID, dim3(kBlock), 0, st,  \
-                     SRC, R, STRIDE, setup, W, H, ntx, nty, cx, cy, rfx, rfy, threshold, vec_ok, depth)
+  do {                                                                                               \
+    if (with_loss) SDFR_LAUNCH_FWD_L(RT, PK, SRC, STRIDE, SX, SY, GX, GY, GRID, true);               \
+    else SDFR_LAUNCH_FWD_L(RT, PK, SRC, STRIDE, SX, SY, GX, GY, GRID, false);                        \
+  } while (0)
 #define SDFR_LAUNCH_FWD(RT, PK, SRC, STRIDE)                                                         \
   do {                                                                                               \
     if (macro)                                                                                       \
@@ -596,17 +686,51 @@ extern "C" int sdfr_render_forward(const float* sdf, int R, long long sdf_view_s
   }
 #undef SDFR_LAUNCH_FWD
 #undef SDFR_LAUNCH_FWD_G
+#undef SDFR_LAUNCH_FWD_L
+  if (with_loss)
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(B), dim3(64), 0, st, loss_part, setup, ntx, nty, geom.w(),
+                       geom.h(), loss, loss_stats);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }
+}  // namespace
 
-extern "C" int sdfr_render_backward(const float* grad_depth, const float* depth, const float* sdf,
-                                    int R, long long sdf_view_stride, const float* pos,
-                                    const float* quat, const float* inv_scale, int B, int W, int H,
-                                    float cx, float cy, float fx, float fy, int sdf_grad_mode,
-                                    float* g_sdf, long long g_sdf_view_stride, float* g_pos,
-                                    float* g_quat, float* g_inv_scale, void* workspace,
-                                    size_t workspace_bytes, int device, void* stream) {
+extern "C" int sdfr_render_forward(const float* sdf, int R, long long sdf_view_stride,
+                                   const float* pos, const float* quat, const float* inv_scale,
+                                   int B, int W, int H, float cx, float cy, float fx, float fy,
+                                   float threshold, float* depth, void* workspace,
+                                   size_t workspace_bytes, int device, void* stream) {
+  return forward_impl("sdfr_render_forward", sdf, R, sdf_view_stride, pos, quat, inv_scale, B, W, H, cx,
+                      cy, fx, fy, threshold, depth, nullptr, nullptr, nullptr, workspace,
+                      workspace_bytes, device, stream);
+}
+
+extern "C" int sdfr_render_forward_l1(const float* sdf, int R, long long sdf_view_stride,
+                                      const float* pos, const float* quat, const float* inv_scale,
+                                      int B, int W, int H, float cx, float cy, float fx, float fy,
+                                      float threshold, const float* target, float* depth, float* loss,
+                                      float* loss_stats, void* workspace, size_t workspace_bytes,
+                                      int device, void* stream) {
+  if (B > 0 && W > 0 && H > 0 && (!target || !loss || !loss_stats))
+    return fail(SDFR_E_NULL, "sdfr_render_forward_l1: NULL pointer argument");
+  return forward_impl("sdfr_render_forward_l1", sdf, R, sdf_view_stride, pos, quat, inv_scale, B, W, H,
+                      cx, cy, fx, fy, threshold, depth, target, loss, loss_stats, workspace,
+                      workspace_bytes, device, stream);
+}
+
+
+namespace {
+// loss_stats == nullptr: the plain backward (grad_depth = upstream gradient image).  Otherwise
+// grad_depth is the observed depth image and the gradient of the folded-in depth-L1 is formed in
+// the kernel.
+int backward_impl(const char* fn, const float* grad_depth, const float* depth, const float* sdf, int R,
+                  long long sdf_view_stride, const float* pos, const float* quat,
+                  const float* inv_scale, int B, int W, int H, float cx, float cy, float fx, float fy,
+                  int sdf_grad_mode, float* g_sdf, long long g_sdf_view_stride, float* g_pos,
+                  float* g_quat, float* g_inv_scale, const float* loss_grad, const float* loss_stats,
+                  float loss_weight, void* workspace, size_t workspace_bytes, int device,
+                  void* stream) {
+  const bool with_loss = loss_stats != nullptr;
   if (int rc = check_common(R, B, W, H, fx, fy)) return rc;
   const long long vox = (long long)R * R * R;
   if (sdf_view_stride != 0 && sdf_view_stride < vox)
@@ -615,14 +739,14 @@ extern "C" int sdfr_render_backward(const float* grad_depth, const float* depth,
     return fail(SDFR_E_INVALID, "g_sdf_view_stride must be 0 or R^3");
   if (sdf_grad_mode != SDFR_SDF_GRAD_EXACT && sdf_grad_mode != SDFR_SDF_GRAD_CUDA_COMPAT)
     return fail(SDFR_E_INVALID, "unknown sdf_grad_mode %d", sdf_grad_mode);
-  if (!g_sdf) return fail(SDFR_E_NULL, "sdfr_render_backward: g_sdf is NULL");
+  if (!g_sdf) return fail(SDFR_E_NULL, "%s: g_sdf is NULL", fn);
   SDFR_HIP_TRY(hipSetDevice(device));
   hipStream_t st = (hipStream_t)stream;
   const size_t g_bytes = (size_t)vox * sizeof(float) * (g_sdf_view_stride ? (size_t)(B > 0 ? B : 1) : 1);
   SDFR_HIP_TRY(hipMemsetAsync(g_sdf, 0, g_bytes, st));
   if (B == 0) return 0;
   if (!g_pos || !g_quat || !g_inv_scale || !pos || !quat || !inv_scale)
-    return fail(SDFR_E_NULL, "sdfr_render_backward: NULL pointer argument");
+    return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
   if (W == 0 || H == 0) {
     SDFR_HIP_TRY(hipMemsetAsync(g_pos, 0, (size_t)B * 3 * sizeof(float), st));
     SDFR_HIP_TRY(hipMemsetAsync(g_quat, 0, (size_t)B * 4 * sizeof(float), st));
@@ -630,9 +754,9 @@ extern "C" int sdfr_render_backward(const float* grad_depth, const float* depth,
     return 0;
   }
   if (!grad_depth || !depth || !sdf || !workspace)
-    return fail(SDFR_E_NULL, "sdfr_render_backward: NULL pointer argument");
+    return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
   if (workspace_bytes < sdfr_render_backward_workspace_bytes(R, B, W, H))
-    return fail(SDFR_E_WORKSPACE, "sdfr_render_backward: workspace %zu < %zu bytes", workspace_bytes,
+    return fail(SDFR_E_WORKSPACE, "%s: workspace %zu < %zu bytes", fn, workspace_bytes,
                 sdfr_render_backward_workspace_bytes(R, B, W, H));
   if ((uintptr_t)workspace % alignof(ViewSetup))
     return fail(SDFR_E_INVALID, "workspace must be %zu-byte aligned", alignof(ViewSetup));
@@ -647,10 +771,16 @@ extern "C" int sdfr_render_backward(const float* grad_depth, const float* depth,
   const dim3 grid_group((unsigned)((ntx + SDFR_GROUP_X - 1) / SDFR_GROUP_X),
                         (unsigned)((nty + SDFR_GROUP_Y - 1) / SDFR_GROUP_Y), (unsigned)B);
   const float rfx = (float)(1.0 / (double)fx), rfy = (float)(1.0 / (double)fy);
-#define SDFR_LAUNCH_BWD(RT, SX, SY, GX, GY, GRID)                                                    \
-  hipLaunchKernelGGL((render_backward_kernel<RT, SX, SY, GX, GY>), GRID, dim3(kBlock), 0, st,        \
+#define SDFR_LAUNCH_BWD_L(RT, SX, SY, GX, GY, GRID, LOSS)                                            \
+  hipLaunchKernelGGL((render_backward_kernel<RT, SX, SY, GX, GY, LOSS>), GRID, dim3(kBlock), 0, st,  \
                      grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, ntx, nty, cx, cy, rfx, \
-                     rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials)
+                     rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, loss_grad, loss_stats,  \
+                     loss_weight)
+#define SDFR_LAUNCH_BWD(RT, SX, SY, GX, GY, GRID)                                                    \
+  do {                                                                                               \
+    if (with_loss) SDFR_LAUNCH_BWD_L(RT, SX, SY, GX, GY, GRID, true);                                \
+    else SDFR_LAUNCH_BWD_L(RT, SX, SY, GX, GY, GRID, false);                                         \
+  } while (0)
   if (R == 64) {
     if (macro) SDFR_LAUNCH_BWD(64, SDFR_MACRO_SX, SDFR_MACRO_SY, SDFR_GROUP_X, SDFR_GROUP_Y, grid_group);
     else SDFR_LAUNCH_BWD(64, 1, 1, 1, 1, grid_tile);
@@ -659,8 +789,40 @@ extern "C" int sdfr_render_backward(const float* grad_depth, const float* depth,
     else SDFR_LAUNCH_BWD(0, 1, 1, 1, 1, grid_tile);
   }
 #undef SDFR_LAUNCH_BWD
+#undef SDFR_LAUNCH_BWD_L
   hipLaunchKernelGGL(pose_reduce_kernel, dim3(B), dim3(64), 0, st, partials, setup, ntx, nty,
                      geom.w(), geom.h(), g_pos, g_quat, g_inv_scale);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }
+}  // namespace
+
+extern "C" int sdfr_render_backward(const float* grad_depth, const float* depth, const float* sdf,
+                                    int R, long long sdf_view_stride, const float* pos,
+                                    const float* quat, const float* inv_scale, int B, int W, int H,
+                                    float cx, float cy, float fx, float fy, int sdf_grad_mode,
+                                    float* g_sdf, long long g_sdf_view_stride, float* g_pos,
+                                    float* g_quat, float* g_inv_scale, void* workspace,
+                                    size_t workspace_bytes, int device, void* stream) {
+  return backward_impl("sdfr_render_backward", grad_depth, depth, sdf, R, sdf_view_stride, pos, quat,
+                       inv_scale, B, W, H, cx, cy, fx, fy, sdf_grad_mode, g_sdf, g_sdf_view_stride, g_pos,
+                       g_quat, g_inv_scale, nullptr, nullptr, 0.0f, workspace, workspace_bytes, device,
+                       stream);
+}
+
+extern "C" int sdfr_render_backward_l1(const float* loss_grad, float loss_weight,
+                                       const float* loss_stats, const float* target,
+                                       const float* depth, const float* sdf, int R,
+                                       long long sdf_view_stride, const float* pos, const float* quat,
+                                       const float* inv_scale, int B, int W, int H, float cx, float cy,
+                                       float fx, float fy, int sdf_grad_mode, float* g_sdf,
+                                       long long g_sdf_view_stride, float* g_pos, float* g_quat,
+                                       float* g_inv_scale, void* workspace, size_t workspace_bytes,
+                                       int device, void* stream) {
+  if (B > 0 && !loss_stats) return fail(SDFR_E_NULL, "sdfr_render_backward_l1: loss_stats is NULL");
+  return backward_impl("sdfr_render_backward_l1", target, depth, sdf, R, sdf_view_stride, pos, quat,
+                       inv_scale, B, W, H, cx, cy, fx, fy, sdf_grad_mode, g_sdf, g_sdf_view_stride, g_pos,
+                       g_quat, g_inv_scale, loss_grad, loss_stats, loss_weight, workspace,
+                       workspace_bytes, device, stream);
+}
+

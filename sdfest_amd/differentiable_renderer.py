@@ -229,6 +229,79 @@ def render_depth_batch(sdf: torch.Tensor, positions: torch.Tensor, orientations:
                               sdf_grad_mode)
 
 
+class _RenderL1Batch(torch.autograd.Function):
+    """Batched render with the masked depth-L1 folded in: returns the per-view loss
+    and the depth images; the gradient image never exists."""
+
+    @staticmethod
+    def forward(ctx, sdf, position, orientation, inv_scale, target, threshold, camera, sdf_grad_mode):
+        fx, fy, cx, cy, _ = camera.get_pinhole_camera_parameters(0.5)
+        sdf_c = sdf.detach().contiguous()
+        pos = position.detach().contiguous()
+        quat = orientation.detach().contiguous()
+        isc = inv_scale.detach().contiguous()
+        tgt = target.detach().contiguous()
+        for t, n in ((sdf_c, "sdf"), (pos, "position"), (quat, "orientation"), (isc, "inv_scale"),
+                     (tgt, "target")):
+            _check_input(t, n)
+        B, R = pos.shape[0], sdf_c.shape[-1]
+        W, H = camera.width, camera.height
+        if tuple(tgt.shape) != (B, H, W):
+            raise RuntimeError(f"target must have shape {(B, H, W)}, got {tuple(tgt.shape)}")
+        stride = R * R * R if sdf_c.dim() == 4 else 0
+        dev = sdf_c.device
+        depth = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        loss = torch.empty((B,), dtype=torch.float32, device=dev)
+        stats = torch.empty((B, 2), dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        ws = _workspace(dev, L.sdfr_render_forward_l1_workspace_bytes(R, B, W, H))
+        rc = L.sdfr_render_forward_l1(_ptr(sdf_c), R, stride, _ptr(pos), _ptr(quat), _ptr(isc), B, W, H,
+                                      cx, cy, fx, fy, threshold, _ptr(tgt), _ptr(depth), _ptr(loss),
+                                      _ptr(stats), _ptr(ws), ws.numel(), dev.index, _stream(dev))
+        _lib.check(rc, "sdfr_render_forward_l1")
+        ctx.save_for_backward(depth, stats, tgt, sdf_c, pos, quat, isc)
+        ctx.cam = (W, H, cx, cy, fx, fy)
+        ctx.sdf_grad_mode = sdf_grad_mode
+        ctx.mark_non_differentiable(depth)
+        return loss, depth
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_depth_unused):
+        depth, stats, tgt, sdf, pos, quat, isc = ctx.saved_tensors
+        W, H, cx, cy, fx, fy = ctx.cam
+        B, R = pos.shape[0], sdf.shape[-1]
+        stride = R * R * R if sdf.dim() == 4 else 0
+        dev = sdf.device
+        g_sdf = torch.empty_like(sdf)
+        g_pos = torch.empty_like(pos)
+        g_quat = torch.empty_like(quat)
+        g_isc = torch.empty_like(isc)
+        gl = grad_loss.to(torch.float32).contiguous()
+        L = _lib.lib()
+        ws = _workspace(dev, L.sdfr_render_backward_workspace_bytes(R, B, W, H))
+        rc = L.sdfr_render_backward_l1(_ptr(gl), 1.0, _ptr(stats), _ptr(tgt), _ptr(depth), _ptr(sdf), R,
+                                       stride, _ptr(pos), _ptr(quat), _ptr(isc), B, W, H, cx, cy, fx,
+                                       fy, ctx.sdf_grad_mode, _ptr(g_sdf), stride, _ptr(g_pos),
+                                       _ptr(g_quat), _ptr(g_isc), _ptr(ws), ws.numel(), dev.index,
+                                       _stream(dev))
+        _lib.check(rc, "sdfr_render_backward_l1")
+        return g_sdf, g_pos, g_quat, g_isc, None, None, None, None
+
+
+def render_depth_l1_batch(sdf: torch.Tensor, positions: torch.Tensor, orientations: torch.Tensor,
+                          inv_scales: torch.Tensor, targets: torch.Tensor, threshold: float,
+                          camera: Camera, sdf_grad_mode: int = 0):
+    """``render_depth_batch`` and the depth term of ``SDFPipeline._compute_view_losses``
+    (estimation/simple_setup.py:129-135) in one pass over the images.
+
+    Returns ``(loss, depth)``: ``loss[b] = mean |depth[b] - targets[b]|`` over the pixels where both
+    are > 0 (NaN if there is none), differentiable w.r.t. sdf, positions, orientations and
+    inv_scales; ``depth`` (B,H,W) is returned for inspection and carries no gradient.
+    """
+    return _RenderL1Batch.apply(sdf, positions, orientations, inv_scales, targets, threshold, camera,
+                                sdf_grad_mode)
+
+
 class BatchRenderPlan:
     """Pre-allocated buffers for repeated forward+backward of B views (no per-call allocation).
 
@@ -254,8 +327,10 @@ class BatchRenderPlan:
         self.g_quat = torch.empty((B, 4), **f32)
         self.g_inv_scale = torch.empty((B,), **f32)
         L = _lib.lib()
-        nbytes = max(L.sdfr_render_forward_workspace_bytes(R, B, self.W, self.H),
+        nbytes = max(L.sdfr_render_forward_l1_workspace_bytes(R, B, self.W, self.H),
                      L.sdfr_render_backward_workspace_bytes(R, B, self.W, self.H), 256)
+        self.loss = torch.empty((B,), **f32)
+        self.loss_stats = torch.empty((B, 2), **f32)
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         self._L = L
 
@@ -277,4 +352,28 @@ class BatchRenderPlan:
             self.g_inv_scale.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(),
             self.device.index, _stream(self.device))
         _lib.check(rc, "sdfr_render_backward")
+        return self.g_sdf, self.g_pos, self.g_quat, self.g_inv_scale
+
+    def forward_l1(self, sdf, pos, quat, inv_scale, threshold: float, target):
+        """forward + masked depth-L1 against ``target`` (B,H,W): returns (depth, loss (B,))."""
+        rc = self._L.sdfr_render_forward_l1(
+            sdf.data_ptr(), self.R, self.sdf_stride, pos.data_ptr(), quat.data_ptr(),
+            inv_scale.data_ptr(), self.B, self.W, self.H, self.cx, self.cy, self.fx, self.fy,
+            threshold, target.data_ptr(), self.depth.data_ptr(), self.loss.data_ptr(),
+            self.loss_stats.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(),
+            self.device.index, _stream(self.device))
+        _lib.check(rc, "sdfr_render_forward_l1")
+        return self.depth, self.loss
+
+    def backward_l1(self, target, sdf, pos, quat, inv_scale, weight: float = 1.0, loss_grad=None):
+        """gradients of sum_b weight * loss_grad[b] * loss[b] (after ``forward_l1``)."""
+        rc = self._L.sdfr_render_backward_l1(
+            loss_grad.data_ptr() if loss_grad is not None else None, weight,
+            self.loss_stats.data_ptr(), target.data_ptr(), self.depth.data_ptr(), sdf.data_ptr(),
+            self.R, self.sdf_stride, pos.data_ptr(), quat.data_ptr(), inv_scale.data_ptr(), self.B,
+            self.W, self.H, self.cx, self.cy, self.fx, self.fy, self.sdf_grad_mode,
+            self.g_sdf.data_ptr(), self.sdf_stride, self.g_pos.data_ptr(), self.g_quat.data_ptr(),
+            self.g_inv_scale.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(),
+            self.device.index, _stream(self.device))
+        _lib.check(rc, "sdfr_render_backward_l1")
         return self.g_sdf, self.g_pos, self.g_quat, self.g_inv_scale

@@ -36,3 +36,28 @@ def test_depth_to_pointcloud_matches_oracle_and_convention():
     ref = oracle.depth_to_pointcloud(depth, fx, fy, cx0, cy0)
     assert pts.shape == ref.shape == (int((depth != 0).sum()), 3)
     assert np.allclose(pts, ref, rtol=1e-6, atol=1e-7)
+
+
+def test_oracle_depth_l1_matches_torch_expression():
+    """oracle.depth_l1 == the reference's torch expression (simple_setup.py:129-135) and its autograd."""
+    import torch
+    import oracle
+    rng = np.random.default_rng(0)
+    est = rng.uniform(0.5, 2.0, (3, 24, 32))
+    tgt = est + rng.normal(0, 0.05, est.shape)
+    est[rng.uniform(size=est.shape) < 0.3] = 0.0
+    tgt[rng.uniform(size=tgt.shape) < 0.3] = 0.0
+    tgt[0, 0, 0] = est[0, 0, 0] = 1.25          # a tie inside the mask: gradient 0
+    tgt[2] = 0.0                                # empty overlap
+    loss, grad = oracle.depth_l1(est, tgt, weight=0.7)
+    for v in range(3):
+        e = torch.tensor(est[v], requires_grad=True)
+        t = torch.tensor(tgt[v])
+        l = torch.mean(torch.abs(e - t)[(t > 0) & (e > 0)])
+        if v == 2:
+            assert np.isnan(loss[v]) and torch.isnan(l) and np.all(grad[v] == 0)
+            continue
+        (0.7 * l).backward()
+        assert abs(loss[v] - l.item()) < 1e-12
+        np.testing.assert_allclose(grad[v], e.grad.numpy(), rtol=1e-12, atol=0)
+    assert grad[0, 0, 0] == 0.0
