@@ -149,9 +149,12 @@ class FusedRenderAndCompare:
     def __init__(self, decoder, camera: Camera, config: Dict, depth_images: torch.Tensor,
                  camera_positions: Optional[torch.Tensor] = None,
                  camera_orientations: Optional[torch.Tensor] = None,
-                 shape_optimization: bool = True, device="cuda"):
+                 shape_optimization: bool = True, device="cuda", fuse_depth_loss: bool = True):
         from . import _lib
         from .differentiable_renderer import BatchRenderPlan
+        # True: the depth-L1 runs inside the render kernels (sdfr_render_forward_l1 / _backward_l1);
+        # False: sdfr_render_forward -> sdfr_depth_l1_loss -> sdfr_render_backward.  Same results.
+        self.fuse_depth_loss = bool(fuse_depth_loss)
         self.L = _lib.lib()
         self.check = _lib.check
         self.dec = decoder
@@ -244,13 +247,21 @@ class FusedRenderAndCompare:
                                         self.inv_scale.data_ptr(), self.scale_v.data_ptr(), d, st),
                    "sdfr_pose_to_views")
         sdf = self.sdf[0, 0]
-        est = self.plan.forward(sdf, self.pos_c, self.quat_c, self.inv_scale, self.cfg["threshold"])
-        self.check(L.sdfr_depth_l1_loss(est.data_ptr(), self.target.data_ptr(), self.V, self.W, self.H,
-                                        self.cfg["depth_weight"], self.loss_depth.data_ptr(),
-                                        self.grad_est.data_ptr(), self.ws_loss.data_ptr(),
-                                        self.ws_loss.numel(), d, st), "sdfr_depth_l1_loss")
-        g_sdf, g_pos, g_quat, g_is = self.plan.backward(self.grad_est, sdf, self.pos_c, self.quat_c,
-                                                        self.inv_scale)
+        if self.fuse_depth_loss:
+            self.plan.forward_l1(sdf, self.pos_c, self.quat_c, self.inv_scale, self.cfg["threshold"],
+                                 self.target)
+            self.loss_depth = self.plan.loss
+            g_sdf, g_pos, g_quat, g_is = self.plan.backward_l1(self.target, sdf, self.pos_c, self.quat_c,
+                                                               self.inv_scale,
+                                                               weight=self.cfg["depth_weight"])
+        else:
+            est = self.plan.forward(sdf, self.pos_c, self.quat_c, self.inv_scale, self.cfg["threshold"])
+            self.check(L.sdfr_depth_l1_loss(est.data_ptr(), self.target.data_ptr(), self.V, self.W, self.H,
+                                            self.cfg["depth_weight"], self.loss_depth.data_ptr(),
+                                            self.grad_est.data_ptr(), self.ws_loss.data_ptr(),
+                                            self.ws_loss.numel(), d, st), "sdfr_depth_l1_loss")
+            g_sdf, g_pos, g_quat, g_is = self.plan.backward(self.grad_est, sdf, self.pos_c, self.quat_c,
+                                                            self.inv_scale)
         have_pts = self.max_pts > 0
         if have_pts:
             self.check(L.sdfr_pc_loss_forward(self.points.data_ptr(), self.offsets.data_ptr(), self.V,

@@ -170,8 +170,8 @@ def test_c5_full_loop_converges(mug_decoder):
     assert hist[-1]["latent"].abs().max().item() > 1e-3      # the latent really was optimised
 
 
-@pytest.mark.parametrize("shape_opt", [False, True])
-def test_fused_graph_loop_matches_autograd_loop(mug_decoder, shape_opt):
+@pytest.mark.parametrize("shape_opt,fuse_l1", [(False, True), (True, True), (True, False)])
+def test_fused_graph_loop_matches_autograd_loop(mug_decoder, shape_opt, fuse_l1):
     """The launch-sequence / hipGraph iteration against the autograd-driven one: same parameter
     trajectory (2 cameras, 160x120, 8 iterations), eager and graph-replayed."""
     from sdfest_amd import Camera
@@ -200,7 +200,8 @@ def test_fused_graph_loop_matches_autograd_loop(mug_decoder, shape_opt):
     h_ref = []
     ref_loop(obs, p0, q0, s0, z0, camera_positions=cam_pos, camera_orientations=cam_quat,
              shape_optimization=shape_opt, history=h_ref)
-    fused = FusedRenderAndCompare(dec, cam, cfg, obs, cam_pos, cam_quat, shape_optimization=shape_opt)
+    fused = FusedRenderAndCompare(dec, cam, cfg, obs, cam_pos, cam_quat, shape_optimization=shape_opt,
+                                  fuse_depth_loss=fuse_l1)
     for use_graph in (False, True, True):
         h = []
         out = fused(p0, q0, s0, z0, use_graph=use_graph, history=h)

@@ -61,6 +61,16 @@ def main():
         fout = fused(*args[1:])
         torch.cuda.synchronize()
         ftimes.append((time.perf_counter() - t0) / 50 * 1e3)
+    # ... with the depth-L1 as its own kernel between forward and backward (the round-1 v1 sequence)
+    unf = FusedRenderAndCompare(dec, cam, loop.config, targets, fuse_depth_loss=False)
+    unf(*args[1:])
+    torch.cuda.synchronize()
+    utimes = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        unf(*args[1:])
+        torch.cuda.synchronize()
+        utimes.append((time.perf_counter() - t0) / 50 * 1e3)
     # decoder alone
     z = torch.zeros(1, 8, device=dev)
     with torch.no_grad():
@@ -73,6 +83,7 @@ def main():
     print(json.dumps({"workload": f"C5 loop, {views} view(s) 640x480, mug decoder, 50 Adam iterations",
                       "ms_per_iteration_autograd": round(float(np.median(times)), 4),
                       "ms_per_iteration_graph": round(float(np.median(ftimes)), 4),
+                      "ms_per_iteration_graph_separate_l1_kernel": round(float(np.median(utimes)), 4),
                       "graph_final_position_error_mm": round((fout[0] - p_true).norm().item() * 1e3, 3),
                       "decoder_forward_us": round(e0.elapsed_time(e1) / 100 * 1e3, 2),
                       "final_position_error_mm": round((out[0] - p_true).norm().item() * 1e3, 3)}))

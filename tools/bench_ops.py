@@ -78,6 +78,39 @@ def main():
     t = timeit(lambda: plan.forward(sdfs, pos, quat, isc, 0.005), 20)
     out[f"render forward, one SDF per view, B={B}"] = {"us": round(t, 1), "views_per_s": round(B / t * 1e6, 1),
                                                          "hit_pixels": int((plan.depth > 0).sum())}
+    # batched render-and-compare step on the depth term (C3 poses): forward -> masked L1 -> backward,
+    # with the loss as its own kernel vs folded into the render kernels
+    from sdfest_amd import _lib
+    L = _lib.lib()
+    B = 256
+    sdf64 = torch.tensor(oracle.blobs_sdf(0), device=dev)
+    pos, quat, isc = (torch.tensor(a, device=dev) for a in oracle.random_poses(B, seed=1))
+    plan = BatchRenderPlan(64, B, cam, device=dev)
+    tpos = pos + 0.01 * torch.randn_like(pos)
+    target = plan.forward(sdf64, tpos, quat, isc, 0.005).clone()
+    loss = torch.empty(B, device=dev)
+    grad = torch.empty_like(target)
+    ws = torch.empty(max(L.sdfr_depth_l1_workspace_bytes(B, 640, 480), 256), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def separate():
+        est = plan.forward(sdf64, pos, quat, isc, 0.005)
+        _lib.check(L.sdfr_depth_l1_loss(est.data_ptr(), target.data_ptr(), B, 640, 480, 1.0, loss.data_ptr(),
+                                        grad.data_ptr(), ws.data_ptr(), ws.numel(), 0, st), "l1")
+        plan.backward(grad, sdf64, pos, quat, isc)
+
+    def folded():
+        plan.forward_l1(sdf64, pos, quat, isc, 0.005, target)
+        plan.backward_l1(target, sdf64, pos, quat, isc)
+
+    def render_only():
+        plan.forward(sdf64, pos, quat, isc, 0.005)
+        plan.backward(grad, sdf64, pos, quat, isc)
+    t_sep, t_fold, t_r = timeit(separate, 20), timeit(folded, 20), timeit(render_only, 20)
+    out[f"render-and-compare step (depth term), B={B} 640x480"] = {
+        "separate_loss_kernel_us": round(t_sep, 1), "loss_folded_into_renderer_us": round(t_fold, 1),
+        "render_fwd+bwd_only_us": round(t_r, 1), "views_per_s_folded": round(B / t_fold * 1e6, 1),
+        "views_per_s_separate": round(B / t_sep * 1e6, 1)}
     print(json.dumps(out, indent=1))
 
 
