@@ -35,10 +35,6 @@ namespace sdfr {
 namespace {
 
 constexpr int kBlock = 256;
-#ifndef SDFR_GROUP_X   // tiles per workgroup in batch mode (GX x GY tiles of 64 x 8 pixels)
-#define SDFR_GROUP_X 1
-#define SDFR_GROUP_Y 1
-#endif
 
 
 // ---------------------------------------------------------------------------------------------
@@ -271,26 +267,21 @@ __device__ __forceinline__ void forward_tile(
   }
 }
 
-// A workgroup can walk a GX x GY group of tiles.  More than half of the tiles of a batch only
-// store zeros (or, in the backward, do nothing) and an all-culled launch of 153 600 workgroups
-// takes 40 us, so fewer, fatter workgroups looked attractive -- measured, every grouping loses
-// (B=256, forward/backward us: 1x1 257/211, 1x2 264/311, 1x4 270/317, 2x4 295/363; a persistent
-// grid striding over the whole tile list: 377/472): the dispatcher hides the very uneven tile
-// costs only when it has many independent workgroups.  GX = GY = 1 is what ships.
-template <int RT, bool PACKED, int SX, int SY, int GX, int GY, bool LOSS>
+// One workgroup per tile.  (More than half of the tiles of a batch only store zeros -- or, in the
+// backward, do nothing -- and an all-culled launch of 153 600 workgroups takes 40 us, so fewer,
+// fatter workgroups looked attractive.  Measured, B=256, forward/backward us: one tile per
+// workgroup 257/211, 1x2 tiles 264/311, 1x4 270/317, 2x4 295/363; a persistent grid striding over
+// the whole tile list 377/472: the dispatcher hides the very uneven tile costs only when it has
+// many independent workgroups.)
+template <int RT, bool PACKED, int SX, int SY, bool LOSS>
 __global__ __launch_bounds__(kBlock) void render_forward_kernel(
     const float* __restrict__ src, int R, long long src_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, float cx, float cy,
     float rfx, float rfy, float threshold, int vec_ok, float* __restrict__ depth,
     const float* __restrict__ target, float* __restrict__ loss_part) {
-  const int b = blockIdx.z;
-#pragma unroll 1
-  for (int g = 0; g < GX * GY; ++g) {
-    const int tx = blockIdx.x * GX + g % GX, ty = blockIdx.y * GY + g / GX;
-    if (tx < ntx && ty < nty)
-      forward_tile<RT, PACKED, SX, SY, LOSS>(tx, ty, ntx, nty, b, src, R, src_view_stride, setup, W, H, cx,
-                                             cy, rfx, rfy, threshold, vec_ok, depth, target, loss_part);
-  }
+  forward_tile<RT, PACKED, SX, SY, LOSS>(blockIdx.x, blockIdx.y, ntx, nty, blockIdx.z, src, R,
+                                         src_view_stride, setup, W, H, cx, cy, rfx, rfy, threshold,
+                                         vec_ok, depth, target, loss_part);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -303,8 +294,7 @@ struct BackwardLds {
   int tile_max_bits;
 };
 
-// One tile of the backward.  Every return is workgroup-uniform; the caller puts a barrier
-// between tiles (the LDS tables are reused).
+// One tile of the backward.  Every return is workgroup-uniform.
 // LOSS: `grad_depth` is the OBSERVED depth image and the upstream gradient is formed on the fly,
 // go = +-k on the overlap mask (obs > 0) & (est > 0), k = weight * dL/dloss_b / count_b
 // (the gradient of simple_setup.py:129-135's masked mean of |est - obs|; 0 where est == obs).
@@ -477,7 +467,7 @@ __device__ __forceinline__ void backward_tile(
   hash.flush(gvol, Rr * Rr * Rr, from_fixed, tid, kBlock);
 }
 
-template <int RT, int SX, int SY, int GX, int GY, bool LOSS>
+template <int RT, int SX, int SY, bool LOSS>
 __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     const float* __restrict__ grad_depth, const float* __restrict__ depth,
     const float* __restrict__ sdf, int R, long long sdf_view_stride,
@@ -494,16 +484,9 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     const float w = loss_grad ? loss_weight * loss_grad[b] : loss_weight;
     loss_k = cnt > 0.0f ? w / cnt : 0.0f;
   }
-#pragma unroll 1
-  for (int g = 0; g < GX * GY; ++g) {  // a group of tiles per workgroup, as in the forward
-    const int tx = blockIdx.x * GX + g % GX, ty = blockIdx.y * GY + g / GX;
-    if (tx < ntx && ty < nty) {
-      backward_tile<RT, SX, SY, Hash, LOSS>(lds, tx, ty, ntx, nty, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride,
-                                setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride,
-                                partials);
-      __syncthreads();
-    }
-  }
+backward_tile<RT, SX, SY, Hash, LOSS>(lds, blockIdx.x, blockIdx.y, ntx, nty, b, loss_k, grad_depth, depth, sdf,
+                                        R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode,
+                                        g_sdf, g_sdf_view_stride, partials);
 }
 
 // Fixed-order sum of a view's macro-tile partials: one wave per view.
@@ -658,26 +641,21 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
   const bool macro = geom.sx == kMacroTile.sx;
   const int ntx = geom.nx(W), nty = geom.ny(H);
   const dim3 grid_tile((unsigned)ntx, (unsigned)nty, (unsigned)B);
-  const dim3 grid_group((unsigned)((ntx + SDFR_GROUP_X - 1) / SDFR_GROUP_X),
-                        (unsigned)((nty + SDFR_GROUP_Y - 1) / SDFR_GROUP_Y), (unsigned)B);
   const float rfx = (float)(1.0 / (double)fx), rfy = (float)(1.0 / (double)fy);
   const int vec_ok = (W % 4 == 0) && ((uintptr_t)depth % 16 == 0);
-#define SDFR_LAUNCH_FWD_L(RT, PK, SRC, STRIDE, SX, SY, GX, GY, GRID, LOSS)                           \
-  hipLaunchKernelGGL((render_forward_kernel<RT, PK, SX, SY, GX, GY, LOSS>), GRID, dim3(kBlock), 0,  \
-                     st, SRC, R, STRIDE, setup, W, H, ntx, nty, cx, cy, rfx, rfy, threshold, vec_ok,  \
+#define SDFR_LAUNCH_FWD_L(RT, PK, SRC, STRIDE, SX, SY, LOSS)                                          \
+  hipLaunchKernelGGL((render_forward_kernel<RT, PK, SX, SY, LOSS>), grid_tile, dim3(kBlock), 0, st, \
+                     SRC, R, STRIDE, setup, W, H, ntx, nty, cx, cy, rfx, rfy, threshold, vec_ok,      \
                      depth, target, loss_part)
-#define SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, SX, SY, GX, GY, GRID)                                 \
+#define SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, SX, SY)                                               \
   do {                                                                                               \
-    if (with_loss) SDFR_LAUNCH_FWD_L(RT, PK, SRC, STRIDE, SX, SY, GX, GY, GRID, true);               \
-    else SDFR_LAUNCH_FWD_L(RT, PK, SRC, STRIDE, SX, SY, GX, GY, GRID, false);                        \
+    if (with_loss) SDFR_LAUNCH_FWD_L(RT, PK, SRC, STRIDE, SX, SY, true);                             \
+    else SDFR_LAUNCH_FWD_L(RT, PK, SRC, STRIDE, SX, SY, false);                                      \
   } while (0)
 #define SDFR_LAUNCH_FWD(RT, PK, SRC, STRIDE)                                                         \
   do {                                                                                               \
-    if (macro)                                                                                       \
-      SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, SDFR_MACRO_SX, SDFR_MACRO_SY, SDFR_GROUP_X,             \
-                        SDFR_GROUP_Y, grid_group);                                                   \
-    else                                                                                             \
-      SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, 1, 1, 1, 1, grid_tile);                                 \
+    if (macro) SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, SDFR_MACRO_SX, SDFR_MACRO_SY);                 \
+    else SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, 1, 1);                                               \
   } while (0)
   if (packed) {
     if (R == 64) SDFR_LAUNCH_FWD(64, true, cells, 0LL); else SDFR_LAUNCH_FWD(0, true, cells, 0LL);
@@ -768,25 +746,23 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
   const bool macro = geom.sx == kMacroTile.sx;
   const int ntx = geom.nx(W), nty = geom.ny(H);
   const dim3 grid_tile((unsigned)ntx, (unsigned)nty, (unsigned)B);
-  const dim3 grid_group((unsigned)((ntx + SDFR_GROUP_X - 1) / SDFR_GROUP_X),
-                        (unsigned)((nty + SDFR_GROUP_Y - 1) / SDFR_GROUP_Y), (unsigned)B);
   const float rfx = (float)(1.0 / (double)fx), rfy = (float)(1.0 / (double)fy);
-#define SDFR_LAUNCH_BWD_L(RT, SX, SY, GX, GY, GRID, LOSS)                                            \
-  hipLaunchKernelGGL((render_backward_kernel<RT, SX, SY, GX, GY, LOSS>), GRID, dim3(kBlock), 0, st,  \
+#define SDFR_LAUNCH_BWD_L(RT, SX, SY, LOSS)                                                          \
+  hipLaunchKernelGGL((render_backward_kernel<RT, SX, SY, LOSS>), grid_tile, dim3(kBlock), 0, st,     \
                      grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, ntx, nty, cx, cy, rfx, \
                      rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, loss_grad, loss_stats,  \
                      loss_weight)
-#define SDFR_LAUNCH_BWD(RT, SX, SY, GX, GY, GRID)                                                    \
+#define SDFR_LAUNCH_BWD(RT, SX, SY)                                                                  \
   do {                                                                                               \
-    if (with_loss) SDFR_LAUNCH_BWD_L(RT, SX, SY, GX, GY, GRID, true);                                \
-    else SDFR_LAUNCH_BWD_L(RT, SX, SY, GX, GY, GRID, false);                                         \
+    if (with_loss) SDFR_LAUNCH_BWD_L(RT, SX, SY, true);                                              \
+    else SDFR_LAUNCH_BWD_L(RT, SX, SY, false);                                                       \
   } while (0)
   if (R == 64) {
-    if (macro) SDFR_LAUNCH_BWD(64, SDFR_MACRO_SX, SDFR_MACRO_SY, SDFR_GROUP_X, SDFR_GROUP_Y, grid_group);
-    else SDFR_LAUNCH_BWD(64, 1, 1, 1, 1, grid_tile);
+    if (macro) SDFR_LAUNCH_BWD(64, SDFR_MACRO_SX, SDFR_MACRO_SY);
+    else SDFR_LAUNCH_BWD(64, 1, 1);
   } else {
-    if (macro) SDFR_LAUNCH_BWD(0, SDFR_MACRO_SX, SDFR_MACRO_SY, SDFR_GROUP_X, SDFR_GROUP_Y, grid_group);
-    else SDFR_LAUNCH_BWD(0, 1, 1, 1, 1, grid_tile);
+    if (macro) SDFR_LAUNCH_BWD(0, SDFR_MACRO_SX, SDFR_MACRO_SY);
+    else SDFR_LAUNCH_BWD(0, 1, 1);
   }
 #undef SDFR_LAUNCH_BWD
 #undef SDFR_LAUNCH_BWD_L

@@ -1,0 +1,209 @@
+"""Batched synthetic-view generator: the forward-only caller of the renderer.
+
+Mirror of ``SDFVAEViewDataset._generate_sample`` (sdfest/initialization/datasets/
+generated_dataset.py:247-342): sample a latent shape, decode it, draw a random pose inside the
+frustum, render the depth image, optionally smooth it, back-project it to a point set.  The
+reference produces one sample per call (one decode, one render launch, ~20 small torch ops);
+here a whole batch goes through one batched decode and ONE render launch with one SDF per view
+(``sdf_view_stride = R^3``), and the per-sample post-processing runs on the packed batch.
+
+Random numbers: the reference draws from Python's ``random`` and ``torch.randn``; this module
+draws the same distributions from one ``torch.Generator`` (reproducible from a seed).  Every
+sampled quantity can also be passed in, which is how the tests compare with per-sample calls.
+Not covered: ``mask_noise`` (torchvision.RandomAffine) and ``orientation_repr="discretized"``
+(SO3Grid/healpy) -- both raise NotImplementedError.
+"""
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .differentiable_renderer import BatchRenderPlan, Camera
+
+# generated_dataset.py:96-115 (the keys this generator understands)
+DEFAULT_CONFIG = {
+    "width": 640, "height": 480, "fov_deg": 90, "render_threshold": 0.004,
+    "pointcloud": True, "normalize_pose": None, "orientation_repr": "quaternion",
+    "mask_noise": False, "norm_noise": False, "norm_noise_min": -0.2, "norm_noise_max": 0.2,
+    "scale_to_unit_ball": False, "gaussian_noise_probability": 0.0,
+    "gaussian_noise_kernel_size": 5, "gaussian_noise_kernel_std": 1,
+}
+
+
+def sample_uniform_quaternions(n: int, gen: Optional[torch.Generator] = None) -> torch.Tensor:
+    """(n,4) uniformly distributed unit quaternions, Shoemake 1992 (generated_dataset.py:187-207)."""
+    u = torch.rand((n, 3), generator=gen, dtype=torch.float64)
+    a, b = torch.sqrt(1 - u[:, 0]), torch.sqrt(u[:, 0])
+    t2, t3 = 2 * math.pi * u[:, 1], 2 * math.pi * u[:, 2]
+    return torch.stack((a * torch.sin(t2), a * torch.cos(t2), b * torch.sin(t3), b * torch.cos(t3)), 1).float()
+
+
+def sample_poses(n: int, camera: Camera, z_min: float, z_max: float, extent_mean: float,
+                 extent_std: float, gen: Optional[torch.Generator] = None):
+    """Positions with the centre inside the frustum, uniform orientations, Gaussian half-extents
+    (generated_dataset.py:262-271).  Returns (position (n,3), quaternion (n,4), scale (n,)) on CPU.
+
+    Note the reference's own bounds: x_pix ~ U(-width/2, height/2) (sic), y_pix ~ U(-height/2,
+    height/2); kept as they are."""
+    u = torch.rand((n, 3), generator=gen, dtype=torch.float64)
+    z = z_min + (z_max - z_min) * u[:, 0]
+    x_pix = -camera.width / 2 + (camera.height / 2 + camera.width / 2) * u[:, 1]
+    y_pix = -camera.height / 2 + camera.height * u[:, 2]
+    position = torch.stack((x_pix / camera.fx * z, y_pix / camera.fy * z, -z), 1).float()
+    scale = (extent_mean + extent_std * torch.randn(n, generator=gen, dtype=torch.float64)) / 2.0
+    return position, sample_uniform_quaternions(n, gen), scale.float()
+
+
+def gaussian_kernel(std: float, kernel_size: int) -> torch.Tensor:
+    """The smoothing kernel of generated_dataset.py:366-373: scipy's gaussian_filter applied to a
+    unit impulse."""
+    from scipy.ndimage import gaussian_filter
+    if kernel_size % 2 != 1:
+        raise ValueError("Kernel size should be odd.")
+    impulse = np.zeros((kernel_size, kernel_size))
+    impulse[kernel_size // 2, kernel_size // 2] = 1
+    return torch.tensor(gaussian_filter(impulse, std)[None, None], dtype=torch.float32)
+
+
+def smooth_depth(depth: torch.Tensor, kernel: torch.Tensor, apply: torch.Tensor) -> torch.Tensor:
+    """generated_dataset.py:296-308 on a batch: where a pixel's whole kernel window is valid the
+    depth becomes the filtered value, every other pixel keeps its value (invalid stays 0).
+    ``apply`` (B,) bool selects the samples that are filtered at all.  In place; returns depth."""
+    # The reference marks invalid pixels NaN and lets conv2d spread them; which outputs a NaN
+    # reaches depends on the convolution algorithm (a transform-based one contaminates more than
+    # the window).  Same result without NaNs: a window is usable iff it holds no invalid pixel.
+    k = kernel.to(depth)[0, 0]
+    kh, kw = k.shape
+    H, W = depth.shape[-2:]
+    pad = torch.nn.functional.pad
+    dp = pad(depth, (kw // 2, kw // 2, kh // 2, kh // 2))                       # zero padding = "same"
+    ip = pad((depth == 0).to(depth.dtype), (kw // 2, kw // 2, kh // 2, kh // 2))
+    filtered = torch.zeros_like(depth)
+    window_invalid = torch.zeros_like(depth)
+    for i in range(kh):      # direct correlation, tap by tap (no convolution library: 25 fused ops)
+        for j in range(kw):
+            filtered += k[i, j] * dp[:, i:i + H, j:j + W]
+            window_invalid += ip[:, i:i + H, j:j + W]
+    ok = (window_invalid == 0) & apply.to(depth.device)[:, None, None]
+    depth[ok] = filtered[ok]
+    return depth
+
+
+def depth_to_pointsets(depth: torch.Tensor, camera: Camera):
+    """Back-projection of every non-zero pixel of a (B,H,W) batch (pointset_utils.py:57-77,
+    convention "opengl", pixel-centre-0 intrinsics): packed points (N,3) in view-major, row-major
+    order and the per-view counts."""
+    fx, fy, cx, cy, _ = camera.get_pinhole_camera_parameters(0.0)
+    b, rows, cols = torch.nonzero(depth, as_tuple=True)
+    z = depth[b, rows, cols]
+    pts = torch.stack(((cols.float() - cx) * z / fx, -(rows.float() - cy) * z / fy, -z), dim=1)
+    return pts, torch.bincount(b, minlength=depth.shape[0])
+
+
+class SDFVAEViewGenerator:
+    """Batched ``SDFVAEViewDataset`` (generated_dataset.py:26-342).
+
+    ``decoder`` is a :class:`sdfest_amd.SDFDecoder`; ``config`` uses the reference's keys (see
+    DEFAULT_CONFIG; ``z_min``, ``z_max``, ``extent_mean``, ``extent_std`` are required)."""
+
+    def __init__(self, config: Dict, decoder, batch_size: int = 64, device="cuda", seed: Optional[int] = None):
+        cfg = dict(DEFAULT_CONFIG)
+        cfg.update(config)
+        for k in ("z_min", "z_max", "extent_mean", "extent_std"):
+            if k not in cfg:
+                raise KeyError(f"config key {k!r} is required")
+        if cfg["mask_noise"]:
+            raise NotImplementedError("mask_noise (torchvision RandomAffine) is not covered")
+        if cfg["orientation_repr"] != "quaternion":
+            raise NotImplementedError(f"Orientation representation {cfg['orientation_repr']} is not supported.")
+        self.cfg = cfg
+        self.decoder = decoder
+        self.B = int(batch_size)
+        self.device = torch.device(device)
+        f = cfg["width"] / math.tan(cfg["fov_deg"] * math.pi / 180.0 / 2.0) / 2      # :123-132
+        self.camera = Camera(cfg["width"], cfg["height"], f, f, cfg["width"] / 2, cfg["height"] / 2,
+                             pixel_center=0.5)
+        self.gen = torch.Generator()
+        if seed is not None:
+            self.gen.manual_seed(seed)
+        self.kernel = gaussian_kernel(cfg["gaussian_noise_kernel_std"], cfg["gaussian_noise_kernel_size"])
+        self.plan = BatchRenderPlan(decoder._volume_size, self.B, self.camera, device=self.device,
+                                    per_view_sdf=True)
+
+    # -- the GPU part: decode -> render (one launch each for the whole batch) ------------------
+    def render(self, latent: torch.Tensor, position: torch.Tensor, quaternion: torch.Tensor,
+               scale: torch.Tensor) -> torch.Tensor:
+        """(B,H,W) depth images of decode(latent[b]) at pose b (generated_dataset.py:258-280).
+        The returned tensor is the plan's buffer (overwritten by the next call)."""
+        with torch.no_grad():
+            sdf = self.decoder.decode(latent.to(self.device))[:, 0].contiguous()
+            return self.plan.forward(sdf, position.to(self.device).contiguous(),
+                                     quaternion.to(self.device).contiguous(),
+                                     (1.0 / scale.to(self.device)).contiguous(),
+                                     self.cfg["render_threshold"])
+
+    def generate(self, latent=None, position=None, quaternion=None, scale=None, smooth=None) -> Dict:
+        """One batch of samples; any of the sampled quantities may be given instead of drawn.
+
+        Returns a dict of batched tensors with the reference's keys: "depth" (B,H,W),
+        "latent_shape" (B,L), "position" (B,3), "orientation" = "quaternion" (B,4), "scale" (B,),
+        and with ``pointcloud``: "pointset" (list of (N_b,3) views of the packed "points") and
+        "valid" (B,) = the reference's _is_valid (at least one depth pixel)."""
+        cfg, B, dev = self.cfg, self.B, self.device
+        if latent is None:
+            latent = torch.randn((B, self.decoder.latent_size), generator=self.gen)     # SDFVAE.sample
+        p, q, s = sample_poses(B, self.camera, cfg["z_min"], cfg["z_max"], cfg["extent_mean"],
+                               cfg["extent_std"], self.gen)
+        position = (p if position is None else position).to(dev).clone()
+        quaternion = (q if quaternion is None else quaternion).to(dev)
+        scale = (s if scale is None else scale).to(dev).clone()
+        depth = self.render(latent, position, quaternion, scale).clone()
+        if cfg["gaussian_noise_probability"] > 0.0:                                    # :296-308
+            if smooth is None:
+                smooth = torch.rand(B, generator=self.gen) < cfg["gaussian_noise_probability"]
+            smooth_depth(depth, self.kernel, smooth)
+        out = {"depth": depth, "latent_shape": latent.to(dev), "valid": depth.amax(dim=(1, 2)) != 0}
+        if cfg["pointcloud"]:                                                          # :312-334
+            pts, counts = depth_to_pointsets(depth, self.camera)
+            owner = torch.repeat_interleave(torch.arange(B, device=dev), counts)
+            if cfg["normalize_pose"]:
+                centroid = torch.zeros((B, 3), device=dev).index_add_(0, owner, pts)
+                centroid = centroid / counts.clamp(min=1)[:, None]
+                pts = pts - centroid[owner]
+                position -= centroid
+                if cfg["norm_noise"]:
+                    lo, hi = cfg["norm_noise_min"], cfg["norm_noise_max"]
+                    noise = (lo + (hi - lo) * torch.rand((B, 3), generator=self.gen)).to(dev)
+                    position += noise
+                    pts = pts + noise[owner]
+                if cfg["scale_to_unit_ball"]:
+                    # the reference divides by torch.max(torch.linalg.norm(pointset)): the norm of
+                    # the whole (N,3) matrix, one number per sample (:330-332)
+                    fro = torch.sqrt(torch.zeros(B, device=dev).index_add_(0, owner, (pts * pts).sum(1)))
+                    fro = torch.where(counts > 0, fro, torch.ones_like(fro))
+                    pts = pts / fro[owner][:, None]
+                    scale /= fro
+            out["points"], out["counts"] = pts, counts
+            out["pointset"] = list(torch.split(pts, counts.tolist()))
+        out["position"], out["scale"] = position, scale
+        out["quaternion"] = out["orientation"] = quaternion
+        return out
+
+    def samples(self, out: Dict) -> List[Dict]:
+        """Split a batch into the reference's per-sample dictionaries (valid samples only)."""
+        keys = ("depth", "latent_shape", "position", "orientation", "quaternion", "scale")
+        res = []
+        for b in range(self.B):
+            if not bool(out["valid"][b]):
+                continue  # the reference redraws an empty sample (generated_dataset.py:222-235)
+            d = {k: out[k][b] for k in keys}
+            if "pointset" in out:
+                d["pointset"] = out["pointset"][b]
+            res.append(d)
+        return res
+
+    def __iter__(self):
+        while True:
+            for s in self.samples(self.generate()):
+                yield s

@@ -1,0 +1,111 @@
+"""GPU: the batched view generator against per-sample calls of the single-view API,
+i.e. against what SDFVAEViewDataset._generate_sample (generated_dataset.py:247-342) does per sample."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+CFG = {"width": 320, "height": 240, "fov_deg": 90, "z_min": 0.3, "z_max": 0.7, "extent_mean": 0.15,
+       "extent_std": 0.02, "render_threshold": 0.004, "pointcloud": True}
+
+
+@pytest.fixture(scope="module")
+def mug_decoder():
+    from sdfest_amd import SDFDecoder
+    from test_decoder_gpu import mug_config
+    d = np.load(os.path.join(GOLDEN, "decoder_mug.npz"))
+    w = np.load(os.path.join(GOLDEN, "mug_decoder_weights.npz"))
+    return SDFDecoder.from_config(mug_config(d), {k: w[k] for k in w.files}), d
+
+
+def test_batch_equals_per_sample_pipeline(mug_decoder):
+    from sdfest_amd import render_depth_gpu
+    from sdfest_amd.generated_views import SDFVAEViewGenerator
+    from sdfest_amd.pipeline import depth_to_pointcloud
+    dec, d = mug_decoder
+    B = 6
+    gen = SDFVAEViewGenerator(CFG, dec, batch_size=B, seed=3)
+    out = gen.generate()
+    assert out["depth"].shape == (B, 240, 320) and out["latent_shape"].shape == (B, 8)
+    assert int(out["valid"].sum()) >= B - 1
+    for b in range(B):   # generated_dataset.py:258-280, :312-315 one sample at a time
+        with torch.no_grad():
+            sdf = dec.decode(out["latent_shape"][b:b + 1])[0, 0]
+            depth = render_depth_gpu(sdf, out["position"][b], out["quaternion"][b], 1.0 / out["scale"][b],
+                                     threshold=CFG["render_threshold"], camera=gen.camera)
+        assert torch.equal(depth, out["depth"][b])
+        assert torch.equal(depth_to_pointcloud(depth, gen.camera), out["pointset"][b])
+    # the first view also against the CPU oracle (fp32 march on the decoded grid)
+    with torch.no_grad():
+        sdf0 = dec.decode(out["latent_shape"][0:1])[0, 0].cpu().numpy()
+    cam = gen.camera
+    fx, fy, cx, cy, _ = cam.get_pinhole_camera_parameters(0.5)
+    d_or = oracle.render_forward(sdf0, out["position"][0:1].cpu().numpy(), out["quaternion"][0:1].cpu().numpy(),
+                                 (1.0 / out["scale"][0:1]).cpu().numpy(), 320, 240, cx, cy, fx, fy,
+                                 CFG["render_threshold"], dtype=np.float32)[0]
+    d_h = out["depth"][0].cpu().numpy()
+    both = (d_or > 0) & (d_h > 0)
+    assert ((d_or > 0) != (d_h > 0)).sum() <= max(2, 1e-3 * both.sum())
+    assert both.sum() > 200 and np.max(np.abs(d_h[both] / d_or[both] - 1)) < 1e-4
+    samples = gen.samples(out)
+    assert len(samples) == int(out["valid"].sum()) and set(samples[0]) == {
+        "depth", "pointset", "latent_shape", "position", "orientation", "quaternion", "scale"}
+
+
+def test_normalisation_noise_and_smoothing_options(mug_decoder):
+    from sdfest_amd.generated_views import SDFVAEViewGenerator, gaussian_kernel
+    from sdfest_amd.pipeline import depth_to_pointcloud
+    dec, d = mug_decoder
+    B = 4
+    plain = SDFVAEViewGenerator(CFG, dec, batch_size=B, seed=5).generate()
+    cfg = {**CFG, "normalize_pose": True, "scale_to_unit_ball": True, "gaussian_noise_probability": 1.0}
+    gen = SDFVAEViewGenerator(cfg, dec, batch_size=B, seed=99)
+    out = gen.generate(latent=plain["latent_shape"].cpu(), position=plain["position"].cpu(),
+                       quaternion=plain["quaternion"].cpu(), scale=plain["scale"].cpu())
+    k = gaussian_kernel(1, 5)
+    for b in range(B):   # generated_dataset.py:296-334 one sample at a time (NaN trick: CPU conv)
+        depth = plain["depth"][b].cpu().clone()
+        depth[depth == 0] = torch.nan
+        f = torch.nn.functional.conv2d(depth[None, None], k, padding="same")[0, 0]
+        m = torch.logical_or(f.isnan(), f.isinf())
+        depth[~m] = f[~m]
+        depth[depth.isnan()] = 0.0
+        depth = depth.cuda()
+        assert torch.equal(out["depth"][b] == 0, depth == 0)
+        assert torch.allclose(out["depth"][b], depth, rtol=0, atol=2e-6)   # GPU vs CPU conv2d
+        pts = depth_to_pointcloud(out["depth"][b], gen.camera)
+        centroid = pts.mean(0)
+        pts = pts - centroid
+        pos = plain["position"][b] - centroid
+        md = torch.max(torch.linalg.norm(pts))
+        assert torch.allclose(out["pointset"][b], pts / md, rtol=1e-5, atol=1e-7)
+        assert torch.allclose(out["position"][b], pos, rtol=1e-5, atol=1e-7)
+        assert torch.allclose(out["scale"][b], plain["scale"][b] / md, rtol=1e-5)
+        assert abs(torch.linalg.norm(out["pointset"][b]).item() - 1.0) < 1e-4
+    noisy = SDFVAEViewGenerator({**CFG, "normalize_pose": True, "norm_noise": True}, dec, batch_size=B, seed=1)
+    o2 = noisy.generate(latent=plain["latent_shape"].cpu(), position=plain["position"].cpu(),
+                        quaternion=plain["quaternion"].cpu(), scale=plain["scale"].cpu())
+    for b in range(B):
+        c = o2["pointset"][b].mean(0)                    # = the noise that was added to both
+        assert c.abs().max() <= 0.2 + 1e-5 and c.abs().max() > 0
+        ref_c = depth_to_pointcloud(plain["depth"][b], gen.camera).mean(0)
+        assert torch.allclose(o2["position"][b], plain["position"][b] - ref_c + c, atol=1e-5)
+
+
+def test_empty_views_are_flagged_not_returned(mug_decoder):
+    from sdfest_amd.generated_views import SDFVAEViewGenerator
+    dec, _ = mug_decoder
+    gen = SDFVAEViewGenerator({**CFG, "normalize_pose": True, "scale_to_unit_ball": True}, dec, batch_size=3, seed=0)
+    pos = torch.tensor([[0.0, 0.0, -0.5], [0.0, 0.0, 3.0], [0.0, 0.0, -0.5]])   # view 1: behind the camera
+    out = gen.generate(position=pos)
+    assert out["valid"].tolist() == [True, False, True] and out["counts"][1] == 0
+    assert len(gen.samples(out)) == 2 and torch.isfinite(out["scale"]).all()
+    it = iter(gen)
+    s = next(it)
+    assert s["depth"].max() > 0

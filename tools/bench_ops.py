@@ -78,6 +78,22 @@ def main():
     t = timeit(lambda: plan.forward(sdfs, pos, quat, isc, 0.005), 20)
     out[f"render forward, one SDF per view, B={B}"] = {"us": round(t, 1), "views_per_s": round(B / t * 1e6, 1),
                                                          "hit_pixels": int((plan.depth > 0).sum())}
+    # the whole synthetic-view generator (decode -> render -> back-projection), SURVEY 8f-3
+    from sdfest_amd.generated_views import SDFVAEViewGenerator
+    gcfg = {"width": 640, "height": 480, "fov_deg": 90, "z_min": 0.3, "z_max": 0.7, "extent_mean": 0.15,
+            "extent_std": 0.02, "render_threshold": 0.004, "pointcloud": True, "normalize_pose": True}
+    for gb in (64, 256):
+        gen = SDFVAEViewGenerator(gcfg, dec, batch_size=gb, device=dev, seed=0)
+        zl = torch.randn(gb, 8)
+        gp, gq, gs = (t.to(dev) for t in __import__("sdfest_amd.generated_views", fromlist=["x"]).sample_poses(
+            gb, gen.camera, 0.3, 0.7, 0.15, 0.02, gen.gen))
+        zl = zl.to(dev)
+        t_r = timeit(lambda: gen.render(zl, gp, gq, gs), 10)
+        t_g = timeit(lambda: gen.generate(), 5)
+        out[f"view generator B={gb} 640x480"] = {"decode+render_us": round(t_r, 1),
+                                                 "decode+render_views_per_s": round(gb / t_r * 1e6, 1),
+                                                 "full_sample_us": round(t_g, 1),
+                                                 "samples_per_s": round(gb / t_g * 1e6, 1)}
     # batched render-and-compare step on the depth term (C3 poses): forward -> masked L1 -> backward,
     # with the loss as its own kernel vs folded into the render kernels
     from sdfest_amd import _lib
