@@ -138,6 +138,103 @@ __global__ __launch_bounds__(256) void resize3_kernel(const float* __restrict__ 
   out[((size_t)n * C + c) * vo + r] = v;
 }
 
+// The same resize for up-sampling (ratio <= 1), tiled through LDS.  resize3_kernel issues 8 gathers
+// per output and is bound by the per-CU gather rate (0.8 TB/s of stores at 30^3 -> 64^3); here a
+// workgroup owns an 8 x 8 (x, y) patch of output columns, loads the few input columns under it
+// once (coalesced z-rows), interpolates them along z into a second LDS array and blends four of
+// those per output -- the same expression tree, z innermost, as resize3_kernel.  Stores are
+// whole z-rows.   grid: (tiles_x * tiles_y, C, N);  LDS: cols * (n_in + n_out) floats,
+// cols = max_rx * max_ry input columns under a tile (computed by the host with the same arithmetic).
+constexpr int kResizeTile = 8;
+template <int LOG_NO>  // n_out = 1 << LOG_NO (16 .. 128): index splits are shifts, z is fixed per thread
+__global__ __launch_bounds__(256) void resize3_tiled_kernel(const float* __restrict__ in, int C, int n_in,
+                                                            int relu, float clamp, int max_cols,
+                                                            float* __restrict__ out) {
+  constexpr int n_out = 1 << LOG_NO, zmask = n_out - 1;
+  extern __shared__ float lds[];
+  // per-axis interpolation tables of this tile: entries 0..7 x, 8..15 y (indices relative to a0 / b0)
+  __shared__ int t_i0[16], t_i1[16], z_i0[n_out], z_i1[n_out];
+  __shared__ float t_l[16], z_l[n_out];
+  const int tid = threadIdx.x;
+  constexpr int tiles = (n_out + kResizeTile - 1) / kResizeTile;
+  const int tx0 = (blockIdx.x / tiles) * kResizeTile, ty0 = (blockIdx.x % tiles) * kResizeTile;
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float ratio = (float)n_in / (float)n_out;
+  int a0, a1, b0, b1, t0, t1;
+  float fl;
+  resize_axis(tx0, ratio, n_in, a0, t1, fl);
+  resize_axis(min(tx0 + kResizeTile, n_out) - 1, ratio, n_in, t0, a1, fl);
+  resize_axis(ty0, ratio, n_in, b0, t1, fl);
+  resize_axis(min(ty0 + kResizeTile, n_out) - 1, ratio, n_in, t0, b1, fl);
+  const int rx = a1 - a0 + 1, ry = b1 - b0 + 1, cols = rx * ry;  // input columns x in [a0,a1], y in [b0,b1]
+  if (tid < n_out) {
+    resize_axis(tid, ratio, n_in, t0, t1, fl);
+    z_i0[tid] = t0; z_i1[tid] = t1; z_l[tid] = fl;
+  }
+  if (tid >= 128 && tid < 144) {
+    const int j = tid - 128, dd = min(((j < 8) ? tx0 : ty0) + (j & 7), n_out - 1);
+    resize_axis(dd, ratio, n_in, t0, t1, fl);
+    t_i0[j] = t0 - ((j < 8) ? a0 : b0); t_i1[j] = t1 - ((j < 8) ? a0 : b0); t_l[j] = fl;
+  }
+  float* col_in = lds;                            // [cols][n_in]
+  float* col_z = lds + (size_t)max_cols * n_in;   // [cols][n_out], interpolated along z
+  const float* src = in + ((size_t)n * C + c) * n_in * n_in * n_in;
+  for (int i = tid; i < cols * n_in; i += 256) {
+    const int col = i / n_in, z = i - col * n_in;
+    col_in[i] = src[((size_t)(a0 + col / ry) * n_in + (b0 + col % ry)) * n_in + z];
+  }
+  __syncthreads();
+  const int z = tid & zmask;
+  {
+    const int z0 = z_i0[z], z1 = z_i1[z];
+    const float lz = z_l[z], wz0 = 1.0f - lz;
+    for (int col = tid >> LOG_NO; col < cols; col += 256 >> LOG_NO)
+      col_z[(col << LOG_NO) + z] = wz0 * col_in[col * n_in + z0] + lz * col_in[col * n_in + z1];
+  }
+  __syncthreads();
+  float* dst = out + ((size_t)n * C + c) * n_out * n_out * n_out;
+  for (int xy = tid >> LOG_NO; xy < kResizeTile * kResizeTile; xy += 256 >> LOG_NO) {
+    const int jx = xy >> 3, jy = xy & 7;
+    const int x = tx0 + jx, y = ty0 + jy;
+    if (x >= n_out || y >= n_out) continue;
+    const float lx = t_l[jx], ly = t_l[8 + jy], wx0 = 1.0f - lx, wy0 = 1.0f - ly;
+    const int r0 = t_i0[jx] * ry, r1 = t_i1[jx] * ry, c0 = t_i0[8 + jy], c1 = t_i1[8 + jy];
+#define COLZ(r, cc) col_z[(((r) + (cc)) << LOG_NO) + z]
+    float v = wx0 * (wy0 * COLZ(r0, c0) + ly * COLZ(r0, c1)) + lx * (wy0 * COLZ(r1, c0) + ly * COLZ(r1, c1));
+#undef COLZ
+    if (relu) v = fmaxf(v, 0.0f);
+    if (clamp > 0.0f) v = fminf(fmaxf(v, -clamp), clamp);
+    dst[(((((size_t)x) << LOG_NO) + y) << LOG_NO) + z] = v;
+  }
+}
+
+// 1x1x1 convolution with few output channels, element-wise: one thread per voxel, the input read
+// once (coalesced per channel), the same fmaf chain over ci and "+ bias" last as the MFMA path.
+// wmat: the layer's [Kpad][16] matrix (co_tile 0).   grid: (ceil(vox / 256), N)
+template <int COUT>
+__global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ in,
+                                                      const float* __restrict__ wmat,
+                                                      const float* __restrict__ bias, int Cin, int vox,
+                                                      int relu, float* __restrict__ out) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= vox) return;
+  const float* src = in + (size_t)blockIdx.y * Cin * vox + v;
+  float acc[COUT];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) acc[co] = 0.0f;
+  for (int ci = 0; ci < Cin; ++ci) {
+    const float a = src[(size_t)ci * vox];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = fmaf(a, wmat[ci * 16 + co], acc[co]);
+  }
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) {
+    float r = acc[co] + bias[co];
+    if (relu) r = fmaxf(r, 0.0f);
+    out[((size_t)blockIdx.y * COUT + co) * vox + v] = r;
+  }
+}
+
 // grid: ceil(count / 256);  clamp a tensor in place (only when the last layer already has the
 // volume size and enforce_tsdf is set)
 __global__ void clamp_kernel(float* __restrict__ x, size_t count, float clamp) {
@@ -601,6 +698,32 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
   int c = d->conv_cin[0], n = d->conv_in_size[0];
   const size_t vox = (size_t)d->volume * d->volume * d->volume;
   auto resize = [&](const float* src, int C, int ni, int no, int relu, float clamp, float* dst) {
+    // input columns under an 8 x 8 output patch, worst tile (same float arithmetic as the kernel)
+    int max_r = 0;
+    const float ratio = (float)ni / (float)no;
+    auto first_last = [&](int dd, int& i0, int& i1) {
+      float sp = fmaf(ratio, (float)dd + 0.5f, -0.5f);
+      sp = sp < 0.0f ? 0.0f : sp;
+      i0 = std::min((int)sp, ni - 1);
+      i1 = i0 + (i0 < ni - 1 ? 1 : 0);
+    };
+    for (int t0 = 0; t0 < no; t0 += kResizeTile) {
+      int lo, hi, tmp;
+      first_last(t0, lo, tmp);
+      first_last(std::min(t0 + kResizeTile, no) - 1, tmp, hi);
+      max_r = std::max(max_r, hi - lo + 1);
+    }
+    const size_t lds = (size_t)max_r * max_r * (ni + no) * sizeof(float);
+    const int tiles = (no + kResizeTile - 1) / kResizeTile;
+    const bool pow2 = no >= 16 && no <= 128 && (no & (no - 1)) == 0;
+    // (a single decode has too few tiles to fill the chip: the gather kernel is faster there)
+    if (pow2 && ni <= no && lds <= 48 * 1024 && C <= 65535 && (long long)tiles * tiles * C * N >= 2048) {
+      const dim3 grid(tiles * tiles, C, N);
+#define SDFR_RESIZE_T(LOG) hipLaunchKernelGGL((resize3_tiled_kernel<LOG>), grid, dim3(256), lds, st, src, C, ni, relu, clamp, max_r * max_r, dst)
+      if (no == 16) SDFR_RESIZE_T(4); else if (no == 32) SDFR_RESIZE_T(5); else if (no == 64) SDFR_RESIZE_T(6); else SDFR_RESIZE_T(7);
+#undef SDFR_RESIZE_T
+      return;
+    }
     const size_t cnt = (size_t)C * no * no * no;
     hipLaunchKernelGGL(resize3_kernel, dim3((unsigned)((cnt + 255) / 256), N), dim3(256), 0, st, src, C,
                        ni, no, relu, clamp, dst);
@@ -624,11 +747,20 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
     const bool to_out = is_last && m_out == d->volume && (swap || clampv == 0.0f);
     float* layer_dst = to_out ? out : (tape ? tape + (size_t)N * d->tape_conv_off[l] : nullptr);
     float* conv_dst = (!swap && layer_dst) ? layer_dst : buf[cur ^ 1];
-    hipLaunchKernelGGL(conv3d_mfma_kernel, dim3(blocks, (co_n + 15) / 16, N), dim3(256), lds, st,
-                       act_in, d->d_params + d->conv_w_off[l],
-                       reinterpret_cast<const int*>(d->d_params + d->conv_tab_off[l]),
-                       d->d_params + d->conv_b_off[l], conv_dst, c, co_n, n, m, kpad,
-                       swap ? 0 : d->conv_relu[l], tpw);
+    const int conv_relu = swap ? 0 : d->conv_relu[l];
+    const float* wm = d->d_params + d->conv_w_off[l];
+    const float* bs = d->d_params + d->conv_b_off[l];
+    if (k == 1 && co_n <= 4) {
+      const int voxn = n * n * n;
+      const dim3 g1((voxn + 255) / 256, N);
+#define SDFR_CONV1(CO) hipLaunchKernelGGL((conv1x1_kernel<CO>), g1, dim3(256), 0, st, act_in, wm, bs, c, voxn, conv_relu, conv_dst)
+      if (co_n == 1) SDFR_CONV1(1); else if (co_n == 2) SDFR_CONV1(2); else if (co_n == 3) SDFR_CONV1(3); else SDFR_CONV1(4);
+#undef SDFR_CONV1
+    } else {
+      hipLaunchKernelGGL(conv3d_mfma_kernel, dim3(blocks, (co_n + 15) / 16, N), dim3(256), lds, st, act_in,
+                         wm, reinterpret_cast<const int*>(d->d_params + d->conv_tab_off[l]), bs, conv_dst, c,
+                         co_n, n, m, kpad, conv_relu, tpw);
+    }
     if (conv_dst == buf[cur ^ 1]) cur ^= 1;
     act_in = conv_dst;
     c = co_n;
