@@ -45,6 +45,13 @@ struct sdfr_decoder {
   std::vector<size_t> bwd_w_off, bwd_tab_off;
   std::vector<int> bwd_kpad;
   size_t zero_bias_off = 0;
+  // LDS-tiled convolution (conv3d_lds_kernel): per layer, forward and data-gradient
+  struct TilePlan {
+    bool ok = false;
+    int zg = 1, T = 4, I = 6, kpad = 0;   // z-group, output patch T x T columns, input patch I x I
+    size_t w_off = 0, tab_off = 0, lds_bytes = 0;
+  };
+  std::vector<TilePlan> fwd_tile, bwd_tile;
   size_t max_bwd = 0;                      // floats of the largest gradient tensor (incl. padding)
   // tape: post-ReLU outputs kept by a forward that will be differentiated
   size_t tape_fc_off = 0;                  // per-sample float offsets
@@ -244,6 +251,25 @@ __global__ void clamp_kernel(float* __restrict__ x, size_t count, float clamp) {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Copy n floats (n % 4 == 0, both 16-byte aligned) global -> LDS with a whole workgroup: 16-byte
+// pieces, four loads in flight per thread before the first LDS store (a plain `lds[i] = g[i]`
+// loop waits for every load before it issues the next).
+__device__ __forceinline__ void stage_to_lds(float* __restrict__ dst, const float* __restrict__ src, int n,
+                                             int tid) {
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+  f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+  const int n4 = n >> 2;
+  for (int i = tid; i < n4; i += 4 * 256) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = s4[min(i + u * 256, n4 - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i + u * 256 < n4) d4[i + u * 256] = v[u];
+  }
+}
+
+
 // Valid 3-D convolution as an im2col contraction on v_mfma_f32_16x16x4_f32.
 //   wmat  [Kpad][16]  weight matrix, wmat[kk][co] = W[co][ci][a][b][c], kk = ci*k^3 + (a*k+b)*k+c,
 //                     zero for kk >= K or co >= Cout_tile
@@ -261,8 +287,8 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int co_tile = blockIdx.y, nb = blockIdx.z;
   const float* wsrc = wmat + (size_t)co_tile * kpad * 16;
-  for (int i = tid; i < kpad * 16; i += 256) w_l[i] = wsrc[i];
-  for (int i = tid; i < kpad; i += 256) tap_l[i] = taps[i];
+  stage_to_lds(w_l, wsrc, kpad * 16, tid);
+  stage_to_lds(reinterpret_cast<float*>(tap_l), reinterpret_cast<const float*>(taps), kpad, tid);
   __syncthreads();
 
   const int mv = m * m * m;
@@ -309,6 +335,118 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
   }
 }
 
+
+// The same contraction with the input staged in LDS.  conv3d_mfma_kernel gathers every A operand
+// from global memory -- each input value 27 times -- and is bound by the gather rate, not by the
+// matrix cores (860 us for the 8 -> 4 channel layer at 30^3 x 256 samples, MFMA time ~300 us).
+// Here a workgroup owns T x T output columns (all of z): it loads the (T+k-1)^2 input columns of
+// every channel once (coalesced runs), and the im2col operands are LDS reads.
+// Few output channels would waste most of the 16 MFMA columns, so ZG consecutive z outputs share a
+// row: row = (x, y, z-group), column = (dz, co), K' = Cin*k*k*(k+ZG-1) with the weight matrix
+//   wz[(ci,a,b,c')][(dz,co)] = W[co][ci][a][b][c'-dz]   (0 outside 0 <= c'-dz < k)
+// -- 12 of 16 columns used and half the MFMAs for the 8 -> 4 layer (ZG = 3).
+//   taps[kk] = LDS offset of tap kk: ((ci*I + a)*I + b)*n + c'
+// The weight matrix is NOT staged: every workgroup reads the same 23 KB, 256 contiguous bytes per
+// wave and K-step, straight from L1/L2 -- staging it cost as much as the input patch and its LDS
+// halved the occupancy.  Each wave keeps up to RT row-tiles of accumulators so that one
+// (tap, weight) read feeds RT MFMAs.
+// grid: (ceil(m/T)^2, co_tiles, N);  LDS: taps [kpad] | tile [Cin][I][I][n]
+template <int RT>
+__global__ __launch_bounds__(256) void conv3d_lds_kernel(
+    const float* __restrict__ in, const float* __restrict__ wz, const int* __restrict__ taps,
+    const float* __restrict__ bias, float* __restrict__ out, int Cin, int Cout, int n, int m, int kpad,
+    int relu, int zg, int T, int I) {
+  extern __shared__ float lds[];
+  int* tap_l = reinterpret_cast<int*>(lds);
+  float* tile = lds + kpad;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int txy = (m + T - 1) / T;
+  const int tx0 = (blockIdx.x / txy) * T, ty0 = (blockIdx.x % txy) * T;
+  const int co_tile = blockIdx.y, nb = blockIdx.z;
+  const float* wsrc = wz + (size_t)co_tile * kpad * 16;
+  stage_to_lds(reinterpret_cast<float*>(tap_l), reinterpret_cast<const float*>(taps), kpad, tid);
+  const size_t nv = (size_t)n * n * n;
+  const float* src = in + (size_t)nb * Cin * nv;
+  // the input patch: for each (channel, x) the I columns y0 .. y0+I-1 are one contiguous run of
+  // I*n floats.  Each thread owns one offset of the run and walks the runs eight at a time: eight
+  // loads in flight, then eight LDS stores; the run index arithmetic is wave-uniform.
+  {
+    const int run = I * n, y_valid = (n - ty0) * n, n_slab = Cin * I;
+    for (int off = tid; off < run; off += 256) {
+      for (int s0 = 0; s0 < n_slab; s0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int slab = min(s0 + u, n_slab - 1), ci = slab / I, x = tx0 + slab - ci * I;
+          const float* row = src + (size_t)ci * nv + ((size_t)min(x, n - 1) * n + ty0) * n;
+          v[u] = (x < n && off < y_valid) ? row[off] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (s0 + u < n_slab) tile[(s0 + u) * run + off] = v[u];
+      }
+    }
+  }
+  __syncthreads();
+
+  const int zgn = m / zg, n_rows = T * T * zgn, n_rt = (n_rows + 15) / 16;
+  const int rl = lane & 15, kq = lane >> 4;
+  const int cout_t = zg > 1 ? Cout : min(16, Cout - co_tile * 16);  // channels in this column tile
+  const int dz = zg > 1 ? rl / Cout : 0, co = co_tile * 16 + (zg > 1 ? rl % Cout : rl);
+  const bool col_ok = zg > 1 ? (rl < zg * Cout) : (rl < cout_t);
+  const float bv = col_ok ? bias[co] : 0.0f;
+  const size_t mv = (size_t)m * m * m;
+  for (int rt0 = wave; rt0 < n_rt; rt0 += 4 * RT) {
+    int base[RT];
+    f32x4 acc[RT];
+#pragma unroll
+    for (int j = 0; j < RT; ++j) {
+      const int row = min((rt0 + 4 * j) * 16 + rl, n_rows - 1);
+      const int cxy = row / zgn, g = row - cxy * zgn;
+      base[j] = ((cxy / T) * I + cxy % T) * n + g * zg;
+      acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    const int live = min(RT, (n_rt - rt0 + 3) / 4);  // row-tiles of this pass that exist (wave-uniform)
+    // four K-steps at a time: their (tap, weight) reads, then the operand reads they address, are
+    // all in flight before the first MFMA needs one (kpad is a multiple of 16)
+    for (int kk0 = 0; kk0 < kpad; kk0 += 16) {
+      int tp[4];
+      float b[4], a[4][RT];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        tp[u] = tap_l[kk0 + 4 * u + kq];
+        b[u] = wsrc[(kk0 + 4 * u + kq) * 16 + rl];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < RT; ++j)
+          if (j < live) a[u][j] = tile[base[j] + tp[u]];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < RT; ++j)
+          if (j < live) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], b[u], acc[j], 0, 0, 0);
+    }
+    if (col_ok) {
+      float* dst = out + ((size_t)nb * Cout + co) * mv;
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = (rt0 + 4 * j) * 16 + kq * 4 + r;
+          if (row >= n_rows) continue;  // (also covers row-tiles past the end)
+          const int cxy = row / zgn, g = row - cxy * zgn;
+          const int x = tx0 + cxy / T, y = ty0 + cxy % T;
+          if (x >= m || y >= m) continue;
+          float v = acc[j][r] + bv;
+          if (relu) v = fmaxf(v, 0.0f);
+          dst[((size_t)x * m + y) * m + g * zg + dz] = v;
+        }
+      }
+    }
+  }
+}
 
 // ---- backward (VJP to the latent; weights are constants) -------------------------------------
 
@@ -450,6 +588,34 @@ __global__ __launch_bounds__(kFcBlock) void fc_stack_backward_kernel(const float
 }  // namespace sdfr
 
 using namespace sdfr;
+
+// shared by the forward and the VJP: when to take, and how to launch, the LDS-tiled convolution
+// (a single decode has too few tiles to fill the chip; there the gather kernel's finer grid wins)
+#ifndef SDFR_TILED_MIN_WGS
+#define SDFR_TILED_MIN_WGS 1024
+#endif
+#define SDFR_TILED_CONV_HELPERS                                                                      \
+  auto use_tiled = [&](const sdfr_decoder::TilePlan& tp, int m_, int N_) {                           \
+    const long long t = (m_ + tp.T - 1) / tp.T;                                                      \
+    return t * t * N_ >= SDFR_TILED_MIN_WGS;                                                         \
+  };                                                                                                 \
+  auto launch_tiled = [&](const sdfr_decoder::TilePlan& tp, const float* src_, const float* bias_,   \
+                          float* dst_, int cin_, int cout_, int n_, int m_, int relu_) {             \
+    const int t = (m_ + tp.T - 1) / tp.T, co_tiles = tp.zg > 1 ? 1 : (cout_ + 15) / 16;             \
+    const int n_rt = (tp.T * tp.T * (m_ / tp.zg) + 15) / 16;                                         \
+    const dim3 grid(t * t, co_tiles, N);                                                             \
+    const float* w_ = d->d_params + tp.w_off;                                                        \
+    const int* tab_ = reinterpret_cast<const int*>(d->d_params + tp.tab_off);                        \
+    if (n_rt > 8)                                                                                    \
+      hipLaunchKernelGGL((conv3d_lds_kernel<3>), grid, dim3(256), tp.lds_bytes, st, src_, w_, tab_,  \
+                         bias_, dst_, cin_, cout_, n_, m_, tp.kpad, relu_, tp.zg, tp.T, tp.I);       \
+    else if (n_rt > 4)                                                                               \
+      hipLaunchKernelGGL((conv3d_lds_kernel<2>), grid, dim3(256), tp.lds_bytes, st, src_, w_, tab_,  \
+                         bias_, dst_, cin_, cout_, n_, m_, tp.kpad, relu_, tp.zg, tp.T, tp.I);       \
+    else                                                                                             \
+      hipLaunchKernelGGL((conv3d_lds_kernel<1>), grid, dim3(256), tp.lds_bytes, st, src_, w_, tab_,  \
+                         bias_, dst_, cin_, cout_, n_, m_, tp.kpad, relu_, tp.zg, tp.T, tp.I);       \
+  };
 
 extern "C" int sdfr_decoder_create(const float* h_params, size_t n_params, int latent, int n_fc,
                                    const int* fc_out, int n_conv, const int* conv_in_size,
@@ -629,6 +795,71 @@ extern "C" int sdfr_decoder_create(const float* h_params, size_t n_params, int l
     for (int l = 0; l < n_conv; ++l) max_c = std::max(max_c, conv_cin[l]);
     img.insert(img.end(), (size_t)max_c, 0.0f);
   }
+  // LDS-tiled plans (conv3d_lds_kernel).  wfun(co, ci, a, b, c): weight of input channel ci at tap
+  // (a,b,c) for output channel co, in the correlation sense out[x] = sum w(a,b,c) in[x + (a,b,c)].
+  auto plan_tiled = [&](int cin, int cout, int k, int n, auto wfun) {
+    sdfr_decoder::TilePlan tp;
+    const int m = n - k + 1;
+    if (k < 2 || m < 1) return tp;  // 1x1 layers have their own kernel
+    tp.zg = 1;
+    for (int g = 4; g >= 2; --g)
+      if (g * cout <= 16 && m % g == 0) { tp.zg = g; break; }
+    tp.T = std::min(4, m);
+    tp.I = tp.T + k - 1;
+    const int kz = k + tp.zg - 1, K = cin * k * k * kz;
+    tp.kpad = (K + 15) / 16 * 16;
+    tp.lds_bytes = ((size_t)tp.kpad + (size_t)cin * tp.I * tp.I * n) * sizeof(float);
+    if (tp.lds_bytes > 64 * 1024) return tp;
+    const int co_tiles = tp.zg > 1 ? 1 : (cout + 15) / 16;
+    align();
+    tp.w_off = img.size();
+    for (int ct = 0; ct < co_tiles; ++ct)
+      for (int kk = 0; kk < tp.kpad; ++kk)
+        for (int j = 0; j < 16; ++j) {
+          float v = 0.0f;
+          if (kk < K) {
+            const int ci = kk / (k * k * kz), r = kk % (k * k * kz);
+            const int a = r / (k * kz), b = (r / kz) % k, cz = r % kz;
+            const int dz = tp.zg > 1 ? j / cout : 0, co = tp.zg > 1 ? j % cout : ct * 16 + j;
+            const int c = cz - dz;
+            if (dz < tp.zg && co < cout && c >= 0 && c < k) v = wfun(co, ci, a, b, c);
+          }
+          img.push_back(v);
+        }
+    align();
+    tp.tab_off = img.size();
+    for (int kk = 0; kk < tp.kpad; ++kk) {
+      int off = 0;
+      if (kk < K) {
+        const int ci = kk / (k * k * kz), r = kk % (k * k * kz);
+        const int a = r / (k * kz), b = (r / kz) % k, cz = r % kz;
+        off = ((ci * tp.I + a) * tp.I + b) * n + cz;
+      }
+      float f;
+      memcpy(&f, &off, sizeof(f));
+      img.push_back(f);
+    }
+    tp.ok = true;
+    return tp;
+  };
+  {
+    const float* q = h_params;
+    int wdt = latent;
+    for (int l = 0; l < n_fc; ++l) { q += (size_t)fc_out[l] * wdt + fc_out[l]; wdt = fc_out[l]; }
+    for (int l = 0; l < n_conv; ++l) {
+      const int k = conv_k[l], ci_n = conv_cin[l], co_n = conv_cout[l], n = conv_in_size[l];
+      const int k3 = k * k * k, m = n - k + 1;
+      const float* W = q;  // [co][ci][k][k][k]
+      d->fwd_tile.push_back(plan_tiled(ci_n, co_n, k, n, [&](int co, int ci, int a, int b, int c) {
+        return W[((size_t)co * ci_n + ci) * k3 + (a * k + b) * k + c];
+      }));
+      // data gradient: channels swap roles, taps are flipped, the input is the zero-padded gradient
+      d->bwd_tile.push_back(plan_tiled(co_n, ci_n, k, m + 2 * (k - 1), [&](int co, int ci, int a, int b, int c) {
+        return W[((size_t)ci * ci_n + co) * k3 + ((k - 1 - a) * k + (k - 1 - b)) * k + (k - 1 - c)];
+      }));
+      q += (size_t)co_n * ci_n * k3 + co_n;
+    }
+  }
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipMalloc((void**)&d->d_params, img.size() * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(d->d_params, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -728,6 +959,7 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
     hipLaunchKernelGGL(resize3_kernel, dim3((unsigned)((cnt + 255) / 256), N), dim3(256), 0, st, src, C,
                        ni, no, relu, clamp, dst);
   };
+  SDFR_TILED_CONV_HELPERS
   for (int l = 0; l < d->n_conv; ++l) {
     const bool swap = d->conv_swap[l] != 0, is_last = (l == d->n_conv - 1);
     const int k = d->conv_k[l], co_n = d->conv_cout[l], kpad = d->conv_kpad[l];
@@ -756,6 +988,8 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
 #define SDFR_CONV1(CO) hipLaunchKernelGGL((conv1x1_kernel<CO>), g1, dim3(256), 0, st, act_in, wm, bs, c, voxn, conv_relu, conv_dst)
       if (co_n == 1) SDFR_CONV1(1); else if (co_n == 2) SDFR_CONV1(2); else if (co_n == 3) SDFR_CONV1(3); else SDFR_CONV1(4);
 #undef SDFR_CONV1
+    } else if (d->fwd_tile[l].ok && !swap && use_tiled(d->fwd_tile[l], m, N)) {
+      launch_tiled(d->fwd_tile[l], act_in, bs, conv_dst, c, co_n, n, m, conv_relu);
     } else {
       hipLaunchKernelGGL(conv3d_mfma_kernel, dim3(blocks, (co_n + 15) / 16, N), dim3(256), lds, st, act_in,
                          wm, reinterpret_cast<const int*>(d->d_params + d->conv_tab_off[l]), bs, conv_dst, c,
@@ -829,6 +1063,7 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
       cur ^= 1;
     }
   };
+  SDFR_TILED_CONV_HELPERS
   int n = d->volume;
   if (out_n[d->n_conv - 1] != d->volume) {  // final resize
     const int ni = out_n[d->n_conv - 1];
@@ -858,10 +1093,13 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
     const int n_tiles = (nconv * nconv * nconv + 15) / 16;
     const int tpw = n_tiles >= 32768 ? 4 : 1;
     const int blocks = (n_tiles + 4 * tpw - 1) / (4 * tpw);
-    hipLaunchKernelGGL(conv3d_mfma_kernel, dim3(blocks, (ci_n + 15) / 16, N), dim3(256),
-                       (size_t)kpad * 17 * sizeof(float), st, g, d->d_params + d->bwd_w_off[l],
-                       reinterpret_cast<const int*>(d->d_params + d->bwd_tab_off[l]),
-                       d->d_params + d->zero_bias_off, buf[cur], co_n, ci_n, np, nconv, kpad, 0, tpw);
+    if (d->bwd_tile[l].ok && !swap && use_tiled(d->bwd_tile[l], nconv, N))
+      launch_tiled(d->bwd_tile[l], g, d->d_params + d->zero_bias_off, buf[cur], co_n, ci_n, np, nconv, 0);
+    else
+      hipLaunchKernelGGL(conv3d_mfma_kernel, dim3(blocks, (ci_n + 15) / 16, N), dim3(256),
+                         (size_t)kpad * 17 * sizeof(float), st, g, d->d_params + d->bwd_w_off[l],
+                         reinterpret_cast<const int*>(d->d_params + d->bwd_tab_off[l]),
+                         d->d_params + d->zero_bias_off, buf[cur], co_n, ci_n, np, nconv, kpad, 0, tpw);
     g = buf[cur];
     cur ^= 1;
     n = nconv;
