@@ -100,4 +100,24 @@ constexpr int kPackedMinViews = SDFR_PACKED_MIN_VIEWS;
 constexpr int kPackedMaxR = 128;
 
 
+// Device-side fill / copy as ordinary kernels.  The entry points are captured into hipGraphs
+// (FusedRenderAndCompare); with hipMemsetAsync / hipMemcpyAsync nodes in the captured sequence,
+// replays of the loop after the first run produced results that depended on the process's memory
+// layout (the eager sequence never did).  Kernel nodes only: the replayed graph is then exactly the
+// launch sequence.  n_floats is in 4-byte words.
+static __global__ void zero_words_kernel(float* __restrict__ p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.0f;
+}
+static __global__ void copy_words_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+inline void zero_words_async(float* p, size_t n, hipStream_t st) {
+  if (n) hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n);
+}
+inline void copy_words_async(float* dst, const float* src, size_t n, hipStream_t st) {
+  if (n) hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dst, src, n);
+}
+
 }  // namespace sdfr

@@ -45,13 +45,13 @@ struct sdfr_decoder {
   std::vector<size_t> bwd_w_off, bwd_tab_off;
   std::vector<int> bwd_kpad;
   size_t zero_bias_off = 0;
-  // LDS-tiled convolution (conv3d_lds_kernel): per layer, forward and data-gradient
-  struct TilePlan {
-    bool ok = false;
-    int zg = 1, T = 4, I = 6, kpad = 0;   // z-group, output patch T x T columns, input patch I x I
-    size_t w_off = 0, tab_off = 0, lds_bytes = 0;
+  // z-grouped contraction for layers with few output channels (see conv3d_mfma_kernel): per layer,
+  // forward and data-gradient
+  struct ZPlan {
+    int zg = 1, kpad = 0;
+    size_t w_off = 0, tab_off = 0;
   };
-  std::vector<TilePlan> fwd_tile, bwd_tile;
+  std::vector<ZPlan> fwd_z, bwd_z;
   size_t max_bwd = 0;                      // floats of the largest gradient tensor (incl. padding)
   // tape: post-ReLU outputs kept by a forward that will be differentiated
   size_t tape_fc_off = 0;                  // per-sample float offsets
@@ -63,6 +63,7 @@ namespace sdfr {
 namespace {
 
 constexpr int kFcBlock = 256;
+constexpr long long kZGroupMinRows = 64 * 1024;  // z-grouped conv only when it still fills the chip
 constexpr int kMaxHidden = 2048;  // widest Linear layer other than the last
 
 struct FcDesc {
@@ -274,13 +275,24 @@ __device__ __forceinline__ void stage_to_lds(float* __restrict__ dst, const floa
 //   wmat  [Kpad][16]  weight matrix, wmat[kk][co] = W[co][ci][a][b][c], kk = ci*k^3 + (a*k+b)*k+c,
 //                     zero for kk >= K or co >= Cout_tile
 //   taps  [Kpad]      input offset of tap kk: ci*n^3 + (a*n + b)*n + c  (0 for padding taps)
-// One wave = 16 consecutive output voxels x 16 output channels; lane l supplies
-// A[voxel l&15][tap l>>4] and B[tap l>>4][channel l&15]; the accumulator holds
-// D[voxel 4*(l>>4)+r][channel l&15], r = 0..3.   grid: (ceil(tiles / (4*TPW)), co_tiles, N)
+// One wave = 16 consecutive output positions x 16 columns; lane l supplies
+// A[position l&15][tap l>>4] and B[tap l>>4][column l&15]; the accumulator holds
+// D[position 4*(l>>4)+r][column l&15], r = 0..3.   grid: (ceil(tiles / (4*TPW)), co_tiles, N)
+//
+// Z-grouping (zg > 1): with Cout <= 8 most of the 16 columns would be padding, and the kernel is
+// bound by its gathers (one per lane and MFMA), not by the matrix cores.  So zg consecutive z
+// outputs share a row: position = (x, y, z-group), column = (dz, co), and the contraction runs
+// over K' = Cin*k*k*(k+zg-1) taps with
+//   wmat[(ci,a,b,c')][(dz,co)] = W[co][ci][a][b][c'-dz]   (0 outside 0 <= c'-dz < k).
+// For the 8 -> 4 channel layer (zg = 3): 12 of 16 columns used, 120 instead of 216 gathers and
+// 1.9 instead of 3.4 MFMAs per output voxel.
+// (An LDS-staged variant -- input patch of a 4 x 4 column tile in LDS, operands from ds_read --
+// was built and measured on the same layer: 772 us vs 860 us for the plain gather kernel; patch
+// load 319 + MFMA 220 + stores 58 + staging 120, serialised by 2 workgroups per CU.  Not kept.)
 __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
     const float* __restrict__ in, const float* __restrict__ wmat, const int* __restrict__ taps,
     const float* __restrict__ bias, float* __restrict__ out, int Cin, int Cout, int n, int m,
-    int kpad, int relu, int tiles_per_wave) {
+    int kpad, int relu, int tiles_per_wave, int zg) {
   extern __shared__ float lds[];
   float* w_l = lds;                                       // [kpad][16]
   int* tap_l = reinterpret_cast<int*>(lds + (size_t)kpad * 16);  // [kpad]
@@ -291,18 +303,21 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
   stage_to_lds(reinterpret_cast<float*>(tap_l), reinterpret_cast<const float*>(taps), kpad, tid);
   __syncthreads();
 
-  const int mv = m * m * m;
-  const size_t nv = (size_t)n * n * n;
+  const int zgn = m / zg, mrows = m * m * zgn;  // positions: (x, y, z-group), z-group fastest
+  const size_t mv = (size_t)m * m * m, nv = (size_t)n * n * n;
   const float* src = in + (size_t)nb * Cin * nv;
-  const int n_tiles = (mv + 15) / 16;
+  const int n_tiles = (mrows + 15) / 16;
   const int row = lane & 15, kq = lane >> 4;
-  const int co = co_tile * 16 + row;  // this lane's output channel (C/D column = lane & 15)
-  const float bv = (co < Cout) ? bias[co] : 0.0f;
+  // this lane's column (C/D column = lane & 15)
+  const int dz = zg > 1 ? row / Cout : 0;
+  const int co = zg > 1 ? row % Cout : co_tile * 16 + row;
+  const bool col_ok = zg > 1 ? row < zg * Cout : co < Cout;
+  const float bv = col_ok ? bias[co] : 0.0f;
   const int first = (blockIdx.x * 4 + wave) * tiles_per_wave;
   for (int t = first; t < first + tiles_per_wave && t < n_tiles; ++t) {
-    const int pos = min(t * 16 + row, mv - 1);
-    const int z = pos % m, y = (pos / m) % m, x = pos / (m * m);
-    const float* base = src + ((size_t)x * n + y) * n + z;
+    const int pos = min(t * 16 + row, mrows - 1);
+    const int xy = pos / zgn, g = pos - xy * zgn, x = xy / m, y = xy - x * m;
+    const float* base = src + ((size_t)x * n + y) * n + g * zg;
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     // the gathers of 8 K-steps are issued together and only then consumed: the loop is a chain of
     // dependent (LDS tap -> global gather -> MFMA) round trips otherwise
@@ -322,131 +337,21 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
       const int kk = kk0 + kq;
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(base[tap_l[kk]], w_l[kk * 16 + row], acc, 0, 0, 0);
     }
-    if (co < Cout) {
-      float* dst = out + ((size_t)nb * Cout + co) * mv;
+    if (col_ok) {
+      float* dst = out + ((size_t)nb * Cout + co) * mv + dz;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int p = t * 16 + kq * 4 + r;
+        if (p >= mrows) continue;
+        const int pxy = p / zgn, pg = p - pxy * zgn;  // (zg == 1: pxy * m + pg == p)
         float v = acc[r] + bv;
         if (relu) v = fmaxf(v, 0.0f);
-        if (p < mv) dst[p] = v;
+        dst[(size_t)pxy * m + pg * zg] = v;
       }
     }
   }
 }
 
-
-// The same contraction with the input staged in LDS.  conv3d_mfma_kernel gathers every A operand
-// from global memory -- each input value 27 times -- and is bound by the gather rate, not by the
-// matrix cores (860 us for the 8 -> 4 channel layer at 30^3 x 256 samples, MFMA time ~300 us).
-// Here a workgroup owns T x T output columns (all of z): it loads the (T+k-1)^2 input columns of
-// every channel once (coalesced runs), and the im2col operands are LDS reads.
-// Few output channels would waste most of the 16 MFMA columns, so ZG consecutive z outputs share a
-// row: row = (x, y, z-group), column = (dz, co), K' = Cin*k*k*(k+ZG-1) with the weight matrix
-//   wz[(ci,a,b,c')][(dz,co)] = W[co][ci][a][b][c'-dz]   (0 outside 0 <= c'-dz < k)
-// -- 12 of 16 columns used and half the MFMAs for the 8 -> 4 layer (ZG = 3).
-//   taps[kk] = LDS offset of tap kk: ((ci*I + a)*I + b)*n + c'
-// The weight matrix is NOT staged: every workgroup reads the same 23 KB, 256 contiguous bytes per
-// wave and K-step, straight from L1/L2 -- staging it cost as much as the input patch and its LDS
-// halved the occupancy.  Each wave keeps up to RT row-tiles of accumulators so that one
-// (tap, weight) read feeds RT MFMAs.
-// grid: (ceil(m/T)^2, co_tiles, N);  LDS: taps [kpad] | tile [Cin][I][I][n]
-template <int RT>
-__global__ __launch_bounds__(256) void conv3d_lds_kernel(
-    const float* __restrict__ in, const float* __restrict__ wz, const int* __restrict__ taps,
-    const float* __restrict__ bias, float* __restrict__ out, int Cin, int Cout, int n, int m, int kpad,
-    int relu, int zg, int T, int I) {
-  extern __shared__ float lds[];
-  int* tap_l = reinterpret_cast<int*>(lds);
-  float* tile = lds + kpad;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int txy = (m + T - 1) / T;
-  const int tx0 = (blockIdx.x / txy) * T, ty0 = (blockIdx.x % txy) * T;
-  const int co_tile = blockIdx.y, nb = blockIdx.z;
-  const float* wsrc = wz + (size_t)co_tile * kpad * 16;
-  stage_to_lds(reinterpret_cast<float*>(tap_l), reinterpret_cast<const float*>(taps), kpad, tid);
-  const size_t nv = (size_t)n * n * n;
-  const float* src = in + (size_t)nb * Cin * nv;
-  // the input patch: for each (channel, x) the I columns y0 .. y0+I-1 are one contiguous run of
-  // I*n floats.  Each thread owns one offset of the run and walks the runs eight at a time: eight
-  // loads in flight, then eight LDS stores; the run index arithmetic is wave-uniform.
-  {
-    const int run = I * n, y_valid = (n - ty0) * n, n_slab = Cin * I;
-    for (int off = tid; off < run; off += 256) {
-      for (int s0 = 0; s0 < n_slab; s0 += 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int slab = min(s0 + u, n_slab - 1), ci = slab / I, x = tx0 + slab - ci * I;
-          const float* row = src + (size_t)ci * nv + ((size_t)min(x, n - 1) * n + ty0) * n;
-          v[u] = (x < n && off < y_valid) ? row[off] : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (s0 + u < n_slab) tile[(s0 + u) * run + off] = v[u];
-      }
-    }
-  }
-  __syncthreads();
-
-  const int zgn = m / zg, n_rows = T * T * zgn, n_rt = (n_rows + 15) / 16;
-  const int rl = lane & 15, kq = lane >> 4;
-  const int cout_t = zg > 1 ? Cout : min(16, Cout - co_tile * 16);  // channels in this column tile
-  const int dz = zg > 1 ? rl / Cout : 0, co = co_tile * 16 + (zg > 1 ? rl % Cout : rl);
-  const bool col_ok = zg > 1 ? (rl < zg * Cout) : (rl < cout_t);
-  const float bv = col_ok ? bias[co] : 0.0f;
-  const size_t mv = (size_t)m * m * m;
-  for (int rt0 = wave; rt0 < n_rt; rt0 += 4 * RT) {
-    int base[RT];
-    f32x4 acc[RT];
-#pragma unroll
-    for (int j = 0; j < RT; ++j) {
-      const int row = min((rt0 + 4 * j) * 16 + rl, n_rows - 1);
-      const int cxy = row / zgn, g = row - cxy * zgn;
-      base[j] = ((cxy / T) * I + cxy % T) * n + g * zg;
-      acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    }
-    const int live = min(RT, (n_rt - rt0 + 3) / 4);  // row-tiles of this pass that exist (wave-uniform)
-    // four K-steps at a time: their (tap, weight) reads, then the operand reads they address, are
-    // all in flight before the first MFMA needs one (kpad is a multiple of 16)
-    for (int kk0 = 0; kk0 < kpad; kk0 += 16) {
-      int tp[4];
-      float b[4], a[4][RT];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        tp[u] = tap_l[kk0 + 4 * u + kq];
-        b[u] = wsrc[(kk0 + 4 * u + kq) * 16 + rl];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int j = 0; j < RT; ++j)
-          if (j < live) a[u][j] = tile[base[j] + tp[u]];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int j = 0; j < RT; ++j)
-          if (j < live) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], b[u], acc[j], 0, 0, 0);
-    }
-    if (col_ok) {
-      float* dst = out + ((size_t)nb * Cout + co) * mv;
-#pragma unroll
-      for (int j = 0; j < RT; ++j) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = (rt0 + 4 * j) * 16 + kq * 4 + r;
-          if (row >= n_rows) continue;  // (also covers row-tiles past the end)
-          const int cxy = row / zgn, g = row - cxy * zgn;
-          const int x = tx0 + cxy / T, y = ty0 + cxy % T;
-          if (x >= m || y >= m) continue;
-          float v = acc[j][r] + bv;
-          if (relu) v = fmaxf(v, 0.0f);
-          dst[((size_t)x * m + y) * m + g * zg + dz] = v;
-        }
-      }
-    }
-  }
-}
 
 // ---- backward (VJP to the latent; weights are constants) -------------------------------------
 
@@ -588,34 +493,6 @@ __global__ __launch_bounds__(kFcBlock) void fc_stack_backward_kernel(const float
 }  // namespace sdfr
 
 using namespace sdfr;
-
-// shared by the forward and the VJP: when to take, and how to launch, the LDS-tiled convolution
-// (a single decode has too few tiles to fill the chip; there the gather kernel's finer grid wins)
-#ifndef SDFR_TILED_MIN_WGS
-#define SDFR_TILED_MIN_WGS 1024
-#endif
-#define SDFR_TILED_CONV_HELPERS                                                                      \
-  auto use_tiled = [&](const sdfr_decoder::TilePlan& tp, int m_, int N_) {                           \
-    const long long t = (m_ + tp.T - 1) / tp.T;                                                      \
-    return t * t * N_ >= SDFR_TILED_MIN_WGS;                                                         \
-  };                                                                                                 \
-  auto launch_tiled = [&](const sdfr_decoder::TilePlan& tp, const float* src_, const float* bias_,   \
-                          float* dst_, int cin_, int cout_, int n_, int m_, int relu_) {             \
-    const int t = (m_ + tp.T - 1) / tp.T, co_tiles = tp.zg > 1 ? 1 : (cout_ + 15) / 16;             \
-    const int n_rt = (tp.T * tp.T * (m_ / tp.zg) + 15) / 16;                                         \
-    const dim3 grid(t * t, co_tiles, N);                                                             \
-    const float* w_ = d->d_params + tp.w_off;                                                        \
-    const int* tab_ = reinterpret_cast<const int*>(d->d_params + tp.tab_off);                        \
-    if (n_rt > 8)                                                                                    \
-      hipLaunchKernelGGL((conv3d_lds_kernel<3>), grid, dim3(256), tp.lds_bytes, st, src_, w_, tab_,  \
-                         bias_, dst_, cin_, cout_, n_, m_, tp.kpad, relu_, tp.zg, tp.T, tp.I);       \
-    else if (n_rt > 4)                                                                               \
-      hipLaunchKernelGGL((conv3d_lds_kernel<2>), grid, dim3(256), tp.lds_bytes, st, src_, w_, tab_,  \
-                         bias_, dst_, cin_, cout_, n_, m_, tp.kpad, relu_, tp.zg, tp.T, tp.I);       \
-    else                                                                                             \
-      hipLaunchKernelGGL((conv3d_lds_kernel<1>), grid, dim3(256), tp.lds_bytes, st, src_, w_, tab_,  \
-                         bias_, dst_, cin_, cout_, n_, m_, tp.kpad, relu_, tp.zg, tp.T, tp.I);       \
-  };
 
 extern "C" int sdfr_decoder_create(const float* h_params, size_t n_params, int latent, int n_fc,
                                    const int* fc_out, int n_conv, const int* conv_in_size,
@@ -795,52 +672,45 @@ extern "C" int sdfr_decoder_create(const float* h_params, size_t n_params, int l
     for (int l = 0; l < n_conv; ++l) max_c = std::max(max_c, conv_cin[l]);
     img.insert(img.end(), (size_t)max_c, 0.0f);
   }
-  // LDS-tiled plans (conv3d_lds_kernel).  wfun(co, ci, a, b, c): weight of input channel ci at tap
-  // (a,b,c) for output channel co, in the correlation sense out[x] = sum w(a,b,c) in[x + (a,b,c)].
-  auto plan_tiled = [&](int cin, int cout, int k, int n, auto wfun) {
-    sdfr_decoder::TilePlan tp;
+  // z-grouped plans.  wfun(co, ci, a, b, c): weight of input channel ci at tap (a,b,c) for output
+  // channel co, in the correlation sense out[x] = sum w(a,b,c) in[x + (a,b,c)].
+  auto plan_z = [&](int cin, int cout, int k, int n, auto wfun) {
+    sdfr_decoder::ZPlan zp;
     const int m = n - k + 1;
-    if (k < 2 || m < 1) return tp;  // 1x1 layers have their own kernel
-    tp.zg = 1;
+    if (k < 2 || m < 1) return zp;
     for (int g = 4; g >= 2; --g)
-      if (g * cout <= 16 && m % g == 0) { tp.zg = g; break; }
-    tp.T = std::min(4, m);
-    tp.I = tp.T + k - 1;
-    const int kz = k + tp.zg - 1, K = cin * k * k * kz;
-    tp.kpad = (K + 15) / 16 * 16;
-    tp.lds_bytes = ((size_t)tp.kpad + (size_t)cin * tp.I * tp.I * n) * sizeof(float);
-    if (tp.lds_bytes > 64 * 1024) return tp;
-    const int co_tiles = tp.zg > 1 ? 1 : (cout + 15) / 16;
+      if (g * cout <= 16 && m % g == 0) { zp.zg = g; break; }
+    if (zp.zg == 1) return zp;
+    const int kz = k + zp.zg - 1, K = cin * k * k * kz;
+    zp.kpad = (K + 3) / 4 * 4;
+    if ((size_t)zp.kpad * 17 * sizeof(float) > 64 * 1024) { zp.zg = 1; return zp; }
     align();
-    tp.w_off = img.size();
-    for (int ct = 0; ct < co_tiles; ++ct)
-      for (int kk = 0; kk < tp.kpad; ++kk)
-        for (int j = 0; j < 16; ++j) {
-          float v = 0.0f;
-          if (kk < K) {
-            const int ci = kk / (k * k * kz), r = kk % (k * k * kz);
-            const int a = r / (k * kz), b = (r / kz) % k, cz = r % kz;
-            const int dz = tp.zg > 1 ? j / cout : 0, co = tp.zg > 1 ? j % cout : ct * 16 + j;
-            const int c = cz - dz;
-            if (dz < tp.zg && co < cout && c >= 0 && c < k) v = wfun(co, ci, a, b, c);
-          }
-          img.push_back(v);
+    zp.w_off = img.size();
+    for (int kk = 0; kk < zp.kpad; ++kk)
+      for (int j = 0; j < 16; ++j) {
+        float v = 0.0f;
+        if (kk < K) {
+          const int ci = kk / (k * k * kz), r = kk % (k * k * kz);
+          const int a = r / (k * kz), b = (r / kz) % k, cz = r % kz;
+          const int dz = j / cout, co = j % cout, c = cz - dz;
+          if (dz < zp.zg && c >= 0 && c < k) v = wfun(co, ci, a, b, c);
         }
+        img.push_back(v);
+      }
     align();
-    tp.tab_off = img.size();
-    for (int kk = 0; kk < tp.kpad; ++kk) {
+    zp.tab_off = img.size();
+    for (int kk = 0; kk < zp.kpad; ++kk) {
       int off = 0;
       if (kk < K) {
         const int ci = kk / (k * k * kz), r = kk % (k * k * kz);
         const int a = r / (k * kz), b = (r / kz) % k, cz = r % kz;
-        off = ((ci * tp.I + a) * tp.I + b) * n + cz;
+        off = ci * n * n * n + (a * n + b) * n + cz;
       }
       float f;
       memcpy(&f, &off, sizeof(f));
       img.push_back(f);
     }
-    tp.ok = true;
-    return tp;
+    return zp;
   };
   {
     const float* q = h_params;
@@ -850,11 +720,11 @@ extern "C" int sdfr_decoder_create(const float* h_params, size_t n_params, int l
       const int k = conv_k[l], ci_n = conv_cin[l], co_n = conv_cout[l], n = conv_in_size[l];
       const int k3 = k * k * k, m = n - k + 1;
       const float* W = q;  // [co][ci][k][k][k]
-      d->fwd_tile.push_back(plan_tiled(ci_n, co_n, k, n, [&](int co, int ci, int a, int b, int c) {
+      d->fwd_z.push_back(plan_z(ci_n, co_n, k, n, [&](int co, int ci, int a, int b, int c) {
         return W[((size_t)co * ci_n + ci) * k3 + (a * k + b) * k + c];
       }));
       // data gradient: channels swap roles, taps are flipped, the input is the zero-padded gradient
-      d->bwd_tile.push_back(plan_tiled(co_n, ci_n, k, m + 2 * (k - 1), [&](int co, int ci, int a, int b, int c) {
+      d->bwd_z.push_back(plan_z(co_n, ci_n, k, m + 2 * (k - 1), [&](int co, int ci, int a, int b, int c) {
         return W[((size_t)ci * ci_n + co) * k3 + ((k - 1 - a) * k + (k - 1 - b)) * k + (k - 1 - c)];
       }));
       q += (size_t)co_n * ci_n * k3 + co_n;
@@ -959,7 +829,6 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
     hipLaunchKernelGGL(resize3_kernel, dim3((unsigned)((cnt + 255) / 256), N), dim3(256), 0, st, src, C,
                        ni, no, relu, clamp, dst);
   };
-  SDFR_TILED_CONV_HELPERS
   for (int l = 0; l < d->n_conv; ++l) {
     const bool swap = d->conv_swap[l] != 0, is_last = (l == d->n_conv - 1);
     const int k = d->conv_k[l], co_n = d->conv_cout[l], kpad = d->conv_kpad[l];
@@ -971,10 +840,6 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
     }
     const int m = n - k + 1;                     // swapped: k == 1, the conv keeps the incoming size
     const int m_out = d->conv_in_size[l] - k + 1;  // size of the layer's output tensor
-    const int n_tiles = (m * m * m + 15) / 16;
-    const int tpw = n_tiles >= 32768 ? 4 : 1;
-    const int blocks = (n_tiles + 4 * tpw - 1) / (4 * tpw);
-    const size_t lds = (size_t)kpad * 17 * sizeof(float);
     // where the layer's output goes: straight to `out`, to its tape slot, or to the other buffer
     const bool to_out = is_last && m_out == d->volume && (swap || clampv == 0.0f);
     float* layer_dst = to_out ? out : (tape ? tape + (size_t)N * d->tape_conv_off[l] : nullptr);
@@ -988,12 +853,17 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
 #define SDFR_CONV1(CO) hipLaunchKernelGGL((conv1x1_kernel<CO>), g1, dim3(256), 0, st, act_in, wm, bs, c, voxn, conv_relu, conv_dst)
       if (co_n == 1) SDFR_CONV1(1); else if (co_n == 2) SDFR_CONV1(2); else if (co_n == 3) SDFR_CONV1(3); else SDFR_CONV1(4);
 #undef SDFR_CONV1
-    } else if (d->fwd_tile[l].ok && !swap && use_tiled(d->fwd_tile[l], m, N)) {
-      launch_tiled(d->fwd_tile[l], act_in, bs, conv_dst, c, co_n, n, m, conv_relu);
     } else {
-      hipLaunchKernelGGL(conv3d_mfma_kernel, dim3(blocks, (co_n + 15) / 16, N), dim3(256), lds, st, act_in,
-                         wm, reinterpret_cast<const int*>(d->d_params + d->conv_tab_off[l]), bs, conv_dst, c,
-                         co_n, n, m, kpad, conv_relu, tpw);
+      const sdfr_decoder::ZPlan& zp = d->fwd_z[l];
+      // (a single decode is latency-bound: there the finer grid of the ungrouped form wins)
+      const bool zgrp = zp.zg > 1 && !swap && (long long)m * m * (m / zp.zg) * N >= kZGroupMinRows;
+      const int kp = zgrp ? zp.kpad : kpad, rows = m * m * (m / (zgrp ? zp.zg : 1));
+      const int nt = (rows + 15) / 16, tw = nt >= 32768 ? 4 : 1;
+      hipLaunchKernelGGL(conv3d_mfma_kernel, dim3((nt + 4 * tw - 1) / (4 * tw), zgrp ? 1 : (co_n + 15) / 16, N),
+                         dim3(256), (size_t)kp * 17 * sizeof(float), st, act_in,
+                         zgrp ? d->d_params + zp.w_off : wm,
+                         reinterpret_cast<const int*>(d->d_params + (zgrp ? zp.tab_off : d->conv_tab_off[l])),
+                         bs, conv_dst, c, co_n, n, m, kp, conv_relu, tw, zgrp ? zp.zg : 1);
     }
     if (conv_dst == buf[cur ^ 1]) cur ^= 1;
     act_in = conv_dst;
@@ -1010,8 +880,7 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
       if (n != d->volume) {
         resize(act_in, 1, n, d->volume, 0, clampv, out);
       } else {
-        SDFR_HIP_TRY(hipMemcpyAsync(out, act_in, (size_t)N * vox * sizeof(float),
-                                    hipMemcpyDeviceToDevice, st));
+        copy_words_async(out, act_in, (size_t)N * vox, st);
         if (clampv > 0.0f)
           hipLaunchKernelGGL(clamp_kernel, dim3((unsigned)(((size_t)N * vox + 255) / 256)), dim3(256), 0,
                              st, out, (size_t)N * vox, clampv);
@@ -1063,7 +932,6 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
       cur ^= 1;
     }
   };
-  SDFR_TILED_CONV_HELPERS
   int n = d->volume;
   if (out_n[d->n_conv - 1] != d->volume) {  // final resize
     const int ni = out_n[d->n_conv - 1];
@@ -1090,16 +958,18 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
     if (swap) resize_backward(co_n, prev, nin);
     // 2. data gradient = valid conv (kernel k) of the padded tensor with the flipped weights
     const int kpad = d->bwd_kpad[l];
-    const int n_tiles = (nconv * nconv * nconv + 15) / 16;
-    const int tpw = n_tiles >= 32768 ? 4 : 1;
-    const int blocks = (n_tiles + 4 * tpw - 1) / (4 * tpw);
-    if (d->bwd_tile[l].ok && !swap && use_tiled(d->bwd_tile[l], nconv, N))
-      launch_tiled(d->bwd_tile[l], g, d->d_params + d->zero_bias_off, buf[cur], co_n, ci_n, np, nconv, 0);
-    else
-      hipLaunchKernelGGL(conv3d_mfma_kernel, dim3(blocks, (ci_n + 15) / 16, N), dim3(256),
-                         (size_t)kpad * 17 * sizeof(float), st, g, d->d_params + d->bwd_w_off[l],
-                         reinterpret_cast<const int*>(d->d_params + d->bwd_tab_off[l]),
-                         d->d_params + d->zero_bias_off, buf[cur], co_n, ci_n, np, nconv, kpad, 0, tpw);
+    {
+      const sdfr_decoder::ZPlan& zp = d->bwd_z[l];
+      const bool zgrp = zp.zg > 1 && !swap && (long long)nconv * nconv * (nconv / zp.zg) * N >= kZGroupMinRows;
+      const int kp = zgrp ? zp.kpad : kpad, rows = nconv * nconv * (nconv / (zgrp ? zp.zg : 1));
+      const int nt = (rows + 15) / 16, tw = nt >= 32768 ? 4 : 1;
+      hipLaunchKernelGGL(conv3d_mfma_kernel, dim3((nt + 4 * tw - 1) / (4 * tw), zgrp ? 1 : (ci_n + 15) / 16, N),
+                         dim3(256), (size_t)kp * 17 * sizeof(float), st, g,
+                         d->d_params + (zgrp ? zp.w_off : d->bwd_w_off[l]),
+                         reinterpret_cast<const int*>(d->d_params + (zgrp ? zp.tab_off : d->bwd_tab_off[l])),
+                         d->d_params + d->zero_bias_off, buf[cur], co_n, ci_n, np, nconv, kp, 0, tw,
+                         zgrp ? zp.zg : 1);
+    }
     g = buf[cur];
     cur ^= 1;
     n = nconv;
@@ -1112,7 +982,7 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
   // g is now the gradient w.r.t. the (ReLU'd) output of the Linear stack
   const int last = d->fc_out[d->n_fc - 1];
   float* gl = buf[cur];
-  SDFR_HIP_TRY(hipMemcpyAsync(gl, g, (size_t)N * last * sizeof(float), hipMemcpyDeviceToDevice, st));
+  copy_words_async(gl, g, (size_t)N * last, st);
   hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)(((size_t)N * last + 255) / 256)), dim3(256), 0, st,
                      gl, tape + (size_t)N * d->tape_fc_off, (size_t)N * last);
   FcDesc fd;

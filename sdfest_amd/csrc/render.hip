@@ -721,14 +721,14 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
   SDFR_HIP_TRY(hipSetDevice(device));
   hipStream_t st = (hipStream_t)stream;
   const size_t g_bytes = (size_t)vox * sizeof(float) * (g_sdf_view_stride ? (size_t)(B > 0 ? B : 1) : 1);
-  SDFR_HIP_TRY(hipMemsetAsync(g_sdf, 0, g_bytes, st));
+  zero_words_async(g_sdf, g_bytes / sizeof(float), st);
   if (B == 0) return 0;
   if (!g_pos || !g_quat || !g_inv_scale || !pos || !quat || !inv_scale)
     return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
   if (W == 0 || H == 0) {
-    SDFR_HIP_TRY(hipMemsetAsync(g_pos, 0, (size_t)B * 3 * sizeof(float), st));
-    SDFR_HIP_TRY(hipMemsetAsync(g_quat, 0, (size_t)B * 4 * sizeof(float), st));
-    SDFR_HIP_TRY(hipMemsetAsync(g_inv_scale, 0, (size_t)B * sizeof(float), st));
+    zero_words_async(g_pos, (size_t)B * 3, st);
+    zero_words_async(g_quat, (size_t)B * 4, st);
+    zero_words_async(g_inv_scale, (size_t)B, st);
     return 0;
   }
   if (!grad_depth || !depth || !sdf || !workspace)

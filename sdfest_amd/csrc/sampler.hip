@@ -283,14 +283,14 @@ extern "C" int sdfr_pc_loss_backward(const float* grad_out, const float* points,
   SDFR_HIP_TRY(hipSetDevice(device));
   hipStream_t st = (hipStream_t)stream;
   const size_t g_bytes = (size_t)vox * sizeof(float) * (g_sdf_view_stride ? (size_t)(B > 0 ? B : 1) : 1);
-  SDFR_HIP_TRY(hipMemsetAsync(g_sdf, 0, g_bytes, st));
+  zero_words_async(g_sdf, g_bytes / sizeof(float), st);
   if (B == 0) return 0;
   if (!g_pos || !g_quat || !g_scale || !pos || !quat || !scale)
     return fail(SDFR_E_NULL, "sdfr_pc_loss_backward: NULL pointer argument");
   if (max_view_points == 0) {
-    SDFR_HIP_TRY(hipMemsetAsync(g_pos, 0, (size_t)B * 3 * sizeof(float), st));
-    SDFR_HIP_TRY(hipMemsetAsync(g_quat, 0, (size_t)B * 4 * sizeof(float), st));
-    SDFR_HIP_TRY(hipMemsetAsync(g_scale, 0, (size_t)B * sizeof(float), st));
+    zero_words_async(g_pos, (size_t)B * 3, st);
+    zero_words_async(g_quat, (size_t)B * 4, st);
+    zero_words_async(g_scale, (size_t)B, st);
     return 0;
   }
   if (!grad_out || !points || !sdf || !workspace)

@@ -215,3 +215,36 @@ def test_fused_graph_loop_matches_autograd_loop(mug_decoder, shape_opt, fuse_l1)
         assert h[-1]["latent"].abs().max().item() > 1e-3
     else:
         assert h[-1]["latent"].abs().max().item() == 0.0
+
+
+def test_graph_replays_are_repeatable_without_host_work_between_them(mug_decoder):
+    """Regression: 20 back-to-back replays per call, several calls on one captured graph, no host
+    work between replays -- every call must reproduce the eager launch sequence.  (With
+    hipMemsetAsync / hipMemcpyAsync nodes in the captured sequence the second and later calls
+    went elsewhere; the entry points now launch kernels only.)"""
+    from sdfest_amd import Camera, render_depth_gpu
+    from sdfest_amd.pipeline import FusedRenderAndCompare
+    dec, d = mug_decoder
+    cam = Camera(320, 240, 160.0, 160.0, 160.0, 120.0, pixel_center=0.5)
+    dev = "cuda"
+    z_true = torch.tensor(d["z"][9:10], device=dev) * 0.5
+    p_true = torch.tensor([[0.02, -0.01, -0.5]], device=dev)
+    q_true = torch.tensor([[0.2, 0.6, -0.15, 0.75]], device=dev)
+    q_true = q_true / q_true.norm()
+    s_true = torch.tensor([0.055], device=dev)
+    with torch.no_grad():
+        target = render_depth_gpu(dec.decode(z_true)[0, 0], p_true[0], q_true[0], 1 / s_true[0], None, None,
+                                  None, 0.005, cam)
+    assert (target > 0).sum() > 500
+    cfg = {"threshold": 0.005, "max_iterations": 20, "depth_weight": 1.0, "pc_weight": 3.0}
+    q0 = q_true + torch.tensor([[0.06, -0.05, 0.04, 0.0]], device=dev)
+    args = (p_true + 0.01, q0 / q0.norm(), torch.tensor([0.06], device=dev), torch.zeros(1, 8, device=dev))
+    eager = FusedRenderAndCompare(dec, cam, cfg, target[None].contiguous())
+    ref = [t.clone() for t in eager(*args, use_graph=False)]
+    graph = FusedRenderAndCompare(dec, cam, cfg, target[None].contiguous())
+    for call in range(4):
+        out = graph(*args, use_graph=True)
+        torch.cuda.synchronize()
+        assert graph.step.item() == 20
+        for a, b, tol in zip(out, ref, (2e-5, 2e-4, 2e-5, 5e-4)):
+            assert torch.isfinite(a).all() and (a - b).abs().max().item() <= tol, (call, a, b)
