@@ -453,11 +453,8 @@ __device__ __forceinline__ void backward_tile(
   // pose sums: registers -> wave shuffle -> LDS -> macro-tile partial (a wave without a hit pixel
   // has nothing to reduce)
   if (__ballot(any_hit) != 0ull) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float sk = wave_sum(acc[k]);
-      if (lane == 0) wave_part[wave][k] = sk;
-    }
+    const float sk = wave_sum8(acc, lane);  // (8 separate butterflies: +6 us per launch)
+    if ((lane & 7) == 0) wave_part[wave][lane >> 3] = sk;
   } else if (lane < 8) {
     wave_part[wave][lane] = 0.0f;
   }

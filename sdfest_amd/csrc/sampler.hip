@@ -177,10 +177,9 @@ __global__ __launch_bounds__(kPts) void pc_loss_backward_kernel(
       atomicAdd(g0 + Rr * Rr + Rr, w6); atomicAdd(g0 + Rr * Rr + Rr + 1, w7);
     }
   }
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const float sk = wave_sum(acc[k]);
-    if (lane == 0) wave_part[wave][k] = sk;
+  {
+    const float sk = wave_sum8(acc, lane);
+    if ((lane & 7) == 0) wave_part[wave][lane >> 3] = sk;
   }
   __syncthreads();
   if (tid < 8) {
