@@ -39,12 +39,13 @@ struct Cell {
   int lin;  // linear index of corner 000
 };
 
-// Locate the cell of a grid-space point and fetch its 8 corners.  Same cell choice and the
-// same un-clamped (extrapolating) cell coordinate as sdf_renderer_cuda.cu:196-239.
-// PACKED: `src` is the face-record array (two 16-byte loads); else the plain grid (4 z-pair loads).
-template <int RT, bool PACKED>
-__device__ __forceinline__ void gather_cell(const float* __restrict__ src, int R, float gx,
-                                            float gy, float gz, Cell& c) {
+// Locate the cell of a grid-space point and fetch its 8 corners from the plain grid (four z-pair
+// loads).  Same cell choice and the same un-clamped (extrapolating) cell coordinate as
+// sdf_renderer_cuda.cu:196-239.  Used once per hit pixel by the backward and once per point by the
+// sampler; the forward's march has its own sample routine (march_sample).
+template <int RT>
+__device__ __forceinline__ void gather_cell(const float* __restrict__ src, int R, float gx, float gy,
+                                            float gz, Cell& c) {
   const int Rr = RT > 0 ? RT : R;
   const float top = (float)(Rr - 2);
   const float bx = fminf(fmaxf(floorf(gx), 0.0f), top);
@@ -55,20 +56,13 @@ __device__ __forceinline__ void gather_cell(const float* __restrict__ src, int R
   const int lin = (Rr <= 256) ? (int)fmaf(fmaf(bx, (float)Rr, by), (float)Rr, bz)
                               : ((int)bx * Rr + (int)by) * Rr + (int)bz;
   c.lin = lin;
-  if (PACKED) {
-    const float4* rec = reinterpret_cast<const float4*>(src) + (size_t)(unsigned)lin;
-    const float4 a = rec[0], b = rec[Rr * Rr];
-    c.v[0] = a.x; c.v[1] = a.y; c.v[2] = a.z; c.v[3] = a.w;
-    c.v[4] = b.x; c.v[5] = b.y; c.v[6] = b.z; c.v[7] = b.w;
-  } else {
-    const float* base = src + lin;
-    const ZPair p00 = *reinterpret_cast<const ZPair*>(base);
-    const ZPair p01 = *reinterpret_cast<const ZPair*>(base + Rr);
-    const ZPair p10 = *reinterpret_cast<const ZPair*>(base + Rr * Rr);
-    const ZPair p11 = *reinterpret_cast<const ZPair*>(base + Rr * Rr + Rr);
-    c.v[0] = p00.lo; c.v[1] = p00.hi; c.v[2] = p01.lo; c.v[3] = p01.hi;
-    c.v[4] = p10.lo; c.v[5] = p10.hi; c.v[6] = p11.lo; c.v[7] = p11.hi;
-  }
+  const float* base = src + lin;
+  const ZPair p00 = *reinterpret_cast<const ZPair*>(base);
+  const ZPair p01 = *reinterpret_cast<const ZPair*>(base + Rr);
+  const ZPair p10 = *reinterpret_cast<const ZPair*>(base + Rr * Rr);
+  const ZPair p11 = *reinterpret_cast<const ZPair*>(base + Rr * Rr + Rr);
+  c.v[0] = p00.lo; c.v[1] = p00.hi; c.v[2] = p01.lo; c.v[3] = p01.hi;
+  c.v[4] = p10.lo; c.v[5] = p10.hi; c.v[6] = p11.lo; c.v[7] = p11.hi;
 }
 
 // Face records are stored x-major with 2 x 2 blocks in (y, z): a 64-byte chunk of the record array
@@ -91,28 +85,7 @@ __device__ __forceinline__ int record_index(int x, int y, int z, int Hb) {
   return (((x * Hb + (y >> 1)) * Hb + (z >> 1)) << 2) | ((y & 1) << 1) | (z & 1);
 }
 
-// The march's fetch: the two face records of the cell through a buffer descriptor -- one 32-bit
-// byte offset per lane, the second record R^2 records further on as a scalar offset, and the
-// hardware range check (an out-of-range offset reads 0 instead of faulting).
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-template <int RT>
-__device__ __forceinline__ void gather_cell_records(__amdgpu_buffer_rsrc_t recs, int R, float gx,
-                                                    float gy, float gz, Cell& c) {
-  const int Rr = RT > 0 ? RT : R;
-  const float top = (float)(Rr - 2);
-  const float bx = fminf(fmaxf(floorf(gx), 0.0f), top);
-  const float by = fminf(fmaxf(floorf(gy), 0.0f), top);
-  const float bz = fminf(fmaxf(floorf(gz), 0.0f), top);
-  c.ox = gx - bx; c.oy = gy - by; c.oz = gz - bz;
-  const int lin = (Rr <= 256) ? (int)fmaf(fmaf(bx, (float)Rr, by), (float)Rr, bz)
-                              : ((int)bx * Rr + (int)by) * Rr + (int)bz;
-  c.lin = lin;
-  const int rix = record_index((int)bx, (int)by, (int)bz, (Rr + 1) >> 1);
-  const i32x4 a = __builtin_amdgcn_raw_buffer_load_b128(recs, rix * 16, 0, 0);
-  const i32x4 b = __builtin_amdgcn_raw_buffer_load_b128(recs, rix * 16, record_slab(Rr) * 16, 0);
-  c.v[0] = __int_as_float(a.x); c.v[1] = __int_as_float(a.y); c.v[2] = __int_as_float(a.z); c.v[3] = __int_as_float(a.w);
-  c.v[4] = __int_as_float(b.x); c.v[5] = __int_as_float(b.y); c.v[6] = __int_as_float(b.z); c.v[7] = __int_as_float(b.w);
-}
 
 // ---------------------------------------------------------------------------------------------
 // The march's sample: trilinear SDF value at a grid-space point, written for the VALU.

@@ -383,7 +383,7 @@ __device__ __forceinline__ void backward_tile(
     const float t = z * __builtin_amdgcn_rcpf(-d.z);  // -z / d.z   (cu:339)
     const V3 o = mk(fmaf(t, dobj.x, -s.e[0]), fmaf(t, dobj.y, -s.e[1]), fmaf(t, dobj.z, -s.e[2]));
     Cell c;
-    gather_cell<RT, false>(vol, R, fmaf(o.x * isc, h, h), fmaf(o.y * isc, h, h), fmaf(o.z * isc, h, h), c);
+    gather_cell<RT>(vol, R, fmaf(o.x * isc, h, h), fmaf(o.y * isc, h, h), fmaf(o.z * isc, h, h), c);
     const float tri = trilerp(c);
     // gradient of the trilinear value w.r.t. the cell coordinate
     const float ax = 1.0f - c.ox, ay = 1.0f - c.oy, az = 1.0f - c.oz;
@@ -559,6 +559,7 @@ int check_common(int R, int B, int W, int H, float fx, float fy) {
   if (B < 0 || W < 0 || H < 0) return fail(SDFR_E_INVALID, "negative size B=%d W=%d H=%d", B, W, H);
   if (B > 65535) return fail(SDFR_E_INVALID, "B=%d exceeds 65535 views per call", B);
   if (kSmallTile.ny(H) > 65535) return fail(SDFR_E_INVALID, "H=%d too large", H);
+  if ((long long)W * H > 0x7fffffffLL) return fail(SDFR_E_INVALID, "image of %d x %d pixels too large", W, H);
   if ((long long)W * H * (long long)(B > 0 ? B : 1) > (1LL << 40))
     return fail(SDFR_E_INVALID, "image batch too large");
   if (!(fx != 0.0f) || !(fy != 0.0f)) return fail(SDFR_E_INVALID, "focal length must be non-zero");

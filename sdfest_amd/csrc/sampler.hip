@@ -60,7 +60,7 @@ __device__ __forceinline__ bool sample_cell(const PointFrame& f, const float* __
   const float cxf = floorf(gx), cyf = floorf(gy), czf = floorf(gz);
   const bool inside = !(cxf < 0.0f) && !(cyf < 0.0f) && !(czf < 0.0f) && !(cxf > top) && !(cyf > top) &&
                       !(czf > top) && (gx == gx) && (gy == gy) && (gz == gz);
-  gather_cell<RT, false>(vol, R, gx, gy, gz, c);  // clamps the cell, so the loads are always safe
+  gather_cell<RT>(vol, R, gx, gy, gz, c);  // clamps the cell, so the loads are always safe
   return inside;
 }
 
