@@ -387,7 +387,9 @@ __device__ __forceinline__ float resize_weight(int d, int i, float ratio, int n_
 }
 
 // Transpose of resize3_kernel, one axis per launch (the interpolation is separable), in gather
-// form: deterministic, no atomics.  The tensor is viewed as [outer][n_out][inner] -> [outer][n_in][inner]:
+// form: deterministic, no atomics.  (All three axes in one launch -- to save two ~5 us launches per
+// resize in the captured loop -- was measured: the <= 10^3-term gather per voxel costs more than it
+// saves, 182 -> 221 us for a forward + VJP.)  The tensor is viewed as [outer][n_out][inner] -> [outer][n_in][inner]:
 //   g_in[o][i][r] = sum over the few d with i0(d) == i or i1(d) == i of w(d -> i) * g_out[o][d][r]
 __global__ __launch_bounds__(256) void resize_axis_backward_kernel(const float* __restrict__ g_out,
                                                                    size_t outer, int n_in, int n_out,
@@ -412,10 +414,11 @@ __global__ __launch_bounds__(256) void resize_axis_backward_kernel(const float* 
   g_in[idx] = acc;
 }
 
-// g[i] = 0 where the forward activation was not positive (ReLU'), in place
-__global__ void relu_mask_kernel(float* __restrict__ g, const float* __restrict__ act, size_t count) {
+// out[i] = g[i] where the forward activation was positive, else 0 (ReLU'), out of place
+__global__ void relu_mask_copy_kernel(const float* __restrict__ g, const float* __restrict__ act,
+                                      float* __restrict__ out, size_t count) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < count && !(act[i] > 0.0f)) g[i] = 0.0f;
+  if (i < count) out[i] = (act[i] > 0.0f) ? g[i] : 0.0f;
 }
 
 // Backward of the last (wide) Linear layer: t[n][i] = sum_o Wt[i][o] * g_last[n][o], one workgroup
@@ -982,9 +985,8 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
   // g is now the gradient w.r.t. the (ReLU'd) output of the Linear stack
   const int last = d->fc_out[d->n_fc - 1];
   float* gl = buf[cur];
-  copy_words_async(gl, g, (size_t)N * last, st);
-  hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)(((size_t)N * last + 255) / 256)), dim3(256), 0, st,
-                     gl, tape + (size_t)N * d->tape_fc_off, (size_t)N * last);
+  hipLaunchKernelGGL(relu_mask_copy_kernel, dim3((unsigned)(((size_t)N * last + 255) / 256)), dim3(256), 0, st,
+                     g, tape + (size_t)N * d->tape_fc_off, gl, (size_t)N * last);
   FcDesc fd;
   fd.n_fc = d->n_fc;
   fd.width[0] = d->latent;

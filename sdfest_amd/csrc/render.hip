@@ -27,6 +27,8 @@
 //     flushed as 32-byte runs of global float atomics (one per touched voxel per macro-tile).
 #include <type_traits>
 
+#include <algorithm>
+
 #include "common.hpp"
 #include "device.hpp"
 
@@ -40,12 +42,11 @@ constexpr int kBlock = 256;
 // ---------------------------------------------------------------------------------------------
 // set-up: one thread per view
 // ---------------------------------------------------------------------------------------------
-__global__ void view_setup_kernel(const float* __restrict__ pos, const float* __restrict__ quat,
-                                  const float* __restrict__ inv_scale, int B, int R, int W, int H,
-                                  float cx, float cy, float fx, float fy,
-                                  ViewSetup* __restrict__ out) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+__device__ __forceinline__ void compute_view_setup(int b, const float* __restrict__ pos,
+                                                   const float* __restrict__ quat,
+                                                   const float* __restrict__ inv_scale, int R, int W, int H,
+                                                   float cx, float cy, float fx, float fy,
+                                                   ViewSetup* __restrict__ out) {
   const float x = quat[4 * b], y = quat[4 * b + 1], z = quat[4 * b + 2], w = quat[4 * b + 3];
   const V3 p = mk(pos[3 * b], pos[3 * b + 1], pos[3 * b + 2]);
   const float isc = inv_scale[b];
@@ -102,6 +103,25 @@ __global__ void view_setup_kernel(const float* __restrict__ pos, const float* __
   out[b] = s;
 }
 
+__global__ void view_setup_kernel(const float* __restrict__ pos, const float* __restrict__ quat,
+                                  const float* __restrict__ inv_scale, int B, int R, int W, int H,
+                                  float cx, float cy, float fx, float fy,
+                                  ViewSetup* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) compute_view_setup(b, pos, quat, inv_scale, R, W, H, cx, cy, fx, fy, out);
+}
+
+// The backward's prologue in one launch: zero the gradient volume(s) and set the views up (every
+// launch costs ~5 us of a ~30 us single-view call whatever it does).  grid: ceil(max(n_words, B) / 256)
+__global__ __launch_bounds__(256) void backward_prologue_kernel(
+    float* __restrict__ g_sdf, size_t n_words, const float* __restrict__ pos,
+    const float* __restrict__ quat, const float* __restrict__ inv_scale, int B, int R, int W, int H,
+    float cx, float cy, float fx, float fy, ViewSetup* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n_words) g_sdf[i] = 0.0f;
+  if (i < (size_t)B) compute_view_setup((int)i, pos, quat, inv_scale, R, W, H, cx, cy, fx, fy, out);
+}
+
 // ---------------------------------------------------------------------------------------------
 // face records: rec[lin] = the 4 corners of the cell face x = const whose corner 00 is voxel lin:
 // (v(x,y,z), v(x,y,z+1), v(x,y+1,z), v(x,y+1,z+1)) as one float4.  A cell is the two records
@@ -112,9 +132,13 @@ __global__ void view_setup_kernel(const float* __restrict__ pos, const float* __
 // ---------------------------------------------------------------------------------------------
 // (A 2x2x2-blocked record order was measured: +10 integer ops per step, no gain -- the march is
 // bound by dependent-load latency, not by lines per access.  Records stay in grid order.)
-__global__ __launch_bounds__(256) void pack_cells_kernel(const float* __restrict__ sdf, int R,
-                                                         float4* __restrict__ cells) {
+// The launch also sets the views up (threads b < B): one prologue launch for a batched forward.
+__global__ __launch_bounds__(256) void pack_cells_kernel(
+    const float* __restrict__ sdf, int R, float4* __restrict__ cells, const float* __restrict__ pos,
+    const float* __restrict__ quat, const float* __restrict__ inv_scale, int B, int W, int H, float cx,
+    float cy, float fx, float fy, ViewSetup* __restrict__ setup) {
   const int lin = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lin < B) compute_view_setup(lin, pos, quat, inv_scale, R, W, H, cx, cy, fx, fy, setup);
   const int RR = R * R;
   if (lin >= RR * R) return;
   const int z = lin % R, y = (lin / R) % R;
@@ -627,13 +651,14 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
   float* cells = (float*)((char*)workspace + setup_bytes(B));  // 128-byte aligned
   float* loss_part = (float*)((char*)workspace +
                               ((sdfr_render_forward_workspace_bytes(R, B, W, H) + 127) & ~(size_t)127));
-  hipLaunchKernelGGL(view_setup_kernel, dim3((B + 63) / 64), dim3(64), 0, st, pos, quat, inv_scale,
-                     B, R, W, H, cx, cy, fx, fy, setup);
   const bool packed = use_packed(R, B, sdf_view_stride);
   if (packed) {
-    const int n = R * R * R;
-    hipLaunchKernelGGL(pack_cells_kernel, dim3((n + 255) / 256), dim3(256), 0, st, sdf, R,
-                       (float4*)cells);
+    const int n = std::max(R * R * R, B);
+    hipLaunchKernelGGL(pack_cells_kernel, dim3((n + 255) / 256), dim3(256), 0, st, sdf, R, (float4*)cells,
+                       pos, quat, inv_scale, B, W, H, cx, cy, fx, fy, setup);
+  } else {
+    hipLaunchKernelGGL(view_setup_kernel, dim3((B + 63) / 64), dim3(64), 0, st, pos, quat, inv_scale, B, R,
+                       W, H, cx, cy, fx, fy, setup);
   }
   const TileGeom geom = forward_geom(B, W, H);
   const bool macro = geom.sx == kMacroTile.sx;
@@ -718,12 +743,15 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
   if (!g_sdf) return fail(SDFR_E_NULL, "%s: g_sdf is NULL", fn);
   SDFR_HIP_TRY(hipSetDevice(device));
   hipStream_t st = (hipStream_t)stream;
-  const size_t g_bytes = (size_t)vox * sizeof(float) * (g_sdf_view_stride ? (size_t)(B > 0 ? B : 1) : 1);
-  zero_words_async(g_sdf, g_bytes / sizeof(float), st);
-  if (B == 0) return 0;
+  const size_t g_words = (size_t)vox * (g_sdf_view_stride ? (size_t)(B > 0 ? B : 1) : 1);
+  if (B == 0) {
+    zero_words_async(g_sdf, g_words, st);
+    return 0;
+  }
   if (!g_pos || !g_quat || !g_inv_scale || !pos || !quat || !inv_scale)
     return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
   if (W == 0 || H == 0) {
+    zero_words_async(g_sdf, g_words, st);
     zero_words_async(g_pos, (size_t)B * 3, st);
     zero_words_async(g_quat, (size_t)B * 4, st);
     zero_words_async(g_inv_scale, (size_t)B, st);
@@ -738,8 +766,8 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
     return fail(SDFR_E_INVALID, "workspace must be %zu-byte aligned", alignof(ViewSetup));
   ViewSetup* setup = (ViewSetup*)workspace;
   float* partials = (float*)((char*)workspace + setup_bytes(B));
-  hipLaunchKernelGGL(view_setup_kernel, dim3((B + 63) / 64), dim3(64), 0, st, pos, quat, inv_scale,
-                     B, R, W, H, cx, cy, fx, fy, setup);
+  hipLaunchKernelGGL(backward_prologue_kernel, dim3((unsigned)((std::max(g_words, (size_t)B) + 255) / 256)),
+                     dim3(256), 0, st, g_sdf, g_words, pos, quat, inv_scale, B, R, W, H, cx, cy, fx, fy, setup);
   const TileGeom geom = backward_geom(B, W, H);
   const bool macro = geom.sx == kMacroTile.sx;
   const int ntx = geom.nx(W), nty = geom.ny(H);

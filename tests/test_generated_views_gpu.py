@@ -109,3 +109,18 @@ def test_empty_views_are_flagged_not_returned(mug_decoder):
     it = iter(gen)
     s = next(it)
     assert s["depth"].max() > 0
+
+
+def test_reference_dataset_test_shapes(mug_decoder):
+    """The assertions of the reference's tests/initilization/test_generated_dataset.py:58-74, same config."""
+    from sdfest_amd.generated_views import SDFVAEViewGenerator
+    dec, _ = mug_decoder
+    cfg = {"extent_mean": 0.1, "extent_std": 0, "pointcloud": False, "normalize_pose": True, "z_min": 0.15,
+           "z_max": 1.0}
+    gen = SDFVAEViewGenerator(cfg, dec, batch_size=4, seed=0)
+    sample = next(iter(gen))
+    assert sample["depth"].shape == (480, 640) and "pointset" not in sample
+    gen.cfg["pointcloud"] = True
+    sample = next(iter(gen))
+    assert sample["pointset"].shape[1] == 3 and sample["pointset"].shape[0] == int((sample["depth"] != 0).sum())
+    assert sample["scale"].item() == pytest.approx(0.05)

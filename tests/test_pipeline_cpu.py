@@ -25,6 +25,23 @@ def test_quaternion_helpers_match_reference_goldens():
     assert np.allclose(quaternion_multiply(q, quaternion_invert(q)).numpy(), [0, 0, 0, 1], atol=1e-12)
 
 
+def test_quaternion_known_answers_of_the_reference_suite():
+    """The input/expected pairs of tests/initilization/test_quaternion.py:8-50, exact equality."""
+    t = torch.tensor
+    q = t([0, 0, 0, 1.0])
+    assert torch.all(q == quaternion_invert(q))
+    assert torch.all(quaternion_invert(t([1.0, 0, 0, 0.0])) == t([-1.0, 0, 0, 0]))
+    q = torch.rand(5, 3, 4)
+    assert quaternion_invert(q).shape == q.shape
+    p = t([1.0, 1.0, 0])
+    assert torch.all(quaternion_apply(t([0, 0, 0, 1.0]), p) == p)
+    assert torch.all(quaternion_apply(t([1.0, 0, 0, 0]), p) == t([1.0, -1.0, 0]))          # pi about x
+    assert torch.all(quaternion_apply(t([1.0, 0, 0, 0]), t([[1.0, 1.0, 0], [1.0, 2.0, 0]]))
+                     == t([[1.0, -1.0, 0], [1.0, -2.0, 0]]))                               # batched points
+    assert torch.all(quaternion_apply(t([[1.0, 0, 0, 0], [0, 1.0, 0, 0]]), p)
+                     == t([[1.0, -1.0, 0], [-1.0, 1.0, 0]]))                               # batched quaternions
+
+
 def test_depth_to_pointcloud_matches_oracle_and_convention():
     rng = np.random.default_rng(0)
     depth = rng.uniform(0.5, 2.0, (48, 64)).astype(np.float32)
