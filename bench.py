@@ -160,19 +160,32 @@ def main():
     cam = Camera(W, H, W / 2.0, W / 2.0, W / 2.0, H / 2.0, pixel_center=0.5)
     plan = BatchRenderPlan(64, B, cam, device=device)
 
+    # The one exchange of a step -- the all-reduce of d/dSDF (RCCL) -- is issued asynchronously
+    # and waited for just before the NEXT backward overwrites the buffer: it runs beside the next
+    # step's forward, which does not read it.  Same work per step, nothing skipped; the last
+    # step's exchange is waited for inside the timed region.
+    pending = [None]
+
+    def finish_exchange():
+        if pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
+
     def step(ev=None):
         if ev:
             ev[0].record()
         plan.forward(sdf, pos, quat, isc, thr)
         if ev:
             ev[1].record()
+        finish_exchange()
         plan.backward(g, sdf, pos, quat, isc)
         if ev:
             ev[2].record()
         if use_dist:
-            allreduce_shared_gradients(plan.g_sdf)   # the one exchange of the step (RCCL)
+            pending[0] = allreduce_shared_gradients(plan.g_sdf, async_op=True)
 
     def barrier():
+        finish_exchange()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()

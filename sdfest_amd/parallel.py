@@ -27,20 +27,35 @@ def _dist():
     return dist if dist.is_available() and dist.is_initialized() else None
 
 
+class _Done:
+    """Handle of an exchange that needed no communication."""
+
+    def wait(self):
+        return True
+
+
 def allreduce_shared_gradients(g_sdf: torch.Tensor,
-                               extra: Optional[Sequence[torch.Tensor]] = None, group=None):
+                               extra: Optional[Sequence[torch.Tensor]] = None, group=None,
+                               async_op: bool = False):
     """Sum the shared gradients over ranks, in place.  No-op when not distributed.
 
     g_sdf: this rank's d/dSDF (sum over its own views).  extra: small tensors shared by all
     ranks (e.g. the world-frame pose gradient of a single object seen by many cameras); they
     ride in the same bucket so the step has exactly one collective.
+
+    async_op=True (only without `extra`): returns a handle at once; ``handle.wait()`` makes the
+    current stream wait for the sum.  The exchange then runs beside whatever is launched in
+    between -- e.g. the next step's forward, which does not read g_sdf (the backward, which
+    overwrites it, must come after the wait).
     """
     dist = _dist()
+    if async_op and extra:
+        raise ValueError("async_op is only supported without extra tensors")
     if dist is None:
-        return g_sdf
+        return _Done() if async_op else g_sdf
     if not extra:
-        dist.all_reduce(g_sdf, op=dist.ReduceOp.SUM, group=group)
-        return g_sdf
+        work = dist.all_reduce(g_sdf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        return work if async_op else g_sdf
     flat = torch.cat([g_sdf.reshape(-1)] + [e.reshape(-1) for e in extra])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     n = g_sdf.numel()

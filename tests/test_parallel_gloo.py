@@ -27,6 +27,7 @@ def test_shard_views_partitions_exactly():
 def test_allreduce_is_noop_when_not_distributed():
     g = torch.arange(8.0)
     assert allreduce_shared_gradients(g) is g and torch.equal(g, torch.arange(8.0))
+    assert allreduce_shared_gradients(g, async_op=True).wait() and torch.equal(g, torch.arange(8.0))
 
 
 def _free_port():
@@ -53,7 +54,13 @@ def _worker(rank, world, port, out):
         g2 = torch.tensor(per_view[b:e].sum(0))
         allreduce_shared_gradients(g2)
         ok3 = np.allclose(g2.numpy(), per_view.sum(0), atol=1e-5)
-        out[rank] = int(ok1 and ok2 and ok3)
+        # the asynchronous form bench.py uses to run the exchange beside the next forward
+        g3 = torch.tensor(per_view[b:e].sum(0))
+        handle = allreduce_shared_gradients(g3, async_op=True)
+        other = torch.ones(3) * 2          # unrelated work between issue and wait
+        handle.wait()
+        ok4 = np.allclose(g3.numpy(), per_view.sum(0), atol=1e-5) and float(other.sum()) == 6.0
+        out[rank] = int(ok1 and ok2 and ok3 and ok4)
     finally:
         dist.destroy_process_group()
 
