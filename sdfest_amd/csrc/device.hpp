@@ -313,7 +313,7 @@ struct RunHash {
     }
   }
 };
-using BatchHash = RunHash<2, 512>;    // 64 x 8-pixel tiles of a batch
+using BatchHash = RunHash<2, 512>;    // 64 x 8-pixel tiles of a batch; blocks of 256 points of the sampler
 using SmallHash = RunHash<1, 1024>;   // 32 x 8-pixel tiles of small calls, any resolution
 
 __device__ __forceinline__ float wave_max(float v) {

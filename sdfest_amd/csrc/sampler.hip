@@ -90,7 +90,9 @@ __global__ __launch_bounds__(kPts) void pc_loss_backward_kernel(
     const float* __restrict__ quat, const float* __restrict__ scale, const float* __restrict__ sdf,
     int R, long long sdf_view_stride, float* __restrict__ g_sdf, long long g_sdf_view_stride,
     float* __restrict__ partials, int nblk) {
-  __shared__ SmallHash hash;   // point clouds of any density
+  // 4-voxel runs x 512 slots: back-projected depth images are coherent (measured on 64 rendered
+  // views, 1.13 M points: 122 -> 99 us against 2 x 1024; uniformly random points 80 -> 83 us)
+  __shared__ BatchHash hash;
   __shared__ float wave_part[kPts / 64][8];
   __shared__ int blk_max_bits;
 

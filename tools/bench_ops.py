@@ -43,6 +43,25 @@ def main():
         tb = timeit(lambda: _backward_raw(go, pts, offs, M, pos, quat, sc, sdf))
         out[f"pc_loss V={V} M={M}"] = {"forward_us": round(tf, 1), "backward_us": round(tb, 1),
                                        "Mpoints_per_s_fwd+bwd": round(V * M / (tf + tb), 1)}
+    # ... and on real point sets: the back-projected depth images of 64 rendered views (coherent
+    # points, what the loop feeds it) instead of uniformly random ones
+    from sdfest_amd import Camera as _Cam
+    from sdfest_amd.generated_views import depth_to_pointsets
+    cam_r = _Cam(640, 480, 320.0, 320.0, 320.0, 240.0, pixel_center=0.5)
+    Vr = 64
+    pr, qr, ir = (torch.tensor(a, device=dev) for a in oracle.random_poses(Vr, seed=1))
+    plan_r = BatchRenderPlan(64, Vr, cam_r, device=dev)
+    depth_r = plan_r.forward(sdf, pr, qr, ir, 0.005)
+    pts_r, counts_r = depth_to_pointsets(depth_r, cam_r)
+    offs_r = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), counts_r.cumsum(0)]).to(torch.int32)
+    Mr = int(counts_r.max())
+    sc_r = 1.0 / ir
+    go_r = torch.rand(pts_r.shape[0], device=dev) * 2 - 1
+    tf = timeit(lambda: _forward_raw(pts_r, offs_r, Mr, pr, qr, sc_r, sdf))
+    tb = timeit(lambda: _backward_raw(go_r, pts_r, offs_r, Mr, pr, qr, sc_r, sdf))
+    out[f"pc_loss on {Vr} back-projected views ({pts_r.shape[0]} points)"] = {
+        "forward_us": round(tf, 1), "backward_us": round(tb, 1),
+        "Mpoints_per_s_fwd+bwd": round(pts_r.shape[0] / (tf + tb), 1)}
     # decoder
     g = os.path.join(ROOT, "tests", "golden")
     d = np.load(os.path.join(g, "decoder_mug.npz"))
