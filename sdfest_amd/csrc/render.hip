@@ -5,7 +5,7 @@
 //   forward   sdfest/differentiable_renderer/csrc/sdf_renderer_cuda.cu:241-298
 //   backward  sdfest/differentiable_renderer/csrc/sdf_renderer_cuda.cu:300-468
 // How it computes it is not a translation:
-//   * a set-up kernel turns each pose into a 128-byte record (rotation, object-frame camera
+//   * a set-up kernel turns each pose into a 256-byte record (rotation, object-frame camera
 //     position, grid-space ray origin, conservative screen rectangle of the bounding cube);
 //     the image kernels read it through the scalar cache instead of re-deriving it per pixel;
 //   * a workgroup owns a 64x8-pixel tile (2 sub-tiles of 32x8, a wave = an 8x8 patch; 32x8 for
@@ -23,11 +23,13 @@
 //     one 32-byte partial per macro-tile -> a fixed-order reduction kernel (bitwise
 //     reproducible); the reference issues 8 same-address float atomics per hit pixel
 //     (sdf_renderer_cuda.cu:459-466);
-//   * d/dsdf contributions of a macro-tile are pre-summed in an LDS hash of 8-voxel z-runs and
-//     flushed as 32-byte runs of global float atomics (one per touched voxel per macro-tile).
-#include <type_traits>
-
+//   * d/dsdf contributions of a tile are pre-summed in an LDS hash of short z-runs, in 64-bit
+//     fixed point (device.hpp, RunHash), and flushed as runs of global float atomics (one per
+//     touched voxel per tile);
+//   * the depth term of the render-and-compare loss can ride inside both kernels (LOSS): no loss
+//     kernel, no gradient image.
 #include <algorithm>
+#include <type_traits>
 
 #include "common.hpp"
 #include "device.hpp"
