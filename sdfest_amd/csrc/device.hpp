@@ -235,6 +235,15 @@ __device__ __forceinline__ float wave_sum8(const float (&v)[8], int lane) {
 // every pixel), a big table costs occupancy.  Batches use 4 x 512, small calls 2 x 1024.
 constexpr int kFixedBits = 44;
 
+// float -> 64-bit integer (round to nearest) for |x| < 2^51.  gfx950 has no f32 -> i64 conversion;
+// the compiler's expansion is ~12 VALU instructions and a tile performs 8 per hit pixel (a sixth of
+// the backward's VALU work).  Adding 1.5 * 2^52 in double leaves the integer in the mantissa:
+// convert, add, and one 32-bit subtract on the high word.
+__device__ __forceinline__ long long fixed_from_float(float x) {
+  const double d = (double)x + 6755399441055744.0;
+  return __double_as_longlong(d) - 0x4338000000000000LL;
+}
+
 template <int SHIFT, int SLOTS>
 struct RunHash {
   static constexpr int kShift = SHIFT, kSlots = SLOTS, kLen = 1 << SHIFT;
@@ -266,7 +275,7 @@ struct RunHash {
   __device__ __forceinline__ void add_one(float* __restrict__ gvol, int slot, int lin, float w,
                                           float to_fixed) {
     if (slot >= 0)
-      atomicAdd(&vals[(slot << SHIFT) + (lin & (kLen - 1))], (unsigned long long)(long long)(w * to_fixed));
+      atomicAdd(&vals[(slot << SHIFT) + (lin & (kLen - 1))], (unsigned long long)fixed_from_float(w * to_fixed));
     else
       atomicAdd(gvol + lin, w);
   }
