@@ -348,3 +348,52 @@ def test_c3_full_bench_configuration_parity(R):
                                                dtype=np.float32)
         l1 = np.abs(dimg * g[sl][..., None]).sum(axis=(1, 2), dtype=np.float64)
         assert np.all(np.abs(pose[sl] - ref[sl]) <= REL * l1), b0
+
+
+def test_off_centre_non_square_intrinsics(R):
+    """fx != fy and a principal point far from the image centre (single view and a packed batch):
+    the set-up's screen rectangle and the ray generation must agree with the oracle."""
+    sdf = oracle.blobs_sdf(0)
+    W, H, fx, fy, cx, cy = 200, 136, 150.0, 95.0, 61.5, 103.25
+    for B, seed in ((1, 21), (5, 22)):
+        pos, quat, isc = oracle.random_poses(B, seed=seed, width=W, height=H, f=120.0)
+        pos[:, 0] -= 0.25 * np.abs(pos[:, 2])      # towards the shifted principal point
+        pos[:, 1] -= 0.30 * np.abs(pos[:, 2])
+        cam = (W, H, cx, cy, fx, fy)
+        d = hip_forward(R, sdf, pos, quat, isc, *cam, 0.005)
+        do, _, m = oracle.render_forward(sdf, pos, quat, isc, *cam, 0.005, dtype=np.float32, with_aux=True)
+        assert (do > 0).sum() > 200 * B
+        for b in range(B):
+            check_depth(d[b], do[b], m[b], f"B{B} view{b}")
+        g = np.random.default_rng(seed).uniform(-1, 1, d.shape).astype(np.float32)
+        hb = hip_backward(R, g, d, sdf, pos, quat, isc, *cam)
+        ob = oracle.render_backward(g, d, sdf, pos, quat, isc, *cam[2:], dtype=np.float32)
+        assert rel_err(hb[0], ob[0]) <= REL
+        for b in range(B):
+            dimg = oracle.render_derivative_images(d[b], sdf, pos[b], quat[b], isc[b:b + 1], *cam[2:],
+                                                   dtype=np.float64)[0]
+            l1 = pose_l1(dimg, g[b])
+            pose = np.concatenate([hb[1][b], hb[2][b], hb[3][b:b + 1]])
+            ref = np.concatenate([ob[1][b], ob[2][b], ob[3][b:b + 1]])
+            assert np.all(np.abs(pose - ref) <= REL * l1), (B, b, pose, ref, l1)
+
+
+def test_large_grids_take_the_integer_index_path(R):
+    """R = 129 (just above the packed-record limit) and R = 264 (> 256: the float-formed linear index
+    would no longer be exact, the integer form is used) -- forward and backward against the oracle."""
+    for Rn in (129, 264):
+        sdf = oracle.sphere_sdf(0.55, R=Rn)
+        W, H, f = 96, 72, 80.0
+        B = 5 if Rn == 129 else 1
+        pos, quat, isc = oracle.random_poses(B, seed=Rn, width=W, height=H, f=f)
+        cam = (W, H, W / 2, H / 2, f, f)
+        d = hip_forward(R, sdf, pos, quat, isc, *cam, 0.005)
+        do, _, m = oracle.render_forward(sdf, pos, quat, isc, *cam, 0.005, dtype=np.float32, with_aux=True)
+        assert (do > 0).sum() > 50 * B
+        for b in range(B):
+            check_depth(d[b], do[b], m[b], f"R{Rn} view{b}")
+        g = np.random.default_rng(Rn).uniform(-1, 1, d.shape).astype(np.float32)
+        hb = hip_backward(R, g, d, sdf, pos, quat, isc, *cam)
+        ob = oracle.render_backward(g, d, sdf, pos, quat, isc, *cam[2:], dtype=np.float32)
+        assert rel_err(hb[0], ob[0]) <= REL
+        assert np.abs(hb[0]).max() > 0
