@@ -228,6 +228,23 @@ SDFR_API int sdfr_depth_l1_loss(const float* estimate, const float* target, int 
 SDFR_API int sdfr_pc_l1_loss(const float* values, const int* offsets, int V, int max_view_points,
                     float weight, float* loss, float* grad_values, int device, void* stream);
 
+/* pointset_utils.depth_to_pointcloud (sdfest/initialization/pointset_utils.py:57-77, convention "opengl",
+ * no mask, no normalisation) for V images at once: the non-zero pixels, view-major and row-major,
+ *     x = (col - cx0) * z * rfx,  y = -(row - cy0) * z * rfy,  z = -depth     (pixel-centre-0 intrinsics).
+ * rfx, rfy are the reciprocal focal lengths: torch evaluates `t / scalar` on the GPU as
+ * `t * float(1.0 / scalar)` (reciprocal in double, rounded once), and the caller that holds the double
+ * computes exactly that -- the points are then bit-identical to the reference expression's.
+ * Two calls because the caller sizes the output: sdfr_depth_count writes counts[v] (DEVICE ints) and
+ * the per-block counts into `workspace`; the caller reads the counts, builds the exclusive prefix
+ * `offsets` [V] (DEVICE ints) and allocates points [sum][3]; sdfr_depth_to_points fills them from the
+ * SAME depth and workspace. */
+SDFR_API size_t sdfr_depth_points_workspace_bytes(int V, int W, int H);
+SDFR_API int sdfr_depth_count(const float* depth, int V, int W, int H, int* counts, void* workspace,
+                     size_t workspace_bytes, int device, void* stream);
+SDFR_API int sdfr_depth_to_points(const float* depth, int V, int W, int H, float rfx, float rfy, float cx0,
+                         float cy0, const int* offsets, const void* workspace, float* points,
+                         int device, void* stream);
+
 /* a += b  (sums the renderer's and the sampler's d/dSDF) */
 SDFR_API int sdfr_add_inplace(float* a, const float* b, size_t n, int device, void* stream);
 

@@ -55,6 +55,10 @@ SIGNATURES = {
     "sdfr_depth_l1_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
     "sdfr_depth_l1_loss": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_f, c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),
     "sdfr_pc_l1_loss": (c_int, [c_fp, c_fp, c_int, c_int, c_f, c_fp, c_fp, c_int, c_fp]),
+    "sdfr_depth_points_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
+    "sdfr_depth_count": (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_fp, c_sz, c_int, c_fp]),
+    "sdfr_depth_to_points": (c_int, [c_fp, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_fp, c_fp, c_fp, c_int,
+                                     c_fp]),
     "sdfr_add_inplace": (c_int, [c_fp, c_fp, c_sz, c_int, c_fp]),
     "sdfr_adam_step": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_f, c_f, c_f, c_f, c_int, c_int, c_fp]),
 }

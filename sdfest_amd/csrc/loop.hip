@@ -218,6 +218,87 @@ __global__ void adam_step_kernel(float* __restrict__ params, const float* __rest
   if (i == 0) step[0] = t;
 }
 
+// ---------------------------------------------------------------------------------------------
+// depth image(s) -> packed point set (pointset_utils.depth_to_pointcloud :57-77, convention
+// "opengl", pixel-centre-0 intrinsics): every non-zero pixel, view-major, row-major.
+// Two passes over the images instead of torch.nonzero + gathers: count per block of 1024 pixels,
+// then a stable in-block compaction at the block's offset.
+// ---------------------------------------------------------------------------------------------
+constexpr int kCompactPix = 1024;  // pixels per workgroup: 256 threads x 4 consecutive pixels
+
+// grid (nblk, V): block_count[v][blk] and (atomically) count[v]
+__global__ __launch_bounds__(256) void depth_count_kernel(const float* __restrict__ depth, int npix, int nblk,
+                                                          int* __restrict__ block_count,
+                                                          int* __restrict__ count) {
+  __shared__ int wsum[4];
+  const int v = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+  const float* img = depth + (size_t)v * npix;
+  const int p0 = blk * kCompactPix + tid * 4;
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) c += (p0 + k < npix && img[p0 + k] != 0.0f) ? 1 : 0;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+  if ((tid & 63) == 0) wsum[tid >> 6] = c;
+  __syncthreads();
+  if (tid == 0) {
+    const int t = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    block_count[(size_t)v * nblk + blk] = t;
+    if (t) atomicAdd(&count[v], t);
+  }
+}
+
+// grid (nblk, V): points[offsets[v] + rank of the pixel within its view] = back-projection
+__global__ __launch_bounds__(256) void depth_compact_kernel(const float* __restrict__ depth, int W, int npix,
+                                                            int nblk, const int* __restrict__ block_count,
+                                                            const int* __restrict__ offsets, float rfx,
+                                                            float rfy, float cx0, float cy0,
+                                                            float* __restrict__ points) {
+  __shared__ int wsum[4];
+  __shared__ int base_s;
+  const int v = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int* bc = block_count + (size_t)v * nblk;
+  if (bc[blk] == 0) return;  // workgroup-uniform
+  // pixels of this view in earlier blocks (one wave sums the block counts in a fixed order)
+  if (wave == 0) {
+    int s = 0;
+    for (int i = lane; i < blk; i += 64) s += bc[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) base_s = offsets[v] + s;
+  }
+  const float* img = depth + (size_t)v * npix;
+  const int p0 = blk * kCompactPix + tid * 4;
+  float z[4];
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    z[k] = (p0 + k < npix) ? img[p0 + k] : 0.0f;
+    c += (z[k] != 0.0f) ? 1 : 0;
+  }
+  // exclusive scan of c over the workgroup: within the wave, then across the four waves
+  int incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int before = incl - c;
+  for (int w = 0; w < wave; ++w) before += wsum[w];
+  float* out = points + 3 * (size_t)(base_s + before);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (z[k] == 0.0f) continue;
+    const int p = p0 + k, row = p / W, col = p - row * W;
+    out[0] = ((float)col - cx0) * z[k] * rfx;   // torch divides by a scalar as "* (1 / scalar)" on the GPU
+    out[1] = -((float)row - cy0) * z[k] * rfy;
+    out[2] = -z[k];
+    out += 3;
+  }
+}
+
 }  // namespace
 }  // namespace sdfr
 
@@ -319,6 +400,48 @@ extern "C" int sdfr_adam_step(float* params, const float* grads, float* exp_avg,
   hipLaunchKernelGGL(adam_step_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, params, grads, exp_avg,
                      exp_avg_sq, step, n_params, lr_position, lr_orientation, lr_scale, lr_latent,
                      update_latent);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" size_t sdfr_depth_points_workspace_bytes(int V, int W, int H) {
+  if (V <= 0 || W <= 0 || H <= 0) return 0;
+  const long long nblk = ((long long)W * H + kCompactPix - 1) / kCompactPix;
+  return (size_t)V * (size_t)nblk * sizeof(int);
+}
+
+extern "C" int sdfr_depth_count(const float* depth, int V, int W, int H, int* counts, void* workspace,
+                                size_t workspace_bytes, int device, void* stream) {
+  if (V < 0 || W < 0 || H < 0 || V > 65535 || (long long)W * H > 0x7fffffffLL)
+    return fail(SDFR_E_INVALID, "sdfr_depth_count: bad sizes");
+  if (V == 0) return 0;
+  if (!counts) return fail(SDFR_E_NULL, "sdfr_depth_count: NULL pointer argument");
+  SDFR_HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  zero_words_async(reinterpret_cast<float*>(counts), (size_t)V, st);
+  if (W == 0 || H == 0) return 0;
+  if (!depth || !workspace) return fail(SDFR_E_NULL, "sdfr_depth_count: NULL pointer argument");
+  if (workspace_bytes < sdfr_depth_points_workspace_bytes(V, W, H))
+    return fail(SDFR_E_WORKSPACE, "sdfr_depth_count: workspace too small");
+  const int npix = W * H, nblk = (npix + kCompactPix - 1) / kCompactPix;
+  hipLaunchKernelGGL(depth_count_kernel, dim3(nblk, V), dim3(256), 0, st, depth, npix, nblk, (int*)workspace,
+                     counts);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfr_depth_to_points(const float* depth, int V, int W, int H, float rfx, float rfy, float cx0,
+                                    float cy0, const int* offsets, const void* workspace, float* points,
+                                    int device, void* stream) {
+  if (V < 0 || W < 0 || H < 0 || V > 65535 || (long long)W * H > 0x7fffffffLL)
+    return fail(SDFR_E_INVALID, "sdfr_depth_to_points: bad sizes");
+  if (V == 0 || W == 0 || H == 0) return 0;
+  if (!depth || !offsets || !workspace || !points)
+    return fail(SDFR_E_NULL, "sdfr_depth_to_points: NULL pointer argument");
+  SDFR_HIP_TRY(hipSetDevice(device));
+  const int npix = W * H, nblk = (npix + kCompactPix - 1) / kCompactPix;
+  hipLaunchKernelGGL(depth_compact_kernel, dim3(nblk, V), dim3(256), 0, (hipStream_t)stream, depth, W, npix,
+                     nblk, (const int*)workspace, offsets, rfx, rfy, cx0, cy0, points);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -124,3 +124,26 @@ def test_reference_dataset_test_shapes(mug_decoder):
     sample = next(iter(gen))
     assert sample["pointset"].shape[1] == 3 and sample["pointset"].shape[0] == int((sample["depth"] != 0).sum())
     assert sample["scale"].item() == pytest.approx(0.05)
+
+
+def test_batched_back_projection_kernel_equals_torch_expression():
+    """sdfr_depth_count / sdfr_depth_to_points against pointset_utils.depth_to_pointcloud's expression
+    (torch ops on the same device): same points, same order, bit for bit -- ragged sizes, an empty
+    view, a view that is all points, image sizes that are no multiple of the block."""
+    from sdfest_amd import Camera
+    from sdfest_amd.generated_views import depth_to_pointsets
+    from sdfest_amd.pipeline import depth_to_pointcloud
+    rng = np.random.default_rng(5)
+    for W, H, V in ((640, 480, 5), (37, 29, 4), (1, 1, 2), (1030, 3, 3)):
+        cam = Camera(W, H, 0.9 * W + 3.3, 1.1 * W + 1.7, 0.47 * W, 0.55 * H, pixel_center=0.5)
+        d = rng.uniform(0.3, 2.0, (V, H, W)).astype(np.float32)
+        d[rng.uniform(size=d.shape) < 0.7] = 0
+        d[1] = 0
+        if V > 2:
+            d[2] = np.abs(d[2]) + 0.5
+        depth = torch.tensor(d, device="cuda")
+        pts, counts = depth_to_pointsets(depth, cam)
+        parts = torch.split(pts, counts.tolist())
+        assert counts.tolist() == [(d[v] != 0).sum() for v in range(V)]
+        for v in range(V):
+            assert torch.equal(parts[v], depth_to_pointcloud(depth[v], cam)), (W, H, v)
