@@ -52,6 +52,8 @@ struct sdfr_decoder {
     size_t w_off = 0, tab_off = 0;
   };
   std::vector<ZPlan> fwd_z, bwd_z;
+  // direct (VALU) convolution for batches, conv3d_direct_kernel: weights [ci][a][b][c][co], 0 = none
+  std::vector<size_t> fwd_direct_off, bwd_direct_off;
   size_t max_bwd = 0;                      // floats of the largest gradient tensor (incl. padding)
   // tape: post-ReLU outputs kept by a forward that will be differentiated
   size_t tape_fc_off = 0;                  // per-sample float offsets
@@ -353,6 +355,133 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
 }
 
 
+// Batched 3x3x3 convolution on the vector ALUs.  For the decoder's narrow layers (4 .. 16 output
+// channels) the matrix cores are the wrong tool: a 16-column MFMA tile is mostly padding, and both
+// MFMA forms above are bound by how they fetch their operands (560 us gather-bound, 772 us LDS-staged
+// for the 8 -> 4 layer at 256 samples; its 6 GMAC are 76 us of packed-fp32 FMA).  Here:
+//   * a workgroup owns TX x TY output columns (all of z) and stages the input patch of CK channels
+//     at a time in LDS (coalesced runs, as many workgroups per CU as fit: loads of one overlap the
+//     FMAs of another);
+//   * a thread owns one column and ZR = 4 consecutive z: 4 x COUT accumulators in registers;
+//   * per (ci, a, b) it reads its 6-float z-run once (ds_read_b128 + b64) and issues 3 x 4 x COUT FMAs
+//     whose weight operands are wave-uniform -> scalar registers (no operand traffic at all).
+// wd: [Cin][3][3][3][COUT].   grid: (tiles_x * tiles_y, 1, N), block 256 = TX*TY columns x ZC chunks
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3d_direct_kernel(
+    const float* __restrict__ in, const float* __restrict__ wd, const float* __restrict__ bias,
+    float* __restrict__ out, int Cin, int n, int m, int relu, int TX, int TY, int CK) {
+  constexpr int K = 3, ZR = 4;
+  constexpr int kUnrollB = COUT >= 8 ? 1 : K;  // keep a step's weights within the scalar registers
+  extern __shared__ float tile[];  // [CK][IX][IY][n]
+  const int tid = threadIdx.x;
+  const int IX = TX + K - 1, IY = TY + K - 1, ZC = 256 / (TX * TY);
+  const int tiles_y = (m + TY - 1) / TY;
+  const int tx0 = (blockIdx.x / tiles_y) * TX, ty0 = (blockIdx.x % tiles_y) * TY;
+  const int nb = blockIdx.z;
+  const size_t nv = (size_t)n * n * n, mv = (size_t)m * m * m;
+  const float* src = in + (size_t)nb * Cin * nv;
+  const int col = tid / ZC, zc = tid - col * ZC;
+  const int lx = col / TY, ly = col - lx * TY, z0 = zc * ZR;
+  float acc[ZR][COUT];
+#pragma unroll
+  for (int z = 0; z < ZR; ++z)
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[z][co] = 0.0f;
+  const int run = IY * n, y_valid = (n - ty0) * n;
+  // 16-byte loads when every run starts and ends on a 16-byte boundary (n % 4 == 0; TY is even)
+  const bool vec4 = (n & 3) == 0 && ((uintptr_t)in & 15) == 0;
+  // 16-byte path: the patch of chunk i+1 is fetched into registers while chunk i is being
+  // convolved (<= 6 loads per thread: a chunk is <= 24 KB), so a workgroup waits for memory once
+  const int run4 = run >> 2;
+  f32x4 pre[6];
+  auto prefetch = [&](int c0) {
+    const int e4 = min(CK, Cin - c0) * IX * run4;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int e = min(tid + 256 * j, e4 - 1);
+      const int slab = e / run4, off = (e - slab * run4) << 2;
+      const int ci = slab / IX, x = tx0 + slab - ci * IX;
+      const float* row = src + (size_t)(c0 + ci) * nv + ((size_t)min(x, n - 1) * n + ty0) * n;
+      pre[j] = (x < n && off < y_valid) ? *reinterpret_cast<const f32x4*>(row + off)
+                                         : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+  };
+  if (vec4) prefetch(0);
+  for (int c0 = 0; c0 < Cin; c0 += CK) {
+    const int ck = min(CK, Cin - c0), n_slab = ck * IX;
+    __syncthreads();  // the previous chunk has been consumed
+    if (vec4) {
+      const int e4 = n_slab * run4;
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        if (tid + 256 * j < e4) reinterpret_cast<f32x4*>(tile)[tid + 256 * j] = pre[j];
+    } else {
+      for (int off = tid; off < run; off += 256) {
+        for (int s0 = 0; s0 < n_slab; s0 += 8) {
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int slab = min(s0 + u, n_slab - 1), ci = slab / IX, x = tx0 + slab - ci * IX;
+            const float* row = src + (size_t)(c0 + ci) * nv + ((size_t)min(x, n - 1) * n + ty0) * n;
+            v[u] = (x < n && off < y_valid) ? row[off] : 0.0f;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (s0 + u < n_slab) tile[(s0 + u) * run + off] = v[u];
+        }
+      }
+    }
+    __syncthreads();
+    if (vec4 && c0 + CK < Cin) prefetch(c0 + CK);
+    if (z0 < m) {
+      for (int ci = 0; ci < ck; ++ci) {
+        // (a is not unrolled: the 27 * COUT weights of a channel do not fit the scalar registers,
+        // and spilled scalars come back through v_readlane)
+#pragma unroll 1
+        for (int a = 0; a < K; ++a)
+#pragma unroll kUnrollB
+          for (int b = 0; b < K; ++b) {
+            const float* p = tile + ((ci * IX + lx + a) * IY + ly + b) * n + z0;
+            // the 6-float z-run as one 16-byte and one 8-byte LDS read (the runs of a wave then cover
+            // all banks evenly; six 4-byte reads hit 8 banks 8 ways each: 3.7x slower, measured).  Values
+            // past the end of a row belong to outputs z >= m, which are never stored.
+            float v[ZR + K - 1];
+            if (vec4) {
+              const f32x4 q = *reinterpret_cast<const f32x4*>(p);
+              const float2 r = *reinterpret_cast<const float2*>(p + 4);
+              v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3]; v[4] = r.x; v[5] = r.y;
+            } else {
+#pragma unroll
+              for (int t = 0; t < ZR + K - 1; ++t) v[t] = (z0 + t < n) ? p[t] : 0.0f;
+            }
+            const float* w = wd + ((((size_t)(c0 + ci) * K + a) * K + b) * K) * COUT;  // wave-uniform
+#pragma unroll
+            for (int c = 0; c < K; ++c)
+#pragma unroll
+              for (int z = 0; z < ZR; ++z)
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[z][co] = fmaf(v[z + c], w[c * COUT + co], acc[z][co]);
+          }
+      }
+    }
+  }
+  const int x = tx0 + lx, y = ty0 + ly;
+  if (x < m && y < m && z0 < m) {
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+      float* dst = out + ((size_t)nb * COUT + co) * mv + ((size_t)x * m + y) * m + z0;
+      const float bv = bias[co];
+#pragma unroll
+      for (int z = 0; z < ZR; ++z)
+        if (z0 + z < m) {
+          float r = acc[z][co] + bv;
+          if (relu) r = fmaxf(r, 0.0f);
+          dst[z] = r;
+        }
+    }
+  }
+}
+
 // ---- backward (VJP to the latent; weights are constants) -------------------------------------
 
 // out[N][C][np^3] = zero-padded (by `pad` on every side) copy of g[N][C][m^3], multiplied by the
@@ -496,6 +625,34 @@ __global__ __launch_bounds__(kFcBlock) void fc_stack_backward_kernel(const float
 }  // namespace sdfr
 
 using namespace sdfr;
+
+namespace {
+// The direct convolution is for batches (enough tiles to fill the chip); returns false when the
+// layer / batch does not qualify and the caller falls back to the MFMA kernel.
+bool launch_direct(const sdfr_decoder* d, size_t w_off, const float* src, const float* bias, float* dst,
+                   int cin, int cout, int n, int m, int relu, int N, hipStream_t st) {
+  if (w_off == 0 || n > 64 || m < 4) return false;
+  const int ZC = (m + 3) / 4;                       // z chunks of 4 outputs per column
+  int zc_pow = 1;
+  while (zc_pow < ZC) zc_pow <<= 1;                 // threads per column (power of two <= 16)
+  if (zc_pow > 16) return false;
+  const int cols = 256 / zc_pow;                    // columns per workgroup
+  int TX = 1, TY = cols;
+  while (TY > 2 * TX) { TX <<= 1; TY >>= 1; }       // as square as powers of two allow
+  const int tiles = ((m + TX - 1) / TX) * ((m + TY - 1) / TY);
+  if ((long long)tiles * N < 512) return false;
+  // channels per LDS chunk: patch of CK channels <= 24 KB
+  const int per_ch = (TX + 2) * (TY + 2) * n;
+  int CK = std::max(1, std::min(cin, (24 * 1024 / 4) / per_ch));
+  const size_t lds = ((size_t)CK * per_ch + 8) * sizeof(float);  // + the over-read of the last z-run
+  const dim3 grid(tiles, 1, N);
+  const float* w = d->d_params + w_off;
+#define SDFR_DIRECT(CO) hipLaunchKernelGGL((conv3d_direct_kernel<CO>), grid, dim3(256), lds, st, src, w, bias, dst, cin, n, m, relu, TX, TY, CK)
+  if (cout == 4) SDFR_DIRECT(4); else if (cout == 8) SDFR_DIRECT(8); else SDFR_DIRECT(16);
+#undef SDFR_DIRECT
+  return true;
+}
+}  // namespace
 
 extern "C" int sdfr_decoder_create(const float* h_params, size_t n_params, int latent, int n_fc,
                                    const int* fc_out, int n_conv, const int* conv_in_size,
@@ -730,6 +887,24 @@ extern "C" int sdfr_decoder_create(const float* h_params, size_t n_params, int l
       d->bwd_z.push_back(plan_z(co_n, ci_n, k, m + 2 * (k - 1), [&](int co, int ci, int a, int b, int c) {
         return W[((size_t)ci * ci_n + co) * k3 + ((k - 1 - a) * k + (k - 1 - b)) * k + (k - 1 - c)];
       }));
+      // direct-convolution weights [ci][a][b][c][co] (k = 3, 4 / 8 / 16 output channels)
+      auto direct = [&](int cin, int cout, auto wfun) -> size_t {
+        if (k != 3 || !(cout == 4 || cout == 8 || cout == 16)) return 0;
+        align();
+        const size_t off = img.size();
+        for (int ci = 0; ci < cin; ++ci)
+          for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b)
+              for (int c = 0; c < 3; ++c)
+                for (int co = 0; co < cout; ++co) img.push_back(wfun(co, ci, a, b, c));
+        return off;
+      };
+      d->fwd_direct_off.push_back(direct(ci_n, co_n, [&](int co, int ci, int a, int b, int c) {
+        return W[((size_t)co * ci_n + ci) * k3 + (a * k + b) * k + c];
+      }));
+      d->bwd_direct_off.push_back(direct(co_n, ci_n, [&](int co, int ci, int a, int b, int c) {
+        return W[((size_t)ci * ci_n + co) * k3 + ((k - 1 - a) * k + (k - 1 - b)) * k + (k - 1 - c)];
+      }));
       q += (size_t)co_n * ci_n * k3 + co_n;
     }
   }
@@ -856,6 +1031,8 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
 #define SDFR_CONV1(CO) hipLaunchKernelGGL((conv1x1_kernel<CO>), g1, dim3(256), 0, st, act_in, wm, bs, c, voxn, conv_relu, conv_dst)
       if (co_n == 1) SDFR_CONV1(1); else if (co_n == 2) SDFR_CONV1(2); else if (co_n == 3) SDFR_CONV1(3); else SDFR_CONV1(4);
 #undef SDFR_CONV1
+    } else if (!swap && launch_direct(d, d->fwd_direct_off[l], act_in, bs, conv_dst, c, co_n, n, m, conv_relu, N, st)) {
+      // (batched: direct VALU convolution)
     } else {
       const sdfr_decoder::ZPlan& zp = d->fwd_z[l];
       // (a single decode is latency-bound: there the finer grid of the ungrouped form wins)
@@ -961,7 +1138,10 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
     if (swap) resize_backward(co_n, prev, nin);
     // 2. data gradient = valid conv (kernel k) of the padded tensor with the flipped weights
     const int kpad = d->bwd_kpad[l];
-    {
+    if (!swap && launch_direct(d, d->bwd_direct_off[l], g, d->d_params + d->zero_bias_off, buf[cur], co_n, ci_n, np,
+                               nconv, 0, N, st)) {
+      // (batched: direct VALU convolution)
+    } else {
       const sdfr_decoder::ZPlan& zp = d->bwd_z[l];
       const bool zgrp = zp.zg > 1 && !swap && (long long)nconv * nconv * (nconv / zp.zg) * N >= kZGroupMinRows;
       const int kp = zgrp ? zp.kpad : kpad, rows = nconv * nconv * (nconv / (zgrp ? zp.zg : 1));
