@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import oracle
-from helpers import GOLDEN
+from helpers import GOLDEN, decoder_probe_G
 
 pytestmark = pytest.mark.gpu
 
@@ -193,3 +193,33 @@ def test_decoder_latent_gradient_other_architecture_vs_torch():
     assert np.max(np.abs(out.detach().cpu().numpy() - ref.detach().numpy())) <= 1e-4 * ref.abs().max().item()
     g, gr = z.grad.cpu().numpy(), zt.grad.numpy()
     assert np.max(np.abs(g - gr)) <= 2e-4 * np.abs(gr).max(), (g, gr)
+
+
+def test_batched_decoder_kernels_equal_single_decodes(mug):
+    """A batch large enough for every batched kernel (direct convolutions, tiled resizes, z-grouped
+    MFMA) against one-at-a-time decodes, which take the latency-oriented kernels: forward and VJP."""
+    from sdfest_amd import SDFDecoder
+    d, wts = mug
+    dec = SDFDecoder.from_config(mug_config(d), wts)
+    N = 130
+    rng = np.random.default_rng(11)
+    z_np = np.concatenate([d["z"], rng.normal(size=(N - len(d["z"]), 8)).astype(np.float32)])
+    G = torch.tensor(decoder_probe_G(), device="cuda")
+    w = torch.tensor(rng.uniform(0.5, 1.5, N).astype(np.float32), device="cuda")
+    z = torch.tensor(z_np, device="cuda", requires_grad=True)
+    out = dec.decode(z)
+    (out[:, 0] * G * w[:, None, None, None]).sum().backward()
+    ref0 = d["z0_full"]
+    picks = [0, 1, 7, 64, 129]
+    for i in picks:
+        zi = torch.tensor(z_np[i:i + 1], device="cuda", requires_grad=True)
+        oi = dec.decode(zi)
+        (oi[:, 0] * G * w[i]).sum().backward()
+        a, b = out[i].detach(), oi[0].detach()
+        assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-3), i
+        ga, gb = z.grad[i], zi.grad[0]
+        assert (ga - gb).abs().max().item() <= 2e-4 * gb.abs().max().item(), (i, ga, gb)
+    # and the golden output of the reference decoder for the first latent (z = 0 is d["z"][0]?)
+    with torch.no_grad():
+        o = dec.decode(torch.zeros(N, 8, device="cuda"))
+    assert np.max(np.abs(o[N - 1, 0].cpu().numpy() - ref0)) <= 1e-4 * np.max(np.abs(ref0))
