@@ -65,6 +65,20 @@ def test_decoder_matches_oracle_on_other_architectures():
              fc=[{"out": 2 * 5 ** 3}],
              conv=[dict(in_size=5, in_channels=2, out_channels=5, kernel_size=3, relu=True),
                    dict(in_size=10, in_channels=5, out_channels=1, kernel_size=3, relu=False)]),
+        # batches: the direct convolution with 8 and 4 output channels on odd sizes (its scalar path, z runs
+        # that end inside a 4-chunk) ...
+        dict(volume=11, latent=3, tsdf=False, batch=150,
+             fc=[{"out": 16 * 4 ** 3}],
+             conv=[dict(in_size=4, in_channels=16, out_channels=16, kernel_size=3, relu=True),
+                   dict(in_size=11, in_channels=16, out_channels=8, kernel_size=3, relu=True),
+                   dict(in_size=13, in_channels=8, out_channels=4, kernel_size=3, relu=True),
+                   dict(in_size=11, in_channels=4, out_channels=1, kernel_size=1, relu=False)]),
+        # ... and on sizes that are multiples of 4 (its 16-byte path), with a final resize
+        dict(volume=12, latent=3, tsdf=False, batch=160,
+             fc=[{"out": 4 * 8 ** 3}],
+             conv=[dict(in_size=8, in_channels=4, out_channels=8, kernel_size=3, relu=True),
+                   dict(in_size=12, in_channels=8, out_channels=4, kernel_size=3, relu=True),
+                   dict(in_size=10, in_channels=4, out_channels=1, kernel_size=1, relu=False)]),
     ]
     for case in cases:
         state = {}
@@ -82,7 +96,7 @@ def test_decoder_matches_oracle_on_other_architectures():
         cfg = {"latent_size": case["latent"], "tsdf": case["tsdf"], "sdf_size": case["volume"],
                "decoder": {"fc_layers": case["fc"], "conv_layers": case["conv"]}}
         dec = SDFDecoder.from_config(cfg, state, sdf_size=case["volume"])
-        z = rng.normal(size=(3, case["latent"])).astype(np.float32)
+        z = rng.normal(size=(case.get("batch", 3), case["latent"])).astype(np.float32)
         params = oracle.pack_decoder_params(state, len(case["fc"]), len(case["conv"]))
         for enforce in (False, True):
             ref = oracle.decoder_forward(params, cfg, z, dtype=np.float32, enforce_tsdf=enforce)
