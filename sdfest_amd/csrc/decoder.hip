@@ -15,6 +15,9 @@
 //     bias and ReLU are applied to the accumulator;
 //   * the resize is its own element-wise kernel with ATen's align_corners=False index arithmetic
 //     (the output of a layer is at most 4 MiB and stays in L2 / Infinity Cache between launches).
+//   * batches take different kernels where the single-decode ones are bound by their operand
+//     fetch: conv3d_direct_kernel (packed-fp32 FMAs, LDS input patch, scalar-register weights) for
+//     3x3x3 layers with 4 / 8 / 16 output channels, resize3_tiled_kernel for up-sampling;
 //   * 1x1 layers: a 1x1x1 convolution commutes with the trilinear resize in front of it (both are
 //     linear, one across channels, one across space; the interpolation weights sum to 1, so the
 //     bias passes through).  When Cout <= Cin such a layer runs conv -> resize instead of
