@@ -42,6 +42,9 @@ def depth_to_pointcloud(depth_image: torch.Tensor, camera: Camera) -> torch.Tens
 
     Reference: pointset_utils.depth_to_pointcloud (:57-77, convention "opengl", no mask, no
     normalisation) -- note the pixel-centre-0 intrinsics."""
+    if depth_image.is_cuda and depth_image.dtype == torch.float32:
+        from .generated_views import depth_to_pointsets   # sdfr_depth_count / sdfr_depth_to_points
+        return depth_to_pointsets(depth_image[None], camera)[0]
     fx, fy, cx, cy, _ = camera.get_pinhole_camera_parameters(0.0)
     rows, cols = torch.nonzero(depth_image, as_tuple=True)
     z = depth_image[rows, cols]

@@ -15,6 +15,15 @@ CFG = {"width": 320, "height": 240, "fov_deg": 90, "z_min": 0.3, "z_max": 0.7, "
        "extent_std": 0.02, "render_threshold": 0.004, "pointcloud": True}
 
 
+def torch_points(depth, cam):
+    """pointset_utils.depth_to_pointcloud (:57-77, "opengl") in torch ops on the tensor's device -- the
+    reference expression the batched kernel must reproduce bit for bit."""
+    fx, fy, cx, cy, _ = cam.get_pinhole_camera_parameters(0.0)
+    rows, cols = torch.nonzero(depth, as_tuple=True)
+    z = depth[rows, cols]
+    return torch.stack(((cols.float() - cx) * z / fx, -(rows.float() - cy) * z / fy, -z), dim=1)
+
+
 @pytest.fixture(scope="module")
 def mug_decoder():
     from sdfest_amd import SDFDecoder
@@ -40,6 +49,7 @@ def test_batch_equals_per_sample_pipeline(mug_decoder):
             depth = render_depth_gpu(sdf, out["position"][b], out["quaternion"][b], 1.0 / out["scale"][b],
                                      threshold=CFG["render_threshold"], camera=gen.camera)
         assert torch.equal(depth, out["depth"][b])
+        assert torch.equal(torch_points(depth, gen.camera), out["pointset"][b])
         assert torch.equal(depth_to_pointcloud(depth, gen.camera), out["pointset"][b])
     # the first view also against the CPU oracle (fp32 march on the decoded grid)
     with torch.no_grad():
@@ -146,4 +156,5 @@ def test_batched_back_projection_kernel_equals_torch_expression():
         parts = torch.split(pts, counts.tolist())
         assert counts.tolist() == [(d[v] != 0).sum() for v in range(V)]
         for v in range(V):
-            assert torch.equal(parts[v], depth_to_pointcloud(depth[v], cam)), (W, H, v)
+            assert torch.equal(parts[v], torch_points(depth[v], cam)), (W, H, v)
+            assert torch.equal(parts[v], depth_to_pointcloud(depth[v], cam))
