@@ -546,26 +546,22 @@ __global__ __launch_bounds__(256) void resize_axis_backward_kernel(const float* 
   g_in[idx] = acc;
 }
 
-// out[i] = g[i] where the forward activation was positive, else 0 (ReLU'), out of place
-__global__ void relu_mask_copy_kernel(const float* __restrict__ g, const float* __restrict__ act,
-                                      float* __restrict__ out, size_t count) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < count) out[i] = (act[i] > 0.0f) ? g[i] : 0.0f;
-}
-
 // Backward of the last (wide) Linear layer: t[n][i] = sum_o Wt[i][o] * g_last[n][o], one workgroup
 // per (i, sample) -- a 50 x 8192 GEMV spread over 50 workgroups instead of one.
+// `act`: the layer's forward output; its ReLU' is applied to g_last on the fly (no mask launch).
 __global__ __launch_bounds__(kFcBlock) void fc_last_backward_kernel(const float* __restrict__ params,
                                                                     FcDesc d,
                                                                     const float* __restrict__ g_last,
+                                                                    const float* __restrict__ act,
                                                                     float* __restrict__ t_out) {
   __shared__ float red[kFcBlock / 64];
   const int i = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
   const int l = d.n_fc - 1, win = d.width[l], wout = d.width[l + 1];
   const float* wt = params + d.w_off[l] + (size_t)i * wout;
   const float* g = g_last + (size_t)n * wout;
+  const float* a = act + (size_t)n * wout;
   float part = 0.0f;
-  for (int o = tid; o < wout; o += kFcBlock) part = fmaf(wt[o], g[o], part);
+  for (int o = tid; o < wout; o += kFcBlock) part = fmaf(wt[o], (a[o] > 0.0f) ? g[o] : 0.0f, part);
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
   if ((tid & 63) == 0) red[tid >> 6] = part;
@@ -1166,10 +1162,6 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
     }
   }
   // g is now the gradient w.r.t. the (ReLU'd) output of the Linear stack
-  const int last = d->fc_out[d->n_fc - 1];
-  float* gl = buf[cur];
-  hipLaunchKernelGGL(relu_mask_copy_kernel, dim3((unsigned)(((size_t)N * last + 255) / 256)), dim3(256), 0, st,
-                     g, tape + (size_t)N * d->tape_fc_off, gl, (size_t)N * last);
   FcDesc fd;
   fd.n_fc = d->n_fc;
   fd.width[0] = d->latent;
@@ -1180,7 +1172,7 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
   }
   float* t_mid = buf[cur ^ 1];
   hipLaunchKernelGGL(fc_last_backward_kernel, dim3(fd.width[d->n_fc - 1], N), dim3(kFcBlock), 0, st,
-                     d->d_params, fd, gl, t_mid);
+                     d->d_params, fd, g, tape + (size_t)N * d->tape_fc_off, t_mid);
   hipLaunchKernelGGL(fc_stack_backward_kernel, dim3(N), dim3(kFcBlock), 0, st, d->d_params, fd, z, t_mid, g_z);
   SDFR_HIP_TRY(hipGetLastError());
   (void)n;
