@@ -161,6 +161,19 @@ SDFR_API int sdfr_pc_loss_backward(const float* grad_out, const float* points, c
                           float* g_scale, void* workspace, size_t workspace_bytes, int device,
                           void* stream);
 
+/* sdfr_pc_loss_backward for the loss the loop really uses (simple_setup.py:137-144),
+ *     loss[v] = mean |pc_loss values of view v|,   objective = weight * sum_v loss[v]:
+ * the upstream gradient +-weight / M_v is formed from the sign of each point's value inside the
+ * kernel and loss[v] (NaN for a view without points, as torch.mean of nothing) is a by-product, so
+ * neither sdfr_pc_loss_forward nor sdfr_pc_l1_loss has to run.  Gradients are identical to
+ * forward -> sdfr_pc_l1_loss -> sdfr_pc_loss_backward.  Workspace: sdfr_pc_loss_backward_workspace_bytes. */
+SDFR_API int sdfr_pc_l1_backward(float weight, float* loss, const float* points, const int* offsets, int B,
+                        int max_view_points, const float* pos, const float* quat, const float* scale,
+                        const float* sdf, int R, long long sdf_view_stride, float* g_sdf,
+                        long long g_sdf_view_stride, float* g_pos, float* g_quat, float* g_scale,
+                        void* workspace, size_t workspace_bytes, int device, void* stream);
+
+
 /* ---- VAE decoder forward ------------------------------------------------------------------ */
 
 /* Replaces SDFDecoder.forward / SDFVAE.decode (sdfest/vae/sdf_vae.py:217-259, :79-87).

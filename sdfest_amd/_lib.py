@@ -41,6 +41,8 @@ SIGNATURES = {
     "sdfr_pc_loss_backward_workspace_bytes": (c_sz, [c_int, c_int]),
     "sdfr_pc_loss_backward": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_int,
                                       c_ll, c_fp, c_ll, c_fp, c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),
+    "sdfr_pc_l1_backward": (c_int, [c_f, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_ll,
+                                    c_fp, c_ll, c_fp, c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),
     "sdfr_decoder_create": (c_int, [c_fp, c_sz, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_fp,
                                     c_fp, c_int, c_f, c_int, c_fp]),
     "sdfr_decoder_destroy": (None, [c_fp]),

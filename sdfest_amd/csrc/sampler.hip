@@ -83,13 +83,17 @@ __global__ __launch_bounds__(kPts) void pc_loss_forward_kernel(
   out[i] = inside ? trilerp(c) * f.scale : 0.0f;
 }
 
-template <int RT>
+// L1: the upstream gradient is not read but formed here, for the loss  weight * mean |value|  over
+// the view's points (simple_setup.py:144): go = +-weight / M_v by the sign of the point's value, and
+// the block's sum of |value| goes to `loss_part` -- the loop then needs neither the sampler's
+// forward launch nor the loss launch.
+template <int RT, bool L1>
 __global__ __launch_bounds__(kPts) void pc_loss_backward_kernel(
     const float* __restrict__ grad_out, const float* __restrict__ points,
     const int* __restrict__ offsets, int n_single, const float* __restrict__ pos,
     const float* __restrict__ quat, const float* __restrict__ scale, const float* __restrict__ sdf,
     int R, long long sdf_view_stride, float* __restrict__ g_sdf, long long g_sdf_view_stride,
-    float* __restrict__ partials, int nblk) {
+    float* __restrict__ partials, int nblk, float l1_weight, float* __restrict__ loss_part) {
   // 4-voxel runs x 512 slots: back-projected depth images are coherent (measured on 64 rendered
   // views, 1.13 M points: 122 -> 99 us against 2 x 1024; uniformly random points 80 -> 83 us)
   __shared__ BatchHash hash;
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(kPts) void pc_loss_backward_kernel(
   if (tid == 0) blk_max_bits = 0;
 
   bool live = false;
-  float go = 0.0f;
+  float go = 0.0f, l1_abs = 0.0f;
   V3 vrel = mk(0, 0, 0), o = mk(0, 0, 0);
   Cell c;
   c.lin = 0; c.ox = c.oy = c.oz = 0.0f;
@@ -120,7 +124,14 @@ __global__ __launch_bounds__(kPts) void pc_loss_backward_kernel(
   if (i < end) {
     const V3 P = mk(points[3 * (size_t)i], points[3 * (size_t)i + 1], points[3 * (size_t)i + 2]);
     live = sample_cell<RT>(f, vol, R, P, vrel, o, c);
-    go = live ? grad_out[i] : 0.0f;
+    if (L1) {
+      const float val = live ? trilerp(c) * f.scale : 0.0f;  // losses.py:133-135: masked values are 0
+      const float k = l1_weight / (float)(end - begin);       // as pc_l1_kernel (loop.hip)
+      go = val > 0.0f ? k : (val < 0.0f ? -k : 0.0f);
+      l1_abs = fabsf(val);
+    } else {
+      go = live ? grad_out[i] : 0.0f;
+    }
   }
   __syncthreads();
   const float gmax = wave_max(fabsf(go));
@@ -183,12 +194,23 @@ __global__ __launch_bounds__(kPts) void pc_loss_backward_kernel(
     const float sk = wave_sum8(acc, lane);
     if ((lane & 7) == 0) wave_part[wave][lane >> 3] = sk;
   }
+  __shared__ float wave_abs[kPts / 64];
+  if (L1) {
+    const float sa = wave_sum(l1_abs);
+    if (lane == 0) wave_abs[wave] = sa;
+  }
   __syncthreads();
   if (tid < 8) {
     float t = 0.0f;
 #pragma unroll
     for (int wv = 0; wv < kPts / 64; ++wv) t += wave_part[wv][tid];
     partials[((size_t)v * nblk + blockIdx.x) * 8 + tid] = t;
+  }
+  if (L1 && tid == 0) {
+    float t = 0.0f;
+#pragma unroll
+    for (int wv = 0; wv < kPts / 64; ++wv) t += wave_abs[wv];
+    loss_part[(size_t)v * nblk + blockIdx.x] = t;
   }
   const float bound = 2.0f * __int_as_float(blk_max_bits) * fabsf(f.scale);
   int e2;
@@ -201,10 +223,16 @@ __global__ __launch_bounds__(kPts) void pc_loss_backward_kernel(
 __global__ __launch_bounds__(64) void pc_loss_reduce_kernel(
     const float* __restrict__ partials, const int* __restrict__ offsets, int n_single, int nblk,
     const float* __restrict__ quat, float* __restrict__ g_pos, float* __restrict__ g_quat,
-    float* __restrict__ g_scale) {
+    float* __restrict__ g_scale, const float* __restrict__ loss_part, float* __restrict__ loss) {
   const int v = blockIdx.x, lane = threadIdx.x;
   const int len = offsets ? offsets[v + 1] - offsets[v] : n_single;
   const int nb = (len + kPts - 1) / kPts;
+  if (loss_part) {  // loss[v] = mean |value| (NaN for an empty view, as torch.mean of nothing)
+    float sa = 0.0f;
+    for (int i = lane; i < nb; i += 64) sa += loss_part[(size_t)v * nblk + i];
+    sa = wave_sum(sa);
+    if (lane == 0) loss[v] = sa / (float)len;
+  }
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = lane; i < nb; i += 64) {
     const float4* p = reinterpret_cast<const float4*>(partials + ((size_t)v * nblk + i) * 8);
@@ -263,8 +291,64 @@ extern "C" int sdfr_pc_loss_forward(const float* points, const int* offsets, int
 
 extern "C" size_t sdfr_pc_loss_backward_workspace_bytes(int B, int max_view_points) {
   if (B <= 0 || max_view_points <= 0) return 0;
-  return (size_t)B * ((max_view_points + kPts - 1) / kPts) * 8 * sizeof(float);
+  return (size_t)B * ((max_view_points + kPts - 1) / kPts) * 9 * sizeof(float);  // 8 pose sums + |value| sum
 }
+
+namespace {
+// loss == nullptr: grad_out is the upstream gradient.  Otherwise the L1 form (grad_out unused).
+int pc_backward_impl(const char* fn, const float* grad_out, float l1_weight, float* loss,
+                     const float* points, const int* offsets, int B, int max_view_points,
+                     const float* pos, const float* quat, const float* scale, const float* sdf, int R,
+                     long long sdf_view_stride, float* g_sdf, long long g_sdf_view_stride, float* g_pos,
+                     float* g_quat, float* g_scale, void* workspace, size_t workspace_bytes, int device,
+                     void* stream) {
+  const bool l1 = loss != nullptr;
+  if (int rc = check_pc(R, B, max_view_points)) return rc;
+  const long long vox = (long long)R * R * R;
+  if (!offsets && B > 1) return fail(SDFR_E_NULL, "offsets may be NULL only for a single view");
+  if (sdf_view_stride != 0 && sdf_view_stride < vox)
+    return fail(SDFR_E_INVALID, "sdf_view_stride must be 0 or >= R^3");
+  if (g_sdf_view_stride != 0 && g_sdf_view_stride != vox)
+    return fail(SDFR_E_INVALID, "g_sdf_view_stride must be 0 or R^3");
+  if (!g_sdf) return fail(SDFR_E_NULL, "%s: g_sdf is NULL", fn);
+  SDFR_HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  const size_t g_bytes = (size_t)vox * sizeof(float) * (g_sdf_view_stride ? (size_t)(B > 0 ? B : 1) : 1);
+  zero_words_async(g_sdf, g_bytes / sizeof(float), st);
+  if (B == 0) return 0;
+  if (!g_pos || !g_quat || !g_scale || !pos || !quat || !scale)
+    return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
+  if (max_view_points == 0) {
+    zero_words_async(g_pos, (size_t)B * 3, st);
+    zero_words_async(g_quat, (size_t)B * 4, st);
+    zero_words_async(g_scale, (size_t)B, st);
+    if (l1) zero_words_async(loss, (size_t)B, st);
+    return 0;
+  }
+  if ((!l1 && !grad_out) || !points || !sdf || !workspace)
+    return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
+  if (workspace_bytes < sdfr_pc_loss_backward_workspace_bytes(B, max_view_points))
+    return fail(SDFR_E_WORKSPACE, "%s: workspace %zu < %zu bytes", fn, workspace_bytes,
+                sdfr_pc_loss_backward_workspace_bytes(B, max_view_points));
+  if ((uintptr_t)workspace % 16) return fail(SDFR_E_INVALID, "workspace must be 16-byte aligned");
+  const int nblk = (max_view_points + kPts - 1) / kPts;
+  const dim3 grid((unsigned)nblk, (unsigned)B);
+  float* partials = (float*)workspace;
+  float* loss_part = partials + (size_t)B * nblk * 8;
+#define SDFR_PC_BWD(RT, L1)                                                                          \
+  hipLaunchKernelGGL((pc_loss_backward_kernel<RT, L1>), grid, dim3(kPts), 0, st, grad_out, points,   \
+                     offsets, max_view_points, pos, quat, scale, sdf, R, sdf_view_stride, g_sdf,     \
+                     g_sdf_view_stride, partials, nblk, l1_weight, loss_part)
+  if (R == 64) { if (l1) SDFR_PC_BWD(64, true); else SDFR_PC_BWD(64, false); }
+  else { if (l1) SDFR_PC_BWD(0, true); else SDFR_PC_BWD(0, false); }
+#undef SDFR_PC_BWD
+  hipLaunchKernelGGL(pc_loss_reduce_kernel, dim3(B), dim3(64), 0, st, partials, offsets,
+                     max_view_points, nblk, quat, g_pos, g_quat, g_scale,
+                     l1 ? (const float*)loss_part : (const float*)nullptr, loss);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+}  // namespace
 
 extern "C" int sdfr_pc_loss_backward(const float* grad_out, const float* points, const int* offsets,
                                      int B, int max_view_points, const float* pos, const float* quat,
@@ -273,46 +357,19 @@ extern "C" int sdfr_pc_loss_backward(const float* grad_out, const float* points,
                                      long long g_sdf_view_stride, float* g_pos, float* g_quat,
                                      float* g_scale, void* workspace, size_t workspace_bytes,
                                      int device, void* stream) {
-  if (int rc = check_pc(R, B, max_view_points)) return rc;
-  const long long vox = (long long)R * R * R;
-  if (!offsets && B > 1) return fail(SDFR_E_NULL, "offsets may be NULL only for a single view");
-  if (sdf_view_stride != 0 && sdf_view_stride < vox)
-    return fail(SDFR_E_INVALID, "sdf_view_stride must be 0 or >= R^3");
-  if (g_sdf_view_stride != 0 && g_sdf_view_stride != vox)
-    return fail(SDFR_E_INVALID, "g_sdf_view_stride must be 0 or R^3");
-  if (!g_sdf) return fail(SDFR_E_NULL, "sdfr_pc_loss_backward: g_sdf is NULL");
-  SDFR_HIP_TRY(hipSetDevice(device));
-  hipStream_t st = (hipStream_t)stream;
-  const size_t g_bytes = (size_t)vox * sizeof(float) * (g_sdf_view_stride ? (size_t)(B > 0 ? B : 1) : 1);
-  zero_words_async(g_sdf, g_bytes / sizeof(float), st);
-  if (B == 0) return 0;
-  if (!g_pos || !g_quat || !g_scale || !pos || !quat || !scale)
-    return fail(SDFR_E_NULL, "sdfr_pc_loss_backward: NULL pointer argument");
-  if (max_view_points == 0) {
-    zero_words_async(g_pos, (size_t)B * 3, st);
-    zero_words_async(g_quat, (size_t)B * 4, st);
-    zero_words_async(g_scale, (size_t)B, st);
-    return 0;
-  }
-  if (!grad_out || !points || !sdf || !workspace)
-    return fail(SDFR_E_NULL, "sdfr_pc_loss_backward: NULL pointer argument");
-  if (workspace_bytes < sdfr_pc_loss_backward_workspace_bytes(B, max_view_points))
-    return fail(SDFR_E_WORKSPACE, "sdfr_pc_loss_backward: workspace %zu < %zu bytes", workspace_bytes,
-                sdfr_pc_loss_backward_workspace_bytes(B, max_view_points));
-  if ((uintptr_t)workspace % 16) return fail(SDFR_E_INVALID, "workspace must be 16-byte aligned");
-  const int nblk = (max_view_points + kPts - 1) / kPts;
-  const dim3 grid((unsigned)nblk, (unsigned)B);
-  float* partials = (float*)workspace;
-  if (R == 64)
-    hipLaunchKernelGGL(pc_loss_backward_kernel<64>, grid, dim3(kPts), 0, st, grad_out, points, offsets,
-                       max_view_points, pos, quat, scale, sdf, R, sdf_view_stride, g_sdf,
-                       g_sdf_view_stride, partials, nblk);
-  else
-    hipLaunchKernelGGL(pc_loss_backward_kernel<0>, grid, dim3(kPts), 0, st, grad_out, points, offsets,
-                       max_view_points, pos, quat, scale, sdf, R, sdf_view_stride, g_sdf,
-                       g_sdf_view_stride, partials, nblk);
-  hipLaunchKernelGGL(pc_loss_reduce_kernel, dim3(B), dim3(64), 0, st, partials, offsets,
-                     max_view_points, nblk, quat, g_pos, g_quat, g_scale);
-  SDFR_HIP_TRY(hipGetLastError());
-  return 0;
+  return pc_backward_impl("sdfr_pc_loss_backward", grad_out, 0.0f, nullptr, points, offsets, B,
+                          max_view_points, pos, quat, scale, sdf, R, sdf_view_stride, g_sdf,
+                          g_sdf_view_stride, g_pos, g_quat, g_scale, workspace, workspace_bytes, device, stream);
+}
+
+extern "C" int sdfr_pc_l1_backward(float weight, float* loss, const float* points, const int* offsets,
+                                   int B, int max_view_points, const float* pos, const float* quat,
+                                   const float* scale, const float* sdf, int R, long long sdf_view_stride,
+                                   float* g_sdf, long long g_sdf_view_stride, float* g_pos, float* g_quat,
+                                   float* g_scale, void* workspace, size_t workspace_bytes, int device,
+                                   void* stream) {
+  if (B > 0 && !loss) return fail(SDFR_E_NULL, "sdfr_pc_l1_backward: loss is NULL");
+  return pc_backward_impl("sdfr_pc_l1_backward", nullptr, weight, loss, points, offsets, B, max_view_points,
+                          pos, quat, scale, sdf, R, sdf_view_stride, g_sdf, g_sdf_view_stride, g_pos, g_quat,
+                          g_scale, workspace, workspace_bytes, device, stream);
 }

@@ -155,8 +155,9 @@ class FusedRenderAndCompare:
                  shape_optimization: bool = True, device="cuda", fuse_depth_loss: bool = True):
         from . import _lib
         from .differentiable_renderer import BatchRenderPlan
-        # True: the depth-L1 runs inside the render kernels (sdfr_render_forward_l1 / _backward_l1);
-        # False: sdfr_render_forward -> sdfr_depth_l1_loss -> sdfr_render_backward.  Same results.
+        # True: the depth-L1 runs inside the render kernels (sdfr_render_forward_l1 / _backward_l1) and the
+        # point-cloud L1 inside the sampler's backward (sdfr_pc_l1_backward);
+        # False: every loss is a kernel of its own between a forward and a backward.  Same results.
         self.fuse_depth_loss = bool(fuse_depth_loss)
         self.L = _lib.lib()
         self.check = _lib.check
@@ -266,7 +267,16 @@ class FusedRenderAndCompare:
             g_sdf, g_pos, g_quat, g_is = self.plan.backward(self.grad_est, sdf, self.pos_c, self.quat_c,
                                                             self.inv_scale)
         have_pts = self.max_pts > 0
-        if have_pts:
+        if have_pts and self.fuse_depth_loss:
+            # the point-cloud term in one pass: loss value and gradients, no sampler forward, no loss kernel
+            self.check(L.sdfr_pc_l1_backward(self.cfg["pc_weight"], self.loss_pc.data_ptr(), self.points.data_ptr(),
+                                             self.offsets.data_ptr(), self.V, self.max_pts, self.pos_c.data_ptr(),
+                                             self.quat_c.data_ptr(), self.scale_v.data_ptr(), sdf.data_ptr(),
+                                             self.R, 0, self.g_sdf_pc.data_ptr(), 0, self.g_pos_pc.data_ptr(),
+                                             self.g_quat_pc.data_ptr(), self.g_scale_pc.data_ptr(),
+                                             self.ws_pc.data_ptr(), self.ws_pc.numel(), d, st),
+                       "sdfr_pc_l1_backward")
+        elif have_pts:
             self.check(L.sdfr_pc_loss_forward(self.points.data_ptr(), self.offsets.data_ptr(), self.V,
                                               self.max_pts, self.pos_c.data_ptr(), self.quat_c.data_ptr(),
                                               self.scale_v.data_ptr(), sdf.data_ptr(), self.R, 0,

@@ -130,3 +130,51 @@ def test_full_size_point_cloud_properties():
         assert same.mean() > 0.9999
         assert np.max(np.abs(v - ref)[same]) <= REL * np.abs(ref).max()
         assert 0.3 < (v != 0).mean() < 0.5   # a third of the points lie inside the volume
+
+
+def test_l1_backward_in_one_pass_equals_the_three_call_sequence():
+    """sdfr_pc_l1_backward against sdfr_pc_loss_forward -> sdfr_pc_l1_loss -> sdfr_pc_loss_backward:
+    same loss, bit-identical pose gradients (fixed-order sums of identical terms), d/dSDF up to the
+    order of float atomics; ragged views, an empty view, points outside the volume."""
+    from sdfest_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    lens = [700, 0, 1500, 257]
+    V = len(lens)
+    pts = np.concatenate([rng.uniform(-0.9, 0.9, (n, 3)) for n in lens]).astype(np.float32) + np.array([0, 0, -1.0], np.float32)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    pos = np.tile(np.array([[0.02, -0.03, -1.0]], np.float32), (V, 1)) + rng.normal(0, 0.02, (V, 3)).astype(np.float32)
+    quat = rng.normal(size=(V, 4)).astype(np.float32)
+    scale = rng.uniform(0.5, 0.8, V).astype(np.float32)
+    sdf = oracle.blobs_sdf(0)
+    t = lambda a, dt=torch.float32: torch.tensor(a, dtype=dt, device=dev)
+    P, O, p, q, s, S = t(pts), t(offs, torch.int32), t(pos), t(quat), t(scale), t(sdf)
+    N, M, w = len(pts), max(lens), 3.0
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(max(L.sdfr_pc_loss_backward_workspace_bytes(V, M), 256), dtype=torch.uint8, device=dev)
+
+    def outs():
+        return (torch.empty(64, 64, 64, device=dev), torch.empty(V, 3, device=dev), torch.empty(V, 4, device=dev),
+                torch.empty(V, device=dev))
+    vals, gv, loss_a = torch.empty(N, device=dev), torch.empty(N, device=dev), torch.empty(V, device=dev)
+    _lib.check(L.sdfr_pc_loss_forward(P.data_ptr(), O.data_ptr(), V, M, p.data_ptr(), q.data_ptr(), s.data_ptr(),
+                                      S.data_ptr(), 64, 0, vals.data_ptr(), 0, st), "fwd")
+    _lib.check(L.sdfr_pc_l1_loss(vals.data_ptr(), O.data_ptr(), V, M, w, loss_a.data_ptr(), gv.data_ptr(), 0, st), "l1")
+    a = outs()
+    _lib.check(L.sdfr_pc_loss_backward(gv.data_ptr(), P.data_ptr(), O.data_ptr(), V, M, p.data_ptr(), q.data_ptr(),
+                                       s.data_ptr(), S.data_ptr(), 64, 0, a[0].data_ptr(), 0, a[1].data_ptr(),
+                                       a[2].data_ptr(), a[3].data_ptr(), ws.data_ptr(), ws.numel(), 0, st), "bwd")
+    b, loss_b = outs(), torch.empty(V, device=dev)
+    _lib.check(L.sdfr_pc_l1_backward(w, loss_b.data_ptr(), P.data_ptr(), O.data_ptr(), V, M, p.data_ptr(),
+                                     q.data_ptr(), s.data_ptr(), S.data_ptr(), 64, 0, b[0].data_ptr(), 0,
+                                     b[1].data_ptr(), b[2].data_ptr(), b[3].data_ptr(), ws.data_ptr(), ws.numel(),
+                                     0, st), "l1 bwd")
+    la, lb = loss_a.cpu().numpy(), loss_b.cpu().numpy()
+    assert np.isnan(la[1]) and np.isnan(lb[1])
+    np.testing.assert_allclose(lb[[0, 2, 3]], la[[0, 2, 3]], rtol=2e-6)
+    for k in (1, 2, 3):
+        assert torch.equal(a[k], b[k]), k
+    ga, gb = a[0].cpu().numpy(), b[0].cpu().numpy()
+    assert np.abs(ga).max() > 0 and np.max(np.abs(ga - gb)) <= 1e-5 * np.abs(ga).max()
+    assert (vals == 0).sum() > 10          # some points fall outside the volume
