@@ -334,14 +334,20 @@ class BatchRenderPlan:
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         self._L = L
 
-    def forward(self, sdf, pos, quat, inv_scale, threshold: float) -> torch.Tensor:
+    def forward(self, sdf, pos, quat, inv_scale, threshold: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Render into the plan's depth buffer, or into ``out`` (B,H,W float32 contiguous on the plan's
+        device) when the caller keeps the images (the plan's buffer is overwritten by the next call)."""
+        dst = self.depth if out is None else out
+        if out is not None and (out.shape != self.depth.shape or out.dtype != torch.float32
+                                or not out.is_contiguous() or out.device != self.depth.device):
+            raise RuntimeError("out must be a contiguous float32 tensor of shape (B, H, W) on the plan's device")
         rc = self._L.sdfr_render_forward(
             sdf.data_ptr(), self.R, self.sdf_stride, pos.data_ptr(), quat.data_ptr(),
             inv_scale.data_ptr(), self.B, self.W, self.H, self.cx, self.cy, self.fx, self.fy,
-            threshold, self.depth.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(),
+            threshold, dst.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(),
             self.device.index, _stream(self.device))
         _lib.check(rc, "sdfr_render_forward")
-        return self.depth
+        return dst
 
     def backward(self, grad_depth, sdf, pos, quat, inv_scale):
         rc = self._L.sdfr_render_backward(

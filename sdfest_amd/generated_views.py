@@ -154,15 +154,15 @@ class SDFVAEViewGenerator:
 
     # -- the GPU part: decode -> render (one launch each for the whole batch) ------------------
     def render(self, latent: torch.Tensor, position: torch.Tensor, quaternion: torch.Tensor,
-               scale: torch.Tensor) -> torch.Tensor:
+               scale: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """(B,H,W) depth images of decode(latent[b]) at pose b (generated_dataset.py:258-280).
-        The returned tensor is the plan's buffer (overwritten by the next call)."""
+        Without ``out`` the returned tensor is the plan's buffer (overwritten by the next call)."""
         with torch.no_grad():
             sdf = self.decoder.decode(latent.to(self.device))[:, 0].contiguous()
             return self.plan.forward(sdf, position.to(self.device).contiguous(),
                                      quaternion.to(self.device).contiguous(),
                                      (1.0 / scale.to(self.device)).contiguous(),
-                                     self.cfg["render_threshold"])
+                                     self.cfg["render_threshold"], out=out)
 
     def generate(self, latent=None, position=None, quaternion=None, scale=None, smooth=None) -> Dict:
         """One batch of samples; any of the sampled quantities may be given instead of drawn.
@@ -179,14 +179,16 @@ class SDFVAEViewGenerator:
         position = (p if position is None else position).to(dev).clone()
         quaternion = (q if quaternion is None else quaternion).to(dev)
         scale = (s if scale is None else scale).to(dev).clone()
-        depth = self.render(latent, position, quaternion, scale).clone()
+        depth = self.render(latent, position, quaternion, scale,
+                            out=torch.empty((B, cfg["height"], cfg["width"]), dtype=torch.float32, device=dev))
         if cfg["gaussian_noise_probability"] > 0.0:                                    # :296-308
             if smooth is None:
                 smooth = torch.rand(B, generator=self.gen) < cfg["gaussian_noise_probability"]
             smooth_depth(depth, self.kernel, smooth)
-        out = {"depth": depth, "latent_shape": latent.to(dev), "valid": depth.amax(dim=(1, 2)) != 0}
+        out = {"depth": depth, "latent_shape": latent.to(dev)}
         if cfg["pointcloud"]:                                                          # :312-334
             pts, counts = depth_to_pointsets(depth, self.camera)
+            out["valid"] = counts > 0          # = the reference's depth.max() != 0, from the counts
             owner = torch.repeat_interleave(torch.arange(B, device=dev), counts)
             if cfg["normalize_pose"]:
                 centroid = torch.zeros((B, 3), device=dev).index_add_(0, owner, pts)
@@ -207,6 +209,8 @@ class SDFVAEViewGenerator:
                     scale /= fro
             out["points"], out["counts"] = pts, counts
             out["pointset"] = list(torch.split(pts, counts.tolist()))
+        if "valid" not in out:
+            out["valid"] = depth.amax(dim=(1, 2)) != 0
         out["position"], out["scale"] = position, scale
         out["quaternion"] = out["orientation"] = quaternion
         return out
