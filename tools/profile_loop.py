@@ -1,9 +1,22 @@
-import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-exec(open(os.path.join(ROOT, "tools", "_loop_scene.py")).read())
-cfg2 = dict(config); cfg2["max_iterations"] = 10
-f = FusedRenderAndCompare(dec, cam, cfg2, targets)
-for rep in range(3):
-    f(*args[1:], use_graph=True)
-torch.cuda.synchronize()
+#!/usr/bin/env python3
+"""Run a few captured iterations of the C5 loop: the program to put after `rocprofv3 --kernel-trace --`
+(per-kernel table: profiles/r01_c5_loop_kernels.md)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch  # noqa: E402
+from _loop_scene import c5_scene  # noqa: E402
+
+
+def main():
+    from sdfest_amd.pipeline import FusedRenderAndCompare
+    s = c5_scene(max_iterations=10)
+    loop = FusedRenderAndCompare(s["decoder"], s["camera"], s["config"], s["targets"])
+    for _ in range(3):
+        loop(*s["init"], use_graph=True)
+    torch.cuda.synchronize()
+
+
+if __name__ == "__main__":
+    main()
