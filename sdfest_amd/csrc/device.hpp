@@ -324,6 +324,8 @@ struct RunHash {
 };
 using BatchHash = RunHash<2, 512>;    // 64 x 8-pixel tiles of a batch; blocks of 256 points of the sampler
 using SmallHash = RunHash<1, 1024>;   // 32 x 8-pixel tiles of small calls, any resolution
+using WideHash = RunHash<2, 1024>;    // 64 x 8-pixel tiles of batches of low-resolution images
+constexpr long long kWideHashMaxPixels = 320 * 240;
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -490,7 +490,10 @@ __device__ __forceinline__ void backward_tile(
   hash.flush(gvol, Rr * Rr * Rr, from_fixed, tid, kBlock);
 }
 
-template <int RT, int SX, int SY, bool LOSS>
+// WIDE: the batch tile with a 4 x 1024 table, for low-resolution images (a pixel then spans several
+// voxels and a tile touches more runs than 512 slots hold: 320x240 batches 137 -> 115 us; at 640x480
+// the bigger table costs occupancy, 173 -> 261 us).
+template <int RT, int SX, int SY, bool LOSS, bool WIDE>
 __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     const float* __restrict__ grad_depth, const float* __restrict__ depth,
     const float* __restrict__ sdf, int R, long long sdf_view_stride,
@@ -498,7 +501,8 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     float rfx, float rfy, int sdf_grad_mode, float* __restrict__ g_sdf,
     long long g_sdf_view_stride, float* __restrict__ partials, const float* __restrict__ loss_grad,
     const float* __restrict__ loss_stats, float loss_weight) {
-  using Hash = typename std::conditional<(SX * SY > 1), BatchHash, SmallHash>::type;
+  using Hash = typename std::conditional<(SX * SY > 1), typename std::conditional<WIDE, WideHash, BatchHash>::type,
+                                         SmallHash>::type;
   __shared__ BackwardLds<Hash> lds;
   const int b = blockIdx.z;
   float loss_k = 0.0f;
@@ -775,23 +779,26 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
   const int ntx = geom.nx(W), nty = geom.ny(H);
   const dim3 grid_tile((unsigned)ntx, (unsigned)nty, (unsigned)B);
   const float rfx = (float)(1.0 / (double)fx), rfy = (float)(1.0 / (double)fy);
-#define SDFR_LAUNCH_BWD_L(RT, SX, SY, LOSS)                                                          \
-  hipLaunchKernelGGL((render_backward_kernel<RT, SX, SY, LOSS>), grid_tile, dim3(kBlock), 0, st,     \
-                     grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, ntx, nty, cx, cy, rfx, \
-                     rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, loss_grad, loss_stats,  \
-                     loss_weight)
-#define SDFR_LAUNCH_BWD(RT, SX, SY)                                                                  \
+  const bool wide = macro && (long long)W * H <= kWideHashMaxPixels;
+#define SDFR_LAUNCH_BWD_L(RT, SX, SY, LOSS, WIDE)                                                    \
+  hipLaunchKernelGGL((render_backward_kernel<RT, SX, SY, LOSS, WIDE>), grid_tile, dim3(kBlock), 0,   \
+                     st, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, ntx, nty, cx, cy,  \
+                     rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, loss_grad,         \
+                     loss_stats, loss_weight)
+#define SDFR_LAUNCH_BWD(RT)                                                                          \
   do {                                                                                               \
-    if (with_loss) SDFR_LAUNCH_BWD_L(RT, SX, SY, true);                                              \
-    else SDFR_LAUNCH_BWD_L(RT, SX, SY, false);                                                       \
+    if (!macro) {                                                                                    \
+      if (with_loss) SDFR_LAUNCH_BWD_L(RT, 1, 1, true, false);                                       \
+      else SDFR_LAUNCH_BWD_L(RT, 1, 1, false, false);                                                \
+    } else if (wide) {                                                                               \
+      if (with_loss) SDFR_LAUNCH_BWD_L(RT, SDFR_MACRO_SX, SDFR_MACRO_SY, true, true);                \
+      else SDFR_LAUNCH_BWD_L(RT, SDFR_MACRO_SX, SDFR_MACRO_SY, false, true);                         \
+    } else {                                                                                         \
+      if (with_loss) SDFR_LAUNCH_BWD_L(RT, SDFR_MACRO_SX, SDFR_MACRO_SY, true, false);               \
+      else SDFR_LAUNCH_BWD_L(RT, SDFR_MACRO_SX, SDFR_MACRO_SY, false, false);                        \
+    }                                                                                                \
   } while (0)
-  if (R == 64) {
-    if (macro) SDFR_LAUNCH_BWD(64, SDFR_MACRO_SX, SDFR_MACRO_SY);
-    else SDFR_LAUNCH_BWD(64, 1, 1);
-  } else {
-    if (macro) SDFR_LAUNCH_BWD(0, SDFR_MACRO_SX, SDFR_MACRO_SY);
-    else SDFR_LAUNCH_BWD(0, 1, 1);
-  }
+  if (R == 64) SDFR_LAUNCH_BWD(64); else SDFR_LAUNCH_BWD(0);
 #undef SDFR_LAUNCH_BWD
 #undef SDFR_LAUNCH_BWD_L
   hipLaunchKernelGGL(pose_reduce_kernel, dim3(B), dim3(64), 0, st, partials, setup, ntx, nty,

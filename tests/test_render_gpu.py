@@ -397,3 +397,26 @@ def test_large_grids_take_the_integer_index_path(R):
         ob = oracle.render_backward(g, d, sdf, pos, quat, isc, *cam[2:], dtype=np.float32)
         assert rel_err(hb[0], ob[0]) <= REL
         assert np.abs(hb[0]).max() > 0
+
+
+def test_low_resolution_batch_takes_the_wide_table(R):
+    """128 views of 320x240: batch tiles with the 4 x 1024 run table (render_backward_kernel<..., WIDE>)
+    against the oracle, and the pose gradients against single-view calls (small tiles, other table)."""
+    sdf = oracle.blobs_sdf(0)
+    B, W, H, f = 128, 320, 240, 160.0
+    pos, quat, isc = oracle.random_poses(B, seed=31, width=W, height=H, f=f)
+    cam = (W, H, W / 2, H / 2, f, f)
+    d = hip_forward(R, sdf, pos, quat, isc, *cam, 0.005)
+    g = np.random.default_rng(31).uniform(-1, 1, d.shape).astype(np.float32)
+    hb = hip_backward(R, g, d, sdf, pos, quat, isc, *cam)
+    ob = oracle.render_backward(g, d, sdf, pos, quat, isc, *cam[2:], dtype=np.float32)
+    assert (d > 0).sum() > 200 * B
+    assert rel_err(hb[0], ob[0]) <= REL
+    for b in (0, 17, 127):
+        h1 = hip_backward(R, g[b], d[b], sdf, pos[b], quat[b], isc[b:b + 1], *cam)
+        dimg = oracle.render_derivative_images(d[b], sdf, pos[b], quat[b], isc[b:b + 1], *cam[2:], dtype=np.float64)[0]
+        l1 = pose_l1(dimg, g[b])
+        pose_b = np.concatenate([hb[1][b], hb[2][b], hb[3][b:b + 1]])
+        pose_1 = np.concatenate([h1[1][0], h1[2][0], h1[3]])
+        ref = np.concatenate([ob[1][b], ob[2][b], ob[3][b:b + 1]])
+        assert np.all(np.abs(pose_b - ref) <= REL * l1) and np.all(np.abs(pose_1 - ref) <= REL * l1)
