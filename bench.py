@@ -10,7 +10,7 @@ all-reduce of the shared d/dSDF when N > 1).  N GPUs = N shards of 256 views of 
 256*N-view batch (configs[3] at N=8), so scaling is weak.  Everything is resident in HBM
 before the timed region.  `--batch 1` gives configs[1] (one view per launch).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]      (N > 1: spawns its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
@@ -43,9 +43,9 @@ def parse():
 
 def synthetic_inputs(B_total, rank, B, W, H, device):
     """blobs(0) SDF and this rank's contiguous shard of the seeded pose list."""
-    import oracle  # input generators only (numpy); nothing of the oracle is timed here
-    sdf = oracle.blobs_sdf(0)
-    pos, quat, isc = oracle.random_poses(B_total, seed=1, width=W, height=H, f=W / 2.0)
+    from sdfest_amd.synthetic import blobs_sdf, random_poses
+    sdf = blobs_sdf(0)
+    pos, quat, isc = random_poses(B_total, seed=1, width=W, height=H, f=W / 2.0)
     sl = slice(rank * B, (rank + 1) * B)
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=device)
     gen = torch.Generator(device=device)
@@ -136,10 +136,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "RANK" not in os.environ and N > 1:
+        # plain `python bench.py --gpus N`: this process has not touched the GPU; it starts the N
+        # ranks as child processes (what torch.distributed.run would do), relays their output
+        # (rank 0 prints the result line) and exits with their status.
+        from sdfest_amd.parallel import spawn_ranks
+        raise SystemExit(spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], N))
     if world != N:
-        if world == 1 and N > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         N = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False); "
+                         "the product has no CPU path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -207,6 +214,7 @@ def main():
 
     fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
     bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
+    step_ms = np.array([e[0].elapsed_time(e[2]) for e in events])
     hits = int((plan.depth > 0).sum().item())
 
     if rank == 0:
@@ -251,6 +259,8 @@ def main():
                               "unit": "GB/s per GPU",
                               "frac": round(bytes_per_view * value / N / HBM_PEAK, 5)},
             "kernel_ms": {"forward_call": round(fwd_ms, 4), "backward_call": round(bwd_ms, 4)},
+            "step_ms_events": {"min": round(float(step_ms.min()), 4), "median": round(float(np.median(step_ms)), 4),
+                               "max": round(float(step_ms.max()), 4), "n": int(step_ms.size)},
         }
         if N == 1 and not args.no_cpu_baseline:
             sample = args.cpu_sample or min(B, 256)

@@ -1181,7 +1181,9 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
     fd.w_off[l] = (long long)d->fc_w_off[l];
     fd.b_off[l] = (long long)d->fc_b_off[l];
   }
-  float* t_mid = buf[cur ^ 1];
+  // g == buf[cur ^ 1] here (every step above ends with g = buf[cur]; cur ^= 1): the transposed wide layer
+  // must write the FREE buffer -- other workgroups still read g while this one stores.
+  float* t_mid = buf[cur];
   hipLaunchKernelGGL(fc_last_backward_kernel, dim3(fd.width[d->n_fc - 1], N), dim3(kFcBlock), 0, st,
                      d->d_params, fd, g, tape + (size_t)N * d->tape_fc_off, t_mid);
   hipLaunchKernelGGL(fc_stack_backward_kernel, dim3(N), dim3(kFcBlock), 0, st, d->d_params, fd, z, t_mid, g_z);

@@ -44,9 +44,13 @@ _ws_cache = {}
 
 
 def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
-    """Per (device, thread) scratch buffer, grown on demand.  Forward runs on the caller's
-    thread and backward on an autograd worker thread; keying by thread keeps them apart."""
-    key = (device.index, threading.get_ident())
+    """Per (device, stream, thread) scratch buffer, grown on demand.  Forward runs on the caller's
+    thread and backward on an autograd worker thread; keying by thread keeps them apart, keying by
+    stream keeps two streams driven from one thread from sharing view records and partial sums
+    without any ordering between them.  A buffer that is outgrown goes back to the caching
+    allocator, which keeps it out of circulation until the work queued on ITS stream (the stream it
+    was allocated on = the only one that used it) has finished."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
     with _ws_lock:
         buf = _ws_cache.get(key)
         if buf is None or buf.numel() < nbytes:
@@ -334,9 +338,28 @@ class BatchRenderPlan:
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         self._L = L
 
+    def _check(self, sdf, pos, quat, inv_scale, **images) -> None:
+        """The C ABI takes raw device pointers: a tensor of another dtype, shape, device or layout
+        would be read as garbage or out of bounds on the GPU.  Same exception type as the
+        reference's CHECK_CUDA / CHECK_CONTIGUOUS (sdf_renderer.cpp:9-13)."""
+        R, B = self.R, self.B
+        want = {"sdf": (B, R, R, R) if self.sdf_stride else (R, R, R), "position": (B, 3),
+                "orientation": (B, 4), "inv_scale": (B,)}
+        got = {"sdf": sdf, "position": pos, "orientation": quat, "inv_scale": inv_scale}
+        for name, t in images.items():
+            want[name] = (B, self.H, self.W)
+            got[name] = t
+        for name, t in got.items():
+            _check_input(t, name)
+            if t.device != self.device:
+                raise RuntimeError(f"{name} is on {t.device}, the plan on {self.device}")
+            if tuple(t.shape) != want[name]:
+                raise RuntimeError(f"{name} must have shape {want[name]}, got {tuple(t.shape)}")
+
     def forward(self, sdf, pos, quat, inv_scale, threshold: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Render into the plan's depth buffer, or into ``out`` (B,H,W float32 contiguous on the plan's
         device) when the caller keeps the images (the plan's buffer is overwritten by the next call)."""
+        self._check(sdf, pos, quat, inv_scale)
         dst = self.depth if out is None else out
         if out is not None and (out.shape != self.depth.shape or out.dtype != torch.float32
                                 or not out.is_contiguous() or out.device != self.depth.device):
@@ -350,6 +373,7 @@ class BatchRenderPlan:
         return dst
 
     def backward(self, grad_depth, sdf, pos, quat, inv_scale):
+        self._check(sdf, pos, quat, inv_scale, grad_depth=grad_depth)
         rc = self._L.sdfr_render_backward(
             grad_depth.data_ptr(), self.depth.data_ptr(), sdf.data_ptr(), self.R, self.sdf_stride,
             pos.data_ptr(), quat.data_ptr(), inv_scale.data_ptr(), self.B, self.W, self.H,
@@ -362,6 +386,7 @@ class BatchRenderPlan:
 
     def forward_l1(self, sdf, pos, quat, inv_scale, threshold: float, target):
         """forward + masked depth-L1 against ``target`` (B,H,W): returns (depth, loss (B,))."""
+        self._check(sdf, pos, quat, inv_scale, target=target)
         rc = self._L.sdfr_render_forward_l1(
             sdf.data_ptr(), self.R, self.sdf_stride, pos.data_ptr(), quat.data_ptr(),
             inv_scale.data_ptr(), self.B, self.W, self.H, self.cx, self.cy, self.fx, self.fy,
@@ -373,6 +398,11 @@ class BatchRenderPlan:
 
     def backward_l1(self, target, sdf, pos, quat, inv_scale, weight: float = 1.0, loss_grad=None):
         """gradients of sum_b weight * loss_grad[b] * loss[b] (after ``forward_l1``)."""
+        self._check(sdf, pos, quat, inv_scale, target=target)
+        if loss_grad is not None:
+            _check_input(loss_grad, "loss_grad")
+            if tuple(loss_grad.shape) != (self.B,) or loss_grad.device != self.device:
+                raise RuntimeError(f"loss_grad must have shape ({self.B},) on {self.device}")
         rc = self._L.sdfr_render_backward_l1(
             loss_grad.data_ptr() if loss_grad is not None else None, weight,
             self.loss_stats.data_ptr(), target.data_ptr(), self.depth.data_ptr(), sdf.data_ptr(),

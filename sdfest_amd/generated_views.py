@@ -158,11 +158,10 @@ class SDFVAEViewGenerator:
         """(B,H,W) depth images of decode(latent[b]) at pose b (generated_dataset.py:258-280).
         Without ``out`` the returned tensor is the plan's buffer (overwritten by the next call)."""
         with torch.no_grad():
-            sdf = self.decoder.decode(latent.to(self.device))[:, 0].contiguous()
-            return self.plan.forward(sdf, position.to(self.device).contiguous(),
-                                     quaternion.to(self.device).contiguous(),
-                                     (1.0 / scale.to(self.device)).contiguous(),
-                                     self.cfg["render_threshold"], out=out)
+            f32 = dict(device=self.device, dtype=torch.float32)   # caller-supplied poses may be float64
+            sdf = self.decoder.decode(latent.to(**f32))[:, 0].contiguous()
+            return self.plan.forward(sdf, position.to(**f32).contiguous(), quaternion.to(**f32).contiguous(),
+                                     (1.0 / scale.to(**f32)).contiguous(), self.cfg["render_threshold"], out=out)
 
     def generate(self, latent=None, position=None, quaternion=None, scale=None, smooth=None) -> Dict:
         """One batch of samples; any of the sampled quantities may be given instead of drawn.

@@ -64,3 +64,59 @@ def allreduce_shared_gradients(g_sdf: torch.Tensor,
         e.copy_(flat[n:n + e.numel()].view_as(e))
         n += e.numel()
     return g_sdf
+
+
+def spawn_ranks(cmd: Sequence[str], world_size: int, master_port: Optional[int] = None,
+                env: Optional[dict] = None, timeout: Optional[float] = None) -> int:
+    """Start `world_size` fresh processes of `cmd`, one per GPU, with the torch.distributed
+    environment (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT) set, wait for
+    all of them and return 0 only if every one exited 0.
+
+    The caller must not have touched the GPU: the workers are plain child processes
+    (``subprocess.Popen``, no fork of an initialised runtime, no exec of a running one), the
+    same thing ``python -m torch.distributed.run --nproc-per-node N`` starts.  Their stdout and
+    stderr are inherited, so rank 0's result line reaches the caller's stdout unchanged.  When
+    one worker fails, the others are terminated (exact PIDs) instead of waiting in a collective.
+    """
+    import os
+    import socket
+    import subprocess
+    import time
+
+    if world_size < 1:
+        raise ValueError("world_size must be >= 1")
+    if master_port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            master_port = s.getsockname()[1]
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(world_size), LOCAL_WORLD_SIZE=str(world_size), MASTER_ADDR="127.0.0.1",
+                MASTER_PORT=str(master_port))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(world_size):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(list(cmd), env=e))
+    deadline = None if timeout is None else time.monotonic() + timeout
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+        if rc != 0 or (deadline is not None and time.monotonic() > deadline):
+            for p in live:
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            return rc or 124
+        if live:
+            time.sleep(0.02)
+    return rc

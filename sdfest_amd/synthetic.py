@@ -1,0 +1,43 @@
+"""Synthetic inputs of the benchmark configurations: the blobs(seed) SDF,
+an analytic sphere, and the seeded random pose list of C3/C4.  Plain numpy; shared by bench.py,
+the tools, __graft_entry__.smoke() and the tests (the oracle re-exports them)."""
+import numpy as np
+
+
+def blobs_sdf(seed=0, R=64, K=8):
+    """Union of K seeded spheres on linspace(-1,1,R)^3, indexing 'ij', float32."""
+    rng = np.random.default_rng(seed)
+    centers = rng.uniform(-0.45, 0.45, (K, 3))
+    radii = rng.uniform(0.15, 0.35, K)
+    g = np.linspace(-1, 1, R)
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    d = np.full((R, R, R), np.inf)
+    for c, r in zip(centers, radii):
+        d = np.minimum(d, np.sqrt((X - c[0]) ** 2 + (Y - c[1]) ** 2 + (Z - c[2]) ** 2) - r)
+    return d.astype(np.float32)
+
+
+def sphere_sdf(radius=0.5, R=64):
+    g = np.linspace(-1, 1, R)
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    return (np.sqrt(X * X + Y * Y + Z * Z) - radius).astype(np.float32)
+
+
+def random_poses(B, seed=1, width=640, height=480, f=320.0):
+    """C3/C4 pose generator: Shoemake-uniform q, z~U(1.2,2), centre pixel in the
+    central 50% of the image, scale~U(0.4,0.6).  Returns pos(B,3), quat(B,4), inv_scale(B)."""
+    rng = np.random.default_rng(seed)
+    u1, u2, u3 = rng.uniform(size=(3, B))
+    quat = np.stack([
+        np.sqrt(1 - u1) * np.sin(2 * np.pi * u2),
+        np.sqrt(1 - u1) * np.cos(2 * np.pi * u2),
+        np.sqrt(u1) * np.sin(2 * np.pi * u3),
+        np.sqrt(u1) * np.cos(2 * np.pi * u3),
+    ], axis=1)
+    z = rng.uniform(1.2, 2.0, B)
+    cx, cy = width / 2, height / 2
+    u = rng.uniform(0.25 * width, 0.75 * width, B)
+    v = rng.uniform(0.25 * height, 0.75 * height, B)
+    pos = np.stack([(u - cx) * z / f, -(v - cy) * z / f, -z], axis=1)
+    scale = rng.uniform(0.4, 0.6, B)
+    return pos.astype(np.float32), quat.astype(np.float32), (1.0 / scale).astype(np.float32)
