@@ -72,11 +72,10 @@ struct TileGeom {
 #endif
 constexpr TileGeom kMacroTile{SDFR_MACRO_SX, SDFR_MACRO_SY};
 constexpr TileGeom kSmallTile{1, 1};
-// Measured on MI355X (640x480, blobs scene): the forward is as fast or faster with small tiles
-// at every batch size (B=1: 14 vs 46 us, B=256: 303 vs 310 us), so it always uses them.  The
-// backward gains from macro-tiles only when there are enough of them (B=64: 128 vs 141 us with
-// small tiles, B=256: 421 vs 265 us): more LDS pre-summation per global atomic, fewer brick
-// initialisations.
+// Both image kernels take the macro tile (64 x 8 pixels) once a call has >= 16384 of them (B >= ~55
+// at 640x480) and the 32 x 8 sub-tile below that: the backward gains more LDS pre-summation per
+// global atomic (B=256: 421 vs 265 us with small tiles), the forward fewer workgroups to dispatch;
+// single views need the finer grid to fill 256 CUs (B=1: 14 vs 46 us).
 #ifndef SDFR_BWD_MACRO_MIN
 #define SDFR_BWD_MACRO_MIN 16384
 #endif

@@ -457,7 +457,9 @@ __device__ __forceinline__ void backward_tile(
     }
     // Outside [0,1] cell coordinates (extrapolation) a weight can exceed the bound the fixed-
     // point scale assumes; such a pixel (never the case for a hit inside the volume) and the
-    // degenerate-scale case go straight to global float atomics.
+    // degenerate-scale case go straight to global float atomics.  So does a pixel whose upstream
+    // gradient is NaN (all 8 weights are then NaN, fmaxf(NaN, NaN) = NaN and the comparison below is
+    // false): NaN reaches g_sdf as it does through the reference's atomicAdd.
     const float wmax = fmaxf(fmaxf(fmaxf(fabsf(w0), fabsf(w1)), fmaxf(fabsf(w2), fabsf(w3))),
                              fmaxf(fmaxf(fabsf(w4), fabsf(w5)), fmaxf(fabsf(w6), fabsf(w7))));
     if (fixed_ok && wmax * to_fixed < 3.5e13f /* 2^45 */) {

@@ -179,7 +179,9 @@ __global__ __launch_bounds__(kPts) void pc_loss_backward_kernel(
     const float x0w = ax * gs, x1w = c.ox * gs;
     const float w0 = x0w * ay * az, w1 = x0w * ay * c.oz, w2 = x0w * c.oy * az, w3 = x0w * c.oy * c.oz;
     const float w4 = x1w * ay * az, w5 = x1w * ay * c.oz, w6 = x1w * c.oy * az, w7 = x1w * c.oy * c.oz;
-    if (fixed_ok) {
+    // (a NaN upstream gradient can be dropped by the block's fmaxf-based maximum: such a lane, like
+    // any lane beyond the fixed-point range, adds in float, so NaN/Inf reach g_sdf as in autograd)
+    if (fixed_ok && fabsf(gs) * to_fixed < 3.5e13f /* 2^45 */) {
       const float wk[8] = {w0, w1, w2, w3, w4, w5, w6, w7};
       hash.add_cell(gvol, c.lin, Rr, wk, to_fixed);
     } else if (go != 0.0f) {

@@ -109,3 +109,66 @@ def test_march_step_cap_terminates_where_the_reference_hangs():
     d = r.forward_raw(sdf, pos[:1].contiguous(), quat[:1].contiguous(), isc[:1].contiguous(), 64, 48, 32.0, 24.0,
                       40.0, 40.0, 0.01)
     assert (d > 0).sum() > 100 and abs(d[d > 0].min().item() - 1.0) < 1e-5
+
+
+def test_batch_render_plan_validates_its_tensors():
+    """BatchRenderPlan hands raw device pointers to the C ABI: wrong dtype / shape / device / layout
+    must raise before anything is launched (round-1 advice)."""
+    from sdfest_amd import BatchRenderPlan, Camera
+    dev = torch.device("cuda", 0)
+    cam = Camera(64, 48, 40.0, 40.0, 32.0, 24.0, pixel_center=0.5)
+    B = 3
+    plan = BatchRenderPlan(64, B, cam, device=dev)
+    sdf = torch.tensor(oracle.sphere_sdf(0.5), device=dev)
+    pos = torch.tensor([[0.0, 0.0, -2.0]] * B, device=dev)
+    quat = torch.tensor([[0.0, 0.0, 0.0, 1.0]] * B, device=dev)
+    isc = torch.ones(B, device=dev)
+    g = torch.ones((B, 48, 64), device=dev)
+    plan.forward(sdf, pos, quat, isc, 0.01)
+    plan.backward(g, sdf, pos, quat, isc)
+    torch.cuda.synchronize()
+    bad = [
+        (dict(sdf=sdf.double()), "float32"), (dict(pos=pos.double()), "float32"),
+        (dict(sdf=sdf[:32]), "shape"), (dict(pos=pos[:2]), "shape"), (dict(quat=quat[:, :3].contiguous()), "shape"),
+        (dict(isc=isc.view(B, 1)), "shape"), (dict(sdf=sdf.permute(2, 1, 0)), "contiguous"),
+        (dict(pos=pos.cpu()), "CUDA"), (dict(sdf=sdf.expand(B, 64, 64, 64).contiguous()), "shape"),
+    ]
+    for kw, what in bad:
+        a = dict(sdf=sdf, pos=pos, quat=quat, isc=isc)
+        a.update(kw)
+        with pytest.raises(RuntimeError, match=what):
+            plan.forward(a["sdf"], a["pos"], a["quat"], a["isc"], 0.01)
+    with pytest.raises(RuntimeError, match="shape"):
+        plan.backward(g[:, :24], sdf, pos, quat, isc)
+    with pytest.raises(RuntimeError, match="float32"):
+        plan.forward_l1(sdf, pos, quat, isc, 0.01, g.double())
+    per_view = BatchRenderPlan(64, B, cam, device=dev, per_view_sdf=True)
+    with pytest.raises(RuntimeError, match="shape"):          # one grid for a per-view plan: out of bounds before
+        per_view.forward(sdf, pos, quat, isc, 0.01)
+
+
+def test_nan_upstream_gradient_reaches_the_outputs():
+    """The reference adds grad * weight with atomicAdd (cu:373-388, :459-466): a NaN upstream gradient
+    poisons the touched voxels and the pose gradients.  The fixed-point LDS sums must not turn it into
+    finite garbage (round-1 advice): such pixels take the float path."""
+    import sdfest_amd.differentiable_renderer as r
+    dev = "cuda"
+    sdf = torch.tensor(oracle.blobs_sdf(0), device=dev)
+    for B in (1, 6):
+        pos = torch.tensor([[0.0, 0.0, -1.5]] * B, device=dev)
+        quat = torch.tensor([[0.0, 0.0, 0.0, 1.0]] * B, device=dev)
+        isc = torch.full((B,), 2.0, device=dev)
+        d = r.forward_raw(sdf, pos, quat, isc, 160, 120, 80.0, 60.0, 80.0, 80.0, 0.005)
+        g = torch.ones_like(d)
+        ref = r.backward_raw(g, d, sdf, pos, quat, isc, 160, 120, 80.0, 60.0, 80.0, 80.0)
+        rows, cols = torch.nonzero(d[0] > 0, as_tuple=True)
+        k = len(rows) // 2
+        g[0, rows[k], cols[k]] = float("nan")
+        out = r.backward_raw(g, d, sdf, pos, quat, isc, 160, 120, 80.0, 60.0, 80.0, 80.0)
+        torch.cuda.synchronize()
+        nan_vox = torch.isnan(out[0])
+        assert 1 <= int(nan_vox.sum()) <= 8                       # the 8 corners of one cell (weights may be 0)
+        assert torch.allclose(out[0][~nan_vox], ref[0][~nan_vox], rtol=1e-5, atol=1e-6)
+        assert torch.isnan(out[1][0]).all() and torch.isnan(out[2][0]).all() and torch.isnan(out[3][0])
+        if B > 1:                                                 # the other views are untouched
+            assert torch.equal(out[1][1:], ref[1][1:]) and torch.equal(out[3][1:], ref[3][1:])

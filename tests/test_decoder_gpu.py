@@ -209,6 +209,44 @@ def test_decoder_latent_gradient_other_architecture_vs_torch():
     assert np.max(np.abs(g - gr)) <= 2e-4 * np.abs(gr).max(), (g, gr)
 
 
+def test_decoder_latent_gradient_wide_hidden_layer_vs_torch():
+    """The transposed wide Linear layer runs one workgroup per (hidden unit, sample): with a hidden
+    width of 2048 and 6 samples that is 12 288 workgroups, several times what is resident at once, so
+    late workgroups read the layer's input gradient long after early ones have stored their results.
+    (Round-1 advice: the results used to be stored into that same buffer.)  Against PyTorch float64."""
+    from sdfest_amd import SDFDecoder
+    rng = np.random.default_rng(2)
+    fc = [{"out": 2048}, {"out": 2 * 6 ** 3}]
+    conv = [dict(in_size=6, in_channels=2, out_channels=4, kernel_size=3, relu=True),
+            dict(in_size=8, in_channels=4, out_channels=1, kernel_size=1, relu=False)]
+    state, width = {}, 7
+    for i, l in enumerate(fc):
+        state[f"decoder._fc_layers.{i}.weight"] = rng.normal(size=(l["out"], width)).astype(np.float32) / np.sqrt(width)
+        state[f"decoder._fc_layers.{i}.bias"] = rng.normal(size=l["out"]).astype(np.float32) * 0.1
+        width = l["out"]
+    for i, l in enumerate(conv):
+        k = l["kernel_size"]
+        state[f"decoder._conv_layers.{i}.weight"] = rng.normal(
+            size=(l["out_channels"], l["in_channels"], k, k, k)).astype(np.float32) / np.sqrt(l["in_channels"] * k ** 3)
+        state[f"decoder._conv_layers.{i}.bias"] = rng.normal(size=l["out_channels"]).astype(np.float32) * 0.1
+    cfg = {"latent_size": 7, "tsdf": False, "decoder": {"fc_layers": fc, "conv_layers": conv}}
+    dec = SDFDecoder.from_config(cfg, state, sdf_size=8)
+    N = 6
+    G = rng.normal(size=(N, 8, 8, 8)).astype(np.float32)
+    z0 = rng.normal(size=(N, 7)).astype(np.float32)
+    zt = torch.tensor(z0, dtype=torch.float64, requires_grad=True)
+    ref = torch_decoder(state, fc, conv, 8, zt)
+    (ref[:, 0] * torch.tensor(G).double()).sum().backward()
+    gr = zt.grad.numpy()
+    for _ in range(5):   # a race shows up in some runs only
+        z = torch.tensor(z0, device="cuda", requires_grad=True)
+        out = dec.decode(z)
+        (out[:, 0] * torch.tensor(G, device="cuda")).sum().backward()
+        assert np.max(np.abs(out.detach().cpu().numpy() - ref.detach().numpy())) <= 1e-4 * ref.abs().max().item()
+        g = z.grad.cpu().numpy()
+        assert np.max(np.abs(g - gr)) <= 2e-4 * np.abs(gr).max(), (g, gr)
+
+
 def test_batched_decoder_kernels_equal_single_decodes(mug):
     """A batch large enough for every batched kernel (direct convolutions, tiled resizes, z-grouped
     MFMA) against one-at-a-time decodes, which take the latency-oriented kernels: forward and VJP."""
