@@ -139,7 +139,7 @@ def test_batch_render_plan_validates_its_tensors():
         with pytest.raises(RuntimeError, match=what):
             plan.forward(a["sdf"], a["pos"], a["quat"], a["isc"], 0.01)
     with pytest.raises(RuntimeError, match="shape"):
-        plan.backward(g[:, :24], sdf, pos, quat, isc)
+        plan.backward(g[:, :24].contiguous(), sdf, pos, quat, isc)
     with pytest.raises(RuntimeError, match="float32"):
         plan.forward_l1(sdf, pos, quat, isc, 0.01, g.double())
     per_view = BatchRenderPlan(64, B, cam, device=dev, per_view_sdf=True)
