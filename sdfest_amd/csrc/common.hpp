@@ -49,7 +49,9 @@ struct alignas(128) ViewSetup {
   float ep[3];    // e + scale  (slab planes, object frame)
   float em[3];    // e - scale
   float dgk;      // inv_scale * (R-1)/2: object-frame direction -> grid-space direction
-  float pad[29];
+  float tp[3];    // e + hi, e + lo of the MAY-HIT box (object frame): the part of the cube outside of
+  float tm[3];    //   which no sample can pass the hit test (render.hip, plane minima); = ep, em without it
+  float pad[23];
 };
 static_assert(sizeof(ViewSetup) == 256, "ViewSetup must stay 256 bytes");
 

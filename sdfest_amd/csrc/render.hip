@@ -39,16 +39,32 @@ namespace sdfr {
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef SDFR_TIGHT_BOX
+#define SDFR_TIGHT_BOX 1  // 0: timing experiments without the may-hit box
+#endif
+constexpr bool kTightBox = SDFR_TIGHT_BOX;
 
 
 // ---------------------------------------------------------------------------------------------
 // set-up: one thread per view
 // ---------------------------------------------------------------------------------------------
+// plane_min (nullable): 3 x R minima of the grid over its x-, y- and z-planes (plane_min_block).
+// With it the view's MAY-HIT box is formed: a sample can pass the hit test dist < threshold * t
+// (cu:289) only if its trilinear value is below vmax = threshold * t_far / scale, a trilinear value
+// is a convex combination of its cell's corners, and the cells of slab i of an axis have their
+// corners in planes i and i+1 -- so outside the slabs with min(plane i, plane i+1) < vmax every ray
+// is a certain miss.  Rays are then culled against that box (tiles against its screen rectangle)
+// and marched only up to its far side; rays that do cross it march from the FULL cube's near plane
+// exactly as before (the trajectory of a hit is the reference's).  Measured on the benchmark scene:
+// the box keeps 57 % of the in-cube rays, 81 % of the march steps and 60 % of the rectangle area
+// (tools/analysis/aabb_pruning.py).
 __device__ __forceinline__ void compute_view_setup(int b, const float* __restrict__ pos,
                                                    const float* __restrict__ quat,
                                                    const float* __restrict__ inv_scale, int R, int W, int H,
                                                    float cx, float cy, float fx, float fy,
-                                                   ViewSetup* __restrict__ out) {
+                                                   ViewSetup* __restrict__ out,
+                                                   const float* __restrict__ plane_min = nullptr,
+                                                   float threshold = 0.0f) {
   const float x = quat[4 * b], y = quat[4 * b + 1], z = quat[4 * b + 2], w = quat[4 * b + 3];
   const V3 p = mk(pos[3 * b], pos[3 * b + 1], pos[3 * b + 2]);
   const float isc = inv_scale[b];
@@ -68,14 +84,39 @@ __device__ __forceinline__ void compute_view_setup(int b, const float* __restric
   s.q[0] = x; s.q[1] = y; s.q[2] = z; s.q[3] = w;
   s.scale = scale;
   s.isc = isc;
-  // Conservative screen rectangle of the cube |o_i| <= scale.  A ray can only pass the slab
-  // test if its pixel centre lies inside the projection of the cube, which (cube entirely in
-  // front of the camera) lies inside the bounding rectangle of the 8 projected corners.
+  // may-hit box in object coordinates, lo[a] .. hi[a] (the whole cube without plane minima)
+  float lo[3] = {-scale, -scale, -scale}, hi[3] = {scale, scale, scale};
+  bool empty = false;
+  if (plane_min && scale > 0.0f && scale < 1e30f) {
+    const float plen = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
+    const float vhit = fmaxf(threshold, 0.0f) * (plen + 1.7321f * scale) * isc * 1.0001f;  // >= thr * t / scale
+    if (vhit == vhit && vhit < 1e30f) {
+      const float cell = scale / h;  // one grid cell in object units
+      for (int a = 0; a < 3; ++a) {
+        const float* pm = plane_min + a * R;
+        int first = R, last = -1;
+        for (int i = 0; i + 1 < R; ++i) {
+          if (fminf(pm[i], pm[i + 1]) < vhit) {
+            if (first == R) first = i;
+            last = i;
+          }
+        }
+        if (last < 0) { empty = true; break; }
+        // slab i spans grid coordinates [i, i+1]; 1/16 cell of slack for the rounding of the slab
+        // arithmetic and of the march's own floor()
+        lo[a] = fmaxf(-scale, ((float)first - 0.0625f) * cell - scale);
+        hi[a] = fminf(scale, ((float)(last + 1) + 0.0625f) * cell - scale);
+      }
+    }
+  }
+  // Conservative screen rectangle of the box.  A ray can only pass the slab test if its pixel
+  // centre lies inside the projection of the box, which (box entirely in front of the camera)
+  // lies inside the bounding rectangle of the 8 projected corners.
   float umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f;
   bool in_front = true;
   for (int c = 0; c < 8; ++c) {
-    const float sx = (c & 1) ? scale : -scale, sy = (c & 2) ? scale : -scale,
-                sz = (c & 4) ? scale : -scale;
+    const float sx = (c & 1) ? hi[0] : lo[0], sy = (c & 2) ? hi[1] : lo[1],
+                sz = (c & 4) ? hi[2] : lo[2];
     const float X = p.x + s.rot[0] * sx + s.rot[1] * sy + s.rot[2] * sz;
     const float Y = p.y + s.rot[3] * sx + s.rot[4] * sy + s.rot[5] * sz;
     const float Z = p.z + s.rot[6] * sx + s.rot[7] * sy + s.rot[8] * sz;
@@ -95,22 +136,45 @@ __device__ __forceinline__ void compute_view_setup(int b, const float* __restric
     const float fy1 = fminf(fmaxf(ceilf(vmax - 0.5f + my) + 1.0f, 0.0f), (float)H);
     x0 = (int)fx0; x1 = (int)fx1; y0 = (int)fy0; y1 = (int)fy1;
   }
+  if (empty) { x0 = y0 = x1 = y1 = 0; }  // no cell of the grid can be hit from this pose
   s.rect[0] = x0; s.rect[1] = y0; s.rect[2] = x1; s.rect[3] = y1;
   for (int k = 0; k < 3; ++k) {
     s.ep[k] = s.e[k] + scale;
     s.em[k] = s.e[k] - scale;
+    s.tp[k] = s.e[k] + hi[k];
+    s.tm[k] = s.e[k] + lo[k];
   }
   s.dgk = isc * h;
-  for (int k = 0; k < 29; ++k) s.pad[k] = 0.0f;
+  for (int k = 0; k < 23; ++k) s.pad[k] = 0.0f;
   out[b] = s;
 }
 
 __global__ void view_setup_kernel(const float* __restrict__ pos, const float* __restrict__ quat,
                                   const float* __restrict__ inv_scale, int B, int R, int W, int H,
                                   float cx, float cy, float fx, float fy,
-                                  ViewSetup* __restrict__ out) {
+                                  ViewSetup* __restrict__ out, const float* __restrict__ plane_min,
+                                  float threshold) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < B) compute_view_setup(b, pos, quat, inv_scale, R, W, H, cx, cy, fx, fy, out);
+  if (b < B) compute_view_setup(b, pos, quat, inv_scale, R, W, H, cx, cy, fx, fy, out, plane_min, threshold);
+}
+
+// Minimum of the grid over one plane: block j = axis * R + i reduces the R^2 values with index i
+// along `axis`.  (NaN values are ignored: a sample that sees one never passes the hit test.)
+__device__ __forceinline__ void plane_min_block(const float* __restrict__ sdf, int R, int j,
+                                                float* __restrict__ plane_min) {
+  __shared__ float red[4];
+  const int axis = j / R, i = j % R, RR = R * R;
+  float m = 3.0e38f;
+  for (int k = threadIdx.x; k < RR; k += 256) {
+    const int u = k / R, v = k % R;
+    const int idx = axis == 0 ? i * RR + k : (axis == 1 ? u * RR + i * R + v : k * R + i);
+    m = fminf(m, sdf[idx]);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) plane_min[j] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
 }
 
 // The backward's prologue in one launch: zero the gradient volume(s) and set the views up (every
@@ -134,13 +198,16 @@ __global__ __launch_bounds__(256) void backward_prologue_kernel(
 // ---------------------------------------------------------------------------------------------
 // (A 2x2x2-blocked record order was measured: +10 integer ops per step, no gain -- the march is
 // bound by dependent-load latency, not by lines per access.  Records stay in grid order.)
-// The launch also sets the views up (threads b < B): one prologue launch for a batched forward.
-__global__ __launch_bounds__(256) void pack_cells_kernel(
-    const float* __restrict__ sdf, int R, float4* __restrict__ cells, const float* __restrict__ pos,
-    const float* __restrict__ quat, const float* __restrict__ inv_scale, int B, int W, int H, float cx,
-    float cy, float fx, float fy, ViewSetup* __restrict__ setup) {
+// The launch's last 3R blocks compute the plane minima for the may-hit boxes (compute_view_setup);
+// the views are set up by the next launch, which needs them.
+__global__ __launch_bounds__(256) void pack_cells_kernel(const float* __restrict__ sdf, int R,
+                                                         float4* __restrict__ cells, int n_pack_blocks,
+                                                         float* __restrict__ plane_min) {
+  if ((int)blockIdx.x >= n_pack_blocks) {
+    plane_min_block(sdf, R, (int)blockIdx.x - n_pack_blocks, plane_min);
+    return;
+  }
   const int lin = blockIdx.x * blockDim.x + threadIdx.x;
-  if (lin < B) compute_view_setup(lin, pos, quat, inv_scale, R, W, H, cx, cy, fx, fy, setup);
   const int RR = R * R;
   if (lin >= RR * R) return;
   const int z = lin % R, y = (lin / R) % R;
@@ -168,7 +235,9 @@ __device__ __forceinline__ bool overlaps(const Rect& r, int px, int py, int w, i
 // also reads the observed depth and the tile leaves (sum |est - obs|, count) over the overlap
 // mask (obs > 0) & (est > 0) in `loss_part`; est = 0 off the object, so only hit pixels can be in
 // the mask and culled tiles never touch the observed image.
-template <int RT, bool PACKED, int SX, int SY, bool LOSS>
+// TIGHT: rays are also tested against the view's may-hit box (compute_view_setup) and march only up
+// to its far side.
+template <int RT, bool PACKED, int SX, int SY, bool LOSS, bool TIGHT>
 __device__ __forceinline__ void forward_tile(
     int tile_x, int tile_y, int ntx, int nty, int b, const float* __restrict__ src, int R,
     long long src_view_stride, const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy,
@@ -238,16 +307,22 @@ __device__ __forceinline__ void forward_tile(
       // infinity when the origin is outside the slab (-> t_near > t_far or t_far < 0) and at
       // opposite infinities when it is inside (-> the axis does not constrain the interval).
       // Pixels outside the screen rectangle fail this test by construction of the rectangle.
-      float t_near = -1e-10f, tf = 1e10f;
+      float t_near = -1e-10f, tf = 1e10f, t_near2 = -1e-10f, tf2 = 1e10f;
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         const float inv = __builtin_amdgcn_rcpf(dv[a]);
         const float ta = s.ep[a] * inv, tb = s.em[a] * inv;
         t_near = fmaxf(t_near, fminf(ta, tb));
         tf = fminf(tf, fmaxf(ta, tb));
+        if (TIGHT) {
+          const float tc = s.tp[a] * inv, td = s.tm[a] * inv;
+          t_near2 = fmaxf(t_near2, fminf(tc, td));
+          tf2 = fminf(tf2, fmaxf(tc, td));
+        }
       }
-      const bool miss = !inside || (t_near > tf) || (tf < 0.0f);
-      float t = fmaxf(t_near, 0.0f);
+      const bool miss = !inside || (t_near > tf) || (tf < 0.0f) || (TIGHT && ((t_near2 > tf2) || (tf2 < 0.0f)));
+      float t = fmaxf(t_near, 0.0f);  // the march starts at the FULL cube's near plane (cu:262-268)
+      if (TIGHT) tf = fminf(tf, tf2);  // ... and no sample behind the may-hit box can be a hit
       if (!miss && (t < tf)) {
         const f32x2 dgxy = {dv[0] * kgrid, dv[1] * kgrid};
         const float dgz = dv[2] * kgrid;
@@ -305,7 +380,7 @@ __global__ __launch_bounds__(kBlock) void render_forward_kernel(
     const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, float cx, float cy,
     float rfx, float rfy, float threshold, int vec_ok, float* __restrict__ depth,
     const float* __restrict__ target, float* __restrict__ loss_part) {
-  forward_tile<RT, PACKED, SX, SY, LOSS>(blockIdx.x, blockIdx.y, ntx, nty, blockIdx.z, src, R,
+  forward_tile<RT, PACKED, SX, SY, LOSS, PACKED && kTightBox>(blockIdx.x, blockIdx.y, ntx, nty, blockIdx.z, src, R,
                                          src_view_stride, setup, W, H, cx, cy, rfx, rfy, threshold,
                                          vec_ok, depth, target, loss_part);
 }
@@ -606,6 +681,7 @@ bool use_packed(int R, int B, long long sdf_view_stride) {
   return sdf_view_stride == 0 && B >= kPackedMinViews && R <= kPackedMaxR;
 }
 size_t packed_bytes(int R) { return (size_t)R * record_slab(R) * 4 * sizeof(float); }
+size_t plane_bytes(int R) { return ((size_t)3 * R * sizeof(float) + 127) & ~(size_t)127; }
 
 }  // namespace
 }  // namespace sdfr
@@ -615,7 +691,7 @@ using namespace sdfr;
 extern "C" size_t sdfr_render_forward_workspace_bytes(int R, int B, int W, int H) {
   (void)W; (void)H;
   size_t n = setup_bytes(B);
-  if (R >= 2 && R <= kPackedMaxR) n += packed_bytes(R);
+  if (R >= 2 && R <= kPackedMaxR) n += packed_bytes(R) + plane_bytes(R);
   return n;
 }
 
@@ -660,14 +736,16 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
   float* loss_part = (float*)((char*)workspace +
                               ((sdfr_render_forward_workspace_bytes(R, B, W, H) + 127) & ~(size_t)127));
   const bool packed = use_packed(R, B, sdf_view_stride);
+  float* plane_min = nullptr;
   if (packed) {
-    const int n = std::max(R * R * R, B);
-    hipLaunchKernelGGL(pack_cells_kernel, dim3((n + 255) / 256), dim3(256), 0, st, sdf, R, (float4*)cells,
-                       pos, quat, inv_scale, B, W, H, cx, cy, fx, fy, setup);
-  } else {
-    hipLaunchKernelGGL(view_setup_kernel, dim3((B + 63) / 64), dim3(64), 0, st, pos, quat, inv_scale, B, R,
-                       W, H, cx, cy, fx, fy, setup);
+    const int n_pack = (R * R * R + 255) / 256;
+    plane_min = (float*)((char*)cells + packed_bytes(R));
+    hipLaunchKernelGGL(pack_cells_kernel, dim3(n_pack + (kTightBox ? 3 * R : 0)), dim3(256), 0, st, sdf, R,
+                       (float4*)cells, n_pack, plane_min);
+    if (!kTightBox) plane_min = nullptr;
   }
+  hipLaunchKernelGGL(view_setup_kernel, dim3((B + 63) / 64), dim3(64), 0, st, pos, quat, inv_scale, B, R,
+                     W, H, cx, cy, fx, fy, setup, plane_min, threshold);
   const TileGeom geom = forward_geom(B, W, H);
   const bool macro = geom.sx == kMacroTile.sx;
   const int ntx = geom.nx(W), nty = geom.ny(H);
@@ -774,6 +852,8 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
     return fail(SDFR_E_INVALID, "workspace must be %zu-byte aligned", alignof(ViewSetup));
   ViewSetup* setup = (ViewSetup*)workspace;
   float* partials = (float*)((char*)workspace + setup_bytes(B));
+  // (the backward does not know the forward's threshold, so its rectangles are those of the full cube;
+  // depth is 0 outside the forward's may-hit rectangle anyway)
   hipLaunchKernelGGL(backward_prologue_kernel, dim3((unsigned)((std::max(g_words, (size_t)B) + 255) / 256)),
                      dim3(256), 0, st, g_sdf, g_words, pos, quat, inv_scale, B, R, W, H, cx, cy, fx, fy, setup);
   const TileGeom geom = backward_geom(B, W, H);

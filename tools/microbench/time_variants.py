@@ -1,7 +1,7 @@
 """Time forward/backward of several builds of the library (ablation / variant .so files)."""
 import ctypes, os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import oracle
 from sdfest_amd import _lib
