@@ -64,7 +64,7 @@ def test_argument_errors_without_gpu(libpath):
     rc = L.sdfr_render_forward(None, 64, 0, None, None, None, 1, 8, 8, 4.0, 4.0, 4.0, 4.0, 0.01,
                                None, None, 0, 0, None)
     assert rc == -2
-    assert L.sdfr_render_forward_workspace_bytes(64, 3, 640, 480) == 3 * 256 + 64 ** 3 * 16
+    assert L.sdfr_render_forward_workspace_bytes(64, 3, 640, 480) == 3 * 256 + 64 ** 3 * 16 + 768  # views + face records + 3 x R plane minima
     assert L.sdfr_render_backward_workspace_bytes(64, 2, 640, 480) == 2 * 256 + 2 * 20 * 60 * 32
 
 
