@@ -268,6 +268,32 @@ SDFR_API int sdfr_adam_step(float* params, const float* grads, float* exp_avg, f
                    int* step, int n_params, float lr_position, float lr_orientation,
                    float lr_scale, float lr_latent, int update_latent, int device, void* stream);
 
+/* :164-175 + losses.py:138-153 -- point constraint on the (un-normalised) orientation parameter:
+ * loss[0] = weight * |q (source,0) conj(q) - target| (quaternion_apply, quaternion_utils.py:36-54);
+ * its gradient w.r.t. q is ADDED to g_orientation[4].  loss / g_orientation may be NULL. */
+SDFR_API int sdfr_point_constraint(const float* orientation, const float* source, const float* target,
+                          float weight, float* loss, float* g_orientation, int device, void* stream);
+
+/* :177-211 -- inlier ratio of one view (the reference passes the LAST view's loop variables,
+ * :463-470) and the best-estimate bookkeeping: ratio = #(|in - est| / in < relative_threshold) /
+ * #(in != 0); history[step[0] - 1] = ratio (if 1 <= step[0] <= max_history; step = sdfr_adam_step's
+ * counter, call after it); a strictly larger ratio, or the first, copies params[n_params] to
+ * best_params.  state[3] = {best ratio, its 1-based iteration, has_best}: zero it before a run.
+ * counts[2] is integer scratch that must be zero on the first call (left zero by every call). */
+SDFR_API int sdfr_inlier_ratio(const float* depth_input, const float* depth_estimate, int W, int H,
+                      float relative_threshold, const int* step, int* counts, float* history,
+                      int max_history, float* state, const float* params, int n_params,
+                      float* best_params, int device, void* stream);
+
+/* losses.py:8-29 -- nn_loss: dist[i] = min_j max(0, -2 a_i.b_j + |a_i|^2 + |b_j|^2), nearest[i] = the
+ * first minimising j; points are (N,3) / (M,3).  The backward is the VJP autograd gives the
+ * reference: through the selected pair, none for a clamped (zero) distance; g_to is overwritten. */
+SDFR_API int sdfr_nn_loss_forward(const float* points_from, int N, const float* points_to, int M,
+                         float* dist, int* nearest, int device, void* stream);
+SDFR_API int sdfr_nn_loss_backward(const float* grad_dist, const float* points_from, int N,
+                          const float* points_to, int M, const float* dist, const int* nearest,
+                          float* g_from, float* g_to, int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

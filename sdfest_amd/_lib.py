@@ -63,6 +63,11 @@ SIGNATURES = {
                                      c_fp]),
     "sdfr_add_inplace": (c_int, [c_fp, c_fp, c_sz, c_int, c_fp]),
     "sdfr_adam_step": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_f, c_f, c_f, c_f, c_int, c_int, c_fp]),
+    "sdfr_point_constraint": (c_int, [c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_int, c_fp]),
+    "sdfr_inlier_ratio": (c_int, [c_fp, c_fp, c_int, c_int, c_f, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_int,
+                                  c_fp, c_int, c_fp]),
+    "sdfr_nn_loss_forward": (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_int, c_fp]),
+    "sdfr_nn_loss_backward": (c_int, [c_fp, c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp]),
 }
 
 

@@ -106,6 +106,139 @@ __global__ void views_to_pose_grad_kernel(const float* __restrict__ orientation,
   g_scale[0] = gs;
 }
 
+// ---------------------------------------------------------------------------------------------
+// What the loop does besides the two image losses (simple_setup.py):
+//   :164-175  point constraint: weight * | quaternion_apply(orientation, source) - target |
+//             (losses.py:138-153) on the UN-normalised orientation parameter -- quaternion_apply is
+//             q (v,0) conj(q) (quaternion_utils.py:36-54), which scales by |q|^2;
+//   :177-211  inlier ratio of the LAST view's input / estimate (the loop variables that survive the
+//             `for` over views, :463-470) and the best-so-far bookkeeping.
+// ---------------------------------------------------------------------------------------------
+// r = q (s,0) conj(q) = (w^2 - u.u) s + 2 (u.s) u + 2 w (u x s);  loss = weight |r - t|;  the gradient
+// w.r.t. q is ADDED to g_orientation (the image terms have been written there before).
+__global__ void point_constraint_kernel(const float* __restrict__ q, const float* __restrict__ src,
+                                        const float* __restrict__ tgt, float weight,
+                                        float* __restrict__ loss, float* __restrict__ g_orientation) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const V3 u = mk(q[0], q[1], q[2]), s = mk(src[0], src[1], src[2]);
+  const float w = q[3];
+  const float us = dot(u, s), uu = dot(u, u);
+  const V3 uxs = cross(u, s);
+  const V3 r = (w * w - uu) * s + (2.0f * us) * u + (2.0f * w) * uxs;
+  const V3 d = r - mk(tgt[0], tgt[1], tgt[2]);
+  const float len = sqrtf(dot(d, d));
+  if (loss) loss[0] = weight * len;
+  if (!g_orientation) return;
+  const float k = len > 0.0f ? weight / len : 0.0f;  // torch: the norm's gradient at 0 is 0
+  const V3 n = k * d;
+  const float ns = dot(n, s), nu = dot(n, u);
+  const V3 sxn = cross(s, n);
+  g_orientation[0] += -2.0f * u.x * ns + 2.0f * s.x * nu + 2.0f * us * n.x + 2.0f * w * sxn.x;
+  g_orientation[1] += -2.0f * u.y * ns + 2.0f * s.y * nu + 2.0f * us * n.y + 2.0f * w * sxn.y;
+  g_orientation[2] += -2.0f * u.z * ns + 2.0f * s.z * nu + 2.0f * us * n.z + 2.0f * w * sxn.z;
+  g_orientation[3] += 2.0f * w * ns + 2.0f * dot(n, uxs);
+}
+
+// counts[0] += #(|in - est| / in < thr), counts[1] += #(in != 0) over one chunk of pixels.  The
+// expression is the reference's (:182-186): a zero input gives inf or NaN, neither is below thr.
+__global__ __launch_bounds__(256) void inlier_count_kernel(const float* __restrict__ depth_in,
+                                                           const float* __restrict__ depth_est, int npix,
+                                                           float rel_thr, int* __restrict__ counts) {
+  int inl = 0, val = 0;
+  for (int i = blockIdx.x * 1024 + threadIdx.x; i < npix && i < (blockIdx.x + 1) * 1024; i += 256) {
+    const float a = depth_in[i], e = depth_est[i];
+    inl += (fabsf(a - e) / a < rel_thr) ? 1 : 0;
+    val += (a != 0.0f) ? 1 : 0;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    inl += __shfl_xor(inl, off, 64);
+    val += __shfl_xor(val, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (inl) atomicAdd(&counts[0], inl);
+    if (val) atomicAdd(&counts[1], val);
+  }
+}
+
+// ratio = inliers / valid; history[step - 1] = ratio; a strictly better ratio (or the first) takes
+// the current parameters as the best estimate (:203-211).  state = {best ratio, its iteration
+// (1-based), has_best}; counts are cleared for the next iteration.
+__global__ void inlier_update_kernel(int* __restrict__ counts, const int* __restrict__ step,
+                                     float* __restrict__ history, int max_history,
+                                     float* __restrict__ state, const float* __restrict__ params,
+                                     int n_params, float* __restrict__ best_params) {
+  __shared__ int better;
+  if (threadIdx.x == 0) {
+    const float ratio = (float)counts[0] / (float)counts[1];
+    const int it = step[0];  // steps taken so far: Adam has run for this iteration already
+    if (history && it >= 1 && it <= max_history) history[it - 1] = ratio;
+    better = (state[2] == 0.0f) || (ratio > state[0]);
+    if (better) { state[0] = ratio; state[1] = (float)it; state[2] = 1.0f; }
+    counts[0] = 0; counts[1] = 0;
+  }
+  __syncthreads();
+  if (better && best_params)
+    for (int i = threadIdx.x; i < n_params; i += blockDim.x) best_params[i] = params[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// losses.nn_loss (losses.py:8-29): squared distance of every point of `from` to its nearest point
+// of `to`, evaluated as the reference does (-2 a.b + |a|^2 + |b|^2, negatives clamped to 0).  One
+// thread per `from` point, `to` staged through LDS in blocks of 256.  D = 3.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nn_loss_forward_kernel(const float* __restrict__ from, int N,
+                                                              const float* __restrict__ to, int M,
+                                                              float* __restrict__ dist,
+                                                              int* __restrict__ nearest) {
+  __shared__ float tile[256][4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < N;
+  const float ax = live ? from[3 * i] : 0.0f, ay = live ? from[3 * i + 1] : 0.0f, az = live ? from[3 * i + 2] : 0.0f;
+  const float a2 = (ax * ax + ay * ay) + az * az;
+  float best = 3.0e38f;
+  int arg = -1;
+  for (int j0 = 0; j0 < M; j0 += 256) {
+    const int j = j0 + threadIdx.x;
+    if (j < M) {
+      const float bx = to[3 * j], by = to[3 * j + 1], bz = to[3 * j + 2];
+      tile[threadIdx.x][0] = bx; tile[threadIdx.x][1] = by; tile[threadIdx.x][2] = bz;
+      tile[threadIdx.x][3] = (bx * bx + by * by) + bz * bz;
+    }
+    __syncthreads();
+    const int n = min(256, M - j0);
+    for (int k = 0; k < n; ++k) {
+      const float ab = (ax * tile[k][0] + ay * tile[k][1]) + az * tile[k][2];
+      float d = (-2.0f * ab + a2) + tile[k][3];
+      d = d < 0.0f ? 0.0f : d;
+      if (d < best) { best = d; arg = j0 + k; }  // first minimum, like torch.min
+    }
+    __syncthreads();
+  }
+  if (live) { dist[i] = best; nearest[i] = arg; }
+}
+
+// VJP of the above through the selected pair: d/da = 2 (a - b_j), d/db_j = -2 (a - b_j); a clamped
+// distance (exactly 0) passes no gradient (the in-place d[d < 0] = 0).
+__global__ __launch_bounds__(256) void nn_loss_backward_kernel(const float* __restrict__ grad_dist,
+                                                               const float* __restrict__ from, int N,
+                                                               const float* __restrict__ to,
+                                                               const float* __restrict__ dist,
+                                                               const int* __restrict__ nearest,
+                                                               float* __restrict__ g_from,
+                                                               float* __restrict__ g_to) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const int j = nearest[i];
+  float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+  if (j >= 0 && dist[i] > 0.0f) {
+    const float g = 2.0f * grad_dist[i];
+    gx = g * (from[3 * i] - to[3 * j]); gy = g * (from[3 * i + 1] - to[3 * j + 1]); gz = g * (from[3 * i + 2] - to[3 * j + 2]);
+    if (g_to) { atomicAdd(g_to + 3 * j, -gx); atomicAdd(g_to + 3 * j + 1, -gy); atomicAdd(g_to + 3 * j + 2, -gz); }
+  }
+  if (g_from) { g_from[3 * i] = gx; g_from[3 * i + 1] = gy; g_from[3 * i + 2] = gz; }
+}
+
 constexpr int kLossChunk = 4096;  // pixels per workgroup of the depth-loss reduction
 
 // pass 1: per (view, chunk) the sum of |est - tgt| and the count over the overlap mask
@@ -400,6 +533,67 @@ extern "C" int sdfr_adam_step(float* params, const float* grads, float* exp_avg,
   hipLaunchKernelGGL(adam_step_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, params, grads, exp_avg,
                      exp_avg_sq, step, n_params, lr_position, lr_orientation, lr_scale, lr_latent,
                      update_latent);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfr_point_constraint(const float* orientation, const float* source, const float* target,
+                                     float weight, float* loss, float* g_orientation, int device,
+                                     void* stream) {
+  if (!orientation || !source || !target) return fail(SDFR_E_NULL, "sdfr_point_constraint: NULL pointer argument");
+  SDFR_HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(point_constraint_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, orientation, source,
+                     target, weight, loss, g_orientation);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfr_inlier_ratio(const float* depth_input, const float* depth_estimate, int W, int H,
+                                 float relative_threshold, const int* step, int* counts, float* history,
+                                 int max_history, float* state, const float* params, int n_params,
+                                 float* best_params, int device, void* stream) {
+  if (W < 0 || H < 0 || (long long)W * H > 0x7fffffffLL || n_params < 0 || max_history < 0)
+    return fail(SDFR_E_INVALID, "sdfr_inlier_ratio: bad sizes");
+  if (!depth_input || !depth_estimate || !step || !counts || !state || (n_params > 0 && best_params && !params))
+    return fail(SDFR_E_NULL, "sdfr_inlier_ratio: NULL pointer argument");
+  SDFR_HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  const int npix = W * H;
+  if (npix > 0)
+    hipLaunchKernelGGL(inlier_count_kernel, dim3((npix + 1023) / 1024), dim3(256), 0, st, depth_input,
+                       depth_estimate, npix, relative_threshold, counts);
+  hipLaunchKernelGGL(inlier_update_kernel, dim3(1), dim3(256), 0, st, counts, step, history, max_history, state,
+                     params, n_params, best_params);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfr_nn_loss_forward(const float* points_from, int N, const float* points_to, int M,
+                                    float* dist, int* nearest, int device, void* stream) {
+  if (N < 0 || M < 0) return fail(SDFR_E_INVALID, "sdfr_nn_loss_forward: negative size");
+  if (N == 0) return 0;
+  if (M == 0) return fail(SDFR_E_INVALID, "sdfr_nn_loss_forward: empty target set (torch: min over an empty dimension)");
+  if (!points_from || !points_to || !dist || !nearest)
+    return fail(SDFR_E_NULL, "sdfr_nn_loss_forward: NULL pointer argument");
+  SDFR_HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(nn_loss_forward_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     points_from, N, points_to, M, dist, nearest);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfr_nn_loss_backward(const float* grad_dist, const float* points_from, int N,
+                                     const float* points_to, int M, const float* dist, const int* nearest,
+                                     float* g_from, float* g_to, int device, void* stream) {
+  if (N < 0 || M < 0) return fail(SDFR_E_INVALID, "sdfr_nn_loss_backward: negative size");
+  SDFR_HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  if (g_to) zero_words_async(g_to, (size_t)M * 3, st);
+  if (N == 0) return 0;
+  if (!grad_dist || !points_from || !points_to || !dist || !nearest)
+    return fail(SDFR_E_NULL, "sdfr_nn_loss_backward: NULL pointer argument");
+  hipLaunchKernelGGL(nn_loss_backward_kernel, dim3((N + 255) / 256), dim3(256), 0, st, grad_dist, points_from, N,
+                     points_to, dist, nearest, g_from, g_to);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -58,6 +58,7 @@ constexpr bool kTightBox = SDFR_TIGHT_BOX;
 // exactly as before (the trajectory of a hit is the reference's).  Measured on the benchmark scene:
 // the box keeps 57 % of the in-cube rays, 81 % of the march steps and 60 % of the rectangle area
 // (tools/analysis/aabb_pruning.py).
+template <bool WAVE = false>
 __device__ __forceinline__ void compute_view_setup(int b, const float* __restrict__ pos,
                                                    const float* __restrict__ quat,
                                                    const float* __restrict__ inv_scale, int R, int W, int H,
@@ -95,10 +96,25 @@ __device__ __forceinline__ void compute_view_setup(int b, const float* __restric
       for (int a = 0; a < 3; ++a) {
         const float* pm = plane_min + a * R;
         int first = R, last = -1;
-        for (int i = 0; i + 1 < R; ++i) {
-          if (fminf(pm[i], pm[i + 1]) < vhit) {
-            if (first == R) first = i;
-            last = i;
+        if (WAVE) {
+          // the whole wave scans the R-1 slabs of the axis: 64 per round, first / last set bit of the ballot
+          // (a serial scan by one thread is 3(R-1) dependent loads: 17 us per launch at R = 64, measured)
+          const int lane = threadIdx.x & 63;
+          for (int i0 = 0; i0 + 1 < R; i0 += 64) {
+            const int i = i0 + lane;
+            const bool f = (i + 1 < R) && (fminf(pm[i], pm[i + 1]) < vhit);
+            const unsigned long long m = __ballot(f);
+            if (m) {
+              if (first == R) first = i0 + __builtin_ctzll(m);
+              last = i0 + 63 - __builtin_clzll(m);
+            }
+          }
+        } else {
+          for (int i = 0; i + 1 < R; ++i) {
+            if (fminf(pm[i], pm[i + 1]) < vhit) {
+              if (first == R) first = i;
+              last = i;
+            }
           }
         }
         if (last < 0) { empty = true; break; }
@@ -146,7 +162,7 @@ __device__ __forceinline__ void compute_view_setup(int b, const float* __restric
   }
   s.dgk = isc * h;
   for (int k = 0; k < 23; ++k) s.pad[k] = 0.0f;
-  out[b] = s;
+  if (!WAVE || (threadIdx.x & 63) == 0) out[b] = s;
 }
 
 __global__ void view_setup_kernel(const float* __restrict__ pos, const float* __restrict__ quat,
@@ -154,8 +170,9 @@ __global__ void view_setup_kernel(const float* __restrict__ pos, const float* __
                                   float cx, float cy, float fx, float fy,
                                   ViewSetup* __restrict__ out, const float* __restrict__ plane_min,
                                   float threshold) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < B) compute_view_setup(b, pos, quat, inv_scale, R, W, H, cx, cy, fx, fy, out, plane_min, threshold);
+  // one wave per view (the wave shares the scan of the plane minima, lane 0 writes the record)
+  const int b = blockIdx.x;
+  if (b < B) compute_view_setup<true>(b, pos, quat, inv_scale, R, W, H, cx, cy, fx, fy, out, plane_min, threshold);
 }
 
 // Minimum of the grid over one plane: block j = axis * R + i reduces the R^2 values with index i
@@ -744,7 +761,7 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
                        (float4*)cells, n_pack, plane_min);
     if (!kTightBox) plane_min = nullptr;
   }
-  hipLaunchKernelGGL(view_setup_kernel, dim3((B + 63) / 64), dim3(64), 0, st, pos, quat, inv_scale, B, R,
+  hipLaunchKernelGGL(view_setup_kernel, dim3(B), dim3(64), 0, st, pos, quat, inv_scale, B, R,
                      W, H, cx, cy, fx, fy, setup, plane_min, threshold);
   const TileGeom geom = forward_geom(B, W, H);
   const bool macro = geom.sx == kMacroTile.sx;

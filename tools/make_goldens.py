@@ -262,6 +262,173 @@ def make_quaternion(ref):
         inv=qu.quaternion_invert(t(q1)).numpy())
 
 
+def make_loop_g7(ref):
+    """G7: a few iterations of the render-and-compare loop of
+    estimation/simple_setup.py:381-470 assembled from IMPORTED reference pieces --
+    the numpy twin (simple_renderer.render_depth, value "d") with the reduction of
+    sdf_renderer.py:242-261, losses.pc_loss, losses.point_constraint_loss, quaternion_utils,
+    SDFVAE.decode with the mug weights, torch.optim.Adam.  simple_setup.py and
+    pointset_utils.py themselves cannot be imported here (open3d / the CUDA JIT build), so the
+    loop statements, _compute_view_losses (:115-162), _compute_inlier_ratio (:177-188) and
+    depth_to_pointcloud (pointset_utils.py:57-77) are the only lines restated.  Writes the
+    parameter trajectory, the loss terms and the inlier ratios (last view's loop variables,
+    :463-470) of two runs: A = 2 views with cameras, shape optimisation on;
+    B = 1 view, point constraint, shape optimisation off."""
+    import torch
+    import yaml
+    sys.path.insert(0, ref)
+    from sdfest.estimation import losses
+    from sdfest.initialization import quaternion_utils as qu
+    from sdfest.vae import sdf_vae
+    sr = load_simple_renderer(ref)
+    with open(os.path.join(ref, "tests/initilization/vae_model/mug.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    vae = sdf_vae.SDFVAE(sdf_size=64, latent_size=cfg["latent_size"], encoder_dict=cfg["encoder"],
+                         decoder_dict=cfg["decoder"], device="cpu")
+    vae.load_state_dict(torch.load(os.path.join(ref, "tests/initilization/vae_model/mug.pt"),
+                                   map_location="cpu"))
+    vae.eval()
+    W, H, FOV, THR = 96, 72, 90.0, 0.005
+    fx, fy, cx, cy = fov_to_intrinsics(W, H, FOV)   # pixel centre 0.5 (generate_rays)
+    cx0, cy0 = cx - 0.5, cy - 0.5                   # Camera.get_pinhole_camera_parameters(0.0)
+
+    class TwinRender(torch.autograd.Function):  # = SDFRendererFunction, sdf_renderer.py:136-261
+        @staticmethod
+        def forward(ctx, sdf, position, orientation, inv_scale):
+            ctx.save_for_backward(sdf, position, orientation, inv_scale)
+            with contextlib.redirect_stdout(io.StringIO()):
+                image, der = sr.render_depth(sr.SDFObject(sdf.detach().numpy()), W, H, FOV, "d", THR,
+                                             position.detach().numpy(), orientation.detach().numpy(),
+                                             inv_scale.detach().numpy())
+            ctx.der = der
+            return torch.from_numpy(image)
+
+        @staticmethod
+        def backward(ctx, inp):
+            der = ctx.der
+            sdf, pos, quat, inv_s = ctx.saved_tensors
+            g = inp.numpy()
+            g_sdf = torch.zeros_like(sdf)
+            zero = np.zeros_like(g)
+            s = lambda n: float(np.sum(der.get(n, zero) * g))
+            g_p = torch.tensor([s("x"), s("y"), s("z")], dtype=pos.dtype)
+            g_q = torch.tensor([s("qx"), s("qy"), s("qz"), s("qw")], dtype=quat.dtype)
+            g_is = torch.tensor(s("s_inv"), dtype=inv_s.dtype)
+            for k, v in der.get("sdf", {}).items():
+                g_sdf[k] = float(np.sum(v * g))
+            return g_sdf, g_p, g_q, g_is
+
+    def depth_to_pointcloud(depth):  # pointset_utils.py:57-77, "opengl", no mask
+        idx = torch.nonzero(depth, as_tuple=True)
+        z = depth[idx]
+        return torch.stack(((idx[1].float() - cx0) * z / fx, -(idx[0].float() - cy0) * z / fy, -z), 1)
+
+    def inlier_ratio(depth_in, depth_est, thr=0.03):  # simple_setup.py:177-188
+        rel = torch.abs(depth_in - depth_est) / depth_in
+        return (torch.count_nonzero(rel < thr) / torch.count_nonzero(depth_in)).item()
+
+    def run(tag, z_true, p_true, q_true, s_true, cams, n_iter, shape_opt, point_constraint, out):
+        f32 = torch.float32
+        cam_p = torch.tensor([c[0] for c in cams], dtype=f32)
+        cam_q = torch.tensor([c[1] for c in cams], dtype=f32)
+        cam_q = cam_q / cam_q.norm(dim=1, keepdim=True)
+        with torch.no_grad():
+            sdf_true = vae.decode(torch.tensor(z_true, dtype=f32)[None])
+            targets = []
+            for cp, cq in zip(cam_p, cam_q):
+                qi = qu.quaternion_invert(cq)
+                pc = qu.quaternion_apply(qi, torch.tensor(p_true, dtype=f32)[None] - cp)
+                oc = qu.quaternion_multiply(qi, torch.tensor(q_true, dtype=f32)[None])
+                targets.append(TwinRender.apply(sdf_true[0, 0].double(), pc[0].double(), oc[0].double(),
+                                                torch.tensor(1.0 / s_true, dtype=torch.float64)).float())
+        depth_images = torch.stack(targets)
+        # initial estimate: the truth, perturbed (C5's recipe, SURVEY 8d)
+        position = (torch.tensor(p_true, dtype=f32) + 0.01)[None].clone().requires_grad_()
+        ang = np.deg2rad(10.0) / 2
+        dq = torch.tensor([np.sin(ang) * 0.6, np.sin(ang) * 0.0, np.sin(ang) * 0.8, np.cos(ang)], dtype=f32)
+        orientation = qu.quaternion_multiply(torch.tensor(q_true, dtype=f32), dq)[None].clone().requires_grad_()
+        scale = torch.tensor([s_true * 1.08], dtype=f32).requires_grad_()
+        latent = torch.zeros((1, cfg["latent_size"]), dtype=f32).requires_grad_()
+        out[f"{tag}_depth_images"] = depth_images.numpy()
+        out[f"{tag}_cam_pos"] = cam_p.numpy(); out[f"{tag}_cam_quat"] = cam_q.numpy()
+        out[f"{tag}_init"] = np.concatenate([position.detach().numpy().ravel(), orientation.detach().numpy().ravel(),
+                                             scale.detach().numpy().ravel(), latent.detach().numpy().ravel()])
+        opt = torch.optim.Adam([{"params": position, "lr": 1e-3}, {"params": orientation, "lr": 1e-2},
+                                {"params": scale, "lr": 1e-3}, {"params": latent, "lr": 1e-2}])
+        traj, terms, ratios, grads = [], [], [], []
+        for it in range(n_iter):
+            opt.zero_grad()
+            norm_orientation = orientation / torch.sqrt(torch.sum(orientation ** 2))
+            with torch.set_grad_enabled(shape_opt):
+                sdf = vae.decode(latent)
+            loss_depth = torch.tensor(0.0, requires_grad=True)
+            loss_pc = torch.tensor(0.0, requires_grad=True)
+            for depth_image, cp, cq in zip(depth_images, cam_p, cam_q):
+                q_w2c = qu.quaternion_invert(cq)
+                position_c = qu.quaternion_apply(q_w2c, position - cp)
+                orientation_c = qu.quaternion_multiply(q_w2c, norm_orientation)
+                depth_estimate = TwinRender.apply(sdf[0, 0], position_c[0], orientation_c[0], 1 / scale[0]).float()
+                overlap = (depth_image > 0) & (depth_estimate > 0)
+                loss_depth = loss_depth + torch.mean(torch.abs(depth_estimate - depth_image)[overlap])
+                pts = depth_to_pointcloud(depth_image)
+                loss_pc = loss_pc + torch.mean(torch.abs(
+                    losses.pc_loss(pts, position_c[0], orientation_c[0], scale[0], sdf[0, 0])))
+            if point_constraint is not None:
+                src, tgt, wgt = point_constraint
+                loss_con = wgt * losses.point_constraint_loss(orientation[0], torch.tensor(src, dtype=f32),
+                                                              torch.tensor(tgt, dtype=f32))
+            else:
+                loss_con = orientation.new_tensor(0.0)
+            loss = 1.0 * loss_depth + 3.0 * loss_pc + loss_con   # default.yaml:14-16
+            loss.backward()
+            grads.append(np.concatenate([position.grad.numpy().ravel(), orientation.grad.numpy().ravel(),
+                                         scale.grad.numpy().ravel(),
+                                         latent.grad.numpy().ravel() if latent.grad is not None
+                                         else np.zeros(cfg["latent_size"], np.float32)]))
+            opt.step()
+            with torch.no_grad():
+                orientation /= torch.sqrt(torch.sum(orientation ** 2))
+                ratios.append(inlier_ratio(depth_image, depth_estimate))   # LAST view's variables
+            traj.append(np.concatenate([position.detach().numpy().ravel(), orientation.detach().numpy().ravel(),
+                                        scale.detach().numpy().ravel(), latent.detach().numpy().ravel()]))
+            terms.append([loss_depth.item(), loss_pc.item(), float(loss_con), loss.item()])
+            print(f"  {tag} it{it}: depth {loss_depth.item():.6f} pc {loss_pc.item():.6f} con {float(loss_con):.6f} "
+                  f"inlier {ratios[-1]:.4f} hits {[int((t > 0).sum()) for t in depth_images]}")
+        out[f"{tag}_traj"] = np.array(traj); out[f"{tag}_terms"] = np.array(terms)
+        out[f"{tag}_inlier"] = np.array(ratios); out[f"{tag}_grads"] = np.array(grads)
+
+    rng = np.random.default_rng(17)
+    out = {"W": W, "H": H, "fov": FOV, "thr": THR, "fx": fx, "fy": fy, "cx": cx, "cy": cy}
+    q_true = rng.normal(size=4); q_true /= np.linalg.norm(q_true)
+    z_true = (0.5 * rng.normal(size=cfg["latent_size"])).astype(np.float32)
+    cams_a = [((0.0, 0.0, 0.0), (0.0, 0.0, 0.0, 1.0)),
+              ((0.25, 0.05, -0.08), (0.02, 0.33, -0.04, 0.94))]
+    run("a", z_true, (0.02, -0.01, -0.40), q_true, 0.12, cams_a, 5, True, None, out)
+    out["b_constraint_source"] = np.array([0.0, 1.0, 0.0], np.float32)
+    out["b_constraint_target"] = np.array([0.1, 0.9, -0.2], np.float32)
+    out["b_constraint_weight"] = 0.05
+    run("b", z_true, (-0.03, 0.02, -0.35), q_true, 0.10, cams_a[:1], 4, False,
+        (out["b_constraint_source"], out["b_constraint_target"], 0.05), out)
+    out["z_true"] = z_true; out["q_true"] = q_true
+    # nn_loss (losses.py:8-29) and point_constraint_loss (:138-153) on seeded inputs
+    a = torch.tensor(rng.normal(size=(200, 3)), dtype=torch.float32, requires_grad=True)
+    b = torch.tensor(rng.normal(size=(333, 3)) * 1.3, dtype=torch.float32, requires_grad=True)
+    d = losses.nn_loss(a, b)
+    gw = torch.tensor(rng.uniform(-1, 1, 200), dtype=torch.float32)
+    d.backward(gw)
+    out.update(nn_from=a.detach().numpy(), nn_to=b.detach().numpy(), nn_d=d.detach().numpy(), nn_gout=gw.numpy(),
+               nn_gfrom=a.grad.numpy(), nn_gto=b.grad.numpy())
+    qs = rng.normal(size=(6, 4)); src = rng.normal(size=(6, 3)); tgt = rng.normal(size=(6, 3))
+    pc_v, pc_g = [], []
+    for i in range(6):
+        q = torch.tensor(qs[i], dtype=torch.float64, requires_grad=True)
+        v = losses.point_constraint_loss(q, torch.tensor(src[i]), torch.tensor(tgt[i]))
+        v.backward()
+        pc_v.append(v.item()); pc_g.append(q.grad.numpy().copy())
+    out.update(pcl_q=qs, pcl_src=src, pcl_tgt=tgt, pcl_value=np.array(pc_v), pcl_gq=np.array(pc_g))
+    np.savez_compressed(os.path.join(OUT, "loop_g7.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -269,7 +436,7 @@ def main():
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     jobs = {"render": make_render, "pc_loss": make_pc_loss, "decoder": make_decoder,
-            "quaternion": make_quaternion}
+            "quaternion": make_quaternion, "loop_g7": make_loop_g7}
     for name, fn in jobs.items():
         if args.only and args.only != name:
             continue

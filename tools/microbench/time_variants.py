@@ -3,12 +3,13 @@ import ctypes, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-import oracle
+from sdfest_amd import synthetic as oracle   # input generators only
 from sdfest_amd import _lib
 
 def load(path):
     h = ctypes.CDLL(path)
     for name, (res, args) in _lib.SIGNATURES.items():
+        if not hasattr(h, name): continue   # an older build
         fn = getattr(h, name); fn.restype = res; fn.argtypes = args
     return h
 
