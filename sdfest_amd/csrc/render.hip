@@ -43,6 +43,10 @@ constexpr int kBlock = 256;
 #define SDFR_TIGHT_BOX 1  // 0: timing experiments without the may-hit box
 #endif
 constexpr bool kTightBox = SDFR_TIGHT_BOX;
+#ifndef SDFR_FWD_WAVES
+#define SDFR_FWD_WAVES 2
+#endif
+constexpr int kFwdWaves = SDFR_FWD_WAVES;  // waves per workgroup of the batch forward (macro tiles)
 
 
 // ---------------------------------------------------------------------------------------------
@@ -254,13 +258,14 @@ __device__ __forceinline__ bool overlaps(const Rect& r, int px, int py, int w, i
 // the mask and culled tiles never touch the observed image.
 // TIGHT: rays are also tested against the view's may-hit box (compute_view_setup) and march only up
 // to its far side.
-template <int RT, bool PACKED, int SX, int SY, bool LOSS, bool TIGHT>
+template <int RT, bool PACKED, int SX, int SY, bool LOSS, bool TIGHT, int NW>
 __device__ __forceinline__ void forward_tile(
     int tile_x, int tile_y, int ntx, int nty, int b, const float* __restrict__ src, int R,
     long long src_view_stride, const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy,
     float rfx, float rfy, float threshold, int vec_ok, float* __restrict__ depth,
     const float* __restrict__ target, float* __restrict__ loss_part) {
   constexpr int kSubs = SX * SY, kTileW = SX * kSubW, kTileH = SY * kSubH;
+  constexpr int kThreads = NW * 64;  // NW waves walk the tile's 4 * kSubs 8x8 patches
   using PF = Patch<kPatchWFwd>;
   const int px0 = tile_x * kTileW, py0 = tile_y * kTileH;
   const ViewSetup& s = setup[b];
@@ -274,14 +279,14 @@ __device__ __forceinline__ void forward_tile(
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     if (vec_ok) {
 #pragma unroll
-      for (int i = tid; i < kTileW * kTileH / 4; i += kBlock) {
+      for (int i = tid; i < kTileW * kTileH / 4; i += kThreads) {
         const int row = py0 + i / (kTileW / 4), col = px0 + (i % (kTileW / 4)) * 4;
         // whole 64-byte runs, written once and not re-read here: keep them out of L2 (measured
         // -2 %; on the scattered per-pixel result stores the same hint cost +28 % WRITE_SIZE)
         if (row < H && col < W) __builtin_nontemporal_store(zero4, reinterpret_cast<f32x4*>(img + (size_t)row * W + col));
       }
     } else {
-      for (int i = tid; i < kTileW * kTileH; i += kBlock) {
+      for (int i = tid; i < kTileW * kTileH; i += kThreads) {
         const int row = py0 + i / kTileW, col = px0 + i % kTileW;
         if (row < H && col < W) img[(size_t)row * W + col] = 0.0f;
       }
@@ -303,13 +308,14 @@ __device__ __forceinline__ void forward_tile(
 
   float l_sum = 0.0f, l_cnt = 0.0f;  // LOSS: this lane's share of the tile's (sum, count)
   const float* obs = LOSS ? target + (size_t)b * H * W : nullptr;
-  for (int sub = 0; sub < kSubs; ++sub) {
+  for (int it = wave; it < 4 * kSubs; it += NW) {
+    const int sub = it >> 2, pw = it & 3;  // sub-tile and 8x8 patch inside it (NW = 4: patch = wave)
     const int sx = px0 + (sub % SX) * kSubW, sy = py0 + (sub / SX) * kSubH;
-    const int col = sx + PF::ox(wave) + PF::x(lane), row = sy + PF::oy(wave) + PF::y(lane);
+    const int col = sx + PF::ox(pw) + PF::x(lane), row = sy + PF::oy(pw) + PF::y(lane);
     const bool inside = (col < W) && (row < H);
     float result = 0.0f;
     // wave-uniform: does this wave's 8x8 patch touch the rectangle at all?
-    if (overlaps(rc, sx + PF::ox(wave), sy + PF::oy(wave), PF::W, PF::H)) {
+    if (overlaps(rc, sx + PF::ox(pw), sy + PF::oy(pw), PF::W, PF::H)) {
       // unit ray (cu:137-154), rotated into the object frame with d.z = -1 folded in
       const float dx = ((float)col + 0.5f - cx) * rfx;
       const float dy = -((float)row + 0.5f - cy) * rfy;
@@ -378,6 +384,7 @@ __device__ __forceinline__ void forward_tile(
     l_sum = wave_sum(l_sum);
     l_cnt = wave_sum(l_cnt);
     if (lane == 0) { wave_loss[wave][0] = l_sum; wave_loss[wave][1] = l_cnt; }
+    if (tid < 8 && (tid >> 1) >= NW) wave_loss[tid >> 1][tid & 1] = 0.0f;
     __syncthreads();
     if (tid < 2)
       loss_part[(((size_t)b * nty + tile_y) * ntx + tile_x) * 2 + tid] =
@@ -391,13 +398,17 @@ __device__ __forceinline__ void forward_tile(
 // workgroup 257/211, 1x2 tiles 264/311, 1x4 270/317, 2x4 295/363; a persistent grid striding over
 // the whole tile list 377/472: the dispatcher hides the very uneven tile costs only when it has
 // many independent workgroups.)
-template <int RT, bool PACKED, int SX, int SY, bool LOSS>
-__global__ __launch_bounds__(kBlock) void render_forward_kernel(
+// NW waves per workgroup.  The dispatcher's cost is per workgroup, not per wave (all-culled launches of
+// 1-, 2- and 4-wave workgroups: 66 / 66 / 67 us), and a new workgroup needs a free slot on NW SIMDs at
+// once: 64 x 8 tiles walked by 2 waves (4 patches each) 167 us, by 4 waves 172, by 1 wave 183; 8- and
+// 16-wave workgroups on 128 x 8 ... 128 x 16 tiles 186 ... 237.
+template <int RT, bool PACKED, int SX, int SY, bool LOSS, int NW>
+__global__ __launch_bounds__(NW * 64) void render_forward_kernel(
     const float* __restrict__ src, int R, long long src_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, float cx, float cy,
     float rfx, float rfy, float threshold, int vec_ok, float* __restrict__ depth,
     const float* __restrict__ target, float* __restrict__ loss_part) {
-  forward_tile<RT, PACKED, SX, SY, LOSS, PACKED && kTightBox>(blockIdx.x, blockIdx.y, ntx, nty, blockIdx.z, src, R,
+  forward_tile<RT, PACKED, SX, SY, LOSS, PACKED && kTightBox, NW>(blockIdx.x, blockIdx.y, ntx, nty, blockIdx.z, src, R,
                                          src_view_stride, setup, W, H, cx, cy, rfx, rfy, threshold,
                                          vec_ok, depth, target, loss_part);
 }
@@ -770,7 +781,8 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
   const float rfx = (float)(1.0 / (double)fx), rfy = (float)(1.0 / (double)fy);
   const int vec_ok = (W % 4 == 0) && ((uintptr_t)depth % 16 == 0);
 #define SDFR_LAUNCH_FWD_L(RT, PK, SRC, STRIDE, SX, SY, LOSS)                                          \
-  hipLaunchKernelGGL((render_forward_kernel<RT, PK, SX, SY, LOSS>), grid_tile, dim3(kBlock), 0, st, \
+  hipLaunchKernelGGL((render_forward_kernel<RT, PK, SX, SY, LOSS, (SX * SY > 1 ? kFwdWaves : 4)>), grid_tile, \
+                     dim3((SX * SY > 1 ? kFwdWaves : 4) * 64), 0, st, \
                      SRC, R, STRIDE, setup, W, H, ntx, nty, cx, cy, rfx, rfy, threshold, vec_ok,      \
                      depth, target, loss_part)
 #define SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, SX, SY)                                               \
