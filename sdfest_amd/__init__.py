@@ -8,8 +8,8 @@ from .differentiable_renderer import (BatchRenderPlan, Camera, SDFRendererFuncti
                                       render_depth_batch, render_depth_l1_batch,
                                       render_depth_gpu)
 
-from .losses import pc_loss, pc_loss_batch
+from .losses import nn_loss, pc_loss, pc_loss_batch, point_constraint_loss
 from .vae import SDFDecoder
-from .pipeline import RenderAndCompare
+from .pipeline import FusedRenderAndCompare, RenderAndCompare
 
-__all__ = ["RenderAndCompare", "SDFDecoder", "pc_loss", "pc_loss_batch", "BatchRenderPlan", "Camera", "SDFRendererFunctionGPU", "render_depth_gpu", "render_depth_batch", "render_depth_l1_batch"]
+__all__ = ["RenderAndCompare", "FusedRenderAndCompare", "SDFDecoder", "pc_loss", "pc_loss_batch", "nn_loss", "point_constraint_loss", "BatchRenderPlan", "Camera", "SDFRendererFunctionGPU", "render_depth_gpu", "render_depth_batch", "render_depth_l1_batch"]

@@ -92,3 +92,69 @@ def pc_loss_batch(points: torch.Tensor, offsets: torch.Tensor, max_view_points: 
     if offsets.dtype != torch.int32 or not offsets.is_cuda or not offsets.is_contiguous():
         raise RuntimeError("offsets must be a contiguous int32 CUDA tensor")
     return _PCLoss.apply(points, offsets, int(max_view_points), positions, orientations, scales, sdf)
+
+
+class _NNLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points_from, points_to):
+        a = points_from.detach().contiguous()
+        b = points_to.detach().contiguous()
+        N, M = a.shape[0], b.shape[0]
+        dist = torch.empty(N, dtype=torch.float32, device=a.device)
+        nearest = torch.empty(N, dtype=torch.int32, device=a.device)
+        rc = _lib.lib().sdfr_nn_loss_forward(_ptr(a), N, _ptr(b), M, _ptr(dist), _ptr(nearest), a.device.index,
+                                             _stream(a.device))
+        _lib.check(rc, "sdfr_nn_loss_forward")
+        ctx.save_for_backward(a, b, dist, nearest)
+        return dist
+
+    @staticmethod
+    def backward(ctx, grad_dist):
+        a, b, dist, nearest = ctx.saved_tensors
+        g_from, g_to = torch.empty_like(a), torch.empty_like(b)
+        rc = _lib.lib().sdfr_nn_loss_backward(_ptr(grad_dist.contiguous()), _ptr(a), a.shape[0], _ptr(b), b.shape[0],
+                                              _ptr(dist), _ptr(nearest), _ptr(g_from), _ptr(g_to), a.device.index,
+                                              _stream(a.device))
+        _lib.check(rc, "sdfr_nn_loss_backward")
+        return g_from, g_to
+
+
+def nn_loss(points_from: torch.Tensor, points_to: torch.Tensor) -> torch.Tensor:
+    """Squared distance from every point of ``points_from`` (N,3) to its nearest neighbour in
+    ``points_to`` (M,3), shape (N,) -- reference: losses.py:8-29, same expression
+    (-2 a.b + |a|^2 + |b|^2, negatives clamped to 0) and the gradient autograd gives it.  The
+    reference's loop never uses it (``loss_nn = 0``, simple_setup.py:147); D = 3 only."""
+    for t, n in ((points_from, "points_from"), (points_to, "points_to")):
+        _check_input(t, n)
+        if t.dim() != 2 or t.shape[1] != 3:
+            raise RuntimeError(f"{n} must have shape (N, 3)")
+    return _NNLoss.apply(points_from, points_to)
+
+
+class _PointConstraint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, orientation_q, source, target):
+        q, s, t = (x.detach().contiguous() for x in (orientation_q, source, target))
+        loss = torch.empty(1, dtype=torch.float32, device=q.device)
+        g_q = torch.zeros(4, dtype=torch.float32, device=q.device)
+        rc = _lib.lib().sdfr_point_constraint(_ptr(q), _ptr(s), _ptr(t), 1.0, _ptr(loss), _ptr(g_q), q.device.index,
+                                              _stream(q.device))
+        _lib.check(rc, "sdfr_point_constraint")
+        ctx.save_for_backward(g_q)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad):
+        (g_q,) = ctx.saved_tensors
+        return grad * g_q, None, None
+
+
+def point_constraint_loss(orientation_q: torch.Tensor, source: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """| quaternion_apply(orientation_q, source) - target |, a scalar (reference: losses.py:138-153).
+    quaternion_apply is q (v,0) conj(q): an un-normalised q also scales by |q|^2, as in the reference.
+    Differentiable w.r.t. orientation_q (4,); source, target (3,) are constants."""
+    for t, n, k in ((orientation_q, "orientation_q", 4), (source, "source", 3), (target, "target", 3)):
+        _check_input(t, n)
+        if tuple(t.shape) != (k,):
+            raise RuntimeError(f"{n} must have shape ({k},)")
+    return _PointConstraint.apply(orientation_q, source, target)

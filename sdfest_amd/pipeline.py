@@ -14,7 +14,37 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from .differentiable_renderer import Camera, render_depth_batch
-from .losses import pc_loss_batch
+from .losses import pc_loss_batch, point_constraint_loss
+
+
+def compute_inlier_ratio(depth_input: torch.Tensor, depth_estimate: torch.Tensor,
+                         relative_inlier_threshold: float = 0.03) -> torch.Tensor:
+    """Ratio of pixels with a small relative depth error (simple_setup.py:177-188), as the reference
+    writes it: a pixel without input depth divides by zero (inf or NaN, never below the threshold)."""
+    rel = torch.abs(depth_input - depth_estimate) / depth_input
+    return torch.count_nonzero(rel < relative_inlier_threshold) / torch.count_nonzero(depth_input)
+
+
+class _BestEstimate:
+    """simple_setup.py:190-211 and :583-596.  The reference keeps REFERENCES to the parameter tensors,
+    which Adam and the renormalisation then update in place -- so its ``best_inlier_ratio`` result is
+    the LAST iterate whatever the ratios were.  That is reproduced (`result()`); the snapshot one
+    would expect from the name is kept beside it (`snapshot`, with its 1-based `iteration`)."""
+
+    def __init__(self):
+        self.ratio, self.iteration, self.snapshot = None, None, None
+
+    def update(self, ratio, iteration, params):
+        if self.ratio is None or ratio > self.ratio:
+            self.ratio, self.iteration = ratio, iteration
+            self.snapshot = tuple(p.detach().clone() for p in params)
+
+
+def _selection_strategy(config: Dict) -> str:
+    strategy = config.get("result_selection_strategy", "last_iteration")
+    if strategy not in ("last_iteration", "best_inlier_ratio"):
+        raise ValueError(f"Result selection strategy {strategy} is not supported.")   # :592-596
+    return strategy
 
 
 # ---- quaternion helpers (scalar-last), reference: initialization/quaternion_utils.py:12-66 ------
@@ -101,10 +131,18 @@ class RenderAndCompare:
                  scale: torch.Tensor, latent: torch.Tensor,
                  camera_positions: Optional[torch.Tensor] = None,
                  camera_orientations: Optional[torch.Tensor] = None,
-                 shape_optimization: bool = True, history: Optional[List] = None):
+                 shape_optimization: bool = True, history: Optional[List] = None,
+                 point_constraint: Optional[Sequence] = None):
         """depth_images (V,H,W); position (1,3), orientation (1,4), scale (1,), latent (1,L): the
-        initial estimate (the reference gets it from its init network, out of scope here).
-        Returns the optimised (position, orientation, scale, latent)."""
+        initial estimate (the reference gets it from its init network).  point_constraint:
+        (source (3,), target (3,), weight) as in simple_setup.py:224, :164-175.
+        Returns the optimised (position, orientation, scale, latent); with
+        ``config["result_selection_strategy"] == "best_inlier_ratio"`` what the reference returns for
+        it (see :class:`_BestEstimate`); ``self.best`` holds the bookkeeping of the run.
+        ``nn_weight`` has no effect: the reference's ``loss_nn`` is the constant 0 (:147)."""
+        _selection_strategy(self.config)
+        rel_thr = self.config.get("relative_inlier_threshold", 0.03)
+        self.best = _BestEstimate()
         V = depth_images.shape[0]
         dev = self.device
         if camera_positions is None:
@@ -127,16 +165,29 @@ class RenderAndCompare:
             loss_depth, loss_pc, est = self.losses(depth_images, points, offsets, lens,
                                                    camera_positions, camera_orientations, position,
                                                    orientation, scale, sdf)
-            loss = self.config["depth_weight"] * loss_depth + self.config["pc_weight"] * loss_pc
+            if point_constraint is not None:   # on the un-normalised parameter, :164-175
+                src, tgt, wgt = point_constraint
+                loss_con = wgt * point_constraint_loss(orientation[0], src.to(dev, torch.float32),
+                                                       tgt.to(dev, torch.float32))
+            else:
+                loss_con = orientation.new_tensor(0.0)
+            loss = (self.config["depth_weight"] * loss_depth + self.config["pc_weight"] * loss_pc
+                    + loss_con)
             loss.backward()
             optimizer.step()
             with torch.no_grad():
                 orientation /= torch.sqrt(torch.sum(orientation ** 2))
+                # the reference passes the loop variables that survive its `for` over the views: the
+                # LAST view's input and estimate, rendered before this step (:463-470)
+                ratio = compute_inlier_ratio(depth_images[V - 1], est[V - 1].detach(), rel_thr)
+                self.best.update(ratio, it + 1, (position, orientation, scale, latent))
             if history is not None:
                 history.append({"loss": loss.detach(), "loss_depth": loss_depth.detach(),
-                                "loss_pc": loss_pc.detach(), "position": position.detach().clone(),
+                                "loss_pc": loss_pc.detach(), "loss_point_constraint": loss_con.detach(),
+                                "inlier_ratio": ratio, "position": position.detach().clone(),
                                 "orientation": orientation.detach().clone(),
                                 "scale": scale.detach().clone(), "latent": latent.detach().clone()})
+        # "best_inlier_ratio" returns the tensors the reference stored -- the live parameters (:583-596)
         return position.detach(), orientation.detach(), scale.detach(), latent.detach()
 
 
@@ -152,7 +203,11 @@ class FusedRenderAndCompare:
     def __init__(self, decoder, camera: Camera, config: Dict, depth_images: torch.Tensor,
                  camera_positions: Optional[torch.Tensor] = None,
                  camera_orientations: Optional[torch.Tensor] = None,
-                 shape_optimization: bool = True, device="cuda", fuse_depth_loss: bool = True):
+                 shape_optimization: bool = True, device="cuda", fuse_depth_loss: bool = True,
+                 point_constraint: Optional[Sequence] = None, track_inliers: Optional[bool] = None):
+        """point_constraint: (source (3,), target (3,), weight), simple_setup.py:164-175.
+        track_inliers: run the inlier-ratio bookkeeping of :177-211 every iteration (two small launches);
+        default: only for ``result_selection_strategy == "best_inlier_ratio"``."""
         from . import _lib
         from .differentiable_renderer import BatchRenderPlan
         # True: the depth-L1 runs inside the render kernels (sdfr_render_forward_l1 / _backward_l1) and the
@@ -210,6 +265,22 @@ class FusedRenderAndCompare:
                                       self.L.sdfr_decoder_backward_workspace_bytes(decoder._h, 1), 256), **u8)
         self.ws_loss = torch.empty(max(self.L.sdfr_depth_l1_workspace_bytes(V, W, H), 256), **u8)
         self.ws_pc = torch.empty(max(self.L.sdfr_pc_loss_backward_workspace_bytes(V, self.max_pts), 256), **u8)
+        self.strategy = _selection_strategy(config)
+        self.track_inliers = (self.strategy == "best_inlier_ratio") if track_inliers is None else bool(track_inliers)
+        self.rel_thr = float(config.get("relative_inlier_threshold", 0.03))
+        self.max_history = int(config["max_iterations"])
+        self.inlier_history = torch.zeros(max(self.max_history, 1), **f32)
+        self.inlier_counts = torch.zeros(2, dtype=torch.int32, device=self.dev)
+        self.best_state = torch.zeros(3, **f32)        # best ratio, its 1-based iteration, has_best
+        self.best_params = torch.zeros(n, **f32)
+        if point_constraint is not None:
+            src, tgt, wgt = point_constraint
+            self.pc_source = torch.as_tensor(src, dtype=torch.float32).to(self.dev).contiguous()
+            self.pc_target = torch.as_tensor(tgt, dtype=torch.float32).to(self.dev).contiguous()
+            self.pc_weight = float(wgt)
+        else:
+            self.pc_source = None
+        self.loss_con = torch.zeros(1, **f32)
         self.graph = None
 
     # views of the parameter buffer
@@ -298,6 +369,10 @@ class FusedRenderAndCompare:
                                              self.g_quat_pc.data_ptr() if have_pts else None,
                                              self.g_scale_pc.data_ptr() if have_pts else None,
                                              g, g + 12, g + 28, d, st), "sdfr_views_to_pose_grad")
+        if self.pc_source is not None:   # + the point constraint's gradient on the orientation parameter
+            self.check(L.sdfr_point_constraint(quat, self.pc_source.data_ptr(), self.pc_target.data_ptr(),
+                                               self.pc_weight, self.loss_con.data_ptr(), g + 12, d, st),
+                       "sdfr_point_constraint")
         if self.shape_opt:
             if have_pts:
                 self.check(L.sdfr_add_inplace(g_sdf.data_ptr(), self.g_sdf_pc.data_ptr(), g_sdf.numel(), d, st),
@@ -308,6 +383,15 @@ class FusedRenderAndCompare:
         self.check(L.sdfr_adam_step(p, g, self.m.data_ptr(), self.v.data_ptr(), self.step.data_ptr(),
                                     8 + self.Lz, 1e-3, 1e-2, 1e-3, 1e-2, int(self.shape_opt), d, st),
                    "sdfr_adam_step")
+        if self.track_inliers:
+            # :463-470 -- the LAST view's input and the estimate rendered before this step, against the
+            # parameters after it
+            est_last = self.plan.depth[self.V - 1]
+            self.check(L.sdfr_inlier_ratio(self.target[self.V - 1].data_ptr(), est_last.data_ptr(), self.W, self.H,
+                                           self.rel_thr, self.step.data_ptr(), self.inlier_counts.data_ptr(),
+                                           self.inlier_history.data_ptr(), self.max_history,
+                                           self.best_state.data_ptr(), p, 8 + self.Lz,
+                                           self.best_params.data_ptr(), d, st), "sdfr_inlier_ratio")
 
     def __call__(self, position, orientation, scale, latent, use_graph: bool = True,
                  history: Optional[List] = None):
@@ -319,23 +403,26 @@ class FusedRenderAndCompare:
             self.params[7:8] = scale.reshape(1)
             self.params[8:] = latent.reshape(-1)
             self.m.zero_(); self.v.zero_(); self.step.zero_(); self.grads.zero_()
+            self.inlier_counts.zero_(); self.best_state.zero_(); self.inlier_history.zero_()
         if not self.shape_opt:
             self._decode(self._stream(), False)
         n_iter = self.cfg["max_iterations"]
         if use_graph and self.graph is None:
             # warm up on a side stream (lazy module loads), restore the state, then capture
-            saved = [t.clone() for t in (self.params, self.m, self.v, self.step)]
+            state = (self.params, self.m, self.v, self.step, self.inlier_counts, self.best_state,
+                     self.inlier_history, self.best_params)
+            saved = [t.clone() for t in state]
             s = torch.cuda.Stream(self.dev)
             s.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(s):
                 self.iteration()
             torch.cuda.current_stream(self.dev).wait_stream(s)
-            for t, c in zip((self.params, self.m, self.v, self.step), saved):
+            for t, c in zip(state, saved):
                 t.copy_(c)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.iteration()
-            for t, c in zip((self.params, self.m, self.v, self.step), saved):
+            for t, c in zip(state, saved):
                 t.copy_(c)   # the capture itself does not execute, but keep the state explicit
         for _ in range(n_iter):
             if use_graph:
@@ -344,9 +431,21 @@ class FusedRenderAndCompare:
                 self.iteration()
             if history is not None:
                 history.append({"loss": (self.cfg["depth_weight"] * self.loss_depth.sum()
-                                         + self.cfg["pc_weight"] * self.loss_pc.sum()).clone(),
+                                         + self.cfg["pc_weight"] * self.loss_pc.sum()
+                                         + self.loss_con.sum()).clone(),
                                 "position": self.position.clone()[None],
                                 "orientation": self.orientation.clone()[None],
                                 "scale": self.scale.clone(), "latent": self.latent.clone()[None]})
+        # "best_inlier_ratio": the reference returns the parameter tensors themselves, i.e. the last
+        # iterate (_BestEstimate); the snapshot taken at the best ratio is in best_estimate()
         return (self.position.clone()[None], self.orientation.clone()[None], self.scale.clone(),
                 self.latent.clone()[None])
+
+    def best_estimate(self):
+        """(ratio, 1-based iteration, (position, orientation, scale, latent)) at the best inlier ratio of the
+        last run (strictly greater wins, the first counts: simple_setup.py:203-210); needs track_inliers."""
+        ratio, it, has = self.best_state.tolist()
+        if not has:
+            return None
+        bp = self.best_params
+        return ratio, int(it), (bp[0:3].clone()[None], bp[3:7].clone()[None], bp[7:8].clone(), bp[8:].clone()[None])

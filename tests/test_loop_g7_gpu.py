@@ -1,0 +1,155 @@
+"""GPU: the render-and-compare loop against G7 -- iterations of simple_setup.py:381-470
+assembled from IMPORTED reference pieces (numpy twin renderer + its reduction, losses.pc_loss,
+losses.point_constraint_loss, quaternion_utils, SDFVAE.decode with the mug weights, torch.optim.Adam)
+by tools/make_goldens.py::make_loop_g7 -> tests/golden/loop_g7.npz.  Run A: 2 views with camera
+extrinsics, shape optimisation on; run B: 1 view, point constraint, shape optimisation off.
+Checked per iteration: parameters, first-iteration gradients, loss terms, the inlier ratio of the LAST
+view's loop variables (:463-470); plus nn_loss / point_constraint_loss on seeded inputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g7():
+    d = np.load(os.path.join(GOLDEN, "loop_g7.npz"))
+    return {k: d[k] for k in d.files}
+
+
+@pytest.fixture(scope="module")
+def mug():
+    from sdfest_amd import SDFDecoder
+    from test_decoder_gpu import mug_config
+    d = np.load(os.path.join(GOLDEN, "decoder_mug.npz"))
+    w = np.load(os.path.join(GOLDEN, "mug_decoder_weights.npz"))
+    return SDFDecoder.from_config(mug_config(d), {k: w[k] for k in w.files})
+
+
+def _setup(g7, tag):
+    from sdfest_amd import Camera
+    W, H = int(g7["W"]), int(g7["H"])
+    cam = Camera(W, H, float(g7["fx"]), float(g7["fy"]), float(g7["cx"]), float(g7["cy"]), pixel_center=0.5)
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device="cuda")
+    init = g7[f"{tag}_init"]
+    n_iter = g7[f"{tag}_traj"].shape[0]
+    cfg = {"threshold": float(g7["thr"]), "max_iterations": n_iter, "depth_weight": 1.0, "pc_weight": 3.0,
+           "nn_weight": 0.0, "result_selection_strategy": "best_inlier_ratio"}
+    args = dict(depth=t(g7[f"{tag}_depth_images"]), cam_pos=t(g7[f"{tag}_cam_pos"]), cam_quat=t(g7[f"{tag}_cam_quat"]),
+                p0=t(init[None, 0:3]), q0=t(init[None, 3:7]), s0=t(init[7:8]), z0=t(init[None, 8:]))
+    con = None
+    if tag == "b":
+        con = (t(g7["b_constraint_source"]), t(g7["b_constraint_target"]), float(g7["b_constraint_weight"]))
+    return cam, cfg, args, con
+
+
+def _check_trajectory(g7, tag, hist, tol_scale=1.0):
+    traj, terms, inl = g7[f"{tag}_traj"], g7[f"{tag}_terms"], g7[f"{tag}_inlier"]
+    for it in range(traj.shape[0]):
+        h = hist[it]
+        got = np.concatenate([h["position"].cpu().numpy().ravel(), h["orientation"].cpu().numpy().ravel(),
+                              h["scale"].cpu().numpy().ravel(), h["latent"].cpu().numpy().ravel()])
+        # Adam's steps are ~lr (1e-3 position / scale, 1e-2 orientation / latent): agree to 2 % of a step per
+        # iteration (the twin marches in float64, the kernels in fp32; a pixel on the hit threshold moves a mean)
+        lr = np.array([1e-3] * 3 + [1e-2] * 4 + [1e-3] + [1e-2] * (len(got) - 8))
+        err = np.abs(got - traj[it]) / lr
+        assert err.max() < 0.02 * (it + 1) * tol_scale, (tag, it, err)
+        if "loss" in h:
+            assert abs(float(h["loss"]) - terms[it, 3]) < 2e-4 * abs(terms[it, 3]) + 1e-6, (tag, it)
+        if "inlier_ratio" in h:
+            assert abs(float(h["inlier_ratio"]) - inl[it]) < 2.5 / 300.0, (tag, it, float(h["inlier_ratio"]), inl[it])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_autograd_loop_matches_g7(g7, mug, tag):
+    from sdfest_amd.pipeline import RenderAndCompare
+    cam, cfg, a, con = _setup(g7, tag)
+    loop = RenderAndCompare(mug, cam, cfg)
+    hist = []
+    out = loop(a["depth"], a["p0"], a["q0"], a["s0"], a["z0"], camera_positions=a["cam_pos"],
+               camera_orientations=a["cam_quat"], shape_optimization=(tag == "a"), history=hist,
+               point_constraint=con)
+    _check_trajectory(g7, tag, hist)
+    terms = g7[f"{tag}_terms"]
+    for it, h in enumerate(hist):
+        assert abs(float(h["loss_depth"]) - terms[it, 0]) < 3e-4 * terms[it, 0]
+        assert abs(float(h["loss_pc"]) - terms[it, 1]) < 3e-4 * terms[it, 1]
+        assert abs(float(h["loss_point_constraint"]) - terms[it, 2]) < 1e-5 + 1e-5 * terms[it, 2]
+    # best_inlier_ratio: the reference hands back the tensors it stored -- the live parameters, i.e. the last
+    # iterate -- while the ratio that won may belong to an earlier iteration
+    assert torch.equal(out[0], hist[-1]["position"]) and torch.equal(out[3], hist[-1]["latent"])
+    inl = g7[f"{tag}_inlier"]
+    best_it = int(np.argmax(inl)) + 1        # strictly greater wins: the first maximum
+    assert loop.best.iteration == best_it or abs(float(loop.best.ratio) - inl.max()) < 2.5 / 300.0
+    if tag == "b":
+        assert torch.equal(out[3], a["z0"])      # shape optimisation off: the latent does not move
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_fused_loop_matches_g7(g7, mug, tag, use_graph):
+    from sdfest_amd.pipeline import FusedRenderAndCompare
+    cam, cfg, a, con = _setup(g7, tag)
+    loop = FusedRenderAndCompare(mug, cam, cfg, a["depth"], camera_positions=a["cam_pos"],
+                                 camera_orientations=a["cam_quat"], shape_optimization=(tag == "a"),
+                                 point_constraint=con)
+    hist = []
+    out = loop(a["p0"], a["q0"], a["s0"], a["z0"], use_graph=use_graph, history=hist)
+    torch.cuda.synchronize()
+    _check_trajectory(g7, tag, hist)
+    inl = g7[f"{tag}_inlier"]
+    got = loop.inlier_history.cpu().numpy()[:len(inl)]
+    assert np.max(np.abs(got - inl)) < 2.5 / 300.0, (got, inl)
+    ratio, it, params = loop.best_estimate()
+    assert abs(ratio - got.max()) < 1e-7 and it == int(np.argmax(got)) + 1
+    # the snapshot is the parameter vector after iteration `it`
+    assert torch.equal(params[0], hist[it - 1]["position"]) and torch.equal(params[1], hist[it - 1]["orientation"])
+    assert torch.equal(out[0], hist[-1]["position"])
+
+
+def test_first_gradient_matches_g7(g7, mug):
+    """Iteration 1 of run A before Adam: d loss / d (position, orientation, scale, latent) as autograd gave
+    them to the reference pieces (the chain through both cameras, the normalisation and the decoder)."""
+    from sdfest_amd.pipeline import RenderAndCompare
+    cam, cfg, a, _ = _setup(g7, "a")
+    loop = RenderAndCompare(mug, cam, cfg)
+    p, q, s, z = (x.clone().requires_grad_() for x in (a["p0"], a["q0"], a["s0"], a["z0"]))
+    points, offsets, lens = loop.prepare_views(a["depth"])
+    sdf = mug.decode(z)[0, 0]
+    ld, lp, _ = loop.losses(a["depth"], points, offsets, lens, a["cam_pos"], a["cam_quat"], p, q, s, sdf)
+    (1.0 * ld + 3.0 * lp).backward()
+    got = np.concatenate([x.grad.cpu().numpy().ravel() for x in (p, q, s, z)])
+    ref = g7["a_grads"][0]
+    scale = np.array([np.abs(ref[0:3]).max()] * 3 + [np.abs(ref[3:7]).max()] * 4 + [abs(ref[7])]
+                     + [np.abs(ref[8:]).max()] * (len(ref) - 8))
+    assert np.all(np.abs(got - ref) < 2e-3 * scale), (got, ref)
+
+
+def test_nn_loss_matches_reference(g7):
+    from sdfest_amd import nn_loss
+    t = lambda a: torch.tensor(a, device="cuda")
+    a, b = t(g7["nn_from"]).requires_grad_(), t(g7["nn_to"]).requires_grad_()
+    d = nn_loss(a, b)
+    mag = (g7["nn_from"] ** 2).sum(1) + 1.0
+    assert np.all(np.abs(d.detach().cpu().numpy() - g7["nn_d"]) < 2e-6 * mag)
+    d.backward(t(g7["nn_gout"]))
+    assert np.allclose(a.grad.cpu().numpy(), g7["nn_gfrom"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(b.grad.cpu().numpy(), g7["nn_gto"], rtol=1e-5, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        nn_loss(a.detach().cpu(), b.detach())
+
+
+def test_point_constraint_loss_matches_reference(g7):
+    from sdfest_amd import point_constraint_loss
+    for i in range(len(g7["pcl_value"])):
+        q = torch.tensor(g7["pcl_q"][i], dtype=torch.float32, device="cuda", requires_grad=True)
+        v = point_constraint_loss(q, torch.tensor(g7["pcl_src"][i], dtype=torch.float32, device="cuda"),
+                                  torch.tensor(g7["pcl_tgt"][i], dtype=torch.float32, device="cuda"))
+        v.backward()
+        assert abs(v.item() - g7["pcl_value"][i]) < 1e-5 * (1 + abs(g7["pcl_value"][i]))
+        assert np.allclose(q.grad.cpu().numpy(), g7["pcl_gq"][i], rtol=2e-5, atol=1e-5)
