@@ -294,6 +294,13 @@ SDFR_API int sdfr_nn_loss_backward(const float* grad_dist, const float* points_f
                           const float* points_to, int M, const float* dist, const int* nearest,
                           float* g_from, float* g_to, int device, void* stream);
 
+/* generated_dataset.py:234-245 -- perturbed mask of the view generator: mask[b][i][j] = 1 where the
+ * input pixel nearest to M_b (j + 0.5 - W/2, i + 0.5 - H/2, 1) + (W/2 - 0.5, H/2 - 0.5) has depth != 0
+ * (0 outside the image); matrices[B][6] = the row-major 2x3 INVERSE affine maps in pixels about the image
+ * centre (what torchvision's RandomAffine hands to grid_sample(nearest, align_corners=False)). */
+SDFR_API int sdfr_affine_mask(const float* depth, int B, int W, int H, const float* matrices,
+                     unsigned char* mask, int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

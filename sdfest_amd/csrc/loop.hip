@@ -239,6 +239,31 @@ __global__ __launch_bounds__(256) void nn_loss_backward_kernel(const float* __re
   if (g_from) { g_from[3 * i] = gx; g_from[3 * i + 1] = gy; g_from[3 * i + 2] = gz; }
 }
 
+// ---------------------------------------------------------------------------------------------
+// generated_dataset.py:234-245 -- the mask perturbation of the synthetic-view generator: a random
+// affine map of the exact mask (depth != 0), nearest neighbour, zeros outside.  The reference calls
+// torchvision's RandomAffine, which for tensors is an inverse affine matrix about the image centre
+// applied to the pixel-centre grid and torch's grid_sample(mode = nearest, align_corners = False):
+// output pixel (row i, col j) takes the input pixel nearest to m (j + 0.5 - W/2, i + 0.5 - H/2, 1)
+// + (W/2 - 0.5, H/2 - 0.5), rounding half to even.  One thread per output pixel, grid.y = view.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void affine_mask_kernel(const float* __restrict__ depth, int W, int H,
+                                                          const float* __restrict__ matrices,
+                                                          unsigned char* __restrict__ mask) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= W * H) return;
+  const float* m = matrices + 6 * b;
+  const float xo = (float)(i % W) + 0.5f - 0.5f * (float)W, yo = (float)(i / W) + 0.5f - 0.5f * (float)H;
+  const float xs = fmaf(m[0], xo, fmaf(m[1], yo, m[2])) + (0.5f * (float)W - 0.5f);
+  const float ys = fmaf(m[3], xo, fmaf(m[4], yo, m[5])) + (0.5f * (float)H - 0.5f);
+  const float cx = rintf(xs), cy = rintf(ys);
+  bool on = false;
+  if (cx >= 0.0f && cx <= (float)(W - 1) && cy >= 0.0f && cy <= (float)(H - 1))
+    on = depth[(size_t)b * W * H + (size_t)cy * W + (size_t)cx] != 0.0f;
+  mask[(size_t)b * W * H + i] = on ? 1 : 0;
+}
+
 constexpr int kLossChunk = 4096;  // pixels per workgroup of the depth-loss reduction
 
 // pass 1: per (view, chunk) the sum of |est - tgt| and the count over the overlap mask
@@ -594,6 +619,19 @@ extern "C" int sdfr_nn_loss_backward(const float* grad_dist, const float* points
     return fail(SDFR_E_NULL, "sdfr_nn_loss_backward: NULL pointer argument");
   hipLaunchKernelGGL(nn_loss_backward_kernel, dim3((N + 255) / 256), dim3(256), 0, st, grad_dist, points_from, N,
                      points_to, dist, nearest, g_from, g_to);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfr_affine_mask(const float* depth, int B, int W, int H, const float* matrices,
+                                unsigned char* mask, int device, void* stream) {
+  if (B < 0 || W < 0 || H < 0 || B > 65535 || (long long)W * H > 0x7fffffffLL)
+    return fail(SDFR_E_INVALID, "sdfr_affine_mask: bad sizes");
+  if (B == 0 || W == 0 || H == 0) return 0;
+  if (!depth || !matrices || !mask) return fail(SDFR_E_NULL, "sdfr_affine_mask: NULL pointer argument");
+  SDFR_HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(affine_mask_kernel, dim3((unsigned)((W * H + 255) / 256), (unsigned)B), dim3(256), 0,
+                     (hipStream_t)stream, depth, W, H, matrices, mask);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }

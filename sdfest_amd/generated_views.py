@@ -10,8 +10,14 @@ here a whole batch goes through one batched decode and ONE render launch with on
 Random numbers: the reference draws from Python's ``random`` and ``torch.randn``; this module
 draws the same distributions from one ``torch.Generator`` (reproducible from a seed).  Every
 sampled quantity can also be passed in, which is how the tests compare with per-sample calls.
-Not covered: ``mask_noise`` (torchvision.RandomAffine) and ``orientation_repr="discretized"``
-(SO3Grid/healpy) -- both raise NotImplementedError.
+``mask_noise`` (generated_dataset.py:234-245, :286-291): the reference perturbs the exact mask with
+torchvision's ``RandomAffine(degrees=(0, 1), translate=(0.00, 0.01), scale=(0.999, 1.001))``
+(torchvision==0.12.0, requirements.txt:148 -- not in this image, not under /root/reference).  Its
+published algorithm is restated: the parameter distributions of ``RandomAffine.get_params``, the
+inverse matrix of ``functional._get_inverse_affine_matrix`` and the nearest-neighbour resampling of
+``functional_tensor.affine`` (= torch's ``grid_sample``), the last as one HIP kernel
+(``sdfr_affine_mask``) pinned against ``torch.nn.functional.grid_sample``.
+``orientation_repr="discretized"`` (:169-175, :358-360): :mod:`sdfest_amd.so3grid`.
 """
 import math
 from typing import Dict, List, Optional
@@ -25,7 +31,8 @@ from .differentiable_renderer import BatchRenderPlan, Camera
 DEFAULT_CONFIG = {
     "width": 640, "height": 480, "fov_deg": 90, "render_threshold": 0.004,
     "pointcloud": True, "normalize_pose": None, "orientation_repr": "quaternion",
-    "mask_noise": False, "norm_noise": False, "norm_noise_min": -0.2, "norm_noise_max": 0.2,
+    "mask_noise": False, "mask_noise_min": 0.1, "mask_noise_max": 2.0, "orientation_grid_resolution": 2,
+    "norm_noise": False, "norm_noise_min": -0.2, "norm_noise_max": 0.2,
     "scale_to_unit_ball": False, "gaussian_noise_probability": 0.0,
     "gaussian_noise_kernel_size": 5, "gaussian_noise_kernel_std": 1,
 }
@@ -53,6 +60,48 @@ def sample_poses(n: int, camera: Camera, z_min: float, z_max: float, extent_mean
     position = torch.stack((x_pix / camera.fx * z, y_pix / camera.fy * z, -z), 1).float()
     scale = (extent_mean + extent_std * torch.randn(n, generator=gen, dtype=torch.float64)) / 2.0
     return position, sample_uniform_quaternions(n, gen), scale.float()
+
+
+def inverse_affine_matrices(angle_deg: torch.Tensor, translate: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """(n,6) row-major 2x3 inverse affine maps about the image centre, in pixels, no shear:
+    torchvision 0.12 ``functional._get_inverse_affine_matrix(center=[0, 0], angle, translate, scale,
+    shear=[0, 0])`` -- rotation by ``angle`` degrees, then the inverse translation."""
+    rot = angle_deg.double() * (math.pi / 180.0)
+    a, b, c, d = torch.cos(rot), -torch.sin(rot), torch.sin(rot), torch.cos(rot)
+    sc = scale.double()
+    m0, m1, m3, m4 = d / sc, -b / sc, -c / sc, a / sc
+    tx, ty = translate[:, 0].double(), translate[:, 1].double()
+    m2 = m0 * (-tx) + m1 * (-ty)
+    m5 = m3 * (-tx) + m4 * (-ty)
+    return torch.stack((m0, m1, m2, m3, m4, m5), 1).float()
+
+
+def sample_mask_affine(n: int, width: int, height: int, gen: Optional[torch.Generator] = None):
+    """``RandomAffine.get_params`` for degrees=(0, 1), translate=(0.00, 0.01), scale=(0.999, 1.001)
+    (generated_dataset.py:242-244): angle ~ U(0, 1) degrees, whole-pixel shifts round(U(-t W, t W)),
+    round(U(-t H, t H)), scale ~ U(0.999, 1.001).  Returns (angle (n,), translate (n,2), scale (n,))."""
+    u = torch.rand((n, 4), generator=gen, dtype=torch.float64)
+    angle = u[:, 0] * 1.0
+    max_dx, max_dy = 0.00 * width, 0.01 * height
+    translate = torch.stack((torch.round(-max_dx + 2 * max_dx * u[:, 1]), torch.round(-max_dy + 2 * max_dy * u[:, 2])), 1)
+    scale = 0.999 + 0.002 * u[:, 3]
+    return angle, translate, scale
+
+
+def perturb_masks(depth: torch.Tensor, matrices: torch.Tensor) -> torch.Tensor:
+    """(B,H,W) bool: the exact masks ``depth != 0`` under the inverse affine maps ``matrices`` (B,6),
+    nearest neighbour, False outside (generated_dataset.py:234-245 on a batch)."""
+    from . import _lib
+    B, H, W = depth.shape
+    dev = depth.device
+    depth = depth.contiguous()
+    m = matrices.to(device=dev, dtype=torch.float32).contiguous()
+    if tuple(m.shape) != (B, 6):
+        raise RuntimeError(f"matrices must have shape ({B}, 6)")
+    out = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib().sdfr_affine_mask(depth.data_ptr(), B, W, H, m.data_ptr(), out.data_ptr(), dev.index,
+                                           torch.cuda.current_stream(dev).cuda_stream), "sdfr_affine_mask")
+    return out.bool()
 
 
 def gaussian_kernel(std: float, kernel_size: int) -> torch.Tensor:
@@ -134,9 +183,10 @@ class SDFVAEViewGenerator:
         for k in ("z_min", "z_max", "extent_mean", "extent_std"):
             if k not in cfg:
                 raise KeyError(f"config key {k!r} is required")
-        if cfg["mask_noise"]:
-            raise NotImplementedError("mask_noise (torchvision RandomAffine) is not covered")
-        if cfg["orientation_repr"] != "quaternion":
+        if cfg["orientation_repr"] == "discretized":                                 # :169-172
+            from .so3grid import SO3Grid
+            self.orientation_grid = SO3Grid(cfg["orientation_grid_resolution"])
+        elif cfg["orientation_repr"] != "quaternion":
             raise NotImplementedError(f"Orientation representation {cfg['orientation_repr']} is not supported.")
         self.cfg = cfg
         self.decoder = decoder
@@ -163,8 +213,10 @@ class SDFVAEViewGenerator:
             return self.plan.forward(sdf, position.to(**f32).contiguous(), quaternion.to(**f32).contiguous(),
                                      (1.0 / scale.to(**f32)).contiguous(), self.cfg["render_threshold"], out=out)
 
-    def generate(self, latent=None, position=None, quaternion=None, scale=None, smooth=None) -> Dict:
-        """One batch of samples; any of the sampled quantities may be given instead of drawn.
+    def generate(self, latent=None, position=None, quaternion=None, scale=None, smooth=None,
+                 mask_affine=None, mask_noise_value=None) -> Dict:
+        """One batch of samples; any of the sampled quantities may be given instead of drawn
+        (mask_affine: (angle (B,), translate (B,2), scale (B,)); mask_noise_value: (B,) background depth).
 
         Returns a dict of batched tensors with the reference's keys: "depth" (B,H,W),
         "latent_shape" (B,L), "position" (B,3), "orientation" = "quaternion" (B,4), "scale" (B,),
@@ -180,10 +232,22 @@ class SDFVAEViewGenerator:
         scale = (s if scale is None else scale).to(dev).clone()
         depth = self.render(latent, position, quaternion, scale,
                             out=torch.empty((B, cfg["height"], cfg["width"]), dtype=torch.float32, device=dev))
+        final_mask = None
+        if cfg["mask_noise"]:                                                          # :286-291
+            if mask_affine is None:
+                mask_affine = sample_mask_affine(B, cfg["width"], cfg["height"], self.gen)
+            final_mask = perturb_masks(depth, inverse_affine_matrices(*mask_affine))
+            if mask_noise_value is None:
+                lo, hi = cfg["mask_noise_min"], cfg["mask_noise_max"]
+                mask_noise_value = lo + (hi - lo) * torch.rand(B, generator=self.gen)
+            # depth[~exact_mask] = one background depth per sample
+            depth = torch.where(depth != 0, depth, mask_noise_value.to(depth)[:, None, None].expand_as(depth)).contiguous()
         if cfg["gaussian_noise_probability"] > 0.0:                                    # :296-308
             if smooth is None:
                 smooth = torch.rand(B, generator=self.gen) < cfg["gaussian_noise_probability"]
             smooth_depth(depth, self.kernel, smooth)
+        if final_mask is not None:
+            depth = (depth * final_mask).contiguous()                                  # :310  depth[~final_mask] = 0
         out = {"depth": depth, "latent_shape": latent.to(dev)}
         if cfg["pointcloud"]:                                                          # :312-334
             pts, counts = depth_to_pointsets(depth, self.camera)
@@ -212,6 +276,9 @@ class SDFVAEViewGenerator:
             out["valid"] = depth.amax(dim=(1, 2)) != 0
         out["position"], out["scale"] = position, scale
         out["quaternion"] = out["orientation"] = quaternion
+        if cfg["orientation_repr"] == "discretized":                                   # :358-360
+            index = self.orientation_grid.quat_to_index(quaternion.detach().cpu().numpy().astype(np.float64))
+            out["orientation"] = torch.as_tensor(np.atleast_1d(index), device=dev, dtype=torch.long)
         return out
 
     def samples(self, out: Dict) -> List[Dict]:

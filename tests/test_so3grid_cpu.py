@@ -1,0 +1,87 @@
+"""CPU: the SO(3) grid (sdfest_amd/so3grid.py) -- the known answers of the reference's own suite
+(tests/initilization/test_so3grid.py) and the defining properties of the HEALPix NESTED pixelisation that
+healpy (absent from the image) supplies to the reference."""
+import numpy as np
+import pytest
+
+from sdfest_amd.so3grid import SO3Grid, ang2pix_nest, pix2ang_nest
+
+
+def test_num_cells():                                         # test_so3grid.py:6-20
+    for r in (0, 1, 2):
+        assert SO3Grid(r).num_cells() == 6 * 12 * 2 ** (3 * r)
+
+
+def test_hopf_to_quat_conversion():                           # test_so3grid.py:23-45
+    assert (SO3Grid._hopf_to_quat(0, 0, 0) == np.array([0, 0, 0, 1])).all()
+    np.testing.assert_allclose(SO3Grid._hopf_to_quat(0.3, 0.4, 0.2),
+                               np.array([0.1464593191, 0.1866245482, 0.06812327794, 0.9690614866]))
+    quat_direct = np.array([-0.06218820609, 0.8541691906, 0.311796094, -0.4114739562])
+    np.testing.assert_allclose(SO3Grid._hopf_to_quat(0.3, 4, 0.2), -quat_direct)
+
+
+def test_quat_hopf_conversions():                             # test_so3grid.py:48-71
+    quat = np.array([0.3, 0.2, 0.6, 1])
+    quat /= np.linalg.norm(quat)
+    np.testing.assert_allclose(quat, SO3Grid._hopf_to_quat(*SO3Grid._quat_to_hopf(quat)))
+    hopf = (0.3, 0.1, 0.2)
+    np.testing.assert_allclose(hopf, SO3Grid._quat_to_hopf(SO3Grid._hopf_to_quat(*hopf)))
+
+
+def test_indices():                                           # test_so3grid.py:74-110
+    grid = SO3Grid(0)
+    assert grid.hopf_to_index(*grid.index_to_hopf(10)) == 10
+    assert grid.quat_to_index(grid.index_to_quat(30)) == 30
+    psi, theta, phi = grid.index_to_hopf(15)
+    assert grid.hopf_to_index(psi + 0.11, theta - 0.11, phi + 0.12) == 15
+
+
+@pytest.mark.parametrize("resol", [0, 1, 2, 3])
+def test_every_cell_round_trips_and_vectorises(resol):
+    grid = SO3Grid(resol)
+    idx = np.arange(grid.num_cells())
+    q = grid.index_to_quat(idx)
+    assert q.shape == (grid.num_cells(), 4) and np.allclose(np.linalg.norm(q, axis=1), 1.0)
+    assert np.all(q[:, 0] >= 0)
+    assert np.array_equal(grid.quat_to_index(q), idx)
+    assert grid.quat_to_index(q[17]) == 17 and isinstance(grid.quat_to_index(q[17]), int)
+
+
+def test_healpix_base_pixels():
+    """N_side = 1: the 12 base-pixel centres (Gorski et al. 2005, fig. 4): z = 2/3, 0, -2/3."""
+    theta, phi = pix2ang_nest(1, np.arange(12))
+    np.testing.assert_allclose(np.cos(theta), [2 / 3] * 4 + [0] * 4 + [-2 / 3] * 4, atol=1e-15)
+    np.testing.assert_allclose(phi, [np.pi / 4 + k * np.pi / 2 for k in range(4)] + [k * np.pi / 2 for k in range(4)]
+                               + [np.pi / 4 + k * np.pi / 2 for k in range(4)], atol=1e-15)
+
+
+@pytest.mark.parametrize("nside", [1, 2, 4, 8, 16, 64])
+def test_healpix_round_trip_rings_and_nesting(nside):
+    npix = 12 * nside * nside
+    pix = np.arange(npix)
+    theta, phi = pix2ang_nest(nside, pix)
+    assert np.array_equal(ang2pix_nest(nside, theta, phi), pix)
+    # iso-latitude rings: 4 nside - 1 distinct z values, symmetric, 4 i pixels on ring i of a cap
+    z = np.round(np.cos(theta), 12)
+    rings, counts = np.unique(z, return_counts=True)
+    assert len(rings) == 4 * nside - 1 and np.allclose(rings, -rings[::-1])
+    assert np.array_equal(counts[::-1][:nside], 4 * np.arange(1, nside + 1))
+    assert np.all(counts[nside - 1:3 * nside] == 4 * nside)
+    # NESTED: the 4 children of pixel p at 2 nside are 4p .. 4p+3
+    t2, p2 = pix2ang_nest(2 * nside, np.arange(4 * npix))
+    assert np.array_equal(ang2pix_nest(nside, t2, p2), np.arange(4 * npix) // 4)
+
+
+def test_healpix_equal_area():
+    rng = np.random.default_rng(0)
+    n = 2_000_000
+    theta, phi = np.arccos(rng.uniform(-1, 1, n)), rng.uniform(0, 2 * np.pi, n)
+    for nside in (2, 8):
+        npix = 12 * nside * nside
+        c = np.bincount(ang2pix_nest(nside, theta, phi), minlength=npix)
+        assert c.shape == (npix,)
+        mean = n / npix
+        assert np.all(np.abs(c - mean) < 6 * np.sqrt(mean))      # 6 sigma of a Poisson count
+    # and a point stays in its pixel under a small displacement away from the pixel's border
+    t, p = pix2ang_nest(8, np.arange(768))
+    assert np.array_equal(ang2pix_nest(8, t + 1e-3, p + 1e-3), np.arange(768))
