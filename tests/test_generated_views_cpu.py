@@ -66,11 +66,30 @@ def test_batched_back_projection_equals_per_view():
 def test_unsupported_options_raise():
     import pytest
     base = {"z_min": 0.3, "z_max": 1.0, "extent_mean": 0.2, "extent_std": 0.02}
-    with pytest.raises(NotImplementedError):
-        gv.SDFVAEViewGenerator({**base, "mask_noise": True}, None)
-    with pytest.raises(NotImplementedError):
-        gv.SDFVAEViewGenerator({**base, "orientation_repr": "discretized"}, None)
+    with pytest.raises(NotImplementedError):    # generated_dataset.py:361-364
+        gv.SDFVAEViewGenerator({**base, "orientation_repr": "euler"}, None)
     with pytest.raises(KeyError):
         gv.SDFVAEViewGenerator({"z_min": 0.3}, None)
     with pytest.raises(ValueError):
         gv.gaussian_kernel(1.0, 4)
+
+
+def test_mask_affine_parameters_and_matrices():
+    """RandomAffine.get_params for degrees=(0,1), translate=(0,0.01), scale=(0.999,1.001) at 640x480 and
+    the inverse matrix about the image centre (torchvision functional._get_inverse_affine_matrix)."""
+    import math
+    g = torch.Generator().manual_seed(0)
+    angle, translate, scale = gv.sample_mask_affine(4000, 640, 480, g)
+    assert angle.min() >= 0 and angle.max() <= 1 and abs(angle.mean().item() - 0.5) < 0.03
+    assert torch.all(translate[:, 0] == 0)                           # 0.00 * width
+    assert torch.all(translate[:, 1] == translate[:, 1].round()) and translate[:, 1].abs().max() == 5   # round(U(-4.8, 4.8))
+    assert scale.min() >= 0.999 and scale.max() <= 1.001
+    m = gv.inverse_affine_matrices(torch.tensor([0.0, 90.0, 30.0]), torch.tensor([[3.0, -2.0], [0.0, 0.0], [1.0, 4.0]]),
+                                   torch.tensor([1.0, 2.0, 0.5])).double()
+    assert torch.allclose(m[0], torch.tensor([1.0, 0, -3, 0, 1, 2]).double())          # inverse of a shift
+    assert torch.allclose(m[1], torch.tensor([0.0, 0.5, 0, -0.5, 0, 0]).double(), atol=1e-7)
+    # the forward map (rotate by +angle: [[c, -s], [s, c]], scale, then shift) composed with it is the identity
+    c, s_ = math.cos(math.radians(30.0)), math.sin(math.radians(30.0))
+    fwd = torch.tensor([[0.5 * c, -0.5 * s_, 1.0], [0.5 * s_, 0.5 * c, 4.0], [0, 0, 1]]).double()
+    inv = torch.cat([m[2].reshape(2, 3), torch.tensor([[0.0, 0, 1]]).double()])
+    assert torch.allclose(inv @ fwd, torch.eye(3).double(), atol=1e-6)
