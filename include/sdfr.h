@@ -301,6 +301,32 @@ SDFR_API int sdfr_nn_loss_backward(const float* grad_dist, const float* points_f
 SDFR_API int sdfr_affine_mask(const float* depth, int B, int W, int H, const float* matrices,
                      unsigned char* mask, int device, void* stream);
 
+/* ---- initialisation network forward: sdfest/initialization/pointnet.py:7-96,
+ * sdf_pose_network.py:9-115, estimation/simple_setup.py:795-812 ------------------------------------ */
+
+/* one per-point layer of VanillaPointNet on a set of M points, inference mode:
+ *   Y = relu((X W[:, :cin]^T + cvec) * bn_scale + bn_shift);   y = resid ? resid + Y : Y  (y may be NULL);
+ *   colmax[col] = max over the points of Y[:, col]  (written, cout floats).
+ * x [M][ldx], w [cout][ldw] as torch stores nn.Linear.weight, y / resid [M][ldy].  bn_scale / bn_shift are
+ * the folded BatchNorm1d (gamma / sqrt(var + eps), beta - mean * scale; 1 and 0 without batch norm).
+ * A dense link's concatenated set maximum enters through cvec = bias + W[:, cin:] . max (sdfr_linear_vec). */
+SDFR_API int sdfr_pointnet_layer(const float* x, int M, int cin, int ldx, const float* w, int ldw,
+                        const float* cvec, const float* bn_scale, const float* bn_shift,
+                        const float* resid, float* y, int ldy, int cout, float* colmax, int device,
+                        void* stream);
+
+/* y[cout] = act((W[:, koff:koff+k] . x + bias) * bn_scale + bn_shift): the head's layers on the set feature
+ * and the bias vectors of dense links.  bias, bn_scale / bn_shift may be NULL; relu = 0 / 1. */
+SDFR_API int sdfr_linear_vec(const float* w, int ldw, int koff, const float* x, int k, const float* bias,
+                    const float* bn_scale, const float* bn_shift, int relu, float* y, int cout,
+                    int device, void* stream);
+
+/* simple_setup.py:795-812, :978-1009 -- posterior[C] = softmax(logits), with a prior: posterior * prior /
+ * train_prior (train_prior may be NULL), L1-normalised; out_index = argmax (first maximum), out_max = its
+ * probability. */
+SDFR_API int sdfr_orientation_posterior(const float* logits, int C, const float* prior, const float* train_prior,
+                               float* posterior, int* out_index, float* out_max, int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,10 @@ SIGNATURES = {
     "sdfr_point_constraint": (c_int, [c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_int, c_fp]),
     "sdfr_inlier_ratio": (c_int, [c_fp, c_fp, c_int, c_int, c_f, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_int,
                                   c_fp, c_int, c_fp]),
+    "sdfr_pointnet_layer": (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int,
+                                    c_fp, c_int, c_fp]),
+    "sdfr_linear_vec": (c_int, [c_fp, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_fp, c_int, c_int, c_fp]),
+    "sdfr_orientation_posterior": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp]),
     "sdfr_affine_mask": (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_fp, c_int, c_fp]),
     "sdfr_nn_loss_forward": (c_int, [c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_int, c_fp]),
     "sdfr_nn_loss_backward": (c_int, [c_fp, c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp]),

@@ -41,3 +41,43 @@ def random_poses(B, seed=1, width=640, height=480, f=320.0):
     pos = np.stack([(u - cx) * z / f, -(v - cy) * z / f, -z], axis=1)
     scale = rng.uniform(0.4, 0.6, B)
     return pos.astype(np.float32), quat.astype(np.float32), (1.0 / scale).astype(np.float32)
+
+
+MUG_INIT_BACKBONE = {"in_size": 3, "mlp_out_sizes": [128, 128, 128, 128, 1024], "batchnorm": True, "dense": True,
+                     "residual": True}                         # estimation/configs/models/mug.yaml:98-103
+MUG_INIT_HEAD = {"in_size": 1024, "mlp_out_sizes": [512, 256, 128], "batchnorm": True,
+                 "orientation_repr": "discretized", "orientation_grid_resolution": 1}   # mug.yaml:106-111
+
+
+def init_network_state(seed, backbone=MUG_INIT_BACKBONE, head=MUG_INIT_HEAD, shape_dimension=8, num_cells=576):
+    """Seeded random weights with the reference's SDFPoseNet state-dict keys (the trained weights are not in
+    the reference repository): He-scaled Linear weights, small biases, BatchNorm parameters and running
+    statistics away from their defaults.  float32 numpy arrays; the same numbers in tools/make_goldens.py
+    and in the tests, so the fixtures hold outputs only."""
+    rng = np.random.default_rng(seed)
+    state = {}
+
+    def linear(prefix, cin, cout):
+        state[prefix + ".weight"] = (rng.normal(size=(cout, cin)) * np.sqrt(2.0 / cin)).astype(np.float32)
+        state[prefix + ".bias"] = rng.uniform(-0.1, 0.1, cout).astype(np.float32)
+
+    def bn(prefix, c):
+        state[prefix + ".weight"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+        state[prefix + ".bias"] = rng.uniform(-0.2, 0.2, c).astype(np.float32)
+        state[prefix + ".running_mean"] = rng.normal(0, 0.1, c).astype(np.float32)
+        state[prefix + ".running_var"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+
+    sizes = backbone["mlp_out_sizes"]
+    for i, c in enumerate(sizes):
+        cin = backbone["in_size"] if i == 0 else (2 if backbone.get("dense") else 1) * sizes[i - 1]
+        linear(f"_backbone._linear_layers.{i}", cin, c)
+        if backbone["batchnorm"]:
+            bn(f"_backbone._bn_layers.{i}", c)
+    hs = head["mlp_out_sizes"]
+    for i, c in enumerate(hs):
+        linear(f"_head._linear_layers.{i}", head["in_size"] if i == 0 else hs[i - 1], c)
+        if head["batchnorm"]:
+            bn(f"_head._bn_layers.{i}", c)
+    n_out = shape_dimension + (8 if head.get("orientation_repr", "quaternion") == "quaternion" else 4 + num_cells)
+    linear("_head._final_layer", hs[-1], n_out)
+    return state

@@ -78,3 +78,16 @@ def test_oracle_depth_l1_matches_torch_expression():
         assert abs(loss[v] - l.item()) < 1e-12
         np.testing.assert_allclose(grad[v], e.grad.numpy(), rtol=1e-12, atol=0)
     assert grad[0, 0, 0] == 0.0
+
+
+def test_adjust_categorical_posterior_known_answers():
+    """The reference suite's test of SDFPipeline._adjust_categorical_posterior
+    (tests/estimation/test_simple_setup.py:6-26), same inputs and expectations."""
+    from sdfest_amd.init_network import adjust_categorical_posterior
+    posterior = torch.tensor([0.8, 0.2, 0.0, 0.0])
+    train_prior = torch.tensor([0.4, 0.4, 0.1, 0.1])
+    assert torch.allclose(adjust_categorical_posterior(posterior, torch.tensor([0.25] * 4), train_prior), posterior)
+    exp = torch.tensor([0.8 * 0.1 / 0.4, 0.2 * 0.4 / 0.4, 0.0, 0.0])
+    exp /= torch.sum(exp)
+    assert torch.allclose(adjust_categorical_posterior(posterior, torch.tensor([0.1, 0.4, 0.25, 0.25]), train_prior), exp)
+    assert torch.allclose(adjust_categorical_posterior(posterior, torch.tensor([0.25] * 4), None), posterior)

@@ -391,7 +391,7 @@ def make_loop_g7(ref):
                 ratios.append(inlier_ratio(depth_image, depth_estimate))   # LAST view's variables
             traj.append(np.concatenate([position.detach().numpy().ravel(), orientation.detach().numpy().ravel(),
                                         scale.detach().numpy().ravel(), latent.detach().numpy().ravel()]))
-            terms.append([loss_depth.item(), loss_pc.item(), float(loss_con), loss.item()])
+            terms.append([loss_depth.item(), loss_pc.item(), float(loss_con.detach()), loss.item()])
             print(f"  {tag} it{it}: depth {loss_depth.item():.6f} pc {loss_pc.item():.6f} con {float(loss_con):.6f} "
                   f"inlier {ratios[-1]:.4f} hits {[int((t > 0).sum()) for t in depth_images]}")
         out[f"{tag}_traj"] = np.array(traj); out[f"{tag}_terms"] = np.array(terms)
@@ -429,6 +429,73 @@ def make_loop_g7(ref):
     np.savez_compressed(os.path.join(OUT, "loop_g7.npz"), **out)
 
 
+def make_init_network(ref):
+    """Forward of the initialisation network on seeded random weights
+    (sdfest_amd.synthetic.init_network_state: the trained weights are not in the reference repository).
+    Backbone: the IMPORTED sdfest/initialization/pointnet.py::VanillaPointNet in eval mode.  Head:
+    sdf_pose_network.py cannot be imported (it imports so3grid -> healpy, absent), so SDFPoseHead.forward
+    (:88-115) is restated with the torch modules it is made of (nn.Linear, nn.BatchNorm1d, relu); the
+    arithmetic is torch's.  Writes the set features, the head outputs, softmax / adjusted posteriors."""
+    import torch
+    import torch.nn as nn
+    sys.path.insert(0, ref)
+    from sdfest.initialization import pointnet
+    from sdfest_amd.synthetic import MUG_INIT_BACKBONE, MUG_INIT_HEAD, init_network_state
+    out = {}
+    rng = np.random.default_rng(23)
+    for tag, bb, hd in (("mug", MUG_INIT_BACKBONE, MUG_INIT_HEAD),
+                        ("plain", {"in_size": 3, "mlp_out_sizes": [64, 64, 200], "batchnorm": False, "dense": False,
+                                   "residual": True},
+                         {"in_size": 200, "mlp_out_sizes": [96], "batchnorm": False, "orientation_repr": "quaternion"})):
+        state = init_network_state(7 if tag == "mug" else 8, bb, hd)
+        net = pointnet.VanillaPointNet(bb["in_size"], bb["mlp_out_sizes"], bb["batchnorm"], residual=bb["residual"],
+                                       dense=bb["dense"])
+        sd = {k[len("_backbone."):]: torch.tensor(v) for k, v in state.items() if k.startswith("_backbone.")}
+        missing = net.load_state_dict(sd, strict=False)
+        assert not missing.unexpected_keys and all("num_batches_tracked" in k for k in missing.missing_keys)
+        net.eval()
+        hs = hd["mlp_out_sizes"]
+        lins = [nn.Linear(hd["in_size"] if i == 0 else hs[i - 1], c) for i, c in enumerate(hs)]
+        bns = [nn.BatchNorm1d(c) for c in hs] if hd["batchnorm"] else []
+        final = nn.Linear(hs[-1], state["_head._final_layer.weight"].shape[0])
+        with torch.no_grad():
+            for i, l in enumerate(lins):
+                l.weight.copy_(torch.tensor(state[f"_head._linear_layers.{i}.weight"]))
+                l.bias.copy_(torch.tensor(state[f"_head._linear_layers.{i}.bias"]))
+            for i, b in enumerate(bns):
+                b.weight.copy_(torch.tensor(state[f"_head._bn_layers.{i}.weight"]))
+                b.bias.copy_(torch.tensor(state[f"_head._bn_layers.{i}.bias"]))
+                b.running_mean.copy_(torch.tensor(state[f"_head._bn_layers.{i}.running_mean"]))
+                b.running_var.copy_(torch.tensor(state[f"_head._bn_layers.{i}.running_var"]))
+                b.eval()
+            final.weight.copy_(torch.tensor(state["_head._final_layer.weight"]))
+            final.bias.copy_(torch.tensor(state["_head._final_layer.bias"]))
+        for ci, M in enumerate((777, 2500) if tag == "mug" else (300,)):
+            pts = (rng.normal(size=(M, 3)) * np.array([0.05, 0.04, 0.03])).astype(np.float32)
+            pts -= pts.mean(0, keepdims=True)
+            with torch.no_grad():
+                feat = net(torch.tensor(pts)[None])                       # (1, C)
+                o = feat
+                for i, l in enumerate(lins):                              # sdf_pose_network.py:88-93
+                    o = l(o)
+                    if hd["batchnorm"]:
+                        o = bns[i](o)
+                    o = nn.functional.relu(o)
+                o = final(o)
+            out[f"{tag}{ci}_points"] = pts
+            out[f"{tag}{ci}_feature"] = feat[0].numpy()
+            out[f"{tag}{ci}_head"] = o[0].numpy()
+            print(f"  {tag}{ci}: M={M} feature |max| {np.abs(feat.numpy()).max():.3f} head |max| {np.abs(o.numpy()).max():.3f}")
+    # posterior: softmax and the adjustment of simple_setup.py:978-1009 (imported? no: open3d) -- torch ops
+    logits = torch.tensor(out["mug0_head"][12:])
+    post = torch.softmax(logits, -1)
+    prior = torch.tensor(rng.uniform(0.1, 1.0, logits.numel()).astype(np.float32)); prior /= prior.sum()
+    train = torch.tensor(rng.uniform(0.5, 1.0, logits.numel()).astype(np.float32)); train /= train.sum()
+    adj = torch.nn.functional.normalize(post.clone() * prior / train, p=1, dim=-1)
+    out.update(post=post.numpy(), prior=prior.numpy(), train_prior=train.numpy(), post_adjusted=adj.numpy())
+    np.savez_compressed(os.path.join(OUT, "init_network.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -436,7 +503,7 @@ def main():
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     jobs = {"render": make_render, "pc_loss": make_pc_loss, "decoder": make_decoder,
-            "quaternion": make_quaternion, "loop_g7": make_loop_g7}
+            "quaternion": make_quaternion, "loop_g7": make_loop_g7, "init_network": make_init_network}
     for name, fn in jobs.items():
         if args.only and args.only != name:
             continue
