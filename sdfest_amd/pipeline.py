@@ -117,7 +117,12 @@ class RenderAndCompare:
                                  self.config["threshold"], self.cam)          # (V,H,W)
         overlap = (depth_images > 0) & (est > 0)
         err = torch.abs(est - depth_images) * overlap
-        loss_depth = (err.sum(dim=(1, 2)) / overlap.sum(dim=(1, 2))).sum()    # empty overlap -> NaN, as :131
+        count = overlap.sum(dim=(1, 2))
+        # torch.mean(depth_error[overlap_mask]) (:131): an empty overlap makes the VALUE NaN, but no pixel is
+        # selected, so no gradient flows from it -- the parameters keep finite gradients (the kernels of the
+        # fused loop behave the same: loss NaN, contributions 0)
+        per_view = torch.where(count > 0, err.sum(dim=(1, 2)) / count.clamp(min=1), err.new_tensor(float("nan")))
+        loss_depth = per_view.sum()
         if points.shape[0]:
             val = pc_loss_batch(points, offsets, max(lens), pos_c.contiguous(), quat_c.contiguous(),
                                 scale.expand(V).contiguous(), sdf)

@@ -248,3 +248,33 @@ def test_graph_replays_are_repeatable_without_host_work_between_them(mug_decoder
         assert graph.step.item() == 20
         for a, b, tol in zip(out, ref, (2e-5, 2e-4, 2e-5, 5e-4)):
             assert torch.isfinite(a).all() and (a - b).abs().max().item() <= tol, (call, a, b)
+
+
+def test_empty_overlap_view_gives_nan_loss_and_finite_steps(mug_decoder):
+    """simple_setup.py:125-131: `torch.mean(depth_error[overlap_mask])` of an empty overlap is NaN, yet no pixel
+    is selected, so that view contributes no gradient: the reference's loss is NaN while its Adam steps stay
+    finite.  Both loops do the same, and agree with each other."""
+    from sdfest_amd import Camera
+    from sdfest_amd.pipeline import FusedRenderAndCompare, RenderAndCompare
+    dec, d = mug_decoder
+    sdf = d["z0_full"].astype(np.float64)
+    W, H, f = 64, 48, 60.0
+    cam = Camera(W, H, f, f, W / 2, H / 2, pixel_center=0.5)
+    p_true, s_true = np.array([0.01, -0.015, -0.45]), 0.11
+    q_true = np.array([0.3, 0.5, -0.1, 0.8]); q_true /= np.linalg.norm(q_true)
+    obs0 = oracle.render_forward(sdf, p_true, q_true, [1 / s_true], W, H, W / 2, H / 2, f, f, 0.005, dtype=np.float64)[0]
+    obs1 = np.zeros_like(obs0)
+    obs1[2:6, 2:8] = 0.4                      # the second view saw something in a corner the estimate never covers
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device="cuda")
+    obs = t(np.stack([obs0, obs1]))
+    cfg = {"threshold": 0.005, "max_iterations": 3, "depth_weight": 1.0, "pc_weight": 3.0}
+    p0, q0, s0, z0 = t((p_true + 0.005)[None]), t(q_true[None]), t([0.115]), torch.zeros(1, 8, device="cuda")
+    h1, h2 = [], []
+    RenderAndCompare(dec, cam, cfg)(obs, p0, q0, s0, z0, history=h1)
+    FusedRenderAndCompare(dec, cam, cfg, obs)(p0, q0, s0, z0, use_graph=False, history=h2)
+    for a, b in zip(h1, h2):
+        assert torch.isnan(a["loss"]) and torch.isnan(b["loss"])
+        for k in ("position", "orientation", "scale", "latent"):
+            assert torch.isfinite(a[k]).all() and torch.isfinite(b[k]).all()
+            assert torch.allclose(a[k].reshape(-1), b[k].reshape(-1), rtol=0, atol=2e-4), k
+    assert (h1[-1]["position"] - p0).abs().max() > 1e-3       # and the first view did move the estimate
