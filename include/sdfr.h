@@ -172,6 +172,13 @@ SDFR_API int sdfr_pc_l1_backward(float weight, float* loss, const float* points,
                         const float* sdf, int R, long long sdf_view_stride, float* g_sdf,
                         long long g_sdf_view_stride, float* g_pos, float* g_quat, float* g_scale,
                         void* workspace, size_t workspace_bytes, int device, void* stream);
+/* the same, ADDING the d/dSDF contributions to g_sdf instead of overwriting it: in the loop the sampler runs
+ * after the renderer's backward and sums into its volume (one zero fill and one addition launch less). */
+SDFR_API int sdfr_pc_l1_backward_accumulate(float weight, float* loss, const float* points, const int* offsets, int B,
+                        int max_view_points, const float* pos, const float* quat, const float* scale,
+                        const float* sdf, int R, long long sdf_view_stride, float* g_sdf,
+                        long long g_sdf_view_stride, float* g_pos, float* g_quat, float* g_scale,
+                        void* workspace, size_t workspace_bytes, int device, void* stream);
 
 
 /* ---- VAE decoder forward ------------------------------------------------------------------ */

@@ -43,6 +43,8 @@ SIGNATURES = {
                                       c_ll, c_fp, c_ll, c_fp, c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),
     "sdfr_pc_l1_backward": (c_int, [c_f, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_ll,
                                     c_fp, c_ll, c_fp, c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),
+    "sdfr_pc_l1_backward_accumulate": (c_int, [c_f, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_ll,
+                                    c_fp, c_ll, c_fp, c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),
     "sdfr_decoder_create": (c_int, [c_fp, c_sz, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_fp,
                                     c_fp, c_int, c_f, c_int, c_fp]),
     "sdfr_decoder_destroy": (None, [c_fp]),

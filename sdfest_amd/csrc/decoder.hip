@@ -548,6 +548,41 @@ __global__ __launch_bounds__(256) void resize_axis_backward_kernel(const float* 
   g_in[idx] = acc;
 }
 
+// The x pass of the transposed resize (outer = N*C volumes, inner = n_in^2) writing straight into the
+// zero-padded, ReLU-masked tensor the next transposed convolution reads (= the pass followed by
+// pad_mask_kernel, one launch less per layer in the captured loop):
+//   out[o][x + pad][y + pad][z + pad] = (act[o][x][y][z] > 0 or no act) ? sum_d w(d -> x) g_out[o][d][y][z] : 0
+__global__ __launch_bounds__(256) void resize_x_backward_pad_kernel(const float* __restrict__ g_out, size_t outer,
+                                                                    int n_in, int n_out,
+                                                                    const float* __restrict__ act, int pad,
+                                                                    float* __restrict__ out) {
+  const int np = n_in + 2 * pad;
+  const size_t vp = (size_t)np * np * np;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= outer * vp) return;
+  const size_t o = idx / vp;
+  const int r = (int)(idx - o * vp);
+  const int z = r % np - pad, y = (r / np) % np - pad, i = r / (np * np) - pad;
+  float acc = 0.0f;
+  if (i >= 0 && i < n_in && y >= 0 && y < n_in && z >= 0 && z < n_in) {
+    const size_t inner = (size_t)n_in * n_in, rr = (size_t)y * n_in + z;
+    const size_t src = (o * n_in + i) * inner + rr;
+    if (!act || act[src] > 0.0f) {
+      const float ratio = (float)n_in / (float)n_out, inv = (float)n_out / (float)n_in;
+      int d0 = (int)floorf(((float)i - 0.5f) * inv - 0.5f) - 1;
+      int d1 = (int)ceilf(((float)i + 1.5f) * inv - 0.5f) + 1;
+      d0 = max(d0, 0);
+      d1 = min(d1, n_out - 1);
+      const float* p = g_out + (o * n_out) * inner + rr;
+      for (int d = d0; d <= d1; ++d) {
+        const float w = resize_weight(d, i, ratio, n_in);
+        if (w != 0.0f) acc = fmaf(w, p[(size_t)d * inner], acc);
+      }
+    }
+  }
+  out[idx] = acc;
+}
+
 // Backward of the last (wide) Linear layer: t[n][i] = sum_o Wt[i][o] * g_last[n][o], one workgroup
 // per (i, sample) -- a 50 x 8192 GEMV spread over 50 workgroups instead of one.
 // `act`: the layer's forward output; its ReLU' is applied to g_last on the fly (no mask launch).
@@ -1099,20 +1134,29 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
   std::vector<int> out_n(d->n_conv);
   for (int l = 0; l < d->n_conv; ++l) out_n[l] = d->conv_in_size[l] - d->conv_k[l] + 1;
   // transpose of a trilinear resize of [N*C] volumes n_out^3 -> n_in^3: z, then y, then x
-  auto resize_backward = [&](int C, int n_in, int n_out) {
+  // pad >= 0: the last pass also applies the ReLU mask `act` (may be null) and the zero padding of the
+  // transposed convolution that follows (resize_x_backward_pad_kernel)
+  auto resize_backward = [&](int C, int n_in, int n_out, int pad = -1, const float* act = nullptr) {
     const size_t nc = (size_t)N * C;
     struct Pass { size_t outer; size_t inner; } passes[3] = {
         {nc * n_out * n_out, 1},                  // z:  [nc][no][no][no] -> [nc][no][no][ni]
         {nc * n_out, (size_t)n_in},               // y:  [nc][no][no][ni] -> [nc][no][ni][ni]
         {nc, (size_t)n_in * n_in}};               // x:  [nc][no][ni][ni] -> [nc][ni][ni][ni]
     for (int a = 0; a < 3; ++a) {
-      const size_t cnt = passes[a].outer * n_in * passes[a].inner;
-      hipLaunchKernelGGL(resize_axis_backward_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st,
-                         g, passes[a].outer, n_in, n_out, passes[a].inner, buf[cur]);
+      if (a == 2 && pad >= 0) {
+        const size_t np = (size_t)n_in + 2 * pad, cnt = nc * np * np * np;
+        hipLaunchKernelGGL(resize_x_backward_pad_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, g, nc,
+                           n_in, n_out, act, pad, buf[cur]);
+      } else {
+        const size_t cnt = passes[a].outer * n_in * passes[a].inner;
+        hipLaunchKernelGGL(resize_axis_backward_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st,
+                           g, passes[a].outer, n_in, n_out, passes[a].inner, buf[cur]);
+      }
       g = buf[cur];
       cur ^= 1;
     }
   };
+  bool padded = false;  // g already is layer l's padded, masked output gradient (written by the resize above)
   int n = d->volume;
   if (out_n[d->n_conv - 1] != d->volume) {  // final resize
     const int ni = out_n[d->n_conv - 1];
@@ -1128,7 +1172,9 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
     const int nconv = swap ? prev : nin;            // ... and of the one it produces
     // 1. ReLU' and zero padding of the output gradient
     const float* act = d->conv_relu[l] ? tape + (size_t)N * d->tape_conv_off[l] : nullptr;
-    if (!swap || act) {
+    if (padded) {
+      padded = false;
+    } else if (!swap || act) {
       const size_t cntp = (size_t)co_n * (swap ? m : np) * (swap ? m : np) * (swap ? m : np);
       hipLaunchKernelGGL(pad_mask_kernel, dim3((unsigned)((cntp + 255) / 256), N), dim3(256), 0, st, g, act,
                          co_n, m, swap ? 0 : k - 1, buf[cur]);
@@ -1168,7 +1214,16 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
     n = nconv;
     // 3. the resize in front of this layer, if any
     if (!swap && prev != nin) {
-      resize_backward(ci_n, prev, nin);
+      // the layer below (l - 1) produced this tensor: if its transposed convolution is of the padded kind,
+      // the last resize pass writes its input directly
+      const bool fuse = l > 0 && !d->conv_swap[l - 1] && out_n[l - 1] == prev && d->conv_cout[l - 1] == ci_n;
+      if (fuse) {
+        resize_backward(ci_n, prev, nin, d->conv_k[l - 1] - 1,
+                        d->conv_relu[l - 1] ? tape + (size_t)N * d->tape_conv_off[l - 1] : nullptr);
+        padded = true;
+      } else {
+        resize_backward(ci_n, prev, nin);
+      }
       n = prev;
     }
   }

@@ -303,7 +303,7 @@ int pc_backward_impl(const char* fn, const float* grad_out, float l1_weight, flo
                      const float* pos, const float* quat, const float* scale, const float* sdf, int R,
                      long long sdf_view_stride, float* g_sdf, long long g_sdf_view_stride, float* g_pos,
                      float* g_quat, float* g_scale, void* workspace, size_t workspace_bytes, int device,
-                     void* stream) {
+                     void* stream, bool accumulate = false) {
   const bool l1 = loss != nullptr;
   if (int rc = check_pc(R, B, max_view_points)) return rc;
   const long long vox = (long long)R * R * R;
@@ -316,7 +316,7 @@ int pc_backward_impl(const char* fn, const float* grad_out, float l1_weight, flo
   SDFR_HIP_TRY(hipSetDevice(device));
   hipStream_t st = (hipStream_t)stream;
   const size_t g_bytes = (size_t)vox * sizeof(float) * (g_sdf_view_stride ? (size_t)(B > 0 ? B : 1) : 1);
-  zero_words_async(g_sdf, g_bytes / sizeof(float), st);
+  if (!accumulate) zero_words_async(g_sdf, g_bytes / sizeof(float), st);
   if (B == 0) return 0;
   if (!g_pos || !g_quat || !g_scale || !pos || !quat || !scale)
     return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
@@ -374,4 +374,16 @@ extern "C" int sdfr_pc_l1_backward(float weight, float* loss, const float* point
   return pc_backward_impl("sdfr_pc_l1_backward", nullptr, weight, loss, points, offsets, B, max_view_points,
                           pos, quat, scale, sdf, R, sdf_view_stride, g_sdf, g_sdf_view_stride, g_pos, g_quat,
                           g_scale, workspace, workspace_bytes, device, stream);
+}
+
+extern "C" int sdfr_pc_l1_backward_accumulate(float weight, float* loss, const float* points, const int* offsets,
+                                              int B, int max_view_points, const float* pos, const float* quat,
+                                              const float* scale, const float* sdf, int R,
+                                              long long sdf_view_stride, float* g_sdf, long long g_sdf_view_stride,
+                                              float* g_pos, float* g_quat, float* g_scale, void* workspace,
+                                              size_t workspace_bytes, int device, void* stream) {
+  if (B > 0 && !loss) return fail(SDFR_E_NULL, "sdfr_pc_l1_backward_accumulate: loss is NULL");
+  return pc_backward_impl("sdfr_pc_l1_backward_accumulate", nullptr, weight, loss, points, offsets, B,
+                          max_view_points, pos, quat, scale, sdf, R, sdf_view_stride, g_sdf, g_sdf_view_stride, g_pos,
+                          g_quat, g_scale, workspace, workspace_bytes, device, stream, true);
 }

@@ -343,15 +343,17 @@ class FusedRenderAndCompare:
             g_sdf, g_pos, g_quat, g_is = self.plan.backward(self.grad_est, sdf, self.pos_c, self.quat_c,
                                                             self.inv_scale)
         have_pts = self.max_pts > 0
+        summed = False   # the sampler's d/dSDF already added to the renderer's
         if have_pts and self.fuse_depth_loss:
-            # the point-cloud term in one pass: loss value and gradients, no sampler forward, no loss kernel
-            self.check(L.sdfr_pc_l1_backward(self.cfg["pc_weight"], self.loss_pc.data_ptr(), self.points.data_ptr(),
-                                             self.offsets.data_ptr(), self.V, self.max_pts, self.pos_c.data_ptr(),
-                                             self.quat_c.data_ptr(), self.scale_v.data_ptr(), sdf.data_ptr(),
-                                             self.R, 0, self.g_sdf_pc.data_ptr(), 0, self.g_pos_pc.data_ptr(),
-                                             self.g_quat_pc.data_ptr(), self.g_scale_pc.data_ptr(),
-                                             self.ws_pc.data_ptr(), self.ws_pc.numel(), d, st),
-                       "sdfr_pc_l1_backward")
+            # the point-cloud term in one pass: loss value and gradients, no sampler forward, no loss kernel;
+            # its d/dSDF goes straight into the volume the renderer's backward has just written
+            self.check(L.sdfr_pc_l1_backward_accumulate(
+                self.cfg["pc_weight"], self.loss_pc.data_ptr(), self.points.data_ptr(), self.offsets.data_ptr(),
+                self.V, self.max_pts, self.pos_c.data_ptr(), self.quat_c.data_ptr(), self.scale_v.data_ptr(),
+                sdf.data_ptr(), self.R, 0, g_sdf.data_ptr(), 0, self.g_pos_pc.data_ptr(), self.g_quat_pc.data_ptr(),
+                self.g_scale_pc.data_ptr(), self.ws_pc.data_ptr(), self.ws_pc.numel(), d, st),
+                "sdfr_pc_l1_backward_accumulate")
+            summed = True
         elif have_pts:
             self.check(L.sdfr_pc_loss_forward(self.points.data_ptr(), self.offsets.data_ptr(), self.V,
                                               self.max_pts, self.pos_c.data_ptr(), self.quat_c.data_ptr(),
@@ -379,7 +381,7 @@ class FusedRenderAndCompare:
                                                self.pc_weight, self.loss_con.data_ptr(), g + 12, d, st),
                        "sdfr_point_constraint")
         if self.shape_opt:
-            if have_pts:
+            if have_pts and not summed:
                 self.check(L.sdfr_add_inplace(g_sdf.data_ptr(), self.g_sdf_pc.data_ptr(), g_sdf.numel(), d, st),
                            "sdfr_add_inplace")
             self.check(L.sdfr_decoder_backward_latent(self.dec._h, self.latent.data_ptr(), self.tape.data_ptr(),
