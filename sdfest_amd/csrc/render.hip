@@ -43,6 +43,15 @@ constexpr int kBlock = 256;
 #define SDFR_TIGHT_BOX 1  // 0: timing experiments without the may-hit box
 #endif
 constexpr bool kTightBox = SDFR_TIGHT_BOX;
+// In-kernel stamps of the backward's hit tiles (timing builds only: -DSDFR_STAMPS, read by
+// tools/microbench/backward_stamps.py): wave 0's first active lane stores s_memtime at phase boundaries into a
+// per-tile record (plain stores: atomics on shared counters distort the kernel five-fold).
+#ifdef SDFR_STAMPS
+__device__ unsigned long long g_stamps[153600 * 16];
+#define SDFR_STAMP(k) do { if (wave == 0 && lane == (int)__ffsll((long long)__ballot(1)) - 1) stamp__[k] = clock64(); } while (0)
+#else
+#define SDFR_STAMP(k) do {} while (0)
+#endif
 #ifndef SDFR_FWD_WAVES
 #define SDFR_FWD_WAVES 2
 #endif
@@ -480,6 +489,10 @@ __device__ __forceinline__ void backward_tile(
     if (tid < 8) part[tid] = 0.0f;
     return;
   }
+#ifdef SDFR_STAMPS
+  unsigned long long* stamp__ = g_stamps + ((((size_t)b * nty + tile_y) * ntx + tile_x) % 153600) * 16;
+#endif
+  SDFR_STAMP(0);   // the tile's depth (and upstream gradient) loads are back
   hash.clear(tid, kBlock);
   if (tid == 0) tile_max_bits = 0;
   __syncthreads();
@@ -487,6 +500,7 @@ __device__ __forceinline__ void backward_tile(
   if (lane == 0) atomicMax(&tile_max_bits, __float_as_int(gmax));  // non-negative floats order as ints
   __syncthreads();
 
+  SDFR_STAMP(1);   // table cleared, tile maximum known (2 barriers)
   const float* vol = sdf + (size_t)b * sdf_view_stride;
   float* gvol = g_sdf + (size_t)b * g_sdf_view_stride;
   const float h = 0.5f * (float)(Rr - 1);
@@ -514,6 +528,9 @@ __device__ __forceinline__ void backward_tile(
     Cell c;
     gather_cell<RT>(vol, R, fmaf(o.x * isc, h, h), fmaf(o.y * isc, h, h), fmaf(o.z * isc, h, h), c);
     const float tri = trilerp(c);
+#ifdef SDFR_STAMPS
+    if (sub == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SDFR_STAMP(6); }   // grid gathers of sub-tile 0 back
+#endif
     // gradient of the trilinear value w.r.t. the cell coordinate
     const float ax = 1.0f - c.ox, ay = 1.0f - c.oy, az = 1.0f - c.oz;
     const float c00 = fmaf(c.v[4], c.ox, c.v[0] * ax), c01 = fmaf(c.v[5], c.ox, c.v[1] * ax);
@@ -565,6 +582,9 @@ __device__ __forceinline__ void backward_tile(
     // false): NaN reaches g_sdf as it does through the reference's atomicAdd.
     const float wmax = fmaxf(fmaxf(fmaxf(fabsf(w0), fabsf(w1)), fmaxf(fabsf(w2), fabsf(w3))),
                              fmaxf(fmaxf(fabsf(w4), fabsf(w5)), fmaxf(fabsf(w6), fabsf(w7))));
+#ifdef SDFR_STAMPS
+    if (sub == 0) SDFR_STAMP(7);   // derivative arithmetic and weights of sub-tile 0 done
+#endif
     if (fixed_ok && wmax * to_fixed < 3.5e13f /* 2^45 */) {
       const float wk[8] = {w0, w1, w2, w3, w4, w5, w6, w7};
 #ifdef SDFR_ABLATE_NO_SCATTER  // timing-only build
@@ -579,8 +599,12 @@ __device__ __forceinline__ void backward_tile(
       atomicAdd(g0 + Rr * Rr, w4);      atomicAdd(g0 + Rr * Rr + 1, w5);
       atomicAdd(g0 + Rr * Rr + Rr, w6); atomicAdd(g0 + Rr * Rr + Rr + 1, w7);
     }
+#ifdef SDFR_STAMPS
+    if (sub == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); SDFR_STAMP(8); }   // table look-ups and adds of sub-tile 0 done
+#endif
   }
 
+  SDFR_STAMP(2);   // both sub-tiles done
   // pose sums: registers -> wave shuffle -> LDS -> macro-tile partial (a wave without a hit pixel
   // has nothing to reduce)
   if (__ballot(any_hit) != 0ull) {
@@ -592,7 +616,13 @@ __device__ __forceinline__ void backward_tile(
   __syncthreads();
   if (tid < 8) part[tid] = (wave_part[0][tid] + wave_part[1][tid]) + (wave_part[2][tid] + wave_part[3][tid]);
 
+  SDFR_STAMP(3);   // pose sums, barrier (= the slowest wave)
   hash.flush(gvol, Rr * Rr * Rr, from_fixed, tid, kBlock);
+  SDFR_STAMP(4);   // flush issued
+#ifdef SDFR_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  SDFR_STAMP(5);   // flush acknowledged
+#endif
 }
 
 // WIDE: the batch tile with a 4 x 1024 table, for low-resolution images (a pixel then spans several
@@ -948,3 +978,14 @@ extern "C" int sdfr_render_backward_l1(const float* loss_grad, float loss_weight
                        workspace_bytes, device, stream);
 }
 
+#ifdef SDFR_STAMPS
+extern "C" __attribute__((visibility("default"))) int sdfr_debug_stamps(unsigned long long* h_out, int reset) {
+  if (hipMemcpyFromSymbol(h_out, HIP_SYMBOL(sdfr::g_stamps), sizeof(unsigned long long) * 153600 * 16) != hipSuccess) return 1;
+  if (reset) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(sdfr::g_stamps)) != hipSuccess) return 2;
+    if (hipMemset(p, 0, sizeof(unsigned long long) * 153600 * 16) != hipSuccess) return 3;
+  }
+  return 0;
+}
+#endif
