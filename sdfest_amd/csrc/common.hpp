@@ -55,10 +55,11 @@ struct alignas(128) ViewSetup {
 };
 static_assert(sizeof(ViewSetup) == 256, "ViewSetup must stay 256 bytes");
 
-// A workgroup (4 waves) owns a tile of SX x SY sub-tiles of 32 x 8 pixels and walks them; inside
-// a sub-tile each wave is an 8 x 8 pixel patch.  Two geometries are compiled: the 64 x 32
-// macro-tile (2 x 4 sub-tiles) for batches, and the single 32 x 8 sub-tile when a call has too
-// few macro-tiles to fill 256 CUs (single-view calls of the drop-in autograd path).
+// A workgroup owns a tile of SX x SY sub-tiles of 32 x 8 pixels; a sub-tile is four wave-sized patches
+// (8 x 8 pixels in the forward, 16 x 4 in the backward).  Two geometries are compiled: the 64 x 8 macro
+// tile (2 x 1 sub-tiles; forward: 2 waves walking 4 patches each, backward: 4 waves, 2 patches each) for
+// batches, and the single 32 x 8 sub-tile (4 waves, one patch each) when a call has too few macro tiles
+// to fill 256 CUs (single-view calls of the drop-in autograd path).
 constexpr int kSubW = 32;
 constexpr int kSubH = 8;
 struct TileGeom {
