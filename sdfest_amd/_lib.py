@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdfr_hip.so")
+# SDFR_LIB: another build of the same library (timing experiments: tools/microbench/build_variant.sh)
+LIB_PATH = os.environ.get("SDFR_LIB") or os.path.join(_HERE, "libsdfr_hip.so")
 _lib = None
 
 c_fp = ctypes.c_void_p

@@ -247,6 +247,8 @@ __device__ __forceinline__ long long fixed_from_float(float x) {
 template <int SHIFT, int SLOTS>
 struct RunHash {
   static constexpr int kShift = SHIFT, kSlots = SLOTS, kLen = 1 << SHIFT;
+  static constexpr int kBits = kFixedBits;                 // contributions are scaled to < 2^kBits
+  static constexpr float kWeightLimit = 3.5e13f;           // 2^45: larger scaled weights bypass the table
   unsigned long long vals[SLOTS << SHIFT];
   int keys[SLOTS];
 
@@ -322,10 +324,88 @@ struct RunHash {
     }
   }
 };
+// Runs of 4 voxels whose entries are z-PAIRS: entry e of a run is one 64-bit word holding two signed 32-bit
+// fixed-point sums, low half = voxel 4 key + e, high half = voxel 4 key + e + 1 (so a run reaches one voxel
+// into the next one and a cell's z-pair never straddles two runs).  A column of a cell -- two corners -- is
+// ONE LDS atomic and one look-up: 4 adds and 4 look-ups per hit pixel instead of 8 adds and 4-8 look-ups.
+// The backward's cost follows the number of LDS instructions a tile issues, not their
+// width.  Adding (hi << 32) + lo as one 64-bit integer keeps both halves exact as long as the low sum stays
+// inside 32 bits: contributions are scaled to < 2^22 and a tile has <= 512 pixels.  The price is resolution:
+// a contribution is rounded to 2^-22 of the tile's bound (2 max|grad| scale) instead of being represented
+// exactly; sums stay independent of the order of arrival.
+template <int SLOTS>
+struct PairRunHash {
+  static constexpr int kSlots = SLOTS, kLen = 4;
+  static constexpr int kBits = 22;
+  static constexpr float kWeightLimit = 8.0e6f;  // 2^23
+  unsigned long long vals[SLOTS * 4];
+  int keys[SLOTS];
+
+  __device__ __forceinline__ void clear(int tid, int nthreads) {
+    for (int i = tid; i < SLOTS; i += nthreads) keys[i] = -1;
+    for (int i = tid; i < SLOTS * 4; i += nthreads) vals[i] = 0ull;
+  }
+
+  __device__ __forceinline__ int slot_of(int key) {  // as RunHash::slot_of
+    unsigned h = (((unsigned)key * 2654435761u) >> 16) & (SLOTS - 1);
+#pragma unroll 1
+    for (int probe = 0; probe < 32; ++probe) {
+      int cur = __builtin_nontemporal_load(&keys[h]);
+      if (cur == -1) cur = atomicCAS(&keys[h], -1, key);
+      if (cur == -1 || cur == key) return (int)h;
+      h = (h + 1) & (SLOTS - 1);
+    }
+    return -1;
+  }
+
+  __device__ __forceinline__ void add_cell(float* __restrict__ gvol, int lin, int Rr, const float (&w)[8],
+                                           float to_fixed) {
+    const int col[4] = {lin, lin + Rr, lin + Rr * Rr, lin + Rr * Rr + Rr};
+    int key[4], cur[4];
+    unsigned h[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      key[j] = col[j] >> 2;
+      h[j] = (((unsigned)key[j] * 2654435761u) >> 16) & (SLOTS - 1);
+      cur[j] = __builtin_nontemporal_load(&keys[h[j]]);
+    }
+    int slot[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) slot[j] = (cur[j] == key[j]) ? (int)h[j] : slot_of(key[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (slot[j] >= 0) {
+        const long long lo = fixed_from_float(w[2 * j] * to_fixed), hi = fixed_from_float(w[2 * j + 1] * to_fixed);
+        atomicAdd(&vals[slot[j] * 4 + (col[j] & 3)], (unsigned long long)(lo + (hi << 32)));
+      } else {  // crowded table
+        atomicAdd(gvol + col[j], w[2 * j]);
+        atomicAdd(gvol + col[j] + 1, w[2 * j + 1]);
+      }
+    }
+  }
+
+  // thread -> (slot, voxel k = 0..4 of the run): low half of entry k plus high half of entry k - 1
+  __device__ __forceinline__ void flush(float* __restrict__ gvol, int nvox, float from_fixed, int tid, int nthreads) {
+    for (int i = tid; i < SLOTS * 5; i += nthreads) {
+      const int slot = i / 5, k = i - slot * 5;
+      const int key = keys[slot];
+      if (key < 0) continue;
+      long long sum = 0;
+      if (k < 4) sum += (long long)(int)(unsigned)(vals[slot * 4 + k] & 0xffffffffull);
+      if (k > 0) {
+        const long long q = (long long)vals[slot * 4 + k - 1];
+        sum += (q - (long long)(int)(unsigned)((unsigned long long)q & 0xffffffffull)) >> 32;
+      }
+      const int lin = key * 4 + k;
+      if (sum != 0 && lin < nvox) atomicAdd(gvol + lin, (float)sum * from_fixed);
+    }
+  }
+};
+#ifndef SDFR_BWD_PAIR_HASH
+#define SDFR_BWD_PAIR_HASH 1  // 0: the plain z-run table for full-size batches (timing experiments)
+#endif
 using BatchHash = RunHash<2, 512>;    // 64 x 8-pixel tiles of a batch; blocks of 256 points of the sampler
 using SmallHash = RunHash<1, 1024>;   // 32 x 8-pixel tiles of small calls, any resolution
-using WideHash = RunHash<2, 1024>;    // 64 x 8-pixel tiles of batches of low-resolution images
-constexpr long long kWideHashMaxPixels = 320 * 240;
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

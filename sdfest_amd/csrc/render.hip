@@ -510,8 +510,8 @@ __device__ __forceinline__ void backward_tile(
   int e2;
   (void)frexpf(bound, &e2);  // bound = m * 2^e2, m in [0.5, 1)  ->  2^e2 > bound
   const bool fixed_ok = (bound > 0.0f) && (bound < 1e30f) && (e2 > -80);
-  const float to_fixed = fixed_ok ? ldexpf(1.0f, kFixedBits - e2) : 0.0f;
-  const float from_fixed = fixed_ok ? ldexpf(1.0f, e2 - kFixedBits) : 0.0f;
+  const float to_fixed = fixed_ok ? ldexpf(1.0f, Hash::kBits - e2) : 0.0f;
+  const float from_fixed = fixed_ok ? ldexpf(1.0f, e2 - Hash::kBits) : 0.0f;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 #pragma unroll
@@ -585,7 +585,7 @@ __device__ __forceinline__ void backward_tile(
 #ifdef SDFR_STAMPS
     if (sub == 0) SDFR_STAMP(7);   // derivative arithmetic and weights of sub-tile 0 done
 #endif
-    if (fixed_ok && wmax * to_fixed < 3.5e13f /* 2^45 */) {
+    if (fixed_ok && wmax * to_fixed < Hash::kWeightLimit) {
       const float wk[8] = {w0, w1, w2, w3, w4, w5, w6, w7};
 #ifdef SDFR_ABLATE_NO_SCATTER  // timing-only build
       acc[7] += 1e-30f * (w0 + w1 + w2 + w3 + w4 + w5 + w6 + w7 + to_fixed);
@@ -625,10 +625,10 @@ __device__ __forceinline__ void backward_tile(
 #endif
 }
 
-// WIDE: the batch tile with a 4 x 1024 table, for low-resolution images (a pixel then spans several
-// voxels and a tile touches more runs than 512 slots hold: 320x240 batches 137 -> 115 us; at 640x480
-// the bigger table costs occupancy, 173 -> 261 us).
-template <int RT, int SX, int SY, bool LOSS, bool WIDE>
+// Batches pre-sum in the z-pair run table (device.hpp, PairRunHash), small calls in 2-voxel runs x 1024 slots.
+// (Until the pair table, batches of low-resolution images took a 4 x 1024 run table of their own: 320x240
+// 117.6 -> 109.8 us, 160x120 107.1 -> 73.1 us per 256 views with the one pair table for all image sizes.)
+template <int RT, int SX, int SY, bool LOSS>
 __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     const float* __restrict__ grad_depth, const float* __restrict__ depth,
     const float* __restrict__ sdf, int R, long long sdf_view_stride,
@@ -636,8 +636,12 @@ __global__ __launch_bounds__(kBlock) void render_backward_kernel(
     float rfx, float rfy, int sdf_grad_mode, float* __restrict__ g_sdf,
     long long g_sdf_view_stride, float* __restrict__ partials, const float* __restrict__ loss_grad,
     const float* __restrict__ loss_stats, float loss_weight) {
-  using Hash = typename std::conditional<(SX * SY > 1), typename std::conditional<WIDE, WideHash, BatchHash>::type,
-                                         SmallHash>::type;
+#if SDFR_BWD_PAIR_HASH
+  using FullHash = PairRunHash<512>;
+#else
+  using FullHash = BatchHash;
+#endif
+  using Hash = typename std::conditional<(SX * SY > 1), FullHash, SmallHash>::type;
   __shared__ BackwardLds<Hash> lds;
   const int b = blockIdx.z;
   float loss_k = 0.0f;
@@ -920,23 +924,19 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
   const int ntx = geom.nx(W), nty = geom.ny(H);
   const dim3 grid_tile((unsigned)ntx, (unsigned)nty, (unsigned)B);
   const float rfx = (float)(1.0 / (double)fx), rfy = (float)(1.0 / (double)fy);
-  const bool wide = macro && (long long)W * H <= kWideHashMaxPixels;
-#define SDFR_LAUNCH_BWD_L(RT, SX, SY, LOSS, WIDE)                                                    \
-  hipLaunchKernelGGL((render_backward_kernel<RT, SX, SY, LOSS, WIDE>), grid_tile, dim3(kBlock), 0,   \
+#define SDFR_LAUNCH_BWD_L(RT, SX, SY, LOSS)                                                          \
+  hipLaunchKernelGGL((render_backward_kernel<RT, SX, SY, LOSS>), grid_tile, dim3(kBlock), 0,         \
                      st, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, ntx, nty, cx, cy,  \
                      rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, loss_grad,         \
                      loss_stats, loss_weight)
 #define SDFR_LAUNCH_BWD(RT)                                                                          \
   do {                                                                                               \
     if (!macro) {                                                                                    \
-      if (with_loss) SDFR_LAUNCH_BWD_L(RT, 1, 1, true, false);                                       \
-      else SDFR_LAUNCH_BWD_L(RT, 1, 1, false, false);                                                \
-    } else if (wide) {                                                                               \
-      if (with_loss) SDFR_LAUNCH_BWD_L(RT, SDFR_MACRO_SX, SDFR_MACRO_SY, true, true);                \
-      else SDFR_LAUNCH_BWD_L(RT, SDFR_MACRO_SX, SDFR_MACRO_SY, false, true);                         \
+      if (with_loss) SDFR_LAUNCH_BWD_L(RT, 1, 1, true);                                              \
+      else SDFR_LAUNCH_BWD_L(RT, 1, 1, false);                                                       \
     } else {                                                                                         \
-      if (with_loss) SDFR_LAUNCH_BWD_L(RT, SDFR_MACRO_SX, SDFR_MACRO_SY, true, false);               \
-      else SDFR_LAUNCH_BWD_L(RT, SDFR_MACRO_SX, SDFR_MACRO_SY, false, false);                        \
+      if (with_loss) SDFR_LAUNCH_BWD_L(RT, SDFR_MACRO_SX, SDFR_MACRO_SY, true);                      \
+      else SDFR_LAUNCH_BWD_L(RT, SDFR_MACRO_SX, SDFR_MACRO_SY, false);                               \
     }                                                                                                \
   } while (0)
   if (R == 64) SDFR_LAUNCH_BWD(64); else SDFR_LAUNCH_BWD(0);

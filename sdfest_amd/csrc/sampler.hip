@@ -18,6 +18,14 @@ namespace sdfr {
 namespace {
 
 constexpr int kPts = 256;  // points per workgroup
+#ifndef SDFR_SAMPLER_PAIR
+#define SDFR_SAMPLER_PAIR 1  // 0: plain 4-voxel runs (timing experiments)
+#endif
+#if SDFR_SAMPLER_PAIR
+using SamplerHash = PairRunHash<512>;   // z-pair runs: one LDS add per column of a cell (device.hpp)
+#else
+using SamplerHash = BatchHash;
+#endif
 
 struct PointFrame {
   float qn[4];
@@ -96,7 +104,7 @@ __global__ __launch_bounds__(kPts) void pc_loss_backward_kernel(
     float* __restrict__ partials, int nblk, float l1_weight, float* __restrict__ loss_part) {
   // 4-voxel runs x 512 slots: back-projected depth images are coherent (measured on 64 rendered
   // views, 1.13 M points: 122 -> 99 us against 2 x 1024; uniformly random points 80 -> 83 us)
-  __shared__ BatchHash hash;
+  __shared__ SamplerHash hash;
   __shared__ float wave_part[kPts / 64][8];
   __shared__ int blk_max_bits;
 
@@ -174,14 +182,14 @@ __global__ __launch_bounds__(kPts) void pc_loss_backward_kernel(
     int e2;
     (void)frexpf(bound, &e2);
     const bool fixed_ok = (bound > 0.0f) && (bound < 1e30f) && (e2 > -80);
-    const float to_fixed = fixed_ok ? ldexpf(1.0f, kFixedBits - e2) : 0.0f;
+    const float to_fixed = fixed_ok ? ldexpf(1.0f, SamplerHash::kBits - e2) : 0.0f;
     const float gs = go * f.scale;
     const float x0w = ax * gs, x1w = c.ox * gs;
     const float w0 = x0w * ay * az, w1 = x0w * ay * c.oz, w2 = x0w * c.oy * az, w3 = x0w * c.oy * c.oz;
     const float w4 = x1w * ay * az, w5 = x1w * ay * c.oz, w6 = x1w * c.oy * az, w7 = x1w * c.oy * c.oz;
     // (a NaN upstream gradient can be dropped by the block's fmaxf-based maximum: such a lane, like
     // any lane beyond the fixed-point range, adds in float, so NaN/Inf reach g_sdf as in autograd)
-    if (fixed_ok && fabsf(gs) * to_fixed < 3.5e13f /* 2^45 */) {
+    if (fixed_ok && fabsf(gs) * to_fixed < SamplerHash::kWeightLimit) {
       const float wk[8] = {w0, w1, w2, w3, w4, w5, w6, w7};
       hash.add_cell(gvol, c.lin, Rr, wk, to_fixed);
     } else if (go != 0.0f) {
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(kPts) void pc_loss_backward_kernel(
   const float bound = 2.0f * __int_as_float(blk_max_bits) * fabsf(f.scale);
   int e2;
   (void)frexpf(bound, &e2);
-  const float from_fixed = ldexpf(1.0f, e2 - kFixedBits);
+  const float from_fixed = ldexpf(1.0f, e2 - SamplerHash::kBits);
   hash.flush(gvol, Rr * Rr * Rr, from_fixed, tid, kPts);
 }
 

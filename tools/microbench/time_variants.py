@@ -14,10 +14,11 @@ def load(path):
     return h
 
 def main():
-    B, W, H = int(os.environ.get("B", 256)), 640, 480
+    B, W, H = int(os.environ.get("B", 256)), int(os.environ.get("W", 640)), int(os.environ.get("H", 480))
+    f, cxx, cyy = W / 2.0, W / 2.0, H / 2.0
     dev = torch.device("cuda:0")
     sdf = torch.tensor(oracle.blobs_sdf(0), device=dev)
-    pos, quat, isc = (torch.tensor(a, device=dev) for a in oracle.random_poses(B, seed=1))
+    pos, quat, isc = (torch.tensor(a, device=dev) for a in oracle.random_poses(B, seed=1, width=W, height=H, f=f))
     g = torch.rand((B, H, W), device=dev) * 2 - 1
     depth = torch.empty((B, H, W), device=dev)
     gs = torch.empty((64, 64, 64), device=dev); gp = torch.empty((B, 3), device=dev)
@@ -43,11 +44,11 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     def fwd(L, ws):
         rc = L.sdfr_render_forward(sdf.data_ptr(), 64, 0, pos.data_ptr(), quat.data_ptr(), isc.data_ptr(), B, W, H,
-                              320.0, 240.0, 320.0, 320.0, thr, depth.data_ptr(), ws.data_ptr(), ws.numel(), 0, st)
+                              cxx, cyy, f, f, thr, depth.data_ptr(), ws.data_ptr(), ws.numel(), 0, st)
         assert rc == 0, L.sdfr_last_error()
     def bwd(L, ws):
         rc = L.sdfr_render_backward(g.data_ptr(), depth.data_ptr(), sdf.data_ptr(), 64, 0, pos.data_ptr(), quat.data_ptr(),
-                               isc.data_ptr(), B, W, H, 320.0, 240.0, 320.0, 320.0, 0, gs.data_ptr(), 0, gp.data_ptr(),
+                               isc.data_ptr(), B, W, H, cxx, cyy, f, f, 0, gs.data_ptr(), 0, gp.data_ptr(),
                                gq.data_ptr(), gi.data_ptr(), ws.data_ptr(), ws.numel(), 0, st)
         assert rc == 0, L.sdfr_last_error()
     rounds = int(os.environ.get("ROUNDS", 7))
