@@ -342,8 +342,12 @@ struct PairRunHash {
   int keys[SLOTS];
 
   __device__ __forceinline__ void clear(int tid, int nthreads) {
-    for (int i = tid; i < SLOTS; i += nthreads) keys[i] = -1;
-    for (int i = tid; i < SLOTS * 4; i += nthreads) vals[i] = 0ull;
+    // 16-byte stores: the cost of an LDS phase follows its instruction count
+    typedef int i32x4v __attribute__((ext_vector_type(4)));
+    i32x4v* k4 = reinterpret_cast<i32x4v*>(keys);
+    i32x4v* v4 = reinterpret_cast<i32x4v*>(vals);
+    for (int i = tid; i < SLOTS / 4; i += nthreads) k4[i] = i32x4v{-1, -1, -1, -1};
+    for (int i = tid; i < SLOTS * 2; i += nthreads) v4[i] = i32x4v{0, 0, 0, 0};
   }
 
   __device__ __forceinline__ int slot_of(int key) {  // as RunHash::slot_of
@@ -384,7 +388,10 @@ struct PairRunHash {
     }
   }
 
-  // thread -> (slot, voxel k = 0..4 of the run): low half of entry k plus high half of entry k - 1
+  // thread -> (slot, voxel k = 0..4 of the run): low half of entry k plus high half of entry k - 1.
+  // (One lane per ENTRY with the neighbour's high half fetched by DPP -- 2 LDS reads per step instead of 3 --
+  // needs a second, quarter-filled global atomic for voxel 4: backward 158.7 -> 209 us.  The flush's global
+  // atomics, not its LDS reads, are the expensive part.)
   __device__ __forceinline__ void flush(float* __restrict__ gvol, int nvox, float from_fixed, int tid, int nthreads) {
     for (int i = tid; i < SLOTS * 5; i += nthreads) {
       const int slot = i / 5, k = i - slot * 5;
