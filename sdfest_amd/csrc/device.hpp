@@ -350,14 +350,15 @@ struct PairRunHash {
     for (int i = tid; i < SLOTS * 2; i += nthreads) v4[i] = i32x4v{0, 0, 0, 0};
   }
 
-  __device__ __forceinline__ int slot_of(int key) {  // as RunHash::slot_of
-    unsigned h = (((unsigned)key * 2654435761u) >> 16) & (SLOTS - 1);
+  // as RunHash::slot_of, continuing from a first probe that has been read already (`cur` = keys[h]): no
+  // second read of a slot that was seen empty or taken
+  __device__ __forceinline__ int slot_after(int key, unsigned h, int cur) {
 #pragma unroll 1
     for (int probe = 0; probe < 32; ++probe) {
-      int cur = __builtin_nontemporal_load(&keys[h]);
       if (cur == -1) cur = atomicCAS(&keys[h], -1, key);
       if (cur == -1 || cur == key) return (int)h;
       h = (h + 1) & (SLOTS - 1);
+      cur = __builtin_nontemporal_load(&keys[h]);
     }
     return -1;
   }
@@ -375,7 +376,7 @@ struct PairRunHash {
     }
     int slot[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) slot[j] = (cur[j] == key[j]) ? (int)h[j] : slot_of(key[j]);
+    for (int j = 0; j < 4; ++j) slot[j] = (cur[j] == key[j]) ? (int)h[j] : slot_after(key[j], h[j], cur[j]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (slot[j] >= 0) {
