@@ -337,17 +337,31 @@ class BatchRenderPlan:
         self.loss_stats = torch.empty((B, 2), **f32)
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         self._L = L
+        self._shape_sdf = (B, R, R, R) if per_view_sdf else (R, R, R)
+        self._shape_pos, self._shape_quat, self._shape_isc = (B, 3), (B, 4), (B,)
+        self._shape_img = (B, self.H, self.W)
 
     def _check(self, sdf, pos, quat, inv_scale, **images) -> None:
         """The C ABI takes raw device pointers: a tensor of another dtype, shape, device or layout
         would be read as garbage or out of bounds on the GPU.  Same exception type as the
-        reference's CHECK_CUDA / CHECK_CONTIGUOUS (sdf_renderer.cpp:9-13)."""
-        R, B = self.R, self.B
-        want = {"sdf": (B, R, R, R) if self.sdf_stride else (R, R, R), "position": (B, 3),
-                "orientation": (B, 4), "inv_scale": (B,)}
+        reference's CHECK_CUDA / CHECK_CONTIGUOUS (sdf_renderer.cpp:9-13).  One combined test on the
+        hot path (a single-view call is ~14 us of GPU work: per-tensor helper calls and dictionaries
+        made the eager loop host-bound); the slow path only names what is wrong."""
+        dev, f32 = self.device, torch.float32
+        ok = (sdf.device == dev and sdf.dtype is f32 and sdf.shape == self._shape_sdf and sdf.is_contiguous()
+              and pos.device == dev and pos.dtype is f32 and pos.shape == self._shape_pos and pos.is_contiguous()
+              and quat.device == dev and quat.dtype is f32 and quat.shape == self._shape_quat and quat.is_contiguous()
+              and inv_scale.device == dev and inv_scale.dtype is f32 and inv_scale.shape == self._shape_isc
+              and inv_scale.is_contiguous())
+        for t in images.values():
+            ok = ok and (t.device == dev and t.dtype is f32 and t.shape == self._shape_img and t.is_contiguous())
+        if ok:
+            return
+        want = {"sdf": self._shape_sdf, "position": self._shape_pos, "orientation": self._shape_quat,
+                "inv_scale": self._shape_isc}
         got = {"sdf": sdf, "position": pos, "orientation": quat, "inv_scale": inv_scale}
         for name, t in images.items():
-            want[name] = (B, self.H, self.W)
+            want[name] = self._shape_img
             got[name] = t
         for name, t in got.items():
             _check_input(t, name)
