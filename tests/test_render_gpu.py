@@ -48,8 +48,13 @@ def check_depth(d_hip, d_ref, margin, name=""):
     assert mism.sum() <= max(2, 1e-4 * d_ref.size), f"{name}: {int(mism.sum())} fragile flips"
     both = (d_hip > 0) & (d_ref > 0)
     if both.any():
-        err = np.max(np.abs(d_hip[both] / d_ref[both] - 1))
-        assert err < REL, f"{name}: depth rel err {err}"
+        # the oracle's margin is the smallest |lhs - rhs| of ANY branch of a pixel's march, the per-step hit tests
+        # included: a pixel below it may also take its hit one sample earlier or later (a depth off by ~threshold)
+        rel = np.abs(d_hip / np.where(both, d_ref, 1.0) - 1) * both
+        assert rel[robust].max(initial=0.0) < REL, f"{name}: depth rel err {rel[robust].max()}"
+        fragile = both & ~robust & (rel >= REL)
+        assert fragile.sum() <= max(2, 1e-4 * d_ref.size) and rel[~robust].max(initial=0.0) < 0.05, \
+            f"{name}: {int(fragile.sum())} fragile pixels, rel err {rel[~robust].max(initial=0.0)}"
     return mism
 
 
