@@ -121,6 +121,10 @@ __device__ __forceinline__ void resize_axis(int d, float ratio, int n_in, int& i
   l1 = src - (float)i0;
 }
 
+// w0 * a + w1 * b with the rounding spelled out (one product rounded, then one fma): the three resize kernels
+// must agree bit for bit, which "a * b + c * d" under -ffp-contract=fast does not promise.
+__device__ __forceinline__ float blend(float w0, float a, float w1, float b) { return fmaf(w0, a, w1 * b); }
+
 // grid: ceil(C * n_out^3 / 256) x N;  relu: max(., 0);  clamp > 0 clamps the result to [-clamp, clamp]
 __global__ __launch_bounds__(256) void resize3_kernel(const float* __restrict__ in, int C, int n_in,
                                                       int n_out, int relu, float clamp,
@@ -141,10 +145,10 @@ __global__ __launch_bounds__(256) void resize3_kernel(const float* __restrict__ 
   const float* p = in + ((size_t)n * C + c) * vi;
 #define AT(ix, iy, iz) p[((size_t)(ix) * n_in + (iy)) * n_in + (iz)]
   const float wx0 = 1.0f - lx, wy0 = 1.0f - ly, wz0 = 1.0f - lz;
-  float v = wx0 * (wy0 * (wz0 * AT(x0, y0, z0) + lz * AT(x0, y0, z1)) +
-                   ly * (wz0 * AT(x0, y1, z0) + lz * AT(x0, y1, z1))) +
-            lx * (wy0 * (wz0 * AT(x1, y0, z0) + lz * AT(x1, y0, z1)) +
-                  ly * (wz0 * AT(x1, y1, z0) + lz * AT(x1, y1, z1)));
+  float v = blend(wx0, blend(wy0, blend(wz0, AT(x0, y0, z0), lz, AT(x0, y0, z1)),
+                             ly, blend(wz0, AT(x0, y1, z0), lz, AT(x0, y1, z1))),
+                  lx, blend(wy0, blend(wz0, AT(x1, y0, z0), lz, AT(x1, y0, z1)),
+                            ly, blend(wz0, AT(x1, y1, z0), lz, AT(x1, y1, z1))));
 #undef AT
   if (relu) v = fmaxf(v, 0.0f);
   if (clamp > 0.0f) v = fminf(fmaxf(v, -clamp), clamp);
@@ -159,6 +163,8 @@ __global__ __launch_bounds__(256) void resize3_kernel(const float* __restrict__ 
 // whole z-rows.   grid: (tiles_x * tiles_y, C, N);  LDS: cols * (n_in + n_out) floats,
 // cols = max_rx * max_ry input columns under a tile (computed by the host with the same arithmetic).
 constexpr int kResizeTile = 8;
+// tensors up to this many elements take the launch-count-saving fused forms (single decodes, up to 8 latents)
+constexpr size_t kFewElements = (size_t)1 << 21;
 template <int LOG_NO>  // n_out = 1 << LOG_NO (16 .. 128): index splits are shifts, z is fixed per thread
 __global__ __launch_bounds__(256) void resize3_tiled_kernel(const float* __restrict__ in, int C, int n_in,
                                                             int relu, float clamp, int max_cols,
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(256) void resize3_tiled_kernel(const float* __restr
     const int z0 = z_i0[z], z1 = z_i1[z];
     const float lz = z_l[z], wz0 = 1.0f - lz;
     for (int col = tid >> LOG_NO; col < cols; col += 256 >> LOG_NO)
-      col_z[(col << LOG_NO) + z] = wz0 * col_in[col * n_in + z0] + lz * col_in[col * n_in + z1];
+      col_z[(col << LOG_NO) + z] = blend(wz0, col_in[col * n_in + z0], lz, col_in[col * n_in + z1]);
   }
   __syncthreads();
   float* dst = out + ((size_t)n * C + c) * n_out * n_out * n_out;
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(256) void resize3_tiled_kernel(const float* __restr
     const float lx = t_l[jx], ly = t_l[8 + jy], wx0 = 1.0f - lx, wy0 = 1.0f - ly;
     const int r0 = t_i0[jx] * ry, r1 = t_i1[jx] * ry, c0 = t_i0[8 + jy], c1 = t_i1[8 + jy];
 #define COLZ(r, cc) col_z[(((r) + (cc)) << LOG_NO) + z]
-    float v = wx0 * (wy0 * COLZ(r0, c0) + ly * COLZ(r0, c1)) + lx * (wy0 * COLZ(r1, c0) + ly * COLZ(r1, c1));
+    float v = blend(wx0, blend(wy0, COLZ(r0, c0), ly, COLZ(r0, c1)), lx, blend(wy0, COLZ(r1, c0), ly, COLZ(r1, c1)));
 #undef COLZ
     if (relu) v = fmaxf(v, 0.0f);
     if (clamp > 0.0f) v = fminf(fmaxf(v, -clamp), clamp);
@@ -245,6 +251,55 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
     float r = acc[co] + bias[co];
     if (relu) r = fmaxf(r, 0.0f);
     out[((size_t)blockIdx.y * COUT + co) * vox + v] = r;
+  }
+}
+
+// The swapped last layer of a single decode in one launch (one launch less per iteration of the captured loop):
+// out = resize(conv1x1(in)), the 1x1 mix (same fmaf chain over ci and "+ bias" last as conv1x1_kernel) formed
+// at each of the 8 corners, then resize3_kernel's expression tree -- bit-identical to the two launches.
+// grid: (ceil(n_out^3 / 256), N)
+template <int COUT>
+__global__ __launch_bounds__(256) void resize3_mix_kernel(const float* __restrict__ in, const float* __restrict__ wmat,
+                                                          const float* __restrict__ bias, int Cin, int n_in,
+                                                          int n_out, int relu, float clamp,
+                                                          float* __restrict__ out) {
+  const size_t vo = (size_t)n_out * n_out * n_out, vi = (size_t)n_in * n_in * n_in;
+  const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= vo) return;
+  const int n = blockIdx.y;
+  const int z = (int)(r % n_out), y = (int)((r / n_out) % n_out), x = (int)(r / ((size_t)n_out * n_out));
+  const float ratio = (float)n_in / (float)n_out;
+  int xi[2], yi[2], zi[2];
+  float lx, ly, lz;
+  resize_axis(x, ratio, n_in, xi[0], xi[1], lx);
+  resize_axis(y, ratio, n_in, yi[0], yi[1], ly);
+  resize_axis(z, ratio, n_in, zi[0], zi[1], lz);
+  const float* p = in + (size_t)n * Cin * vi;
+  float corner[8][COUT];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const size_t off = ((size_t)xi[k >> 2] * n_in + yi[(k >> 1) & 1]) * n_in + zi[k & 1];
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = 0.0f;
+    for (int ci = 0; ci < Cin; ++ci) {
+      const float a = p[(size_t)ci * vi + off];
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) acc[co] = fmaf(a, wmat[ci * 16 + co], acc[co]);
+    }
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) corner[k][co] = acc[co] + bias[co];
+  }
+  const float wx0 = 1.0f - lx, wy0 = 1.0f - ly, wz0 = 1.0f - lz;
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) {
+    float v = blend(wx0, blend(wy0, blend(wz0, corner[0][co], lz, corner[1][co]),
+                               ly, blend(wz0, corner[2][co], lz, corner[3][co])),
+                    lx, blend(wy0, blend(wz0, corner[4][co], lz, corner[5][co]),
+                              ly, blend(wz0, corner[6][co], lz, corner[7][co])));
+    if (relu) v = fmaxf(v, 0.0f);
+    if (clamp > 0.0f) v = fminf(fmaxf(v, -clamp), clamp);
+    out[((size_t)n * COUT + co) * vo + r] = v;
   }
 }
 
@@ -548,6 +603,101 @@ __global__ __launch_bounds__(256) void resize_axis_backward_kernel(const float* 
   g_in[idx] = acc;
 }
 
+constexpr int kZyTaps = 10;  // longest source range resize_zy_backward_kernel takes (a 2x resize: 8)
+// range of output indices d that can carry weight on input index i (a superset; zero weights are skipped)
+__device__ __forceinline__ void resize_sources(int i, int n_in, int n_out, int& d0, int& d1) {
+  const float inv = (float)n_out / (float)n_in;
+  d0 = max((int)floorf(((float)i - 0.5f) * inv - 0.5f) - 1, 0);
+  d1 = min((int)ceilf(((float)i + 1.5f) * inv - 0.5f) + 1, n_out - 1);
+}
+
+// The z pass and the y pass of the transposed resize in one launch (single latents: the captured loop is bound
+// by its launch count; a 2x resize has <= 4 x 4 weighted terms per voxel).  [outer][n_out][n_out] ->
+// [outer][n_in][n_in]; the inner chain (over z) and the outer chain (over y) are the two passes' fmaf chains in
+// their order, so the result is bit-identical to resize_axis_backward_kernel run twice.
+__global__ __launch_bounds__(256) void resize_zy_backward_kernel(const float* __restrict__ g_out, size_t outer,
+                                                                 int n_in, int n_out, float* __restrict__ g_in) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= outer * n_in * n_in) return;
+  const int iz = (int)(idx % n_in), iy = (int)((idx / n_in) % n_in);
+  const size_t o = idx / ((size_t)n_in * n_in);
+  const float ratio = (float)n_in / (float)n_out;
+  int y0, y1, z0, z1;
+  resize_sources(iy, n_in, n_out, y0, y1);
+  resize_sources(iz, n_in, n_out, z0, z1);
+  // the z weights do not depend on the row: form them once; a tap past z1 re-reads z1 with weight 0
+  // (the host takes this kernel only when no range is longer than kZyTaps)
+  float wz[kZyTaps];
+  int oz[kZyTaps];
+#pragma unroll
+  for (int k = 0; k < kZyTaps; ++k) {
+    const int dz = min(z0 + k, z1);
+    wz[k] = (z0 + k <= z1) ? resize_weight(dz, iz, ratio, n_in) : 0.0f;
+    oz[k] = dz;
+  }
+  const float* p = g_out + o * n_out * n_out;
+  float acc = 0.0f;
+  for (int dy = y0; dy <= y1; ++dy) {
+    const float wy = resize_weight(dy, iy, ratio, n_in);
+    if (wy == 0.0f) continue;
+    const float* row = p + (size_t)dy * n_out;
+    float v[kZyTaps];
+#pragma unroll
+    for (int k = 0; k < kZyTaps; ++k) v[k] = row[oz[k]];   // independent loads, all in flight
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kZyTaps; ++k)
+      if (wz[k] != 0.0f) t = fmaf(wz[k], v[k], t);
+    acc = fmaf(wy, t, acc);
+  }
+  g_in[idx] = acc;
+}
+
+// The x pass of the transposed resize followed by the transposed 1x1 layer that was swapped with it (Cin -> COUT
+// channels, conv1x1_kernel's chain and "+ 0" bias), ReLU-masked and zero-padded for the transposed convolution
+// below: three launches of the captured loop in one, same arithmetic.   grid: (ceil(np^3 / 256), N)
+template <int COUT>
+__global__ __launch_bounds__(256) void resize_x_backward_mix_pad_kernel(
+    const float* __restrict__ g_out, int Cin, int n_in, int n_out, const float* __restrict__ wmat,
+    const float* __restrict__ bias, const float* __restrict__ act, int pad, float* __restrict__ out) {
+  const int np = n_in + 2 * pad;
+  const size_t vp = (size_t)np * np * np, vin = (size_t)n_in * n_in * n_in;
+  const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= vp) return;
+  const int n = blockIdx.y;
+  const int z = (int)(r % np) - pad, y = (int)((r / np) % np) - pad, i = (int)(r / ((size_t)np * np)) - pad;
+  float res[COUT];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) res[co] = 0.0f;
+  if (i >= 0 && i < n_in && y >= 0 && y < n_in && z >= 0 && z < n_in) {
+    const size_t inner = (size_t)n_in * n_in, rr = (size_t)y * n_in + z;
+    const float ratio = (float)n_in / (float)n_out;
+    int d0, d1;
+    resize_sources(i, n_in, n_out, d0, d1);
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = 0.0f;
+    for (int ci = 0; ci < Cin; ++ci) {
+      const float* p = g_out + (((size_t)n * Cin + ci) * n_out) * inner + rr;
+      float a = 0.0f;
+      for (int d = d0; d <= d1; ++d) {
+        const float w = resize_weight(d, i, ratio, n_in);
+        if (w != 0.0f) a = fmaf(w, p[(size_t)d * inner], a);
+      }
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) acc[co] = fmaf(a, wmat[ci * 16 + co], acc[co]);
+    }
+    const size_t src = (size_t)i * inner + rr;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+      const float v = acc[co] + bias[co];
+      res[co] = (!act || act[((size_t)n * COUT + co) * vin + src] > 0.0f) ? v : 0.0f;
+    }
+  }
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) out[((size_t)n * COUT + co) * vp + r] = res[co];
+}
+
 // The x pass of the transposed resize (outer = N*C volumes, inner = n_in^2) writing straight into the
 // zero-padded, ReLU-masked tensor the next transposed convolution reads (= the pass followed by
 // pad_mask_kernel, one launch less per layer in the captured loop):
@@ -598,7 +748,23 @@ __global__ __launch_bounds__(kFcBlock) void fc_last_backward_kernel(const float*
   const float* g = g_last + (size_t)n * wout;
   const float* a = act + (size_t)n * wout;
   float part = 0.0f;
-  for (int o = tid; o < wout; o += kFcBlock) part = fmaf(wt[o], (a[o] > 0.0f) ? g[o] : 0.0f, part);
+  if ((wout & 3) == 0 && (((uintptr_t)wt | (uintptr_t)g | (uintptr_t)a) & 15) == 0) {
+    // 16-byte loads, all of a thread's loads in flight at once (8192 outputs: 8 per array): 15.9 -> 4.6 us in the loop
+    const float4 *w4 = reinterpret_cast<const float4*>(wt), *g4 = reinterpret_cast<const float4*>(g),
+                 *a4 = reinterpret_cast<const float4*>(a);
+    float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+#pragma unroll 8
+    for (int o = tid; o < wout / 4; o += kFcBlock) {
+      const float4 w = w4[o], gv = g4[o], av = a4[o];
+      p0 = fmaf(w.x, (av.x > 0.0f) ? gv.x : 0.0f, p0);
+      p1 = fmaf(w.y, (av.y > 0.0f) ? gv.y : 0.0f, p1);
+      p2 = fmaf(w.z, (av.z > 0.0f) ? gv.z : 0.0f, p2);
+      p3 = fmaf(w.w, (av.w > 0.0f) ? gv.w : 0.0f, p3);
+    }
+    part = (p0 + p1) + (p2 + p3);
+  } else {
+    for (int o = tid; o < wout; o += kFcBlock) part = fmaf(wt[o], (a[o] > 0.0f) ? g[o] : 0.0f, part);
+  }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
   if ((tid & 63) == 0) red[tid >> 6] = part;
@@ -1061,6 +1227,32 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
     const int conv_relu = swap ? 0 : d->conv_relu[l];
     const float* wm = d->d_params + d->conv_w_off[l];
     const float* bs = d->d_params + d->conv_b_off[l];
+    if (swap && k == 1 && co_n <= 4 && m_out != n &&
+        (size_t)N * co_n * m_out * m_out * m_out <= kFewElements) {
+      // single latents: the 1x1 mix inside the resize (one launch)
+      float* dst = layer_dst ? layer_dst : buf[cur ^ 1];
+      const size_t vo = (size_t)m_out * m_out * m_out;
+      const dim3 gm((unsigned)((vo + 255) / 256), N);
+      const float clampm = to_out ? clampv : 0.0f;
+#define SDFR_MIXF(CO) hipLaunchKernelGGL((resize3_mix_kernel<CO>), gm, dim3(256), 0, st, act_in, wm, bs, c, n, m_out, d->conv_relu[l], clampm, dst)
+      if (co_n == 1) SDFR_MIXF(1); else if (co_n == 2) SDFR_MIXF(2); else if (co_n == 3) SDFR_MIXF(3); else SDFR_MIXF(4);
+#undef SDFR_MIXF
+      if (dst == buf[cur ^ 1]) cur ^= 1;
+      act_in = dst;
+      c = co_n;
+      n = m_out;
+      if (is_last && act_in != out) {
+        if (n != d->volume) {
+          resize(act_in, 1, n, d->volume, 0, clampv, out);
+        } else {
+          copy_words_async(out, act_in, (size_t)N * vox, st);
+          if (clampv > 0.0f)
+            hipLaunchKernelGGL(clamp_kernel, dim3((unsigned)(((size_t)N * vox + 255) / 256)), dim3(256), 0,
+                               st, out, (size_t)N * vox, clampv);
+        }
+      }
+      continue;
+    }
     if (k == 1 && co_n <= 4) {
       const int voxn = n * n * n;
       const dim3 g1((voxn + 255) / 256, N);
@@ -1136,14 +1328,39 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
   // transpose of a trilinear resize of [N*C] volumes n_out^3 -> n_in^3: z, then y, then x
   // pad >= 0: the last pass also applies the ReLU mask `act` (may be null) and the zero padding of the
   // transposed convolution that follows (resize_x_backward_pad_kernel)
-  auto resize_backward = [&](int C, int n_in, int n_out, int pad = -1, const float* act = nullptr) {
+  // Single latents (the captured loop) are bound by the launch count: there the z and y passes share a launch.
+  // mix_w != nullptr: the x pass also applies the transposed 1x1 layer C -> mix_cout channels
+  // (resize_x_backward_mix_pad_kernel; needs pad >= 0).
+  auto resize_backward = [&](int C, int n_in, int n_out, int pad = -1, const float* act = nullptr,
+                             const float* mix_w = nullptr, int mix_cout = 0) {
     const size_t nc = (size_t)N * C;
+    bool few = nc * n_out * n_out * n_out <= kFewElements;
+    if (few) {  // longest source range, same arithmetic as resize_sources
+      const float inv = (float)n_out / (float)n_in;
+      for (int i = 0; i < n_in && few; ++i) {
+        const int d0 = std::max((int)floorf(((float)i - 0.5f) * inv - 0.5f) - 1, 0);
+        const int d1 = std::min((int)ceilf(((float)i + 1.5f) * inv - 0.5f) + 1, n_out - 1);
+        few = d1 - d0 + 1 <= kZyTaps;
+      }
+    }
     struct Pass { size_t outer; size_t inner; } passes[3] = {
         {nc * n_out * n_out, 1},                  // z:  [nc][no][no][no] -> [nc][no][no][ni]
         {nc * n_out, (size_t)n_in},               // y:  [nc][no][no][ni] -> [nc][no][ni][ni]
         {nc, (size_t)n_in * n_in}};               // x:  [nc][no][ni][ni] -> [nc][ni][ni][ni]
     for (int a = 0; a < 3; ++a) {
-      if (a == 2 && pad >= 0) {
+      if (a == 0 && few) {
+        const size_t cnt = nc * n_out * n_in * n_in;
+        hipLaunchKernelGGL(resize_zy_backward_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, g,
+                           nc * n_out, n_in, n_out, buf[cur]);
+        a = 1;
+      } else if (a == 2 && mix_w) {
+        const size_t np = (size_t)n_in + 2 * pad;
+        const dim3 gm((unsigned)((np * np * np + 255) / 256), N);
+        const float* zb = d->d_params + d->zero_bias_off;
+#define SDFR_MIX(CO) hipLaunchKernelGGL((resize_x_backward_mix_pad_kernel<CO>), gm, dim3(256), 0, st, g, C, n_in, n_out, mix_w, zb, act, pad, buf[cur])
+        if (mix_cout == 1) SDFR_MIX(1); else if (mix_cout == 2) SDFR_MIX(2); else if (mix_cout == 3) SDFR_MIX(3); else SDFR_MIX(4);
+#undef SDFR_MIX
+      } else if (a == 2 && pad >= 0) {
         const size_t np = (size_t)n_in + 2 * pad, cnt = nc * np * np * np;
         hipLaunchKernelGGL(resize_x_backward_pad_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, g, nc,
                            n_in, n_out, act, pad, buf[cur]);
@@ -1182,6 +1399,19 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
       cur ^= 1;
     }
     // (swapped 1x1 layer: forward was conv -> resize, so the resize is transposed first)
+    // single latents: its last pass also runs the transposed 1x1 layer and writes the padded, masked input of
+    // the transposed convolution below (conv1x1 + pad_mask launches saved)
+    const bool mix = swap && !act && k == 1 && ci_n <= 4 && l > 0 && !d->conv_swap[l - 1] && out_n[l - 1] == prev &&
+                     d->conv_cout[l - 1] == ci_n && prev != nin &&
+                     (size_t)N * co_n * nin * nin * nin <= kFewElements;
+    if (mix) {
+      resize_backward(co_n, prev, nin, d->conv_k[l - 1] - 1,
+                      d->conv_relu[l - 1] ? tape + (size_t)N * d->tape_conv_off[l - 1] : nullptr,
+                      d->d_params + d->bwd_w_off[l], ci_n);
+      padded = true;
+      n = prev;
+      continue;
+    }
     if (swap) resize_backward(co_n, prev, nin);
     // 2. data gradient = valid conv (kernel k) of the padded tensor with the flipped weights
     const int kpad = d->bwd_kpad[l];
