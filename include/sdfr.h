@@ -236,6 +236,20 @@ SDFR_API int sdfr_views_to_pose_grad(const float* orientation, const float* scal
                             const float* gb_scale, float* g_position, float* g_orientation,
                             float* g_scale, int device, void* stream);
 
+/* The same chain with the two per-view reductions that precede it folded in: three launches of a
+ * launch-bound loop in one.  Call sdfr_render_backward / _l1 with g_pos = g_quat = g_inv_scale = NULL and
+ * sdfr_pc_loss_backward / sdfr_pc_l1_backward / _accumulate with g_pos = g_quat = g_scale = NULL ("deferred": they
+ * then leave their per-tile / per-block partial sums in their workspaces and skip their reduce launch), then
+ * pass those workspaces here, untouched in between, with the same V (= B), W, H, offsets, max_view_points and the
+ * per-view quaternions quat_c the sampler was given.  Either workspace may be NULL (term absent).  pc_loss [V]:
+ * the loss values of sdfr_pc_l1_backward* (which does not write them when deferred), NULL for the plain backward.
+ * Same additions in the same order as the three separate launches: identical results.  V <= 64. */
+SDFR_API int sdfr_views_to_pose_grad_deferred(const float* orientation, const float* scale, const float* cam_quat,
+                                     int V, const void* render_workspace, int W, int H,
+                                     const void* pc_workspace, const int* offsets, int max_view_points,
+                                     const float* quat_c, float* pc_loss, float* g_position,
+                                     float* g_orientation, float* g_scale, int device, void* stream);
+
 /* :125-131 -- loss[v] = mean |estimate - target| over (target > 0) & (estimate > 0) (NaN when the
  * overlap is empty, like torch.mean of an empty selection); grad_estimate = weight * d loss / d
  * estimate.  Deterministic two-pass reduction. */

@@ -57,6 +57,8 @@ SIGNATURES = {
     "sdfr_pose_to_views": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp]),
     "sdfr_views_to_pose_grad": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                         c_fp, c_fp, c_fp, c_int, c_fp]),
+    "sdfr_views_to_pose_grad_deferred": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp, c_int, c_int, c_fp, c_fp, c_int,
+                                                 c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp]),
     "sdfr_depth_l1_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
     "sdfr_depth_l1_loss": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_f, c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),
     "sdfr_pc_l1_loss": (c_int, [c_fp, c_fp, c_int, c_int, c_f, c_fp, c_fp, c_int, c_fp]),

@@ -94,6 +94,11 @@ inline TileGeom backward_geom(int B, int W, int H) {
                                                                                          : kSmallTile;
 }
 
+// points per workgroup of the sampler's kernels = points per partial record of its backward (sampler.hip; the
+// deferred gradient chain in loop.hip reads those records)
+constexpr int kSamplerPts = 256;
+constexpr int kDeferredMaxViews = 64;  // sdfr_views_to_pose_grad_deferred: views per call
+
 // packed cell records are used for a grid shared by >= kPackedMinViews views, up to kPackedMaxR
 #ifndef SDFR_PACKED_MIN_VIEWS
 #define SDFR_PACKED_MIN_VIEWS 4

@@ -352,10 +352,11 @@ __device__ __forceinline__ void stage_to_lds(float* __restrict__ dst, const floa
 __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
     const float* __restrict__ in, const float* __restrict__ wmat, const int* __restrict__ taps,
     const float* __restrict__ bias, float* __restrict__ out, int Cin, int Cout, int n, int m,
-    int kpad, int relu, int tiles_per_wave, int zg) {
+    int kpad, int relu, int tiles_per_wave, int zg, int split_k) {
   extern __shared__ float lds[];
   float* w_l = lds;                                       // [kpad][16]
   int* tap_l = reinterpret_cast<int*>(lds + (size_t)kpad * 16);  // [kpad]
+  float* red = lds + (size_t)kpad * 17;                   // split_k: [4 waves][64 lanes][4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int co_tile = blockIdx.y, nb = blockIdx.z;
   const float* wsrc = wmat + (size_t)co_tile * kpad * 16;
@@ -373,6 +374,54 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
   const int co = zg > 1 ? row % Cout : co_tile * 16 + row;
   const bool col_ok = zg > 1 ? row < zg * Cout : co < Cout;
   const float bv = col_ok ? bias[co] : 0.0f;
+  if (split_k) {
+    // Single latents: a layer has fewer tiles than the chip has SIMDs and a wave's K loop is a chain of
+    // kpad / 32 gather round trips (8 us of a 10 us launch for the 16 -> 16 layer).  The four waves of a
+    // workgroup share ONE tile, each taking every fourth 32-tap chunk, and wave 0 adds the four partial
+    // accumulators, (w0 + w1) + (w2 + w3).   grid: (tiles, co_tiles, N)
+    const int t = blockIdx.x;
+    const int pos = min(t * 16 + row, mrows - 1);
+    const int xy = pos / zgn, g = pos - xy * zgn, x = xy / m, y = xy - x * m;
+    const float* base = src + ((size_t)x * n + y) * n + g * zg;
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int full = kpad / 32;
+    for (int c = wave; c < full; c += 4) {
+      const int kk0 = c * 32;
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int kk = kk0 + 4 * u + kq;
+        a[u] = base[tap_l[kk]];
+        b[u] = w_l[kk * 16 + row];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+    }
+    if (wave == (full & 3)) {  // the wave with the fewest chunks takes the tail
+      for (int kk0 = full * 32; kk0 < kpad; kk0 += 4) {
+        const int kk = kk0 + kq;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(base[tap_l[kk]], w_l[kk * 16 + row], acc, 0, 0, 0);
+      }
+    }
+    *reinterpret_cast<f32x4*>(red + (size_t)tid * 4) = acc;
+    __syncthreads();
+    if (wave != 0 || !col_ok) return;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(red + (size_t)lane * 4);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(red + (size_t)(64 + lane) * 4);
+    const f32x4 a2 = *reinterpret_cast<const f32x4*>(red + (size_t)(128 + lane) * 4);
+    const f32x4 a3 = *reinterpret_cast<const f32x4*>(red + (size_t)(192 + lane) * 4);
+    float* dst = out + ((size_t)nb * Cout + co) * mv + dz;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int p = t * 16 + kq * 4 + r;
+      if (p >= mrows) continue;
+      const int pxy = p / zgn, pg = p - pxy * zgn;
+      float v = ((a0[r] + a1[r]) + (a2[r] + a3[r])) + bv;
+      if (relu) v = fmaxf(v, 0.0f);
+      dst[(size_t)pxy * m + pg * zg] = v;
+    }
+    return;
+  }
   const int first = (blockIdx.x * 4 + wave) * tiles_per_wave;
   for (int t = first; t < first + tiles_per_wave && t < n_tiles; ++t) {
     const int pos = min(t * 16 + row, mrows - 1);
@@ -829,6 +878,15 @@ __global__ __launch_bounds__(kFcBlock) void fc_stack_backward_kernel(const float
 using namespace sdfr;
 
 namespace {
+// conv3d_mfma_kernel's split-K form: for launches with so few tiles that a wave's K loop is the critical path
+#ifndef SDFR_SPLITK_MAX_TILES
+#define SDFR_SPLITK_MAX_TILES 2048
+#endif
+int use_split_k(bool zgrp, int n_tiles, int co_tiles, int N, int kpad) {
+  // (the choice does not depend on N up to 16 samples: small batches decode bit-identically to single latents)
+  return (!zgrp && (long long)n_tiles * co_tiles <= SDFR_SPLITK_MAX_TILES && N <= 16 && kpad >= 128) ? 1 : 0;
+}
+
 // The direct convolution is for batches (enough tiles to fill the chip); returns false when the
 // layer / batch does not qualify and the caller falls back to the MFMA kernel.
 bool launch_direct(const sdfr_decoder* d, size_t w_off, const float* src, const float* bias, float* dst,
@@ -1264,14 +1322,17 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
     } else {
       const sdfr_decoder::ZPlan& zp = d->fwd_z[l];
       // (a single decode is latency-bound: there the finer grid of the ungrouped form wins)
-      const bool zgrp = zp.zg > 1 && !swap && (long long)m * m * (m / zp.zg) * N >= kZGroupMinRows;
+      // (up to 16 samples the split-K form decides, so that small batches equal single decodes bit for bit)
+      const int split = use_split_k(false, (m * m * m + 15) / 16, (co_n + 15) / 16, N, kpad);
+      const bool zgrp = !split && zp.zg > 1 && !swap && (long long)m * m * (m / zp.zg) * N >= kZGroupMinRows;
       const int kp = zgrp ? zp.kpad : kpad, rows = m * m * (m / (zgrp ? zp.zg : 1));
       const int nt = (rows + 15) / 16, tw = nt >= 32768 ? 4 : 1;
-      hipLaunchKernelGGL(conv3d_mfma_kernel, dim3((nt + 4 * tw - 1) / (4 * tw), zgrp ? 1 : (co_n + 15) / 16, N),
-                         dim3(256), (size_t)kp * 17 * sizeof(float), st, act_in,
+      hipLaunchKernelGGL(conv3d_mfma_kernel,
+                         dim3(split ? nt : (nt + 4 * tw - 1) / (4 * tw), zgrp ? 1 : (co_n + 15) / 16, N),
+                         dim3(256), (size_t)kp * 17 * sizeof(float) + (split ? 4096 : 0), st, act_in,
                          zgrp ? d->d_params + zp.w_off : wm,
                          reinterpret_cast<const int*>(d->d_params + (zgrp ? zp.tab_off : d->conv_tab_off[l])),
-                         bs, conv_dst, c, co_n, n, m, kp, conv_relu, tw, zgrp ? zp.zg : 1);
+                         bs, conv_dst, c, co_n, n, m, kp, conv_relu, tw, zgrp ? zp.zg : 1, split);
     }
     if (conv_dst == buf[cur ^ 1]) cur ^= 1;
     act_in = conv_dst;
@@ -1429,15 +1490,18 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
       // (batched: direct VALU convolution)
     } else {
       const sdfr_decoder::ZPlan& zp = d->bwd_z[l];
-      const bool zgrp = zp.zg > 1 && !swap && (long long)nconv * nconv * (nconv / zp.zg) * N >= kZGroupMinRows;
+      const int split = use_split_k(false, (nconv * nconv * nconv + 15) / 16, (ci_n + 15) / 16, N, kpad);
+      const bool zgrp = !split && zp.zg > 1 && !swap &&
+                        (long long)nconv * nconv * (nconv / zp.zg) * N >= kZGroupMinRows;
       const int kp = zgrp ? zp.kpad : kpad, rows = nconv * nconv * (nconv / (zgrp ? zp.zg : 1));
       const int nt = (rows + 15) / 16, tw = nt >= 32768 ? 4 : 1;
-      hipLaunchKernelGGL(conv3d_mfma_kernel, dim3((nt + 4 * tw - 1) / (4 * tw), zgrp ? 1 : (ci_n + 15) / 16, N),
-                         dim3(256), (size_t)kp * 17 * sizeof(float), st, g,
+      hipLaunchKernelGGL(conv3d_mfma_kernel,
+                         dim3(split ? nt : (nt + 4 * tw - 1) / (4 * tw), zgrp ? 1 : (ci_n + 15) / 16, N),
+                         dim3(256), (size_t)kp * 17 * sizeof(float) + (split ? 4096 : 0), st, g,
                          d->d_params + (zgrp ? zp.w_off : d->bwd_w_off[l]),
                          reinterpret_cast<const int*>(d->d_params + (zgrp ? zp.tab_off : d->bwd_tab_off[l])),
                          d->d_params + d->zero_bias_off, buf[cur], co_n, ci_n, np, nconv, kp, 0, tw,
-                         zgrp ? zp.zg : 1);
+                         zgrp ? zp.zg : 1, split);
     }
     g = buf[cur];
     cur ^= 1;

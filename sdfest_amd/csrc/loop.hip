@@ -106,6 +106,109 @@ __global__ void views_to_pose_grad_kernel(const float* __restrict__ orientation,
   g_scale[0] = gs;
 }
 
+// The same chain with the two per-view reductions in front of it folded in (pose_reduce_kernel of render.hip,
+// pc_loss_reduce_kernel of sampler.hip: same order of additions, so the same numbers): one launch instead of
+// three.  One workgroup; wave w reduces views w, w + 4, ... into LDS, thread 0 then runs the chain.
+__global__ __launch_bounds__(256) void views_to_pose_grad_deferred_kernel(
+    const float* __restrict__ orientation, const float* __restrict__ scale, const float* __restrict__ cam_quat,
+    int V, const ViewSetup* __restrict__ setup, const float* __restrict__ tile_part, int ntx, int nty,
+    int tile_w, int tile_h, const float* __restrict__ pc_part, const float* __restrict__ pc_loss_part,
+    const int* __restrict__ offsets, int n_single, int nblk, const float* __restrict__ quat_c,
+    float* __restrict__ pc_loss, float* __restrict__ g_position, float* __restrict__ g_orientation,
+    float* __restrict__ g_scale) {
+  __shared__ float view_g[kDeferredMaxViews][16];  // [0..7] renderer: pos, quat, inv_scale; [8..15] sampler
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int v = wave; v < V; v += 4) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (tile_part) {
+      const ViewSetup& s = setup[v];
+      const int x0 = s.rect[0], y0 = s.rect[1], x1 = s.rect[2], y1 = s.rect[3];
+      if (x1 > x0 && y1 > y0) {
+        const int tx0 = x0 / tile_w, tx1 = (x1 - 1) / tile_w, ty0 = y0 / tile_h, ty1 = (y1 - 1) / tile_h;
+        const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1);
+        const float* base = tile_part + (size_t)v * ntx * nty * 8;
+        for (int i = lane; i < n; i += 64) {
+          const int ty = ty0 + i / nx, tx = tx0 + i % nx;
+          const float4* p = reinterpret_cast<const float4*>(base + ((size_t)ty * ntx + tx) * 8);
+          const float4 a = p[0], c = p[1];
+          acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+          acc[4] += c.x; acc[5] += c.y; acc[6] += c.z; acc[7] += c.w;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = wave_sum(acc[k]);
+    }
+    if (lane < 8) {
+      float r = acc[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) r = (lane == k) ? acc[k] : r;
+      view_g[v][lane] = r;
+    }
+    float pcs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (pc_part) {
+      const int len = offsets ? offsets[v + 1] - offsets[v] : n_single;
+      const int nb = (len + kSamplerPts - 1) / kSamplerPts;
+      if (pc_loss_part) {
+        float sa = 0.0f;
+        for (int i = lane; i < nb; i += 64) sa += pc_loss_part[(size_t)v * nblk + i];
+        sa = wave_sum(sa);
+        if (lane == 0) pc_loss[v] = sa / (float)len;
+      }
+      for (int i = lane; i < nb; i += 64) {
+        const float4* p = reinterpret_cast<const float4*>(pc_part + ((size_t)v * nblk + i) * 8);
+        const float4 a = p[0], c = p[1];
+        pcs[0] += a.x; pcs[1] += a.y; pcs[2] += a.z; pcs[3] += a.w;
+        pcs[4] += c.x; pcs[5] += c.y; pcs[6] += c.z; pcs[7] += c.w;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) pcs[k] = wave_sum(pcs[k]);
+      // Jacobian of q^ = q / |q| on the view's quaternion, as pc_loss_reduce_kernel
+      const float x = quat_c[4 * v], y = quat_c[4 * v + 1], z = quat_c[4 * v + 2], w = quat_c[4 * v + 3];
+      const float inv_norm = 1.0f / sqrtf(x * x + y * y + z * z + w * w);
+      const float qn[4] = {x * inv_norm, y * inv_norm, z * inv_norm, w * inv_norm};
+      const float dq = qn[0] * pcs[3] + qn[1] * pcs[4] + qn[2] * pcs[5] + qn[3] * pcs[6];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pcs[3 + k] = (pcs[3 + k] - qn[k] * dq) * inv_norm;
+    }
+    if (lane < 8) {
+      float r = pcs[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) r = (lane == k) ? pcs[k] : r;
+      view_g[v][8 + lane] = r;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const float q[4] = {orientation[0], orientation[1], orientation[2], orientation[3]};
+  const float inv_n = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const float nq[4] = {q[0] * inv_n, q[1] * inv_n, q[2] * inv_n, q[3] * inv_n};
+  float gp[3] = {0, 0, 0}, gn[4] = {0, 0, 0, 0}, gs = 0.0f;
+  const float s = scale[0];
+  for (int v = 0; v < V; ++v) {
+    const float a[4] = {-cam_quat[4 * v], -cam_quat[4 * v + 1], -cam_quat[4 * v + 2], cam_quat[4 * v + 3]};
+    float m[9];
+    quat_matrix(a, m);
+    const float* ga = view_g[v];
+    const float* gb = view_g[v] + 8;
+    float gpc[3], gqc[4];
+    for (int k = 0; k < 3; ++k) gpc[k] = (tile_part ? ga[k] : 0.0f) + (pc_part ? gb[k] : 0.0f);
+    for (int k = 0; k < 4; ++k) gqc[k] = (tile_part ? ga[3 + k] : 0.0f) + (pc_part ? gb[3 + k] : 0.0f);
+    gp[0] += m[0] * gpc[0] + m[3] * gpc[1] + m[6] * gpc[2];
+    gp[1] += m[1] * gpc[0] + m[4] * gpc[1] + m[7] * gpc[2];
+    gp[2] += m[2] * gpc[0] + m[5] * gpc[1] + m[8] * gpc[2];
+    const float ax = a[0], ay = a[1], az = a[2], aw = a[3];
+    gn[0] += aw * gqc[0] + az * gqc[1] - ay * gqc[2] - ax * gqc[3];
+    gn[1] += -az * gqc[0] + aw * gqc[1] + ax * gqc[2] - ay * gqc[3];
+    gn[2] += ay * gqc[0] - ax * gqc[1] + aw * gqc[2] - az * gqc[3];
+    gn[3] += ax * gqc[0] + ay * gqc[1] + az * gqc[2] + aw * gqc[3];
+    gs += (tile_part ? -ga[7] / (s * s) : 0.0f) + (pc_part ? gb[7] : 0.0f);
+  }
+  const float d = nq[0] * gn[0] + nq[1] * gn[1] + nq[2] * gn[2] + nq[3] * gn[3];
+  for (int k = 0; k < 3; ++k) g_position[k] = gp[k];
+  for (int k = 0; k < 4; ++k) g_orientation[k] = (gn[k] - nq[k] * d) * inv_n;
+  g_scale[0] = gs;
+}
+
 // ---------------------------------------------------------------------------------------------
 // What the loop does besides the two image losses (simple_setup.py):
 //   :164-175  point constraint: weight * | quaternion_apply(orientation, source) - target |
@@ -491,6 +594,38 @@ extern "C" int sdfr_views_to_pose_grad(const float* orientation, const float* sc
   hipLaunchKernelGGL(views_to_pose_grad_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, orientation,
                      scale, cam_quat, V, ga_pos, ga_quat, ga_inv_scale, gb_pos, gb_quat, gb_scale,
                      g_position, g_orientation, g_scale);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfr_views_to_pose_grad_deferred(const float* orientation, const float* scale, const float* cam_quat,
+                                                int V, const void* render_workspace, int W, int H,
+                                                const void* pc_workspace, const int* offsets, int max_view_points,
+                                                const float* quat_c, float* pc_loss, float* g_position,
+                                                float* g_orientation, float* g_scale, int device, void* stream) {
+  if (V < 0 || V > kDeferredMaxViews)
+    return fail(SDFR_E_INVALID, "sdfr_views_to_pose_grad_deferred: V=%d out of range [0,%d]", V, kDeferredMaxViews);
+  if (!orientation || !scale || !cam_quat || !g_position || !g_orientation || !g_scale)
+    return fail(SDFR_E_NULL, "sdfr_views_to_pose_grad_deferred: NULL pointer argument");
+  if (render_workspace && (W <= 0 || H <= 0))
+    return fail(SDFR_E_INVALID, "sdfr_views_to_pose_grad_deferred: W=%d H=%d", W, H);
+  if (pc_workspace && (max_view_points <= 0 || !quat_c || (!offsets && V > 1)))
+    return fail(SDFR_E_INVALID, "sdfr_views_to_pose_grad_deferred: bad sampler arguments");
+  if (render_workspace && (uintptr_t)render_workspace % alignof(ViewSetup))
+    return fail(SDFR_E_INVALID, "render_workspace must be %zu-byte aligned", alignof(ViewSetup));
+  SDFR_HIP_TRY(hipSetDevice(device));
+  // the layouts sdfr_render_backward* and sdfr_pc_*_backward* leave behind (render.hip backward_impl,
+  // sampler.hip pc_backward_impl)
+  const ViewSetup* setup = (const ViewSetup*)render_workspace;
+  const float* tile_part = render_workspace ? (const float*)((const char*)render_workspace + (size_t)V * sizeof(ViewSetup)) : nullptr;
+  const TileGeom geom = render_workspace ? backward_geom(V, W, H) : kSmallTile;
+  const int ntx = render_workspace ? geom.nx(W) : 0, nty = render_workspace ? geom.ny(H) : 0;
+  const int nblk = pc_workspace ? (max_view_points + kSamplerPts - 1) / kSamplerPts : 0;
+  const float* pc_part = (const float*)pc_workspace;
+  const float* pc_loss_part = (pc_workspace && pc_loss) ? pc_part + (size_t)V * nblk * 8 : nullptr;
+  hipLaunchKernelGGL(views_to_pose_grad_deferred_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, orientation,
+                     scale, cam_quat, V, setup, tile_part, ntx, nty, geom.w(), geom.h(), pc_part, pc_loss_part,
+                     offsets, max_view_points, nblk, quat_c, pc_loss, g_position, g_orientation, g_scale);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }

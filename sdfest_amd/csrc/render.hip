@@ -897,7 +897,11 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
     zero_words_async(g_sdf, g_words, st);
     return 0;
   }
-  if (!g_pos || !g_quat || !g_inv_scale || !pos || !quat || !inv_scale)
+  // deferred: the tile partials stay in the workspace for sdfr_views_to_pose_grad_deferred (one launch less)
+  const bool deferred = !g_pos && !g_quat && !g_inv_scale;
+  if (deferred && (W == 0 || H == 0))
+    return fail(SDFR_E_INVALID, "%s: deferred pose gradients need a non-empty image", fn);
+  if ((!deferred && (!g_pos || !g_quat || !g_inv_scale)) || !pos || !quat || !inv_scale)
     return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
   if (W == 0 || H == 0) {
     zero_words_async(g_sdf, g_words, st);
@@ -942,8 +946,9 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
   if (R == 64) SDFR_LAUNCH_BWD(64); else SDFR_LAUNCH_BWD(0);
 #undef SDFR_LAUNCH_BWD
 #undef SDFR_LAUNCH_BWD_L
-  hipLaunchKernelGGL(pose_reduce_kernel, dim3(B), dim3(64), 0, st, partials, setup, ntx, nty,
-                     geom.w(), geom.h(), g_pos, g_quat, g_inv_scale);
+  if (!deferred)
+    hipLaunchKernelGGL(pose_reduce_kernel, dim3(B), dim3(64), 0, st, partials, setup, ntx, nty,
+                       geom.w(), geom.h(), g_pos, g_quat, g_inv_scale);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }

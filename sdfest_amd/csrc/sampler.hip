@@ -17,7 +17,7 @@
 namespace sdfr {
 namespace {
 
-constexpr int kPts = 256;  // points per workgroup
+constexpr int kPts = kSamplerPts;  // points per workgroup
 #ifndef SDFR_SAMPLER_PAIR
 #define SDFR_SAMPLER_PAIR 1  // 0: plain 4-voxel runs (timing experiments)
 #endif
@@ -326,7 +326,11 @@ int pc_backward_impl(const char* fn, const float* grad_out, float l1_weight, flo
   const size_t g_bytes = (size_t)vox * sizeof(float) * (g_sdf_view_stride ? (size_t)(B > 0 ? B : 1) : 1);
   if (!accumulate) zero_words_async(g_sdf, g_bytes / sizeof(float), st);
   if (B == 0) return 0;
-  if (!g_pos || !g_quat || !g_scale || !pos || !quat || !scale)
+  // deferred: the block partials stay in the workspace for sdfr_views_to_pose_grad_deferred (one launch less)
+  const bool deferred = !g_pos && !g_quat && !g_scale;
+  if (deferred && max_view_points == 0)
+    return fail(SDFR_E_INVALID, "%s: deferred pose gradients need max_view_points > 0", fn);
+  if ((!deferred && (!g_pos || !g_quat || !g_scale)) || !pos || !quat || !scale)
     return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
   if (max_view_points == 0) {
     zero_words_async(g_pos, (size_t)B * 3, st);
@@ -352,9 +356,10 @@ int pc_backward_impl(const char* fn, const float* grad_out, float l1_weight, flo
   if (R == 64) { if (l1) SDFR_PC_BWD(64, true); else SDFR_PC_BWD(64, false); }
   else { if (l1) SDFR_PC_BWD(0, true); else SDFR_PC_BWD(0, false); }
 #undef SDFR_PC_BWD
-  hipLaunchKernelGGL(pc_loss_reduce_kernel, dim3(B), dim3(64), 0, st, partials, offsets,
-                     max_view_points, nblk, quat, g_pos, g_quat, g_scale,
-                     l1 ? (const float*)loss_part : (const float*)nullptr, loss);
+  if (!deferred)
+    hipLaunchKernelGGL(pc_loss_reduce_kernel, dim3(B), dim3(64), 0, st, partials, offsets,
+                       max_view_points, nblk, quat, g_pos, g_quat, g_scale,
+                       l1 ? (const float*)loss_part : (const float*)nullptr, loss);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -386,14 +386,17 @@ class BatchRenderPlan:
         _lib.check(rc, "sdfr_render_forward")
         return dst
 
-    def backward(self, grad_depth, sdf, pos, quat, inv_scale):
+    def backward(self, grad_depth, sdf, pos, quat, inv_scale, defer_pose: bool = False):
+        """``defer_pose``: leave the pose gradients as tile partials in ``self.workspace`` for
+        ``sdfr_views_to_pose_grad_deferred`` (include/sdfr.h); g_pos / g_quat / g_inv_scale are then not written."""
         self._check(sdf, pos, quat, inv_scale, grad_depth=grad_depth)
         rc = self._L.sdfr_render_backward(
             grad_depth.data_ptr(), self.depth.data_ptr(), sdf.data_ptr(), self.R, self.sdf_stride,
             pos.data_ptr(), quat.data_ptr(), inv_scale.data_ptr(), self.B, self.W, self.H,
             self.cx, self.cy, self.fx, self.fy, self.sdf_grad_mode, self.g_sdf.data_ptr(),
-            self.sdf_stride, self.g_pos.data_ptr(), self.g_quat.data_ptr(),
-            self.g_inv_scale.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(),
+            self.sdf_stride, None if defer_pose else self.g_pos.data_ptr(),
+            None if defer_pose else self.g_quat.data_ptr(),
+            None if defer_pose else self.g_inv_scale.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(),
             self.device.index, _stream(self.device))
         _lib.check(rc, "sdfr_render_backward")
         return self.g_sdf, self.g_pos, self.g_quat, self.g_inv_scale
@@ -410,8 +413,10 @@ class BatchRenderPlan:
         _lib.check(rc, "sdfr_render_forward_l1")
         return self.depth, self.loss
 
-    def backward_l1(self, target, sdf, pos, quat, inv_scale, weight: float = 1.0, loss_grad=None):
-        """gradients of sum_b weight * loss_grad[b] * loss[b] (after ``forward_l1``)."""
+    def backward_l1(self, target, sdf, pos, quat, inv_scale, weight: float = 1.0, loss_grad=None,
+                    defer_pose: bool = False):
+        """gradients of sum_b weight * loss_grad[b] * loss[b] (after ``forward_l1``); ``defer_pose`` as in
+        ``backward``."""
         self._check(sdf, pos, quat, inv_scale, target=target)
         if loss_grad is not None:
             _check_input(loss_grad, "loss_grad")
@@ -422,8 +427,9 @@ class BatchRenderPlan:
             self.loss_stats.data_ptr(), target.data_ptr(), self.depth.data_ptr(), sdf.data_ptr(),
             self.R, self.sdf_stride, pos.data_ptr(), quat.data_ptr(), inv_scale.data_ptr(), self.B,
             self.W, self.H, self.cx, self.cy, self.fx, self.fy, self.sdf_grad_mode,
-            self.g_sdf.data_ptr(), self.sdf_stride, self.g_pos.data_ptr(), self.g_quat.data_ptr(),
-            self.g_inv_scale.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(),
+            self.g_sdf.data_ptr(), self.sdf_stride, None if defer_pose else self.g_pos.data_ptr(),
+            None if defer_pose else self.g_quat.data_ptr(),
+            None if defer_pose else self.g_inv_scale.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(),
             self.device.index, _stream(self.device))
         _lib.check(rc, "sdfr_render_backward_l1")
         return self.g_sdf, self.g_pos, self.g_quat, self.g_inv_scale

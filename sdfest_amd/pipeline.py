@@ -209,8 +209,11 @@ class FusedRenderAndCompare:
                  camera_positions: Optional[torch.Tensor] = None,
                  camera_orientations: Optional[torch.Tensor] = None,
                  shape_optimization: bool = True, device="cuda", fuse_depth_loss: bool = True,
-                 point_constraint: Optional[Sequence] = None, track_inliers: Optional[bool] = None):
+                 point_constraint: Optional[Sequence] = None, track_inliers: Optional[bool] = None,
+                 merge_launches: bool = True):
         """point_constraint: (source (3,), target (3,), weight), simple_setup.py:164-175.
+        merge_launches: the per-view reductions of both backward passes run inside the gradient chain's launch
+        (``sdfr_views_to_pose_grad_deferred``, up to 64 views); False: one launch each.  Same numbers.
         track_inliers: run the inlier-ratio bookkeeping of :177-211 every iteration (two small launches);
         default: only for ``result_selection_strategy == "best_inlier_ratio"``."""
         from . import _lib
@@ -230,6 +233,7 @@ class FusedRenderAndCompare:
         self.shape_opt = bool(shape_optimization)
         V, H, W = depth_images.shape
         self.V, self.H, self.W = V, H, W
+        self.defer_pose = bool(merge_launches) and V <= 64
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.target = depth_images.to(**f32).contiguous()
         self.cam_pos = (torch.zeros((V, 3), **f32) if camera_positions is None
@@ -327,13 +331,16 @@ class FusedRenderAndCompare:
                                         self.inv_scale.data_ptr(), self.scale_v.data_ptr(), d, st),
                    "sdfr_pose_to_views")
         sdf = self.sdf[0, 0]
+        # the renderer's and the sampler's per-view reductions run inside the gradient chain's launch
+        # (sdfr_views_to_pose_grad_deferred: two launches less per iteration)
+        defer = self.defer_pose
         if self.fuse_depth_loss:
             self.plan.forward_l1(sdf, self.pos_c, self.quat_c, self.inv_scale, self.cfg["threshold"],
                                  self.target)
             self.loss_depth = self.plan.loss
             g_sdf, g_pos, g_quat, g_is = self.plan.backward_l1(self.target, sdf, self.pos_c, self.quat_c,
                                                                self.inv_scale,
-                                                               weight=self.cfg["depth_weight"])
+                                                               weight=self.cfg["depth_weight"], defer_pose=defer)
         else:
             est = self.plan.forward(sdf, self.pos_c, self.quat_c, self.inv_scale, self.cfg["threshold"])
             self.check(L.sdfr_depth_l1_loss(est.data_ptr(), self.target.data_ptr(), self.V, self.W, self.H,
@@ -341,7 +348,7 @@ class FusedRenderAndCompare:
                                             self.grad_est.data_ptr(), self.ws_loss.data_ptr(),
                                             self.ws_loss.numel(), d, st), "sdfr_depth_l1_loss")
             g_sdf, g_pos, g_quat, g_is = self.plan.backward(self.grad_est, sdf, self.pos_c, self.quat_c,
-                                                            self.inv_scale)
+                                                            self.inv_scale, defer_pose=defer)
         have_pts = self.max_pts > 0
         summed = False   # the sampler's d/dSDF already added to the renderer's
         if have_pts and self.fuse_depth_loss:
@@ -350,8 +357,9 @@ class FusedRenderAndCompare:
             self.check(L.sdfr_pc_l1_backward_accumulate(
                 self.cfg["pc_weight"], self.loss_pc.data_ptr(), self.points.data_ptr(), self.offsets.data_ptr(),
                 self.V, self.max_pts, self.pos_c.data_ptr(), self.quat_c.data_ptr(), self.scale_v.data_ptr(),
-                sdf.data_ptr(), self.R, 0, g_sdf.data_ptr(), 0, self.g_pos_pc.data_ptr(), self.g_quat_pc.data_ptr(),
-                self.g_scale_pc.data_ptr(), self.ws_pc.data_ptr(), self.ws_pc.numel(), d, st),
+                sdf.data_ptr(), self.R, 0, g_sdf.data_ptr(), 0, None if defer else self.g_pos_pc.data_ptr(),
+                None if defer else self.g_quat_pc.data_ptr(), None if defer else self.g_scale_pc.data_ptr(),
+                self.ws_pc.data_ptr(), self.ws_pc.numel(), d, st),
                 "sdfr_pc_l1_backward_accumulate")
             summed = True
         elif have_pts:
@@ -366,16 +374,26 @@ class FusedRenderAndCompare:
                                                self.offsets.data_ptr(), self.V, self.max_pts,
                                                self.pos_c.data_ptr(), self.quat_c.data_ptr(),
                                                self.scale_v.data_ptr(), sdf.data_ptr(), self.R, 0,
-                                               self.g_sdf_pc.data_ptr(), 0, self.g_pos_pc.data_ptr(),
-                                               self.g_quat_pc.data_ptr(), self.g_scale_pc.data_ptr(),
+                                               self.g_sdf_pc.data_ptr(), 0,
+                                               None if defer else self.g_pos_pc.data_ptr(),
+                                               None if defer else self.g_quat_pc.data_ptr(),
+                                               None if defer else self.g_scale_pc.data_ptr(),
                                                self.ws_pc.data_ptr(), self.ws_pc.numel(), d, st),
                        "sdfr_pc_loss_backward")
-        self.check(L.sdfr_views_to_pose_grad(quat, scale, self.cam_quat.data_ptr(), self.V, g_pos.data_ptr(),
-                                             g_quat.data_ptr(), g_is.data_ptr(),
-                                             self.g_pos_pc.data_ptr() if have_pts else None,
-                                             self.g_quat_pc.data_ptr() if have_pts else None,
-                                             self.g_scale_pc.data_ptr() if have_pts else None,
-                                             g, g + 12, g + 28, d, st), "sdfr_views_to_pose_grad")
+        if defer:
+            self.check(L.sdfr_views_to_pose_grad_deferred(
+                quat, scale, self.cam_quat.data_ptr(), self.V, self.plan.workspace.data_ptr(), self.W, self.H,
+                self.ws_pc.data_ptr() if have_pts else None, self.offsets.data_ptr() if have_pts else None,
+                self.max_pts, self.quat_c.data_ptr(),
+                self.loss_pc.data_ptr() if (have_pts and self.fuse_depth_loss) else None,
+                g, g + 12, g + 28, d, st), "sdfr_views_to_pose_grad_deferred")
+        else:
+            self.check(L.sdfr_views_to_pose_grad(quat, scale, self.cam_quat.data_ptr(), self.V, g_pos.data_ptr(),
+                                                 g_quat.data_ptr(), g_is.data_ptr(),
+                                                 self.g_pos_pc.data_ptr() if have_pts else None,
+                                                 self.g_quat_pc.data_ptr() if have_pts else None,
+                                                 self.g_scale_pc.data_ptr() if have_pts else None,
+                                                 g, g + 12, g + 28, d, st), "sdfr_views_to_pose_grad")
         if self.pc_source is not None:   # + the point constraint's gradient on the orientation parameter
             self.check(L.sdfr_point_constraint(quat, self.pc_source.data_ptr(), self.pc_target.data_ptr(),
                                                self.pc_weight, self.loss_con.data_ptr(), g + 12, d, st),

@@ -217,6 +217,51 @@ def test_fused_graph_loop_matches_autograd_loop(mug_decoder, shape_opt, fuse_l1)
         assert h[-1]["latent"].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("fuse_l1", [True, False])
+def test_merged_reduction_launches_give_the_same_trajectory(mug_decoder, fuse_l1):
+    """sdfr_views_to_pose_grad_deferred (the renderer's and the sampler's per-view reductions inside the gradient
+    chain's launch) against the three separate launches: same additions in the same order, so a pose-only run
+    (no atomics on the way to the pose gradients) is bit-identical, 3 views, eager and graph-replayed."""
+    from sdfest_amd import Camera
+    from sdfest_amd.pipeline import FusedRenderAndCompare, RenderAndCompare
+    dec, d = mug_decoder
+    W, H, f = 160, 120, 150.0
+    cam = Camera(W, H, f, f, W / 2, H / 2, pixel_center=0.5)
+    dev = "cuda"
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device=dev)
+    cam_pos = t([[0.0, 0.0, 0.0], [0.25, 0.05, 0.02], [-0.2, 0.1, 0.0]])
+    cq = np.array([0.02, 0.27, 0.01, 1.0]); cq /= np.linalg.norm(cq)
+    cq2 = np.array([-0.05, -0.2, 0.03, 1.0]); cq2 /= np.linalg.norm(cq2)
+    cam_quat = t([[0, 0, 0, 1.0], cq, cq2])
+    p_true = t([[0.01, -0.015, -0.45]]); s_true = t([0.11])
+    q_true = t([[0.3, 0.5, -0.1, 0.8]]); q_true = q_true / q_true.norm()
+    cfg = {"threshold": 0.005, "max_iterations": 6, "depth_weight": 1.0, "pc_weight": 3.0}
+    with torch.no_grad():
+        sdf = dec.decode(t(d["z"][10:11]) * 0.3)[0, 0]
+        _, _, obs = RenderAndCompare(dec, cam, cfg).losses(
+            torch.ones((3, H, W), device=dev), torch.zeros((0, 3), device=dev), None, [], cam_pos, cam_quat,
+            p_true, q_true, s_true, sdf)
+    obs = obs.contiguous()
+    assert (obs > 0).sum(dim=(1, 2)).min() > 500
+    p0 = p_true + t([[0.008, -0.006, 0.01]]); s0 = t([0.12])
+    q0 = q_true + t([[0.04, -0.03, 0.02, 0.01]]); z0 = t(d["z"][10:11]) * 0.3
+    runs = {}
+    for merged in (False, True):
+        loop = FusedRenderAndCompare(dec, cam, cfg, obs, cam_pos, cam_quat, shape_optimization=False,
+                                     fuse_depth_loss=fuse_l1, merge_launches=merged)
+        assert loop.defer_pose == merged
+        for use_graph in (False, True):
+            h = []
+            loop(p0, q0, s0, z0, use_graph=use_graph, history=h)
+            runs[(merged, use_graph)] = h
+    ref = runs[(False, False)]
+    assert (ref[-1]["position"] - p0).abs().max().item() > 1e-3
+    for key, h in runs.items():
+        for it in range(cfg["max_iterations"]):
+            for name in ("position", "orientation", "scale", "loss"):
+                assert torch.equal(h[it][name], ref[it][name]), (key, it, name, h[it][name], ref[it][name])
+
+
 def test_graph_replays_are_repeatable_without_host_work_between_them(mug_decoder):
     """Regression: 20 back-to-back replays per call, several calls on one captured graph, no host
     work between replays -- every call must reproduce the eager launch sequence.  (With
