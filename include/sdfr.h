@@ -243,12 +243,25 @@ SDFR_API int sdfr_views_to_pose_grad(const float* orientation, const float* scal
  * pass those workspaces here, untouched in between, with the same V (= B), W, H, offsets, max_view_points and the
  * per-view quaternions quat_c the sampler was given.  Either workspace may be NULL (term absent).  pc_loss [V]:
  * the loss values of sdfr_pc_l1_backward* (which does not write them when deferred), NULL for the plain backward.
- * Same additions in the same order as the three separate launches: identical results.  V <= 64. */
+ * Same sums in the same order as the three separate launches (results agree to the last bit or two).  V <= 64. */
 SDFR_API int sdfr_views_to_pose_grad_deferred(const float* orientation, const float* scale, const float* cam_quat,
                                      int V, const void* render_workspace, int W, int H,
                                      const void* pc_workspace, const int* offsets, int max_view_points,
                                      const float* quat_c, float* pc_loss, float* g_position,
                                      float* g_orientation, float* g_scale, int device, void* stream);
+
+/* sdfr_render_backward_l1 and sdfr_pc_l1_backward_accumulate of one loop iteration in ONE launch (they are
+ * independent and neither fills the chip for a handful of views): arguments as in those two calls -- the per-view
+ * poses are pos / quat with inv_scale for the renderer and scale (= 1 / inv_scale) for the sampler -- and the same
+ * results in g_sdf (zero-filled first, then both terms added).  The pose gradients are always left deferred in the
+ * two workspaces: follow with sdfr_views_to_pose_grad_deferred, which also writes the point-cloud loss values. */
+SDFR_API int sdfr_render_backward_l1_pc(
+    const float* loss_grad, float loss_weight, const float* loss_stats, const float* target, const float* depth,
+    const float* sdf, int R, long long sdf_view_stride, const float* pos, const float* quat, const float* inv_scale,
+    int B, int W, int H, float cx, float cy, float fx, float fy, int sdf_grad_mode, float* g_sdf,
+    long long g_sdf_view_stride, void* workspace, size_t workspace_bytes, float pc_weight, const float* points,
+    const int* offsets, int max_view_points, const float* scale, void* pc_workspace, size_t pc_workspace_bytes,
+    int device, void* stream);
 
 /* :125-131 -- loss[v] = mean |estimate - target| over (target > 0) & (estimate > 0) (NaN when the
  * overlap is empty, like torch.mean of an empty selection); grad_estimate = weight * d loss / d

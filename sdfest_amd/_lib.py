@@ -59,6 +59,9 @@ SIGNATURES = {
                                         c_fp, c_fp, c_fp, c_int, c_fp]),
     "sdfr_views_to_pose_grad_deferred": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp, c_int, c_int, c_fp, c_fp, c_int,
                                                  c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp]),
+    "sdfr_render_backward_l1_pc": (c_int, [c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_int, c_ll, c_fp, c_fp, c_fp,
+                                           c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_int, c_fp, c_ll, c_fp, c_sz,
+                                           c_f, c_fp, c_fp, c_int, c_fp, c_fp, c_sz, c_int, c_fp]),
     "sdfr_depth_l1_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
     "sdfr_depth_l1_loss": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_f, c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),
     "sdfr_pc_l1_loss": (c_int, [c_fp, c_fp, c_int, c_int, c_f, c_fp, c_fp, c_int, c_fp]),

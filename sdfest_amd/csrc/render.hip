@@ -33,6 +33,7 @@
 
 #include "common.hpp"
 #include "device.hpp"
+#include "sampler_device.hpp"
 
 
 namespace sdfr {
@@ -655,6 +656,43 @@ backward_tile<RT, SX, SY, Hash, LOSS>(lds, blockIdx.x, blockIdx.y, ntx, nty, b, 
                                         g_sdf, g_sdf_view_stride, partials);
 }
 
+// The renderer's backward (depth-L1 form) and the sampler's backward (point-cloud L1 form) of one loop iteration in
+// ONE launch.  They are independent -- both read the SDF and the poses and add into the same d/dSDF volume --
+// and in the captured loop each is a launch of its own that cannot fill the chip (1 200 small tiles, 13 blocks
+// of points): side by side they take max(12, 14) us instead of 12 + 14.  The first `pc_rows` rows of the grid
+// are the sampler's blocks (they take longest, so they start first), the rest the image tiles.
+template <int RT, int SX, int SY>
+__global__ __launch_bounds__(kBlock) void render_backward_pc_kernel(
+    const float* __restrict__ target, const float* __restrict__ depth,
+    const float* __restrict__ sdf, int R, long long sdf_view_stride,
+    const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, float cx, float cy,
+    float rfx, float rfy, int sdf_grad_mode, float* __restrict__ g_sdf,
+    long long g_sdf_view_stride, float* __restrict__ partials, const float* __restrict__ loss_grad,
+    const float* __restrict__ loss_stats, float loss_weight, int pc_rows, PcBackwardArgs pa) {
+#if SDFR_BWD_PAIR_HASH
+  using FullHash = PairRunHash<512>;
+#else
+  using FullHash = BatchHash;
+#endif
+  using Hash = typename std::conditional<(SX * SY > 1), FullHash, SmallHash>::type;
+  constexpr size_t kLdsBytes = sizeof(BackwardLds<Hash>) > sizeof(PcBackwardLds) ? sizeof(BackwardLds<Hash>)
+                                                                                 : sizeof(PcBackwardLds);
+  __shared__ __attribute__((aligned(16))) unsigned char raw[kLdsBytes];
+  const int b = blockIdx.z;
+  if ((int)blockIdx.y < pc_rows) {
+    const int bx = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+    if (bx < pa.nblk) pc_backward_block<RT, true>(*reinterpret_cast<PcBackwardLds*>(raw), pa, bx, b);
+    return;
+  }
+  const float cnt = loss_stats[2 * b + 1];
+  const float w = loss_grad ? loss_weight * loss_grad[b] : loss_weight;
+  const float loss_k = cnt > 0.0f ? w / cnt : 0.0f;
+  backward_tile<RT, SX, SY, Hash, true>(*reinterpret_cast<BackwardLds<Hash>*>(raw), blockIdx.x,
+                                        (int)blockIdx.y - pc_rows, ntx, nty, b, loss_k, target, depth, sdf, R,
+                                        sdf_view_stride, setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf,
+                                        g_sdf_view_stride, partials);
+}
+
 // Fixed-order sum of a view's macro-tile partials: one wave per view.
 __global__ __launch_bounds__(64) void pose_reduce_kernel(const float* __restrict__ partials,
                                                          const ViewSetup* __restrict__ setup,
@@ -879,7 +917,7 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
                   int sdf_grad_mode, float* g_sdf, long long g_sdf_view_stride, float* g_pos,
                   float* g_quat, float* g_inv_scale, const float* loss_grad, const float* loss_stats,
                   float loss_weight, void* workspace, size_t workspace_bytes, int device,
-                  void* stream) {
+                  void* stream, const PcBackwardArgs* pc = nullptr) {
   const bool with_loss = loss_stats != nullptr;
   if (int rc = check_common(R, B, W, H, fx, fy)) return rc;
   const long long vox = (long long)R * R * R;
@@ -943,7 +981,18 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
       else SDFR_LAUNCH_BWD_L(RT, SDFR_MACRO_SX, SDFR_MACRO_SY, false);                               \
     }                                                                                                \
   } while (0)
-  if (R == 64) SDFR_LAUNCH_BWD(64); else SDFR_LAUNCH_BWD(0);
+  if (pc) {  // the sampler's blocks ride in the same launch (sdfr_render_backward_l1_pc)
+    const int pc_rows = (pc->nblk + ntx - 1) / ntx;
+    const dim3 grid_pc((unsigned)ntx, (unsigned)(nty + pc_rows), (unsigned)B);
+#define SDFR_LAUNCH_BWD_PC(RT, SX, SY)                                                               \
+  hipLaunchKernelGGL((render_backward_pc_kernel<RT, SX, SY>), grid_pc, dim3(kBlock), 0, st,          \
+                     grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, ntx, nty, cx, cy, rfx,  \
+                     rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, loss_grad, loss_stats,   \
+                     loss_weight, pc_rows, *pc)
+    if (R == 64) { if (macro) SDFR_LAUNCH_BWD_PC(64, SDFR_MACRO_SX, SDFR_MACRO_SY); else SDFR_LAUNCH_BWD_PC(64, 1, 1); }
+    else { if (macro) SDFR_LAUNCH_BWD_PC(0, SDFR_MACRO_SX, SDFR_MACRO_SY); else SDFR_LAUNCH_BWD_PC(0, 1, 1); }
+#undef SDFR_LAUNCH_BWD_PC
+  } else if (R == 64) SDFR_LAUNCH_BWD(64); else SDFR_LAUNCH_BWD(0);
 #undef SDFR_LAUNCH_BWD
 #undef SDFR_LAUNCH_BWD_L
   if (!deferred)
@@ -981,6 +1030,33 @@ extern "C" int sdfr_render_backward_l1(const float* loss_grad, float loss_weight
                        inv_scale, B, W, H, cx, cy, fx, fy, sdf_grad_mode, g_sdf, g_sdf_view_stride, g_pos,
                        g_quat, g_inv_scale, loss_grad, loss_stats, loss_weight, workspace,
                        workspace_bytes, device, stream);
+}
+
+extern "C" int sdfr_render_backward_l1_pc(
+    const float* loss_grad, float loss_weight, const float* loss_stats, const float* target, const float* depth,
+    const float* sdf, int R, long long sdf_view_stride, const float* pos, const float* quat, const float* inv_scale,
+    int B, int W, int H, float cx, float cy, float fx, float fy, int sdf_grad_mode, float* g_sdf,
+    long long g_sdf_view_stride, void* workspace, size_t workspace_bytes, float pc_weight, const float* points,
+    const int* offsets, int max_view_points, const float* scale, void* pc_workspace, size_t pc_workspace_bytes,
+    int device, void* stream) {
+  const char* fn = "sdfr_render_backward_l1_pc";
+  if (B <= 0 || W <= 0 || H <= 0 || max_view_points <= 0)
+    return fail(SDFR_E_INVALID, "%s: needs B, W, H, max_view_points > 0 (B=%d W=%d H=%d points=%d)", fn, B, W, H,
+                max_view_points);
+  if (R > 1023) return fail(SDFR_E_INVALID, "%s: R=%d out of range", fn, R);
+  if (!loss_stats || !points || !scale || !pc_workspace) return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
+  if (!offsets && B > 1) return fail(SDFR_E_NULL, "offsets may be NULL only for a single view");
+  if (pc_workspace_bytes < sdfr_pc_loss_backward_workspace_bytes(B, max_view_points))
+    return fail(SDFR_E_WORKSPACE, "%s: sampler workspace %zu < %zu bytes", fn, pc_workspace_bytes,
+                sdfr_pc_loss_backward_workspace_bytes(B, max_view_points));
+  if ((uintptr_t)pc_workspace % 16) return fail(SDFR_E_INVALID, "sampler workspace must be 16-byte aligned");
+  const int nblk = (max_view_points + kSamplerPts - 1) / kSamplerPts;
+  float* pc_part = (float*)pc_workspace;
+  const PcBackwardArgs pa{nullptr, points, offsets, max_view_points, pos, quat, scale, sdf, R, sdf_view_stride,
+                          g_sdf, g_sdf_view_stride, pc_part, nblk, pc_weight, pc_part + (size_t)B * nblk * 8};
+  return backward_impl(fn, target, depth, sdf, R, sdf_view_stride, pos, quat, inv_scale, B, W, H, cx, cy, fx, fy,
+                       sdf_grad_mode, g_sdf, g_sdf_view_stride, nullptr, nullptr, nullptr, loss_grad, loss_stats,
+                       loss_weight, workspace, workspace_bytes, device, stream, &pa);
 }
 
 #ifdef SDFR_STAMPS

@@ -433,3 +433,21 @@ class BatchRenderPlan:
             self.device.index, _stream(self.device))
         _lib.check(rc, "sdfr_render_backward_l1")
         return self.g_sdf, self.g_pos, self.g_quat, self.g_inv_scale
+
+    def backward_l1_pc(self, target, sdf, pos, quat, inv_scale, scale, points, offsets, max_view_points: int,
+                       pc_workspace, weight: float = 1.0, pc_weight: float = 1.0, loss_grad=None):
+        """``backward_l1`` and the sampler's L1 backward (``sdfr_pc_l1_backward_accumulate``) in one launch
+        (``sdfr_render_backward_l1_pc``): g_sdf holds both terms, the pose gradients stay deferred in
+        ``self.workspace`` and ``pc_workspace`` for ``sdfr_views_to_pose_grad_deferred``."""
+        self._check(sdf, pos, quat, inv_scale, target=target)
+        rc = self._L.sdfr_render_backward_l1_pc(
+            loss_grad.data_ptr() if loss_grad is not None else None, weight,
+            self.loss_stats.data_ptr(), target.data_ptr(), self.depth.data_ptr(), sdf.data_ptr(),
+            self.R, self.sdf_stride, pos.data_ptr(), quat.data_ptr(), inv_scale.data_ptr(), self.B,
+            self.W, self.H, self.cx, self.cy, self.fx, self.fy, self.sdf_grad_mode,
+            self.g_sdf.data_ptr(), self.sdf_stride, self.workspace.data_ptr(), self.workspace.numel(),
+            pc_weight, points.data_ptr(), offsets.data_ptr() if offsets is not None else None, max_view_points,
+            scale.data_ptr(), pc_workspace.data_ptr(), pc_workspace.numel(),
+            self.device.index, _stream(self.device))
+        _lib.check(rc, "sdfr_render_backward_l1_pc")
+        return self.g_sdf

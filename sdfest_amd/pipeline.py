@@ -334,7 +334,19 @@ class FusedRenderAndCompare:
         # the renderer's and the sampler's per-view reductions run inside the gradient chain's launch
         # (sdfr_views_to_pose_grad_deferred: two launches less per iteration)
         defer = self.defer_pose
-        if self.fuse_depth_loss:
+        have_pts = self.max_pts > 0
+        summed = False   # the sampler's d/dSDF already added to the renderer's
+        if self.fuse_depth_loss and defer and have_pts:
+            # both backward passes side by side in one launch (they are independent and neither fills the chip)
+            self.plan.forward_l1(sdf, self.pos_c, self.quat_c, self.inv_scale, self.cfg["threshold"],
+                                 self.target)
+            self.loss_depth = self.plan.loss
+            g_sdf = self.plan.backward_l1_pc(self.target, sdf, self.pos_c, self.quat_c, self.inv_scale,
+                                             self.scale_v, self.points, self.offsets, self.max_pts, self.ws_pc,
+                                             weight=self.cfg["depth_weight"], pc_weight=self.cfg["pc_weight"])
+            g_pos = g_quat = g_is = None
+            summed = True
+        elif self.fuse_depth_loss:
             self.plan.forward_l1(sdf, self.pos_c, self.quat_c, self.inv_scale, self.cfg["threshold"],
                                  self.target)
             self.loss_depth = self.plan.loss
@@ -349,9 +361,9 @@ class FusedRenderAndCompare:
                                             self.ws_loss.numel(), d, st), "sdfr_depth_l1_loss")
             g_sdf, g_pos, g_quat, g_is = self.plan.backward(self.grad_est, sdf, self.pos_c, self.quat_c,
                                                             self.inv_scale, defer_pose=defer)
-        have_pts = self.max_pts > 0
-        summed = False   # the sampler's d/dSDF already added to the renderer's
-        if have_pts and self.fuse_depth_loss:
+        if summed:
+            pass
+        elif have_pts and self.fuse_depth_loss:
             # the point-cloud term in one pass: loss value and gradients, no sampler forward, no loss kernel;
             # its d/dSDF goes straight into the volume the renderer's backward has just written
             self.check(L.sdfr_pc_l1_backward_accumulate(

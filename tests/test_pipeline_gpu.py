@@ -219,9 +219,11 @@ def test_fused_graph_loop_matches_autograd_loop(mug_decoder, shape_opt, fuse_l1)
 
 @pytest.mark.parametrize("fuse_l1", [True, False])
 def test_merged_reduction_launches_give_the_same_trajectory(mug_decoder, fuse_l1):
-    """sdfr_views_to_pose_grad_deferred (the renderer's and the sampler's per-view reductions inside the gradient
-    chain's launch) against the three separate launches: same additions in the same order, so a pose-only run
-    (no atomics on the way to the pose gradients) is bit-identical, 3 views, eager and graph-replayed."""
+    """The merged launches of the loop (sdfr_views_to_pose_grad_deferred: the renderer's and the sampler's per-view
+    reductions inside the gradient chain's launch; sdfr_render_backward_l1_pc: both backward passes side by side)
+    against one launch each: the same sums in the same order, so a pose-only run (no atomics on the way to the pose
+    gradients) agrees to the last bit or two (the compiler contracts a*b + c*d per kernel) and each form repeats
+    bit for bit, eager and graph-replayed; 3 views."""
     from sdfest_amd import Camera
     from sdfest_amd.pipeline import FusedRenderAndCompare, RenderAndCompare
     dec, d = mug_decoder
@@ -257,9 +259,12 @@ def test_merged_reduction_launches_give_the_same_trajectory(mug_decoder, fuse_l1
     ref = runs[(False, False)]
     assert (ref[-1]["position"] - p0).abs().max().item() > 1e-3
     for key, h in runs.items():
+        same_form = runs[(key[0], False)]
         for it in range(cfg["max_iterations"]):
             for name in ("position", "orientation", "scale", "loss"):
-                assert torch.equal(h[it][name], ref[it][name]), (key, it, name, h[it][name], ref[it][name])
+                assert torch.equal(h[it][name], same_form[it][name]), (key, it, name)
+                err = (h[it][name] - ref[it][name]).abs().max().item()
+                assert err <= 1e-6 * (it + 1), (key, it, name, h[it][name], ref[it][name])
 
 
 def test_graph_replays_are_repeatable_without_host_work_between_them(mug_decoder):
