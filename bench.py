@@ -31,8 +31,8 @@ HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md: 8 TB/s; 6.29 TB/s me
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="views per GPU per step")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
@@ -200,12 +200,17 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    # HIP events around the two calls of every `stride`-th timed step (each record is a packet of its own between
+    # two kernels; SDFR_BENCH_EVENT_STRIDE=1 brackets every step)
+    stride = max(1, int(os.environ.get("SDFR_BENCH_EVENT_STRIDE", "4")))
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] if k % stride == 0 else None
+              for k in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(events[k])
     barrier()
+    events = [e for e in events if e is not None]
     elapsed = time.perf_counter() - t0
     if use_dist:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)

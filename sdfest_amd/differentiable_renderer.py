@@ -440,6 +440,21 @@ class BatchRenderPlan:
         (``sdfr_render_backward_l1_pc``): g_sdf holds both terms, the pose gradients stay deferred in
         ``self.workspace`` and ``pc_workspace`` for ``sdfr_views_to_pose_grad_deferred``."""
         self._check(sdf, pos, quat, inv_scale, target=target)
+        dev = self.device
+        if not (scale.device == dev and scale.dtype is torch.float32 and scale.shape == self._shape_isc
+                and scale.is_contiguous()):
+            raise RuntimeError(f"scale must be a contiguous float32 tensor of shape {self._shape_isc} on {dev}")
+        if not (points.device == dev and points.dtype is torch.float32 and points.dim() == 2 and points.shape[1] == 3
+                and points.is_contiguous()):
+            raise RuntimeError(f"points must be a contiguous float32 (M, 3) tensor on {dev}")
+        if offsets is None:
+            if self.B != 1 or points.shape[0] < max_view_points:
+                raise RuntimeError("offsets may be None only for one view with max_view_points <= len(points)")
+        elif not (offsets.device == dev and offsets.dtype is torch.int32 and offsets.shape == (self.B + 1,)
+                  and offsets.is_contiguous()):
+            raise RuntimeError(f"offsets must be a contiguous int32 tensor of shape ({self.B + 1},) on {dev}")
+        if pc_workspace.device != dev or not pc_workspace.is_contiguous() or pc_workspace.dtype is not torch.uint8:
+            raise RuntimeError(f"pc_workspace must be a contiguous uint8 tensor on {dev}")
         rc = self._L.sdfr_render_backward_l1_pc(
             loss_grad.data_ptr() if loss_grad is not None else None, weight,
             self.loss_stats.data_ptr(), target.data_ptr(), self.depth.data_ptr(), sdf.data_ptr(),
