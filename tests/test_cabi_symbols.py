@@ -66,6 +66,25 @@ def test_argument_errors_without_gpu(libpath):
     assert rc == -2
     assert L.sdfr_render_forward_workspace_bytes(64, 3, 640, 480) == 3 * 256 + 64 ** 3 * 16 + 768  # views + face records + 3 x R plane minima
     assert L.sdfr_render_backward_workspace_bytes(64, 2, 640, 480) == 2 * 256 + 2 * 20 * 60 * 32
+    # the merged launches of the loop: the deferred gradient chain and the two backward passes side by side
+    import ctypes
+    buf = (ctypes.c_float * 64)()
+    q = ctypes.cast(buf, ctypes.c_void_p)   # a non-NULL pointer that is never dereferenced
+    rc = L.sdfr_views_to_pose_grad_deferred(q, q, q, 65, None, 0, 0, None, None, 0, None, None, q, q, q, 0, None)
+    assert rc != 0 and b"V=65" in L.sdfr_last_error()
+    rc = L.sdfr_views_to_pose_grad_deferred(q, q, q, 2, None, 0, 0, None, None, 0, None, None, None, q, q, 0, None)
+    assert rc != 0 and b"NULL" in L.sdfr_last_error()
+    rc = L.sdfr_views_to_pose_grad_deferred(q, q, q, 2, None, 0, 0, q, None, 100, q, None, q, q, q, 0, None)
+    assert rc != 0 and b"sampler" in L.sdfr_last_error()      # two views need offsets
+    rc = L.sdfr_render_backward_l1_pc(None, 1.0, q, q, q, q, 64, 0, q, q, q, 0, 32, 24, 16.0, 12.0, 30.0, 30.0, 0,
+                                      q, 0, q, 1 << 20, 1.0, q, None, 100, q, q, 1 << 20, 0, None)
+    assert rc != 0 and b"B=0" in L.sdfr_last_error()
+    rc = L.sdfr_render_backward_l1_pc(None, 1.0, q, q, q, q, 64, 0, q, q, q, 2, 32, 24, 16.0, 12.0, 30.0, 30.0, 0,
+                                      q, 0, q, 1 << 20, 1.0, q, None, 100, q, q, 1 << 20, 0, None)
+    assert rc != 0 and b"offsets" in L.sdfr_last_error()
+    rc = L.sdfr_render_backward_l1_pc(None, 1.0, q, q, q, q, 64, 0, q, q, q, 1, 32, 24, 16.0, 12.0, 30.0, 30.0, 0,
+                                      q, 0, q, 1 << 20, 1.0, q, None, 100, q, q, 16, 0, None)
+    assert rc != 0 and b"workspace" in L.sdfr_last_error()
 
 
 def test_product_does_not_import_oracle():
