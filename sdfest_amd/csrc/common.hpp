@@ -86,8 +86,14 @@ constexpr long long kBackwardMacroMinTiles = SDFR_BWD_MACRO_MIN;
 #ifndef SDFR_FWD_MACRO_MIN
 #define SDFR_FWD_MACRO_MIN 16384
 #endif
+// the forward's batch tile (timing experiments: -DSDFR_FWD_SX / -DSDFR_FWD_SY; the backward keeps kMacroTile)
+#ifndef SDFR_FWD_SX
+#define SDFR_FWD_SX SDFR_MACRO_SX
+#define SDFR_FWD_SY SDFR_MACRO_SY
+#endif
+constexpr TileGeom kFwdMacroTile{SDFR_FWD_SX, SDFR_FWD_SY};
 inline TileGeom forward_geom(int B, int W, int H) {
-  return ((long long)B * kMacroTile.nx(W) * kMacroTile.ny(H) >= SDFR_FWD_MACRO_MIN) ? kMacroTile : kSmallTile;
+  return ((long long)B * kMacroTile.nx(W) * kMacroTile.ny(H) >= SDFR_FWD_MACRO_MIN) ? kFwdMacroTile : kSmallTile;
 }
 inline TileGeom backward_geom(int B, int W, int H) {
   return ((long long)B * kMacroTile.nx(W) * kMacroTile.ny(H) >= kBackwardMacroMinTiles) ? kMacroTile

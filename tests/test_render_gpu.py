@@ -180,6 +180,23 @@ def test_batch_random_poses_equals_per_view(R):
         assert np.all(np.abs(pose - ref) <= REL * l1), (b, pose, ref, l1)
 
 
+def test_batched_forward_with_a_4_byte_aligned_sdf(R):
+    """The batch path packs face records and takes plane minima (four z-planes per block with 16-byte loads when
+    the grid pointer allows it): a grid that starts 4 bytes into an allocation gives the same image."""
+    sdf = oracle.blobs_sdf(0)
+    B, W, H, f = 6, 160, 120, 80.0
+    pos, quat, isc = oracle.random_poses(B, seed=3, width=W, height=H, f=f)
+    cam = (W, H, W / 2, H / 2, f, f)
+    aligned = R.forward_raw(dev(sdf), dev(pos), dev(quat), dev(isc), *cam, 0.005)
+    big = torch.zeros(64 ** 3 + 8, device="cuda")
+    for off in (1, 2, 3):
+        view = big[off:off + 64 ** 3].view(64, 64, 64)
+        view.copy_(dev(sdf))
+        assert view.data_ptr() % 16 == 4 * off and view.is_contiguous()
+        assert torch.equal(R.forward_raw(view, dev(pos), dev(quat), dev(isc), *cam, 0.005), aligned)
+    assert (aligned > 0).sum().item() > 1000
+
+
 def test_per_view_sdf_batches(R):
     sdfs = np.stack([oracle.blobs_sdf(0), oracle.sphere_sdf(0.5), oracle.blobs_sdf(3)])
     pos, quat, isc = oracle.random_poses(3, seed=5, width=160, height=120, f=80.0)
