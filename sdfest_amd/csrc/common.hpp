@@ -51,7 +51,8 @@ struct alignas(128) ViewSetup {
   float dgk;      // inv_scale * (R-1)/2: object-frame direction -> grid-space direction
   float tp[3];    // e + hi, e + lo of the MAY-HIT box (object frame): the part of the cube outside of
   float tm[3];    //   which no sample can pass the hit test (render.hip, plane minima); = ep, em without it
-  float pad[23];
+  int bwd_big;    // batch backward: 1 = this view's tiles are 32 x 32 pixels, 0 = 64 x 8 (backward_big_tiles)
+  float pad[22];
 };
 static_assert(sizeof(ViewSetup) == 256, "ViewSetup must stay 256 bytes");
 
@@ -64,10 +65,10 @@ constexpr int kSubW = 32;
 constexpr int kSubH = 8;
 struct TileGeom {
   int sx, sy;  // sub-tiles per tile
-  int w() const { return sx * kSubW; }
-  int h() const { return sy * kSubH; }
-  int nx(int W) const { return (W + w() - 1) / w(); }
-  int ny(int H) const { return (H + h() - 1) / h(); }
+  __host__ __device__ constexpr int w() const { return sx * kSubW; }
+  __host__ __device__ constexpr int h() const { return sy * kSubH; }
+  __host__ __device__ constexpr int nx(int W) const { return (W + w() - 1) / w(); }
+  __host__ __device__ constexpr int ny(int H) const { return (H + h() - 1) / h(); }
 };
 #ifndef SDFR_MACRO_SX
 #define SDFR_MACRO_SX 2
@@ -104,6 +105,31 @@ inline TileGeom backward_geom(int B, int W, int H) {
 // deferred gradient chain in loop.hip reads those records)
 constexpr int kSamplerPts = 256;
 constexpr int kDeferredMaxViews = 64;  // sdfr_views_to_pose_grad_deferred: views per call
+
+// The batch backward picks its tile shape PER VIEW.  What a tile costs is its flush -- one global float atomic per
+// voxel its hit pixels touched -- and what it saves is the pre-summation of the pixels that share those voxels, so
+// the tile should be as large and as square as the LDS table (512 z-runs) allows.  Measured on 256 views of
+// 640x480 (backward us) against the pixels one voxel spans on the screen, r = f * voxel size / distance:
+//   r ~ 4.6: 64x8 238, 32x32 178 | 3.2 (C3): 156 / 126 | 2.3: 134 / 137 | 1.6: 117 / 150 | 1.1: 104 / 166
+// (32x24: 185 / 131 / 121 / 126 / 143, 64x16: 182 / 134 / 135 / 138 / 152, 32x16: 222 / 140 / 123 / 115 / 114):
+// 32 x 32 tiles from r = 2.0 (thresholds 1.7 / 2.0 / 2.2 / 2.4 / 2.8 measured), 64 x 8 below -- where a 32 x 32 tile spans more cells than the table holds and the
+// overflow goes to global atomics pixel by pixel.
+constexpr TileGeom kBwdBigTile{1, 4};
+#ifndef SDFR_BWD_BIG_MIN_RATIO
+#define SDFR_BWD_BIG_MIN_RATIO 2.0f
+#endif
+// One launch serves both tilings without an integer division (a culled workgroup's life is its instruction
+// chain): the grid is the 64 x 8 tiling's, (nx, rows) workgroups per view, and workgroup (bx, by) of a view with
+// 32 x 32 tiles takes tile (2 bx + (by & 1), by >> 1) -- or leaves.  Its record of partial sums is by * nx + bx.
+__host__ __device__ constexpr int backward_batch_rows(int H) {
+  return kMacroTile.ny(H) > 2 * kBwdBigTile.ny(H) ? kMacroTile.ny(H) : 2 * kBwdBigTile.ny(H);
+}
+__host__ __device__ constexpr int backward_tile_stride(int W, int H) {   // records per view
+  return kMacroTile.nx(W) * backward_batch_rows(H);
+}
+__host__ __device__ constexpr int backward_big_record(int tx, int ty, int W) {
+  return (2 * ty + (tx & 1)) * kMacroTile.nx(W) + (tx >> 1);
+}
 
 // packed cell records are used for a grid shared by >= kPackedMinViews views, up to kPackedMaxR
 #ifndef SDFR_PACKED_MIN_VIEWS

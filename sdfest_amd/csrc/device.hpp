@@ -405,7 +405,13 @@ struct PairRunHash {
         sum += (q - (long long)(int)(unsigned)((unsigned long long)q & 0xffffffffull)) >> 32;
       }
       const int lin = key * 4 + k;
+#if defined(SDFR_TIMING_FLUSH_STORE)   // timing-only builds: what the flush's global atomics cost
+      if (sum != 0 && lin < nvox) gvol[lin] = (float)sum * from_fixed;
+#elif defined(SDFR_TIMING_FLUSH_NONE)
+      if (sum == 0x7fffffffffffll && lin < nvox) gvol[lin] = (float)sum * from_fixed;
+#else
       if (sum != 0 && lin < nvox) atomicAdd(gvol + lin, (float)sum * from_fixed);
+#endif
     }
   }
 };

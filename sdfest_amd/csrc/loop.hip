@@ -111,8 +111,9 @@ __global__ void views_to_pose_grad_kernel(const float* __restrict__ orientation,
 // three.  One workgroup; wave w reduces views w, w + 4, ... into LDS, thread 0 then runs the chain.
 __global__ __launch_bounds__(256) void views_to_pose_grad_deferred_kernel(
     const float* __restrict__ orientation, const float* __restrict__ scale, const float* __restrict__ cam_quat,
-    int V, const ViewSetup* __restrict__ setup, const float* __restrict__ tile_part, int ntx, int nty,
-    int tile_w, int tile_h, const float* __restrict__ pc_part, const float* __restrict__ pc_loss_part,
+    int V, const ViewSetup* __restrict__ setup, const float* __restrict__ tile_part, int W, int H, int ntx_all,
+    int nty_all, int tile_w_all, int tile_h_all, int stride, const float* __restrict__ pc_part,
+    const float* __restrict__ pc_loss_part,
     const int* __restrict__ offsets, int n_single, int nblk, const float* __restrict__ quat_c,
     float* __restrict__ pc_loss, float* __restrict__ g_position, float* __restrict__ g_orientation,
     float* __restrict__ g_scale) {
@@ -122,14 +123,22 @@ __global__ __launch_bounds__(256) void views_to_pose_grad_deferred_kernel(
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (tile_part) {
       const ViewSetup& s = setup[v];
+      // the view's tiling, as pose_reduce_kernel (render.hip): a batch backward picks it per view
+      int ntx = ntx_all, nty = nty_all, tile_w = tile_w_all, tile_h = tile_h_all;
+      size_t first = (size_t)v * ntx * nty;
+      const bool big = stride > 0 && s.bwd_big;
+      if (stride > 0) first = (size_t)v * stride;
+      if (big) { tile_w = kBwdBigTile.w(); tile_h = kBwdBigTile.h(); }
+      (void)nty;
       const int x0 = s.rect[0], y0 = s.rect[1], x1 = s.rect[2], y1 = s.rect[3];
       if (x1 > x0 && y1 > y0) {
         const int tx0 = x0 / tile_w, tx1 = (x1 - 1) / tile_w, ty0 = y0 / tile_h, ty1 = (y1 - 1) / tile_h;
         const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1);
-        const float* base = tile_part + (size_t)v * ntx * nty * 8;
+        const float* base = tile_part + first * 8;
         for (int i = lane; i < n; i += 64) {
           const int ty = ty0 + i / nx, tx = tx0 + i % nx;
-          const float4* p = reinterpret_cast<const float4*>(base + ((size_t)ty * ntx + tx) * 8);
+          const size_t rec = big ? (size_t)backward_big_record(tx, ty, W) : (size_t)ty * ntx + tx;
+          const float4* p = reinterpret_cast<const float4*>(base + rec * 8);
           const float4 a = p[0], c = p[1];
           acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
           acc[4] += c.x; acc[5] += c.y; acc[6] += c.z; acc[7] += c.w;
@@ -620,11 +629,13 @@ extern "C" int sdfr_views_to_pose_grad_deferred(const float* orientation, const 
   const float* tile_part = render_workspace ? (const float*)((const char*)render_workspace + (size_t)V * sizeof(ViewSetup)) : nullptr;
   const TileGeom geom = render_workspace ? backward_geom(V, W, H) : kSmallTile;
   const int ntx = render_workspace ? geom.nx(W) : 0, nty = render_workspace ? geom.ny(H) : 0;
+  const int stride = (render_workspace && geom.sx * geom.sy > 1) ? backward_tile_stride(W, H) : 0;
   const int nblk = pc_workspace ? (max_view_points + kSamplerPts - 1) / kSamplerPts : 0;
   const float* pc_part = (const float*)pc_workspace;
   const float* pc_loss_part = (pc_workspace && pc_loss) ? pc_part + (size_t)V * nblk * 8 : nullptr;
   hipLaunchKernelGGL(views_to_pose_grad_deferred_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, orientation,
-                     scale, cam_quat, V, setup, tile_part, ntx, nty, geom.w(), geom.h(), pc_part, pc_loss_part,
+                     scale, cam_quat, V, setup, tile_part, W, H, ntx, nty, geom.w(), geom.h(), stride, pc_part,
+                     pc_loss_part,
                      offsets, max_view_points, nblk, quat_c, pc_loss, g_position, g_orientation, g_scale);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;

@@ -53,6 +53,9 @@ __device__ unsigned long long g_stamps[153600 * 16];
 #else
 #define SDFR_STAMP(k) do {} while (0)
 #endif
+#ifndef SDFR_BWD_SLOTS
+#define SDFR_BWD_SLOTS 512  // slots of the batch backward's z-pair run table
+#endif
 #ifndef SDFR_FWD_WAVES
 #define SDFR_FWD_WAVES 2
 #endif
@@ -175,7 +178,12 @@ __device__ __forceinline__ void compute_view_setup(int b, const float* __restric
     s.tm[k] = s.e[k] + lo[k];
   }
   s.dgk = isc * h;
-  for (int k = 0; k < 23; ++k) s.pad[k] = 0.0f;
+  {  // pixels one voxel spans on the screen at the object's distance (common.hpp, kBwdBigTile)
+    const float dist = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
+    const float r = sqrtf(fabsf(fx * fy)) * (scale / h) / fmaxf(dist, 1e-20f);
+    s.bwd_big = (r >= SDFR_BWD_BIG_MIN_RATIO) ? 1 : 0;   // (NaN -> 0)
+  }
+  for (int k = 0; k < 22; ++k) s.pad[k] = 0.0f;
   if (!WAVE || (threadIdx.x & 63) == 0) out[b] = s;
 }
 
@@ -461,7 +469,7 @@ struct BackwardLds {
 // (the gradient of simple_setup.py:129-135's masked mean of |est - obs|; 0 where est == obs).
 template <int RT, int SX, int SY, typename Hash, bool LOSS>
 __device__ __forceinline__ void backward_tile(
-    BackwardLds<Hash>& lds, int tile_x, int tile_y, int ntx, int nty, int b, float loss_k,
+    BackwardLds<Hash>& lds, int tile_x, int tile_y, size_t record, int b, float loss_k,
     const float* __restrict__ grad_depth, const float* __restrict__ depth,
     const float* __restrict__ sdf, int R, long long sdf_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx, float rfy,
@@ -482,7 +490,7 @@ __device__ __forceinline__ void backward_tile(
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const float* zimg = depth + (size_t)b * H * W;
   const float* gimg = grad_depth + (size_t)b * H * W;
-  float* part = partials + (((size_t)b * nty + tile_y) * ntx + tile_x) * 8;
+  float* part = partials + record * 8;  // this tile's pose sums
 
   // all depth reads of the macro-tile up front (independent loads), then the upstream
   // gradient of the hit pixels only
@@ -513,7 +521,7 @@ __device__ __forceinline__ void backward_tile(
     return;
   }
 #ifdef SDFR_STAMPS
-  unsigned long long* stamp__ = g_stamps + ((((size_t)b * nty + tile_y) * ntx + tile_x) % 153600) * 16;
+  unsigned long long* stamp__ = g_stamps + (record % 153600) * 16;
 #endif
   SDFR_STAMP(0);   // the tile's depth (and upstream gradient) loads are back
   hash.clear(tid, kBlock);
@@ -651,31 +659,67 @@ __device__ __forceinline__ void backward_tile(
 // Batches pre-sum in the z-pair run table (device.hpp, PairRunHash), small calls in 2-voxel runs x 1024 slots.
 // (Until the pair table, batches of low-resolution images took a 4 x 1024 run table of their own: 320x240
 // 117.6 -> 109.8 us, 160x120 107.1 -> 73.1 us per 256 views with the one pair table for all image sizes.)
-template <int RT, int SX, int SY, bool LOSS>
-__global__ __launch_bounds__(kBlock) void render_backward_kernel(
-    const float* __restrict__ grad_depth, const float* __restrict__ depth,
-    const float* __restrict__ sdf, int R, long long sdf_view_stride,
-    const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, float cx, float cy,
-    float rfx, float rfy, int sdf_grad_mode, float* __restrict__ g_sdf,
-    long long g_sdf_view_stride, float* __restrict__ partials, const float* __restrict__ loss_grad,
-    const float* __restrict__ loss_stats, float loss_weight) {
 #if SDFR_BWD_PAIR_HASH
-  using FullHash = PairRunHash<512>;
+using BatchTable = PairRunHash<SDFR_BWD_SLOTS>;
 #else
-  using FullHash = BatchHash;
+using BatchTable = BatchHash;
 #endif
-  using Hash = typename std::conditional<(SX * SY > 1), FullHash, SmallHash>::type;
-  __shared__ BackwardLds<Hash> lds;
-  const int b = blockIdx.z;
+
+// One tile of view b.  BATCH: workgroup (bx, by) of the view's own tiling -- 32 x 32 pixels or 64 x 8, chosen per
+// view by the set-up (ViewSetup::bwd_big; common.hpp, kBwdBigTile) -- otherwise the 32 x 8 tile (bx, by) of a
+// small call.  Returns are workgroup-uniform.
+template <int RT, bool BATCH, bool LOSS>
+__device__ __forceinline__ void backward_dispatch(
+    unsigned char* raw, int bx, int by, int ntx, int nty, int stride, int b,
+    const float* __restrict__ grad_depth, const float* __restrict__ depth, const float* __restrict__ sdf, int R,
+    long long sdf_view_stride, const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx,
+    float rfy, int sdf_grad_mode, float* __restrict__ g_sdf, long long g_sdf_view_stride,
+    float* __restrict__ partials, const float* __restrict__ loss_grad, const float* __restrict__ loss_stats,
+    float loss_weight) {
   float loss_k = 0.0f;
   if (LOSS) {  // same expression as depth_l1_grad_kernel (loop.hip): k = weight / count, 0 if empty
     const float cnt = loss_stats[2 * b + 1];
     const float w = loss_grad ? loss_weight * loss_grad[b] : loss_weight;
     loss_k = cnt > 0.0f ? w / cnt : 0.0f;
   }
-backward_tile<RT, SX, SY, Hash, LOSS>(lds, blockIdx.x, blockIdx.y, ntx, nty, b, loss_k, grad_depth, depth, sdf,
-                                        R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode,
-                                        g_sdf, g_sdf_view_stride, partials);
+  if (BATCH) {
+    auto& lds = *reinterpret_cast<BackwardLds<BatchTable>*>(raw);
+    const size_t record = (size_t)b * stride + by * ntx + bx;   // ntx = the 64 x 8 tiling's
+    if (setup[b].bwd_big) {
+      const int tx = 2 * bx + (by & 1), ty = by >> 1;
+      if (tx >= kBwdBigTile.nx(W) || ty >= kBwdBigTile.ny(H)) return;
+      backward_tile<RT, kBwdBigTile.sx, kBwdBigTile.sy, BatchTable, LOSS>(
+          lds, tx, ty, record, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx,
+          rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
+    } else {
+      if (by >= nty) return;
+      backward_tile<RT, SDFR_MACRO_SX, SDFR_MACRO_SY, BatchTable, LOSS>(
+          lds, bx, by, record, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx,
+          rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
+    }
+  } else {
+    auto& lds = *reinterpret_cast<BackwardLds<SmallHash>*>(raw);
+    backward_tile<RT, 1, 1, SmallHash, LOSS>(
+        lds, bx, by, ((size_t)b * nty + by) * ntx + bx, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride,
+        setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
+  }
+}
+
+// grid: (tiles x, rows, views): BATCH: the 64 x 8 tiling's columns x backward_batch_rows(H); else the 32 x 8 tiling
+template <int RT, bool BATCH, bool LOSS>
+__global__ __launch_bounds__(kBlock) void render_backward_kernel(
+    const float* __restrict__ grad_depth, const float* __restrict__ depth,
+    const float* __restrict__ sdf, int R, long long sdf_view_stride,
+    const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, int stride, float cx, float cy,
+    float rfx, float rfy, int sdf_grad_mode, float* __restrict__ g_sdf,
+    long long g_sdf_view_stride, float* __restrict__ partials, const float* __restrict__ loss_grad,
+    const float* __restrict__ loss_stats, float loss_weight) {
+  __shared__ __attribute__((aligned(16))) unsigned char raw[BATCH ? sizeof(BackwardLds<BatchTable>)
+                                                                  : sizeof(BackwardLds<SmallHash>)];
+  backward_dispatch<RT, BATCH, LOSS>(raw, blockIdx.x, blockIdx.y, ntx, nty, stride, blockIdx.z,
+                                     grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy,
+                                     sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, loss_grad, loss_stats,
+                                     loss_weight);
 }
 
 // The renderer's backward (depth-L1 form) and the sampler's backward (point-cloud L1 form) of one loop iteration in
@@ -683,22 +727,16 @@ backward_tile<RT, SX, SY, Hash, LOSS>(lds, blockIdx.x, blockIdx.y, ntx, nty, b, 
 // and in the captured loop each is a launch of its own that cannot fill the chip (1 200 small tiles, 13 blocks
 // of points): side by side they take max(12, 14) us instead of 12 + 14.  The first `pc_rows` rows of the grid
 // are the sampler's blocks (they take longest, so they start first), the rest the image tiles.
-template <int RT, int SX, int SY>
+template <int RT, bool BATCH>
 __global__ __launch_bounds__(kBlock) void render_backward_pc_kernel(
     const float* __restrict__ target, const float* __restrict__ depth,
     const float* __restrict__ sdf, int R, long long sdf_view_stride,
-    const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, float cx, float cy,
+    const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, int stride, float cx, float cy,
     float rfx, float rfy, int sdf_grad_mode, float* __restrict__ g_sdf,
     long long g_sdf_view_stride, float* __restrict__ partials, const float* __restrict__ loss_grad,
     const float* __restrict__ loss_stats, float loss_weight, int pc_rows, PcBackwardArgs pa) {
-#if SDFR_BWD_PAIR_HASH
-  using FullHash = PairRunHash<512>;
-#else
-  using FullHash = BatchHash;
-#endif
-  using Hash = typename std::conditional<(SX * SY > 1), FullHash, SmallHash>::type;
-  constexpr size_t kLdsBytes = sizeof(BackwardLds<Hash>) > sizeof(PcBackwardLds) ? sizeof(BackwardLds<Hash>)
-                                                                                 : sizeof(PcBackwardLds);
+  constexpr size_t kTileLds = BATCH ? sizeof(BackwardLds<BatchTable>) : sizeof(BackwardLds<SmallHash>);
+  constexpr size_t kLdsBytes = kTileLds > sizeof(PcBackwardLds) ? kTileLds : sizeof(PcBackwardLds);
   __shared__ __attribute__((aligned(16))) unsigned char raw[kLdsBytes];
   const int b = blockIdx.z;
   if ((int)blockIdx.y < pc_rows) {
@@ -706,35 +744,37 @@ __global__ __launch_bounds__(kBlock) void render_backward_pc_kernel(
     if (bx < pa.nblk) pc_backward_block<RT, true>(*reinterpret_cast<PcBackwardLds*>(raw), pa, bx, b);
     return;
   }
-  const float cnt = loss_stats[2 * b + 1];
-  const float w = loss_grad ? loss_weight * loss_grad[b] : loss_weight;
-  const float loss_k = cnt > 0.0f ? w / cnt : 0.0f;
-  backward_tile<RT, SX, SY, Hash, true>(*reinterpret_cast<BackwardLds<Hash>*>(raw), blockIdx.x,
-                                        (int)blockIdx.y - pc_rows, ntx, nty, b, loss_k, target, depth, sdf, R,
-                                        sdf_view_stride, setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf,
-                                        g_sdf_view_stride, partials);
+  backward_dispatch<RT, BATCH, true>(raw, blockIdx.x, (int)blockIdx.y - pc_rows, ntx, nty, stride, b, target, depth,
+                                     sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf,
+                                     g_sdf_view_stride, partials, loss_grad, loss_stats, loss_weight);
 }
 
-// Fixed-order sum of a view's macro-tile partials: one wave per view.
+// Fixed-order sum of a view's tile partials: one wave per view.  stride > 0: a batch backward (the view's own
+// tiling, `stride` records per view); else the tiling (ntx, nty, tile_w, tile_h) for every view.
 __global__ __launch_bounds__(64) void pose_reduce_kernel(const float* __restrict__ partials,
-                                                         const ViewSetup* __restrict__ setup,
-                                                         int ntx, int nty, int tile_w, int tile_h,
+                                                         const ViewSetup* __restrict__ setup, int W, int H,
+                                                         int ntx, int nty, int tile_w, int tile_h, int stride,
                                                          float* __restrict__ g_pos,
                                                          float* __restrict__ g_quat,
                                                          float* __restrict__ g_inv_scale) {
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
   const ViewSetup& s = setup[b];
-  // live macro-tile range of this view (same predicate as the image kernels)
+  size_t first = (size_t)b * ntx * nty;
+  const bool big = stride > 0 && s.bwd_big;
+  if (stride > 0) first = (size_t)b * stride;
+  if (big) { tile_w = kBwdBigTile.w(); tile_h = kBwdBigTile.h(); }
+  // live tile range of this view (same predicate as the image kernels)
   const int x0 = s.rect[0], y0 = s.rect[1], x1 = s.rect[2], y1 = s.rect[3];
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (x1 > x0 && y1 > y0) {
     const int tx0 = x0 / tile_w, tx1 = (x1 - 1) / tile_w, ty0 = y0 / tile_h, ty1 = (y1 - 1) / tile_h;
     const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1);
-    const float* base = partials + (size_t)b * ntx * nty * 8;
+    const float* base = partials + first * 8;
     for (int i = lane; i < n; i += 64) {
       const int ty = ty0 + i / nx, tx = tx0 + i % nx;
-      const float4* p = reinterpret_cast<const float4*>(base + ((size_t)ty * ntx + tx) * 8);
+      const size_t rec = big ? (size_t)backward_big_record(tx, ty, W) : (size_t)ty * ntx + tx;
+      const float4* p = reinterpret_cast<const float4*>(base + rec * 8);
       const float4 a = p[0], c = p[1];
       acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
       acc[4] += c.x; acc[5] += c.y; acc[6] += c.z; acc[7] += c.w;
@@ -827,8 +867,9 @@ extern "C" size_t sdfr_render_forward_l1_workspace_bytes(int R, int B, int W, in
 extern "C" size_t sdfr_render_backward_workspace_bytes(int R, int B, int W, int H) {
   (void)R;
   if (B <= 0 || W <= 0 || H <= 0) return setup_bytes(B);
-  // partial sums: one 32-byte record per tile of the finer geometry
-  return setup_bytes(B) + (size_t)B * kSmallTile.nx(W) * kSmallTile.ny(H) * 8 * sizeof(float);
+  // partial sums: one 32-byte record per tile of the finer geometry (or per workgroup of a batch launch)
+  const size_t small = (size_t)kSmallTile.nx(W) * kSmallTile.ny(H), batch = (size_t)backward_tile_stride(W, H);
+  return setup_bytes(B) + (size_t)B * (small > batch ? small : batch) * 8 * sizeof(float);
 }
 
 namespace {
@@ -983,43 +1024,37 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
   // depth is 0 outside the forward's may-hit rectangle anyway)
   hipLaunchKernelGGL(backward_prologue_kernel, dim3((unsigned)((std::max(g_words, (size_t)B) + 255) / 256)),
                      dim3(256), 0, st, g_sdf, g_words, pos, quat, inv_scale, B, R, W, H, cx, cy, fx, fy, setup);
+  // batch: `stride` workgroups per view, each view in its own tiling (common.hpp, kBwdBigTile); else 32 x 8 tiles
   const TileGeom geom = backward_geom(B, W, H);
-  const bool macro = geom.sx == kMacroTile.sx;
+  const bool batch = geom.sx * geom.sy > 1;
   const int ntx = geom.nx(W), nty = geom.ny(H);
-  const dim3 grid_tile((unsigned)ntx, (unsigned)nty, (unsigned)B);
+  const int stride = batch ? backward_tile_stride(W, H) : 0;
+  const int rows = batch ? backward_batch_rows(H) : nty;
+  const int pc_rows = pc ? (pc->nblk + ntx - 1) / ntx : 0;
+  const dim3 grid_tile((unsigned)ntx, (unsigned)(rows + pc_rows), (unsigned)B);
   const float rfx = (float)(1.0 / (double)fx), rfy = (float)(1.0 / (double)fy);
-#define SDFR_LAUNCH_BWD_L(RT, SX, SY, LOSS)                                                          \
-  hipLaunchKernelGGL((render_backward_kernel<RT, SX, SY, LOSS>), grid_tile, dim3(kBlock), 0,         \
-                     st, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, ntx, nty, cx, cy,  \
-                     rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, loss_grad,         \
-                     loss_stats, loss_weight)
-#define SDFR_LAUNCH_BWD(RT)                                                                          \
+#define SDFR_BWD_ARGS                                                                                \
+  grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, ntx, nty, stride, cx, cy, rfx, rfy,       \
+      sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, loss_grad, loss_stats, loss_weight
+#define SDFR_LAUNCH_BWD(RT, BATCH)                                                                   \
   do {                                                                                               \
-    if (!macro) {                                                                                    \
-      if (with_loss) SDFR_LAUNCH_BWD_L(RT, 1, 1, true);                                              \
-      else SDFR_LAUNCH_BWD_L(RT, 1, 1, false);                                                       \
-    } else {                                                                                         \
-      if (with_loss) SDFR_LAUNCH_BWD_L(RT, SDFR_MACRO_SX, SDFR_MACRO_SY, true);                      \
-      else SDFR_LAUNCH_BWD_L(RT, SDFR_MACRO_SX, SDFR_MACRO_SY, false);                               \
-    }                                                                                                \
+    if (pc)                                                                                          \
+      hipLaunchKernelGGL((render_backward_pc_kernel<RT, BATCH>), grid_tile, dim3(kBlock), 0, st,     \
+                         SDFR_BWD_ARGS, pc_rows, *pc);                                               \
+    else if (with_loss)                                                                              \
+      hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, true>), grid_tile, dim3(kBlock), 0, st,  \
+                         SDFR_BWD_ARGS);                                                             \
+    else                                                                                             \
+      hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false>), grid_tile, dim3(kBlock), 0, st, \
+                         SDFR_BWD_ARGS);                                                             \
   } while (0)
-  if (pc) {  // the sampler's blocks ride in the same launch (sdfr_render_backward_l1_pc)
-    const int pc_rows = (pc->nblk + ntx - 1) / ntx;
-    const dim3 grid_pc((unsigned)ntx, (unsigned)(nty + pc_rows), (unsigned)B);
-#define SDFR_LAUNCH_BWD_PC(RT, SX, SY)                                                               \
-  hipLaunchKernelGGL((render_backward_pc_kernel<RT, SX, SY>), grid_pc, dim3(kBlock), 0, st,          \
-                     grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, ntx, nty, cx, cy, rfx,  \
-                     rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, loss_grad, loss_stats,   \
-                     loss_weight, pc_rows, *pc)
-    if (R == 64) { if (macro) SDFR_LAUNCH_BWD_PC(64, SDFR_MACRO_SX, SDFR_MACRO_SY); else SDFR_LAUNCH_BWD_PC(64, 1, 1); }
-    else { if (macro) SDFR_LAUNCH_BWD_PC(0, SDFR_MACRO_SX, SDFR_MACRO_SY); else SDFR_LAUNCH_BWD_PC(0, 1, 1); }
-#undef SDFR_LAUNCH_BWD_PC
-  } else if (R == 64) SDFR_LAUNCH_BWD(64); else SDFR_LAUNCH_BWD(0);
+  if (R == 64) { if (batch) SDFR_LAUNCH_BWD(64, true); else SDFR_LAUNCH_BWD(64, false); }
+  else { if (batch) SDFR_LAUNCH_BWD(0, true); else SDFR_LAUNCH_BWD(0, false); }
 #undef SDFR_LAUNCH_BWD
-#undef SDFR_LAUNCH_BWD_L
+#undef SDFR_BWD_ARGS
   if (!deferred)
-    hipLaunchKernelGGL(pose_reduce_kernel, dim3(B), dim3(64), 0, st, partials, setup, ntx, nty,
-                       geom.w(), geom.h(), g_pos, g_quat, g_inv_scale);
+    hipLaunchKernelGGL(pose_reduce_kernel, dim3(B), dim3(64), 0, st, partials, setup, W, H, ntx, nty,
+                       geom.w(), geom.h(), stride, g_pos, g_quat, g_inv_scale);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -372,6 +372,37 @@ def test_c3_full_bench_configuration_parity(R):
         assert np.all(np.abs(pose[sl] - ref[sl]) <= REL * l1), b0
 
 
+@pytest.mark.parametrize("W,H,B,f", [(640, 480, 48, 320.0), (200, 136, 256, 300.0)])
+def test_batch_backward_mixes_both_tile_shapes(R, W, H, B, f):
+    """A batch backward tiles every view by how many pixels one voxel spans on the screen -- 32 x 32 pixel tiles
+    from 2 pixels per voxel, 64 x 8 below (common.hpp, kBwdBigTile) -- in ONE launch: large and small objects
+    interleaved in a batch (and an image whose size is no multiple of either tile) against the oracle, and against
+    the same views one at a time (32 x 8 tiles, another summation order)."""
+    sdf = oracle.blobs_sdf(0)
+    cam = (W, H, W / 2.0, H / 2.0, f, f)
+    assert B * ((W + 63) // 64) * ((H + 7) // 8) >= 16384          # a batch launch (common.hpp, backward_geom)
+    pos, quat, isc = oracle.random_poses(B, seed=7, width=W, height=H, f=f)
+    isc = isc.copy()
+    isc[1::2] *= 2.6                               # every other object 2.6 x smaller
+    ratio = f * (2.0 / isc / 63.0) / np.linalg.norm(pos, axis=1)
+    assert (ratio >= 2.0).sum() >= 4 and (ratio < 2.0).sum() >= 16    # both tilings in one launch
+    d = hip_forward(R, sdf, pos, quat, isc, *cam, 0.005)
+    assert (d > 0).reshape(B, -1).sum(1).min() > 30
+    g = np.random.default_rng(8).uniform(-1, 1, d.shape).astype(np.float32)
+    hb = hip_backward(R, g, d, sdf, pos, quat, isc, *cam)
+    ob = oracle.render_backward(g, d, sdf, pos, quat, isc, *cam[2:], dtype=np.float32)
+    assert rel_err(hb[0], ob[0]) <= REL
+    pose = np.concatenate([hb[1], hb[2], hb[3][:, None]], axis=1)
+    ref = np.concatenate([ob[1], ob[2], ob[3][:, None]], axis=1)
+    dimg = oracle.render_derivative_images(d, sdf, pos, quat, isc, *cam[2:], dtype=np.float32)
+    l1 = np.abs(dimg * g[..., None]).sum(axis=(1, 2), dtype=np.float64)
+    assert np.all(np.abs(pose - ref) <= REL * l1)
+    for b in range(min(B, 64)):
+        h1 = hip_backward(R, g[b], d[b], sdf, pos[b], quat[b], isc[b:b + 1], *cam)
+        one = np.concatenate([h1[1][0], h1[2][0], h1[3]])
+        assert np.all(np.abs(pose[b] - one) <= 1e-5 * l1[b]), b
+
+
 def test_off_centre_non_square_intrinsics(R):
     """fx != fy and a principal point far from the image centre (single view and a packed batch):
     the set-up's screen rectangle and the ray generation must agree with the oracle."""

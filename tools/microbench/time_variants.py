@@ -32,6 +32,8 @@ def main():
     if mode == "mug":   # mug-sized objects at 0.4-0.6 m: ~1.1 pixels per voxel
         pos = pos * torch.tensor([0.3, 0.3, 0.3], device=dev)
         isc = torch.full((B,), 1 / 0.055, device=dev)
+    if "ISC_MUL" in os.environ:   # smaller objects at the same places: fewer pixels per voxel
+        isc = (isc * float(os.environ["ISC_MUL"])).contiguous()
     if mode == "nosurface":
         sdf = torch.ones_like(sdf)
     if mode == "offscreen":
