@@ -167,29 +167,30 @@ def main():
     cam = Camera(W, H, W / 2.0, W / 2.0, W / 2.0, H / 2.0, pixel_center=0.5)
     plan = BatchRenderPlan(64, B, cam, device=device)
 
-    # The one exchange of a step -- the all-reduce of d/dSDF (RCCL) -- is issued asynchronously
-    # and waited for just before the NEXT backward overwrites the buffer: it runs beside the next
-    # step's forward, which does not read it.  Same work per step, nothing skipped; the last
-    # step's exchange is waited for inside the timed region.
-    pending = [None]
+    # The one exchange of a step -- the all-reduce of d/dSDF (RCCL) -- is issued asynchronously.  The plan
+    # alternates between two gradient volumes (a step's forward zero-fills the volume its backward will add
+    # into), so the exchange of step k only has to be complete before the forward of step k + 2 re-uses its
+    # volume: it runs beside the next step.  Same work per step, nothing skipped; the last steps' exchanges are
+    # waited for inside the timed region.
+    pending = []
 
-    def finish_exchange():
-        if pending[0] is not None:
-            pending[0].wait()
-            pending[0] = None
+    def finish_exchange(keep=0):
+        while len(pending) > keep:
+            pending.pop(0).wait()
 
     def step(ev=None):
         if ev:
             ev[0].record()
-        plan.forward(sdf, pos, quat, isc, thr)
+        finish_exchange(keep=1)
+        # forward + backward of the same views = one step (sdfr_render_step_forward / _backward)
+        plan.forward(sdf, pos, quat, isc, thr, prepare_backward=True)
         if ev:
             ev[1].record()
-        finish_exchange()
         plan.backward(g, sdf, pos, quat, isc)
         if ev:
             ev[2].record()
         if use_dist:
-            pending[0] = allreduce_shared_gradients(plan.g_sdf, async_op=True)
+            pending.append(allreduce_shared_gradients(plan.g_sdf, async_op=True))
 
     def barrier():
         finish_exchange()

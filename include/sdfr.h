@@ -103,6 +103,37 @@ SDFR_API int sdfr_render_backward(const float* grad_depth, const float* depth, c
                          float* g_inv_scale, void* workspace, size_t workspace_bytes, int device,
                          void* stream);
 
+/* ---- one step = forward + backward of the SAME views ---------------------------------------- */
+
+/* The reference's render-and-compare loop always runs the two halves as a pair:
+ * SDFRendererFunctionGPU.forward saves (image, sdf, pos, quat, inv_scale) and .backward gets them back
+ * (sdf_renderer.py:311-331, :334-357).  As two independent calls the backward repeats work the forward
+ * has done (its own view set-up, with the whole cube's screen rectangle because it does not know the
+ * threshold) and opens with a launch of its own (zero fill of g_sdf + set-up).  A step keeps the pair's
+ * state in ONE workspace:
+ *   sdfr_render_step_forward   = sdfr_render_forward; its prologue launch also zero-fills `g_sdf`
+ *                                (g_sdf_view_stride as in sdfr_render_backward);
+ *   sdfr_render_step_backward  = sdfr_render_backward for the views, camera and image size of the
+ *                                preceding sdfr_render_step_forward on the same workspace: no prologue
+ *                                launch, tiles culled with the forward's may-hit rectangles.  `depth` must
+ *                                be that forward's output (it is 0 outside those rectangles), g_sdf the
+ *                                volume it zero-filled.  pos / quat / inv_scale are not passed again.
+ * Results equal the two stand-alone calls: depth bit for bit; pose gradients up to the rounding of their
+ * fixed-order tile sums (the order follows the view's rectangle; still bitwise reproducible run to run),
+ * g_sdf up to the order of its float atomics.  Nothing else may use the workspace between the two calls. */
+SDFR_API size_t sdfr_render_step_workspace_bytes(int R, int B, int W, int H);
+SDFR_API int sdfr_render_step_forward(const float* sdf, int R, long long sdf_view_stride, const float* pos,
+                             const float* quat, const float* inv_scale, int B, int W, int H, float cx,
+                             float cy, float fx, float fy, float threshold, float* depth, float* g_sdf,
+                             long long g_sdf_view_stride, void* workspace, size_t workspace_bytes,
+                             int device, void* stream);
+SDFR_API int sdfr_render_step_backward(const float* grad_depth, const float* depth, const float* sdf, int R,
+                              long long sdf_view_stride, int B, int W, int H, float cx, float cy,
+                              float fx, float fy, int sdf_grad_mode, float* g_sdf,
+                              long long g_sdf_view_stride, float* g_pos, float* g_quat,
+                              float* g_inv_scale, void* workspace, size_t workspace_bytes, int device,
+                              void* stream);
+
 /* ---- render + masked depth-L1 in one pass ------------------------------------ */
 
 /* The depth term of SDFPipeline._compute_view_losses (sdfest/estimation/simple_setup.py:129-135)

@@ -75,19 +75,14 @@ constexpr int kFwdWaves = SDFR_FWD_WAVES;  // waves per workgroup of the batch f
 // exactly as before (the trajectory of a hit is the reference's).  Measured on the benchmark scene:
 // the box keeps 57 % of the in-cube rays, 81 % of the march steps and 60 % of the rectangle area
 // (tools/analysis/aabb_pruning.py).
-template <bool WAVE = false>
-__device__ __forceinline__ void compute_view_setup(int b, const float* __restrict__ pos,
-                                                   const float* __restrict__ quat,
-                                                   const float* __restrict__ inv_scale, int R, int W, int H,
-                                                   float cx, float cy, float fx, float fy,
-                                                   ViewSetup* __restrict__ out,
-                                                   const float* __restrict__ plane_min = nullptr,
-                                                   float threshold = 0.0f) {
+// pose part of a view's record: everything that does not depend on the grid
+__device__ __forceinline__ void setup_pose(int b, const float* __restrict__ pos, const float* __restrict__ quat,
+                                           const float* __restrict__ inv_scale, int R, float fx, float fy,
+                                           ViewSetup& s) {
   const float x = quat[4 * b], y = quat[4 * b + 1], z = quat[4 * b + 2], w = quat[4 * b + 3];
   const V3 p = mk(pos[3 * b], pos[3 * b + 1], pos[3 * b + 2]);
   const float isc = inv_scale[b];
   const float scale = 1.0f / isc;
-  ViewSetup s;
   // rotation matrix in the form the reference evaluates (sdf_renderer_cuda.cu:112-121)
   s.rot[0] = 1 - 2 * (y * y + z * z); s.rot[1] = 2 * (x * y - w * z);     s.rot[2] = 2 * (x * z + w * y);
   s.rot[3] = 2 * (x * y + w * z);     s.rot[4] = 1 - 2 * (x * x + z * z); s.rot[5] = 2 * (y * z - w * x);
@@ -102,6 +97,24 @@ __device__ __forceinline__ void compute_view_setup(int b, const float* __restric
   s.q[0] = x; s.q[1] = y; s.q[2] = z; s.q[3] = w;
   s.scale = scale;
   s.isc = isc;
+  s.dgk = isc * h;
+  {  // pixels one voxel spans on the screen at the object's distance (common.hpp, kBwdBigTile)
+    const float dist = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
+    const float r = sqrtf(fabsf(fx * fy)) * (scale / h) / fmaxf(dist, 1e-20f);
+    s.bwd_big = (r >= SDFR_BWD_BIG_MIN_RATIO) ? 1 : 0;   // (NaN -> 0)
+  }
+  for (int k = 0; k < 22; ++k) s.pad[k] = 0.0f;
+}
+
+// grid part: the may-hit box from the plane minima (nullable), its screen rectangle, the slab planes.
+// WAVE: the 64 lanes of a wave share the work of one view (all lanes end up with the same record).
+template <bool WAVE>
+__device__ __forceinline__ void setup_box(ViewSetup& s, int R, int W, int H, float cx, float cy, float fx,
+                                          float fy, const float* __restrict__ plane_min, float threshold) {
+  const V3 p = mk(s.p[0], s.p[1], s.p[2]);
+  const float scale = s.scale, isc = s.isc;
+  const float h = 0.5f * (float)(R - 1);
+  const int lane = threadIdx.x & 63;
   // may-hit box in object coordinates, lo[a] .. hi[a] (the whole cube without plane minima)
   float lo[3] = {-scale, -scale, -scale}, hi[3] = {scale, scale, scale};
   bool empty = false;
@@ -116,7 +129,6 @@ __device__ __forceinline__ void compute_view_setup(int b, const float* __restric
         if (WAVE) {
           // the whole wave scans the R-1 slabs of the axis: 64 per round, first / last set bit of the ballot
           // (a serial scan by one thread is 3(R-1) dependent loads: 17 us per launch at R = 64, measured)
-          const int lane = threadIdx.x & 63;
           for (int i0 = 0; i0 + 1 < R; i0 += 64) {
             const int i = i0 + lane;
             const bool f = (i + 1 < R) && (fminf(pm[i], pm[i + 1]) < vhit);
@@ -147,7 +159,7 @@ __device__ __forceinline__ void compute_view_setup(int b, const float* __restric
   // lies inside the bounding rectangle of the 8 projected corners.
   float umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f;
   bool in_front = true;
-  for (int c = 0; c < 8; ++c) {
+  auto corner = [&](int c) {
     const float sx = (c & 1) ? hi[0] : lo[0], sy = (c & 2) ? hi[1] : lo[1],
                 sz = (c & 4) ? hi[2] : lo[2];
     const float X = p.x + s.rot[0] * sx + s.rot[1] * sy + s.rot[2] * sz;
@@ -159,6 +171,18 @@ __device__ __forceinline__ void compute_view_setup(int b, const float* __restric
     const float v = cy - fy * Y * iz;
     umin = fminf(umin, u); umax = fmaxf(umax, u);
     vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+  };
+  if (WAVE) {
+    // corner lane & 7 per lane, then the 8-lane groups fold (min / max are exact: the same values in any order)
+    corner(lane & 7);
+#pragma unroll
+    for (int off = 1; off <= 4; off <<= 1) {
+      umin = fminf(umin, __shfl_xor(umin, off, 64)); umax = fmaxf(umax, __shfl_xor(umax, off, 64));
+      vmin = fminf(vmin, __shfl_xor(vmin, off, 64)); vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+    }
+    in_front = __ballot(!in_front) == 0ull;
+  } else {
+    for (int c = 0; c < 8; ++c) corner(c);
   }
   int x0 = 0, y0 = 0, x1 = W, y1 = H;
   if (in_front) {
@@ -177,13 +201,19 @@ __device__ __forceinline__ void compute_view_setup(int b, const float* __restric
     s.tp[k] = s.e[k] + hi[k];
     s.tm[k] = s.e[k] + lo[k];
   }
-  s.dgk = isc * h;
-  {  // pixels one voxel spans on the screen at the object's distance (common.hpp, kBwdBigTile)
-    const float dist = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
-    const float r = sqrtf(fabsf(fx * fy)) * (scale / h) / fmaxf(dist, 1e-20f);
-    s.bwd_big = (r >= SDFR_BWD_BIG_MIN_RATIO) ? 1 : 0;   // (NaN -> 0)
-  }
-  for (int k = 0; k < 22; ++k) s.pad[k] = 0.0f;
+}
+
+template <bool WAVE = false>
+__device__ __forceinline__ void compute_view_setup(int b, const float* __restrict__ pos,
+                                                   const float* __restrict__ quat,
+                                                   const float* __restrict__ inv_scale, int R, int W, int H,
+                                                   float cx, float cy, float fx, float fy,
+                                                   ViewSetup* __restrict__ out,
+                                                   const float* __restrict__ plane_min = nullptr,
+                                                   float threshold = 0.0f) {
+  ViewSetup s;
+  setup_pose(b, pos, quat, inv_scale, R, fx, fy, s);
+  setup_box<WAVE>(s, R, W, H, cx, cy, fx, fy, plane_min, threshold);
   if (!WAVE || (threadIdx.x & 63) == 0) out[b] = s;
 }
 
@@ -197,12 +227,35 @@ __global__ void view_setup_kernel(const float* __restrict__ pos, const float* __
   if (b < B) compute_view_setup<true>(b, pos, quat, inv_scale, R, W, H, cx, cy, fx, fy, out, plane_min, threshold);
 }
 
+// The plane minima reach the set-up waves of the SAME launch (forward_prologue_kernel) as tagged entries: 16 bytes
+// per plane, two 64-bit words {bits(min), tag} and {~bits(min), tag}, each written with one agent-scope atomic
+// store.  A reader that sees the current tag in both words and complementary payloads holds the value (single-copy
+// atomicity of the 64-bit words: no fence, no counter to reset); the tag is the workspace's epoch + 1, which the
+// forward kernel advances after the launch, so entries of earlier calls -- or whatever else the caller kept in the
+// workspace -- never read as ready (two matching tags and complementary payloads: 2^-96 for random bytes).
+struct PlaneEntry {
+  unsigned long long a, b;
+};
+constexpr int kSyncHeaderWords = 32;  // 128 bytes: word 0 = epoch
+__device__ __forceinline__ void publish_plane_min(float* __restrict__ plane_min, PlaneEntry* __restrict__ ent,
+                                                  unsigned tag, int j, float m) {
+  if (ent) {
+    const unsigned bits = __float_as_uint(m);
+    __hip_atomic_store(&ent[j].a, ((unsigned long long)tag << 32) | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ent[j].b, ((unsigned long long)tag << 32) | (unsigned)~bits, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    plane_min[j] = m;
+  }
+}
+
 // Minimum of the grid over one plane: block j = axis * R + i reduces the R^2 values with index i
 // along `axis`.  (NaN values are ignored: a sample that sees one never passes the hit test.)
 // z-planes (axis 2) are strided by R floats: a block takes FOUR of them with 16-byte loads (R % 4 == 0; block
 // j = 2R + i does planes i .. i+3 when i % 4 == 0 and nothing otherwise), a quarter of the lines per plane.
 __device__ __forceinline__ void plane_min_block(const float* __restrict__ sdf, int R, int j,
-                                                float* __restrict__ plane_min) {
+                                                float* __restrict__ plane_min, PlaneEntry* __restrict__ ent = nullptr,
+                                                unsigned tag = 0u) {
   __shared__ float red[4][4];
   const int axis = j / R, i = j % R, RR = R * R;
   const int tid = threadIdx.x;
@@ -220,7 +273,9 @@ __device__ __forceinline__ void plane_min_block(const float* __restrict__ sdf, i
     }
     if ((tid & 63) == 0) { red[tid >> 6][0] = m0; red[tid >> 6][1] = m1; red[tid >> 6][2] = m2; red[tid >> 6][3] = m3; }
     __syncthreads();
-    if (tid < 4) plane_min[j + tid] = fminf(fminf(red[0][tid], red[1][tid]), fminf(red[2][tid], red[3][tid]));
+    if (tid < 4)
+      publish_plane_min(plane_min, ent, tag, j + tid,
+                        fminf(fminf(red[0][tid], red[1][tid]), fminf(red[2][tid], red[3][tid])));
     return;
   }
   float m = 3.0e38f;
@@ -233,7 +288,7 @@ __device__ __forceinline__ void plane_min_block(const float* __restrict__ sdf, i
   for (int off = 32; off >= 1; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
   if ((tid & 63) == 0) red[tid >> 6][0] = m;
   __syncthreads();
-  if (tid == 0) plane_min[j] = fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0]));
+  if (tid == 0) publish_plane_min(plane_min, ent, tag, j, fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0])));
 }
 
 // The backward's prologue in one launch: zero the gradient volume(s) and set the views up (every
@@ -259,6 +314,66 @@ __global__ __launch_bounds__(256) void backward_prologue_kernel(
 // bound by dependent-load latency, not by lines per access.  Records stay in grid order.)
 // The launch's last 3R blocks compute the plane minima for the may-hit boxes (compute_view_setup);
 // the views are set up by the next launch, which needs them.
+// Plane minima for the one-launch prologue (R % 4 == 0, 16-byte aligned grid): 3R blocks, every thread a few
+// 16-byte loads that are all in flight together (the set-up waves of the launch wait for the slowest block).
+//   block i      in [0, R):    x-plane i, 16 KiB contiguous
+//   block R + i  in [R, 2R):   y-plane i, R rows of R floats
+//   block 2R + k in [2R, 3R):  z-planes 4 zq .. 4 zq + 3 (zq = k % (R/4)) over a QUARTER of the (x, y) rows
+//                              (part = k / (R/4)): the loads of a z-plane are strided by a grid row, so the work
+//                              is spread over four blocks and the readers take the minimum of the four entries
+// Entries: x -> i, y -> R + i, z -> 2R + part * R + z   (6R entries of 16 bytes).
+__device__ __forceinline__ float4 min4(float4 a, float4 b) {
+  return make_float4(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), fminf(a.w, b.w));
+}
+__device__ __forceinline__ void plane_min_fast_block(const float* __restrict__ sdf, int R, int blk,
+                                                     PlaneEntry* __restrict__ ent, unsigned tag) {
+  __shared__ float4 red4[4];
+  const int tid = threadIdx.x, RR = R * R, Rq = R >> 2;
+  const float4* v = reinterpret_cast<const float4*>(sdf);
+  float4 m = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f);
+  const int axis = blk / R, i = blk - axis * R;
+  if (axis == 0) {
+    const float4* base = v + (size_t)i * (RR >> 2);
+#pragma unroll 4
+    for (int q = tid; q < (RR >> 2); q += 256) m = min4(m, base[q]);
+  } else if (axis == 1) {
+    const float4* base = v + (size_t)i * Rq;
+#pragma unroll 4
+    for (int q = tid; q < R * Rq; q += 256) m = min4(m, base[(size_t)(q / Rq) * (RR >> 2) + (q % Rq)]);
+  } else {
+    const int zq = i % Rq, part = i / Rq, rows = RR >> 2;
+    const float4* base = v + (size_t)part * rows * Rq + zq;
+#pragma unroll 4
+    for (int r = tid; r < rows; r += 256) m = min4(m, base[(size_t)r * Rq]);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    m.x = fminf(m.x, __shfl_xor(m.x, off, 64)); m.y = fminf(m.y, __shfl_xor(m.y, off, 64));
+    m.z = fminf(m.z, __shfl_xor(m.z, off, 64)); m.w = fminf(m.w, __shfl_xor(m.w, off, 64));
+  }
+  if ((tid & 63) == 0) red4[tid >> 6] = m;
+  __syncthreads();
+  if (tid < 4) {
+    const float4 a = min4(min4(red4[0], red4[1]), min4(red4[2], red4[3]));
+    if (axis < 2) {
+      if (tid == 0) publish_plane_min(nullptr, ent, tag, blk, fminf(fminf(a.x, a.y), fminf(a.z, a.w)));
+    } else {
+      const int zq = i % Rq, part = i / Rq;
+      const float val = tid == 0 ? a.x : (tid == 1 ? a.y : (tid == 2 ? a.z : a.w));
+      publish_plane_min(nullptr, ent, tag, 2 * R + part * R + 4 * zq + tid, val);
+    }
+  }
+}
+
+__device__ __forceinline__ void pack_cell(const float* __restrict__ sdf, int R, float4* __restrict__ cells, int lin) {
+  const int RR = R * R;
+  if (lin >= RR * R) return;
+  const int z = lin % R, y = (lin / R) % R;
+  if (y >= R - 1 || z >= R - 1) return;
+  const float* p = sdf + lin;
+  cells[record_index(lin / RR, y, z, (R + 1) >> 1)] = make_float4(p[0], p[1], p[R], p[R + 1]);
+}
+
 __global__ __launch_bounds__(256) void pack_cells_kernel(const float* __restrict__ sdf, int R,
                                                          float4* __restrict__ cells, int n_pack_blocks,
                                                          float* __restrict__ plane_min) {
@@ -268,13 +383,69 @@ __global__ __launch_bounds__(256) void pack_cells_kernel(const float* __restrict
     plane_min_block(sdf, R, (int)blockIdx.x, plane_min);
     return;
   }
-  const int lin = ((int)blockIdx.x - n_plane) * blockDim.x + threadIdx.x;
-  const int RR = R * R;
-  if (lin >= RR * R) return;
-  const int z = lin % R, y = (lin / R) % R;
-  if (y >= R - 1 || z >= R - 1) return;
-  const float* p = sdf + lin;
-  cells[record_index(lin / RR, y, z, (R + 1) >> 1)] = make_float4(p[0], p[1], p[R], p[R + 1]);
+  pack_cell(sdf, R, cells, ((int)blockIdx.x - n_plane) * (int)blockDim.x + (int)threadIdx.x);
+}
+
+// The forward's prologue in ONE launch (it was two: the view set-up needs the plane minima of the grid, and every
+// launch of the step costs ~5 us whatever it does).  Blocks, in dispatch order:
+//   [0, n_plane)            plane minima, published as tagged entries (PlaneEntry)
+//   [n_plane, +n_setup)     4 views each, one wave per view: the block polls the 3R entries (agent-scope atomic
+//                           loads) until all carry this launch's tag, then sets its views up from them
+//   the rest                face records of the grid (pack_cell) and the zero fill of `g_zero` (the gradient
+//                           volume of the step's backward, sdfr_render_step_forward)
+// The set-up blocks can only wait for blocks dispatched before them, which never wait themselves; and the wait is
+// bounded: after kPrologueMaxPolls rounds a block sets its views up WITHOUT plane minima (the whole cube as the
+// may-hit box: slower, same depth), so no schedule can hang the launch.
+constexpr int kPrologueMaxPolls = 1 << 16;
+__global__ __launch_bounds__(256) void forward_prologue_kernel(
+    const float* __restrict__ sdf, int R, float4* __restrict__ cells, int n_plane, int n_setup,
+    unsigned* __restrict__ sync, const float* __restrict__ pos, const float* __restrict__ quat,
+    const float* __restrict__ inv_scale, int B, int W, int H, float cx, float cy, float fx, float fy,
+    ViewSetup* __restrict__ out, float threshold, float* __restrict__ g_zero, size_t n_zero) {
+  const unsigned tag = sync[0] + 1u;  // the epoch the last forward on this workspace left, + 1
+  PlaneEntry* ent = reinterpret_cast<PlaneEntry*>(sync + kSyncHeaderWords);
+  int blk = (int)blockIdx.x;
+  if (blk < n_plane) {
+    plane_min_fast_block(sdf, R, blk, ent, tag);
+    return;
+  }
+  blk -= n_plane;
+  if (blk < n_setup) {
+    __shared__ float pm_s[6 * kPackedMaxR];
+    const int tid = (int)threadIdx.x, n_ent = 6 * R;
+    // the pose part of this wave's view first: its loads and arithmetic run while the plane blocks work
+    const int b = blk * 4 + (tid >> 6);
+    ViewSetup s;
+    if (b < B) setup_pose(b, pos, quat, inv_scale, R, fx, fy, s);
+    bool ready = false;
+    for (int poll = 0; poll < kPrologueMaxPolls; ++poll) {
+      bool ok = true;
+      for (int j = tid; j < n_ent; j += 256) {
+        const unsigned long long a = __hip_atomic_load(&ent[j].a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long c = __hip_atomic_load(&ent[j].b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool good = (unsigned)(a >> 32) == tag && (unsigned)(c >> 32) == tag && (unsigned)a == ~(unsigned)c;
+        if (good) pm_s[j] = __uint_as_float((unsigned)a);
+        ok = ok && good;
+      }
+      if (__syncthreads_and(ok)) { ready = true; break; }   // (also orders the pm_s writes before the reads below)
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (ready) {  // z-planes: the minimum of the four partial entries (thread z reads and writes only column z)
+      for (int z = tid; z < R; z += 256)
+        pm_s[2 * R + z] = fminf(fminf(pm_s[2 * R + z], pm_s[3 * R + z]), fminf(pm_s[4 * R + z], pm_s[5 * R + z]));
+      __syncthreads();
+    }
+    if (b < B) {
+      setup_box<true>(s, R, W, H, cx, cy, fx, fy, ready ? pm_s : nullptr, threshold);
+      if ((tid & 63) == 0) out[b] = s;
+    }
+    return;
+  }
+  blk -= n_setup;
+  const int lin = blk * 256 + (int)threadIdx.x;
+  const size_t vox = (size_t)R * R * R;
+  for (size_t i = (size_t)lin; i < n_zero; i += vox) g_zero[i] = 0.0f;   // (lin < vox or the block has no thread)
+  pack_cell(sdf, R, cells, lin);
 }
 
 struct Rect {
@@ -447,10 +618,13 @@ __global__ __launch_bounds__(NW * 64) void render_forward_kernel(
     const float* __restrict__ src, int R, long long src_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, float cx, float cy,
     float rfx, float rfy, float threshold, int vec_ok, float* __restrict__ depth,
-    const float* __restrict__ target, float* __restrict__ loss_part) {
+    const float* __restrict__ target, float* __restrict__ loss_part, unsigned* __restrict__ epoch) {
   forward_tile<RT, PACKED, SX, SY, LOSS, PACKED && kTightBox, NW>(blockIdx.x, blockIdx.y, ntx, nty, blockIdx.z, src, R,
                                          src_view_stride, setup, W, H, cx, cy, rfx, rfy, threshold,
                                          vec_ok, depth, target, loss_part);
+  // the workspace's epoch advances once per forward call, after its prologue launch (forward_prologue_kernel):
+  // the plane-minimum entries that launch published can never read as ready again
+  if (epoch && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && threadIdx.x == 0) epoch[0] += 1u;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -843,7 +1017,20 @@ bool use_packed(int R, int B, long long sdf_view_stride) {
   return sdf_view_stride == 0 && B >= kPackedMinViews && R <= kPackedMaxR;
 }
 size_t packed_bytes(int R) { return (size_t)R * record_slab(R) * 4 * sizeof(float); }
-size_t plane_bytes(int R) { return ((size_t)3 * R * sizeof(float) + 127) & ~(size_t)127; }
+// the prologue's sync region: 128-byte header (epoch) + 3R plane-minimum entries of 16 bytes
+size_t plane_bytes(int R) {
+  return (size_t)kSyncHeaderWords * 4 + (((size_t)6 * R * sizeof(PlaneEntry) + 127) & ~(size_t)127);
+}
+// A step (sdfr_render_step_forward + sdfr_render_step_backward) keeps everything side by side in one workspace:
+// [view records][sync region][face records][tile partials of the backward]
+size_t step_sync_offset(int B) { return setup_bytes(B); }
+size_t step_cells_offset(int R, int B) { return step_sync_offset(B) + plane_bytes(R); }
+size_t step_partials_offset(int R, int B) {
+  return step_cells_offset(R, B) + ((R >= 2 && R <= kPackedMaxR) ? packed_bytes(R) : 0);
+}
+#ifndef SDFR_FUSED_PROLOGUE
+#define SDFR_FUSED_PROLOGUE 1  // 0: pack + plane minima and the view set-up as two launches (timing experiments)
+#endif
 
 }  // namespace
 }  // namespace sdfr
@@ -864,6 +1051,16 @@ extern "C" size_t sdfr_render_forward_l1_workspace_bytes(int R, int B, int W, in
   return n;
 }
 
+extern "C" size_t sdfr_render_step_workspace_bytes(int R, int B, int W, int H) {
+  if (R < 2 || B <= 0) return 256;
+  size_t n = step_partials_offset(R, B);
+  if (W > 0 && H > 0) {
+    const size_t small = (size_t)kSmallTile.nx(W) * kSmallTile.ny(H), batch = (size_t)backward_tile_stride(W, H);
+    n += (size_t)B * (small > batch ? small : batch) * 8 * sizeof(float);
+  }
+  return n;
+}
+
 extern "C" size_t sdfr_render_backward_workspace_bytes(int R, int B, int W, int H) {
   (void)R;
   if (B <= 0 || W <= 0 || H <= 0) return setup_bytes(B);
@@ -873,19 +1070,41 @@ extern "C" size_t sdfr_render_backward_workspace_bytes(int R, int B, int W, int 
 }
 
 namespace {
+// where a forward call keeps its pieces in the caller's workspace
+struct ForwardLayout {
+  ViewSetup* setup;
+  float* cells;      // face records (packed_bytes)
+  unsigned* sync;    // prologue sync region (plane_bytes): epoch + plane-minimum entries
+  float* loss_part;  // LOSS: (sum, count) per tile
+};
+ForwardLayout plain_forward_layout(void* workspace, int R, int B, int W, int H) {
+  char* w = (char*)workspace;
+  ForwardLayout l;
+  l.setup = (ViewSetup*)w;
+  l.cells = (float*)(w + setup_bytes(B));  // 128-byte aligned
+  l.sync = (unsigned*)((char*)l.cells + packed_bytes(R));
+  l.loss_part = (float*)(w + ((sdfr_render_forward_workspace_bytes(R, B, W, H) + 127) & ~(size_t)127));
+  return l;
+}
+
 // target == nullptr: the plain forward.  Otherwise the forward with the depth-L1 folded in.
+// g_zero (nullable): n_zero words zero-filled by the prologue (the step's gradient volume).
 int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_stride, const float* pos,
                  const float* quat, const float* inv_scale, int B, int W, int H, float cx, float cy,
                  float fx, float fy, float threshold, float* depth, const float* target, float* loss,
-                 float* loss_stats, void* workspace, size_t workspace_bytes, int device,
-                 void* stream) {
+                 float* loss_stats, void* workspace, size_t workspace_bytes, size_t need, const ForwardLayout& lay,
+                 float* g_zero, size_t n_zero, int device, void* stream) {
   const bool with_loss = target != nullptr;
-  const size_t need = with_loss ? sdfr_render_forward_l1_workspace_bytes(R, B, W, H)
-                                : sdfr_render_forward_workspace_bytes(R, B, W, H);
   if (int rc = check_common(R, B, W, H, fx, fy)) return rc;
   if (sdf_view_stride != 0 && sdf_view_stride < (long long)R * R * R)
     return fail(SDFR_E_INVALID, "sdf_view_stride must be 0 or >= R^3");
-  if (B == 0 || W == 0 || H == 0) return 0;
+  if (B == 0 || W == 0 || H == 0) {
+    if (g_zero && n_zero) {
+      SDFR_HIP_TRY(hipSetDevice(device));
+      zero_words_async(g_zero, n_zero, (hipStream_t)stream);
+    }
+    return 0;
+  }
   if (!sdf || !pos || !quat || !inv_scale || !depth || !workspace)
     return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
   if (workspace_bytes < need)
@@ -894,21 +1113,31 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
     return fail(SDFR_E_INVALID, "workspace must be %zu-byte aligned", alignof(ViewSetup));
   SDFR_HIP_TRY(hipSetDevice(device));
   hipStream_t st = (hipStream_t)stream;
-  ViewSetup* setup = (ViewSetup*)workspace;
-  float* cells = (float*)((char*)workspace + setup_bytes(B));  // 128-byte aligned
-  float* loss_part = (float*)((char*)workspace +
-                              ((sdfr_render_forward_workspace_bytes(R, B, W, H) + 127) & ~(size_t)127));
+  ViewSetup* setup = lay.setup;
+  float* cells = lay.cells;
+  float* loss_part = lay.loss_part;
   const bool packed = use_packed(R, B, sdf_view_stride);
-  float* plane_min = nullptr;
-  if (packed) {
-    const int n_pack = (R * R * R + 255) / 256;
-    plane_min = (float*)((char*)cells + packed_bytes(R));
-    hipLaunchKernelGGL(pack_cells_kernel, dim3(n_pack + (kTightBox ? 3 * R : 0)), dim3(256), 0, st, sdf, R,
-                       (float4*)cells, n_pack, plane_min);
-    if (!kTightBox) plane_min = nullptr;
+  unsigned* epoch = nullptr;
+  // (the one-launch prologue reads the grid with 16-byte loads: other grids take the two-launch form)
+  if (packed && kTightBox && SDFR_FUSED_PROLOGUE && (R & 3) == 0 && ((uintptr_t)sdf & 15) == 0) {
+    const int n_pack = (R * R * R + 255) / 256, n_setup = (B + 3) / 4;
+    hipLaunchKernelGGL(forward_prologue_kernel, dim3(3 * R + n_setup + n_pack), dim3(256), 0, st, sdf, R,
+                       (float4*)cells, 3 * R, n_setup, lay.sync, pos, quat, inv_scale, B, W, H, cx, cy, fx, fy,
+                       setup, threshold, g_zero, n_zero);
+    epoch = lay.sync;
+  } else {
+    if (g_zero) zero_words_async(g_zero, n_zero, st);
+    float* plane_min = nullptr;
+    if (packed) {
+      const int n_pack = (R * R * R + 255) / 256;
+      plane_min = (float*)(lay.sync + kSyncHeaderWords);
+      hipLaunchKernelGGL(pack_cells_kernel, dim3(n_pack + (kTightBox ? 3 * R : 0)), dim3(256), 0, st, sdf, R,
+                         (float4*)cells, n_pack, plane_min);
+      if (!kTightBox) plane_min = nullptr;
+    }
+    hipLaunchKernelGGL(view_setup_kernel, dim3(B), dim3(64), 0, st, pos, quat, inv_scale, B, R,
+                       W, H, cx, cy, fx, fy, setup, plane_min, threshold);
   }
-  hipLaunchKernelGGL(view_setup_kernel, dim3(B), dim3(64), 0, st, pos, quat, inv_scale, B, R,
-                     W, H, cx, cy, fx, fy, setup, plane_min, threshold);
   const TileGeom geom = forward_geom(B, W, H);
   const bool macro = geom.sx * geom.sy > 1;
   const int ntx = geom.nx(W), nty = geom.ny(H);
@@ -919,7 +1148,7 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
   hipLaunchKernelGGL((render_forward_kernel<RT, PK, SX, SY, LOSS, (SX * SY > 1 ? kFwdWaves : 4)>), grid_tile, \
                      dim3((SX * SY > 1 ? kFwdWaves : 4) * 64), 0, st, \
                      SRC, R, STRIDE, setup, W, H, ntx, nty, cx, cy, rfx, rfy, threshold, vec_ok,      \
-                     depth, target, loss_part)
+                     depth, target, loss_part, epoch)
 #define SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, SX, SY)                                               \
   do {                                                                                               \
     if (with_loss) SDFR_LAUNCH_FWD_L(RT, PK, SRC, STRIDE, SX, SY, true);                             \
@@ -953,7 +1182,8 @@ extern "C" int sdfr_render_forward(const float* sdf, int R, long long sdf_view_s
                                    size_t workspace_bytes, int device, void* stream) {
   return forward_impl("sdfr_render_forward", sdf, R, sdf_view_stride, pos, quat, inv_scale, B, W, H, cx,
                       cy, fx, fy, threshold, depth, nullptr, nullptr, nullptr, workspace,
-                      workspace_bytes, device, stream);
+                      workspace_bytes, sdfr_render_forward_workspace_bytes(R, B, W, H),
+                      plain_forward_layout(workspace, R, B, W, H), nullptr, 0, device, stream);
 }
 
 extern "C" int sdfr_render_forward_l1(const float* sdf, int R, long long sdf_view_stride,
@@ -966,7 +1196,8 @@ extern "C" int sdfr_render_forward_l1(const float* sdf, int R, long long sdf_vie
     return fail(SDFR_E_NULL, "sdfr_render_forward_l1: NULL pointer argument");
   return forward_impl("sdfr_render_forward_l1", sdf, R, sdf_view_stride, pos, quat, inv_scale, B, W, H,
                       cx, cy, fx, fy, threshold, depth, target, loss, loss_stats, workspace,
-                      workspace_bytes, device, stream);
+                      workspace_bytes, sdfr_render_forward_l1_workspace_bytes(R, B, W, H),
+                      plain_forward_layout(workspace, R, B, W, H), nullptr, 0, device, stream);
 }
 
 
@@ -980,7 +1211,9 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
                   int sdf_grad_mode, float* g_sdf, long long g_sdf_view_stride, float* g_pos,
                   float* g_quat, float* g_inv_scale, const float* loss_grad, const float* loss_stats,
                   float loss_weight, void* workspace, size_t workspace_bytes, int device,
-                  void* stream, const PcBackwardArgs* pc = nullptr) {
+                  void* stream, const PcBackwardArgs* pc = nullptr, bool prepared = false) {
+  // prepared: a step's backward (sdfr_render_step_backward) -- the views were set up and g_sdf zero-filled by
+  // the step's forward, in the step layout of the workspace; pos / quat / inv_scale are not read
   const bool with_loss = loss_stats != nullptr;
   if (int rc = check_common(R, B, W, H, fx, fy)) return rc;
   const long long vox = (long long)R * R * R;
@@ -1002,7 +1235,7 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
   const bool deferred = !g_pos && !g_quat && !g_inv_scale;
   if (deferred && (W == 0 || H == 0))
     return fail(SDFR_E_INVALID, "%s: deferred pose gradients need a non-empty image", fn);
-  if ((!deferred && (!g_pos || !g_quat || !g_inv_scale)) || !pos || !quat || !inv_scale)
+  if ((!deferred && (!g_pos || !g_quat || !g_inv_scale)) || (!prepared && (!pos || !quat || !inv_scale)))
     return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
   if (W == 0 || H == 0) {
     zero_words_async(g_sdf, g_words, st);
@@ -1013,17 +1246,20 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
   }
   if (!grad_depth || !depth || !sdf || !workspace)
     return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
-  if (workspace_bytes < sdfr_render_backward_workspace_bytes(R, B, W, H))
-    return fail(SDFR_E_WORKSPACE, "%s: workspace %zu < %zu bytes", fn, workspace_bytes,
-                sdfr_render_backward_workspace_bytes(R, B, W, H));
+  const size_t need = prepared ? sdfr_render_step_workspace_bytes(R, B, W, H)
+                               : sdfr_render_backward_workspace_bytes(R, B, W, H);
+  if (workspace_bytes < need)
+    return fail(SDFR_E_WORKSPACE, "%s: workspace %zu < %zu bytes", fn, workspace_bytes, need);
   if ((uintptr_t)workspace % alignof(ViewSetup))
     return fail(SDFR_E_INVALID, "workspace must be %zu-byte aligned", alignof(ViewSetup));
   ViewSetup* setup = (ViewSetup*)workspace;
-  float* partials = (float*)((char*)workspace + setup_bytes(B));
-  // (the backward does not know the forward's threshold, so its rectangles are those of the full cube;
-  // depth is 0 outside the forward's may-hit rectangle anyway)
-  hipLaunchKernelGGL(backward_prologue_kernel, dim3((unsigned)((std::max(g_words, (size_t)B) + 255) / 256)),
-                     dim3(256), 0, st, g_sdf, g_words, pos, quat, inv_scale, B, R, W, H, cx, cy, fx, fy, setup);
+  float* partials = (float*)((char*)workspace + (prepared ? step_partials_offset(R, B) : setup_bytes(B)));
+  // (a stand-alone backward does not know the forward's threshold, so its rectangles are those of the full cube;
+  // depth is 0 outside the forward's may-hit rectangle anyway.  A step's backward culls with the forward's own,
+  // tighter rectangles and launches no prologue.)
+  if (!prepared)
+    hipLaunchKernelGGL(backward_prologue_kernel, dim3((unsigned)((std::max(g_words, (size_t)B) + 255) / 256)),
+                       dim3(256), 0, st, g_sdf, g_words, pos, quat, inv_scale, B, R, W, H, cx, cy, fx, fy, setup);
   // batch: `stride` workgroups per view, each view in its own tiling (common.hpp, kBwdBigTile); else 32 x 8 tiles
   const TileGeom geom = backward_geom(B, W, H);
   const bool batch = geom.sx * geom.sy > 1;
@@ -1071,6 +1307,53 @@ extern "C" int sdfr_render_backward(const float* grad_depth, const float* depth,
                        inv_scale, B, W, H, cx, cy, fx, fy, sdf_grad_mode, g_sdf, g_sdf_view_stride, g_pos,
                        g_quat, g_inv_scale, nullptr, nullptr, 0.0f, workspace, workspace_bytes, device,
                        stream);
+}
+
+extern "C" int sdfr_render_step_forward(const float* sdf, int R, long long sdf_view_stride, const float* pos,
+                                        const float* quat, const float* inv_scale, int B, int W, int H, float cx,
+                                        float cy, float fx, float fy, float threshold, float* depth, float* g_sdf,
+                                        long long g_sdf_view_stride, void* workspace, size_t workspace_bytes,
+                                        int device, void* stream) {
+  const char* fn = "sdfr_render_step_forward";
+  const long long vox = (long long)R * R * R;
+  if (R >= 2 && R <= 1023 && g_sdf_view_stride != 0 && g_sdf_view_stride != vox)
+    return fail(SDFR_E_INVALID, "g_sdf_view_stride must be 0 or R^3");
+  if (B > 0 && !g_sdf) return fail(SDFR_E_NULL, "%s: g_sdf is NULL", fn);
+  ForwardLayout lay{};
+  if (workspace && R >= 2 && R <= 1023 && B > 0) {
+    char* w = (char*)workspace;
+    lay.setup = (ViewSetup*)w;
+    lay.sync = (unsigned*)(w + step_sync_offset(B));
+    lay.cells = (float*)(w + step_cells_offset(R, B));
+    lay.loss_part = nullptr;
+  }
+  const size_t g_words = (R >= 2 && R <= 1023) ? (size_t)vox * (g_sdf_view_stride ? (size_t)(B > 0 ? B : 1) : 1) : 0;
+  return forward_impl(fn, sdf, R, sdf_view_stride, pos, quat, inv_scale, B, W, H, cx, cy, fx, fy, threshold, depth,
+                      nullptr, nullptr, nullptr, workspace, workspace_bytes,
+                      sdfr_render_step_workspace_bytes(R, B, W, H), lay, g_sdf, g_words, device, stream);
+}
+
+extern "C" int sdfr_render_step_backward(const float* grad_depth, const float* depth, const float* sdf, int R,
+                                         long long sdf_view_stride, int B, int W, int H, float cx, float cy,
+                                         float fx, float fy, int sdf_grad_mode, float* g_sdf,
+                                         long long g_sdf_view_stride, float* g_pos, float* g_quat,
+                                         float* g_inv_scale, void* workspace, size_t workspace_bytes, int device,
+                                         void* stream) {
+  if (B == 0 || W == 0 || H == 0) {
+    // nothing was rendered: g_sdf is zero already (the step's forward filled it); the pose gradients are zero
+    if (int rc = check_common(R, B, W, H, fx, fy)) return rc;
+    if (B > 0 && g_pos && g_quat && g_inv_scale) {
+      SDFR_HIP_TRY(hipSetDevice(device));
+      zero_words_async(g_pos, (size_t)B * 3, (hipStream_t)stream);
+      zero_words_async(g_quat, (size_t)B * 4, (hipStream_t)stream);
+      zero_words_async(g_inv_scale, (size_t)B, (hipStream_t)stream);
+    }
+    return 0;
+  }
+  return backward_impl("sdfr_render_step_backward", grad_depth, depth, sdf, R, sdf_view_stride, nullptr, nullptr,
+                       nullptr, B, W, H, cx, cy, fx, fy, sdf_grad_mode, g_sdf, g_sdf_view_stride, g_pos, g_quat,
+                       g_inv_scale, nullptr, nullptr, 0.0f, workspace, workspace_bytes, device, stream, nullptr,
+                       true);
 }
 
 extern "C" int sdfr_render_backward_l1(const float* loss_grad, float loss_weight,

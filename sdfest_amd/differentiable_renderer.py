@@ -332,7 +332,13 @@ class BatchRenderPlan:
         self.g_inv_scale = torch.empty((B,), **f32)
         L = _lib.lib()
         nbytes = max(L.sdfr_render_forward_l1_workspace_bytes(R, B, self.W, self.H),
-                     L.sdfr_render_backward_workspace_bytes(R, B, self.W, self.H), 256)
+                     L.sdfr_render_backward_workspace_bytes(R, B, self.W, self.H),
+                     L.sdfr_render_step_workspace_bytes(R, B, self.W, self.H), 256)
+        # a step (forward(..., prepare_backward=True) + backward) zero-fills the NEXT gradient volume in the
+        # forward's prologue: two volumes alternate, so the previous step's g_sdf (e.g. still being all-reduced)
+        # is not touched by the next forward
+        self._g_sdf_pair = [self.g_sdf, torch.empty_like(self.g_sdf)]
+        self._step = None   # what the last forward prepared: (tensor ids / versions, depth tensor)
         self.loss = torch.empty((B,), **f32)
         self.loss_stats = torch.empty((B, 2), **f32)
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
@@ -370,14 +376,37 @@ class BatchRenderPlan:
             if tuple(t.shape) != want[name]:
                 raise RuntimeError(f"{name} must have shape {want[name]}, got {tuple(t.shape)}")
 
-    def forward(self, sdf, pos, quat, inv_scale, threshold: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    @staticmethod
+    def _key(sdf, pos, quat, inv_scale):
+        return (sdf.data_ptr(), sdf._version, pos.data_ptr(), pos._version, quat.data_ptr(), quat._version,
+                inv_scale.data_ptr(), inv_scale._version)
+
+    def forward(self, sdf, pos, quat, inv_scale, threshold: float, out: Optional[torch.Tensor] = None,
+                prepare_backward: bool = False) -> torch.Tensor:
         """Render into the plan's depth buffer, or into ``out`` (B,H,W float32 contiguous on the plan's
-        device) when the caller keeps the images (the plan's buffer is overwritten by the next call)."""
+        device) when the caller keeps the images (the plan's buffer is overwritten by the next call).
+
+        ``prepare_backward``: this forward and the next ``backward`` of the same tensors form one step
+        (``sdfr_render_step_forward`` / ``sdfr_render_step_backward``, include/sdfr.h): the forward's
+        prologue also zero-fills the gradient volume and the backward starts from the forward's view
+        records -- one launch less, fewer live tiles, same results.  ``self.g_sdf`` then alternates
+        between two volumes from step to step."""
         self._check(sdf, pos, quat, inv_scale)
         dst = self.depth if out is None else out
         if out is not None and (out.shape != self.depth.shape or out.dtype != torch.float32
                                 or not out.is_contiguous() or out.device != self.depth.device):
             raise RuntimeError("out must be a contiguous float32 tensor of shape (B, H, W) on the plan's device")
+        if prepare_backward:
+            nxt = self._g_sdf_pair[1] if self.g_sdf is self._g_sdf_pair[0] else self._g_sdf_pair[0]
+            rc = self._L.sdfr_render_step_forward(
+                sdf.data_ptr(), self.R, self.sdf_stride, pos.data_ptr(), quat.data_ptr(),
+                inv_scale.data_ptr(), self.B, self.W, self.H, self.cx, self.cy, self.fx, self.fy,
+                threshold, dst.data_ptr(), nxt.data_ptr(), self.sdf_stride, self.workspace.data_ptr(),
+                self.workspace.numel(), self.device.index, _stream(self.device))
+            _lib.check(rc, "sdfr_render_step_forward")
+            self._step = (self._key(sdf, pos, quat, inv_scale), dst, nxt)
+            return dst
+        self._step = None
         rc = self._L.sdfr_render_forward(
             sdf.data_ptr(), self.R, self.sdf_stride, pos.data_ptr(), quat.data_ptr(),
             inv_scale.data_ptr(), self.B, self.W, self.H, self.cx, self.cy, self.fx, self.fy,
@@ -388,8 +417,23 @@ class BatchRenderPlan:
 
     def backward(self, grad_depth, sdf, pos, quat, inv_scale, defer_pose: bool = False):
         """``defer_pose``: leave the pose gradients as tile partials in ``self.workspace`` for
-        ``sdfr_views_to_pose_grad_deferred`` (include/sdfr.h); g_pos / g_quat / g_inv_scale are then not written."""
+        ``sdfr_views_to_pose_grad_deferred`` (include/sdfr.h); g_pos / g_quat / g_inv_scale are then not written.
+
+        After ``forward(..., prepare_backward=True)`` on the same (unmodified) tensors this is the step's
+        backward; any other call in between, or different inputs, falls back to the stand-alone backward."""
         self._check(sdf, pos, quat, inv_scale, grad_depth=grad_depth)
+        step, self._step = self._step, None
+        if step is not None and not defer_pose and step[0] == self._key(sdf, pos, quat, inv_scale):
+            _, depth, g_sdf = step
+            rc = self._L.sdfr_render_step_backward(
+                grad_depth.data_ptr(), depth.data_ptr(), sdf.data_ptr(), self.R, self.sdf_stride,
+                self.B, self.W, self.H, self.cx, self.cy, self.fx, self.fy, self.sdf_grad_mode,
+                g_sdf.data_ptr(), self.sdf_stride, self.g_pos.data_ptr(), self.g_quat.data_ptr(),
+                self.g_inv_scale.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(),
+                self.device.index, _stream(self.device))
+            _lib.check(rc, "sdfr_render_step_backward")
+            self.g_sdf = g_sdf
+            return self.g_sdf, self.g_pos, self.g_quat, self.g_inv_scale
         rc = self._L.sdfr_render_backward(
             grad_depth.data_ptr(), self.depth.data_ptr(), sdf.data_ptr(), self.R, self.sdf_stride,
             pos.data_ptr(), quat.data_ptr(), inv_scale.data_ptr(), self.B, self.W, self.H,
@@ -403,6 +447,7 @@ class BatchRenderPlan:
 
     def forward_l1(self, sdf, pos, quat, inv_scale, threshold: float, target):
         """forward + masked depth-L1 against ``target`` (B,H,W): returns (depth, loss (B,))."""
+        self._step = None   # the workspace is about to be re-used
         self._check(sdf, pos, quat, inv_scale, target=target)
         rc = self._L.sdfr_render_forward_l1(
             sdf.data_ptr(), self.R, self.sdf_stride, pos.data_ptr(), quat.data_ptr(),
@@ -417,6 +462,7 @@ class BatchRenderPlan:
                     defer_pose: bool = False):
         """gradients of sum_b weight * loss_grad[b] * loss[b] (after ``forward_l1``); ``defer_pose`` as in
         ``backward``."""
+        self._step = None   # the workspace is about to be re-used
         self._check(sdf, pos, quat, inv_scale, target=target)
         if loss_grad is not None:
             _check_input(loss_grad, "loss_grad")
@@ -439,6 +485,7 @@ class BatchRenderPlan:
         """``backward_l1`` and the sampler's L1 backward (``sdfr_pc_l1_backward_accumulate``) in one launch
         (``sdfr_render_backward_l1_pc``): g_sdf holds both terms, the pose gradients stay deferred in
         ``self.workspace`` and ``pc_workspace`` for ``sdfr_views_to_pose_grad_deferred``."""
+        self._step = None   # the workspace is about to be re-used
         self._check(sdf, pos, quat, inv_scale, target=target)
         dev = self.device
         if not (scale.device == dev and scale.dtype is torch.float32 and scale.shape == self._shape_isc

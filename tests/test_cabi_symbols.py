@@ -61,13 +61,26 @@ def test_argument_errors_without_gpu(libpath):
     rc = L.sdfr_render_forward(None, 1, 0, None, None, None, 1, 8, 8, 4.0, 4.0, 4.0, 4.0, 0.01,
                                None, None, 0, 0, None)
     assert rc == -1 and b"R=1" in L.sdfr_last_error()
+    buf0 = (ctypes.c_float * 64)()
+    q0 = ctypes.cast(buf0, ctypes.c_void_p)   # a non-NULL pointer that is never dereferenced
     rc = L.sdfr_render_forward(None, 64, 0, None, None, None, 1, 8, 8, 4.0, 4.0, 4.0, 4.0, 0.01,
                                None, None, 0, 0, None)
     assert rc == -2
-    assert L.sdfr_render_forward_workspace_bytes(64, 3, 640, 480) == 3 * 256 + 64 ** 3 * 16 + 768  # views + face records + 3 x R plane minima
+    # views + face records + the prologue's sync region (128-byte header + 6 x R plane-minimum entries of 16 bytes)
+    assert L.sdfr_render_forward_workspace_bytes(64, 3, 640, 480) == 3 * 256 + 64 ** 3 * 16 + 128 + 6 * 64 * 16
+    # a step keeps views, sync region, face records and the backward's tile partials side by side
+    assert L.sdfr_render_step_workspace_bytes(64, 2, 640, 480) == (2 * 256 + 128 + 6 * 64 * 16 + 64 ** 3 * 16
+                                                                    + 2 * 20 * 60 * 32)
+    assert L.sdfr_render_step_forward(q0, 64, 0, q0, q0, q0, 2, 8, 8, 4.0, 4.0, 4.0, 4.0, 0.01, q0, None, 0,
+                                      q0, 1 << 30, 0, None) == -2 and b"g_sdf" in L.sdfr_last_error()
+    assert L.sdfr_render_step_forward(q0, 64, 0, q0, q0, q0, 2, 8, 8, 4.0, 4.0, 4.0, 4.0, 0.01, q0, q0, 5,
+                                      q0, 1 << 30, 0, None) == -1    # g_sdf_view_stride must be 0 or R^3
+    assert L.sdfr_render_step_forward(q0, 64, 0, q0, q0, q0, 2, 8, 8, 4.0, 4.0, 4.0, 4.0, 0.01, q0, q0, 0,
+                                      q0, 64, 0, None) == -3 and b"workspace" in L.sdfr_last_error()
+    assert L.sdfr_render_step_backward(q0, q0, q0, 64, 0, 2, 8, 8, 4.0, 4.0, 4.0, 4.0, 7, q0, 0, q0, q0, q0,
+                                       q0, 1 << 30, 0, None) == -1 and b"sdf_grad_mode" in L.sdfr_last_error()
     assert L.sdfr_render_backward_workspace_bytes(64, 2, 640, 480) == 2 * 256 + 2 * 20 * 60 * 32
     # the merged launches of the loop: the deferred gradient chain and the two backward passes side by side
-    import ctypes
     buf = (ctypes.c_float * 64)()
     q = ctypes.cast(buf, ctypes.c_void_p)   # a non-NULL pointer that is never dereferenced
     rc = L.sdfr_views_to_pose_grad_deferred(q, q, q, 65, None, 0, 0, None, None, 0, None, None, q, q, q, 0, None)

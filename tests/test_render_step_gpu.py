@@ -1,0 +1,153 @@
+"""GPU: a step (sdfr_render_step_forward + sdfr_render_step_backward, include/sdfr.h) against the two stand-alone
+calls it replaces -- which the other tests pin against the oracle and the goldens -- and against the oracle itself.
+
+The step's forward has a one-launch prologue (plane minima -> view set-up inside one launch, through tagged entries
+in the workspace) and zero-fills the gradient volume; its backward starts from the forward's view records."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device="cuda")
+
+
+def make(B, W, H, f, seed, per_view_sdf=False):
+    from sdfest_amd import BatchRenderPlan, Camera
+    cam = Camera(W, H, f, f, W / 2.0, H / 2.0, pixel_center=0.5)
+    pos, quat, isc = oracle.random_poses(B, seed=seed, width=W, height=H, f=f)
+    g = np.random.default_rng(seed + 100).uniform(-1, 1, (B, H, W)).astype(np.float32)
+    plans = [BatchRenderPlan(64, B, cam, per_view_sdf=per_view_sdf) for _ in range(2)]
+    return plans, (dev(pos), dev(quat), dev(isc)), dev(g), (pos, quat, isc)
+
+
+def run_step(plan, sdf, pose, g, thr=0.005):
+    d = plan.forward(sdf, *pose, thr, prepare_backward=True)
+    assert plan._step is not None
+    before = plan.g_sdf
+    out = plan.backward(g, sdf, *pose)
+    assert plan._step is None and plan.g_sdf is not before            # the step path ran (volumes alternate)
+    return d.clone(), [o.clone() for o in out]
+
+
+def run_separate(plan, sdf, pose, g, thr=0.005):
+    d = plan.forward(sdf, *pose, thr)
+    out = plan.backward(g, sdf, *pose)
+    return d.clone(), [o.clone() for o in out]
+
+
+def assert_same(step, ref, name=""):
+    (d, (gs, gp, gq, gi)), (d0, (gs0, gp0, gq0, gi0)) = step, ref
+    assert torch.equal(d, d0), name
+    assert (d0 > 0).sum().item() > 100, name
+    # pose gradients: fixed-order sums of the same per-tile partials, but the order follows the view's rectangle
+    # (the step's is the tighter may-hit rectangle): equal up to the rounding of a sum of a few hundred terms
+    for a, b in ((gp, gp0), (gq, gq0), (gi, gi0)):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 2e-5, name
+    assert rel_err(gs.cpu().numpy(), gs0.cpu().numpy()) <= 1e-5, name      # float-atomic order only
+
+
+@pytest.mark.parametrize("B,W,H,f", [(256, 200, 136, 300.0),     # batch tiles, packed records, one-launch prologue
+                                     (8, 640, 480, 320.0),       # small tiles, packed records
+                                     (5, 320, 240, 160.0),       # a last set-up block with one view
+                                     (2, 160, 120, 80.0)])       # plain grid (no records, no plane minima)
+def test_step_equals_the_two_standalone_calls(B, W, H, f):
+    (p_step, p_ref), pose, g, _ = make(B, W, H, f, seed=11)
+    grids = [dev(oracle.blobs_sdf(0)), dev(oracle.blobs_sdf(1)), dev(oracle.blobs_sdf(0) + 0.08)]
+    # several steps on ONE workspace with a different grid each time: the plane minima a step's set-up reads must
+    # be the ones its own launch published (epoch), never an earlier step's
+    for k in range(6):
+        sdf = grids[k % 3]
+        assert_same(run_step(p_step, sdf, pose, g), run_separate(p_ref, sdf, pose, g), f"step {k}")
+
+
+def test_step_on_a_workspace_full_of_other_bytes():
+    """The sync region of the workspace is never initialised by the caller: whatever it holds -- zeros, ones, random
+    bytes, another call's partial sums -- cannot read as this launch's plane minima."""
+    (p_step, p_ref), pose, g, _ = make(16, 320, 240, 160.0, seed=12)
+    sdf = dev(oracle.blobs_sdf(0))
+    ref = run_separate(p_ref, sdf, pose, g)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    for fill in ("zeros", "ones", "random", "standalone"):
+        if fill == "zeros":
+            p_step.workspace.zero_()
+        elif fill == "ones":
+            p_step.workspace.fill_(255)
+        elif fill == "random":
+            p_step.workspace.copy_(torch.randint(0, 256, p_step.workspace.shape, dtype=torch.uint8, device="cuda",
+                                                 generator=gen))
+        else:
+            run_separate(p_step, sdf, pose, g)      # the stand-alone layouts overlap the step's sync region
+        assert_same(run_step(p_step, sdf, pose, g), ref, fill)
+
+
+def test_step_with_one_grid_per_view():
+    (p_step, p_ref), pose, g, _ = make(6, 160, 120, 80.0, seed=13, per_view_sdf=True)
+    sdf = dev(np.stack([oracle.blobs_sdf(k % 3) for k in range(6)]))
+    step, ref = run_step(p_step, sdf, pose, g), run_separate(p_ref, sdf, pose, g)
+    assert step[1][0].shape == (6, 64, 64, 64)
+    assert_same(step, ref)
+
+
+def test_step_replayed_from_a_graph_sees_each_replays_grid():
+    """A captured step is replayed with the SAME kernel arguments: the epoch that separates one launch's plane
+    minima from the next lives in the workspace and advances on the device."""
+    (p_step, p_ref), pose, g, _ = make(32, 200, 136, 150.0, seed=14)
+    grids = [oracle.blobs_sdf(0), oracle.blobs_sdf(1), oracle.blobs_sdf(0) + 0.1]
+    sdf = dev(grids[0])
+    run_step(p_step, sdf, pose, g)          # warm-up outside the capture
+    run_step(p_step, sdf, pose, g)          # (two: the captured step then uses the first volume again)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            d = p_step.forward(sdf, *pose, 0.005, prepare_backward=True)
+            gs, gp, gq, gi = p_step.backward(g, sdf, *pose)
+    version = sdf._version
+    for k in range(5):
+        sdf.copy_(dev(grids[k % 3]))        # same storage, new values: the graph reads what is there now
+        graph.replay()
+        torch.cuda.synchronize()
+        ref = run_separate(p_ref, sdf, pose, g)
+        assert_same((d, (gs, gp, gq, gi)), ref, f"replay {k}")
+    assert sdf._version > version
+
+
+def test_backward_after_changed_inputs_is_the_standalone_call():
+    (p_step, p_ref), pose, g, _ = make(8, 160, 120, 80.0, seed=15)
+    sdf = dev(oracle.blobs_sdf(0))
+    p_step.forward(sdf, *pose, 0.005, prepare_backward=True)
+    pose[0].add_(0.0)                       # an in-place write: not the tensors the forward prepared any more
+    before = p_step.g_sdf
+    out = p_step.backward(g, sdf, *pose)
+    assert p_step.g_sdf is before           # stand-alone path: the volume did not alternate
+    ref = run_separate(p_ref, sdf, pose, g)
+    assert rel_err(out[1].cpu().numpy(), ref[1][1].cpu().numpy()) <= 2e-5 and rel_err(out[0].cpu().numpy(), ref[1][0].cpu().numpy()) <= 1e-5
+
+
+def test_step_at_the_bench_configuration_against_the_oracle():
+    """C3 as bench.py runs it (step path): depth hit count, d/dSDF and the pose gradients of a sample of views
+    against the oracle."""
+    import os
+    (p_step, _), pose, g, (pos, quat, isc) = make(256, 640, 480, 320.0, seed=1)
+    sdf_np = oracle.blobs_sdf(0)
+    d, (gs, gp, gq, gi) = run_step(p_step, dev(sdf_np), pose, g)
+    assert int((d > 0).sum().item()) in range(4207800, 4207900)
+    oracle.set_threads(min(64, os.cpu_count() or 1))
+    dn, gn = d.cpu().numpy(), g.cpu().numpy()
+    ob = oracle.render_backward(gn, dn, sdf_np, pos, quat, isc, 320.0, 240.0, 320.0, 320.0, dtype=np.float32)
+    assert rel_err(gs.cpu().numpy(), ob[0]) <= 1e-4
+    pose_hip = np.concatenate([gp.cpu().numpy(), gq.cpu().numpy(), gi.cpu().numpy()[:, None]], axis=1)
+    ref = np.concatenate([ob[1], ob[2], ob[3][:, None]], axis=1)
+    sl = slice(0, 32)
+    dimg = oracle.render_derivative_images(dn[sl], sdf_np, pos[sl], quat[sl], isc[sl], 320.0, 240.0, 320.0, 320.0,
+                                           dtype=np.float32)
+    l1 = np.abs(dimg * gn[sl][..., None]).sum(axis=(1, 2), dtype=np.float64)
+    assert np.all(np.abs(pose_hip[sl] - ref[sl]) <= 1e-4 * l1)

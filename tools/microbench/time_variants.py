@@ -42,6 +42,7 @@ def main():
     for path in sys.argv[1:]:
         L = load(path)
         nb = max(L.sdfr_render_forward_workspace_bytes(64, B, W, H), L.sdfr_render_backward_workspace_bytes(64, B, W, H))
+        if hasattr(L, "sdfr_render_step_workspace_bytes"): nb = max(nb, L.sdfr_render_step_workspace_bytes(64, B, W, H))
         libs.append((path, L, torch.empty(nb + 256, dtype=torch.uint8, device=dev)))
     st = torch.cuda.current_stream().cuda_stream
     def fwd(L, ws):
@@ -53,11 +54,29 @@ def main():
                                isc.data_ptr(), B, W, H, cxx, cyy, f, f, 0, gs.data_ptr(), 0, gp.data_ptr(),
                                gq.data_ptr(), gi.data_ptr(), ws.data_ptr(), ws.numel(), 0, st)
         assert rc == 0, L.sdfr_last_error()
+    gs2 = torch.empty_like(gs)
+    def sfwd(L, ws):
+        rc = L.sdfr_render_step_forward(sdf.data_ptr(), 64, 0, pos.data_ptr(), quat.data_ptr(), isc.data_ptr(), B, W, H,
+                                        cxx, cyy, f, f, thr, depth.data_ptr(), gs2.data_ptr(), 0, ws.data_ptr(), ws.numel(), 0, st)
+        assert rc == 0, L.sdfr_last_error()
+    def sbwd(L, ws):
+        rc = L.sdfr_render_step_backward(g.data_ptr(), depth.data_ptr(), sdf.data_ptr(), 64, 0, B, W, H, cxx, cyy, f, f, 0,
+                                         gs2.data_ptr(), 0, gp.data_ptr(), gq.data_ptr(), gi.data_ptr(), ws.data_ptr(),
+                                         ws.numel(), 0, st)
+        assert rc == 0, L.sdfr_last_error()
+    def pair(L, ws): fwd(L, ws); bwd(L, ws)
+    def step(L, ws): sfwd(L, ws); sbwd(L, ws)
     rounds = int(os.environ.get("ROUNDS", 7))
-    res = {path: {"fwd": [], "bwd": []} for path, _, _ in libs}
+    res = {path: {"fwd": [], "bwd": [], "pair": [], "step": [], "sfwd": []} for path, _, _ in libs}
+    with_step = os.environ.get("STEP", "1") == "1"
     for r in range(rounds + 1):
         for path, L, ws in libs:
-            for name, fn in (("fwd", fwd), ("bwd", bwd)):
+            fns = [("fwd", fwd), ("bwd", bwd)]
+            if with_step:
+                fns.append(("pair", pair))
+                if hasattr(L, "sdfr_render_step_forward"):
+                    fns += [("sfwd", sfwd), ("step", step)]
+            for name, fn in fns:
                 fn(L, ws); torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 n = 10
@@ -70,5 +89,7 @@ def main():
         f = float(np.median(res[path]["fwd"])); b = float(np.median(res[path]["bwd"]))
         print(f"{os.path.basename(path):40s} B={B} fwd {f:8.1f} us  bwd {b:8.1f} us  hits={hits} "
               f"-> {B/((f+b)*1e-6):,.0f} renders/s  (median of {rounds} interleaved rounds; "
-              f"fwd min {min(res[path]['fwd']):.1f} bwd min {min(res[path]['bwd']):.1f})", flush=True)
+              f"fwd min {min(res[path]['fwd']):.1f} bwd min {min(res[path]['bwd']):.1f})"
+              + "".join(f"  {k} {float(np.median(v)):.1f} us" for k, v in res[path].items() if v and k not in ("fwd", "bwd")),
+              flush=True)
 main()
