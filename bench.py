@@ -210,6 +210,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(events[k])
+    t_enqueued = time.perf_counter() - t0      # host time to issue the K steps (GPU-bound if below `elapsed`)
     barrier()
     events = [e for e in events if e is not None]
     elapsed = time.perf_counter() - t0
@@ -267,6 +268,7 @@ def main():
             "kernel_ms": {"forward_call": round(fwd_ms, 4), "backward_call": round(bwd_ms, 4)},
             "step_ms_events": {"min": round(float(step_ms.min()), 4), "median": round(float(np.median(step_ms)), 4),
                                "max": round(float(step_ms.max()), 4), "n": int(step_ms.size)},
+            "host_issue_ms_per_step": round(t_enqueued / args.steps * 1e3, 4),
         }
         if N == 1 and not args.no_cpu_baseline:
             sample = args.cpu_sample or min(B, 256)

@@ -1125,6 +1125,12 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
                        (float4*)cells, 3 * R, n_setup, lay.sync, pos, quat, inv_scale, B, W, H, cx, cy, fx, fy,
                        setup, threshold, g_zero, n_zero);
     epoch = lay.sync;
+  } else if (g_zero && !packed) {
+    // a step over a few views (or with one grid per view): zero fill + set-up in ONE launch -- the stand-alone
+    // backward's prologue, run early.  Without plane minima the record does not depend on the threshold, and the
+    // one-thread and one-wave forms of the set-up give the same record (min / max of the same 8 corners).
+    hipLaunchKernelGGL(backward_prologue_kernel, dim3((unsigned)((std::max(n_zero, (size_t)B) + 255) / 256)),
+                       dim3(256), 0, st, g_zero, n_zero, pos, quat, inv_scale, B, R, W, H, cx, cy, fx, fy, setup);
   } else {
     if (g_zero) zero_words_async(g_zero, n_zero, st);
     float* plane_min = nullptr;

@@ -142,6 +142,65 @@ def backward_raw(grad_depth, depth, sdf, position, orientation, inv_scale, width
     return g_sdf, g_pos, g_quat, g_isc
 
 
+def step_forward_raw(sdf, position, orientation, inv_scale, width, height, cx, cy, fx, fy, threshold):
+    """``forward_raw`` as the first half of a step (``sdfr_render_step_forward``, include/sdfr.h): the same
+    depth images, and the prologue launch also zero-fills the gradient volume and leaves the view records
+    for ``step_backward_raw``.  The step owns its workspace (the shared scratch buffer may be re-used by
+    other renders before this one's backward runs).  Returns (depth, state)."""
+    for t, n in ((sdf, "sdf"), (position, "position"), (orientation, "orientation"),
+                 (inv_scale, "inv_scale")):
+        _check_input(t, n)
+    B = position.shape[0]
+    if position.shape != (B, 3) or orientation.shape != (B, 4) or inv_scale.shape != (B,):
+        raise RuntimeError("expected position (B,3), orientation (B,4), inv_scale (B,)")
+    R = sdf.shape[-1]
+    if sdf.dim() == 3:
+        stride = 0
+    elif sdf.dim() == 4 and sdf.shape[0] == B:
+        stride = R * R * R
+    else:
+        raise RuntimeError("sdf must be (R,R,R) or (B,R,R,R)")
+    if tuple(sdf.shape[-3:]) != (R, R, R):
+        raise RuntimeError("sdf must be cubic")
+    dev = sdf.device
+    depth = torch.empty((B, height, width), dtype=torch.float32, device=dev)
+    g_sdf = torch.empty_like(sdf)
+    L = _lib.lib()
+    ws = torch.empty(max(L.sdfr_render_step_workspace_bytes(R, B, width, height), 256), dtype=torch.uint8,
+                     device=dev)
+    rc = L.sdfr_render_step_forward(_ptr(sdf), R, stride, _ptr(position), _ptr(orientation), _ptr(inv_scale),
+                                    B, width, height, cx, cy, fx, fy, threshold, _ptr(depth), _ptr(g_sdf),
+                                    stride, _ptr(ws), ws.numel(), dev.index, _stream(dev))
+    _lib.check(rc, "sdfr_render_step_forward")
+    return depth, (ws, g_sdf, _stream(dev))
+
+
+def step_backward_raw(state, grad_depth, depth, sdf, position, orientation, inv_scale, width, height, cx, cy,
+                      fx, fy, sdf_grad_mode=0):
+    """Second half of the step begun by ``step_forward_raw`` (same return value as ``backward_raw``).  A state
+    that has been used already (a second backward through a retained graph), or a backward on another stream,
+    takes the stand-alone call."""
+    dev = sdf.device
+    if state is None or state[2] != _stream(dev):
+        return backward_raw(grad_depth, depth, sdf, position, orientation, inv_scale, width, height, cx, cy,
+                            fx, fy, sdf_grad_mode)
+    for t, n in ((grad_depth, "grad_depth_image"), (depth, "depth_image"), (sdf, "sdf")):
+        _check_input(t, n)
+    ws, g_sdf, _ = state
+    B = position.shape[0]
+    R = sdf.shape[-1]
+    stride = R * R * R if sdf.dim() == 4 else 0
+    g_pos = torch.empty_like(position)
+    g_quat = torch.empty_like(orientation)
+    g_isc = torch.empty_like(inv_scale)
+    L = _lib.lib()
+    rc = L.sdfr_render_step_backward(_ptr(grad_depth), _ptr(depth), _ptr(sdf), R, stride, B, width, height,
+                                     cx, cy, fx, fy, sdf_grad_mode, _ptr(g_sdf), stride, _ptr(g_pos),
+                                     _ptr(g_quat), _ptr(g_isc), _ptr(ws), ws.numel(), dev.index, _stream(dev))
+    _lib.check(rc, "sdfr_render_step_backward")
+    return g_sdf, g_pos, g_quat, g_isc
+
+
 class _RenderBatch(torch.autograd.Function):
     """Batched renderer: B poses of one SDF (or of B SDFs) in one launch."""
 
@@ -152,8 +211,15 @@ class _RenderBatch(torch.autograd.Function):
         pos = position.detach().contiguous()
         quat = orientation.detach().contiguous()
         isc = inv_scale.detach().contiguous()
-        image = forward_raw(sdf_c, pos, quat, isc, camera.width, camera.height, cx, cy, fx, fy,
-                            threshold)
+        # forward + backward of the same views = one step (one launch less per call, tighter culling in the
+        # backward); without a gradient to compute, the plain forward
+        ctx.step = None
+        if any(ctx.needs_input_grad[:4]):
+            image, ctx.step = step_forward_raw(sdf_c, pos, quat, isc, camera.width, camera.height, cx, cy, fx,
+                                               fy, threshold)
+        else:
+            image = forward_raw(sdf_c, pos, quat, isc, camera.width, camera.height, cx, cy, fx, fy,
+                                threshold)
         ctx.save_for_backward(image, sdf_c, pos, quat, isc)
         ctx.cam = (camera.width, camera.height, cx, cy, fx, fy)
         ctx.sdf_grad_mode = sdf_grad_mode
@@ -163,8 +229,9 @@ class _RenderBatch(torch.autograd.Function):
     def backward(ctx, grad_depth_image):
         image, sdf, pos, quat, isc = ctx.saved_tensors
         w, h, cx, cy, fx, fy = ctx.cam
-        g_sdf, g_p, g_q, g_is = backward_raw(grad_depth_image.contiguous(), image, sdf, pos, quat,
-                                             isc, w, h, cx, cy, fx, fy, ctx.sdf_grad_mode)
+        step, ctx.step = ctx.step, None
+        g_sdf, g_p, g_q, g_is = step_backward_raw(step, grad_depth_image.contiguous(), image, sdf, pos, quat,
+                                                  isc, w, h, cx, cy, fx, fy, ctx.sdf_grad_mode)
         return g_sdf, g_p, g_q, g_is, None, None, None
 
 
@@ -179,9 +246,15 @@ class SDFRendererFunctionGPU(torch.autograd.Function):
                      (inv_scale, "inv_scale")):
             _check_input(t, n)
         fx, fy, cx, cy, _ = camera.get_pinhole_camera_parameters(0.5)
-        image = forward_raw(sdf, position.reshape(1, 3), orientation.reshape(1, 4),
-                            inv_scale.reshape(1), camera.width, camera.height, cx, cy, fx, fy,
-                            threshold)[0]
+        # the pair forward / backward of one view is one step (sdfr_render_step_*: 4 launches instead of 5)
+        ctx.step = None
+        args = (sdf, position.reshape(1, 3), orientation.reshape(1, 4), inv_scale.reshape(1), camera.width,
+                camera.height, cx, cy, fx, fy, threshold)
+        if any(ctx.needs_input_grad[:4]):
+            image, ctx.step = step_forward_raw(*args)
+            image = image[0]
+        else:
+            image = forward_raw(*args)[0]
         ctx.save_for_backward(image, sdf, position, orientation, inv_scale)
         ctx.cam = (camera.width, camera.height, cx, cy, fx, fy)
         return image
@@ -190,8 +263,9 @@ class SDFRendererFunctionGPU(torch.autograd.Function):
     def backward(ctx, grad_depth_image: torch.Tensor):
         image, sdf, position, orientation, inv_scale = ctx.saved_tensors
         w, h, cx, cy, fx, fy = ctx.cam
-        g_sdf, g_p, g_q, g_is = backward_raw(
-            grad_depth_image.contiguous().reshape(1, h, w), image.reshape(1, h, w), sdf,
+        step, ctx.step = ctx.step, None
+        g_sdf, g_p, g_q, g_is = step_backward_raw(
+            step, grad_depth_image.contiguous().reshape(1, h, w), image.reshape(1, h, w), sdf,
             position.reshape(1, 3), orientation.reshape(1, 4), inv_scale.reshape(1), w, h, cx, cy,
             fx, fy, render_depth_gpu.sdf_grad_mode)
         # gradients come back in the shape of the inputs ((4,) or (1,4); () or (1,))

@@ -55,7 +55,8 @@ def assert_same(step, ref, name=""):
 @pytest.mark.parametrize("B,W,H,f", [(256, 200, 136, 300.0),     # batch tiles, packed records, one-launch prologue
                                      (8, 640, 480, 320.0),       # small tiles, packed records
                                      (5, 320, 240, 160.0),       # a last set-up block with one view
-                                     (2, 160, 120, 80.0)])       # plain grid (no records, no plane minima)
+                                     (2, 160, 120, 80.0),        # plain grid (no records, no plane minima):
+                                     (1, 640, 480, 320.0)])      # ... zero fill + set-up are ONE prologue launch
 def test_step_equals_the_two_standalone_calls(B, W, H, f):
     (p_step, p_ref), pose, g, _ = make(B, W, H, f, seed=11)
     grids = [dev(oracle.blobs_sdf(0)), dev(oracle.blobs_sdf(1)), dev(oracle.blobs_sdf(0) + 0.08)]
@@ -151,3 +152,52 @@ def test_step_at_the_bench_configuration_against_the_oracle():
                                            dtype=np.float32)
     l1 = np.abs(dimg * gn[sl][..., None]).sum(axis=(1, 2), dtype=np.float64)
     assert np.all(np.abs(pose_hip[sl] - ref[sl]) <= 1e-4 * l1)
+
+
+def test_autograd_functions_run_the_step_and_survive_a_second_backward():
+    """render_depth_gpu / render_depth_batch take the step path when a gradient is wanted (the step owns its
+    workspace, so other renders may run between its two halves); a second backward through a retained graph
+    takes the stand-alone call and gives the same gradients; without requires_grad the plain forward runs."""
+    from sdfest_amd import Camera, render_depth_gpu, render_depth_batch
+    from sdfest_amd import differentiable_renderer as dr
+    W, H, f = 160, 120, 80.0
+    cam = Camera(W, H, f, f, W / 2.0, H / 2.0, pixel_center=0.5)
+    pos, quat, isc = oracle.random_poses(3, seed=21, width=W, height=H, f=f)
+    sdf_np = oracle.blobs_sdf(0)
+    g = dev(np.random.default_rng(3).uniform(-1, 1, (H, W)))
+    calls = {"step": 0, "plain": 0}
+    orig_step, orig_bwd = dr.step_backward_raw, dr.backward_raw
+
+    def count_step(state, *a, **k):
+        calls["step" if state is not None else "plain"] += 1
+        return orig_step(state, *a, **k)
+    dr.step_backward_raw = count_step
+    try:
+        leaves = [dev(sdf_np).requires_grad_(), dev(pos[0]).requires_grad_(), dev(quat[0]).requires_grad_(),
+                  dev(isc[0]).requires_grad_()]
+        d = render_depth_gpu(*leaves, None, None, None, 0.005, cam)
+        other = render_depth_gpu(dev(sdf_np), dev(pos[1]), dev(quat[1]), dev(isc[1]), None, None, None, 0.005, cam)
+        assert not other.requires_grad
+        first = torch.autograd.grad((d * g).sum(), leaves, retain_graph=True)
+        second = torch.autograd.grad((d * g).sum(), leaves)
+        assert calls == {"step": 1, "plain": 1}
+        ref = dr.backward_raw(g[None].contiguous(), d.detach()[None].contiguous(), dev(sdf_np), dev(pos[:1]),
+                              dev(quat[:1]), dev(isc[:1]), W, H, W / 2.0, H / 2.0, f, f)
+        for a, b, c in zip(first, second, ref):
+            assert rel_err(a.cpu().numpy().ravel(), c.cpu().numpy().ravel()) <= 2e-5
+            assert rel_err(b.cpu().numpy().ravel(), c.cpu().numpy().ravel()) <= 2e-5
+        # batched function: two graphs alive at once, backward in the opposite order
+        bl = [dev(sdf_np).requires_grad_(), dev(pos).requires_grad_(), dev(quat).requires_grad_(),
+              dev(isc).requires_grad_()]
+        d1 = render_depth_batch(*bl, 0.005, cam)
+        d2 = render_depth_batch(bl[0], bl[1] * 1.01, bl[2], bl[3], 0.005, cam)
+        gb = dev(np.random.default_rng(4).uniform(-1, 1, (3, H, W)))
+        g2 = torch.autograd.grad((d2 * gb).sum(), bl)
+        g1 = torch.autograd.grad((d1 * gb).sum(), bl)
+        r1 = dr.backward_raw(gb, d1.detach(), dev(sdf_np), dev(pos), dev(quat), dev(isc), W, H, W / 2.0, H / 2.0, f, f)
+        for a, c in zip(g1, r1):
+            assert rel_err(a.cpu().numpy().ravel(), c.cpu().numpy().ravel()) <= 2e-5
+        assert all(torch.isfinite(t).all() for t in g2)
+        assert calls["step"] == 3
+    finally:
+        dr.step_backward_raw = orig_step

@@ -34,9 +34,23 @@ def main():
         g = torch.tensor(g_np, device=dev)
         plan = BatchRenderPlan(64, 1, cam, device=dev)
 
-        def step():
+        def pair():   # two stand-alone calls
             plan.forward(sdf, pos, quat, isc, 0.005)
             plan.backward(g, sdf, pos, quat, isc)
+
+        def step():   # the step API (sdfr_render_step_forward / _backward): one launch less per call
+            plan.forward(sdf, pos, quat, isc, 0.005, prepare_backward=True)
+            plan.backward(g, sdf, pos, quat, isc)
+        for _ in range(20):
+            pair()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(300):
+            pair()
+        e1.record()
+        torch.cuda.synchronize()
+        pair_us = e0.elapsed_time(e1) / 300 * 1e3
         for _ in range(20):
             step()
         torch.cuda.synchronize()
@@ -75,6 +89,7 @@ def main():
         gs = plan.g_sdf.cpu().numpy()
         both = (d[0] > 0) & (do[0] > 0)
         res = {"hip_us_fwd_bwd": round(hip_us, 2), "hip_graph_us_fwd_bwd": round(graph_us, 2),
+               "hip_us_fwd_bwd_standalone_calls": round(pair_us, 2),
                "hip_renders_per_s": round(1e6 / graph_us, 1), "hit_pixels": int((d > 0).sum()),
                "depth_max_rel_err": float(np.max(np.abs(d[0][both] / do[0][both] - 1))),
                "g_sdf_max_abs_err": float(np.max(np.abs(gs - ob[0]))),
