@@ -26,6 +26,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md: 8 TB/s; 6.29 TB/s measured copy)
+HBM_COPY_PEAK = 6.29e12
 
 
 def parse():
@@ -264,7 +265,9 @@ def main():
             "roofline_step": {"bytes_per_view": bytes_per_view,
                               "achieved": round(bytes_per_view * value / N / 1e9, 2),
                               "unit": "GB/s per GPU",
-                              "frac": round(bytes_per_view * value / N / HBM_PEAK, 5)},
+                              "frac": round(bytes_per_view * value / N / HBM_PEAK, 5),
+                              # also against the measured copy ceiling of the part (6.29 TB/s)
+                              "frac_of_measured_copy_peak": round(bytes_per_view * value / N / HBM_COPY_PEAK, 5)},
             "kernel_ms": {"forward_call": round(fwd_ms, 4), "backward_call": round(bwd_ms, 4)},
             "step_ms_events": {"min": round(float(step_ms.min()), 4), "median": round(float(np.median(step_ms)), 4),
                                "max": round(float(step_ms.max()), 4), "n": int(step_ms.size)},
