@@ -166,23 +166,31 @@ def main():
     W, H, B, thr = args.width, args.height, args.batch, 0.005
     sdf_np, poses_np, sdf, pos, quat, isc, g = synthetic_inputs(B * N, rank, B, W, H, device)
     cam = Camera(W, H, W / 2.0, W / 2.0, W / 2.0, H / 2.0, pixel_center=0.5)
-    plan = BatchRenderPlan(64, B, cam, device=device)
-
-    # The one exchange of a step -- the all-reduce of d/dSDF (RCCL) -- is issued asynchronously.  The plan
-    # alternates between two gradient volumes (a step's forward zero-fills the volume its backward will add
-    # into), so the exchange of step k only has to be complete before the forward of step k + 2 re-uses its
-    # volume: it runs beside the next step.  Same work per step, nothing skipped; the last steps' exchanges are
-    # waited for inside the timed region.
+    # The one exchange of a step -- the all-reduce of d/dSDF (RCCL) -- is issued asynchronously.  The plan cycles
+    # through M gradient volumes (a step's forward zero-fills the volume its backward will add into), so the
+    # exchange of step k only has to be complete before the forward of step k + M re-uses its volume: it runs
+    # beside the following steps.  Every cross-stream dependency is a queue packet of ~10 us on this platform
+    # (DESIGN section 8), so the compute stream does not wait once per step: when M exchanges are outstanding it
+    # waits for the (M/2)-th oldest -- the collectives complete in issue order on their stream -- i.e. once per M/2
+    # steps.  Same work per step, nothing skipped; the last steps' exchanges are waited for inside the timed region.
+    M = max(2, int(os.environ.get("SDFR_BENCH_GRAD_VOLUMES", "8" if use_dist else "2")))
+    plan = BatchRenderPlan(64, B, cam, device=device, grad_volumes=M)
     pending = []
 
-    def finish_exchange(keep=0):
-        while len(pending) > keep:
-            pending.pop(0).wait()
+    def finish_exchange(all_of_them=False):
+        if all_of_them:
+            if pending:
+                pending[-1].wait()
+                pending.clear()
+        elif len(pending) >= M:          # the volume of the oldest exchange is the one the next forward zero-fills
+            n = M // 2
+            pending[n - 1].wait()
+            del pending[:n]
 
     def step(ev=None):
         if ev:
             ev[0].record()
-        finish_exchange(keep=1)
+        finish_exchange()
         # forward + backward of the same views = one step (sdfr_render_step_forward / _backward)
         plan.forward(sdf, pos, quat, isc, thr, prepare_backward=True)
         if ev:
@@ -194,7 +202,7 @@ def main():
             pending.append(allreduce_shared_gradients(plan.g_sdf, async_op=True))
 
     def barrier():
-        finish_exchange()
+        finish_exchange(all_of_them=True)
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()

@@ -389,7 +389,9 @@ class BatchRenderPlan:
     """
 
     def __init__(self, R: int, B: int, camera: Camera, device="cuda", per_view_sdf: bool = False,
-                 sdf_grad_mode: int = 0):
+                 sdf_grad_mode: int = 0, grad_volumes: int = 2):
+        if grad_volumes < 2:
+            raise ValueError("grad_volumes must be >= 2")
         self.device = torch.device(device)
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
@@ -409,9 +411,10 @@ class BatchRenderPlan:
                      L.sdfr_render_backward_workspace_bytes(R, B, self.W, self.H),
                      L.sdfr_render_step_workspace_bytes(R, B, self.W, self.H), 256)
         # a step (forward(..., prepare_backward=True) + backward) zero-fills the NEXT gradient volume in the
-        # forward's prologue: two volumes alternate, so the previous step's g_sdf (e.g. still being all-reduced)
-        # is not touched by the next forward
-        self._g_sdf_pair = [self.g_sdf, torch.empty_like(self.g_sdf)]
+        # forward's prologue: `grad_volumes` volumes take turns, so the g_sdf of the previous grad_volumes - 1
+        # steps (e.g. still being all-reduced) are not touched by the next forward
+        self._g_sdf_ring = [self.g_sdf] + [torch.empty_like(self.g_sdf) for _ in range(grad_volumes - 1)]
+        self._g_sdf_next = 1
         self._step = None   # what the last forward prepared: (tensor ids / versions, depth tensor)
         self.loss = torch.empty((B,), **f32)
         self.loss_stats = torch.empty((B, 2), **f32)
@@ -463,15 +466,15 @@ class BatchRenderPlan:
         ``prepare_backward``: this forward and the next ``backward`` of the same tensors form one step
         (``sdfr_render_step_forward`` / ``sdfr_render_step_backward``, include/sdfr.h): the forward's
         prologue also zero-fills the gradient volume and the backward starts from the forward's view
-        records -- one launch less, fewer live tiles, same results.  ``self.g_sdf`` then alternates
-        between two volumes from step to step."""
+        records -- one launch less, fewer live tiles, same results.  ``self.g_sdf`` then cycles
+        through the plan's ``grad_volumes`` volumes from step to step."""
         self._check(sdf, pos, quat, inv_scale)
         dst = self.depth if out is None else out
         if out is not None and (out.shape != self.depth.shape or out.dtype != torch.float32
                                 or not out.is_contiguous() or out.device != self.depth.device):
             raise RuntimeError("out must be a contiguous float32 tensor of shape (B, H, W) on the plan's device")
         if prepare_backward:
-            nxt = self._g_sdf_pair[1] if self.g_sdf is self._g_sdf_pair[0] else self._g_sdf_pair[0]
+            nxt = self._g_sdf_ring[self._g_sdf_next]
             rc = self._L.sdfr_render_step_forward(
                 sdf.data_ptr(), self.R, self.sdf_stride, pos.data_ptr(), quat.data_ptr(),
                 inv_scale.data_ptr(), self.B, self.W, self.H, self.cx, self.cy, self.fx, self.fy,
@@ -507,6 +510,7 @@ class BatchRenderPlan:
                 self.device.index, _stream(self.device))
             _lib.check(rc, "sdfr_render_step_backward")
             self.g_sdf = g_sdf
+            self._g_sdf_next = (self._g_sdf_next + 1) % len(self._g_sdf_ring)
             return self.g_sdf, self.g_pos, self.g_quat, self.g_inv_scale
         rc = self._L.sdfr_render_backward(
             grad_depth.data_ptr(), self.depth.data_ptr(), sdf.data_ptr(), self.R, self.sdf_stride,
