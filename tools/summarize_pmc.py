@@ -14,7 +14,8 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("render_forward_kernel", "render_backward_kernel", "view_setup_kernel",
+    for k in ("render_forward_kernel", "render_backward_kernel", "forward_prologue_kernel",
+              "backward_prologue_kernel", "pack_cells_kernel", "view_setup_kernel",
               "pose_reduce_kernel", "pc_loss", "sampler", "decoder", "fillBuffer"):
         if k in name:
             return k + ("<64>" if "<64>" in name else "")
