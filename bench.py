@@ -148,6 +148,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False); "
                          "the product has no CPU path")
+    # rehearsal on a box with fewer GPUs than ranks (never a measurement): SDFR_BENCH_SHARE_GPU=1 puts every rank on
+    # GPU 0 and SDFR_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device)
+    if os.environ.get("SDFR_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("SDFR_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -158,7 +163,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=N, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=N, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=N)
 
     from sdfest_amd import BatchRenderPlan, Camera
     from sdfest_amd.parallel import allreduce_shared_gradients
@@ -260,7 +268,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"C3: {B} seeded random poses per GPU of the blobs(0) 64^3 SDF, "
                                    f"{W}x{H}, threshold 0.005, forward+backward"
-                                   + (", RCCL all-reduce of dSDF" if N > 1 else ""),
+                                   + (", RCCL all-reduce of dSDF" if N > 1 and backend == "nccl" else "")
+                                   + (f", REHEARSAL: {backend} backend" if backend != "nccl" else "")
+                                   + (", REHEARSAL: all ranks on GPU 0" if os.environ.get("SDFR_BENCH_SHARE_GPU") == "1" else ""),
                        "views_per_gpu": B, "width": W, "height": H, "sdf_resolution": 64,
                        "parallelism": f"views sharded over {N} GPU(s)",
                        "hit_pixels_rank0": hits},
