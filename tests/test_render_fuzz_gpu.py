@@ -1,0 +1,147 @@
+"""GPU: seeded random configurations of the renderer -- image sizes that are no multiple of any tile, odd grid
+resolutions, off-centre intrinsics, thresholds, objects from far away to filling the screen, single views to batch
+launches, one grid per view -- each run four ways: stand-alone forward and backward against the oracle
+(oracle/: CPU restatement pinned by goldens captured from the reference), and the step API
+(sdfr_render_step_forward / _backward) against the stand-alone calls.
+
+The fixed cases of test_render_gpu.py / test_render_step_gpu.py pin the paths one by one; this file walks the
+combinations (which tile geometry, packed records or plain grid, one-launch or two-launch prologue, big or small
+backward tiles, culling rectangles that touch the image border ...) that a caller's sizes select implicitly."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import test_render_gpu as T
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+
+
+def draw(seed):
+    rng = np.random.default_rng(1000 + seed)
+    R = int(rng.choice([8, 17, 32, 33, 64, 64, 64]))
+    B = int(rng.choice([1, 2, 3, 5, 9, 33, 70]))
+    W, H = int(rng.integers(17, 260)), int(rng.integers(9, 200))
+    if seed % 5 == 4:                      # batch launches: >= 16384 tiles of 64 x 8 pixels in the call
+        W, H = int(rng.integers(150, 230)), int(rng.integers(100, 150))
+        B = int(np.ceil(16384 / (((W + 63) // 64) * ((H + 7) // 8)))) + int(rng.integers(0, 40))
+    f = W * rng.uniform(0.45, 1.4)
+    fx, fy = f, f * rng.uniform(0.8, 1.25)
+    cx, cy = W / 2 + rng.uniform(-0.2, 0.2) * W, H / 2 + rng.uniform(-0.2, 0.2) * H
+    thr = float(rng.choice([0.001, 0.005, 0.02]))
+    pos, quat, isc = oracle.random_poses(B, seed=seed, width=W, height=H, f=f)
+    pos = (pos * rng.uniform(0.45, 1.3, (B, 1))).astype(np.float32)       # nearer (down to inside the cube) / farther
+    isc = (isc * rng.uniform(0.6, 3.0, B)).astype(np.float32)             # larger / much smaller objects
+    if B >= 3:
+        pos[B // 2, 0] += 50.0                                             # one object off screen
+    per_view = bool(B <= 9 and rng.uniform() < 0.3)
+    if per_view:
+        sdf = np.stack([oracle.blobs_sdf(k % 3, R=R) for k in range(B)])
+    else:
+        sdf = oracle.blobs_sdf(int(rng.integers(0, 3)), R=R)
+    return dict(R=R, B=B, W=W, H=H, fx=float(fx), fy=float(fy), cx=float(cx), cy=float(cy), thr=thr, pos=pos,
+                quat=quat, isc=isc, sdf=sdf.astype(np.float32), per_view=per_view)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SDFR_FUZZ_SEEDS", "20"))))   # more for a one-off hunt
+def test_random_configuration(seed):
+    from sdfest_amd import BatchRenderPlan, Camera
+    import sdfest_amd.differentiable_renderer as Rm
+    c = draw(seed)
+    B, W, H, R = c["B"], c["W"], c["H"], c["R"]
+    cam = (W, H, c["cx"], c["cy"], c["fx"], c["fy"])
+    name = f"seed {seed}: B={B} {W}x{H} R={R} thr={c['thr']} per_view={c['per_view']}"
+    sdf_t, pos_t, quat_t, isc_t = (T.dev(c[k]) for k in ("sdf", "pos", "quat", "isc"))
+
+    # 1. forward against the oracle (per-view grids: the oracle takes one grid at a time)
+    d = Rm.forward_raw(sdf_t, pos_t, quat_t, isc_t, *cam, c["thr"]).cpu().numpy()
+    if c["per_view"]:
+        outs = [oracle.render_forward(c["sdf"][b], c["pos"][b:b + 1], c["quat"][b:b + 1], c["isc"][b:b + 1], *cam,
+                                      c["thr"], dtype=np.float32, with_aux=True) for b in range(B)]
+        d_ref = np.concatenate([o[0] for o in outs])
+        steps = np.concatenate([o[1] for o in outs])
+        margin = np.concatenate([o[2] for o in outs])
+    else:
+        d_ref, steps, margin = oracle.render_forward(c["sdf"], c["pos"], c["quat"], c["isc"], *cam, c["thr"],
+                                                     dtype=np.float32, with_aux=True)
+    # robust pixels (no branch of their march within ~1e-5 of flipping in the oracle): same hit mask, depth to 1e-4.
+    # The others are few, and a grazing ray that slips past a surface lands wherever the next one is (with coarse
+    # grids and close-ups that is far away), so their depth is not bounded (test_render_gpu.check_depth does
+    # bound it, for its scenes).
+    # (two fp32 marches drift apart by ~1e-7 t per step: after 187 steps -- a camera inside the cube, threshold
+    # 0.001 -- a decision with margin 1.01e-5 went the other way; the margin asked for grows with the march length)
+    robust = margin > 1e-5 * (1.0 + steps / 20.0)
+    mism = (d > 0) != (d_ref > 0)
+    assert not np.any(mism & robust), f"{name}: hit mask differs on {int((mism & robust).sum())} robust pixels"
+    both = (d > 0) & (d_ref > 0)
+    rel = np.abs(d / np.where(both, d_ref, 1.0) - 1) * both
+    assert rel[robust].max(initial=0.0) < REL, f"{name}: depth rel err {rel[robust].max()}"
+    n_off = int(mism.sum() + (both & ~robust & (rel >= REL)).sum())
+    assert n_off <= max(2, 1e-4 * d.size), f"{name}: {n_off} fragile pixels differ"
+
+    # 2. backward against the fp64 oracle, on the HIP depth image (so that both differentiate the same hit pixels).
+    # A pixel's pose derivative jumps where its hit point crosses a cell face (the trilinear interpolant is C0), and
+    # a hit point within fp32 rounding of a face (~1e-4 cells for small objects) falls on either side: such pixels
+    # are found by moving the grid by 3e-4 cells along each of its axes in the oracle, and their jump is allowed for.
+    g = np.random.default_rng(seed).uniform(-1, 1, d.shape).astype(np.float32)
+    hb = [o.cpu().numpy() for o in Rm.backward_raw(T.dev(g), T.dev(d), sdf_t, pos_t, quat_t, isc_t, *cam)]
+    x, y, z, w = (c["quat"][:, k].astype(np.float64) for k in range(4))
+    rot = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], -1),
+                    np.stack([2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)], -1),
+                    np.stack([2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1)], 1)  # cu:112-121
+    delta = 3e-4 * (1.0 / c["isc"].astype(np.float64)) / (0.5 * (R - 1))
+
+    def oracle_backward(b0, b1, grid):
+        sl = slice(b0, b1)
+        pose64 = (c["pos"][sl].astype(np.float64), c["quat"][sl], c["isc"][sl])
+        ob = oracle.render_backward(g[sl], d[sl], grid, *pose64, *cam[2:], dtype=np.float64)
+        di = oracle.render_derivative_images(d[sl], grid, *pose64, *cam[2:], dtype=np.float64)
+        jump = np.zeros_like(di)
+        for axis in range(3):
+            for sign in (-1.0, 1.0):
+                moved = pose64[0] + sign * delta[sl, None] * rot[sl, :, axis]
+                dm = oracle.render_derivative_images(d[sl], grid, moved, *pose64[1:], *cam[2:], dtype=np.float64)
+                jump = np.maximum(jump, np.abs(dm - di))
+        typical = np.abs(di).sum(axis=(1, 2), keepdims=True) / np.maximum((d[sl] > 0).sum(axis=(1, 2)), 1)[:, None, None, None]
+        fragile = np.any(jump > 0.01 * (np.abs(di) + typical), axis=-1)              # (b, H, W)
+        allowance = (np.abs(g[sl])[..., None] * jump * fragile[..., None]).sum(axis=(1, 2))
+        return ob, np.abs(di * g[sl][..., None]).sum(axis=(1, 2)), allowance, int(fragile.sum())
+    if c["per_view"]:
+        parts = [oracle_backward(b, b + 1, c["sdf"][b]) for b in range(B)]
+        g_sdf_ref = np.stack([p[0][0] for p in parts])
+        pose_ref = np.concatenate([np.concatenate([p[0][1], p[0][2], p[0][3][:, None]], axis=1) for p in parts])
+        l1 = np.concatenate([p[1] for p in parts])
+        allowance = np.concatenate([p[2] for p in parts])
+        n_fragile = sum(p[3] for p in parts)
+    else:
+        ob, l1, allowance, n_fragile = oracle_backward(0, B, c["sdf"])
+        g_sdf_ref = ob[0]
+        pose_ref = np.concatenate([ob[1], ob[2], ob[3][:, None]], axis=1)
+    assert n_fragile <= 2 + 0.01 * (d > 0).sum(), f"{name}: {n_fragile} pixels on cell faces"    # not vacuous
+    if np.abs(g_sdf_ref).max() > 0:
+        assert rel_err(hb[0], g_sdf_ref) <= REL, name
+    else:
+        assert not hb[0].any(), name
+    pose = np.concatenate([hb[1], hb[2], hb[3][:, None]], axis=1)
+    excess = np.abs(pose - pose_ref) - (REL * l1 + allowance + 1e-30)
+    assert np.all(excess <= 0), f"{name}: view/entry {np.argwhere(excess > 0)[:5].tolist()}, over by {excess.max():.3g}"
+
+    # 3. the step API against the stand-alone calls: depth bit for bit, gradients to summation order
+    camera = Camera(W, H, c["fx"], c["fy"], c["cx"] - 0.5, c["cy"] - 0.5, pixel_center=0.0)
+    assert np.allclose(camera.get_pinhole_camera_parameters(0.5)[:4], (c["fx"], c["fy"], c["cx"], c["cy"]))
+    plan = BatchRenderPlan(R, B, camera, per_view_sdf=c["per_view"])
+    for _ in range(2):                                   # twice on one workspace: epochs, alternating volumes
+        ds = plan.forward(sdf_t, pos_t, quat_t, isc_t, c["thr"], prepare_backward=True)
+        assert plan._step is not None
+        assert np.array_equal(ds.cpu().numpy(), d), name
+        gs, gp, gq, gi = plan.backward(T.dev(g), sdf_t, pos_t, quat_t, isc_t)
+        assert plan._step is None
+        if np.abs(hb[0]).max() > 0:
+            assert rel_err(gs.cpu().numpy(), hb[0]) <= 2e-5, name
+        step_pose = np.concatenate([gp.cpu().numpy(), gq.cpu().numpy(), gi.cpu().numpy()[:, None]], axis=1)
+        assert np.all(np.abs(step_pose - pose) <= 2e-5 * l1 + 1e-30), name
+    torch.cuda.synchronize()
