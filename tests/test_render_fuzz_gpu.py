@@ -15,6 +15,7 @@ import torch
 
 import oracle
 import test_render_gpu as T
+import test_render_l1_gpu as L1
 from helpers import rel_err
 
 pytestmark = pytest.mark.gpu
@@ -145,3 +146,26 @@ def test_random_configuration(seed):
         step_pose = np.concatenate([gp.cpu().numpy(), gq.cpu().numpy(), gi.cpu().numpy()[:, None]], axis=1)
         assert np.all(np.abs(step_pose - pose) <= 2e-5 * l1 + 1e-30), name
     torch.cuda.synchronize()
+
+    # 4. render + masked depth-L1 in one pass (sdfr_render_forward_l1 / _backward_l1) against the unfused sequence
+    # forward -> sdfr_depth_l1_loss -> backward: same march, same gradient image, so identical fixed-order pose sums
+    rng = np.random.default_rng(seed + 77)
+    tgt = np.where(rng.uniform(size=d.shape) < 0.15, 0.0, d * rng.uniform(0.97, 1.03, d.shape)).astype(np.float32)
+    tgt[:, ::7, ::5] = 1.0                                    # observed depth where nothing is rendered, too
+    l1cam = (W, H, c["cx"], c["cy"], c["fx"], c["fy"])
+    d_f, loss_f, stats, g_f = L1.fused(Rm, c["sdf"], c["pos"], c["quat"], c["isc"], l1cam, tgt, thr=c["thr"],
+                                       weight=0.7, per_view=c["per_view"])
+    d_u, loss_u, g_u = L1.unfused(Rm, c["sdf"], c["pos"], c["quat"], c["isc"], l1cam, tgt, thr=c["thr"], weight=0.7)
+    assert np.array_equal(d_f, d) and np.array_equal(d_u, d), name
+    mask = (tgt > 0) & (d > 0)
+    assert np.array_equal(stats[:, 1], mask.sum(axis=(1, 2)).astype(np.float32)), name
+    l_ref, _ = oracle.depth_l1(d, tgt, weight=0.7)
+    some = mask.sum(axis=(1, 2)) > 0
+    np.testing.assert_allclose(loss_f[some], l_ref[some], rtol=5e-6, err_msg=name)
+    np.testing.assert_allclose(loss_u[some], l_ref[some], rtol=5e-6, err_msg=name)
+    assert np.all(np.isnan(loss_f[~some])), name            # the reference's mean of an empty selection
+    for k in (1, 2, 3):
+        assert np.array_equal(g_f[k], g_u[k]), f"{name}: pose sums differ ({k})"
+    if np.abs(g_u[0]).max() > 0:
+        assert rel_err(g_f[0], g_u[0]) <= 1e-5, name
+
