@@ -120,9 +120,12 @@ class SDFPoseNet:
             colmax = torch.empty(layer.cout, dtype=torch.float32, device=self.dev)
             store = not last or use_res
             Y = torch.empty((M, layer.cout), dtype=torch.float32, device=self.dev) if store else None
-            res_F = F if (use_res and F_width == layer.cout) else None
-            if use_res and res_F is None:
-                raise NotImplementedError("residual link between layers of different point-feature width")
+            res_F = None
+            if use_res and F_width == layer.cout:
+                res_F = F
+            elif use_res:
+                # prev_out = [F | G] (a dense link) into a last layer as wide as both halves together
+                res_F = torch.cat([F, G.reshape(1, -1).expand(M, -1)], dim=1).contiguous()
             rc = self.L.sdfr_pointnet_layer(F.data_ptr(), M, F_width, F.shape[1], layer.w.data_ptr(), layer.cin_total,
                                             cvec.data_ptr(), layer.scale.data_ptr(), layer.shift.data_ptr(),
                                             res_F.data_ptr() if res_F is not None else None,
