@@ -93,8 +93,23 @@ constexpr long long kBackwardMacroMinTiles = SDFR_BWD_MACRO_MIN;
 #define SDFR_FWD_SY SDFR_MACRO_SY
 #endif
 constexpr TileGeom kFwdMacroTile{SDFR_FWD_SX, SDFR_FWD_SY};
+// Wide images take 128 x 8-pixel tiles walked by 4 waves -- the same work per wave as 64 x 8 by 2, half as many
+// workgroups.  What a mostly-culled grid costs is the dispatcher's rate (~0.42 ns per workgroup whatever it does,
+// DESIGN.md section 8): forward us per 256 views of 640x480, 64 x 8 by 2 waves / 128 x 8 by 4: the benchmark 164.6 / 165.3,
+// objects a third of that size 81.8 / 71.3, B = 32 ... 56 5-10 % faster; but 160x120 images (two 128-pixel tiles per
+// row) 106.8 / 165.5, B = 512 300.7 / 311.0, and in the step harness the benchmark itself 160.6 / 162.7 -- hence the
+// two bounds (the benchmark's 153 600 tiles stay on 64 x 8).
+#ifndef SDFR_FWD_WIDE
+#define SDFR_FWD_WIDE 1   // 0: timing experiments without the wide tile
+#endif
+constexpr TileGeom kFwdWideTile{4, 1};
+constexpr int kFwdWideMinWidth = 256;
+constexpr long long kFwdWideMaxTiles = 100000;   // of the 64 x 8 tiling (B <= 166 at 640x480)
 inline TileGeom forward_geom(int B, int W, int H) {
-  return ((long long)B * kMacroTile.nx(W) * kMacroTile.ny(H) >= SDFR_FWD_MACRO_MIN) ? kFwdMacroTile : kSmallTile;
+  const long long tiles = (long long)B * kMacroTile.nx(W) * kMacroTile.ny(H);
+  if (tiles < SDFR_FWD_MACRO_MIN) return kSmallTile;
+  if (SDFR_FWD_WIDE && W >= kFwdWideMinWidth && tiles <= kFwdWideMaxTiles) return kFwdWideTile;
+  return kFwdMacroTile;
 }
 inline TileGeom backward_geom(int B, int W, int H) {
   return ((long long)B * kMacroTile.nx(W) * kMacroTile.ny(H) >= kBackwardMacroMinTiles) ? kMacroTile

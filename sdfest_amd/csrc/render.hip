@@ -1151,8 +1151,8 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
   const float rfx = (float)(1.0 / (double)fx), rfy = (float)(1.0 / (double)fy);
   const int vec_ok = (W % 4 == 0) && ((uintptr_t)depth % 16 == 0);
 #define SDFR_LAUNCH_FWD_L(RT, PK, SRC, STRIDE, SX, SY, LOSS)                                          \
-  hipLaunchKernelGGL((render_forward_kernel<RT, PK, SX, SY, LOSS, (SX * SY > 1 ? kFwdWaves : 4)>), grid_tile, \
-                     dim3((SX * SY > 1 ? kFwdWaves : 4) * 64), 0, st, \
+  hipLaunchKernelGGL((render_forward_kernel<RT, PK, SX, SY, LOSS, (SX * SY > 1 && SX < 4 ? kFwdWaves : 4)>), grid_tile, \
+                     dim3((SX * SY > 1 && SX < 4 ? kFwdWaves : 4) * 64), 0, st, \
                      SRC, R, STRIDE, setup, W, H, ntx, nty, cx, cy, rfx, rfy, threshold, vec_ok,      \
                      depth, target, loss_part, epoch)
 #define SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, SX, SY)                                               \
@@ -1162,7 +1162,8 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
   } while (0)
 #define SDFR_LAUNCH_FWD(RT, PK, SRC, STRIDE)                                                         \
   do {                                                                                               \
-    if (macro) SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, SDFR_FWD_SX, SDFR_FWD_SY);                     \
+    if (geom.sx == kFwdWideTile.sx && geom.sy == kFwdWideTile.sy) SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, 4, 1);  \
+    else if (macro) SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, SDFR_FWD_SX, SDFR_FWD_SY);                \
     else SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, 1, 1);                                               \
   } while (0)
   if (packed) {
