@@ -880,8 +880,19 @@ __device__ __forceinline__ void backward_dispatch(
 }
 
 // grid: (tiles x, rows, views): BATCH: the 64 x 8 tiling's columns x backward_batch_rows(H); else the 32 x 8 tiling
+// 8 waves per SIMD for the backward: the register allocator is held to 64 VGPRs (it takes 67 on its own: 7 waves
+// per SIMD; the price is 8 bytes of scratch): stand-alone backward 134.6 -> 129.3 us, a step's 117.8 -> 116.6 us at the
+// benchmark, mug-sized objects unchanged.  0: the compiler's own choice (timing experiments).
+#ifndef SDFR_BWD_WAVES_PER_EU
+#define SDFR_BWD_WAVES_PER_EU 8
+#endif
+#if SDFR_BWD_WAVES_PER_EU
+#define SDFR_BWD_OCC __attribute__((amdgpu_waves_per_eu(SDFR_BWD_WAVES_PER_EU, SDFR_BWD_WAVES_PER_EU)))
+#else
+#define SDFR_BWD_OCC
+#endif
 template <int RT, bool BATCH, bool LOSS>
-__global__ __launch_bounds__(kBlock) void render_backward_kernel(
+__global__ __launch_bounds__(kBlock) SDFR_BWD_OCC void render_backward_kernel(
     const float* __restrict__ grad_depth, const float* __restrict__ depth,
     const float* __restrict__ sdf, int R, long long sdf_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, int stride, float cx, float cy,
