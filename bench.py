@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: sphere-tracing depth render forward + backward.
 
-Metric (BASELINE.json): depth renders/sec fwd+bwd, 640x480 @ 64^3 SDF.
+Metric (BASELINE.json): depth renders/sec fwd+bwd, 640x480 @ 64^3 SDF; grad max-abs-err vs ref.
+The line carries both halves: `value` (renders/s) and `grad_max_abs_err` / `grad_max_rel_err` (+ `parity`), the
+errors of the benchmarked build's last step against the oracle.  After the headline it appends BASELINE.json's
+other single-GPU configurations (`configs`: C1, C2 with the CPU port beside them, C5).
 
 Workload per GPU ("C3", BASELINE.json configs[2]): 256 seeded random
 poses of the synthetic blobs(0) 64^3 SDF at 640x480, threshold 0.005, upstream gradient
@@ -38,6 +41,10 @@ def parse():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the gradient-error report against the oracle")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C1 / C2 / C5 side measurements")
+    ap.add_argument("--prewarm-ms", type=float, default=300.0,
+                    help="untimed steps before the warm-up steps until this much wall time has passed (clock ramp)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="views in the CPU sample (0 = auto)")
     return ap.parse_args()
 
@@ -110,7 +117,7 @@ def cpu_baseline(sdf, poses, W, H, thr, sample):
     sweep = {1: v_one}
     reps = {}
     for threads in sorted({t for t in (8, 32, 64, 128, ncpu) if 1 < t <= ncpu}):
-        sweep[threads], reps[threads] = _time_oracle(lib, sdf, pos, quat, isc, W, H, thr, threads, 6.0)
+        sweep[threads], reps[threads] = _time_oracle(lib, sdf, pos, quat, isc, W, H, thr, threads, 4.0)
     best = max(sweep, key=lambda k: sweep[k])
     return {"value": round(sweep[best], 2), "unit": "renders/s", "cores": best, "kind": "port",
             "sample": f"{pos.shape[0]} views of the same workload (first poses of the seeded list), "
@@ -121,14 +128,20 @@ def cpu_baseline(sdf, poses, W, H, thr, sample):
 
 
 def load_traffic():
-    """HBM bytes per forward launch from the committed rocprofv3 --pmc passes (profiles/)."""
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), valid only for
+    the build they were taken on: the file carries the sha of the kernel sources, and a line produced by other
+    sources reports traffic null."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(p):
-        try:
-            return json.load(open(p))
-        except Exception:
-            return None
-    return None
+    try:
+        t = json.load(open(p))
+    except Exception:
+        return None, "profiles/pmc_traffic.json missing"
+    from tools.bench_extra import kernel_sources_sha
+    here = kernel_sources_sha()
+    if t.get("kernel_sources_sha16") != here:
+        return None, (f"profiles/pmc_traffic.json was taken on kernel sources {t.get('kernel_sources_sha16')}, "
+                      f"this build is {here}: not reported")
+    return t, f"{t.get('source')}, kernel sources {here}"
 
 
 def main():
@@ -150,7 +163,8 @@ def main():
                          "the product has no CPU path")
     # rehearsal on a box with fewer GPUs than ranks (never a measurement): SDFR_BENCH_SHARE_GPU=1 puts every rank on
     # GPU 0 and SDFR_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device)
-    if os.environ.get("SDFR_BENCH_SHARE_GPU") == "1":
+    share_gpu = os.environ.get("SDFR_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
         local_rank = 0
     backend = os.environ.get("SDFR_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
@@ -169,36 +183,42 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=N)
 
     from sdfest_amd import BatchRenderPlan, Camera
-    from sdfest_amd.parallel import allreduce_shared_gradients
+    from tools.bench_extra import Telemetry, extra_configs, parity_report
 
+    tele = Telemetry(local_rank)
+    tele.start()
     W, H, B, thr = args.width, args.height, args.batch, 0.005
     sdf_np, poses_np, sdf, pos, quat, isc, g = synthetic_inputs(B * N, rank, B, W, H, device)
     cam = Camera(W, H, W / 2.0, W / 2.0, W / 2.0, H / 2.0, pixel_center=0.5)
-    # The one exchange of a step -- the all-reduce of d/dSDF (RCCL) -- is issued asynchronously.  The plan cycles
-    # through M gradient volumes (a step's forward zero-fills the volume its backward will add into), so the
-    # exchange of step k only has to be complete before the forward of step k + M re-uses its volume: it runs
-    # beside the following steps.  Every cross-stream dependency is a queue packet of ~10 us on this platform
-    # (DESIGN section 8), so the compute stream does not wait once per step: when M exchanges are outstanding it
-    # waits for the (M/2)-th oldest -- the collectives complete in issue order on their stream -- i.e. once per M/2
-    # steps.  Same work per step, nothing skipped; the last steps' exchanges are waited for inside the timed region.
+    # The one exchange of a step -- the all-reduce of d/dSDF (RCCL) -- runs beside the following steps.  The plan
+    # cycles through M gradient volumes that are ONE contiguous buffer (a step's forward zero-fills the volume its
+    # backward will add into); every M/2 steps the M/2 volumes just written are summed over the ranks by ONE
+    # all-reduce (1 MiB per volume is latency-bound over xGMI: four volumes cost one latency, not four), and the
+    # compute stream waits for an exchange only when its half of the ring comes up for re-use, M/2 steps later.
+    # Every cross-stream dependency is a queue packet of ~10 us on this platform: this way the
+    # two streams meet once per M/2 steps in each direction instead of once per step.  Same bytes exchanged per
+    # step, nothing skipped; the exchanges still outstanding at the end are waited for inside the timed region.
     M = max(2, int(os.environ.get("SDFR_BENCH_GRAD_VOLUMES", "8" if use_dist else "2")))
+    M += M % 2
+    half = M // 2
     plan = BatchRenderPlan(64, B, cam, device=device, grad_volumes=M)
-    pending = []
+    state = {"k": 0, "pending": [None, None]}
 
-    def finish_exchange(all_of_them=False):
-        if all_of_them:
-            if pending:
-                pending[-1].wait()
-                pending.clear()
-        elif len(pending) >= M:          # the volume of the oldest exchange is the one the next forward zero-fills
-            n = M // 2
-            pending[n - 1].wait()
-            del pending[:n]
+    def finish_exchanges():
+        for i, w in enumerate(state["pending"]):
+            if w is not None:
+                w.wait()
+                state["pending"][i] = None
 
     def step(ev=None):
+        k = state["k"]
         if ev:
             ev[0].record()
-        finish_exchange()
+        if use_dist and k % half == 0:
+            h = (k // half) % 2           # the half of the ring this step starts to re-use
+            if state["pending"][h] is not None:
+                state["pending"][h].wait()
+                state["pending"][h] = None
         # forward + backward of the same views = one step (sdfr_render_step_forward / _backward)
         plan.forward(sdf, pos, quat, isc, thr, prepare_backward=True)
         if ev:
@@ -206,15 +226,45 @@ def main():
         plan.backward(g, sdf, pos, quat, isc)
         if ev:
             ev[2].record()
-        if use_dist:
-            pending.append(allreduce_shared_gradients(plan.g_sdf, async_op=True))
+        state["k"] = k + 1
+        if use_dist and (k + 1) % half == 0:
+            h = (k // half) % 2
+            state["pending"][h] = dist.all_reduce(plan.grad_ring[h * half:(h + 1) * half], op=dist.ReduceOp.SUM,
+                                                  async_op=True)
+
+    def flush_tail():
+        """exchange the volumes of the steps since the last full half (K need not be a multiple of M/2)"""
+        k = state["k"]
+        if use_dist and k % half:
+            h = (k // half) % 2
+            if state["pending"][h] is not None:
+                state["pending"][h].wait()
+            state["pending"][h] = dist.all_reduce(plan.grad_ring[h * half:h * half + k % half],
+                                                  op=dist.ReduceOp.SUM, async_op=True)
+            state["k"] = (k // half + 1) * half
 
     def barrier():
-        finish_exchange(all_of_them=True)
+        flush_tail()
+        finish_exchanges()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+        plan.ring_reset()       # step k writes volume k % M again
+        state["k"] = 0
 
+    # untimed pre-warm: the driver's run is 25 steps = 7 ms from a cold, idle GPU, shorter than the clock governor's
+    # ramp (round 2: 855 k renders/s on the driver's box against 903 k in a longer session).  The steady state is
+    # what the metric means, so the GPU runs the same steps for `--prewarm-ms` before the W warm-up steps; the
+    # telemetry in the line shows the clocks of the timed region.
+    t_pre = time.perf_counter()
+    n_pre = 0
+    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+        for _ in range(16):
+            step()
+        n_pre += 16
+        torch.cuda.synchronize()
+    barrier()
+    prewarm_ms = (time.perf_counter() - t_pre) * 1e3
     for _ in range(args.warmup):
         step()
     barrier()
@@ -223,23 +273,38 @@ def main():
     stride = max(1, int(os.environ.get("SDFR_BENCH_EVENT_STRIDE", "4")))
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] if k % stride == 0 else None
               for k in range(args.steps)]
+    fallbacks0 = plan.prologue_fallbacks()
     barrier()
+    tele.mark("t0")
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(events[k])
     t_enqueued = time.perf_counter() - t0      # host time to issue the K steps (GPU-bound if below `elapsed`)
     barrier()
-    events = [e for e in events if e is not None]
     elapsed = time.perf_counter() - t0
+    tele.mark("t1")
+    events = [e for e in events if e is not None]
     if use_dist:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    time.sleep(0.005)
+    tele.stop()
 
     fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
     bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
     step_ms = np.array([e[0].elapsed_time(e[2]) for e in events])
     hits = int((plan.depth > 0).sum().item())
+    fallbacks = plan.prologue_fallbacks() - fallbacks0
+    collective = None
+    if use_dist:
+        # what the process group really is: the driver can check that RCCL saw N ranks and every rank rendered
+        per_rank = [None] * N
+        dist.all_gather_object(per_rank, {"rank": rank, "hit_pixels": hits, "device": torch.cuda.get_device_name(device),
+                                          "local_device_index": local_rank, "prologue_fallbacks": fallbacks})
+        collective = {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(),
+                      "exchange": f"one all-reduce (sum, fp32) of {half} x 1 MiB d/dSDF volumes per {half} steps, "
+                                  f"ring of {M} volumes", "per_rank": per_rank}
 
     if rank == 0:
         views = B * N * args.steps
@@ -252,9 +317,10 @@ def main():
         k_bytes, k_ms = (fwd_bytes, fwd_ms) if fwd_ms >= bwd_ms else (bwd_bytes, bwd_ms)
         achieved = k_bytes / (k_ms * 1e-3) / 1e9
         # the committed PMC passes were taken on the default workload only
-        traffic = load_traffic() if (B == 256 and W == 640 and H == 480) else None
+        traffic, traffic_source = (load_traffic() if (B == 256 and W == 640 and H == 480)
+                                   else (None, "counter passes exist for the default workload only"))
         line = {
-            "metric": "depth renders/sec fwd+bwd, 640x480 @ 64^3 SDF",
+            "metric": "depth renders/sec fwd+bwd, 640×480 @ 64³ SDF; grad max-abs-err vs ref",
             "value": round(value, 1),
             "unit": "renders/s",
             "n_gpus": N,
@@ -270,7 +336,7 @@ def main():
                                    f"{W}x{H}, threshold 0.005, forward+backward"
                                    + (", RCCL all-reduce of dSDF" if N > 1 and backend == "nccl" else "")
                                    + (f", REHEARSAL: {backend} backend" if backend != "nccl" else "")
-                                   + (", REHEARSAL: all ranks on GPU 0" if os.environ.get("SDFR_BENCH_SHARE_GPU") == "1" else ""),
+                                   + (", REHEARSAL: all ranks on GPU 0" if share_gpu else ""),
                        "views_per_gpu": B, "width": W, "height": H, "sdf_resolution": 64,
                        "parallelism": f"views sharded over {N} GPU(s)",
                        "hit_pixels_rank0": hits},
@@ -278,6 +344,7 @@ def main():
                          "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(achieved * 1e9 / HBM_PEAK, 5),
                          "traffic": (traffic or {}).get(dominant),
+                         "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": int(k_bytes),
                          "avg_launch_ms": round(k_ms, 4)},
             "roofline_step": {"bytes_per_view": bytes_per_view,
@@ -290,11 +357,29 @@ def main():
             "step_ms_events": {"min": round(float(step_ms.min()), 4), "median": round(float(np.median(step_ms)), 4),
                                "max": round(float(step_ms.max()), 4), "n": int(step_ms.size)},
             "host_issue_ms_per_step": round(t_enqueued / args.steps * 1e3, 4),
+            "prewarm": {"untimed_steps": n_pre, "ms": round(prewarm_ms, 1),
+                        "why": "clock ramp: the timed region follows >= --prewarm-ms of the same steps"},
+            "prologue_fallbacks_in_timed_region": fallbacks,
+            "gpu_telemetry": tele.summary("t0", "t1"),
         }
+        if collective:
+            line["collective"] = collective
+        if N == 1 and not args.no_parity:
+            # the other half of the metric: errors of the benchmarked build's last step against the reference
+            # semantics (sdf_renderer_cuda.cu:334-467, simple_renderer.py:317-458) through the pinned oracle
+            par = parity_report(plan, g, sdf_np, poses_np, W, H, thr)
+            line["parity"] = par
+            line["grad_max_abs_err"] = max(par["grad_sdf"]["max_abs_err"], par["grad_pose"]["max_abs_err"])
+            line["grad_max_rel_err"] = max(par["grad_sdf"]["max_err_over_max"],
+                                           par["grad_pose"]["max_rel_err_well_conditioned"] or 0.0)
         if N == 1 and not args.no_cpu_baseline:
             sample = args.cpu_sample or min(B, 256)
             line["cpu_baseline"] = cpu_baseline(sdf_np, poses_np, W, H, thr, sample)
             line["speedup_vs_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
+        if N == 1 and not args.no_configs:
+            del plan
+            torch.cuda.empty_cache()
+            line["configs"] = extra_configs(sdf_np, device, HBM_PEAK)
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()

@@ -61,6 +61,19 @@ extern "C" {
 /* d depth / d sdf weight assignment */
 #define SDFR_SDF_GRAD_EXACT 0       /* trilinear weights (simple_renderer.py:399-408) */
 #define SDFR_SDF_GRAD_CUDA_COMPAT 1 /* the permutation in sdf_renderer_cuda.cu:373-388 */
+/* Flag bit, OR-ed into either of the above: DETERMINISTIC d depth / d sdf.  The reference
+ * sums the per-pixel contributions with float atomics (sdf_renderer_cuda.cu:373-388) and so does the default mode
+ * here, one per touched voxel per tile: the result varies in the last bits from run to run.  With this flag every
+ * contribution is rounded once, per pixel, to the fixed quantum 2^-SDFR_FIXED_QUANTUM_BITS and everything after
+ * that is INTEGER addition into a 64-bit volume in the workspace, converted to float at the end: g_sdf is bitwise
+ * identical from run to run and does not depend on tile shapes, batch composition or -- when the ranks of a
+ * sharded batch add their 64-bit volumes (sdfr_render_fixed_volume_offset) and convert afterwards
+ * (sdfr_fixed_to_float) -- on how the views are spread over GPUs.  For tests and reproducible runs: several
+ * times slower than the default (64-bit LDS table, no dense box).  Shared gradient volume only
+ * (g_sdf_view_stride = 0), R <= 128, sdfr_render_backward / sdfr_render_step_backward only.  Representable range:
+ * |sum| < 2^(63 - 40) = 8.4e6 per voxel; contributions that are not finite count as 0 (NaN) or saturate. */
+#define SDFR_SDF_GRAD_DETERMINISTIC 0x100
+#define SDFR_FIXED_QUANTUM_BITS 40
 
 SDFR_API int sdfr_version(void);
 SDFR_API const char* sdfr_last_error(void);
@@ -68,8 +81,28 @@ SDFR_API const char* sdfr_last_error(void);
 /* ---- sphere-tracing depth render -------------------------------------------------------- */
 
 /* Scratch for sdfr_render_forward (per-view set-up records + the re-packed grid, see
- * render.hip "cell records"). */
+ * render.hip "cell records").
+ * Every renderer workspace (forward, backward, step, depth-L1 forms) starts with the B view records and,
+ * at byte sdfr_render_sync_offset(B), a small sync region that only the forward's prologue launch uses:
+ *   word 0 (uint32)  epoch of the prologue's intra-launch hand-off of the grid's plane minima
+ *   word 1 (uint32)  count of view set-ups that did NOT receive the plane minima in time and fell back to the
+ *                    whole cube as their may-hit box (same depth, slower march); it only ever grows, so a caller
+ *                    that zero-fills the workspace once can read "how often did that happen" at any time.
+ * No call writes into another call's part of a shared workspace's sync region. */
 SDFR_API size_t sdfr_render_forward_workspace_bytes(int R, int B, int W, int H);
+SDFR_API size_t sdfr_render_sync_offset(int B);
+
+/* Deterministic mode: byte offset, in the workspace of sdfr_render_backward (step_layout = 0) or of
+ * sdfr_render_step_backward (1), of the int64 [R][R][R] volume the last deterministic backward left:
+ * g_sdf = volume * 2^-SDFR_FIXED_QUANTUM_BITS.  sdfr_fixed_to_float converts n such words (after, e.g., an
+ * integer all-reduce over the ranks of a sharded batch). */
+SDFR_API size_t sdfr_render_fixed_volume_offset(int R, int B, int W, int H, int step_layout);
+SDFR_API int sdfr_fixed_to_float(const long long* fixed, size_t n, float* out, int device, void* stream);
+
+/* TEST HOOK: bound of the prologue's wait for the plane minima, in polling rounds (default 65536; 0 forces the
+ * fall-back path described above for every view; negative restores the default).  Process-wide; returns the old
+ * value. */
+SDFR_API int sdfr_debug_set_prologue_polls(int max_polls);
 
 /* Replaces sdf_renderer_cpp.forward (sdf_renderer.cpp:42-61 ->
  * sdf_renderer_cuda.cu:472-510, kernel :241-298), extended by a leading batch
@@ -94,7 +127,7 @@ SDFR_API size_t sdfr_render_backward_workspace_bytes(int R, int B, int W, int H)
  *   g_pos [B][3], g_quat [B][4] (x,y,z,w), g_inv_scale [B]: overwritten.
  * Pose gradients are reduced in a fixed order (bitwise reproducible); g_sdf uses
  * float atomics across workgroups (last-bit run-to-run variation, as in the
- * reference). */
+ * reference) unless sdf_grad_mode carries SDFR_SDF_GRAD_DETERMINISTIC. */
 SDFR_API int sdfr_render_backward(const float* grad_depth, const float* depth, const float* sdf, int R,
                          long long sdf_view_stride, const float* pos, const float* quat,
                          const float* inv_scale, int B, int W, int H, float cx, float cy,

@@ -24,6 +24,10 @@ SIGNATURES = {
     "sdfr_version": (c_int, []),
     "sdfr_last_error": (ctypes.c_char_p, []),
     "sdfr_render_forward_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
+    "sdfr_render_sync_offset": (c_sz, [c_int]),
+    "sdfr_debug_set_prologue_polls": (c_int, [c_int]),
+    "sdfr_render_fixed_volume_offset": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
+    "sdfr_fixed_to_float": (c_int, [c_fp, c_sz, c_fp, c_int, c_fp]),
     "sdfr_render_forward": (c_int, [c_fp, c_int, c_ll, c_fp, c_fp, c_fp, c_int, c_int, c_int,
                                     c_f, c_f, c_f, c_f, c_f, c_fp, c_fp, c_sz, c_int, c_fp]),
     "sdfr_render_backward_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),

@@ -153,6 +153,15 @@ __host__ __device__ constexpr int backward_big_record(int tx, int ty, int W) {
 constexpr int kPackedMinViews = SDFR_PACKED_MIN_VIEWS;
 constexpr int kPackedMaxR = 128;
 
+// Every renderer workspace starts the same way: [B view records][sync region][the call's own scratch].  The sync
+// region -- a 128-byte header (word 0: the prologue's epoch, word 1: how many view set-ups fell back to the full
+// cube because the plane minima did not arrive in time, render.hip) and 6 x kPackedMaxR tagged plane-minimum
+// entries of 16 bytes -- has ONE size and ONE place in the forward, backward, step and loss layouts, so no call
+// that shares a workspace with another ever writes over it.
+constexpr int kSyncHeaderWords = 32;
+constexpr size_t kSyncBytes = (size_t)kSyncHeaderWords * 4 + (size_t)6 * kPackedMaxR * 16;
+static_assert(kSyncBytes % 128 == 0, "the scratch behind the sync region stays 128-byte aligned");
+
 
 // Device-side fill / copy as ordinary kernels.  The entry points are captured into hipGraphs
 // (FusedRenderAndCompare); with hipMemsetAsync / hipMemcpyAsync nodes in the captured sequence,

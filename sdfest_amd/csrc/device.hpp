@@ -36,6 +36,7 @@ struct __attribute__((packed, aligned(4))) ZPair {
 struct Cell {
   float v[8];  // corner values, index 4*ix + 2*iy + iz
   float ox, oy, oz;
+  float bx, by, bz;  // the cell's corner 000 (integers in float)
   int lin;  // linear index of corner 000
 };
 
@@ -52,6 +53,7 @@ __device__ __forceinline__ void gather_cell(const float* __restrict__ src, int R
   const float by = fminf(fmaxf(floorf(gy), 0.0f), top);
   const float bz = fminf(fmaxf(floorf(gz), 0.0f), top);
   c.ox = gx - bx; c.oy = gy - by; c.oz = gz - bz;
+  c.bx = bx; c.by = by; c.bz = bz;
   // linear index formed in float (exact: < 2^24 for R <= 256) -- one conversion instead of three
   const int lin = (Rr <= 256) ? (int)fmaf(fmaf(bx, (float)Rr, by), (float)Rr, bz)
                               : ((int)bx * Rr + (int)by) * Rr + (int)bz;
@@ -273,11 +275,16 @@ struct RunHash {
     return -1;
   }
 
-  // one fixed-point add into a resolved slot, or a global float atomic when the table is crowded
+  // one fixed-point add into a resolved slot, or a global atomic when the table is crowded.
+  // DET (deterministic d/dSDF, render.hip): `gvol` is the 64-bit fixed-point volume and everything that reaches it
+  // is an integer -- sums that do not depend on the order of arrival, across tiles, views and ranks.
+  template <bool DET = false>
   __device__ __forceinline__ void add_one(float* __restrict__ gvol, int slot, int lin, float w,
                                           float to_fixed) {
     if (slot >= 0)
       atomicAdd(&vals[(slot << SHIFT) + (lin & (kLen - 1))], (unsigned long long)fixed_from_float(w * to_fixed));
+    else if (DET)
+      atomicAdd(reinterpret_cast<unsigned long long*>(gvol) + lin, (unsigned long long)fixed_from_float(w * to_fixed));
     else
       atomicAdd(gvol + lin, w);
   }
@@ -287,6 +294,7 @@ struct RunHash {
   // reads are issued together and waited for once; only a miss takes the probing loop.  The
   // look-ups are a latency chain per lane (LDS round trip each), so overlapping them matters more
   // than the atomic's own cost.
+  template <bool DET = false>
   __device__ __forceinline__ void add_cell(float* __restrict__ gvol, int lin, int Rr,
                                            const float (&w)[8], float to_fixed) {
     const int col[4] = {lin, lin + Rr, lin + Rr * Rr, lin + Rr * Rr + Rr};
@@ -303,14 +311,16 @@ struct RunHash {
     for (int j = 0; j < 4; ++j) slot[j] = (cur[j] == key[j]) ? (int)h[j] : slot_of(key[j]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      add_one(gvol, slot[j], col[j], w[2 * j], to_fixed);
+      add_one<DET>(gvol, slot[j], col[j], w[2 * j], to_fixed);
       const bool split = (col[j] & (kLen - 1)) == kLen - 1;  // the +z corner starts the next run
       const int s_hi = split ? slot_of(key[j] + 1) : slot[j];
-      add_one(gvol, s_hi, col[j] + 1, w[2 * j + 1], to_fixed);
+      add_one<DET>(gvol, s_hi, col[j] + 1, w[2 * j + 1], to_fixed);
     }
   }
 
-  // flush: consecutive lanes write consecutive voxels of a run (contiguous global float atomics)
+  // flush: consecutive lanes write consecutive voxels of a run (contiguous global float atomics; DET: 64-bit
+  // integer atomics of the sums themselves)
+  template <bool DET = false>
   __device__ __forceinline__ void flush(float* __restrict__ gvol, int nvox, float from_fixed, int tid,
                                         int nthreads) {
     // (A list of the slots in use, so that the flush need not scan the table, was measured:
@@ -320,7 +330,10 @@ struct RunHash {
       if (key < 0) continue;  // most slots of a tile stay empty
       const long long q = (long long)vals[i];
       const int lin = (key << SHIFT) + (i & (kLen - 1));
-      if (q != 0 && lin < nvox) atomicAdd(gvol + lin, (float)q * from_fixed);
+      if (q != 0 && lin < nvox) {
+        if (DET) atomicAdd(reinterpret_cast<unsigned long long*>(gvol) + lin, (unsigned long long)q);
+        else atomicAdd(gvol + lin, (float)q * from_fixed);
+      }
     }
   }
 };
@@ -330,14 +343,16 @@ struct RunHash {
 // ONE LDS atomic and one look-up: 4 adds and 4 look-ups per hit pixel instead of 8 adds and 4-8 look-ups.
 // The backward's cost follows the number of LDS instructions a tile issues, not their
 // width.  Adding (hi << 32) + lo as one 64-bit integer keeps both halves exact as long as the low sum stays
-// inside 32 bits: contributions are scaled to < 2^22 and a tile has <= 512 pixels.  The price is resolution:
-// a contribution is rounded to 2^-22 of the tile's bound (2 max|grad| scale) instead of being represented
-// exactly; sums stay independent of the order of arrival.
+// inside 32 bits: a voxel receives at most one contribution per pixel, so the caller scales contributions to
+// < 2^(31 - log2(pixels) - 1) (render.hip, tile_fixed_bits: 2^21 for the 512-pixel tiles, 2^20 for the 1024-pixel
+// ones, 2^22 for the sampler's 256 points) and sends anything at or above twice that to the global-atomic bypass.
+// The price is resolution: a contribution is rounded to 2^-bits of the tile's bound (2 max|grad| scale) instead
+// of being represented exactly; sums stay independent of the order of arrival.
 template <int SLOTS>
 struct PairRunHash {
   static constexpr int kSlots = SLOTS, kLen = 4;
   static constexpr int kBits = 22;
-  static constexpr float kWeightLimit = 8.0e6f;  // 2^23
+  static constexpr float kWeightLimit = 4194304.0f;  // 2^22: 256 such contributions (the sampler's block) stay below 2^31
   unsigned long long vals[SLOTS * 4];
   int keys[SLOTS];
 
@@ -363,8 +378,10 @@ struct PairRunHash {
     return -1;
   }
 
+  template <bool DET = false>
   __device__ __forceinline__ void add_cell(float* __restrict__ gvol, int lin, int Rr, const float (&w)[8],
                                            float to_fixed) {
+    static_assert(!DET, "32-bit pair sums cannot hold the deterministic mode's quantum: use RunHash");
     const int col[4] = {lin, lin + Rr, lin + Rr * Rr, lin + Rr * Rr + Rr};
     int key[4], cur[4];
     unsigned h[4];
@@ -393,7 +410,9 @@ struct PairRunHash {
   // (One lane per ENTRY with the neighbour's high half fetched by DPP -- 2 LDS reads per step instead of 3 --
   // needs a second, quarter-filled global atomic for voxel 4: backward 158.7 -> 209 us.  The flush's global
   // atomics, not its LDS reads, are the expensive part.)
+  template <bool DET = false>
   __device__ __forceinline__ void flush(float* __restrict__ gvol, int nvox, float from_fixed, int tid, int nthreads) {
+    static_assert(!DET, "use RunHash");
     for (int i = tid; i < SLOTS * 5; i += nthreads) {
       const int slot = i / 5, k = i - slot * 5;
       const int key = keys[slot];
@@ -405,21 +424,37 @@ struct PairRunHash {
         sum += (q - (long long)(int)(unsigned)((unsigned long long)q & 0xffffffffull)) >> 32;
       }
       const int lin = key * 4 + k;
-#if defined(SDFR_TIMING_FLUSH_STORE)   // timing-only builds: what the flush's global atomics cost
-      if (sum != 0 && lin < nvox) gvol[lin] = (float)sum * from_fixed;
-#elif defined(SDFR_TIMING_FLUSH_NONE)
-      if (sum == 0x7fffffffffffll && lin < nvox) gvol[lin] = (float)sum * from_fixed;
-#else
       if (sum != 0 && lin < nvox) atomicAdd(gvol + lin, (float)sum * from_fixed);
-#endif
     }
   }
 };
-#ifndef SDFR_BWD_PAIR_HASH
-#define SDFR_BWD_PAIR_HASH 1  // 0: the plain z-run table for full-size batches (timing experiments)
-#endif
 using BatchHash = RunHash<2, 512>;    // 64 x 8-pixel tiles of a batch; blocks of 256 points of the sampler
 using SmallHash = RunHash<1, 1024>;   // 32 x 8-pixel tiles of small calls, any resolution
+
+// Minimum / maximum over the wave by DPP (row shifts, then the row broadcasts of gfx9): 6 VALU instructions, no LDS
+// traffic; lane 63 ends up with the result.  min / max are idempotent, so a lane without a valid source simply
+// combines with itself (`old` = its own value, bound_ctrl off) and every row may take part in the broadcasts.
+template <int CTRL> __device__ __forceinline__ int dpp_self(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int wave_min_to63(int v) {
+  v = min(v, dpp_self<0x111>(v));  // row_shr:1
+  v = min(v, dpp_self<0x112>(v));  // row_shr:2
+  v = min(v, dpp_self<0x114>(v));  // row_shr:4
+  v = min(v, dpp_self<0x118>(v));  // row_shr:8
+  v = min(v, dpp_self<0x142>(v));  // row_bcast:15
+  v = min(v, dpp_self<0x143>(v));  // row_bcast:31
+  return v;
+}
+__device__ __forceinline__ int wave_max_to63(int v) {
+  v = max(v, dpp_self<0x111>(v));
+  v = max(v, dpp_self<0x112>(v));
+  v = max(v, dpp_self<0x114>(v));
+  v = max(v, dpp_self<0x118>(v));
+  v = max(v, dpp_self<0x142>(v));
+  v = max(v, dpp_self<0x143>(v));
+  return v;
+}
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -18,6 +18,10 @@
 namespace sdfr {
 namespace {
 
+// torch.relu keeps NaN (fmaxf(NaN, 0) would return 0 and hide bad weights or points); the NaN returned is the
+// canonical positive one, which the bit-pattern maximum of the set pooling carries to the output
+__device__ __forceinline__ float relu_nan(float v) { return (v != v) ? __int_as_float(0x7fc00000) : fmaxf(v, 0.0f); }
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kPtsPerBlock = 64, kColsPerBlock = 64, kChunk = 124;
 
@@ -63,19 +67,21 @@ __global__ __launch_bounds__(256) void pointnet_layer_kernel(
     const int col = c0 + j * 16 + row;
     const bool col_ok = col < cout;
     const float cv = col_ok ? cvec[col] : 0.0f, s = col_ok ? bn_scale[col] : 0.0f, t = col_ok ? bn_shift[col] : 0.0f;
-    float vmax = 0.0f;  // ReLU output is >= 0
+    // ReLU output is >= 0 or NaN (torch's relu and max propagate NaN: pointnet.py:64-96); non-negative floats
+    // order as ints and the canonical positive NaN lies above +inf, so the set maximum is taken on the bit patterns
+    int vmax = 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int p = p0 + wave * 16 + kq * 4 + r;
-      const float v = fmaxf(fmaf(acc[j][r] + cv, s, t), 0.0f);
+      const float v = relu_nan(fmaf(acc[j][r] + cv, s, t));
       if (p < M && col_ok) {
-        vmax = fmaxf(vmax, v);
+        vmax = max(vmax, __float_as_int(v));
         if (y) y[(size_t)p * ldy + col] = resid ? resid[(size_t)p * ldy + col] + v : v;
       }
     }
-    vmax = fmaxf(vmax, __shfl_xor(vmax, 16, 64));
-    vmax = fmaxf(vmax, __shfl_xor(vmax, 32, 64));
-    if (kq == 0) wave_max[wave][j * 16 + row] = __float_as_int(vmax);  // non-negative floats order as ints
+    vmax = max(vmax, __shfl_xor(vmax, 16, 64));
+    vmax = max(vmax, __shfl_xor(vmax, 32, 64));
+    if (kq == 0) wave_max[wave][j * 16 + row] = vmax;
   }
   __syncthreads();
   if (tid < kColsPerBlock && c0 + tid < cout)
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(256) void linear_vec_kernel(const float* __restrict
   if (lane == 0) {
     float v = acc + (bias ? bias[col] : 0.0f);
     if (bn_scale) v = fmaf(v, bn_scale[col], bn_shift[col]);
-    y[col] = relu ? fmaxf(v, 0.0f) : v;
+    y[col] = relu ? relu_nan(v) : v;
   }
 }
 

@@ -29,6 +29,7 @@
 //   * the depth term of the render-and-compare loss can ride inside both kernels (LOSS): no loss
 //     kernel, no gradient image.
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 
 #include "common.hpp"
@@ -44,15 +45,6 @@ constexpr int kBlock = 256;
 #define SDFR_TIGHT_BOX 1  // 0: timing experiments without the may-hit box
 #endif
 constexpr bool kTightBox = SDFR_TIGHT_BOX;
-// In-kernel stamps of the backward's hit tiles (timing builds only: -DSDFR_STAMPS, read by
-// tools/microbench/backward_stamps.py): wave 0's first active lane stores s_memtime at phase boundaries into a
-// per-tile record (plain stores: atomics on shared counters distort the kernel five-fold).
-#ifdef SDFR_STAMPS
-__device__ unsigned long long g_stamps[153600 * 16];
-#define SDFR_STAMP(k) do { if (wave == 0 && lane == (int)__ffsll((long long)__ballot(1)) - 1) stamp__[k] = clock64(); } while (0)
-#else
-#define SDFR_STAMP(k) do {} while (0)
-#endif
 #ifndef SDFR_BWD_SLOTS
 #define SDFR_BWD_SLOTS 512  // slots of the batch backward's z-pair run table
 #endif
@@ -236,7 +228,6 @@ __global__ void view_setup_kernel(const float* __restrict__ pos, const float* __
 struct PlaneEntry {
   unsigned long long a, b;
 };
-constexpr int kSyncHeaderWords = 32;  // 128 bytes: word 0 = epoch
 __device__ __forceinline__ void publish_plane_min(float* __restrict__ plane_min, PlaneEntry* __restrict__ ent,
                                                   unsigned tag, int j, float m) {
   if (ent) {
@@ -396,12 +387,15 @@ __global__ __launch_bounds__(256) void pack_cells_kernel(const float* __restrict
 // The set-up blocks can only wait for blocks dispatched before them, which never wait themselves; and the wait is
 // bounded: after kPrologueMaxPolls rounds a block sets its views up WITHOUT plane minima (the whole cube as the
 // may-hit box: slower, same depth), so no schedule can hang the launch.
+// A view that was set up that way is counted in the sync header's word 1 (sdfr_render_prologue_fallbacks): the
+// count stays 0 unless the launch was serialised (a profiler replaying block by block, a CU mask of one CU).
 constexpr int kPrologueMaxPolls = 1 << 16;
+std::atomic<int> g_prologue_max_polls{kPrologueMaxPolls};   // tests force the fallback: sdfr_debug_set_prologue_polls
 __global__ __launch_bounds__(256) void forward_prologue_kernel(
     const float* __restrict__ sdf, int R, float4* __restrict__ cells, int n_plane, int n_setup,
     unsigned* __restrict__ sync, const float* __restrict__ pos, const float* __restrict__ quat,
     const float* __restrict__ inv_scale, int B, int W, int H, float cx, float cy, float fx, float fy,
-    ViewSetup* __restrict__ out, float threshold, float* __restrict__ g_zero, size_t n_zero) {
+    ViewSetup* __restrict__ out, float threshold, float* __restrict__ g_zero, size_t n_zero, int max_polls) {
   const unsigned tag = sync[0] + 1u;  // the epoch the last forward on this workspace left, + 1
   PlaneEntry* ent = reinterpret_cast<PlaneEntry*>(sync + kSyncHeaderWords);
   int blk = (int)blockIdx.x;
@@ -418,7 +412,7 @@ __global__ __launch_bounds__(256) void forward_prologue_kernel(
     ViewSetup s;
     if (b < B) setup_pose(b, pos, quat, inv_scale, R, fx, fy, s);
     bool ready = false;
-    for (int poll = 0; poll < kPrologueMaxPolls; ++poll) {
+    for (int poll = 0; poll < max_polls; ++poll) {
       bool ok = true;
       for (int j = tid; j < n_ent; j += 256) {
         const unsigned long long a = __hip_atomic_load(&ent[j].a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -437,7 +431,10 @@ __global__ __launch_bounds__(256) void forward_prologue_kernel(
     }
     if (b < B) {
       setup_box<true>(s, R, W, H, cx, cy, fx, fy, ready ? pm_s : nullptr, threshold);
-      if ((tid & 63) == 0) out[b] = s;
+      if ((tid & 63) == 0) {
+        out[b] = s;
+        if (!ready) atomicAdd(&sync[1], 1u);
+      }
     }
     return;
   }
@@ -622,26 +619,88 @@ __global__ __launch_bounds__(NW * 64) void render_forward_kernel(
   forward_tile<RT, PACKED, SX, SY, LOSS, PACKED && kTightBox, NW>(blockIdx.x, blockIdx.y, ntx, nty, blockIdx.z, src, R,
                                          src_view_stride, setup, W, H, cx, cy, rfx, rfy, threshold,
                                          vec_ok, depth, target, loss_part);
-  // the workspace's epoch advances once per forward call, after its prologue launch (forward_prologue_kernel):
-  // the plane-minimum entries that launch published can never read as ready again
-  if (epoch && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && threadIdx.x == 0) epoch[0] += 1u;
+  // The workspace's epoch advances once per forward call, after its prologue launch (forward_prologue_kernel), and
+  // the entries that launch published are wiped (equal words never read as an entry: the payloads of a valid one
+  // are complementary).  Either alone keeps an entry of this call from reading as ready in a later one; the wipe
+  // also covers a caller whose other work overwrote the epoch word with the value it had before.
+  if (epoch && (blockIdx.x | blockIdx.y | blockIdx.z) == 0) {
+    if (threadIdx.x == 0) epoch[0] += 1u;
+    unsigned long long* ent = reinterpret_cast<unsigned long long*>(epoch + kSyncHeaderWords);
+    for (int j = threadIdx.x; j < 2 * 6 * kPackedMaxR; j += NW * 64) ent[j] = 0ull;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
 // backward.  grid = (macro-tiles x, macro-tiles y, views)
 // ---------------------------------------------------------------------------------------------
+// d/dSDF of a tile is pre-summed in LDS before it reaches the volume's global float atomics (one per touched voxel
+// per tile).  Two tables share the workgroup's LDS:
+//   * the DENSE BOX (round 3): the tile's hit pixels first agree on the box of grid cells they touch (one pass of ray
+//     / cell arithmetic, min / max over the wave by DPP, one LDS atomic per wave and bound); if the box has at most
+//     kDenseCap voxels the table is simply that box, one int32 per voxel, addressed by arithmetic: 8 ds_add_u32 per
+//     hit pixel that return nothing -- no key, no compare-and-swap, no LDS round trip for the wave to wait for.  The
+//     run hash's look-ups were 29 % + 25 % of a hit tile's time (stamps).  On the benchmark 88 %
+//     of the hit tiles (84 % of the hit pixels) fit (tools/analysis/tile_boxes_r03.py);
+//   * the z-run hash (device.hpp) for the tiles whose box is larger (silhouettes seen at a grazing angle, far objects
+//     under 64 x 8 tiles).
+// Both hold fixed-point sums, so a tile's contribution does not depend on the order in which its lanes arrive.
+#ifndef SDFR_DENSE_CAP
+#define SDFR_DENSE_CAP 4608   // words: 18 KiB, the size of the batch hash it shares the LDS with
+#endif
+constexpr int kDenseCap = SDFR_DENSE_CAP;
+
 template <typename Hash>
 struct BackwardLds {
-  Hash hash;
+  union {
+    Hash hash;
+    int dense[kDenseCap > 0 ? kDenseCap : 4];
+  };
   float wave_part[4][8];
   int tile_max_bits;
+  int box[6];   // cells of the tile's hit pixels: min x, y, z, max x, y, z (index of the cell's corner 000)
 };
+
+// fractional bits of a tile's fixed-point sums in 32-bit words: a voxel receives at most one contribution per pixel,
+// each below 2^(bits - 1) in magnitude (2^bits for the few extrapolating ones that pass the weight limit)
+__host__ __device__ constexpr int tile_fixed_bits(int pixels, int table_bits) {
+  int b = 31;
+  for (int p = 1; p < pixels; p <<= 1) --b;
+  return b < table_bits ? b : table_bits;
+}
+template <typename Hash> struct HashIs32 { static constexpr bool value = false; };
+template <int SLOTS> struct HashIs32<PairRunHash<SLOTS>> { static constexpr bool value = true; };
+
+// grid-space hit point of a pixel of depth z: the arithmetic of the reference's backward (cu:334-345) in the object
+// frame.  ONE function for the bounds pass and the main pass of a tile: the same instruction sequence on the same
+// inputs chooses the same cell in both.
+struct HitPoint {
+  V3 d;        // unit ray, camera frame
+  V3 o;        // hit point, object frame
+  float t;
+  float gx, gy, gz;
+};
+__device__ __forceinline__ HitPoint hit_point(const ViewSetup& s, int row, int col, float z, float cx, float cy,
+                                              float rfx, float rfy, float isc, float h) {
+  HitPoint p;
+  p.d = pixel_ray(row, col, cx, cy, rfx, rfy);
+  const V3 dobj = rot_t(s, p.d);
+  p.t = z * __builtin_amdgcn_rcpf(-p.d.z);  // -z / d.z   (cu:339)
+  p.o = mk(fmaf(p.t, dobj.x, -s.e[0]), fmaf(p.t, dobj.y, -s.e[1]), fmaf(p.t, dobj.z, -s.e[2]));
+  p.gx = fmaf(p.o.x * isc, h, h);
+  p.gy = fmaf(p.o.y * isc, h, h);
+  p.gz = fmaf(p.o.z * isc, h, h);
+  return p;
+}
 
 // One tile of the backward.  Every return is workgroup-uniform.
 // LOSS: `grad_depth` is the OBSERVED depth image and the upstream gradient is formed on the fly,
 // go = +-k on the overlap mask (obs > 0) & (est > 0), k = weight * dL/dloss_b / count_b
 // (the gradient of simple_setup.py:129-135's masked mean of |est - obs|; 0 where est == obs).
-template <int RT, int SX, int SY, typename Hash, bool LOSS>
+// DET: deterministic d/dSDF (SDFR_SDF_GRAD_DETERMINISTIC): `g_sdf` is the 64-bit fixed-point volume, every
+// contribution is rounded ONCE, per pixel, to the fixed quantum 2^-kDetQuantumBits -- a function of the pixel alone,
+// not of its tile -- and everything after that is integer addition (64-bit LDS run table, 64-bit global atomics).
+constexpr int kDetQuantumBits = SDFR_FIXED_QUANTUM_BITS;
+template <int RT, int SX, int SY, typename Hash, bool LOSS, bool DET = false>
 __device__ __forceinline__ void backward_tile(
     BackwardLds<Hash>& lds, int tile_x, int tile_y, size_t record, int b, float loss_k,
     const float* __restrict__ grad_depth, const float* __restrict__ depth,
@@ -651,7 +710,6 @@ __device__ __forceinline__ void backward_tile(
     float* __restrict__ partials) {
   Hash& hash = lds.hash;
   float (*wave_part)[8] = lds.wave_part;
-  int& tile_max_bits = lds.tile_max_bits;
 
   constexpr int kSubs = SX * SY, kTileW = SX * kSubW, kTileH = SY * kSubH;
   using PB = Patch<kPatchWBwd>;
@@ -676,6 +734,11 @@ __device__ __forceinline__ void backward_tile(
     const int row = py0 + (sub / SX) * kSubH + PB::oy(wave) + PB::y(lane);
     zs[sub] = (col < W && row < H) ? zimg[(size_t)row * W + col] : 0.0f;  // (nt loads: +4 %, measured)
   }
+  if (tid == 0) {   // (ordered before the atomics below by the barrier of __syncthreads_or)
+    lds.tile_max_bits = 0;
+    lds.box[0] = lds.box[1] = lds.box[2] = 0x7fffffff;
+    lds.box[3] = lds.box[4] = lds.box[5] = -1;
+  }
   float gmax = 0.0f;
 #pragma unroll
   for (int sub = 0; sub < kSubs; ++sub) {
@@ -694,48 +757,89 @@ __device__ __forceinline__ void backward_tile(
     if (tid < 8) part[tid] = 0.0f;
     return;
   }
-#ifdef SDFR_STAMPS
-  unsigned long long* stamp__ = g_stamps + (record % 153600) * 16;
-#endif
-  SDFR_STAMP(0);   // the tile's depth (and upstream gradient) loads are back
-  hash.clear(tid, kBlock);
-  if (tid == 0) tile_max_bits = 0;
-  __syncthreads();
-  gmax = wave_max(gmax);
-  if (lane == 0) atomicMax(&tile_max_bits, __float_as_int(gmax));  // non-negative floats order as ints
-  __syncthreads();
-
-  SDFR_STAMP(1);   // table cleared, tile maximum known (2 barriers)
-  const float* vol = sdf + (size_t)b * sdf_view_stride;
-  float* gvol = g_sdf + (size_t)b * g_sdf_view_stride;
   const float h = 0.5f * (float)(Rr - 1);
   const float scale = s.scale, isc = s.isc;
-  // fixed-point scale: 2^(kFixedBits - e) with 2^e >= 2 * max|go| * scale  (power of two)
+  const float top = (float)(Rr - 2);
+  // bounds pass: the box of cells under this tile's hit pixels (clamped like the cell choice itself, cu:196-207, so
+  // the bounds are in [0, R - 2] whatever the depth image holds)
+  if (__ballot(any_hit) != 0ull) {
+    int lo0 = 0x7fffffff, lo1 = 0x7fffffff, lo2 = 0x7fffffff, hi0 = -1, hi1 = -1, hi2 = -1;
+#pragma unroll
+    for (int sub = 0; sub < kSubs; ++sub) {
+      if (zs[sub] == 0.0f) continue;
+      const int col = px0 + (sub % SX) * kSubW + PB::ox(wave) + PB::x(lane);
+      const int row = py0 + (sub / SX) * kSubH + PB::oy(wave) + PB::y(lane);
+      const HitPoint hp = hit_point(s, row, col, zs[sub], cx, cy, rfx, rfy, isc, h);
+      const int ix = (int)fminf(fmaxf(floorf(hp.gx), 0.0f), top);
+      const int iy = (int)fminf(fmaxf(floorf(hp.gy), 0.0f), top);
+      const int iz = (int)fminf(fmaxf(floorf(hp.gz), 0.0f), top);
+      lo0 = min(lo0, ix); lo1 = min(lo1, iy); lo2 = min(lo2, iz);
+      hi0 = max(hi0, ix); hi1 = max(hi1, iy); hi2 = max(hi2, iz);
+    }
+    lo0 = wave_min_to63(lo0); lo1 = wave_min_to63(lo1); lo2 = wave_min_to63(lo2);
+    hi0 = wave_max_to63(hi0); hi1 = wave_max_to63(hi1); hi2 = wave_max_to63(hi2);
+    const int gbits = wave_max_to63(__float_as_int(gmax));   // non-negative floats order as ints (NaN: above all)
+    if (lane == 63) {
+      atomicMin(&lds.box[0], lo0); atomicMin(&lds.box[1], lo1); atomicMin(&lds.box[2], lo2);
+      atomicMax(&lds.box[3], hi0); atomicMax(&lds.box[4], hi1); atomicMax(&lds.box[5], hi2);
+      atomicMax(&lds.tile_max_bits, gbits);
+    }
+  }
+  __syncthreads();
+  // the box in voxels: corners reach one past the last cell.  Workgroup-uniform -> scalar registers.
+  const int bx0 = __builtin_amdgcn_readfirstlane(lds.box[0]), by0 = __builtin_amdgcn_readfirstlane(lds.box[1]),
+            bz0 = __builtin_amdgcn_readfirstlane(lds.box[2]);
+  const int ny = __builtin_amdgcn_readfirstlane(lds.box[4]) - by0 + 2,
+            nz = __builtin_amdgcn_readfirstlane(lds.box[5]) - bz0 + 2;
+  const int nvox = (__builtin_amdgcn_readfirstlane(lds.box[3]) - bx0 + 2) * ny * nz;
+  const int tile_max_bits = __builtin_amdgcn_readfirstlane(lds.tile_max_bits);
+  const bool dense = !DET && nvox <= kDenseCap;
+  constexpr int kDenseBits = tile_fixed_bits(kSubs * kBlock, 22);
+  constexpr int kHashBits = HashIs32<Hash>::value ? tile_fixed_bits(kSubs * kBlock, Hash::kBits) : Hash::kBits;
+  if (dense) {
+    typedef int i32x4v __attribute__((ext_vector_type(4)));
+    i32x4v* d4 = reinterpret_cast<i32x4v*>(lds.dense);
+    for (int i = tid; i < (nvox + 3) >> 2; i += kBlock) d4[i] = i32x4v{0, 0, 0, 0};
+  } else {
+    hash.clear(tid, kBlock);
+  }
+  __syncthreads();
+
+  const float* vol = sdf + (size_t)b * sdf_view_stride;
+  float* gvol = g_sdf + (size_t)b * g_sdf_view_stride;
+  // fixed-point scale: 2^(bits - e) with 2^e >= 2 * max|go| * scale  (power of two)
   const float bound = 2.0f * __int_as_float(tile_max_bits) * fabsf(scale);
   int e2;
   (void)frexpf(bound, &e2);  // bound = m * 2^e2, m in [0.5, 1)  ->  2^e2 > bound
-  const bool fixed_ok = (bound > 0.0f) && (bound < 1e30f) && (e2 > -80);
-  const float to_fixed = fixed_ok ? ldexpf(1.0f, Hash::kBits - e2) : 0.0f;
-  const float from_fixed = fixed_ok ? ldexpf(1.0f, e2 - Hash::kBits) : 0.0f;
+  static_assert(!DET || !HashIs32<Hash>::value, "the deterministic mode needs 64-bit table sums");
+  const bool fixed_ok = DET || ((bound > 0.0f) && (bound < 1e30f) && (e2 > -80));
+  const int bits = dense ? kDenseBits : kHashBits;
+  const float to_fixed = DET ? (float)(1ll << kDetQuantumBits) : (fixed_ok ? ldexpf(1.0f, bits - e2) : 0.0f);
+  const float from_fixed = (fixed_ok && !DET) ? ldexpf(1.0f, e2 - bits) : 0.0f;
+  // scaled weights at or above the limit (extrapolating cells) bypass the table
+  const float weight_limit = DET ? 1.0e15f   /* < 2^50: fixed_from_float is exact below 2^51 */
+                             : dense ? (float)(1 << kDenseBits)
+                                     : (HashIs32<Hash>::value ? (float)(1 << (kHashBits < 30 ? kHashBits : 30)) : Hash::kWeightLimit);
+  // dense addressing: word = (ix * ny + iy) * nz + iz - c0, formed in float (exact: < 2^24)
+  const float f_nz = (float)nz, f_nynz = (float)(ny * nz);
+  const int c0 = (bx0 * ny + by0) * nz + bz0;
+  const int rel_max = nvox - (ny * nz + nz + 1) - 1;   // last word a cell's corner 000 may take
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 #pragma unroll
   for (int sub = 0; sub < kSubs; ++sub) {
-    const float z = zs[sub];
+    float z = zs[sub];
     if (z == 0.0f) continue;
+    asm volatile("" : "+v"(z));   // recompute below what the bounds pass computed, do not keep it in registers
     const int col = px0 + (sub % SX) * kSubW + PB::ox(wave) + PB::x(lane);
     const int row = py0 + (sub / SX) * kSubH + PB::oy(wave) + PB::y(lane);
     const float go = gos[sub];
-    const V3 d = pixel_ray(row, col, cx, cy, rfx, rfy);
-    const V3 dobj = rot_t(s, d);
-    const float t = z * __builtin_amdgcn_rcpf(-d.z);  // -z / d.z   (cu:339)
-    const V3 o = mk(fmaf(t, dobj.x, -s.e[0]), fmaf(t, dobj.y, -s.e[1]), fmaf(t, dobj.z, -s.e[2]));
+    const HitPoint hp = hit_point(s, row, col, z, cx, cy, rfx, rfy, isc, h);
+    const V3 d = hp.d, o = hp.o;
+    const float t = hp.t;
     Cell c;
-    gather_cell<RT>(vol, R, fmaf(o.x * isc, h, h), fmaf(o.y * isc, h, h), fmaf(o.z * isc, h, h), c);
+    gather_cell<RT>(vol, R, hp.gx, hp.gy, hp.gz, c);
     const float tri = trilerp(c);
-#ifdef SDFR_STAMPS
-    if (sub == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SDFR_STAMP(6); }   // grid gathers of sub-tile 0 back
-#endif
     // gradient of the trilinear value w.r.t. the cell coordinate
     const float ax = 1.0f - c.ox, ay = 1.0f - c.oy, az = 1.0f - c.oz;
     const float c00 = fmaf(c.v[4], c.ox, c.v[0] * ax), c01 = fmaf(c.v[5], c.ox, c.v[1] * ax);
@@ -787,16 +891,34 @@ __device__ __forceinline__ void backward_tile(
     // false): NaN reaches g_sdf as it does through the reference's atomicAdd.
     const float wmax = fmaxf(fmaxf(fmaxf(fabsf(w0), fabsf(w1)), fmaxf(fabsf(w2), fabsf(w3))),
                              fmaxf(fmaxf(fabsf(w4), fabsf(w5)), fmaxf(fabsf(w6), fabsf(w7))));
-#ifdef SDFR_STAMPS
-    if (sub == 0) SDFR_STAMP(7);   // derivative arithmetic and weights of sub-tile 0 done
-#endif
-    if (fixed_ok && wmax * to_fixed < Hash::kWeightLimit) {
+    if (fixed_ok && wmax * to_fixed < weight_limit) {
       const float wk[8] = {w0, w1, w2, w3, w4, w5, w6, w7};
-#ifdef SDFR_ABLATE_NO_SCATTER  // timing-only build
-      acc[7] += 1e-30f * (w0 + w1 + w2 + w3 + w4 + w5 + w6 + w7 + to_fixed);
-#else
-      hash.add_cell(gvol, c.lin, Rr, wk, to_fixed);
-#endif
+      if (dense) {
+        // word of corner 000 (the clamp cannot act -- the bounds pass saw this very cell -- and keeps every
+        // access inside the box whatever happens)
+        int rel = (int)fmaf(c.bx, f_nynz, fmaf(c.by, f_nz, c.bz)) - c0;
+        rel = min(max(rel, 0), rel_max);
+        int* p0 = lds.dense + rel;
+        int* p1 = p0 + ny * nz;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          // round to nearest through the mantissa: |w * to_fixed| < 2^22
+          const int q = __float_as_int(fmaf(wk[j], to_fixed, 12582912.0f)) - 0x4b400000;
+          int* p = ((j & 4) ? p1 : p0) + ((j & 2) ? nz : 0) + (j & 1);
+          atomicAdd(p, q);   // result unused: ds_add_u32, nothing to wait for
+        }
+      } else {
+        hash.template add_cell<DET>(gvol, c.lin, Rr, wk, to_fixed);
+      }
+    } else if (DET) {
+      // beyond the table's range (or not finite: the conversion saturates, NaN counts as 0 -- a 64-bit integer
+      // volume cannot carry them, include/sdfr.h)
+      unsigned long long* g0 = reinterpret_cast<unsigned long long*>(gvol) + c.lin;
+      const float wk[8] = {w0, w1, w2, w3, w4, w5, w6, w7};
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        atomicAdd(g0 + ((j & 4) ? Rr * Rr : 0) + ((j & 2) ? Rr : 0) + (j & 1),
+                  (unsigned long long)__float2ll_rn(wk[j] * to_fixed));
     } else {
       float* g0 = gvol + c.lin;
       atomicAdd(g0, w0);                atomicAdd(g0 + 1, w1);
@@ -804,12 +926,8 @@ __device__ __forceinline__ void backward_tile(
       atomicAdd(g0 + Rr * Rr, w4);      atomicAdd(g0 + Rr * Rr + 1, w5);
       atomicAdd(g0 + Rr * Rr + Rr, w6); atomicAdd(g0 + Rr * Rr + Rr + 1, w7);
     }
-#ifdef SDFR_STAMPS
-    if (sub == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); SDFR_STAMP(8); }   // table look-ups and adds of sub-tile 0 done
-#endif
   }
 
-  SDFR_STAMP(2);   // both sub-tiles done
   // pose sums: registers -> wave shuffle -> LDS -> macro-tile partial (a wave without a hit pixel
   // has nothing to reduce)
   if (__ballot(any_hit) != 0ull) {
@@ -821,28 +939,31 @@ __device__ __forceinline__ void backward_tile(
   __syncthreads();
   if (tid < 8) part[tid] = (wave_part[0][tid] + wave_part[1][tid]) + (wave_part[2][tid] + wave_part[3][tid]);
 
-  SDFR_STAMP(3);   // pose sums, barrier (= the slowest wave)
-  hash.flush(gvol, Rr * Rr * Rr, from_fixed, tid, kBlock);
-  SDFR_STAMP(4);   // flush issued
-#ifdef SDFR_STAMPS
-  __builtin_amdgcn_s_waitcnt(0);
-  SDFR_STAMP(5);   // flush acknowledged
-#endif
+  if (dense) {
+    // consecutive lanes take consecutive words = consecutive z of a box row: contiguous global float atomics
+    const unsigned m_nz = 0xffffffffu / (unsigned)nz + 1u, m_ny = 0xffffffffu / (unsigned)ny + 1u;   // exact for < 2^16
+    for (int i = tid; i < nvox; i += kBlock) {
+      const int q = lds.dense[i];
+      if (q == 0) continue;
+      const int rowi = (int)__umulhi((unsigned)i, m_nz), zz = i - rowi * nz;
+      const int xx = (int)__umulhi((unsigned)rowi, m_ny), yy = rowi - xx * ny;
+      const int lin = ((bx0 + xx) * Rr + by0 + yy) * Rr + bz0 + zz;
+      atomicAdd(gvol + lin, (float)q * from_fixed);
+    }
+  } else {
+    hash.template flush<DET>(gvol, Rr * Rr * Rr, from_fixed, tid, kBlock);
+  }
 }
 
 // Batches pre-sum in the z-pair run table (device.hpp, PairRunHash), small calls in 2-voxel runs x 1024 slots.
 // (Until the pair table, batches of low-resolution images took a 4 x 1024 run table of their own: 320x240
 // 117.6 -> 109.8 us, 160x120 107.1 -> 73.1 us per 256 views with the one pair table for all image sizes.)
-#if SDFR_BWD_PAIR_HASH
 using BatchTable = PairRunHash<SDFR_BWD_SLOTS>;
-#else
-using BatchTable = BatchHash;
-#endif
 
 // One tile of view b.  BATCH: workgroup (bx, by) of the view's own tiling -- 32 x 32 pixels or 64 x 8, chosen per
 // view by the set-up (ViewSetup::bwd_big; common.hpp, kBwdBigTile) -- otherwise the 32 x 8 tile (bx, by) of a
 // small call.  Returns are workgroup-uniform.
-template <int RT, bool BATCH, bool LOSS>
+template <int RT, bool BATCH, bool LOSS, bool DET = false>
 __device__ __forceinline__ void backward_dispatch(
     unsigned char* raw, int bx, int by, int ntx, int nty, int stride, int b,
     const float* __restrict__ grad_depth, const float* __restrict__ depth, const float* __restrict__ sdf, int R,
@@ -857,23 +978,24 @@ __device__ __forceinline__ void backward_dispatch(
     loss_k = cnt > 0.0f ? w / cnt : 0.0f;
   }
   if (BATCH) {
-    auto& lds = *reinterpret_cast<BackwardLds<BatchTable>*>(raw);
+    using Table = typename std::conditional<DET, BatchHash, BatchTable>::type;   // DET: 64-bit sums
+    auto& lds = *reinterpret_cast<BackwardLds<Table>*>(raw);
     const size_t record = (size_t)b * stride + by * ntx + bx;   // ntx = the 64 x 8 tiling's
     if (setup[b].bwd_big) {
       const int tx = 2 * bx + (by & 1), ty = by >> 1;
       if (tx >= kBwdBigTile.nx(W) || ty >= kBwdBigTile.ny(H)) return;
-      backward_tile<RT, kBwdBigTile.sx, kBwdBigTile.sy, BatchTable, LOSS>(
+      backward_tile<RT, kBwdBigTile.sx, kBwdBigTile.sy, Table, LOSS, DET>(
           lds, tx, ty, record, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx,
           rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
     } else {
       if (by >= nty) return;
-      backward_tile<RT, SDFR_MACRO_SX, SDFR_MACRO_SY, BatchTable, LOSS>(
+      backward_tile<RT, SDFR_MACRO_SX, SDFR_MACRO_SY, Table, LOSS, DET>(
           lds, bx, by, record, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx,
           rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
     }
   } else {
     auto& lds = *reinterpret_cast<BackwardLds<SmallHash>*>(raw);
-    backward_tile<RT, 1, 1, SmallHash, LOSS>(
+    backward_tile<RT, 1, 1, SmallHash, LOSS, DET>(
         lds, bx, by, ((size_t)b * nty + by) * ntx + bx, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride,
         setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
   }
@@ -891,7 +1013,7 @@ __device__ __forceinline__ void backward_dispatch(
 #else
 #define SDFR_BWD_OCC
 #endif
-template <int RT, bool BATCH, bool LOSS>
+template <int RT, bool BATCH, bool LOSS, bool DET = false>
 __global__ __launch_bounds__(kBlock) SDFR_BWD_OCC void render_backward_kernel(
     const float* __restrict__ grad_depth, const float* __restrict__ depth,
     const float* __restrict__ sdf, int R, long long sdf_view_stride,
@@ -899,9 +1021,11 @@ __global__ __launch_bounds__(kBlock) SDFR_BWD_OCC void render_backward_kernel(
     float rfx, float rfy, int sdf_grad_mode, float* __restrict__ g_sdf,
     long long g_sdf_view_stride, float* __restrict__ partials, const float* __restrict__ loss_grad,
     const float* __restrict__ loss_stats, float loss_weight) {
-  __shared__ __attribute__((aligned(16))) unsigned char raw[BATCH ? sizeof(BackwardLds<BatchTable>)
+  constexpr size_t kBatchLds = sizeof(BackwardLds<BatchTable>) > sizeof(BackwardLds<BatchHash>)
+                                   ? sizeof(BackwardLds<BatchTable>) : sizeof(BackwardLds<BatchHash>);
+  __shared__ __attribute__((aligned(16))) unsigned char raw[BATCH ? (DET ? kBatchLds : sizeof(BackwardLds<BatchTable>))
                                                                   : sizeof(BackwardLds<SmallHash>)];
-  backward_dispatch<RT, BATCH, LOSS>(raw, blockIdx.x, blockIdx.y, ntx, nty, stride, blockIdx.z,
+  backward_dispatch<RT, BATCH, LOSS, DET>(raw, blockIdx.x, blockIdx.y, ntx, nty, stride, blockIdx.z,
                                      grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy,
                                      sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, loss_grad, loss_stats,
                                      loss_weight);
@@ -932,6 +1056,13 @@ __global__ __launch_bounds__(kBlock) void render_backward_pc_kernel(
   backward_dispatch<RT, BATCH, true>(raw, blockIdx.x, (int)blockIdx.y - pc_rows, ntx, nty, stride, b, target, depth,
                                      sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf,
                                      g_sdf_view_stride, partials, loss_grad, loss_stats, loss_weight);
+}
+
+// deterministic mode: the 64-bit fixed-point volume -> float (one rounding per voxel)
+__global__ __launch_bounds__(256) void fixed_to_float_kernel(const long long* __restrict__ fixed, size_t n,
+                                                             float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (float)fixed[i] * (1.0f / (float)(1ll << kDetQuantumBits));
 }
 
 // Fixed-order sum of a view's tile partials: one wave per view.  stride > 0: a batch backward (the view's own
@@ -1028,16 +1159,22 @@ bool use_packed(int R, int B, long long sdf_view_stride) {
   return sdf_view_stride == 0 && B >= kPackedMinViews && R <= kPackedMaxR;
 }
 size_t packed_bytes(int R) { return (size_t)R * record_slab(R) * 4 * sizeof(float); }
-// the prologue's sync region: 128-byte header (epoch) + 3R plane-minimum entries of 16 bytes
-size_t plane_bytes(int R) {
-  return (size_t)kSyncHeaderWords * 4 + (((size_t)6 * R * sizeof(PlaneEntry) + 127) & ~(size_t)127);
-}
-// A step (sdfr_render_step_forward + sdfr_render_step_backward) keeps everything side by side in one workspace:
-// [view records][sync region][face records][tile partials of the backward]
-size_t step_sync_offset(int B) { return setup_bytes(B); }
-size_t step_cells_offset(int R, int B) { return step_sync_offset(B) + plane_bytes(R); }
-size_t step_partials_offset(int R, int B) {
-  return step_cells_offset(R, B) + ((R >= 2 && R <= kPackedMaxR) ? packed_bytes(R) : 0);
+// Workspace layouts (common.hpp, kSyncBytes): [view records][sync region] and then
+//   forward        [face records]            (+ [loss records] for the depth-L1 form)
+//   backward       [tile partials]
+//   step           [face records][tile partials]
+size_t sync_offset(int B) { return setup_bytes(B); }
+size_t scratch_offset(int B) { return setup_bytes(B) + kSyncBytes; }
+size_t cells_bytes(int R) { return (R >= 2 && R <= kPackedMaxR) ? packed_bytes(R) : 0; }
+size_t step_partials_offset(int R, int B) { return scratch_offset(B) + cells_bytes(R); }
+// deterministic d/dSDF: a 64-bit fixed-point volume behind the tile partials (grids up to kDetMaxR)
+constexpr int kDetMaxR = 128;
+size_t fixed_bytes(int R) { return (R >= 2 && R <= kDetMaxR) ? (size_t)R * R * R * sizeof(long long) : 0; }
+size_t partials_bytes(int B, int W, int H) {
+  if (B <= 0 || W <= 0 || H <= 0) return 0;
+  // one 32-byte record per tile of the finer geometry (or per workgroup of a batch launch)
+  const size_t small = (size_t)kSmallTile.nx(W) * kSmallTile.ny(H), batch = (size_t)backward_tile_stride(W, H);
+  return (size_t)B * (small > batch ? small : batch) * 8 * sizeof(float);
 }
 #ifndef SDFR_FUSED_PROLOGUE
 #define SDFR_FUSED_PROLOGUE 1  // 0: pack + plane minima and the view set-up as two launches (timing experiments)
@@ -1050,9 +1187,30 @@ using namespace sdfr;
 
 extern "C" size_t sdfr_render_forward_workspace_bytes(int R, int B, int W, int H) {
   (void)W; (void)H;
-  size_t n = setup_bytes(B);
-  if (R >= 2 && R <= kPackedMaxR) n += packed_bytes(R) + plane_bytes(R);
-  return n;
+  return scratch_offset(B) + cells_bytes(R);
+}
+
+extern "C" size_t sdfr_render_sync_offset(int B) { return sync_offset(B); }
+
+extern "C" size_t sdfr_render_fixed_volume_offset(int R, int B, int W, int H, int step_layout) {
+  if (R < 2 || B <= 0) return 0;
+  return (step_layout ? step_partials_offset(R, B) : scratch_offset(B)) + partials_bytes(B, W, H);
+}
+
+extern "C" int sdfr_fixed_to_float(const long long* fixed, size_t n, float* out, int device, void* stream) {
+  if (n == 0) return 0;
+  if (!fixed || !out) return fail(SDFR_E_NULL, "sdfr_fixed_to_float: NULL pointer argument");
+  SDFR_HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fixed,
+                     n, out);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfr_debug_set_prologue_polls(int max_polls) {
+  const int old = g_prologue_max_polls.load(std::memory_order_relaxed);
+  g_prologue_max_polls.store(max_polls < 0 ? kPrologueMaxPolls : max_polls, std::memory_order_relaxed);
+  return old;
 }
 
 extern "C" size_t sdfr_render_forward_l1_workspace_bytes(int R, int B, int W, int H) {
@@ -1064,20 +1222,12 @@ extern "C" size_t sdfr_render_forward_l1_workspace_bytes(int R, int B, int W, in
 
 extern "C" size_t sdfr_render_step_workspace_bytes(int R, int B, int W, int H) {
   if (R < 2 || B <= 0) return 256;
-  size_t n = step_partials_offset(R, B);
-  if (W > 0 && H > 0) {
-    const size_t small = (size_t)kSmallTile.nx(W) * kSmallTile.ny(H), batch = (size_t)backward_tile_stride(W, H);
-    n += (size_t)B * (small > batch ? small : batch) * 8 * sizeof(float);
-  }
-  return n;
+  return step_partials_offset(R, B) + partials_bytes(B, W, H) + fixed_bytes(R);
 }
 
 extern "C" size_t sdfr_render_backward_workspace_bytes(int R, int B, int W, int H) {
-  (void)R;
-  if (B <= 0 || W <= 0 || H <= 0) return setup_bytes(B);
-  // partial sums: one 32-byte record per tile of the finer geometry (or per workgroup of a batch launch)
-  const size_t small = (size_t)kSmallTile.nx(W) * kSmallTile.ny(H), batch = (size_t)backward_tile_stride(W, H);
-  return setup_bytes(B) + (size_t)B * (small > batch ? small : batch) * 8 * sizeof(float);
+  if (B <= 0 || W <= 0 || H <= 0) return scratch_offset(B);
+  return scratch_offset(B) + partials_bytes(B, W, H) + fixed_bytes(R);
 }
 
 namespace {
@@ -1085,15 +1235,15 @@ namespace {
 struct ForwardLayout {
   ViewSetup* setup;
   float* cells;      // face records (packed_bytes)
-  unsigned* sync;    // prologue sync region (plane_bytes): epoch + plane-minimum entries
+  unsigned* sync;    // sync region (kSyncBytes): epoch, fallback count, plane-minimum entries
   float* loss_part;  // LOSS: (sum, count) per tile
 };
 ForwardLayout plain_forward_layout(void* workspace, int R, int B, int W, int H) {
   char* w = (char*)workspace;
   ForwardLayout l;
   l.setup = (ViewSetup*)w;
-  l.cells = (float*)(w + setup_bytes(B));  // 128-byte aligned
-  l.sync = (unsigned*)((char*)l.cells + packed_bytes(R));
+  l.sync = (unsigned*)(w + sync_offset(B));
+  l.cells = (float*)(w + scratch_offset(B));  // 128-byte aligned
   l.loss_part = (float*)(w + ((sdfr_render_forward_workspace_bytes(R, B, W, H) + 127) & ~(size_t)127));
   return l;
 }
@@ -1134,7 +1284,7 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
     const int n_pack = (R * R * R + 255) / 256, n_setup = (B + 3) / 4;
     hipLaunchKernelGGL(forward_prologue_kernel, dim3(3 * R + n_setup + n_pack), dim3(256), 0, st, sdf, R,
                        (float4*)cells, 3 * R, n_setup, lay.sync, pos, quat, inv_scale, B, W, H, cx, cy, fx, fy,
-                       setup, threshold, g_zero, n_zero);
+                       setup, threshold, g_zero, n_zero, g_prologue_max_polls.load(std::memory_order_relaxed));
     epoch = lay.sync;
   } else if (g_zero && !packed) {
     // a step over a few views (or with one grid per view): zero fill + set-up in ONE launch -- the stand-alone
@@ -1239,8 +1389,13 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
     return fail(SDFR_E_INVALID, "sdf_view_stride must be 0 or >= R^3");
   if (g_sdf_view_stride != 0 && g_sdf_view_stride != vox)
     return fail(SDFR_E_INVALID, "g_sdf_view_stride must be 0 or R^3");
+  const bool det = (sdf_grad_mode & SDFR_SDF_GRAD_DETERMINISTIC) != 0;
+  sdf_grad_mode &= ~SDFR_SDF_GRAD_DETERMINISTIC;
   if (sdf_grad_mode != SDFR_SDF_GRAD_EXACT && sdf_grad_mode != SDFR_SDF_GRAD_CUDA_COMPAT)
     return fail(SDFR_E_INVALID, "unknown sdf_grad_mode %d", sdf_grad_mode);
+  if (det && (g_sdf_view_stride != 0 || R > kDetMaxR || loss_stats || pc))
+    return fail(SDFR_E_INVALID, "%s: SDFR_SDF_GRAD_DETERMINISTIC needs one shared gradient volume "
+                "(g_sdf_view_stride = 0), R <= %d and the plain (not loss-fused) backward", fn, kDetMaxR);
   if (!g_sdf) return fail(SDFR_E_NULL, "%s: g_sdf is NULL", fn);
   SDFR_HIP_TRY(hipSetDevice(device));
   hipStream_t st = (hipStream_t)stream;
@@ -1271,13 +1426,21 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
   if ((uintptr_t)workspace % alignof(ViewSetup))
     return fail(SDFR_E_INVALID, "workspace must be %zu-byte aligned", alignof(ViewSetup));
   ViewSetup* setup = (ViewSetup*)workspace;
-  float* partials = (float*)((char*)workspace + (prepared ? step_partials_offset(R, B) : setup_bytes(B)));
+  float* partials = (float*)((char*)workspace + (prepared ? step_partials_offset(R, B) : scratch_offset(B)));
   // (a stand-alone backward does not know the forward's threshold, so its rectangles are those of the full cube;
   // depth is 0 outside the forward's may-hit rectangle anyway.  A step's backward culls with the forward's own,
   // tighter rectangles and launches no prologue.)
   if (!prepared)
     hipLaunchKernelGGL(backward_prologue_kernel, dim3((unsigned)((std::max(g_words, (size_t)B) + 255) / 256)),
                        dim3(256), 0, st, g_sdf, g_words, pos, quat, inv_scale, B, R, W, H, cx, cy, fx, fy, setup);
+  // deterministic mode: the image kernel adds integers into the workspace's 64-bit volume, converted at the end
+  long long* fixed = nullptr;
+  float* g_out = g_sdf;
+  if (det) {
+    fixed = (long long*)((char*)partials + partials_bytes(B, W, H));
+    zero_words_async((float*)fixed, (size_t)vox * 2, st);
+    g_sdf = (float*)fixed;
+  }
   // batch: `stride` workgroups per view, each view in its own tiling (common.hpp, kBwdBigTile); else 32 x 8 tiles
   const TileGeom geom = backward_geom(B, W, H);
   const bool batch = geom.sx * geom.sy > 1;
@@ -1298,6 +1461,9 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
     else if (with_loss)                                                                              \
       hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, true>), grid_tile, dim3(kBlock), 0, st,  \
                          SDFR_BWD_ARGS);                                                             \
+    else if (det)                                                                                    \
+      hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false, true>), grid_tile, dim3(kBlock), 0, st, \
+                         SDFR_BWD_ARGS);                                                             \
     else                                                                                             \
       hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false>), grid_tile, dim3(kBlock), 0, st, \
                          SDFR_BWD_ARGS);                                                             \
@@ -1309,6 +1475,9 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
   if (!deferred)
     hipLaunchKernelGGL(pose_reduce_kernel, dim3(B), dim3(64), 0, st, partials, setup, W, H, ntx, nty,
                        geom.w(), geom.h(), stride, g_pos, g_quat, g_inv_scale);
+  if (det)
+    hipLaunchKernelGGL(fixed_to_float_kernel, dim3((unsigned)((vox + 255) / 256)), dim3(256), 0, st, fixed,
+                       (size_t)vox, g_out);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1341,8 +1510,8 @@ extern "C" int sdfr_render_step_forward(const float* sdf, int R, long long sdf_v
   if (workspace && R >= 2 && R <= 1023 && B > 0) {
     char* w = (char*)workspace;
     lay.setup = (ViewSetup*)w;
-    lay.sync = (unsigned*)(w + step_sync_offset(B));
-    lay.cells = (float*)(w + step_cells_offset(R, B));
+    lay.sync = (unsigned*)(w + sync_offset(B));
+    lay.cells = (float*)(w + scratch_offset(B));
     lay.loss_part = nullptr;
   }
   const size_t g_words = (R >= 2 && R <= 1023) ? (size_t)vox * (g_sdf_view_stride ? (size_t)(B > 0 ? B : 1) : 1) : 0;
@@ -1416,15 +1585,3 @@ extern "C" int sdfr_render_backward_l1_pc(
                        sdf_grad_mode, g_sdf, g_sdf_view_stride, nullptr, nullptr, nullptr, loss_grad, loss_stats,
                        loss_weight, workspace, workspace_bytes, device, stream, &pa);
 }
-
-#ifdef SDFR_STAMPS
-extern "C" __attribute__((visibility("default"))) int sdfr_debug_stamps(unsigned long long* h_out, int reset) {
-  if (hipMemcpyFromSymbol(h_out, HIP_SYMBOL(sdfr::g_stamps), sizeof(unsigned long long) * 153600 * 16) != hipSuccess) return 1;
-  if (reset) {
-    void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(sdfr::g_stamps)) != hipSuccess) return 2;
-    if (hipMemset(p, 0, sizeof(unsigned long long) * 153600 * 16) != hipSuccess) return 3;
-  }
-  return 0;
-}
-#endif

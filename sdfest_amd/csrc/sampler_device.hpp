@@ -9,14 +9,7 @@ namespace sdfr {
 namespace {
 
 constexpr int kPts = kSamplerPts;  // points per workgroup
-#ifndef SDFR_SAMPLER_PAIR
-#define SDFR_SAMPLER_PAIR 1  // 0: plain 4-voxel runs (timing experiments)
-#endif
-#if SDFR_SAMPLER_PAIR
 using SamplerHash = PairRunHash<512>;   // z-pair runs: one LDS add per column of a cell (device.hpp)
-#else
-using SamplerHash = BatchHash;
-#endif
 
 struct PointFrame {
   float qn[4];

@@ -39,6 +39,12 @@ class Camera:
         return self.fx, self.fy, self.cx + shift, self.cy + shift, self.s
 
 
+# sdf_grad_mode values (include/sdfr.h)
+SDF_GRAD_EXACT = 0
+SDF_GRAD_CUDA_COMPAT = 1
+SDF_GRAD_DETERMINISTIC = 0x100    # flag bit: integer accumulation of d/dSDF, bitwise reproducible
+FIXED_QUANTUM_BITS = 40
+
 _ws_lock = threading.Lock()
 _ws_cache = {}
 
@@ -413,12 +419,18 @@ class BatchRenderPlan:
         # a step (forward(..., prepare_backward=True) + backward) zero-fills the NEXT gradient volume in the
         # forward's prologue: `grad_volumes` volumes take turns, so the g_sdf of the previous grad_volumes - 1
         # steps (e.g. still being all-reduced) are not touched by the next forward
-        self._g_sdf_ring = [self.g_sdf] + [torch.empty_like(self.g_sdf) for _ in range(grad_volumes - 1)]
-        self._g_sdf_next = 1
+        # (one contiguous buffer, ``grad_ring``: several steps' volumes can then go into ONE all-reduce)
+        self.grad_ring = torch.empty((grad_volumes,) + tuple(self.g_sdf.shape), **f32)
+        self._g_sdf_ring = list(self.grad_ring.unbind(0))
+        self.g_sdf = self._g_sdf_ring[-1]
+        self._g_sdf_next = 0
         self._step = None   # what the last forward prepared: (tensor ids / versions, depth tensor)
+        self._fixed_layout = None   # deterministic mode: which workspace layout holds the last int64 volume
         self.loss = torch.empty((B,), **f32)
         self.loss_stats = torch.empty((B, 2), **f32)
-        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        # zero-filled once: the sync region's counter of prologue fall-backs (include/sdfr.h) then counts from 0
+        self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        self._sync_offset = L.sdfr_render_sync_offset(B)
         self._L = L
         self._shape_sdf = (B, R, R, R) if per_view_sdf else (R, R, R)
         self._shape_pos, self._shape_quat, self._shape_isc = (B, 3), (B, 4), (B,)
@@ -452,6 +464,17 @@ class BatchRenderPlan:
                 raise RuntimeError(f"{name} is on {t.device}, the plan on {self.device}")
             if tuple(t.shape) != want[name]:
                 raise RuntimeError(f"{name} must have shape {want[name]}, got {tuple(t.shape)}")
+
+    def ring_reset(self) -> None:
+        """The next step writes ``grad_ring[0]`` again (a caller that exchanges halves of the ring aligns them)."""
+        self._g_sdf_next = 0
+        self._step = None
+
+    def prologue_fallbacks(self) -> int:
+        """How many view set-ups of this plan's forwards so far had to do without the grid's plane minima
+        (``include/sdfr.h``, sync region word 1; synchronises).  0 unless the prologue launch was serialised."""
+        o = self._sync_offset + 4
+        return int(self.workspace[o:o + 4].view(torch.int32).item())
 
     @staticmethod
     def _key(sdf, pos, quat, inv_scale):
@@ -497,7 +520,11 @@ class BatchRenderPlan:
         ``sdfr_views_to_pose_grad_deferred`` (include/sdfr.h); g_pos / g_quat / g_inv_scale are then not written.
 
         After ``forward(..., prepare_backward=True)`` on the same (unmodified) tensors this is the step's
-        backward; any other call in between, or different inputs, falls back to the stand-alone backward."""
+        backward; any other call in between, or different inputs, falls back to the stand-alone backward.
+        "Unmodified" is judged by address and torch's version counter: a tensor updated through its raw pointer
+        between the two halves (``sdfr_adam_step``, ``sdfr_pose_to_views``) looks unmodified, and the step's
+        backward would then use the view records of the forward's poses -- do not update poses or the grid
+        between the halves of a step."""
         self._check(sdf, pos, quat, inv_scale, grad_depth=grad_depth)
         step, self._step = self._step, None
         if step is not None and not defer_pose and step[0] == self._key(sdf, pos, quat, inv_scale):
@@ -511,9 +538,17 @@ class BatchRenderPlan:
             _lib.check(rc, "sdfr_render_step_backward")
             self.g_sdf = g_sdf
             self._g_sdf_next = (self._g_sdf_next + 1) % len(self._g_sdf_ring)
+            self._fixed_layout = 1
             return self.g_sdf, self.g_pos, self.g_quat, self.g_inv_scale
+        depth = self.depth
+        if step is not None:
+            # a prepared step whose backward cannot run as such (other tensors, or deferred pose sums): the
+            # stand-alone backward, but into the volume the forward prepared -- the previous step's volume may
+            # still be in an asynchronous all-reduce -- and of the images that forward rendered
+            _, depth, self.g_sdf = step
+            self._g_sdf_next = (self._g_sdf_next + 1) % len(self._g_sdf_ring)
         rc = self._L.sdfr_render_backward(
-            grad_depth.data_ptr(), self.depth.data_ptr(), sdf.data_ptr(), self.R, self.sdf_stride,
+            grad_depth.data_ptr(), depth.data_ptr(), sdf.data_ptr(), self.R, self.sdf_stride,
             pos.data_ptr(), quat.data_ptr(), inv_scale.data_ptr(), self.B, self.W, self.H,
             self.cx, self.cy, self.fx, self.fy, self.sdf_grad_mode, self.g_sdf.data_ptr(),
             self.sdf_stride, None if defer_pose else self.g_pos.data_ptr(),
@@ -521,7 +556,19 @@ class BatchRenderPlan:
             None if defer_pose else self.g_inv_scale.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(),
             self.device.index, _stream(self.device))
         _lib.check(rc, "sdfr_render_backward")
+        self._fixed_layout = 0
         return self.g_sdf, self.g_pos, self.g_quat, self.g_inv_scale
+
+    def g_sdf_fixed(self) -> torch.Tensor:
+        """After a backward in the deterministic mode (``sdf_grad_mode | SDF_GRAD_DETERMINISTIC``): the int64
+        (R,R,R) volume in the workspace that ``g_sdf`` was converted from, ``g_sdf = volume * 2**-40``.  The
+        ranks of a sharded batch add THESE (integer addition: any order, any grouping gives the same bits) and
+        convert afterwards: ``sdfest_amd.parallel.allreduce_fixed_gradients``."""
+        if not (self.sdf_grad_mode & SDF_GRAD_DETERMINISTIC) or self._fixed_layout is None:
+            raise RuntimeError("g_sdf_fixed() needs a backward in the deterministic mode")
+        off = self._L.sdfr_render_fixed_volume_offset(self.R, self.B, self.W, self.H, self._fixed_layout)
+        n = self.R ** 3 * 8
+        return self.workspace[off:off + n].view(torch.int64).view(self.R, self.R, self.R)
 
     def forward_l1(self, sdf, pos, quat, inv_scale, threshold: float, target):
         """forward + masked depth-L1 against ``target`` (B,H,W): returns (depth, loss (B,))."""

@@ -66,6 +66,25 @@ def allreduce_shared_gradients(g_sdf: torch.Tensor,
     return g_sdf
 
 
+def allreduce_fixed_gradients(fixed: torch.Tensor, out: torch.Tensor, group=None) -> torch.Tensor:
+    """Deterministic mode (``SDF_GRAD_DETERMINISTIC``): sum the ranks' int64 fixed-point d/dSDF volumes
+    (``BatchRenderPlan.g_sdf_fixed()``) with ONE all-reduce and convert the sum to float into ``out``
+    (``sdfr_fixed_to_float``).  Integer addition is associative, so the result is bitwise the same for every
+    split of the views over ranks -- and the same as a single process rendering all of them."""
+    from . import _lib
+    dist = _dist()
+    if fixed.dtype != torch.int64 or not fixed.is_contiguous() or not fixed.is_cuda:
+        raise RuntimeError("fixed must be a contiguous int64 CUDA tensor")
+    if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != fixed.numel() or out.device != fixed.device:
+        raise RuntimeError("out must be a contiguous float32 tensor of the same size on the same device")
+    if dist is not None:
+        dist.all_reduce(fixed, op=dist.ReduceOp.SUM, group=group)
+    rc = _lib.lib().sdfr_fixed_to_float(fixed.data_ptr(), fixed.numel(), out.data_ptr(), fixed.device.index,
+                                        torch.cuda.current_stream(fixed.device).cuda_stream)
+    _lib.check(rc, "sdfr_fixed_to_float")
+    return out
+
+
 def spawn_ranks(cmd: Sequence[str], world_size: int, master_port: Optional[int] = None,
                 env: Optional[dict] = None, timeout: Optional[float] = None) -> int:
     """Start `world_size` fresh processes of `cmd`, one per GPU, with the torch.distributed

@@ -12,12 +12,13 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sdfest_amd import BatchRenderPlan, Camera                       # noqa: E402
-from sdfest_amd.parallel import allreduce_shared_gradients, shard_views  # noqa: E402
+from sdfest_amd.parallel import allreduce_fixed_gradients, allreduce_shared_gradients, shard_views  # noqa: E402
 from sdfest_amd.synthetic import blobs_sdf, random_poses              # noqa: E402
 
 
 def main():
     out_path, n_views, W, H = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    det = len(sys.argv) > 5 and sys.argv[5] == "det"   # SDF_GRAD_DETERMINISTIC: integer exchange
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -28,11 +29,14 @@ def main():
     sdf = t(blobs_sdf(0))
     g_all = torch.rand((n_views, H, W), generator=torch.Generator().manual_seed(77)) * 2 - 1
     cam = Camera(W, H, W / 2.0, W / 2.0, W / 2.0, H / 2.0, pixel_center=0.5)
-    plan = BatchRenderPlan(64, e - b, cam, device=dev)
+    plan = BatchRenderPlan(64, e - b, cam, device=dev, sdf_grad_mode=0x100 if det else 0)
     depth = plan.forward(sdf, t(pos[b:e]), t(quat[b:e]), t(isc[b:e]), 0.005).clone()
     g_sdf, g_pos, g_quat, g_is = plan.backward(g_all[b:e].to(dev).contiguous(), sdf, t(pos[b:e]), t(quat[b:e]), t(isc[b:e]))
-    handle = allreduce_shared_gradients(g_sdf, async_op=True)   # the form bench.py uses
-    handle.wait()
+    if det:
+        allreduce_fixed_gradients(plan.g_sdf_fixed(), g_sdf)   # int64 sum over the ranks, then one conversion
+    else:
+        handle = allreduce_shared_gradients(g_sdf, async_op=True)
+        handle.wait()
     torch.cuda.synchronize()
     # per-view outputs stay on their rank; gather them only for the comparison
     parts = [None] * world

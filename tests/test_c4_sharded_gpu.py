@@ -38,3 +38,28 @@ def test_two_ranks_equal_one_process(tmp_path, n_views, W, H):
     # the shared gradient: sum over ranks == the single launch, up to the order of float atomics
     ref = g_sdf.cpu().numpy()
     assert np.max(np.abs(ref - r["g_sdf"])) <= 1e-5 * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("n_views,W,H", [(9, 320, 240)])
+def test_two_ranks_equal_one_process_bitwise_in_the_deterministic_mode(tmp_path, n_views, W, H):
+    """SDFR_SDF_GRAD_DETERMINISTIC: the ranks add their int64 fixed-point volumes and convert afterwards -- the shared
+    gradient is then BITWISE the single-process result, whatever the split."""
+    from sdfest_amd import BatchRenderPlan, Camera
+    from sdfest_amd.parallel import spawn_ranks
+    from sdfest_amd.synthetic import blobs_sdf, random_poses
+    out = str(tmp_path / "c4det.npz")
+    rc = spawn_ranks([sys.executable, os.path.join(HERE, "_c4_worker.py"), out, str(n_views), str(W), str(H), "det"],
+                     2, timeout=240)
+    assert rc == 0
+    r = np.load(out)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    pos, quat, isc = random_poses(n_views, seed=1, width=W, height=H, f=W / 2.0)
+    sdf = t(blobs_sdf(0))
+    g_all = (torch.rand((n_views, H, W), generator=torch.Generator().manual_seed(77)) * 2 - 1).to(dev)
+    cam = Camera(W, H, W / 2.0, W / 2.0, W / 2.0, H / 2.0, pixel_center=0.5)
+    plan = BatchRenderPlan(64, n_views, cam, device=dev, sdf_grad_mode=0x100)
+    plan.forward(sdf, t(pos), t(quat), t(isc), 0.005)
+    g_sdf = plan.backward(g_all.contiguous(), sdf, t(pos), t(quat), t(isc))[0]
+    ref = g_sdf.cpu().numpy()
+    assert np.abs(ref).max() > 0 and np.array_equal(ref, r["g_sdf"])

@@ -1,0 +1,71 @@
+"""GPU: the PLAIN relative error of the pose gradients where the pixel sum is well conditioned (round-2 verdict:
+the suite's yardstick `1e-4 x sum |per-pixel term|` is an fp32-summation bound, not "1e-4 relative").  A component
+is well conditioned when |sum| > 0.1 sum |terms|; on those the HIP gradient must agree with the float64 oracle
+(evaluated on the HIP depth image, as the reference's backward is evaluated on its own forward's output:
+sdf_renderer_cuda.cu:334-467, simple_renderer.py:317-458) to 1e-4 of its own magnitude, at C1, C2 and C3."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+
+
+def check(plan, views, d_hip, g_np, sdf_np, pos, quat, isc, W, H, f, name):
+    ref = oracle.render_backward(g_np[views], d_hip[views], sdf_np, pos[views], quat[views], isc[views], W / 2, H / 2,
+                                 f, f, dtype=np.float64)
+    dimg = oracle.render_derivative_images(d_hip[views], sdf_np, pos[views], quat[views], isc[views], W / 2, H / 2, f,
+                                           f, dtype=np.float64)
+    l1 = np.abs(dimg * g_np[views][:, :, :, None]).sum(axis=(1, 2))
+    hip = np.concatenate([plan.g_pos.cpu().numpy()[views], plan.g_quat.cpu().numpy()[views],
+                          plan.g_inv_scale.cpu().numpy()[views][:, None]], axis=1).astype(np.float64)
+    rp = np.concatenate([ref[1], ref[2], ref[3][:, None]], axis=1)
+    well = np.abs(rp) > 0.1 * l1
+    assert well.sum() >= max(2, len(views)), f"{name}: too few well-conditioned components ({well.sum()})"
+    rel = np.abs(hip - rp)[well] / np.abs(rp[well])
+    assert rel.max() <= 1e-4, f"{name}: plain relative error {rel.max():.3e} on a well-conditioned component"
+    # and the summation bound everywhere
+    assert np.all(np.abs(hip - rp) <= 1e-4 * l1), name
+    return rel.max(), int(well.sum())
+
+
+@pytest.mark.parametrize("name,W,H", [("C1", 160, 120), ("C2", 640, 480)])
+def test_single_view_configs(name, W, H):
+    from sdfest_amd import BatchRenderPlan, Camera
+    f = W / 2.0
+    cam = Camera(W, H, f, f, W / 2.0, H / 2.0, pixel_center=0.5)
+    sdf_np = oracle.blobs_sdf(0)
+    pos, quat, isc = np.array([[0, 0, -1.5]], np.float32), np.array([[0, 0, 0, 1]], np.float32), np.array([2.0], np.float32)
+    g_np = np.random.default_rng(0).uniform(-1, 1, (1, H, W)).astype(np.float32)
+    plan = BatchRenderPlan(64, 1, cam)
+    sdf = dev(sdf_np)
+    d = plan.forward(sdf, dev(pos), dev(quat), dev(isc), 0.005, prepare_backward=True)
+    plan.backward(dev(g_np), sdf, dev(pos), dev(quat), dev(isc))
+    check(plan, [0], d.cpu().numpy(), g_np, sdf_np, pos.astype(np.float64), quat.astype(np.float64),
+          isc.astype(np.float64), W, H, f, name)
+
+
+def test_c3_batch():
+    from sdfest_amd import BatchRenderPlan, Camera
+    B, W, H, f = 256, 640, 480, 320.0
+    cam = Camera(W, H, f, f, W / 2.0, H / 2.0, pixel_center=0.5)
+    sdf_np = oracle.blobs_sdf(0)
+    pos, quat, isc = oracle.random_poses(B, seed=1, width=W, height=H, f=f)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234)
+    g = torch.rand((B, H, W), device="cuda", generator=gen) * 2 - 1
+    plan = BatchRenderPlan(64, B, cam)
+    sdf = dev(sdf_np)
+    pose = (dev(pos), dev(quat), dev(isc))
+    d = plan.forward(sdf, *pose, 0.005, prepare_backward=True)
+    plan.backward(g, sdf, *pose)
+    views = list(range(8))
+    d_hip = d[:8].cpu().numpy()
+    g_np = g[:8].cpu().numpy()
+    check(plan, views, d_hip, g_np, sdf_np, pos.astype(np.float64), quat.astype(np.float64), isc.astype(np.float64),
+          W, H, f, "C3")

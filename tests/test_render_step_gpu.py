@@ -126,9 +126,10 @@ def test_backward_after_changed_inputs_is_the_standalone_call():
     sdf = dev(oracle.blobs_sdf(0))
     p_step.forward(sdf, *pose, 0.005, prepare_backward=True)
     pose[0].add_(0.0)                       # an in-place write: not the tensors the forward prepared any more
-    before = p_step.g_sdf
+    prepared = p_step._step[2]              # the volume the forward zero-filled
     out = p_step.backward(g, sdf, *pose)
-    assert p_step.g_sdf is before           # stand-alone path: the volume did not alternate
+    # stand-alone path, but into the volume the forward prepared (the previous one may still be in an exchange)
+    assert p_step._step is None and p_step.g_sdf is prepared and out[0] is prepared
     ref = run_separate(p_ref, sdf, pose, g)
     assert rel_err(out[1].cpu().numpy(), ref[1][1].cpu().numpy()) <= 2e-5 and rel_err(out[0].cpu().numpy(), ref[1][0].cpu().numpy()) <= 1e-5
 
@@ -201,3 +202,57 @@ def test_autograd_functions_run_the_step_and_survive_a_second_backward():
         assert calls["step"] == 3
     finally:
         dr.step_backward_raw = orig_step
+
+
+def test_plain_calls_sharing_one_workspace_with_a_changing_grid():
+    """Round-2 advisor finding: plain forward + stand-alone backward on ONE workspace, 256 views of 640x480 (the
+    backward's tile partials then cover everything behind the view records), a different grid every step.  The
+    forward's set-up must never build its may-hit boxes from an earlier call's plane minima: depth equals a
+    render on a fresh workspace, bit for bit.  (The sync region now has one place in every layout and the forward
+    wipes its entries after use.)"""
+    from sdfest_amd import BatchRenderPlan, Camera
+    B, W, H, f = 256, 640, 480, 320.0
+    cam = Camera(W, H, f, f, W / 2.0, H / 2.0, pixel_center=0.5)
+    pos, quat, isc = oracle.random_poses(B, seed=1, width=W, height=H, f=f)
+    pose = (dev(pos), dev(quat), dev(isc))
+    g = torch.rand((B, H, W), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)) * 2 - 1
+    shared = BatchRenderPlan(64, B, cam)
+    base = oracle.blobs_sdf(0)
+    # grids whose surfaces differ a lot: a box built from the previous grid would cull rays of this one
+    grids = [base, np.minimum(base + 0.25, oracle.blobs_sdf(1)), oracle.blobs_sdf(2) - 0.05, base + 0.1]
+    for k, grid in enumerate(grids):
+        sdf = dev(np.ascontiguousarray(grid, dtype=np.float32))
+        d = shared.forward(sdf, *pose, 0.005).clone()
+        shared.backward(g, sdf, *pose)                     # writes its partials over the forward's scratch
+        fresh = BatchRenderPlan(64, B, cam)
+        d0 = fresh.forward(sdf, *pose, 0.005)
+        assert torch.equal(d, d0), f"grid {k}: depth differs from a render on a fresh workspace"
+        assert (d0 > 0).sum().item() > 10000
+        del fresh
+    assert shared.prologue_fallbacks() == 0
+
+
+def test_prologue_fallback_path_gives_the_same_depth_and_is_counted():
+    """The set-up blocks of the one-launch prologue wait a bounded number of rounds for the plane minima and then
+    set their views up without them (whole cube as the may-hit box).  Forced here through the test hook: depth is
+    bit-identical at C3, and the workspace's counter reports one fall-back per view."""
+    from sdfest_amd import BatchRenderPlan, Camera, _lib
+    B, W, H, f = 256, 640, 480, 320.0
+    cam = Camera(W, H, f, f, W / 2.0, H / 2.0, pixel_center=0.5)
+    pos, quat, isc = oracle.random_poses(B, seed=1, width=W, height=H, f=f)
+    pose = (dev(pos), dev(quat), dev(isc))
+    sdf = dev(oracle.blobs_sdf(0))
+    plan = BatchRenderPlan(64, B, cam)
+    d0 = plan.forward(sdf, *pose, 0.005).clone()
+    assert plan.prologue_fallbacks() == 0
+    L = _lib.lib()
+    old = L.sdfr_debug_set_prologue_polls(0)
+    try:
+        d1 = plan.forward(sdf, *pose, 0.005).clone()
+        torch.cuda.synchronize()
+    finally:
+        L.sdfr_debug_set_prologue_polls(old)
+    assert plan.prologue_fallbacks() == B
+    assert torch.equal(d0, d1)
+    d2 = plan.forward(sdf, *pose, 0.005, prepare_backward=True)      # back on the normal path, step layout
+    assert torch.equal(d0, d2) and plan.prologue_fallbacks() == B

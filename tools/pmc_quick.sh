@@ -4,7 +4,7 @@ TAG=$1; SET=$2; shift 2
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 150 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/pmc_1 -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/pmc_1.log 2>&1 || echo "pmc pass failed"
+timeout 150 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/pmc_1 -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-configs --prewarm-ms 0 "$@" > $OUT/pmc_1.log 2>&1 || echo "pmc pass failed"
 python3 - <<PY
 import csv,glob,collections
 acc=collections.defaultdict(lambda: collections.defaultdict(list))

@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 4 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 4 --warmup 1 --no-cpu-baseline --no-parity --no-configs --prewarm-ms 0 $*"
 timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/trace.log" 2>&1
 i=0
 for SET in \

@@ -70,10 +70,13 @@ def main():
     # what bench.py reports as roofline.traffic: HBM bytes per launch of the two image kernels
     traffic = {"source": f"profiles/{name}.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; "
                          "2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"}
+    sys.path.insert(0, root)
+    from tools.bench_extra import kernel_sources_sha
+    traffic["kernel_sources_sha16"] = kernel_sources_sha()   # bench.py reports the traffic only for this build
     for k, v in out.items():
         if "hbm_bytes" in v:
             traffic[k.split("<")[0]] = int(v["hbm_bytes"])
-    if len(traffic) > 1:
+    if len(traffic) > 2:
         json.dump(traffic, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
     print("\n".join(lines))
 
