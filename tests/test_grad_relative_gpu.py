@@ -1,6 +1,8 @@
 """GPU: the PLAIN relative error of the pose gradients where the pixel sum is well conditioned (round-2 verdict:
 the suite's yardstick `1e-4 x sum |per-pixel term|` is an fp32-summation bound, not "1e-4 relative").  A component
-is well conditioned when |sum| > 0.1 sum |terms|; on those the HIP gradient must agree with the float64 oracle
+is well conditioned when |sum| > 0.1 sum |terms| -- which a random-sign upstream gradient never produces (its sums
+are residuals of cancellation), so the probe is the upstream gradient ONES, C1's other probe in SURVEY 8d; on
+those components the HIP gradient must agree with the float64 oracle
 (evaluated on the HIP depth image, as the reference's backward is evaluated on its own forward's output:
 sdf_renderer_cuda.cu:334-467, simple_renderer.py:317-458) to 1e-4 of its own magnitude, at C1, C2 and C3."""
 import numpy as np
@@ -17,6 +19,7 @@ def dev(a):
 
 
 def check(plan, views, d_hip, g_np, sdf_np, pos, quat, isc, W, H, f, name):
+    assert np.all(g_np == 1.0)
     ref = oracle.render_backward(g_np[views], d_hip[views], sdf_np, pos[views], quat[views], isc[views], W / 2, H / 2,
                                  f, f, dtype=np.float64)
     dimg = oracle.render_derivative_images(d_hip[views], sdf_np, pos[views], quat[views], isc[views], W / 2, H / 2, f,
@@ -41,7 +44,7 @@ def test_single_view_configs(name, W, H):
     cam = Camera(W, H, f, f, W / 2.0, H / 2.0, pixel_center=0.5)
     sdf_np = oracle.blobs_sdf(0)
     pos, quat, isc = np.array([[0, 0, -1.5]], np.float32), np.array([[0, 0, 0, 1]], np.float32), np.array([2.0], np.float32)
-    g_np = np.random.default_rng(0).uniform(-1, 1, (1, H, W)).astype(np.float32)
+    g_np = np.ones((1, H, W), np.float32)
     plan = BatchRenderPlan(64, 1, cam)
     sdf = dev(sdf_np)
     d = plan.forward(sdf, dev(pos), dev(quat), dev(isc), 0.005, prepare_backward=True)
@@ -56,9 +59,7 @@ def test_c3_batch():
     cam = Camera(W, H, f, f, W / 2.0, H / 2.0, pixel_center=0.5)
     sdf_np = oracle.blobs_sdf(0)
     pos, quat, isc = oracle.random_poses(B, seed=1, width=W, height=H, f=f)
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(1234)
-    g = torch.rand((B, H, W), device="cuda", generator=gen) * 2 - 1
+    g = torch.ones((B, H, W), device="cuda")
     plan = BatchRenderPlan(64, B, cam)
     sdf = dev(sdf_np)
     pose = (dev(pos), dev(quat), dev(isc))
