@@ -177,10 +177,23 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=N, device_id=device)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=N)
+        # RCCL prints a version banner on STDOUT when its communicator comes up; stdout is for the one result
+        # line, so file descriptor 1 points at stderr until the first collective has run
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=N, device_id=device)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=N)
+            warm = torch.zeros(1, device=device)
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     from sdfest_amd import BatchRenderPlan, Camera
     from tools.bench_extra import Telemetry, extra_configs, parity_report

