@@ -28,6 +28,20 @@ __device__ __forceinline__ V3 rot_f(const ViewSetup& s, V3 v) {  // R v
             fmaf(s.rot[6], v.x, fmaf(s.rot[7], v.y, s.rot[8] * v.z)));
 }
 
+// v_min_f32 / v_max_f32 as they are (IEEE mode: the result is the non-NaN operand, a signalling NaN comes out
+// quiet): fminf / fmaxf compile to the same instruction PLUS a canonicalising v_max(x, x) per operand the compiler
+// cannot prove quiet.
+__device__ __forceinline__ float vmin(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // z-adjacent corner pair: 8-byte load at 4-byte alignment (global memory allows it)
 struct __attribute__((packed, aligned(4))) ZPair {
   float lo, hi;

@@ -546,6 +546,7 @@ __device__ __forceinline__ void forward_tile(
   const int px0 = tile_x * kTileW, py0 = tile_y * kTileH;
   const ViewSetup& s = setup[b];
   Rect rc{s.rect[0], s.rect[1], s.rect[2], s.rect[3]};
+  const bool in_rect = overlaps(rc, px0, py0, kTileW, kTileH);
   // the band's column span of the projected may-hit box (one scalar load): tighter than the rectangle's columns
   if (s.spans) {
     const unsigned sp = spans[(size_t)b * span_stride_words(H) + tile_y];
@@ -556,7 +557,9 @@ __device__ __forceinline__ void forward_tile(
   const int tid = threadIdx.x;
 
   if (!overlaps(rc, px0, py0, kTileW, kTileH)) {
-    // nothing of the cube projects here: stream zeros.
+    // nothing of the cube projects here: stream zeros.  (LOSS: the view's reduce sums the records of every tile of
+    // the rectangle, also of those the band span leaves out)
+    if (LOSS && in_rect && tid < 2) loss_part[(((size_t)b * nty + tile_y) * ntx + tile_x) * 2 + tid] = 0.0f;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     if (vec_ok) {
@@ -612,22 +615,28 @@ __device__ __forceinline__ void forward_tile(
       // infinity when the origin is outside the slab (-> t_near > t_far or t_far < 0) and at
       // opposite infinities when it is inside (-> the axis does not constrain the interval).
       // Pixels outside the screen rectangle fail this test by construction of the rectangle.
+      // TIGHT: the may-hit box lies inside the cube and its planes come from the same products (e + hi <= e + scale,
+      // rounding is monotonic), so a ray that crosses the box crosses the cube: of the cube only the near distance
+      // is needed -- the march starts there (cu:262-268) -- and the box decides hit-or-miss and the far end.
+      // (plain minimum / maximum instructions: fminf / fmaxf make the compiler quiet signalling NaNs with an extra
+      // v_max per operand -- a sixth of this block; a NaN operand is dropped here as it is there)
       float t_near = -1e-10f, tf = 1e10f, t_near2 = -1e-10f, tf2 = 1e10f;
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         const float inv = __builtin_amdgcn_rcpf(dv[a]);
         const float ta = s.ep[a] * inv, tb = s.em[a] * inv;
-        t_near = fmaxf(t_near, fminf(ta, tb));
-        tf = fminf(tf, fmaxf(ta, tb));
+        t_near = vmax(t_near, vmin(ta, tb));
         if (TIGHT) {
           const float tc = s.tp[a] * inv, td = s.tm[a] * inv;
-          t_near2 = fmaxf(t_near2, fminf(tc, td));
-          tf2 = fminf(tf2, fmaxf(tc, td));
+          t_near2 = vmax(t_near2, vmin(tc, td));
+          tf2 = vmin(tf2, vmax(tc, td));
+        } else {
+          tf = vmin(tf, vmax(ta, tb));
         }
       }
-      const bool miss = !inside || (t_near > tf) || (tf < 0.0f) || (TIGHT && ((t_near2 > tf2) || (tf2 < 0.0f)));
-      float t = fmaxf(t_near, 0.0f);  // the march starts at the FULL cube's near plane (cu:262-268)
-      if (TIGHT) tf = fminf(tf, tf2);  // ... and no sample behind the may-hit box can be a hit
+      if (TIGHT) tf = tf2;   // no sample behind the may-hit box can be a hit
+      const bool miss = !inside || (TIGHT ? ((t_near2 > tf2) || (tf2 < 0.0f)) : ((t_near > tf) || (tf < 0.0f)));
+      float t = vmax(t_near, 0.0f);  // the march starts at the FULL cube's near plane (cu:262-268)
       if (!miss && (t < tf)) {
         const f32x2 dgxy = {dv[0] * kgrid, dv[1] * kgrid};
         const float dgz = dv[2] * kgrid;
