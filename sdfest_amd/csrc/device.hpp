@@ -119,8 +119,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 __host__ __device__ __forceinline__ constexpr bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// `live` = false: the lane's ray has finished and only rides along in a wave whose other rays still march (two rays
+// per lane, render.hip): its loads go to record 0, one chunk for all such lanes, and its value is ignored.
 template <int RT, bool PACKED>
-__device__ __forceinline__ float march_sample(__amdgpu_buffer_rsrc_t src, int R, f32x2 gxy, float gz) {
+__device__ __forceinline__ float march_sample(__amdgpu_buffer_rsrc_t src, int R, f32x2 gxy, float gz,
+                                              bool live = true) {
   const int Rr = RT > 0 ? RT : R;
   const float top = (float)(Rr - 2), fR = (float)Rr;
   const f32x2 bxy = {fminf(fmaxf(floorf(gxy.x), 0.0f), top), fminf(fmaxf(floorf(gxy.y), 0.0f), top)};
@@ -146,6 +149,7 @@ __device__ __forceinline__ float march_sample(__amdgpu_buffer_rsrc_t src, int R,
     } else {
       rix = record_index((int)bxy.x, (int)bxy.y, (int)bz, (Rr + 1) >> 1);
     }
+    rix = live ? rix : 0;
     const i32x4 a = __builtin_amdgcn_raw_buffer_load_b128(src, rix * 16, 0, 0);
     const i32x4 b = __builtin_amdgcn_raw_buffer_load_b128(src, rix * 16, record_slab(Rr) * 16, 0);
     a01 = f32x2{__int_as_float(a.x), __int_as_float(a.y)};
@@ -154,7 +158,7 @@ __device__ __forceinline__ float march_sample(__amdgpu_buffer_rsrc_t src, int R,
     b23 = f32x2{__int_as_float(b.z), __int_as_float(b.w)};
   } else {
     // plain grid: four z-pairs, 8-byte loads at 4-byte alignment
-    const int off = lin * 4;
+    const int off = live ? lin * 4 : 0;
     const i32x2 p00 = __builtin_amdgcn_raw_buffer_load_b64(src, off, 0, 0);
     const i32x2 p01 = __builtin_amdgcn_raw_buffer_load_b64(src, off, Rr * 4, 0);
     const i32x2 p10 = __builtin_amdgcn_raw_buffer_load_b64(src, off, Rr * Rr * 4, 0);

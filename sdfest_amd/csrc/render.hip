@@ -55,6 +55,10 @@ constexpr bool kTightBox = SDFR_TIGHT_BOX;
 #define SDFR_FWD_WAVES 2
 #endif
 constexpr int kFwdWaves = SDFR_FWD_WAVES;  // waves per workgroup of the batch forward (macro tiles)
+#ifndef SDFR_FWD_K2
+#define SDFR_FWD_K2 1   // 0: one ray per lane everywhere (timing experiments)
+#endif
+constexpr bool kFwdK2 = SDFR_FWD_K2;
 
 
 // ---------------------------------------------------------------------------------------------
@@ -533,7 +537,60 @@ __device__ __forceinline__ bool overlaps(const Rect& r, int px, int py, int w, i
 // the mask and culled tiles never touch the observed image.
 // TIGHT: rays are also tested against the view's may-hit box (compute_view_setup) and march only up
 // to its far side.
-template <int RT, bool PACKED, int SX, int SY, bool LOSS, bool TIGHT, int NW>
+// One lane's ray after the slab tests: unit ray (cu:137-154) rotated into the object frame with d.z = -1 folded
+// in, then the slab test in the object frame (the cube is axis-aligned there, its centre at +e from the ray origin,
+// f_i = dobj_i): same accept/reject as cu:156-194.  A ray parallel to a slab (f = 0) needs no special case: 1/f =
+// +-inf puts both plane distances at the same infinity when the origin is outside the slab (-> t_near > t_far or
+// t_far < 0) and at opposite infinities when it is inside (-> the axis does not constrain the interval).  Pixels
+// outside the screen rectangle fail this test by construction of the rectangle.
+// TIGHT: the may-hit box lies inside the cube and its planes come from the same products (e + hi <= e + scale,
+// rounding is monotonic), so a ray that crosses the box crosses the cube: of the cube only the near distance is
+// needed -- the march starts there (cu:262-268) -- and the box decides hit-or-miss and the far end.
+// (plain minimum / maximum instructions: fminf / fmaxf make the compiler quiet signalling NaNs with an extra
+// v_max per operand -- a sixth of this block; a NaN operand is dropped here as it is there)
+struct Ray {
+  float dg[3];    // direction in grid coordinates per unit of t
+  float t, tf;    // first sample (the FULL cube's near plane, cu:262-268) and the far end of the march
+  float inv_len;  // -d.z of the unit ray: depth = t * inv_len
+  bool go;        // the ray crosses the (may-hit) box in front of the camera
+};
+template <bool TIGHT>
+__device__ __forceinline__ Ray ray_setup(const ViewSetup& s, int row, int col, bool inside, float cx, float cy,
+                                         float rfx, float rfy) {
+  Ray r;
+  const float dx = ((float)col + 0.5f - cx) * rfx;
+  const float dy = -((float)row + 0.5f - cy) * rfy;
+  const float inv_len = __builtin_amdgcn_rsqf(fmaf(dx, dx, fmaf(dy, dy, 1.0f)));
+  const float ux = fmaf(s.rot[0], dx, fmaf(s.rot[3], dy, -s.rot[6]));
+  const float uy = fmaf(s.rot[1], dx, fmaf(s.rot[4], dy, -s.rot[7]));
+  const float uz = fmaf(s.rot[2], dx, fmaf(s.rot[5], dy, -s.rot[8]));
+  const float dv[3] = {ux * inv_len, uy * inv_len, uz * inv_len};
+  float t_near = -1e-10f, tf = 1e10f, t_near2 = -1e-10f, tf2 = 1e10f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float inv = __builtin_amdgcn_rcpf(dv[a]);
+    const float ta = s.ep[a] * inv, tb = s.em[a] * inv;
+    t_near = vmax(t_near, vmin(ta, tb));
+    if (TIGHT) {
+      const float tc = s.tp[a] * inv, td = s.tm[a] * inv;
+      t_near2 = vmax(t_near2, vmin(tc, td));
+      tf2 = vmin(tf2, vmax(tc, td));
+    } else {
+      tf = vmin(tf, vmax(ta, tb));
+    }
+  }
+  if (TIGHT) tf = tf2;   // no sample behind the may-hit box can be a hit
+  const bool miss = !inside || (TIGHT ? ((t_near2 > tf2) || (tf2 < 0.0f)) : ((t_near > tf) || (tf < 0.0f)));
+  r.t = vmax(t_near, 0.0f);
+  r.tf = tf;
+  r.inv_len = inv_len;
+  r.go = !miss && (r.t < tf);
+  const float kgrid = s.dgk;
+  r.dg[0] = dv[0] * kgrid; r.dg[1] = dv[1] * kgrid; r.dg[2] = dv[2] * kgrid;
+  return r;
+}
+
+template <int RT, bool PACKED, int SX, int SY, bool LOSS, bool TIGHT, int NW, bool K2>
 __device__ __forceinline__ void forward_tile(
     int tile_x, int tile_y, int ntx, int nty, int b, const float* __restrict__ src, int R,
     long long src_view_stride, const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy,
@@ -581,9 +638,6 @@ __device__ __forceinline__ void forward_tile(
 
   const int wave = tid >> 6, lane = tid & 63;
   const float scale = s.scale;
-  const float kgrid = s.dgk;
-  const f32x2 ogxy = {s.og[0], s.og[1]};
-  const float ogz = s.og[2];
   const float* vol = src + (size_t)b * src_view_stride;
   const int Rr = RT > 0 ? RT : R;
   // the record array / the grid as a buffer resource: 32-bit byte offsets, hardware range check
@@ -593,6 +647,59 @@ __device__ __forceinline__ void forward_tile(
 
   float l_sum = 0.0f, l_cnt = 0.0f;  // LOSS: this lane's share of the tile's (sum, count)
   const float* obs = LOSS ? target + (size_t)b * H * W : nullptr;
+  const float og[3] = {s.og[0], s.og[1], s.og[2]};
+  if (K2) {
+    // TWO rays per lane: a wave takes two horizontally adjacent 8 x 8 patches at once, lane (x, y) the pixels
+    // (x, y) of both.  The march is a chain of dependent round trips -- position, cell, two gathers, compare --
+    // and what a SIMD's 8 waves can overlap of it is all the latency hiding there is; with two independent
+    // chains per lane every wave keeps twice the gathers in flight (round 3: cutting a tenth of the kernel's VALU
+    // work with the band spans moved it by 2 %: it waits, it does not compute).  A wave then runs until the
+    // longest of 128 rays ends: 0.58 x the iterations of two 64-ray passes (oracle step counts), not 0.5 x.
+    for (int jt = wave; jt < 2 * kSubs; jt += NW) {
+      const int sub = jt >> 1, pr = jt & 1;
+      const int sx = px0 + (sub % SX) * kSubW + 16 * pr, sy = py0 + (sub / SX) * kSubH;
+      const int colA = sx + PF::x(lane), colB = colA + 8, row = sy + PF::y(lane);
+      const bool insA = (colA < W) && (row < H), insB = (colB < W) && (row < H);
+      float resA = 0.0f, resB = 0.0f;
+      const bool ovA = overlaps(rc, sx, sy, 8, 8), ovB = overlaps(rc, sx + 8, sy, 8, 8);   // wave-uniform
+      if (ovA || ovB) {
+        Ray ra, rb;
+        ra.go = rb.go = false;
+        ra.t = rb.t = 0.0f; ra.tf = rb.tf = 0.0f; ra.inv_len = rb.inv_len = 0.0f;
+        ra.dg[0] = ra.dg[1] = ra.dg[2] = rb.dg[0] = rb.dg[1] = rb.dg[2] = 0.0f;
+        if (ovA) ra = ray_setup<TIGHT>(s, row, colA, insA, cx, cy, rfx, rfy);
+        if (ovB) rb = ray_setup<TIGHT>(s, row, colB, insB, cx, cy, rfx, rfy);
+        bool actA = ra.go, actB = rb.go, hitA = false, hitB = false;
+        float tA = ra.t, tB = rb.t;
+        int n = 0;
+        while (actA || actB) {
+          ++n;
+          const f32x2 t2 = {tA, tB};
+          const f32x2 gx = __builtin_elementwise_fma(t2, f32x2{ra.dg[0], rb.dg[0]}, f32x2{og[0], og[0]});
+          const f32x2 gy = __builtin_elementwise_fma(t2, f32x2{ra.dg[1], rb.dg[1]}, f32x2{og[1], og[1]});
+          const f32x2 gz = __builtin_elementwise_fma(t2, f32x2{ra.dg[2], rb.dg[2]}, f32x2{og[2], og[2]});
+          const float vA = march_sample<RT, PACKED>(vsrc, R, f32x2{gx.x, gy.x}, gz.x, actA);
+          const float vB = march_sample<RT, PACKED>(vsrc, R, f32x2{gx.y, gy.y}, gz.y, actB);
+          const f32x2 dist = f32x2{vA, vB} * scale, lim = t2 * threshold, tn = t2 + dist;
+          const bool capped = n >= SDFR_MAX_MARCH_STEPS;
+          const bool hA = actA && (dist.x < lim.x), hB = actB && (dist.y < lim.y);
+          hitA = hitA || hA; hitB = hitB || hB;
+          actA = actA && !hA && (tn.x < ra.tf) && !capped;     // a ray that leaves keeps its t
+          actB = actB && !hB && (tn.y < rb.tf) && !capped;
+          tA = actA ? tn.x : tA;
+          tB = actB ? tn.y : tB;
+        }
+        resA = hitA ? tA * ra.inv_len : 0.0f;
+        resB = hitB ? tB * rb.inv_len : 0.0f;
+        if (LOSS) {
+          if (resA > 0.0f) { const float o = obs[row * W + colA]; if (o > 0.0f) { l_sum += fabsf(resA - o); l_cnt += 1.0f; } }
+          if (resB > 0.0f) { const float o = obs[row * W + colB]; if (o > 0.0f) { l_sum += fabsf(resB - o); l_cnt += 1.0f; } }
+        }
+      }
+      if (insA) img[row * W + colA] = resA;
+      if (insB) img[row * W + colB] = resB;
+    }
+  } else {
   for (int it = wave; it < 4 * kSubs; it += NW) {
     const int sub = it >> 2, pw = it & 3;  // sub-tile and 8x8 patch inside it (NW = 4: patch = wave)
     const int sx = px0 + (sub % SX) * kSubW, sy = py0 + (sub / SX) * kSubH;
@@ -601,45 +708,10 @@ __device__ __forceinline__ void forward_tile(
     float result = 0.0f;
     // wave-uniform: does this wave's 8x8 patch touch the rectangle at all?
     if (overlaps(rc, sx + PF::ox(pw), sy + PF::oy(pw), PF::W, PF::H)) {
-      // unit ray (cu:137-154), rotated into the object frame with d.z = -1 folded in
-      const float dx = ((float)col + 0.5f - cx) * rfx;
-      const float dy = -((float)row + 0.5f - cy) * rfy;
-      const float inv_len = __builtin_amdgcn_rsqf(fmaf(dx, dx, fmaf(dy, dy, 1.0f)));
-      const float ux = fmaf(s.rot[0], dx, fmaf(s.rot[3], dy, -s.rot[6]));
-      const float uy = fmaf(s.rot[1], dx, fmaf(s.rot[4], dy, -s.rot[7]));
-      const float uz = fmaf(s.rot[2], dx, fmaf(s.rot[5], dy, -s.rot[8]));
-      const float dv[3] = {ux * inv_len, uy * inv_len, uz * inv_len};
-      // Slab test in the object frame (the cube is axis-aligned there, its centre at +e from
-      // the ray origin, f_i = dobj_i): same accept/reject as cu:156-194.  A ray parallel to a
-      // slab (f = 0) needs no special case: 1/f = +-inf puts both plane distances at the same
-      // infinity when the origin is outside the slab (-> t_near > t_far or t_far < 0) and at
-      // opposite infinities when it is inside (-> the axis does not constrain the interval).
-      // Pixels outside the screen rectangle fail this test by construction of the rectangle.
-      // TIGHT: the may-hit box lies inside the cube and its planes come from the same products (e + hi <= e + scale,
-      // rounding is monotonic), so a ray that crosses the box crosses the cube: of the cube only the near distance
-      // is needed -- the march starts there (cu:262-268) -- and the box decides hit-or-miss and the far end.
-      // (plain minimum / maximum instructions: fminf / fmaxf make the compiler quiet signalling NaNs with an extra
-      // v_max per operand -- a sixth of this block; a NaN operand is dropped here as it is there)
-      float t_near = -1e-10f, tf = 1e10f, t_near2 = -1e-10f, tf2 = 1e10f;
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const float inv = __builtin_amdgcn_rcpf(dv[a]);
-        const float ta = s.ep[a] * inv, tb = s.em[a] * inv;
-        t_near = vmax(t_near, vmin(ta, tb));
-        if (TIGHT) {
-          const float tc = s.tp[a] * inv, td = s.tm[a] * inv;
-          t_near2 = vmax(t_near2, vmin(tc, td));
-          tf2 = vmin(tf2, vmax(tc, td));
-        } else {
-          tf = vmin(tf, vmax(ta, tb));
-        }
-      }
-      if (TIGHT) tf = tf2;   // no sample behind the may-hit box can be a hit
-      const bool miss = !inside || (TIGHT ? ((t_near2 > tf2) || (tf2 < 0.0f)) : ((t_near > tf) || (tf < 0.0f)));
-      float t = vmax(t_near, 0.0f);  // the march starts at the FULL cube's near plane (cu:262-268)
-      if (!miss && (t < tf)) {
-        const f32x2 dgxy = {dv[0] * kgrid, dv[1] * kgrid};
-        const float dgz = dv[2] * kgrid;
+      const Ray r = ray_setup<TIGHT>(s, row, col, inside, cx, cy, rfx, rfy);
+      if (r.go) {
+        const f32x2 dgxy = {r.dg[0], r.dg[1]}, ogxy = {og[0], og[1]};
+        float t = r.t;
         // sphere tracing, cu:196-260: sample, hit if dist < threshold * t (t = the sample's own
         // t), else advance by dist and stop at the far plane or at the step cap.  A lane that
         // leaves keeps its t: the depth of a hit is formed once, after the loop.
@@ -649,15 +721,15 @@ __device__ __forceinline__ void forward_tile(
           ++n;
           const f32x2 t2 = {t, t};
           const float value = march_sample<RT, PACKED>(vsrc, R, __builtin_elementwise_fma(t2, dgxy, ogxy),
-                                                       fmaf(t, dgz, ogz));
+                                                       fmaf(t, r.dg[2], og[2]));
           const float dist = value * scale;
           hit = dist < threshold * t;
           if (hit) break;
           const float tn = t + dist;
-          if (!(tn < tf) || n >= SDFR_MAX_MARCH_STEPS) break;
+          if (!(tn < r.tf) || n >= SDFR_MAX_MARCH_STEPS) break;
           t = tn;
         }
-        result = hit ? t * inv_len : 0.0f;  // inv_len = -d.z of the unit ray
+        result = hit ? t * r.inv_len : 0.0f;  // inv_len = -d.z of the unit ray
         if (LOSS && result > 0.0f) {
           const float o = obs[row * W + col];
           if (o > 0.0f) {
@@ -668,6 +740,7 @@ __device__ __forceinline__ void forward_tile(
       }
     }
     if (inside) img[row * W + col] = result;
+  }
   }
   if (LOSS) {
     // fixed-order tile sum: lanes (butterfly) -> waves -> one record per tile
@@ -700,7 +773,8 @@ __global__ __launch_bounds__(NW * 64) void render_forward_kernel(
     float rfx, float rfy, float threshold, int vec_ok, float* __restrict__ depth,
     const float* __restrict__ target, float* __restrict__ loss_part, unsigned* __restrict__ epoch,
     const unsigned* __restrict__ spans) {
-  forward_tile<RT, PACKED, SX, SY, LOSS, PACKED && kTightBox, NW>(blockIdx.x, blockIdx.y, ntx, nty, blockIdx.z, src, R,
+  // two rays per lane for the batch tiles of the record march (kFwdK2)
+  forward_tile<RT, PACKED, SX, SY, LOSS, PACKED && kTightBox, NW, (kFwdK2 && PACKED && SX * SY > 1)>(blockIdx.x, blockIdx.y, ntx, nty, blockIdx.z, src, R,
                                          src_view_stride, setup, W, H, cx, cy, rfx, rfy, threshold,
                                          vec_ok, depth, target, loss_part, spans);
   // The workspace's epoch advances once per forward call, after its prologue launch (forward_prologue_kernel), and
