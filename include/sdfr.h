@@ -74,6 +74,16 @@ extern "C" {
  * |sum| < 2^(63 - 40) = 8.4e6 per voxel; contributions that are not finite count as 0 (NaN) or saturate. */
 #define SDFR_SDF_GRAD_DETERMINISTIC 0x100
 #define SDFR_FIXED_QUANTUM_BITS 40
+/* Flag bit, OR-ed into sdf_grad_mode: a PERFORMANCE HINT for batch launches of sdfr_render_backward /
+ * sdfr_render_step_backward, "the views are close": every object spans at least two pixels per voxel on the screen,
+ *     sqrt(|fx fy|) * (2 / (R - 1)) / (inv_scale * |pos|) >= 2       for all views.
+ * The kernel picks each view's tile shape on the device (32 x 32 pixels for such views, 64 x 8 otherwise) and the
+ * launch has to provide workgroups for the finer tiling although close views use half of them; with the hint the
+ * grid has half the rows (backward of the benchmark 125 -> 112 us) and a view that is NOT close takes its tiles two
+ * per workgroup, one after the other -- results are the same whether the hint is true or not, but such views are
+ * slower with it (objects of ~1 pixel per voxel: 103 -> 174 us).  The poses live in device memory, so only the
+ * caller can know; ignored for small calls and for the loss-fused and deterministic forms. */
+#define SDFR_BWD_HALF_GRID 0x200
 
 SDFR_API int sdfr_version(void);
 SDFR_API const char* sdfr_last_error(void);

@@ -137,8 +137,16 @@ constexpr TileGeom kBwdBigTile{1, 4};
 // One launch serves both tilings without an integer division (a culled workgroup's life is its instruction
 // chain): the grid is the 64 x 8 tiling's, (nx, rows) workgroups per view, and workgroup (bx, by) of a view with
 // 32 x 32 tiles takes tile (2 bx + (by & 1), by >> 1) -- or leaves.  Its record of partial sums is by * nx + bx.
-__host__ __device__ constexpr int backward_batch_rows(int H) {
+__host__ __device__ constexpr int backward_batch_rows(int H) {   // rows of partial RECORDS per view
   return kMacroTile.ny(H) > 2 * kBwdBigTile.ny(H) ? kMacroTile.ny(H) : 2 * kBwdBigTile.ny(H);
+}
+// Rows of WORKGROUPS per view.  A view with 32 x 32 tiles uses 2 * ny(32 x 32) rows of the launch and a view with
+// 64 x 8 tiles ny(64 x 8) = twice as many.  SDFR_BWD_HALF_GRID (a caller's hint, include/sdfr.h): the grid has only
+// the former, and a workgroup of a 64 x 8 view takes the tiles (bx, 2 by) and (bx, 2 by + 1) one after the other --
+// half the workgroups to dispatch when the views are close (all of the benchmark's: backward 125 -> 112 us), but
+// a 64 x 8 view's hit tiles then run in pairs (objects of ~1 pixel per voxel: 103 -> 174 us).
+__host__ __device__ constexpr int backward_half_rows(int H) {
+  return 2 * kBwdBigTile.ny(H) > (kMacroTile.ny(H) + 1) / 2 ? 2 * kBwdBigTile.ny(H) : (kMacroTile.ny(H) + 1) / 2;
 }
 __host__ __device__ constexpr int backward_tile_stride(int W, int H) {   // records per view
   return kMacroTile.nx(W) * backward_batch_rows(H);

@@ -56,7 +56,10 @@ constexpr bool kTightBox = SDFR_TIGHT_BOX;
 #endif
 constexpr int kFwdWaves = SDFR_FWD_WAVES;  // waves per workgroup of the batch forward (macro tiles)
 #ifndef SDFR_FWD_K2
-#define SDFR_FWD_K2 1   // 0: one ray per lane everywhere (timing experiments)
+#define SDFR_FWD_K2 0   // 1: two rays per lane in the batch forward (measured: slower)
+#endif
+#ifndef SDFR_BWD_SPANS
+#define SDFR_BWD_SPANS 0   // 1: a step's backward culls its tiles with the forward's band spans (measured: slower)
 #endif
 constexpr bool kFwdK2 = SDFR_FWD_K2;
 
@@ -222,28 +225,41 @@ __device__ __forceinline__ void setup_box(ViewSetup& s, int R, int W, int H, flo
     if (sane) {
       const float mx = 2.0f + 1e-5f * fabsf(fx), my = 2.0f + 1e-5f * fabsf(fy);
       const int nb = span_bands(H);
+      // per edge, once: du/dv (an edge along the rows: +-inf or NaN, harmless below)
+      float slope[12];
+#pragma unroll
+      for (int a = 0, e = 0; a < 8; ++a)
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax)
+          if (!(a & (1 << ax))) {
+            const int c2 = a | (1 << ax);
+            slope[e++] = (cu[c2] - cu[a]) * __builtin_amdgcn_rcpf(cv[c2] - cv[a]);
+          }
       for (int k0 = 0; k0 < nb; k0 += 64) {
         const int k = k0 + lane;
         const float ya = (float)(8 * k) + 0.5f - my, yb = (float)(8 * k) + 7.5f + my;
         float xmin = 3.0e38f, xmax = -3.0e38f;
+        float da[8], db[8];
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
-          if (cv[a] >= ya && cv[a] <= yb) { xmin = fminf(xmin, cu[a]); xmax = fmaxf(xmax, cu[a]); }
-#pragma unroll
-          for (int ax = 0; ax < 3; ++ax) {
-            if (a & (1 << ax)) continue;
-            const int c2 = a | (1 << ax);   // box edge a -- c2
-#pragma unroll
-            for (int side = 0; side < 2; ++side) {
-              const float yy = side ? yb : ya;
-              const float da = cv[a] - yy, db = cv[c2] - yy;
-              if (da * db <= 0.0f) {   // the edge meets the line (an edge lying in it: NaN, ignored by fminf / fmaxf)
-                const float x = fmaf(da * __builtin_amdgcn_rcpf(da - db), cu[c2] - cu[a], cu[a]);
-                xmin = fminf(xmin, x); xmax = fmaxf(xmax, x);
-              }
-            }
-          }
+          da[a] = ya - cv[a];
+          db[a] = yb - cv[a];
+          const float u = (da[a] <= 0.0f && db[a] >= 0.0f) ? cu[a] : __int_as_float(0x7fc00000);   // corner in the band
+          xmin = fminf(xmin, u); xmax = fmaxf(xmax, u);
         }
+#pragma unroll
+        for (int a = 0, e = 0; a < 8; ++a)
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax)
+            if (!(a & (1 << ax))) {
+              const int c2 = a | (1 << ax);   // box edge a -- c2 cut by the band's two boundary rows
+              // (a cut exists where the corners lie on different sides; x = u_a + (row - v_a) du/dv; an edge lying
+              // in the row gives NaN, which fminf / fmaxf drop -- its corners are in the band anyway)
+              const float xa = (da[a] * da[c2] <= 0.0f) ? fmaf(da[a], slope[e], cu[a]) : __int_as_float(0x7fc00000);
+              const float xb = (db[a] * db[c2] <= 0.0f) ? fmaf(db[a], slope[e], cu[a]) : __int_as_float(0x7fc00000);
+              xmin = fminf(xmin, fminf(xa, xb)); xmax = fmaxf(xmax, fmaxf(xa, xb));
+              ++e;
+            }
         int sx0 = 0, sx1 = 0;
         if (xmin <= xmax && 8 * k < y1 && 8 * k + 8 > y0) {
           sx0 = max(x0, (int)fminf(fmaxf(floorf(xmin - 0.5f - mx), 0.0f), (float)W));
@@ -1138,7 +1154,7 @@ using BatchTable = PairRunHash<SDFR_BWD_SLOTS>;
 // One tile of view b.  BATCH: workgroup (bx, by) of the view's own tiling -- 32 x 32 pixels or 64 x 8, chosen per
 // view by the set-up (ViewSetup::bwd_big; common.hpp, kBwdBigTile) -- otherwise the 32 x 8 tile (bx, by) of a
 // small call.  Returns are workgroup-uniform.
-template <int RT, bool BATCH, bool LOSS, bool DET = false>
+template <int RT, bool BATCH, bool LOSS, bool DET = false, bool PAIR = false>
 __device__ __forceinline__ void backward_dispatch(
     unsigned char* raw, int bx, int by, int ntx, int nty, int stride, int b,
     const float* __restrict__ grad_depth, const float* __restrict__ depth, const float* __restrict__ sdf, int R,
@@ -1162,6 +1178,19 @@ __device__ __forceinline__ void backward_dispatch(
       backward_tile<RT, kBwdBigTile.sx, kBwdBigTile.sy, Table, LOSS, DET>(
           lds, tx, ty, record, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx,
           rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, spans);
+    } else if (PAIR) {
+#pragma unroll 1
+      // two tiles, one after the other.  Every exit of a tile is workgroup-uniform, and no barrier is needed between
+      // them: whatever the second tile does to the table comes after ITS first barrier, which the waves reach only
+      // when they have left the first tile (whose last table reads are in its flush); before that barrier the second
+      // tile writes only `box` / `tile_max_bits`, which the first one has not read since its own second barrier.
+      for (int k = 0; k < 2; ++k) {
+        const int ty = 2 * by + k;
+        if (ty >= nty) break;
+        backward_tile<RT, SDFR_MACRO_SX, SDFR_MACRO_SY, Table, LOSS, DET>(
+            lds, bx, ty, (size_t)b * stride + ty * ntx + bx, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride,
+            setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, spans);
+      }
     } else {
       if (by >= nty) return;
       backward_tile<RT, SDFR_MACRO_SX, SDFR_MACRO_SY, Table, LOSS, DET>(
@@ -1188,7 +1217,7 @@ __device__ __forceinline__ void backward_dispatch(
 #else
 #define SDFR_BWD_OCC
 #endif
-template <int RT, bool BATCH, bool LOSS, bool DET = false>
+template <int RT, bool BATCH, bool LOSS, bool DET = false, bool PAIR = false>
 __global__ __launch_bounds__(kBlock) SDFR_BWD_OCC void render_backward_kernel(
     const float* __restrict__ grad_depth, const float* __restrict__ depth,
     const float* __restrict__ sdf, int R, long long sdf_view_stride,
@@ -1200,7 +1229,7 @@ __global__ __launch_bounds__(kBlock) SDFR_BWD_OCC void render_backward_kernel(
                                    ? sizeof(BackwardLds<BatchTable>) : sizeof(BackwardLds<BatchHash>);
   __shared__ __attribute__((aligned(16))) unsigned char raw[BATCH ? (DET ? kBatchLds : sizeof(BackwardLds<BatchTable>))
                                                                   : sizeof(BackwardLds<SmallHash>)];
-  backward_dispatch<RT, BATCH, LOSS, DET>(raw, blockIdx.x, blockIdx.y, ntx, nty, stride, blockIdx.z,
+  backward_dispatch<RT, BATCH, LOSS, DET, PAIR>(raw, blockIdx.x, blockIdx.y, ntx, nty, stride, blockIdx.z,
                                      grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy,
                                      sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, loss_grad, loss_stats,
                                      loss_weight, spans);
@@ -1569,7 +1598,8 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
   if (g_sdf_view_stride != 0 && g_sdf_view_stride != vox)
     return fail(SDFR_E_INVALID, "g_sdf_view_stride must be 0 or R^3");
   const bool det = (sdf_grad_mode & SDFR_SDF_GRAD_DETERMINISTIC) != 0;
-  sdf_grad_mode &= ~SDFR_SDF_GRAD_DETERMINISTIC;
+  const bool half_hint = (sdf_grad_mode & SDFR_BWD_HALF_GRID) != 0;
+  sdf_grad_mode &= ~(SDFR_SDF_GRAD_DETERMINISTIC | SDFR_BWD_HALF_GRID);
   if (sdf_grad_mode != SDFR_SDF_GRAD_EXACT && sdf_grad_mode != SDFR_SDF_GRAD_CUDA_COMPAT)
     return fail(SDFR_E_INVALID, "unknown sdf_grad_mode %d", sdf_grad_mode);
   if (det && (g_sdf_view_stride != 0 || R > kDetMaxR || loss_stats || pc))
@@ -1625,15 +1655,18 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
   const bool batch = geom.sx * geom.sy > 1;
   const int ntx = geom.nx(W), nty = geom.ny(H);
   const int stride = batch ? backward_tile_stride(W, H) : 0;
-  const int rows = batch ? backward_batch_rows(H) : nty;
+  const bool half = half_hint && batch && !det && !with_loss && !pc;   // (a hint: ignored where it does not apply)
+  const int rows = batch ? (half ? backward_half_rows(H) : backward_batch_rows(H)) : nty;
   const int pc_rows = pc ? (pc->nblk + ntx - 1) / ntx : 0;
   const dim3 grid_tile((unsigned)ntx, (unsigned)(rows + pc_rows), (unsigned)B);
   const float rfx = (float)(1.0 / (double)fx), rfy = (float)(1.0 / (double)fy);
 #define SDFR_BWD_ARGS                                                                                \
   grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, ntx, nty, stride, cx, cy, rfx, rfy,       \
       sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, loss_grad, loss_stats, loss_weight
-  // a step's backward culls with the forward's band spans (the stand-alone call set its views up without them)
-  const unsigned* spans = prepared ? (const unsigned*)((const char*)workspace + spans_offset_bytes(B)) : nullptr;
+  // (culling a step's backward tiles with the forward's band spans was built and measured: the two dependent scalar
+  // loads in front of every tile of the rectangle cost more than the culled tiles' depth loads, step +3.5 us)
+  const unsigned* spans = (SDFR_BWD_SPANS && prepared)
+                              ? (const unsigned*)((const char*)workspace + spans_offset_bytes(B)) : nullptr;
 #define SDFR_LAUNCH_BWD(RT, BATCH)                                                                   \
   do {                                                                                               \
     if (pc)                                                                                          \
@@ -1644,6 +1677,9 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
                          SDFR_BWD_ARGS, spans);                                                      \
     else if (det)                                                                                    \
       hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false, true>), grid_tile, dim3(kBlock), 0, st, \
+                         SDFR_BWD_ARGS, spans);                                                      \
+    else if (half)                                                                                   \
+      hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false, false, BATCH>), grid_tile, dim3(kBlock), 0, st, \
                          SDFR_BWD_ARGS, spans);                                                      \
     else                                                                                             \
       hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false>), grid_tile, dim3(kBlock), 0, st, \

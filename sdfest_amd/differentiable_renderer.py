@@ -44,6 +44,23 @@ SDF_GRAD_EXACT = 0
 SDF_GRAD_CUDA_COMPAT = 1
 SDF_GRAD_DETERMINISTIC = 0x100    # flag bit: integer accumulation of d/dSDF, bitwise reproducible
 FIXED_QUANTUM_BITS = 40
+BWD_HALF_GRID = 0x200             # flag bit: performance hint "every view is close" (views_are_close)
+
+
+def views_are_close(position, inv_scale, camera: "Camera", R: int) -> bool:
+    """The caller's side of the ``SDFR_BWD_HALF_GRID`` hint (include/sdfr.h): True when every object spans at
+    least two pixels per voxel on the screen, sqrt(|fx fy|) * (2 / (R - 1)) / (inv_scale * |position|) >= 2.
+    Takes host arrays (or tensors: a CUDA tensor costs a synchronising copy -- evaluate it where the poses are
+    made, not per step)."""
+    import numpy as np
+    pos = position.detach().cpu().numpy() if isinstance(position, torch.Tensor) else np.asarray(position)
+    isc = inv_scale.detach().cpu().numpy() if isinstance(inv_scale, torch.Tensor) else np.asarray(inv_scale)
+    pos = pos.reshape(-1, 3).astype(np.float64)
+    isc = isc.reshape(-1).astype(np.float64)
+    fx, fy, _, _, _ = camera.get_pinhole_camera_parameters(0.5)
+    dist = np.maximum(np.linalg.norm(pos, axis=1), 1e-20)
+    r = np.sqrt(abs(fx * fy)) * (2.0 / (R - 1)) / (isc * dist)
+    return bool(np.all(r >= 2.05))    # (a margin over the kernel's fp32 threshold of 2.0)
 
 _ws_lock = threading.Lock()
 _ws_cache = {}
@@ -395,7 +412,10 @@ class BatchRenderPlan:
     """
 
     def __init__(self, R: int, B: int, camera: Camera, device="cuda", per_view_sdf: bool = False,
-                 sdf_grad_mode: int = 0, grad_volumes: int = 2):
+                 sdf_grad_mode: int = 0, grad_volumes: int = 2, close_views: bool = False):
+        """close_views: the caller's promise-as-a-hint that every view is close (``views_are_close``); the
+        backward then launches half the workgroups.  Same results either way; views that are not close are
+        slower with it."""
         if grad_volumes < 2:
             raise ValueError("grad_volumes must be >= 2")
         self.device = torch.device(device)
@@ -405,7 +425,7 @@ class BatchRenderPlan:
         self.fx, self.fy, self.cx, self.cy, _ = camera.get_pinhole_camera_parameters(0.5)
         self.W, self.H = camera.width, camera.height
         self.sdf_stride = R * R * R if per_view_sdf else 0
-        self.sdf_grad_mode = sdf_grad_mode
+        self.sdf_grad_mode = sdf_grad_mode | (BWD_HALF_GRID if close_views else 0)
         f32 = dict(dtype=torch.float32, device=self.device)
         self.depth = torch.empty((B, self.H, self.W), **f32)
         self.g_sdf = torch.empty((B, R, R, R) if per_view_sdf else (R, R, R), **f32)

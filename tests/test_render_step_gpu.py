@@ -256,3 +256,32 @@ def test_prologue_fallback_path_gives_the_same_depth_and_is_counted():
     assert torch.equal(d0, d1)
     d2 = plan.forward(sdf, *pose, 0.005, prepare_backward=True)      # back on the normal path, step layout
     assert torch.equal(d0, d2) and plan.prologue_fallbacks() == B
+
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_half_grid_hint_changes_nothing_but_the_launch(seed):
+    """SDFR_BWD_HALF_GRID is a performance hint: with it a batch launch has half the rows and a view that is not
+    close takes its 64 x 8 tiles two per workgroup.  Same tiles, same per-tile sums: pose gradients bit for bit,
+    d/dSDF up to the order of its float atomics -- for close views, far views and a mix, stand-alone and step."""
+    from sdfest_amd import BatchRenderPlan, Camera
+    from sdfest_amd.differentiable_renderer import views_are_close
+    B, W, H, f = 64, 640, 480, 320.0
+    cam = Camera(W, H, f, f, W / 2.0, H / 2.0, pixel_center=0.5)
+    pos, quat, isc = oracle.random_poses(B, seed=seed, width=W, height=H, f=f)
+    assert views_are_close(pos, isc, cam, 64)
+    isc = isc.copy()
+    isc[::3] *= 3.0                 # every third object a third of the size: ~1 pixel per voxel, 64 x 8 tiles
+    assert not views_are_close(pos, isc, cam, 64)
+    pose = (dev(pos), dev(quat), dev(isc))
+    g = dev(np.random.default_rng(seed).uniform(-1, 1, (B, H, W)).astype(np.float32))
+    sdf = dev(oracle.blobs_sdf(0))
+    plain, hinted = BatchRenderPlan(64, B, cam), BatchRenderPlan(64, B, cam, close_views=True)
+    for step in (False, True):
+        outs = []
+        for plan in (plain, hinted):
+            d = plan.forward(sdf, *pose, 0.005, prepare_backward=step).clone()
+            outs.append((d, [o.clone() for o in plan.backward(g, sdf, *pose)]))
+        (d0, (gs0, gp0, gq0, gi0)), (d1, (gs1, gp1, gq1, gi1)) = outs
+        assert torch.equal(d0, d1) and (d0 > 0).sum().item() > 10000
+        assert torch.equal(gp0, gp1) and torch.equal(gq0, gq1) and torch.equal(gi0, gi1)
+        assert rel_err(gs1.cpu().numpy(), gs0.cpu().numpy()) <= 1e-5
