@@ -75,8 +75,9 @@ extern "C" {
 #define SDFR_SDF_GRAD_DETERMINISTIC 0x100
 #define SDFR_FIXED_QUANTUM_BITS 40
 /* Flag bit, OR-ed into sdf_grad_mode: a PERFORMANCE HINT for batch launches of sdfr_render_backward /
- * sdfr_render_step_backward, "the views are close": every object spans at least two pixels per voxel on the screen,
- *     sqrt(|fx fy|) * (2 / (R - 1)) / (inv_scale * |pos|) >= 2       for all views.
+ * sdfr_render_step_backward, "the views are close": (nearly) every object spans at least two pixels per voxel on
+ * the screen,
+ *     sqrt(|fx fy|) * (2 / (R - 1)) / (inv_scale * |pos|) >= 2.
  * The kernel picks each view's tile shape on the device (32 x 32 pixels for such views, 64 x 8 otherwise) and the
  * launch has to provide workgroups for the finer tiling although close views use half of them; with the hint the
  * grid has half the rows (backward of the benchmark 125 -> 112 us) and a view that is NOT close takes its tiles two

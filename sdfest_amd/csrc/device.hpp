@@ -204,6 +204,20 @@ template <int PW> struct Patch {
   static __device__ __forceinline__ int x(int lane) { return lane % W; }
   static __device__ __forceinline__ int y(int lane) { return lane / W; }
 };
+// The forward's 8 x 8 patch with each 16-lane group on a 4 x 4 pixel block (a 128-bit gather is processed a quarter
+// wave at a time: the block's rays sample fewer distinct 64-byte chunks than an 8 x 2 strip's, tools/analysis/
+// gather_chunks.py: 13.3 against 15.1 per instruction) -- at the price of 16-byte instead of 32-byte store pieces.
+#ifndef SDFR_FWD_LANE_4X4
+#define SDFR_FWD_LANE_4X4 0
+#endif
+struct PatchFwd : Patch<kPatchWFwd> {
+  static __device__ __forceinline__ int x(int lane) {
+    return SDFR_FWD_LANE_4X4 ? (lane & 3) + 4 * ((lane >> 4) & 1) : lane % 8;
+  }
+  static __device__ __forceinline__ int y(int lane) {
+    return SDFR_FWD_LANE_4X4 ? ((lane >> 2) & 3) + 4 * (lane >> 5) : lane / 8;
+  }
+};
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -615,7 +615,7 @@ __device__ __forceinline__ void forward_tile(
   constexpr int kSubs = SX * SY, kTileW = SX * kSubW, kTileH = SY * kSubH;
   static_assert(kTileH == 8, "a forward tile is one band of the span array");
   constexpr int kThreads = NW * 64;  // NW waves walk the tile's 4 * kSubs 8x8 patches
-  using PF = Patch<kPatchWFwd>;
+  using PF = PatchFwd;
   const int px0 = tile_x * kTileW, py0 = tile_y * kTileH;
   const ViewSetup& s = setup[b];
   Rect rc{s.rect[0], s.rect[1], s.rect[2], s.rect[3]};

@@ -47,11 +47,11 @@ FIXED_QUANTUM_BITS = 40
 BWD_HALF_GRID = 0x200             # flag bit: performance hint "every view is close" (views_are_close)
 
 
-def views_are_close(position, inv_scale, camera: "Camera", R: int) -> bool:
-    """The caller's side of the ``SDFR_BWD_HALF_GRID`` hint (include/sdfr.h): True when every object spans at
-    least two pixels per voxel on the screen, sqrt(|fx fy|) * (2 / (R - 1)) / (inv_scale * |position|) >= 2.
-    Takes host arrays (or tensors: a CUDA tensor costs a synchronising copy -- evaluate it where the poses are
-    made, not per step)."""
+def close_view_fraction(position, inv_scale, camera: "Camera", R: int) -> float:
+    """The caller's side of the ``SDFR_BWD_HALF_GRID`` hint (include/sdfr.h): the share of the views whose object
+    spans at least two pixels per voxel on the screen, sqrt(|fx fy|) * (2 / (R - 1)) / (inv_scale * |position|)
+    >= 2 -- the views the backward gives 32 x 32-pixel tiles.  Takes host arrays (or tensors: a CUDA tensor costs a
+    synchronising copy -- evaluate it where the poses are made, not per step)."""
     import numpy as np
     pos = position.detach().cpu().numpy() if isinstance(position, torch.Tensor) else np.asarray(position)
     isc = inv_scale.detach().cpu().numpy() if isinstance(inv_scale, torch.Tensor) else np.asarray(inv_scale)
@@ -60,7 +60,14 @@ def views_are_close(position, inv_scale, camera: "Camera", R: int) -> bool:
     fx, fy, _, _, _ = camera.get_pinhole_camera_parameters(0.5)
     dist = np.maximum(np.linalg.norm(pos, axis=1), 1e-20)
     r = np.sqrt(abs(fx * fy)) * (2.0 / (R - 1)) / (isc * dist)
-    return bool(np.all(r >= 2.05))    # (a margin over the kernel's fp32 threshold of 2.0)
+    return float(np.mean(r >= 2.0)) if r.size else 0.0
+
+
+def views_are_close(position, inv_scale, camera: "Camera", R: int, share: float = 0.9) -> bool:
+    """True when at least `share` of the views are close (``close_view_fraction``): then the half grid pays --
+    the few views that are not take their tiles two per workgroup."""
+    return close_view_fraction(position, inv_scale, camera, R) >= share
+
 
 _ws_lock = threading.Lock()
 _ws_cache = {}
@@ -413,9 +420,8 @@ class BatchRenderPlan:
 
     def __init__(self, R: int, B: int, camera: Camera, device="cuda", per_view_sdf: bool = False,
                  sdf_grad_mode: int = 0, grad_volumes: int = 2, close_views: bool = False):
-        """close_views: the caller's promise-as-a-hint that every view is close (``views_are_close``); the
-        backward then launches half the workgroups.  Same results either way; views that are not close are
-        slower with it."""
+        """close_views: the caller's hint that (nearly) all views are close (``views_are_close``); the backward
+        then launches half the workgroups.  Same results either way; views that are not close are slower with it."""
         if grad_volumes < 2:
             raise ValueError("grad_volumes must be >= 2")
         self.device = torch.device(device)

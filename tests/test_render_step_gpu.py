@@ -264,14 +264,14 @@ def test_half_grid_hint_changes_nothing_but_the_launch(seed):
     close takes its 64 x 8 tiles two per workgroup.  Same tiles, same per-tile sums: pose gradients bit for bit,
     d/dSDF up to the order of its float atomics -- for close views, far views and a mix, stand-alone and step."""
     from sdfest_amd import BatchRenderPlan, Camera
-    from sdfest_amd.differentiable_renderer import views_are_close
+    from sdfest_amd.differentiable_renderer import close_view_fraction, views_are_close
     B, W, H, f = 64, 640, 480, 320.0
     cam = Camera(W, H, f, f, W / 2.0, H / 2.0, pixel_center=0.5)
     pos, quat, isc = oracle.random_poses(B, seed=seed, width=W, height=H, f=f)
-    assert views_are_close(pos, isc, cam, 64)
+    assert views_are_close(pos, isc, cam, 64) and close_view_fraction(pos, isc, cam, 64) > 0.95
     isc = isc.copy()
     isc[::3] *= 3.0                 # every third object a third of the size: ~1 pixel per voxel, 64 x 8 tiles
-    assert not views_are_close(pos, isc, cam, 64)
+    assert not views_are_close(pos, isc, cam, 64) and 0.6 < close_view_fraction(pos, isc, cam, 64) < 0.7
     pose = (dev(pos), dev(quat), dev(isc))
     g = dev(np.random.default_rng(seed).uniform(-1, 1, (B, H, W)).astype(np.float32))
     sdf = dev(oracle.blobs_sdf(0))

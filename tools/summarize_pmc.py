@@ -42,11 +42,12 @@ def main():
     stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
     for k in sorted(dur, key=lambda k: -sum(dur[k])):
         d = dur[k]
-        # drop the warm-up launch
-        dd = d[1:] if len(d) > 1 else d
+        # the timed steps are the last 20 launches (tools/profile_gpu.sh pre-warms the trace run); without a
+        # pre-warm drop the warm-up launch
+        dd = d[-20:] if len(d) > 40 else (d[1:] if len(d) > 1 else d)
         avg = sum(dd) / len(dd)
         out[k] = {"calls": len(d), "avg_ns": avg}
-        lines.append(f"## {k}: {len(d)} launches, avg {avg/1e3:.1f} us (min {min(d)/1e3:.1f}, max {max(d)/1e3:.1f})")
+        lines.append(f"## {k}: {len(d)} launches, avg of the last {len(dd)} {avg/1e3:.1f} us (min {min(dd)/1e3:.1f}, max {max(dd)/1e3:.1f})")
         for c in sorted(pmc.get(k, {})):
             v = pmc[k][c]
             a = sum(v) / len(v)
