@@ -8,6 +8,7 @@
 #include <cstdio>
 
 #include "sdfr.h"
+#include "tuning.hpp"
 
 namespace sdfr {
 
@@ -71,28 +72,14 @@ struct TileGeom {
   __host__ __device__ constexpr int nx(int W) const { return (W + w() - 1) / w(); }
   __host__ __device__ constexpr int ny(int H) const { return (H + h() - 1) / h(); }
 };
-#ifndef SDFR_MACRO_SX
-#define SDFR_MACRO_SX 2
-#define SDFR_MACRO_SY 1
-#endif
 constexpr TileGeom kMacroTile{SDFR_MACRO_SX, SDFR_MACRO_SY};
 constexpr TileGeom kSmallTile{1, 1};
 // Both image kernels take the macro tile (64 x 8 pixels) once a call has >= 16384 of them (B >= ~55
 // at 640x480) and the 32 x 8 sub-tile below that: the backward gains more LDS pre-summation per
 // global atomic (B=256: 421 vs 265 us with small tiles), the forward fewer workgroups to dispatch;
 // single views need the finer grid to fill 256 CUs (B=1: 14 vs 46 us).
-#ifndef SDFR_BWD_MACRO_MIN
-#define SDFR_BWD_MACRO_MIN 16384
-#endif
 constexpr long long kBackwardMacroMinTiles = SDFR_BWD_MACRO_MIN;
-#ifndef SDFR_FWD_MACRO_MIN
-#define SDFR_FWD_MACRO_MIN 16384
-#endif
 // the forward's batch tile (timing experiments: -DSDFR_FWD_SX / -DSDFR_FWD_SY; the backward keeps kMacroTile)
-#ifndef SDFR_FWD_SX
-#define SDFR_FWD_SX SDFR_MACRO_SX
-#define SDFR_FWD_SY SDFR_MACRO_SY
-#endif
 constexpr TileGeom kFwdMacroTile{SDFR_FWD_SX, SDFR_FWD_SY};
 // Wide images take 128 x 8-pixel tiles walked by 4 waves -- the same work per wave as 64 x 8 by 2, half as many
 // workgroups.  What a mostly-culled grid costs is the dispatcher's rate (~0.42 ns per workgroup whatever it does,
@@ -100,9 +87,6 @@ constexpr TileGeom kFwdMacroTile{SDFR_FWD_SX, SDFR_FWD_SY};
 // objects a third of that size 81.8 / 71.3, B = 32 ... 56 5-10 % faster; but 160x120 images (two 128-pixel tiles per
 // row) 106.8 / 165.5, B = 512 300.7 / 311.0, and in the step harness the benchmark itself 160.6 / 162.7 -- hence the
 // two bounds (the benchmark's 153 600 tiles stay on 64 x 8).
-#ifndef SDFR_FWD_WIDE
-#define SDFR_FWD_WIDE 1   // 0: timing experiments without the wide tile
-#endif
 constexpr TileGeom kFwdWideTile{4, 1};
 constexpr int kFwdWideMinWidth = 256;
 constexpr long long kFwdWideMaxTiles = 100000;   // of the 64 x 8 tiling (B <= 166 at 640x480)
@@ -131,9 +115,6 @@ constexpr int kDeferredMaxViews = 64;  // sdfr_views_to_pose_grad_deferred: view
 // 32 x 32 tiles from r = 2.0 (thresholds 1.7 / 2.0 / 2.2 / 2.4 / 2.8 measured), 64 x 8 below -- where a 32 x 32 tile spans more cells than the table holds and the
 // overflow goes to global atomics pixel by pixel.
 constexpr TileGeom kBwdBigTile{1, 4};
-#ifndef SDFR_BWD_BIG_MIN_RATIO
-#define SDFR_BWD_BIG_MIN_RATIO 2.0f
-#endif
 // One launch serves both tilings without an integer division (a culled workgroup's life is its instruction
 // chain): the grid is the 64 x 8 tiling's, (nx, rows) workgroups per view, and workgroup (bx, by) of a view with
 // 32 x 32 tiles takes tile (2 bx + (by & 1), by >> 1) -- or leaves.  Its record of partial sums is by * nx + bx.
@@ -156,9 +137,6 @@ __host__ __device__ constexpr int backward_big_record(int tx, int ty, int W) {
 }
 
 // packed cell records are used for a grid shared by >= kPackedMinViews views, up to kPackedMaxR
-#ifndef SDFR_PACKED_MIN_VIEWS
-#define SDFR_PACKED_MIN_VIEWS 4
-#endif
 constexpr int kPackedMinViews = SDFR_PACKED_MIN_VIEWS;
 constexpr int kPackedMaxR = 128;
 

@@ -89,10 +89,7 @@ __device__ __forceinline__ void gather_cell(const float* __restrict__ src, int R
 // viewing axis so that the 2 x 2 blocks lie in the plane its rays sweep -- were built and measured:
 // 261 us.  12 MiB of records no longer fit the 4 MiB per-XCD L2.)
 // Hb = ceil(R/2) blocks per axis; one x-slab = 4 Hb^2 records.
-#ifndef SDFR_RECORD_ORDER_LINEAR
-#define SDFR_RECORD_ORDER_LINEAR 0  // 1: records in grid order (timing experiments)
-#endif
-constexpr bool kRecordsBlocked = !SDFR_RECORD_ORDER_LINEAR;
+constexpr bool kRecordsBlocked = true;
 __host__ __device__ __forceinline__ int record_slab(int R) {
   return kRecordsBlocked ? 4 * ((R + 1) >> 1) * ((R + 1) >> 1) : R * R;
 }
@@ -119,11 +116,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 __host__ __device__ __forceinline__ constexpr bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
-// `live` = false: the lane's ray has finished and only rides along in a wave whose other rays still march (two rays
-// per lane, render.hip): its loads go to record 0, one chunk for all such lanes, and its value is ignored.
 template <int RT, bool PACKED>
-__device__ __forceinline__ float march_sample(__amdgpu_buffer_rsrc_t src, int R, f32x2 gxy, float gz,
-                                              bool live = true) {
+__device__ __forceinline__ float march_sample(__amdgpu_buffer_rsrc_t src, int R, f32x2 gxy, float gz) {
   const int Rr = RT > 0 ? RT : R;
   const float top = (float)(Rr - 2), fR = (float)Rr;
   const f32x2 bxy = {fminf(fmaxf(floorf(gxy.x), 0.0f), top), fminf(fmaxf(floorf(gxy.y), 0.0f), top)};
@@ -149,7 +143,6 @@ __device__ __forceinline__ float march_sample(__amdgpu_buffer_rsrc_t src, int R,
     } else {
       rix = record_index((int)bxy.x, (int)bxy.y, (int)bz, (Rr + 1) >> 1);
     }
-    rix = live ? rix : 0;
     const i32x4 a = __builtin_amdgcn_raw_buffer_load_b128(src, rix * 16, 0, 0);
     const i32x4 b = __builtin_amdgcn_raw_buffer_load_b128(src, rix * 16, record_slab(Rr) * 16, 0);
     a01 = f32x2{__int_as_float(a.x), __int_as_float(a.y)};
@@ -158,7 +151,7 @@ __device__ __forceinline__ float march_sample(__amdgpu_buffer_rsrc_t src, int R,
     b23 = f32x2{__int_as_float(b.z), __int_as_float(b.w)};
   } else {
     // plain grid: four z-pairs, 8-byte loads at 4-byte alignment
-    const int off = live ? lin * 4 : 0;
+    const int off = lin * 4;
     const i32x2 p00 = __builtin_amdgcn_raw_buffer_load_b64(src, off, 0, 0);
     const i32x2 p01 = __builtin_amdgcn_raw_buffer_load_b64(src, off, Rr * 4, 0);
     const i32x2 p10 = __builtin_amdgcn_raw_buffer_load_b64(src, off, Rr * Rr * 4, 0);
@@ -204,21 +197,6 @@ template <int PW> struct Patch {
   static __device__ __forceinline__ int x(int lane) { return lane % W; }
   static __device__ __forceinline__ int y(int lane) { return lane / W; }
 };
-// The forward's 8 x 8 patch with each 16-lane group on a 4 x 4 pixel block (a 128-bit gather is processed a quarter
-// wave at a time: the block's rays sample fewer distinct 64-byte chunks than an 8 x 2 strip's, tools/analysis/
-// gather_chunks.py: 13.3 against 15.1 per instruction) -- at the price of 16-byte instead of 32-byte store pieces.
-#ifndef SDFR_FWD_LANE_4X4
-#define SDFR_FWD_LANE_4X4 0
-#endif
-struct PatchFwd : Patch<kPatchWFwd> {
-  static __device__ __forceinline__ int x(int lane) {
-    return SDFR_FWD_LANE_4X4 ? (lane & 3) + 4 * ((lane >> 4) & 1) : lane % 8;
-  }
-  static __device__ __forceinline__ int y(int lane) {
-    return SDFR_FWD_LANE_4X4 ? ((lane >> 2) & 3) + 4 * (lane >> 5) : lane / 8;
-  }
-};
-
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);

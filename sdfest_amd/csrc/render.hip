@@ -41,27 +41,7 @@ namespace sdfr {
 namespace {
 
 constexpr int kBlock = 256;
-#ifndef SDFR_TIGHT_BOX
-#define SDFR_TIGHT_BOX 1  // 0: timing experiments without the may-hit box
-#endif
-constexpr bool kTightBox = SDFR_TIGHT_BOX;
-#ifndef SDFR_BAND_SPANS
-#define SDFR_BAND_SPANS 1  // 0: timing experiments without the band spans (tiles and patches culled by the rectangle)
-#endif
-#ifndef SDFR_BWD_SLOTS
-#define SDFR_BWD_SLOTS 512  // slots of the batch backward's z-pair run table
-#endif
-#ifndef SDFR_FWD_WAVES
-#define SDFR_FWD_WAVES 2
-#endif
 constexpr int kFwdWaves = SDFR_FWD_WAVES;  // waves per workgroup of the batch forward (macro tiles)
-#ifndef SDFR_FWD_K2
-#define SDFR_FWD_K2 0   // 1: two rays per lane in the batch forward (measured: slower)
-#endif
-#ifndef SDFR_BWD_SPANS
-#define SDFR_BWD_SPANS 0   // 1: a step's backward culls its tiles with the forward's band spans (measured: slower)
-#endif
-constexpr bool kFwdK2 = SDFR_FWD_K2;
 
 
 // ---------------------------------------------------------------------------------------------
@@ -218,7 +198,7 @@ __device__ __forceinline__ void setup_box(ViewSetup& s, int R, int W, int H, flo
       cv[c] = cy - fy * Y * iz;
       big = fmaxf(big, fmaxf(fabsf(cu[c]), fabsf(cv[c])));
     }
-    bool sane = SDFR_BAND_SPANS && in_front && !empty && big < 4.0e4f && W <= 65535;
+    bool sane = in_front && !empty && big < 4.0e4f && W <= 65535;
 #pragma unroll
     for (int c = 0; c < 8; ++c) sane = sane && (cu[c] == cu[c]) && (cv[c] == cv[c]);   // (fmaxf drops a NaN)
     s.spans = sane ? 1 : 0;
@@ -606,7 +586,7 @@ __device__ __forceinline__ Ray ray_setup(const ViewSetup& s, int row, int col, b
   return r;
 }
 
-template <int RT, bool PACKED, int SX, int SY, bool LOSS, bool TIGHT, int NW, bool K2>
+template <int RT, bool PACKED, int SX, int SY, bool LOSS, bool TIGHT, int NW>
 __device__ __forceinline__ void forward_tile(
     int tile_x, int tile_y, int ntx, int nty, int b, const float* __restrict__ src, int R,
     long long src_view_stride, const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy,
@@ -615,7 +595,7 @@ __device__ __forceinline__ void forward_tile(
   constexpr int kSubs = SX * SY, kTileW = SX * kSubW, kTileH = SY * kSubH;
   static_assert(kTileH == 8, "a forward tile is one band of the span array");
   constexpr int kThreads = NW * 64;  // NW waves walk the tile's 4 * kSubs 8x8 patches
-  using PF = PatchFwd;
+  using PF = Patch<kPatchWFwd>;
   const int px0 = tile_x * kTileW, py0 = tile_y * kTileH;
   const ViewSetup& s = setup[b];
   Rect rc{s.rect[0], s.rect[1], s.rect[2], s.rect[3]};
@@ -664,58 +644,6 @@ __device__ __forceinline__ void forward_tile(
   float l_sum = 0.0f, l_cnt = 0.0f;  // LOSS: this lane's share of the tile's (sum, count)
   const float* obs = LOSS ? target + (size_t)b * H * W : nullptr;
   const float og[3] = {s.og[0], s.og[1], s.og[2]};
-  if (K2) {
-    // TWO rays per lane: a wave takes two horizontally adjacent 8 x 8 patches at once, lane (x, y) the pixels
-    // (x, y) of both.  The march is a chain of dependent round trips -- position, cell, two gathers, compare --
-    // and what a SIMD's 8 waves can overlap of it is all the latency hiding there is; with two independent
-    // chains per lane every wave keeps twice the gathers in flight (round 3: cutting a tenth of the kernel's VALU
-    // work with the band spans moved it by 2 %: it waits, it does not compute).  A wave then runs until the
-    // longest of 128 rays ends: 0.58 x the iterations of two 64-ray passes (oracle step counts), not 0.5 x.
-    for (int jt = wave; jt < 2 * kSubs; jt += NW) {
-      const int sub = jt >> 1, pr = jt & 1;
-      const int sx = px0 + (sub % SX) * kSubW + 16 * pr, sy = py0 + (sub / SX) * kSubH;
-      const int colA = sx + PF::x(lane), colB = colA + 8, row = sy + PF::y(lane);
-      const bool insA = (colA < W) && (row < H), insB = (colB < W) && (row < H);
-      float resA = 0.0f, resB = 0.0f;
-      const bool ovA = overlaps(rc, sx, sy, 8, 8), ovB = overlaps(rc, sx + 8, sy, 8, 8);   // wave-uniform
-      if (ovA || ovB) {
-        Ray ra, rb;
-        ra.go = rb.go = false;
-        ra.t = rb.t = 0.0f; ra.tf = rb.tf = 0.0f; ra.inv_len = rb.inv_len = 0.0f;
-        ra.dg[0] = ra.dg[1] = ra.dg[2] = rb.dg[0] = rb.dg[1] = rb.dg[2] = 0.0f;
-        if (ovA) ra = ray_setup<TIGHT>(s, row, colA, insA, cx, cy, rfx, rfy);
-        if (ovB) rb = ray_setup<TIGHT>(s, row, colB, insB, cx, cy, rfx, rfy);
-        bool actA = ra.go, actB = rb.go, hitA = false, hitB = false;
-        float tA = ra.t, tB = rb.t;
-        int n = 0;
-        while (actA || actB) {
-          ++n;
-          const f32x2 t2 = {tA, tB};
-          const f32x2 gx = __builtin_elementwise_fma(t2, f32x2{ra.dg[0], rb.dg[0]}, f32x2{og[0], og[0]});
-          const f32x2 gy = __builtin_elementwise_fma(t2, f32x2{ra.dg[1], rb.dg[1]}, f32x2{og[1], og[1]});
-          const f32x2 gz = __builtin_elementwise_fma(t2, f32x2{ra.dg[2], rb.dg[2]}, f32x2{og[2], og[2]});
-          const float vA = march_sample<RT, PACKED>(vsrc, R, f32x2{gx.x, gy.x}, gz.x, actA);
-          const float vB = march_sample<RT, PACKED>(vsrc, R, f32x2{gx.y, gy.y}, gz.y, actB);
-          const f32x2 dist = f32x2{vA, vB} * scale, lim = t2 * threshold, tn = t2 + dist;
-          const bool capped = n >= SDFR_MAX_MARCH_STEPS;
-          const bool hA = actA && (dist.x < lim.x), hB = actB && (dist.y < lim.y);
-          hitA = hitA || hA; hitB = hitB || hB;
-          actA = actA && !hA && (tn.x < ra.tf) && !capped;     // a ray that leaves keeps its t
-          actB = actB && !hB && (tn.y < rb.tf) && !capped;
-          tA = actA ? tn.x : tA;
-          tB = actB ? tn.y : tB;
-        }
-        resA = hitA ? tA * ra.inv_len : 0.0f;
-        resB = hitB ? tB * rb.inv_len : 0.0f;
-        if (LOSS) {
-          if (resA > 0.0f) { const float o = obs[row * W + colA]; if (o > 0.0f) { l_sum += fabsf(resA - o); l_cnt += 1.0f; } }
-          if (resB > 0.0f) { const float o = obs[row * W + colB]; if (o > 0.0f) { l_sum += fabsf(resB - o); l_cnt += 1.0f; } }
-        }
-      }
-      if (insA) img[row * W + colA] = resA;
-      if (insB) img[row * W + colB] = resB;
-    }
-  } else {
   for (int it = wave; it < 4 * kSubs; it += NW) {
     const int sub = it >> 2, pw = it & 3;  // sub-tile and 8x8 patch inside it (NW = 4: patch = wave)
     const int sx = px0 + (sub % SX) * kSubW, sy = py0 + (sub / SX) * kSubH;
@@ -757,7 +685,6 @@ __device__ __forceinline__ void forward_tile(
     }
     if (inside) img[row * W + col] = result;
   }
-  }
   if (LOSS) {
     // fixed-order tile sum: lanes (butterfly) -> waves -> one record per tile
     __shared__ float wave_loss[4][2];
@@ -789,8 +716,7 @@ __global__ __launch_bounds__(NW * 64) void render_forward_kernel(
     float rfx, float rfy, float threshold, int vec_ok, float* __restrict__ depth,
     const float* __restrict__ target, float* __restrict__ loss_part, unsigned* __restrict__ epoch,
     const unsigned* __restrict__ spans) {
-  // two rays per lane for the batch tiles of the record march (kFwdK2)
-  forward_tile<RT, PACKED, SX, SY, LOSS, PACKED && kTightBox, NW, (kFwdK2 && PACKED && SX * SY > 1)>(blockIdx.x, blockIdx.y, ntx, nty, blockIdx.z, src, R,
+  forward_tile<RT, PACKED, SX, SY, LOSS, PACKED, NW>(blockIdx.x, blockIdx.y, ntx, nty, blockIdx.z, src, R,
                                          src_view_stride, setup, W, H, cx, cy, rfx, rfy, threshold,
                                          vec_ok, depth, target, loss_part, spans);
   // The workspace's epoch advances once per forward call, after its prologue launch (forward_prologue_kernel), and
@@ -818,9 +744,6 @@ __global__ __launch_bounds__(NW * 64) void render_forward_kernel(
 //   * the z-run hash (device.hpp) for the tiles whose box is larger (silhouettes seen at a grazing angle, far objects
 //     under 64 x 8 tiles).
 // Both hold fixed-point sums, so a tile's contribution does not depend on the order in which its lanes arrive.
-#ifndef SDFR_DENSE_CAP
-#define SDFR_DENSE_CAP 4608   // words: 18 KiB, the size of the batch hash it shares the LDS with
-#endif
 constexpr int kDenseCap = SDFR_DENSE_CAP;
 
 template <typename Hash>
@@ -881,7 +804,7 @@ __device__ __forceinline__ void backward_tile(
     const float* __restrict__ sdf, int R, long long sdf_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx, float rfy,
     int sdf_grad_mode, float* __restrict__ g_sdf, long long g_sdf_view_stride,
-    float* __restrict__ partials, const unsigned* __restrict__ spans) {
+    float* __restrict__ partials) {
   Hash& hash = lds.hash;
   float (*wave_part)[8] = lds.wave_part;
 
@@ -893,23 +816,6 @@ __device__ __forceinline__ void backward_tile(
   const Rect rc{s.rect[0], s.rect[1], s.rect[2], s.rect[3]};
   if (!overlaps(rc, px0, py0, kTileW, kTileH)) return;  // depth is 0 there by construction
   float* part = partials + record * 8;  // this tile's pose sums
-  if (spans && s.spans) {
-    // a step's backward: the forward's band spans (the tile's kTileH / 8 bands, scalar loads) -- a tile inside the
-    // rectangle but beside the projected box holds no hit either
-    const unsigned* sp = spans + (size_t)b * span_stride_words(H) + (py0 >> 3);
-    int sx0 = 0x7fffffff, sx1 = 0;
-#pragma unroll
-    for (int k = 0; k < kTileH / 8; ++k) {
-      if (py0 + 8 * k < H) {
-        const unsigned w = sp[k];
-        if ((w >> 16) > (w & 0xffffu)) { sx0 = min(sx0, (int)(w & 0xffffu)); sx1 = max(sx1, (int)(w >> 16)); }
-      }
-    }
-    if (!(px0 < sx1 && px0 + kTileW > sx0)) {
-      if (threadIdx.x < 8) part[threadIdx.x] = 0.0f;   // the view's reduce sums every tile of the rectangle
-      return;
-    }
-  }
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const float* zimg = depth + (size_t)b * H * W;
@@ -1161,7 +1067,7 @@ __device__ __forceinline__ void backward_dispatch(
     long long sdf_view_stride, const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx,
     float rfy, int sdf_grad_mode, float* __restrict__ g_sdf, long long g_sdf_view_stride,
     float* __restrict__ partials, const float* __restrict__ loss_grad, const float* __restrict__ loss_stats,
-    float loss_weight, const unsigned* __restrict__ spans) {
+    float loss_weight) {
   float loss_k = 0.0f;
   if (LOSS) {  // same expression as depth_l1_grad_kernel (loop.hip): k = weight / count, 0 if empty
     const float cnt = loss_stats[2 * b + 1];
@@ -1177,7 +1083,7 @@ __device__ __forceinline__ void backward_dispatch(
       if (tx >= kBwdBigTile.nx(W) || ty >= kBwdBigTile.ny(H)) return;
       backward_tile<RT, kBwdBigTile.sx, kBwdBigTile.sy, Table, LOSS, DET>(
           lds, tx, ty, record, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx,
-          rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, spans);
+          rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
     } else if (PAIR) {
 #pragma unroll 1
       // two tiles, one after the other.  Every exit of a tile is workgroup-uniform, and no barrier is needed between
@@ -1189,19 +1095,19 @@ __device__ __forceinline__ void backward_dispatch(
         if (ty >= nty) break;
         backward_tile<RT, SDFR_MACRO_SX, SDFR_MACRO_SY, Table, LOSS, DET>(
             lds, bx, ty, (size_t)b * stride + ty * ntx + bx, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride,
-            setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, spans);
+            setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
       }
     } else {
       if (by >= nty) return;
       backward_tile<RT, SDFR_MACRO_SX, SDFR_MACRO_SY, Table, LOSS, DET>(
           lds, bx, by, record, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx,
-          rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, spans);
+          rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
     }
   } else {
     auto& lds = *reinterpret_cast<BackwardLds<SmallHash>*>(raw);
     backward_tile<RT, 1, 1, SmallHash, LOSS, DET>(
         lds, bx, by, ((size_t)b * nty + by) * ntx + bx, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride,
-        setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, spans);
+        setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
   }
 }
 
@@ -1209,9 +1115,6 @@ __device__ __forceinline__ void backward_dispatch(
 // 8 waves per SIMD for the backward: the register allocator is held to 64 VGPRs (it takes 67 on its own: 7 waves
 // per SIMD; the price is 8 bytes of scratch): stand-alone backward 134.6 -> 129.3 us, a step's 117.8 -> 116.6 us at the
 // benchmark, mug-sized objects unchanged.  0: the compiler's own choice (timing experiments).
-#ifndef SDFR_BWD_WAVES_PER_EU
-#define SDFR_BWD_WAVES_PER_EU 8
-#endif
 #if SDFR_BWD_WAVES_PER_EU
 #define SDFR_BWD_OCC __attribute__((amdgpu_waves_per_eu(SDFR_BWD_WAVES_PER_EU, SDFR_BWD_WAVES_PER_EU)))
 #else
@@ -1224,7 +1127,7 @@ __global__ __launch_bounds__(kBlock) SDFR_BWD_OCC void render_backward_kernel(
     const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, int stride, float cx, float cy,
     float rfx, float rfy, int sdf_grad_mode, float* __restrict__ g_sdf,
     long long g_sdf_view_stride, float* __restrict__ partials, const float* __restrict__ loss_grad,
-    const float* __restrict__ loss_stats, float loss_weight, const unsigned* __restrict__ spans) {
+    const float* __restrict__ loss_stats, float loss_weight) {
   constexpr size_t kBatchLds = sizeof(BackwardLds<BatchTable>) > sizeof(BackwardLds<BatchHash>)
                                    ? sizeof(BackwardLds<BatchTable>) : sizeof(BackwardLds<BatchHash>);
   __shared__ __attribute__((aligned(16))) unsigned char raw[BATCH ? (DET ? kBatchLds : sizeof(BackwardLds<BatchTable>))
@@ -1232,7 +1135,7 @@ __global__ __launch_bounds__(kBlock) SDFR_BWD_OCC void render_backward_kernel(
   backward_dispatch<RT, BATCH, LOSS, DET, PAIR>(raw, blockIdx.x, blockIdx.y, ntx, nty, stride, blockIdx.z,
                                      grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy,
                                      sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, loss_grad, loss_stats,
-                                     loss_weight, spans);
+                                     loss_weight);
 }
 
 // The renderer's backward (depth-L1 form) and the sampler's backward (point-cloud L1 form) of one loop iteration in
@@ -1259,7 +1162,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_pc_kernel(
   }
   backward_dispatch<RT, BATCH, true>(raw, blockIdx.x, (int)blockIdx.y - pc_rows, ntx, nty, stride, b, target, depth,
                                      sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf,
-                                     g_sdf_view_stride, partials, loss_grad, loss_stats, loss_weight, nullptr);
+                                     g_sdf_view_stride, partials, loss_grad, loss_stats, loss_weight);
 }
 
 // deterministic mode: the 64-bit fixed-point volume -> float (one rounding per voxel)
@@ -1381,9 +1284,6 @@ size_t partials_bytes(int B, int W, int H) {
   const size_t small = (size_t)kSmallTile.nx(W) * kSmallTile.ny(H), batch = (size_t)backward_tile_stride(W, H);
   return (size_t)B * (small > batch ? small : batch) * 8 * sizeof(float);
 }
-#ifndef SDFR_FUSED_PROLOGUE
-#define SDFR_FUSED_PROLOGUE 1  // 0: pack + plane minima and the view set-up as two launches (timing experiments)
-#endif
 
 }  // namespace
 }  // namespace sdfr
@@ -1487,7 +1387,7 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
   const bool packed = use_packed(R, B, sdf_view_stride);
   unsigned* epoch = nullptr;
   // (the one-launch prologue reads the grid with 16-byte loads: other grids take the two-launch form)
-  if (packed && kTightBox && SDFR_FUSED_PROLOGUE && (R & 3) == 0 && ((uintptr_t)sdf & 15) == 0) {
+  if (packed && (R & 3) == 0 && ((uintptr_t)sdf & 15) == 0) {
     const int n_pack = (R * R * R + 255) / 256, n_setup = (B + 3) / 4;
     hipLaunchKernelGGL(forward_prologue_kernel, dim3(3 * R + n_setup + n_pack), dim3(256), 0, st, sdf, R,
                        (float4*)cells, 3 * R, n_setup, lay.sync, pos, quat, inv_scale, B, W, H, cx, cy, fx, fy,
@@ -1506,9 +1406,8 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
     if (packed) {
       const int n_pack = (R * R * R + 255) / 256;
       plane_min = (float*)(lay.sync + kSyncHeaderWords);
-      hipLaunchKernelGGL(pack_cells_kernel, dim3(n_pack + (kTightBox ? 3 * R : 0)), dim3(256), 0, st, sdf, R,
+      hipLaunchKernelGGL(pack_cells_kernel, dim3(n_pack + 3 * R), dim3(256), 0, st, sdf, R,
                          (float4*)cells, n_pack, plane_min);
-      if (!kTightBox) plane_min = nullptr;
     }
     hipLaunchKernelGGL(view_setup_kernel, dim3(B), dim3(64), 0, st, pos, quat, inv_scale, B, R,
                        W, H, cx, cy, fx, fy, setup, plane_min, threshold, lay.spans);
@@ -1665,8 +1564,6 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
       sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, loss_grad, loss_stats, loss_weight
   // (culling a step's backward tiles with the forward's band spans was built and measured: the two dependent scalar
   // loads in front of every tile of the rectangle cost more than the culled tiles' depth loads, step +3.5 us)
-  const unsigned* spans = (SDFR_BWD_SPANS && prepared)
-                              ? (const unsigned*)((const char*)workspace + spans_offset_bytes(B)) : nullptr;
 #define SDFR_LAUNCH_BWD(RT, BATCH)                                                                   \
   do {                                                                                               \
     if (pc)                                                                                          \
@@ -1674,16 +1571,16 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
                          SDFR_BWD_ARGS, pc_rows, *pc);                                               \
     else if (with_loss)                                                                              \
       hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, true>), grid_tile, dim3(kBlock), 0, st,  \
-                         SDFR_BWD_ARGS, spans);                                                      \
+                         SDFR_BWD_ARGS);                                                      \
     else if (det)                                                                                    \
       hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false, true>), grid_tile, dim3(kBlock), 0, st, \
-                         SDFR_BWD_ARGS, spans);                                                      \
+                         SDFR_BWD_ARGS);                                                      \
     else if (half)                                                                                   \
       hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false, false, BATCH>), grid_tile, dim3(kBlock), 0, st, \
-                         SDFR_BWD_ARGS, spans);                                                      \
+                         SDFR_BWD_ARGS);                                                      \
     else                                                                                             \
       hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false>), grid_tile, dim3(kBlock), 0, st, \
-                         SDFR_BWD_ARGS, spans);                                                      \
+                         SDFR_BWD_ARGS);                                                      \
   } while (0)
   if (R == 64) { if (batch) SDFR_LAUNCH_BWD(64, true); else SDFR_LAUNCH_BWD(64, false); }
   else { if (batch) SDFR_LAUNCH_BWD(0, true); else SDFR_LAUNCH_BWD(0, false); }

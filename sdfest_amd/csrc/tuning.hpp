@@ -1,0 +1,53 @@
+// tuning.hpp -- every build-time tunable of libsdfr_hip.so in one place (gfx950).
+// These are NUMBERS, not code paths: tile geometry, table sizes, thresholds between launch shapes.  The timing
+// harness (tools/microbench/build_variant.sh NAME -DSDFR_...=...) builds variants by overriding them;
+// tests/test_build_variants_cpu.py compiles a build with every one of them changed.  Experiments that needed other
+// CODE (two rays per lane, Morton lane order, persistent grids, ...) are closed and removed; their numbers are in
+// DESIGN.md sections 8 and 9 and profiles/r0*_experiments.txt.
+#pragma once
+
+// a workgroup's tile = SX x SY sub-tiles of 32 x 8 pixels: batch tile of both image kernels (64 x 8) ...
+#ifndef SDFR_MACRO_SX
+#define SDFR_MACRO_SX 2
+#define SDFR_MACRO_SY 1
+#endif
+// ... and the forward's own batch tile (defaults to the same)
+#ifndef SDFR_FWD_SX
+#define SDFR_FWD_SX SDFR_MACRO_SX
+#define SDFR_FWD_SY SDFR_MACRO_SY
+#endif
+// calls with at least this many 64 x 8 tiles take the batch tile, smaller ones the 32 x 8 sub-tile
+#ifndef SDFR_BWD_MACRO_MIN
+#define SDFR_BWD_MACRO_MIN 16384
+#endif
+#ifndef SDFR_FWD_MACRO_MIN
+#define SDFR_FWD_MACRO_MIN 16384
+#endif
+// 1: medium-sized batches of wide images take 128 x 8-pixel forward tiles walked by 4 waves (common.hpp)
+#ifndef SDFR_FWD_WIDE
+#define SDFR_FWD_WIDE 1
+#endif
+// waves per workgroup of the batch forward (64 x 8 tiles)
+#ifndef SDFR_FWD_WAVES
+#define SDFR_FWD_WAVES 2
+#endif
+// pixels per voxel from which a view's backward tiles are 32 x 32 instead of 64 x 8
+#ifndef SDFR_BWD_BIG_MIN_RATIO
+#define SDFR_BWD_BIG_MIN_RATIO 2.0f
+#endif
+// face records are packed for a grid shared by at least this many views
+#ifndef SDFR_PACKED_MIN_VIEWS
+#define SDFR_PACKED_MIN_VIEWS 4
+#endif
+// slots of the batch backward's z-pair run table (the fall-back of the dense box)
+#ifndef SDFR_BWD_SLOTS
+#define SDFR_BWD_SLOTS 512
+#endif
+// words of the backward's dense LDS box: 18 KiB, the size of the batch hash it shares the LDS with
+#ifndef SDFR_DENSE_CAP
+#define SDFR_DENSE_CAP 4608
+#endif
+// waves per SIMD the backward kernel's register allocation is held to (0: the compiler's choice)
+#ifndef SDFR_BWD_WAVES_PER_EU
+#define SDFR_BWD_WAVES_PER_EU 8
+#endif

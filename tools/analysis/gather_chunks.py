@@ -9,6 +9,7 @@ from sdfest_amd.synthetic import blobs_sdf, random_poses
 
 W, H, f, thr, R = 640, 480, 320.0, 0.005, 64
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 16      # lanes per coalescing group
 sdf = blobs_sdf(0).astype(np.float64)
 pos, quat, isc = random_poses(256, seed=1)
 
@@ -37,6 +38,7 @@ maps["row-major 8x8 (shipped)"] = (l % 8, l // 8)
 maps["4x4 block per 16 lanes"] = ((l & 3) + 4 * ((l >> 4) & 1), ((l >> 2) & 3) + 4 * (l >> 5))
 maps["8x2 strip per 16 lanes = shipped"] = maps["row-major 8x8 (shipped)"]
 maps["2x8 strip per 16 lanes"] = ((l & 1) + 2 * (l >> 4), (l >> 1) & 7)
+maps["2x2 pixel block per lane quad (Morton)"] = ((l & 1) + 2 * ((l >> 2) & 3), ((l >> 1) & 1) + 2 * (l >> 4))
 maps["16x4 patch, 16x1 rows per 16 lanes"] = None   # handled separately
 
 tot = {k: [0, 0] for k in maps}     # [chunks, instructions]
@@ -61,10 +63,10 @@ for b in range(B):
         chim = ch.reshape(H, W)
         for name, m in maps.items():
             if m is None:   # 16x4 patches, lanes row-major: a 16-lane group = one row of 16 pixels
-                blk = chim.reshape(H // 4, 4, W // 16, 16).transpose(0, 2, 1, 3).reshape(-1, 4, 16)
+                blk = chim.reshape(H // 4, 4, W // 16, 16).transpose(0, 2, 1, 3).reshape(-1, 64 // G, G)
             else:
                 mx, my = m
-                blk = chim.reshape(H // 8, 8, W // 8, 8).transpose(0, 2, 1, 3)[:, :, my, mx].reshape(-1, 4, 16)
+                blk = chim.reshape(H // 8, 8, W // 8, 8).transpose(0, 2, 1, 3)[:, :, my, mx].reshape(-1, 64 // G, G)
             live = (blk >= 0).any(axis=(1, 2))
             blk = blk[live]
             s = np.sort(blk, axis=2)
@@ -77,6 +79,6 @@ for b in range(B):
         t[idx] = np.where(stop, t[idx], tnew)
         act[idx[stop]] = False
         it += 1
-print(f"{B} views; chunks per gather instruction (sum over its four 16-lane groups), first load of a step:")
+print(f"{B} views; chunks per gather instruction (sum over its groups of {G} lanes), first load of a step:")
 for name, (c, n) in tot.items():
     print(f"  {name:40s} {c / n:6.2f}   ({n / B:.0f} wave-iterations per view)")

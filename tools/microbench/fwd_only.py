@@ -1,0 +1,17 @@
+"""A few plain forwards of the benchmark batch with the library named by SDFR_LIB (for counter passes:
+tools/pmc_cmd.sh <tag> "<COUNTERS>" tools/microbench/fwd_only.py)."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from sdfest_amd import BatchRenderPlan, Camera
+from sdfest_amd.synthetic import blobs_sdf, random_poses
+B, W, H = 256, 640, 480
+dev = torch.device("cuda:0")
+cam = Camera(W, H, W / 2.0, W / 2.0, W / 2.0, H / 2.0, pixel_center=0.5)
+pos, quat, isc = (torch.tensor(a, device=dev) for a in random_poses(B, seed=1, width=W, height=H, f=W / 2.0))
+sdf = torch.tensor(blobs_sdf(0), device=dev)
+plan = BatchRenderPlan(64, B, cam)
+for _ in range(4):
+    plan.forward(sdf, pos, quat, isc, 0.005)
+torch.cuda.synchronize()
+print("hits", int((plan.depth > 0).sum()))
