@@ -277,9 +277,10 @@ __global__ void view_setup_kernel(const float* __restrict__ pos, const float* __
                                   const float* __restrict__ inv_scale, int B, int R, int W, int H,
                                   float cx, float cy, float fx, float fy,
                                   ViewSetup* __restrict__ out, const float* __restrict__ plane_min,
-                                  float threshold, unsigned* __restrict__ spans) {
+                                  float threshold, unsigned* __restrict__ spans, unsigned* __restrict__ sync) {
   // one wave per view (the wave shares the scan of the plane minima, lane 0 writes the record)
   const int b = blockIdx.x;
+  if (b == 0 && threadIdx.x == 0 && sync) sync[2] += 1u;   // backward epoch: the launch that writes the records
   if (b < B)
     compute_view_setup<true>(b, pos, quat, inv_scale, R, W, H, cx, cy, fx, fy, out, plane_min, threshold, spans);
 }
@@ -352,8 +353,9 @@ __device__ __forceinline__ void plane_min_block(const float* __restrict__ sdf, i
 __global__ __launch_bounds__(256) void backward_prologue_kernel(
     float* __restrict__ g_sdf, size_t n_words, const float* __restrict__ pos,
     const float* __restrict__ quat, const float* __restrict__ inv_scale, int B, int R, int W, int H,
-    float cx, float cy, float fx, float fy, ViewSetup* __restrict__ out) {
+    float cx, float cy, float fx, float fy, ViewSetup* __restrict__ out, unsigned* __restrict__ sync) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) sync[2] += 1u;   // backward epoch (TailOut): the launch that writes the view records advances it
   if (i < n_words) g_sdf[i] = 0.0f;
   if (i < (size_t)B) compute_view_setup((int)i, pos, quat, inv_scale, R, W, H, cx, cy, fx, fy, out);
 }
@@ -465,6 +467,7 @@ __global__ __launch_bounds__(256) void forward_prologue_kernel(
   const unsigned tag = sync[0] + 1u;  // the epoch the last forward on this workspace left, + 1
   PlaneEntry* ent = reinterpret_cast<PlaneEntry*>(sync + kSyncHeaderWords);
   int blk = (int)blockIdx.x;
+  if (blk == 0 && threadIdx.x == 0) sync[2] += 1u;   // backward epoch (TailOut)
   if (blk < n_plane) {
     plane_min_fast_block(sdf, R, blk, ent, tag);
     return;
@@ -767,6 +770,75 @@ __host__ __device__ constexpr int tile_fixed_bits(int pixels, int table_bits) {
 template <typename Hash> struct HashIs32 { static constexpr bool value = false; };
 template <int SLOTS> struct HashIs32<PairRunHash<SLOTS>> { static constexpr bool value = true; };
 
+// TAIL: the view's pose gradients are summed INSIDE the image kernel (no reduce launch: ~4.6 us of a step, ~4.5 us
+// of a 25 us single-view pair).  Every tile of the view's rectangle leaves its 8 sums as a 64-byte record of
+// eight 64-bit words {value, tag}, each written with one agent-scope atomic store (they bypass the per-XCD L2s,
+// which are not coherent with each other), tag = the workspace's backward epoch -- advanced by whichever launch
+// wrote the view records, so no record of an earlier call carries it.  The tile of the rectangle that the
+// dispatcher hands out LAST reads the rectangle's records back (agent-scope atomic loads, tag checked, polling while
+// a tile dispatched before it is still running -- such a tile waits for nothing, so it finishes), adds them in a
+// fixed order and writes the view's gradients.  No fence (a release at agent scope writes the whole L2 back on
+// this part: measured 2x on a single-view pair in round 2), no counter, no second launch.
+struct TailOut {
+  float* g_pos;
+  float* g_quat;
+  float* g_inv_scale;
+  const unsigned* sync;   // the workspace's sync header: word 2 = backward epoch
+};
+constexpr int kTailMaxPolls = 1 << 22;
+
+template <bool TAIL>
+__device__ __forceinline__ void store_partial(float* __restrict__ partials, size_t record, int k, float v, unsigned tag) {
+  if (TAIL)
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(partials) + record * 8 + k,
+                       ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else
+    partials[record * 8 + k] = v;
+}
+
+// KIND: 0 = 32 x 8 tiles of a small call, 1 = 64 x 8 batch tiles, 2 = 32 x 32 batch tiles
+template <int KIND>
+__device__ __forceinline__ size_t tile_record(size_t base, int tx, int ty, int ntx, int W) {
+  return base + (KIND == 2 ? (size_t)backward_big_record(tx, ty, W) : (size_t)ty * ntx + tx);
+}
+// Is (tx, ty) the tile of the rectangle [tx0, tx1] x [ty0, ty1] that the launch dispatches last?  Workgroups go out
+// in the order of blockIdx (x fastest, then y); 32 x 32 tiles sit at workgroup (tx >> 1, 2 ty + (tx & 1)).
+template <int KIND>
+__device__ __forceinline__ bool dispatched_last(int tx, int ty, int tx0, int tx1, int ty1) {
+  if (ty != ty1) return false;
+  if (KIND != 2) return tx == tx1;
+  const int odd = (tx1 & 1) ? tx1 : tx1 - 1;          // largest odd column of the rectangle, if it has one
+  return (odd >= tx0) ? tx == odd : tx == tx1;
+}
+// wave 0 of the view's last tile: sum the rectangle's records (lane = 8 * (tile mod 8) + component)
+template <int KIND>
+__device__ __forceinline__ void tail_reduce(const float* __restrict__ partials, size_t base, int ntx, int W, int b,
+                                            int tx0, int tx1, int ty0, int ty1, unsigned tag, const TailOut& out,
+                                            int lane) {
+  const unsigned long long* words = reinterpret_cast<const unsigned long long*>(partials);
+  const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1), k = lane & 7;
+  float acc = 0.0f;
+  for (int i0 = 0; i0 < n; i0 += 8) {
+    const int i = i0 + (lane >> 3);
+    const bool have = i < n;
+    const int ty = ty0 + i / nx, tx = tx0 + i % nx;
+    const unsigned long long* p = words + tile_record<KIND>(base, have ? tx : tx0, have ? ty : ty0, ntx, W) * 8 + k;
+    unsigned long long w = 0;
+    for (int poll = 0; poll < kTailMaxPolls; ++poll) {
+      w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__all(!have || (unsigned)(w >> 32) == tag)) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (have) acc += __uint_as_float((unsigned)w);
+  }
+  acc += __shfl_xor(acc, 8, 64);
+  acc += __shfl_xor(acc, 16, 64);
+  acc += __shfl_xor(acc, 32, 64);
+  if (lane < 3) out.g_pos[3 * b + lane] = acc;
+  else if (lane < 7) out.g_quat[4 * b + lane - 3] = acc;
+  else if (lane == 7) out.g_inv_scale[b] = acc;
+}
+
 // grid-space hit point of a pixel of depth z: the arithmetic of the reference's backward (cu:334-345) in the object
 // frame.  ONE function for the bounds pass and the main pass of a tile: the same instruction sequence on the same
 // inputs chooses the same cell in both.
@@ -797,9 +869,9 @@ __device__ __forceinline__ HitPoint hit_point(const ViewSetup& s, int row, int c
 // contribution is rounded ONCE, per pixel, to the fixed quantum 2^-kDetQuantumBits -- a function of the pixel alone,
 // not of its tile -- and everything after that is integer addition (64-bit LDS run table, 64-bit global atomics).
 constexpr int kDetQuantumBits = SDFR_FIXED_QUANTUM_BITS;
-template <int RT, int SX, int SY, typename Hash, bool LOSS, bool DET = false>
+template <int RT, int SX, int SY, typename Hash, bool LOSS, bool DET = false, bool TAIL = false>
 __device__ __forceinline__ void backward_tile(
-    BackwardLds<Hash>& lds, int tile_x, int tile_y, size_t record, int b, float loss_k,
+    BackwardLds<Hash>& lds, int tile_x, int tile_y, size_t rec_base, int ntx_rec, const TailOut& tail, int b, float loss_k,
     const float* __restrict__ grad_depth, const float* __restrict__ depth,
     const float* __restrict__ sdf, int R, long long sdf_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx, float rfy,
@@ -815,7 +887,12 @@ __device__ __forceinline__ void backward_tile(
   const ViewSetup& s = setup[b];
   const Rect rc{s.rect[0], s.rect[1], s.rect[2], s.rect[3]};
   if (!overlaps(rc, px0, py0, kTileW, kTileH)) return;  // depth is 0 there by construction
-  float* part = partials + record * 8;  // this tile's pose sums
+  // this tile's pose sums go to record `record` (TAIL: 64-byte tagged records; else 32 bytes for the reduce launch)
+  constexpr int kKind = (SX == kBwdBigTile.sx && SY == kBwdBigTile.sy) ? 2 : (kSubs > 1 ? 1 : 0);
+  const size_t record = tile_record<kKind>(rec_base, tile_x, tile_y, ntx_rec, W);
+  const unsigned tag = TAIL ? tail.sync[2] : 0u;
+  const int rtx0 = rc.x0 / kTileW, rtx1 = (rc.x1 - 1) / kTileW, rty0 = rc.y0 / kTileH, rty1 = (rc.y1 - 1) / kTileH;
+  const bool reducer = TAIL && dispatched_last<kKind>(tile_x, tile_y, rtx0, rtx1, rty1);
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const float* zimg = depth + (size_t)b * H * W;
@@ -851,7 +928,8 @@ __device__ __forceinline__ void backward_tile(
     any_hit = any_hit || hit;
   }
   if (!__syncthreads_or(any_hit)) {
-    if (tid < 8) part[tid] = 0.0f;
+    if (tid < 8) store_partial<TAIL>(partials, record, tid, 0.0f, tag);
+    if (reducer && wave == 0) tail_reduce<kKind>(partials, rec_base, ntx_rec, W, b, rtx0, rtx1, rty0, rty1, tag, tail, lane);
     return;
   }
   const float h = 0.5f * (float)(Rr - 1);
@@ -1034,7 +1112,9 @@ __device__ __forceinline__ void backward_tile(
     wave_part[wave][lane] = 0.0f;
   }
   __syncthreads();
-  if (tid < 8) part[tid] = (wave_part[0][tid] + wave_part[1][tid]) + (wave_part[2][tid] + wave_part[3][tid]);
+  if (tid < 8)
+    store_partial<TAIL>(partials, record, tid,
+                        (wave_part[0][tid] + wave_part[1][tid]) + (wave_part[2][tid] + wave_part[3][tid]), tag);
 
   if (dense) {
     // consecutive lanes take consecutive words = consecutive z of a box row: contiguous global float atomics
@@ -1050,6 +1130,8 @@ __device__ __forceinline__ void backward_tile(
   } else {
     hash.template flush<DET>(gvol, Rr * Rr * Rr, from_fixed, tid, kBlock);
   }
+  // (after the flush: the wait for the view's other tiles does not hold this tile's atomics back)
+  if (reducer && wave == 0) tail_reduce<kKind>(partials, rec_base, ntx_rec, W, b, rtx0, rtx1, rty0, rty1, tag, tail, lane);
 }
 
 // Batches pre-sum in the z-pair run table (device.hpp, PairRunHash), small calls in 2-voxel runs x 1024 slots.
@@ -1060,9 +1142,9 @@ using BatchTable = PairRunHash<SDFR_BWD_SLOTS>;
 // One tile of view b.  BATCH: workgroup (bx, by) of the view's own tiling -- 32 x 32 pixels or 64 x 8, chosen per
 // view by the set-up (ViewSetup::bwd_big; common.hpp, kBwdBigTile) -- otherwise the 32 x 8 tile (bx, by) of a
 // small call.  Returns are workgroup-uniform.
-template <int RT, bool BATCH, bool LOSS, bool DET = false, bool PAIR = false>
+template <int RT, bool BATCH, bool LOSS, bool DET = false, bool PAIR = false, bool TAIL = false>
 __device__ __forceinline__ void backward_dispatch(
-    unsigned char* raw, int bx, int by, int ntx, int nty, int stride, int b,
+    unsigned char* raw, const TailOut& tail, int bx, int by, int ntx, int nty, int stride, int b,
     const float* __restrict__ grad_depth, const float* __restrict__ depth, const float* __restrict__ sdf, int R,
     long long sdf_view_stride, const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx,
     float rfy, int sdf_grad_mode, float* __restrict__ g_sdf, long long g_sdf_view_stride,
@@ -1074,16 +1156,26 @@ __device__ __forceinline__ void backward_dispatch(
     const float w = loss_grad ? loss_weight * loss_grad[b] : loss_weight;
     loss_k = cnt > 0.0f ? w / cnt : 0.0f;
   }
+  if (TAIL && bx == 0 && by == 0 && threadIdx.x < 8) {
+    // a view whose rectangle is empty has no tile to sum for it: its gradients are zero
+    const ViewSetup& s = setup[b];
+    if (s.rect[2] <= s.rect[0] || s.rect[3] <= s.rect[1]) {
+      const int k = threadIdx.x;
+      if (k < 3) tail.g_pos[3 * b + k] = 0.0f;
+      else if (k < 7) tail.g_quat[4 * b + k - 3] = 0.0f;
+      else tail.g_inv_scale[b] = 0.0f;
+    }
+  }
   if (BATCH) {
     using Table = typename std::conditional<DET, BatchHash, BatchTable>::type;   // DET: 64-bit sums
     auto& lds = *reinterpret_cast<BackwardLds<Table>*>(raw);
-    const size_t record = (size_t)b * stride + by * ntx + bx;   // ntx = the 64 x 8 tiling's
+    const size_t base = (size_t)b * stride;   // the view's records; ntx = the 64 x 8 tiling's
     if (setup[b].bwd_big) {
       const int tx = 2 * bx + (by & 1), ty = by >> 1;
       if (tx >= kBwdBigTile.nx(W) || ty >= kBwdBigTile.ny(H)) return;
-      backward_tile<RT, kBwdBigTile.sx, kBwdBigTile.sy, Table, LOSS, DET>(
-          lds, tx, ty, record, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx,
-          rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
+      backward_tile<RT, kBwdBigTile.sx, kBwdBigTile.sy, Table, LOSS, DET, TAIL>(
+          lds, tx, ty, base, ntx, tail, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy,
+          rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
     } else if (PAIR) {
 #pragma unroll 1
       // two tiles, one after the other.  Every exit of a tile is workgroup-uniform, and no barrier is needed between
@@ -1093,20 +1185,20 @@ __device__ __forceinline__ void backward_dispatch(
       for (int k = 0; k < 2; ++k) {
         const int ty = 2 * by + k;
         if (ty >= nty) break;
-        backward_tile<RT, SDFR_MACRO_SX, SDFR_MACRO_SY, Table, LOSS, DET>(
-            lds, bx, ty, (size_t)b * stride + ty * ntx + bx, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride,
+        backward_tile<RT, SDFR_MACRO_SX, SDFR_MACRO_SY, Table, LOSS, DET, TAIL>(
+            lds, bx, ty, base, ntx, tail, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride,
             setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
       }
     } else {
       if (by >= nty) return;
-      backward_tile<RT, SDFR_MACRO_SX, SDFR_MACRO_SY, Table, LOSS, DET>(
-          lds, bx, by, record, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx,
-          rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
+      backward_tile<RT, SDFR_MACRO_SX, SDFR_MACRO_SY, Table, LOSS, DET, TAIL>(
+          lds, bx, by, base, ntx, tail, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy,
+          rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
     }
   } else {
     auto& lds = *reinterpret_cast<BackwardLds<SmallHash>*>(raw);
-    backward_tile<RT, 1, 1, SmallHash, LOSS, DET>(
-        lds, bx, by, ((size_t)b * nty + by) * ntx + bx, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride,
+    backward_tile<RT, 1, 1, SmallHash, LOSS, DET, TAIL>(
+        lds, bx, by, (size_t)b * nty * ntx, ntx, tail, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride,
         setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
   }
 }
@@ -1120,19 +1212,19 @@ __device__ __forceinline__ void backward_dispatch(
 #else
 #define SDFR_BWD_OCC
 #endif
-template <int RT, bool BATCH, bool LOSS, bool DET = false, bool PAIR = false>
+template <int RT, bool BATCH, bool LOSS, bool DET = false, bool PAIR = false, bool TAIL = false>
 __global__ __launch_bounds__(kBlock) SDFR_BWD_OCC void render_backward_kernel(
     const float* __restrict__ grad_depth, const float* __restrict__ depth,
     const float* __restrict__ sdf, int R, long long sdf_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, int stride, float cx, float cy,
     float rfx, float rfy, int sdf_grad_mode, float* __restrict__ g_sdf,
     long long g_sdf_view_stride, float* __restrict__ partials, const float* __restrict__ loss_grad,
-    const float* __restrict__ loss_stats, float loss_weight) {
+    const float* __restrict__ loss_stats, float loss_weight, TailOut tail) {
   constexpr size_t kBatchLds = sizeof(BackwardLds<BatchTable>) > sizeof(BackwardLds<BatchHash>)
                                    ? sizeof(BackwardLds<BatchTable>) : sizeof(BackwardLds<BatchHash>);
   __shared__ __attribute__((aligned(16))) unsigned char raw[BATCH ? (DET ? kBatchLds : sizeof(BackwardLds<BatchTable>))
                                                                   : sizeof(BackwardLds<SmallHash>)];
-  backward_dispatch<RT, BATCH, LOSS, DET, PAIR>(raw, blockIdx.x, blockIdx.y, ntx, nty, stride, blockIdx.z,
+  backward_dispatch<RT, BATCH, LOSS, DET, PAIR, TAIL>(raw, tail, blockIdx.x, blockIdx.y, ntx, nty, stride, blockIdx.z,
                                      grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy,
                                      sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, loss_grad, loss_stats,
                                      loss_weight);
@@ -1160,7 +1252,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_pc_kernel(
     if (bx < pa.nblk) pc_backward_block<RT, true>(*reinterpret_cast<PcBackwardLds*>(raw), pa, bx, b);
     return;
   }
-  backward_dispatch<RT, BATCH, true>(raw, blockIdx.x, (int)blockIdx.y - pc_rows, ntx, nty, stride, b, target, depth,
+  backward_dispatch<RT, BATCH, true>(raw, TailOut{}, blockIdx.x, (int)blockIdx.y - pc_rows, ntx, nty, stride, b, target, depth,
                                      sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf,
                                      g_sdf_view_stride, partials, loss_grad, loss_stats, loss_weight);
 }
@@ -1282,7 +1374,8 @@ size_t partials_bytes(int B, int W, int H) {
   if (B <= 0 || W <= 0 || H <= 0) return 0;
   // one 32-byte record per tile of the finer geometry (or per workgroup of a batch launch)
   const size_t small = (size_t)kSmallTile.nx(W) * kSmallTile.ny(H), batch = (size_t)backward_tile_stride(W, H);
-  return (size_t)B * (small > batch ? small : batch) * 8 * sizeof(float);
+  // (64 bytes per record: the in-kernel reduce's tagged form; the reduce launch's plain form uses the first half)
+  return (size_t)B * (small > batch ? small : batch) * 16 * sizeof(float);
 }
 
 }  // namespace
@@ -1399,7 +1492,8 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
     // backward's prologue, run early.  Without plane minima the record does not depend on the threshold, and the
     // one-thread and one-wave forms of the set-up give the same record (min / max of the same 8 corners).
     hipLaunchKernelGGL(backward_prologue_kernel, dim3((unsigned)((std::max(n_zero, (size_t)B) + 255) / 256)),
-                       dim3(256), 0, st, g_zero, n_zero, pos, quat, inv_scale, B, R, W, H, cx, cy, fx, fy, setup);
+                       dim3(256), 0, st, g_zero, n_zero, pos, quat, inv_scale, B, R, W, H, cx, cy, fx, fy, setup,
+                       lay.sync);
   } else {
     if (g_zero) zero_words_async(g_zero, n_zero, st);
     float* plane_min = nullptr;
@@ -1410,7 +1504,7 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
                          (float4*)cells, n_pack, plane_min);
     }
     hipLaunchKernelGGL(view_setup_kernel, dim3(B), dim3(64), 0, st, pos, quat, inv_scale, B, R,
-                       W, H, cx, cy, fx, fy, setup, plane_min, threshold, lay.spans);
+                       W, H, cx, cy, fx, fy, setup, plane_min, threshold, lay.spans, lay.sync);
   }
   const TileGeom geom = forward_geom(B, W, H);
   const bool macro = geom.sx * geom.sy > 1;
@@ -1540,7 +1634,8 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
   // tighter rectangles and launches no prologue.)
   if (!prepared)
     hipLaunchKernelGGL(backward_prologue_kernel, dim3((unsigned)((std::max(g_words, (size_t)B) + 255) / 256)),
-                       dim3(256), 0, st, g_sdf, g_words, pos, quat, inv_scale, B, R, W, H, cx, cy, fx, fy, setup);
+                       dim3(256), 0, st, g_sdf, g_words, pos, quat, inv_scale, B, R, W, H, cx, cy, fx, fy, setup,
+                       (unsigned*)((char*)workspace + sync_offset(B)));
   // deterministic mode: the image kernel adds integers into the workspace's 64-bit volume, converted at the end
   long long* fixed = nullptr;
   float* g_out = g_sdf;
@@ -1555,6 +1650,9 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
   const int ntx = geom.nx(W), nty = geom.ny(H);
   const int stride = batch ? backward_tile_stride(W, H) : 0;
   const bool half = half_hint && batch && !det && !with_loss && !pc;   // (a hint: ignored where it does not apply)
+  // the view's pose gradients summed inside the image kernel (TailOut) instead of by a reduce launch
+  const bool tail = !deferred && !det && !with_loss && !pc && (SDFR_BWD_TAIL == 2 || (SDFR_BWD_TAIL == 1 && !batch));
+  const TailOut tail_out{g_pos, g_quat, g_inv_scale, (const unsigned*)((const char*)workspace + sync_offset(B))};
   const int rows = batch ? (half ? backward_half_rows(H) : backward_batch_rows(H)) : nty;
   const int pc_rows = pc ? (pc->nblk + ntx - 1) / ntx : 0;
   const dim3 grid_tile((unsigned)ntx, (unsigned)(rows + pc_rows), (unsigned)B);
@@ -1564,6 +1662,15 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
       sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, loss_grad, loss_stats, loss_weight
   // (culling a step's backward tiles with the forward's band spans was built and measured: the two dependent scalar
   // loads in front of every tile of the rectangle cost more than the culled tiles' depth loads, step +3.5 us)
+#define SDFR_LAUNCH_BWD_T(RT, BATCH, TAIL)                                                           \
+  do {                                                                                               \
+    if (half)                                                                                        \
+      hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false, false, BATCH, TAIL>), grid_tile,  \
+                         dim3(kBlock), 0, st, SDFR_BWD_ARGS, tail_out);                              \
+    else                                                                                             \
+      hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false, false, false, TAIL>), grid_tile,  \
+                         dim3(kBlock), 0, st, SDFR_BWD_ARGS, tail_out);                              \
+  } while (0)
 #define SDFR_LAUNCH_BWD(RT, BATCH)                                                                   \
   do {                                                                                               \
     if (pc)                                                                                          \
@@ -1571,22 +1678,19 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
                          SDFR_BWD_ARGS, pc_rows, *pc);                                               \
     else if (with_loss)                                                                              \
       hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, true>), grid_tile, dim3(kBlock), 0, st,  \
-                         SDFR_BWD_ARGS);                                                      \
+                         SDFR_BWD_ARGS, tail_out);                                                   \
     else if (det)                                                                                    \
       hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false, true>), grid_tile, dim3(kBlock), 0, st, \
-                         SDFR_BWD_ARGS);                                                      \
-    else if (half)                                                                                   \
-      hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false, false, BATCH>), grid_tile, dim3(kBlock), 0, st, \
-                         SDFR_BWD_ARGS);                                                      \
-    else                                                                                             \
-      hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false>), grid_tile, dim3(kBlock), 0, st, \
-                         SDFR_BWD_ARGS);                                                      \
+                         SDFR_BWD_ARGS, tail_out);                                                   \
+    else if (tail) SDFR_LAUNCH_BWD_T(RT, BATCH, true);                                               \
+    else SDFR_LAUNCH_BWD_T(RT, BATCH, false);                                                        \
   } while (0)
   if (R == 64) { if (batch) SDFR_LAUNCH_BWD(64, true); else SDFR_LAUNCH_BWD(64, false); }
   else { if (batch) SDFR_LAUNCH_BWD(0, true); else SDFR_LAUNCH_BWD(0, false); }
 #undef SDFR_LAUNCH_BWD
+#undef SDFR_LAUNCH_BWD_T
 #undef SDFR_BWD_ARGS
-  if (!deferred)
+  if (!deferred && !tail)
     hipLaunchKernelGGL(pose_reduce_kernel, dim3(B), dim3(64), 0, st, partials, setup, W, H, ntx, nty,
                        geom.w(), geom.h(), stride, g_pos, g_quat, g_inv_scale);
   if (det)
