@@ -42,6 +42,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kFwdWaves = SDFR_FWD_WAVES;  // waves per workgroup of the batch forward (macro tiles)
+constexpr int kInlineSetupMaxViews = 8;    // a step's forward without a prologue launch (render_forward_kernel, INLINE)
 
 
 // ---------------------------------------------------------------------------------------------
@@ -277,10 +278,9 @@ __global__ void view_setup_kernel(const float* __restrict__ pos, const float* __
                                   const float* __restrict__ inv_scale, int B, int R, int W, int H,
                                   float cx, float cy, float fx, float fy,
                                   ViewSetup* __restrict__ out, const float* __restrict__ plane_min,
-                                  float threshold, unsigned* __restrict__ spans, unsigned* __restrict__ sync) {
+                                  float threshold, unsigned* __restrict__ spans) {
   // one wave per view (the wave shares the scan of the plane minima, lane 0 writes the record)
   const int b = blockIdx.x;
-  if (b == 0 && threadIdx.x == 0 && sync) sync[2] += 1u;   // backward epoch: the launch that writes the records
   if (b < B)
     compute_view_setup<true>(b, pos, quat, inv_scale, R, W, H, cx, cy, fx, fy, out, plane_min, threshold, spans);
 }
@@ -353,9 +353,8 @@ __device__ __forceinline__ void plane_min_block(const float* __restrict__ sdf, i
 __global__ __launch_bounds__(256) void backward_prologue_kernel(
     float* __restrict__ g_sdf, size_t n_words, const float* __restrict__ pos,
     const float* __restrict__ quat, const float* __restrict__ inv_scale, int B, int R, int W, int H,
-    float cx, float cy, float fx, float fy, ViewSetup* __restrict__ out, unsigned* __restrict__ sync) {
+    float cx, float cy, float fx, float fy, ViewSetup* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) sync[2] += 1u;   // backward epoch (TailOut): the launch that writes the view records advances it
   if (i < n_words) g_sdf[i] = 0.0f;
   if (i < (size_t)B) compute_view_setup((int)i, pos, quat, inv_scale, R, W, H, cx, cy, fx, fy, out);
 }
@@ -467,7 +466,6 @@ __global__ __launch_bounds__(256) void forward_prologue_kernel(
   const unsigned tag = sync[0] + 1u;  // the epoch the last forward on this workspace left, + 1
   PlaneEntry* ent = reinterpret_cast<PlaneEntry*>(sync + kSyncHeaderWords);
   int blk = (int)blockIdx.x;
-  if (blk == 0 && threadIdx.x == 0) sync[2] += 1u;   // backward epoch (TailOut)
   if (blk < n_plane) {
     plane_min_fast_block(sdf, R, blk, ent, tag);
     return;
@@ -592,7 +590,7 @@ __device__ __forceinline__ Ray ray_setup(const ViewSetup& s, int row, int col, b
 template <int RT, bool PACKED, int SX, int SY, bool LOSS, bool TIGHT, int NW>
 __device__ __forceinline__ void forward_tile(
     int tile_x, int tile_y, int ntx, int nty, int b, const float* __restrict__ src, int R,
-    long long src_view_stride, const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy,
+    long long src_view_stride, const ViewSetup& s, int W, int H, float cx, float cy,
     float rfx, float rfy, float threshold, int vec_ok, float* __restrict__ depth,
     const float* __restrict__ target, float* __restrict__ loss_part, const unsigned* __restrict__ spans) {
   constexpr int kSubs = SX * SY, kTileW = SX * kSubW, kTileH = SY * kSubH;
@@ -600,7 +598,6 @@ __device__ __forceinline__ void forward_tile(
   constexpr int kThreads = NW * 64;  // NW waves walk the tile's 4 * kSubs 8x8 patches
   using PF = Patch<kPatchWFwd>;
   const int px0 = tile_x * kTileW, py0 = tile_y * kTileH;
-  const ViewSetup& s = setup[b];
   Rect rc{s.rect[0], s.rect[1], s.rect[2], s.rect[3]};
   const bool in_rect = overlaps(rc, px0, py0, kTileW, kTileH);
   // the band's column span of the projected may-hit box (one scalar load): tighter than the rectangle's columns
@@ -712,15 +709,43 @@ __device__ __forceinline__ void forward_tile(
 // 1-, 2- and 4-wave workgroups: 66 / 66 / 67 us), and a new workgroup needs a free slot on NW SIMDs at
 // once: 64 x 8 tiles walked by 2 waves (4 patches each) 167 us, by 4 waves 172, by 1 wave 183; 8- and
 // 16-wave workgroups on 128 x 8 ... 128 x 16 tiles 186 ... 237.
-template <int RT, bool PACKED, int SX, int SY, bool LOSS, int NW>
+// INLINE (a step over a few views of the plain grid, e.g. the single view of the reference's autograd pair,
+// sdf_renderer.py:311-357): the launch has no prologue.  Every workgroup derives its view's record itself -- the
+// same arithmetic in every lane, ~0.7 us of latency instead of a launch of ~4 us in front of a 14 us kernel -- the
+// view's first workgroup leaves the record for the step's backward, and the threads of the grid zero-fill the
+// gradient volume between them.
+struct InlineSetup {
+  const float* pos;
+  const float* quat;
+  const float* inv_scale;
+  float fx, fy;
+  ViewSetup* out;
+  float* g_zero;
+  size_t n_zero;
+};
+template <int RT, bool PACKED, int SX, int SY, bool LOSS, int NW, bool INLINE = false>
 __global__ __launch_bounds__(NW * 64) void render_forward_kernel(
     const float* __restrict__ src, int R, long long src_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, float cx, float cy,
     float rfx, float rfy, float threshold, int vec_ok, float* __restrict__ depth,
     const float* __restrict__ target, float* __restrict__ loss_part, unsigned* __restrict__ epoch,
-    const unsigned* __restrict__ spans) {
+    const unsigned* __restrict__ spans, InlineSetup in) {
+  if (INLINE) {
+    const int b = blockIdx.z;
+    ViewSetup s;
+    setup_pose(b, in.pos, in.quat, in.inv_scale, R, in.fx, in.fy, s);
+    setup_box<false>(s, R, W, H, cx, cy, in.fx, in.fy, nullptr, threshold);
+    if ((blockIdx.x | blockIdx.y) == 0 && threadIdx.x == 0) in.out[b] = s;
+    const size_t nthreads = (size_t)gridDim.x * gridDim.y * gridDim.z * (NW * 64);
+    const size_t me = (((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (NW * 64) + threadIdx.x;
+    for (size_t i = me; i < in.n_zero; i += nthreads) in.g_zero[i] = 0.0f;
+    forward_tile<RT, PACKED, SX, SY, LOSS, PACKED, NW>(blockIdx.x, blockIdx.y, ntx, nty, b, src, R, src_view_stride,
+                                                       s, W, H, cx, cy, rfx, rfy, threshold, vec_ok, depth, target,
+                                                       loss_part, spans);
+    return;
+  }
   forward_tile<RT, PACKED, SX, SY, LOSS, PACKED, NW>(blockIdx.x, blockIdx.y, ntx, nty, blockIdx.z, src, R,
-                                         src_view_stride, setup, W, H, cx, cy, rfx, rfy, threshold,
+                                         src_view_stride, setup[blockIdx.z], W, H, cx, cy, rfx, rfy, threshold,
                                          vec_ok, depth, target, loss_part, spans);
   // The workspace's epoch advances once per forward call, after its prologue launch (forward_prologue_kernel), and
   // the entries that launch published are wiped (equal words never read as an entry: the payloads of a valid one
@@ -770,75 +795,6 @@ __host__ __device__ constexpr int tile_fixed_bits(int pixels, int table_bits) {
 template <typename Hash> struct HashIs32 { static constexpr bool value = false; };
 template <int SLOTS> struct HashIs32<PairRunHash<SLOTS>> { static constexpr bool value = true; };
 
-// TAIL: the view's pose gradients are summed INSIDE the image kernel (no reduce launch: ~4.6 us of a step, ~4.5 us
-// of a 25 us single-view pair).  Every tile of the view's rectangle leaves its 8 sums as a 64-byte record of
-// eight 64-bit words {value, tag}, each written with one agent-scope atomic store (they bypass the per-XCD L2s,
-// which are not coherent with each other), tag = the workspace's backward epoch -- advanced by whichever launch
-// wrote the view records, so no record of an earlier call carries it.  The tile of the rectangle that the
-// dispatcher hands out LAST reads the rectangle's records back (agent-scope atomic loads, tag checked, polling while
-// a tile dispatched before it is still running -- such a tile waits for nothing, so it finishes), adds them in a
-// fixed order and writes the view's gradients.  No fence (a release at agent scope writes the whole L2 back on
-// this part: measured 2x on a single-view pair in round 2), no counter, no second launch.
-struct TailOut {
-  float* g_pos;
-  float* g_quat;
-  float* g_inv_scale;
-  const unsigned* sync;   // the workspace's sync header: word 2 = backward epoch
-};
-constexpr int kTailMaxPolls = 1 << 22;
-
-template <bool TAIL>
-__device__ __forceinline__ void store_partial(float* __restrict__ partials, size_t record, int k, float v, unsigned tag) {
-  if (TAIL)
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(partials) + record * 8 + k,
-                       ((unsigned long long)tag << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else
-    partials[record * 8 + k] = v;
-}
-
-// KIND: 0 = 32 x 8 tiles of a small call, 1 = 64 x 8 batch tiles, 2 = 32 x 32 batch tiles
-template <int KIND>
-__device__ __forceinline__ size_t tile_record(size_t base, int tx, int ty, int ntx, int W) {
-  return base + (KIND == 2 ? (size_t)backward_big_record(tx, ty, W) : (size_t)ty * ntx + tx);
-}
-// Is (tx, ty) the tile of the rectangle [tx0, tx1] x [ty0, ty1] that the launch dispatches last?  Workgroups go out
-// in the order of blockIdx (x fastest, then y); 32 x 32 tiles sit at workgroup (tx >> 1, 2 ty + (tx & 1)).
-template <int KIND>
-__device__ __forceinline__ bool dispatched_last(int tx, int ty, int tx0, int tx1, int ty1) {
-  if (ty != ty1) return false;
-  if (KIND != 2) return tx == tx1;
-  const int odd = (tx1 & 1) ? tx1 : tx1 - 1;          // largest odd column of the rectangle, if it has one
-  return (odd >= tx0) ? tx == odd : tx == tx1;
-}
-// wave 0 of the view's last tile: sum the rectangle's records (lane = 8 * (tile mod 8) + component)
-template <int KIND>
-__device__ __forceinline__ void tail_reduce(const float* __restrict__ partials, size_t base, int ntx, int W, int b,
-                                            int tx0, int tx1, int ty0, int ty1, unsigned tag, const TailOut& out,
-                                            int lane) {
-  const unsigned long long* words = reinterpret_cast<const unsigned long long*>(partials);
-  const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1), k = lane & 7;
-  float acc = 0.0f;
-  for (int i0 = 0; i0 < n; i0 += 8) {
-    const int i = i0 + (lane >> 3);
-    const bool have = i < n;
-    const int ty = ty0 + i / nx, tx = tx0 + i % nx;
-    const unsigned long long* p = words + tile_record<KIND>(base, have ? tx : tx0, have ? ty : ty0, ntx, W) * 8 + k;
-    unsigned long long w = 0;
-    for (int poll = 0; poll < kTailMaxPolls; ++poll) {
-      w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (__all(!have || (unsigned)(w >> 32) == tag)) break;
-      __builtin_amdgcn_s_sleep(2);
-    }
-    if (have) acc += __uint_as_float((unsigned)w);
-  }
-  acc += __shfl_xor(acc, 8, 64);
-  acc += __shfl_xor(acc, 16, 64);
-  acc += __shfl_xor(acc, 32, 64);
-  if (lane < 3) out.g_pos[3 * b + lane] = acc;
-  else if (lane < 7) out.g_quat[4 * b + lane - 3] = acc;
-  else if (lane == 7) out.g_inv_scale[b] = acc;
-}
-
 // grid-space hit point of a pixel of depth z: the arithmetic of the reference's backward (cu:334-345) in the object
 // frame.  ONE function for the bounds pass and the main pass of a tile: the same instruction sequence on the same
 // inputs chooses the same cell in both.
@@ -869,9 +825,9 @@ __device__ __forceinline__ HitPoint hit_point(const ViewSetup& s, int row, int c
 // contribution is rounded ONCE, per pixel, to the fixed quantum 2^-kDetQuantumBits -- a function of the pixel alone,
 // not of its tile -- and everything after that is integer addition (64-bit LDS run table, 64-bit global atomics).
 constexpr int kDetQuantumBits = SDFR_FIXED_QUANTUM_BITS;
-template <int RT, int SX, int SY, typename Hash, bool LOSS, bool DET = false, bool TAIL = false>
+template <int RT, int SX, int SY, typename Hash, bool LOSS, bool DET = false>
 __device__ __forceinline__ void backward_tile(
-    BackwardLds<Hash>& lds, int tile_x, int tile_y, size_t rec_base, int ntx_rec, const TailOut& tail, int b, float loss_k,
+    BackwardLds<Hash>& lds, int tile_x, int tile_y, size_t record, int b, float loss_k,
     const float* __restrict__ grad_depth, const float* __restrict__ depth,
     const float* __restrict__ sdf, int R, long long sdf_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx, float rfy,
@@ -887,12 +843,7 @@ __device__ __forceinline__ void backward_tile(
   const ViewSetup& s = setup[b];
   const Rect rc{s.rect[0], s.rect[1], s.rect[2], s.rect[3]};
   if (!overlaps(rc, px0, py0, kTileW, kTileH)) return;  // depth is 0 there by construction
-  // this tile's pose sums go to record `record` (TAIL: 64-byte tagged records; else 32 bytes for the reduce launch)
-  constexpr int kKind = (SX == kBwdBigTile.sx && SY == kBwdBigTile.sy) ? 2 : (kSubs > 1 ? 1 : 0);
-  const size_t record = tile_record<kKind>(rec_base, tile_x, tile_y, ntx_rec, W);
-  const unsigned tag = TAIL ? tail.sync[2] : 0u;
-  const int rtx0 = rc.x0 / kTileW, rtx1 = (rc.x1 - 1) / kTileW, rty0 = rc.y0 / kTileH, rty1 = (rc.y1 - 1) / kTileH;
-  const bool reducer = TAIL && dispatched_last<kKind>(tile_x, tile_y, rtx0, rtx1, rty1);
+  float* part = partials + record * 8;  // this tile's pose sums
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const float* zimg = depth + (size_t)b * H * W;
@@ -928,8 +879,7 @@ __device__ __forceinline__ void backward_tile(
     any_hit = any_hit || hit;
   }
   if (!__syncthreads_or(any_hit)) {
-    if (tid < 8) store_partial<TAIL>(partials, record, tid, 0.0f, tag);
-    if (reducer && wave == 0) tail_reduce<kKind>(partials, rec_base, ntx_rec, W, b, rtx0, rtx1, rty0, rty1, tag, tail, lane);
+    if (tid < 8) part[tid] = 0.0f;
     return;
   }
   const float h = 0.5f * (float)(Rr - 1);
@@ -1112,9 +1062,7 @@ __device__ __forceinline__ void backward_tile(
     wave_part[wave][lane] = 0.0f;
   }
   __syncthreads();
-  if (tid < 8)
-    store_partial<TAIL>(partials, record, tid,
-                        (wave_part[0][tid] + wave_part[1][tid]) + (wave_part[2][tid] + wave_part[3][tid]), tag);
+  if (tid < 8) part[tid] = (wave_part[0][tid] + wave_part[1][tid]) + (wave_part[2][tid] + wave_part[3][tid]);
 
   if (dense) {
     // consecutive lanes take consecutive words = consecutive z of a box row: contiguous global float atomics
@@ -1130,8 +1078,6 @@ __device__ __forceinline__ void backward_tile(
   } else {
     hash.template flush<DET>(gvol, Rr * Rr * Rr, from_fixed, tid, kBlock);
   }
-  // (after the flush: the wait for the view's other tiles does not hold this tile's atomics back)
-  if (reducer && wave == 0) tail_reduce<kKind>(partials, rec_base, ntx_rec, W, b, rtx0, rtx1, rty0, rty1, tag, tail, lane);
 }
 
 // Batches pre-sum in the z-pair run table (device.hpp, PairRunHash), small calls in 2-voxel runs x 1024 slots.
@@ -1142,9 +1088,9 @@ using BatchTable = PairRunHash<SDFR_BWD_SLOTS>;
 // One tile of view b.  BATCH: workgroup (bx, by) of the view's own tiling -- 32 x 32 pixels or 64 x 8, chosen per
 // view by the set-up (ViewSetup::bwd_big; common.hpp, kBwdBigTile) -- otherwise the 32 x 8 tile (bx, by) of a
 // small call.  Returns are workgroup-uniform.
-template <int RT, bool BATCH, bool LOSS, bool DET = false, bool PAIR = false, bool TAIL = false>
+template <int RT, bool BATCH, bool LOSS, bool DET = false, bool PAIR = false>
 __device__ __forceinline__ void backward_dispatch(
-    unsigned char* raw, const TailOut& tail, int bx, int by, int ntx, int nty, int stride, int b,
+    unsigned char* raw, int bx, int by, int ntx, int nty, int stride, int b,
     const float* __restrict__ grad_depth, const float* __restrict__ depth, const float* __restrict__ sdf, int R,
     long long sdf_view_stride, const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx,
     float rfy, int sdf_grad_mode, float* __restrict__ g_sdf, long long g_sdf_view_stride,
@@ -1156,26 +1102,16 @@ __device__ __forceinline__ void backward_dispatch(
     const float w = loss_grad ? loss_weight * loss_grad[b] : loss_weight;
     loss_k = cnt > 0.0f ? w / cnt : 0.0f;
   }
-  if (TAIL && bx == 0 && by == 0 && threadIdx.x < 8) {
-    // a view whose rectangle is empty has no tile to sum for it: its gradients are zero
-    const ViewSetup& s = setup[b];
-    if (s.rect[2] <= s.rect[0] || s.rect[3] <= s.rect[1]) {
-      const int k = threadIdx.x;
-      if (k < 3) tail.g_pos[3 * b + k] = 0.0f;
-      else if (k < 7) tail.g_quat[4 * b + k - 3] = 0.0f;
-      else tail.g_inv_scale[b] = 0.0f;
-    }
-  }
   if (BATCH) {
     using Table = typename std::conditional<DET, BatchHash, BatchTable>::type;   // DET: 64-bit sums
     auto& lds = *reinterpret_cast<BackwardLds<Table>*>(raw);
-    const size_t base = (size_t)b * stride;   // the view's records; ntx = the 64 x 8 tiling's
+    const size_t record = (size_t)b * stride + by * ntx + bx;   // ntx = the 64 x 8 tiling's
     if (setup[b].bwd_big) {
       const int tx = 2 * bx + (by & 1), ty = by >> 1;
       if (tx >= kBwdBigTile.nx(W) || ty >= kBwdBigTile.ny(H)) return;
-      backward_tile<RT, kBwdBigTile.sx, kBwdBigTile.sy, Table, LOSS, DET, TAIL>(
-          lds, tx, ty, base, ntx, tail, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy,
-          rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
+      backward_tile<RT, kBwdBigTile.sx, kBwdBigTile.sy, Table, LOSS, DET>(
+          lds, tx, ty, record, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx,
+          rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
     } else if (PAIR) {
 #pragma unroll 1
       // two tiles, one after the other.  Every exit of a tile is workgroup-uniform, and no barrier is needed between
@@ -1185,20 +1121,20 @@ __device__ __forceinline__ void backward_dispatch(
       for (int k = 0; k < 2; ++k) {
         const int ty = 2 * by + k;
         if (ty >= nty) break;
-        backward_tile<RT, SDFR_MACRO_SX, SDFR_MACRO_SY, Table, LOSS, DET, TAIL>(
-            lds, bx, ty, base, ntx, tail, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride,
+        backward_tile<RT, SDFR_MACRO_SX, SDFR_MACRO_SY, Table, LOSS, DET>(
+            lds, bx, ty, (size_t)b * stride + ty * ntx + bx, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride,
             setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
       }
     } else {
       if (by >= nty) return;
-      backward_tile<RT, SDFR_MACRO_SX, SDFR_MACRO_SY, Table, LOSS, DET, TAIL>(
-          lds, bx, by, base, ntx, tail, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy,
-          rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
+      backward_tile<RT, SDFR_MACRO_SX, SDFR_MACRO_SY, Table, LOSS, DET>(
+          lds, bx, by, record, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx,
+          rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
     }
   } else {
     auto& lds = *reinterpret_cast<BackwardLds<SmallHash>*>(raw);
-    backward_tile<RT, 1, 1, SmallHash, LOSS, DET, TAIL>(
-        lds, bx, by, (size_t)b * nty * ntx, ntx, tail, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride,
+    backward_tile<RT, 1, 1, SmallHash, LOSS, DET>(
+        lds, bx, by, ((size_t)b * nty + by) * ntx + bx, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride,
         setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
   }
 }
@@ -1212,19 +1148,19 @@ __device__ __forceinline__ void backward_dispatch(
 #else
 #define SDFR_BWD_OCC
 #endif
-template <int RT, bool BATCH, bool LOSS, bool DET = false, bool PAIR = false, bool TAIL = false>
+template <int RT, bool BATCH, bool LOSS, bool DET = false, bool PAIR = false>
 __global__ __launch_bounds__(kBlock) SDFR_BWD_OCC void render_backward_kernel(
     const float* __restrict__ grad_depth, const float* __restrict__ depth,
     const float* __restrict__ sdf, int R, long long sdf_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, int stride, float cx, float cy,
     float rfx, float rfy, int sdf_grad_mode, float* __restrict__ g_sdf,
     long long g_sdf_view_stride, float* __restrict__ partials, const float* __restrict__ loss_grad,
-    const float* __restrict__ loss_stats, float loss_weight, TailOut tail) {
+    const float* __restrict__ loss_stats, float loss_weight) {
   constexpr size_t kBatchLds = sizeof(BackwardLds<BatchTable>) > sizeof(BackwardLds<BatchHash>)
                                    ? sizeof(BackwardLds<BatchTable>) : sizeof(BackwardLds<BatchHash>);
   __shared__ __attribute__((aligned(16))) unsigned char raw[BATCH ? (DET ? kBatchLds : sizeof(BackwardLds<BatchTable>))
                                                                   : sizeof(BackwardLds<SmallHash>)];
-  backward_dispatch<RT, BATCH, LOSS, DET, PAIR, TAIL>(raw, tail, blockIdx.x, blockIdx.y, ntx, nty, stride, blockIdx.z,
+  backward_dispatch<RT, BATCH, LOSS, DET, PAIR>(raw, blockIdx.x, blockIdx.y, ntx, nty, stride, blockIdx.z,
                                      grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy,
                                      sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, loss_grad, loss_stats,
                                      loss_weight);
@@ -1252,7 +1188,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_pc_kernel(
     if (bx < pa.nblk) pc_backward_block<RT, true>(*reinterpret_cast<PcBackwardLds*>(raw), pa, bx, b);
     return;
   }
-  backward_dispatch<RT, BATCH, true>(raw, TailOut{}, blockIdx.x, (int)blockIdx.y - pc_rows, ntx, nty, stride, b, target, depth,
+  backward_dispatch<RT, BATCH, true>(raw, blockIdx.x, (int)blockIdx.y - pc_rows, ntx, nty, stride, b, target, depth,
                                      sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf,
                                      g_sdf_view_stride, partials, loss_grad, loss_stats, loss_weight);
 }
@@ -1374,8 +1310,7 @@ size_t partials_bytes(int B, int W, int H) {
   if (B <= 0 || W <= 0 || H <= 0) return 0;
   // one 32-byte record per tile of the finer geometry (or per workgroup of a batch launch)
   const size_t small = (size_t)kSmallTile.nx(W) * kSmallTile.ny(H), batch = (size_t)backward_tile_stride(W, H);
-  // (64 bytes per record: the in-kernel reduce's tagged form; the reduce launch's plain form uses the first half)
-  return (size_t)B * (small > batch ? small : batch) * 16 * sizeof(float);
+  return (size_t)B * (small > batch ? small : batch) * 8 * sizeof(float);
 }
 
 }  // namespace
@@ -1478,6 +1413,10 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
   float* cells = lay.cells;
   float* loss_part = lay.loss_part;
   const bool packed = use_packed(R, B, sdf_view_stride);
+  const TileGeom geom = forward_geom(B, W, H);
+  // (small tiles: the set-up each workgroup repeats is amortised over one 32 x 8 tile, so only where launches are
+  // what a call costs)
+  const bool inline_setup = g_zero && !packed && !with_loss && geom.sx * geom.sy == 1 && B <= kInlineSetupMaxViews;
   unsigned* epoch = nullptr;
   // (the one-launch prologue reads the grid with 16-byte loads: other grids take the two-launch form)
   if (packed && (R & 3) == 0 && ((uintptr_t)sdf & 15) == 0) {
@@ -1487,13 +1426,14 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
                        setup, threshold, g_zero, n_zero, g_prologue_max_polls.load(std::memory_order_relaxed),
                        lay.spans);
     epoch = lay.sync;
+  } else if (g_zero && !packed && inline_setup) {
+    // a step over a few views of the plain grid: no prologue launch at all (render_forward_kernel, INLINE)
   } else if (g_zero && !packed) {
     // a step over a few views (or with one grid per view): zero fill + set-up in ONE launch -- the stand-alone
     // backward's prologue, run early.  Without plane minima the record does not depend on the threshold, and the
     // one-thread and one-wave forms of the set-up give the same record (min / max of the same 8 corners).
     hipLaunchKernelGGL(backward_prologue_kernel, dim3((unsigned)((std::max(n_zero, (size_t)B) + 255) / 256)),
-                       dim3(256), 0, st, g_zero, n_zero, pos, quat, inv_scale, B, R, W, H, cx, cy, fx, fy, setup,
-                       lay.sync);
+                       dim3(256), 0, st, g_zero, n_zero, pos, quat, inv_scale, B, R, W, H, cx, cy, fx, fy, setup);
   } else {
     if (g_zero) zero_words_async(g_zero, n_zero, st);
     float* plane_min = nullptr;
@@ -1504,9 +1444,8 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
                          (float4*)cells, n_pack, plane_min);
     }
     hipLaunchKernelGGL(view_setup_kernel, dim3(B), dim3(64), 0, st, pos, quat, inv_scale, B, R,
-                       W, H, cx, cy, fx, fy, setup, plane_min, threshold, lay.spans, lay.sync);
+                       W, H, cx, cy, fx, fy, setup, plane_min, threshold, lay.spans);
   }
-  const TileGeom geom = forward_geom(B, W, H);
   const bool macro = geom.sx * geom.sy > 1;
   const int ntx = geom.nx(W), nty = geom.ny(H);
   const dim3 grid_tile((unsigned)ntx, (unsigned)nty, (unsigned)B);
@@ -1516,7 +1455,7 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
   hipLaunchKernelGGL((render_forward_kernel<RT, PK, SX, SY, LOSS, (SX * SY > 1 && SX < 4 ? kFwdWaves : 4)>), grid_tile, \
                      dim3((SX * SY > 1 && SX < 4 ? kFwdWaves : 4) * 64), 0, st, \
                      SRC, R, STRIDE, setup, W, H, ntx, nty, cx, cy, rfx, rfy, threshold, vec_ok,      \
-                     depth, target, loss_part, epoch, lay.spans)
+                     depth, target, loss_part, epoch, lay.spans, InlineSetup{})
 #define SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, SX, SY)                                               \
   do {                                                                                               \
     if (with_loss) SDFR_LAUNCH_FWD_L(RT, PK, SRC, STRIDE, SX, SY, true);                             \
@@ -1528,7 +1467,17 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
     else if (macro) SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, SDFR_FWD_SX, SDFR_FWD_SY);                \
     else SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, 1, 1);                                               \
   } while (0)
-  if (packed) {
+  if (inline_setup) {
+    const InlineSetup in{pos, quat, inv_scale, fx, fy, setup, g_zero, n_zero};
+    if (R == 64)
+      hipLaunchKernelGGL((render_forward_kernel<64, false, 1, 1, false, 4, true>), grid_tile, dim3(256), 0, st, sdf, R,
+                         sdf_view_stride, setup, W, H, ntx, nty, cx, cy, rfx, rfy, threshold, vec_ok, depth, target,
+                         loss_part, epoch, lay.spans, in);
+    else
+      hipLaunchKernelGGL((render_forward_kernel<0, false, 1, 1, false, 4, true>), grid_tile, dim3(256), 0, st, sdf, R,
+                         sdf_view_stride, setup, W, H, ntx, nty, cx, cy, rfx, rfy, threshold, vec_ok, depth, target,
+                         loss_part, epoch, lay.spans, in);
+  } else if (packed) {
     if (R == 64) SDFR_LAUNCH_FWD(64, true, cells, 0LL); else SDFR_LAUNCH_FWD(0, true, cells, 0LL);
   } else {
     if (R == 64) SDFR_LAUNCH_FWD(64, false, sdf, sdf_view_stride); else SDFR_LAUNCH_FWD(0, false, sdf, sdf_view_stride);
@@ -1634,8 +1583,7 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
   // tighter rectangles and launches no prologue.)
   if (!prepared)
     hipLaunchKernelGGL(backward_prologue_kernel, dim3((unsigned)((std::max(g_words, (size_t)B) + 255) / 256)),
-                       dim3(256), 0, st, g_sdf, g_words, pos, quat, inv_scale, B, R, W, H, cx, cy, fx, fy, setup,
-                       (unsigned*)((char*)workspace + sync_offset(B)));
+                       dim3(256), 0, st, g_sdf, g_words, pos, quat, inv_scale, B, R, W, H, cx, cy, fx, fy, setup);
   // deterministic mode: the image kernel adds integers into the workspace's 64-bit volume, converted at the end
   long long* fixed = nullptr;
   float* g_out = g_sdf;
@@ -1650,9 +1598,6 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
   const int ntx = geom.nx(W), nty = geom.ny(H);
   const int stride = batch ? backward_tile_stride(W, H) : 0;
   const bool half = half_hint && batch && !det && !with_loss && !pc;   // (a hint: ignored where it does not apply)
-  // the view's pose gradients summed inside the image kernel (TailOut) instead of by a reduce launch
-  const bool tail = !deferred && !det && !with_loss && !pc && (SDFR_BWD_TAIL == 2 || (SDFR_BWD_TAIL == 1 && !batch));
-  const TailOut tail_out{g_pos, g_quat, g_inv_scale, (const unsigned*)((const char*)workspace + sync_offset(B))};
   const int rows = batch ? (half ? backward_half_rows(H) : backward_batch_rows(H)) : nty;
   const int pc_rows = pc ? (pc->nblk + ntx - 1) / ntx : 0;
   const dim3 grid_tile((unsigned)ntx, (unsigned)(rows + pc_rows), (unsigned)B);
@@ -1662,15 +1607,6 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
       sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, loss_grad, loss_stats, loss_weight
   // (culling a step's backward tiles with the forward's band spans was built and measured: the two dependent scalar
   // loads in front of every tile of the rectangle cost more than the culled tiles' depth loads, step +3.5 us)
-#define SDFR_LAUNCH_BWD_T(RT, BATCH, TAIL)                                                           \
-  do {                                                                                               \
-    if (half)                                                                                        \
-      hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false, false, BATCH, TAIL>), grid_tile,  \
-                         dim3(kBlock), 0, st, SDFR_BWD_ARGS, tail_out);                              \
-    else                                                                                             \
-      hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false, false, false, TAIL>), grid_tile,  \
-                         dim3(kBlock), 0, st, SDFR_BWD_ARGS, tail_out);                              \
-  } while (0)
 #define SDFR_LAUNCH_BWD(RT, BATCH)                                                                   \
   do {                                                                                               \
     if (pc)                                                                                          \
@@ -1678,19 +1614,22 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
                          SDFR_BWD_ARGS, pc_rows, *pc);                                               \
     else if (with_loss)                                                                              \
       hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, true>), grid_tile, dim3(kBlock), 0, st,  \
-                         SDFR_BWD_ARGS, tail_out);                                                   \
+                         SDFR_BWD_ARGS);                                                      \
     else if (det)                                                                                    \
       hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false, true>), grid_tile, dim3(kBlock), 0, st, \
-                         SDFR_BWD_ARGS, tail_out);                                                   \
-    else if (tail) SDFR_LAUNCH_BWD_T(RT, BATCH, true);                                               \
-    else SDFR_LAUNCH_BWD_T(RT, BATCH, false);                                                        \
+                         SDFR_BWD_ARGS);                                                      \
+    else if (half)                                                                                   \
+      hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false, false, BATCH>), grid_tile, dim3(kBlock), 0, st, \
+                         SDFR_BWD_ARGS);                                                      \
+    else                                                                                             \
+      hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false>), grid_tile, dim3(kBlock), 0, st, \
+                         SDFR_BWD_ARGS);                                                      \
   } while (0)
   if (R == 64) { if (batch) SDFR_LAUNCH_BWD(64, true); else SDFR_LAUNCH_BWD(64, false); }
   else { if (batch) SDFR_LAUNCH_BWD(0, true); else SDFR_LAUNCH_BWD(0, false); }
 #undef SDFR_LAUNCH_BWD
-#undef SDFR_LAUNCH_BWD_T
 #undef SDFR_BWD_ARGS
-  if (!deferred && !tail)
+  if (!deferred)
     hipLaunchKernelGGL(pose_reduce_kernel, dim3(B), dim3(64), 0, st, partials, setup, W, H, ntx, nty,
                        geom.w(), geom.h(), stride, g_pos, g_quat, g_inv_scale);
   if (det)

@@ -51,8 +51,3 @@
 #ifndef SDFR_BWD_WAVES_PER_EU
 #define SDFR_BWD_WAVES_PER_EU 8
 #endif
-// the pose gradients of a view are summed inside the backward kernel by the view's last tile (render.hip, TailOut)
-// instead of by a reduce launch: 0 never, 1 small calls (32 x 8 tiles) only, 2 always
-#ifndef SDFR_BWD_TAIL
-#define SDFR_BWD_TAIL 2
-#endif

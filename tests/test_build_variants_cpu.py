@@ -15,7 +15,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 OVERRIDES = {"SDFR_MACRO_SX": "2", "SDFR_MACRO_SY": "1", "SDFR_FWD_SX": "4", "SDFR_FWD_SY": "1",
              "SDFR_BWD_MACRO_MIN": "8192", "SDFR_FWD_MACRO_MIN": "8192", "SDFR_FWD_WIDE": "0", "SDFR_FWD_WAVES": "4",
              "SDFR_BWD_BIG_MIN_RATIO": "2.4f", "SDFR_PACKED_MIN_VIEWS": "2", "SDFR_BWD_SLOTS": "256",
-             "SDFR_DENSE_CAP": "3072", "SDFR_BWD_WAVES_PER_EU": "0", "SDFR_BWD_TAIL": "1"}
+             "SDFR_DENSE_CAP": "3072", "SDFR_BWD_WAVES_PER_EU": "0"}
 
 
 def test_every_tunable_is_listed_and_overridable():
