@@ -171,6 +171,24 @@ SDFR_API int sdfr_render_step_forward(const float* sdf, int R, long long sdf_vie
                              float cy, float fx, float fy, float threshold, float* depth, float* g_sdf,
                              long long g_sdf_view_stride, void* workspace, size_t workspace_bytes,
                              int device, void* stream);
+/* The same pair for the loss-fused forms (below): sdfr_render_step_forward_l1 = sdfr_render_forward_l1 that also
+ * zero-fills g_sdf and leaves the view records; sdfr_render_step_backward_l1_pc = sdfr_render_backward_l1_pc without
+ * its prologue launch.  For a few views of the plain grid the forward has no prologue launch either (every
+ * workgroup derives its view's record): the captured loop's iteration loses two launches. */
+SDFR_API int sdfr_render_step_forward_l1(const float* sdf, int R, long long sdf_view_stride, const float* pos,
+                                const float* quat, const float* inv_scale, int B, int W, int H, float cx, float cy,
+                                float fx, float fy, float threshold, const float* target, float* depth, float* loss,
+                                float* loss_stats, float* g_sdf, long long g_sdf_view_stride, void* workspace,
+                                size_t workspace_bytes, int device, void* stream);
+SDFR_API int sdfr_render_step_backward_l1_pc(
+    const float* loss_grad, float loss_weight, const float* loss_stats, const float* target, const float* depth,
+    const float* sdf, int R, long long sdf_view_stride, const float* pos, const float* quat, const float* inv_scale,
+    int B, int W, int H, float cx, float cy, float fx, float fy, int sdf_grad_mode, float* g_sdf,
+    long long g_sdf_view_stride, void* workspace, size_t workspace_bytes, float pc_weight, const float* points,
+    const int* offsets, int max_view_points, const float* scale, void* pc_workspace, size_t pc_workspace_bytes,
+    int device, void* stream);
+/* byte offset of the backward's tile partials in its workspace (step_layout: of a step's workspace) */
+SDFR_API size_t sdfr_render_partials_offset(int R, int B, int W, int H, int step_layout);
 SDFR_API int sdfr_render_step_backward(const float* grad_depth, const float* depth, const float* sdf, int R,
                               long long sdf_view_stride, int B, int W, int H, float cx, float cy,
                               float fx, float fy, int sdf_grad_mode, float* g_sdf,
@@ -324,6 +342,21 @@ SDFR_API int sdfr_views_to_pose_grad_deferred(const float* orientation, const fl
                                      const void* pc_workspace, const int* offsets, int max_view_points,
                                      const float* quat_c, float* pc_loss, float* g_position,
                                      float* g_orientation, float* g_scale, int device, void* stream);
+
+/* The tail of one iteration of the captured loop in ONE launch (one workgroup): sdfr_views_to_pose_grad_deferred (the
+ * pose gradients go to grads[0..7]), sdfr_point_constraint (con_source NULL: none), sdfr_adam_step on params /
+ * grads [position 3 | orientation 4 | scale 1 | latent n_params - 8] (grads[8..] must hold the latent gradient
+ * already), and sdfr_pose_to_views for the NEXT iteration (pos_c / quat_c / inv_scale / scale_v are read by the
+ * chain as this iteration's and then overwritten with the next one's).  Same arithmetic in the same order as the
+ * four calls.  render_partials_offset: sdfr_render_partials_offset (the tile partials of a stand-alone or of a
+ * step's backward). */
+SDFR_API int sdfr_loop_tail(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int* step, int n_params,
+                   float lr_position, float lr_orientation, float lr_scale, float lr_latent, int update_latent,
+                   const float* cam_pos, const float* cam_quat, int V, const void* render_workspace,
+                   size_t render_partials_offset, int W, int H, const void* pc_workspace, const int* offsets,
+                   int max_view_points, float* pos_c, float* quat_c, float* inv_scale, float* scale_v, float* pc_loss,
+                   const float* con_source, const float* con_target, float con_weight, float* con_loss, int device,
+                   void* stream);
 
 /* sdfr_render_backward_l1 and sdfr_pc_l1_backward_accumulate of one loop iteration in ONE launch (they are
  * independent and neither fills the chip for a handful of views): arguments as in those two calls -- the per-view

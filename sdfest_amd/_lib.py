@@ -26,6 +26,16 @@ SIGNATURES = {
     "sdfr_render_forward_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
     "sdfr_render_sync_offset": (c_sz, [c_int]),
     "sdfr_debug_set_prologue_polls": (c_int, [c_int]),
+    "sdfr_render_partials_offset": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
+    "sdfr_render_step_forward_l1": (c_int, [c_fp, c_int, c_ll, c_fp, c_fp, c_fp, c_int, c_int, c_int,
+                                            c_f, c_f, c_f, c_f, c_f, c_fp, c_fp, c_fp, c_fp, c_fp, c_ll, c_fp, c_sz,
+                                            c_int, c_fp]),
+    "sdfr_render_step_backward_l1_pc": (c_int, [c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_int, c_ll, c_fp, c_fp, c_fp,
+                                                c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_int, c_fp, c_ll, c_fp, c_sz,
+                                                c_f, c_fp, c_fp, c_int, c_fp, c_fp, c_sz, c_int, c_fp]),
+    "sdfr_loop_tail": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_f, c_f, c_f, c_f, c_int, c_fp, c_fp, c_int,
+                               c_fp, c_sz, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
+                               c_f, c_fp, c_int, c_fp]),
     "sdfr_render_fixed_volume_offset": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
     "sdfr_fixed_to_float": (c_int, [c_fp, c_sz, c_fp, c_int, c_fp]),
     "sdfr_render_forward": (c_int, [c_fp, c_int, c_ll, c_fp, c_fp, c_fp, c_int, c_int, c_int,

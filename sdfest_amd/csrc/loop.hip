@@ -36,15 +36,13 @@ __device__ __forceinline__ void quat_matrix(const float* q, float* m) {
 // The reference rotates with quaternion_apply = q * (v,0) * conj(q) (quaternion_utils.py:36-54),
 // which for a non-unit q scales by |q|^2; camera orientations are unit quaternions, for which
 // this equals the matrix product.  The gradient chain below assumes unit camera quaternions.
-__global__ void pose_to_views_kernel(const float* __restrict__ position,
-                                     const float* __restrict__ orientation,
-                                     const float* __restrict__ scale,
-                                     const float* __restrict__ cam_pos,
-                                     const float* __restrict__ cam_quat, int V,
-                                     float* __restrict__ pos_c, float* __restrict__ quat_c,
-                                     float* __restrict__ inv_scale, float* __restrict__ scale_v) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= V) return;
+__device__ __forceinline__ void pose_to_view(int v, const float* __restrict__ position,
+                                             const float* __restrict__ orientation,
+                                             const float* __restrict__ scale,
+                                             const float* __restrict__ cam_pos,
+                                             const float* __restrict__ cam_quat,
+                                             float* __restrict__ pos_c, float* __restrict__ quat_c,
+                                             float* __restrict__ inv_scale, float* __restrict__ scale_v) {
   const float q[4] = {orientation[0], orientation[1], orientation[2], orientation[3]};
   const float inv_n = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   const float nq[4] = {q[0] * inv_n, q[1] * inv_n, q[2] * inv_n, q[3] * inv_n};
@@ -59,6 +57,16 @@ __global__ void pose_to_views_kernel(const float* __restrict__ position,
   quat_mul(qc, nq, quat_c + 4 * v);
   inv_scale[v] = 1.0f / scale[0];
   scale_v[v] = scale[0];
+}
+__global__ void pose_to_views_kernel(const float* __restrict__ position,
+                                     const float* __restrict__ orientation,
+                                     const float* __restrict__ scale,
+                                     const float* __restrict__ cam_pos,
+                                     const float* __restrict__ cam_quat, int V,
+                                     float* __restrict__ pos_c, float* __restrict__ quat_c,
+                                     float* __restrict__ inv_scale, float* __restrict__ scale_v) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < V) pose_to_view(v, position, orientation, scale, cam_pos, cam_quat, pos_c, quat_c, inv_scale, scale_v);
 }
 
 // one thread: sum the per-view gradients back to the world-frame parameters
@@ -109,7 +117,7 @@ __global__ void views_to_pose_grad_kernel(const float* __restrict__ orientation,
 // The same chain with the two per-view reductions in front of it folded in (pose_reduce_kernel of render.hip,
 // pc_loss_reduce_kernel of sampler.hip: same order of additions, so the same numbers): one launch instead of
 // three.  One workgroup; wave w reduces views w, w + 4, ... into LDS, thread 0 then runs the chain.
-__global__ __launch_bounds__(256) void views_to_pose_grad_deferred_kernel(
+__device__ __forceinline__ void deferred_chain(
     const float* __restrict__ orientation, const float* __restrict__ scale, const float* __restrict__ cam_quat,
     int V, const ViewSetup* __restrict__ setup, const float* __restrict__ tile_part, int W, int H, int ntx_all,
     int nty_all, int tile_w_all, int tile_h_all, int stride, const float* __restrict__ pc_part,
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(256) void views_to_pose_grad_deferred_kernel(
     }
   }
   __syncthreads();
-  if (threadIdx.x != 0) return;
+  if (threadIdx.x != 0) return;   // (callers that go on afterwards: every thread reaches the barrier above)
   const float q[4] = {orientation[0], orientation[1], orientation[2], orientation[3]};
   const float inv_n = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   const float nq[4] = {q[0] * inv_n, q[1] * inv_n, q[2] * inv_n, q[3] * inv_n};
@@ -217,6 +225,18 @@ __global__ __launch_bounds__(256) void views_to_pose_grad_deferred_kernel(
   for (int k = 0; k < 4; ++k) g_orientation[k] = (gn[k] - nq[k] * d) * inv_n;
   g_scale[0] = gs;
 }
+__global__ __launch_bounds__(256) void views_to_pose_grad_deferred_kernel(
+    const float* __restrict__ orientation, const float* __restrict__ scale, const float* __restrict__ cam_quat,
+    int V, const ViewSetup* __restrict__ setup, const float* __restrict__ tile_part, int W, int H, int ntx_all,
+    int nty_all, int tile_w_all, int tile_h_all, int stride, const float* __restrict__ pc_part,
+    const float* __restrict__ pc_loss_part,
+    const int* __restrict__ offsets, int n_single, int nblk, const float* __restrict__ quat_c,
+    float* __restrict__ pc_loss, float* __restrict__ g_position, float* __restrict__ g_orientation,
+    float* __restrict__ g_scale) {
+  deferred_chain(orientation, scale, cam_quat, V, setup, tile_part, W, H, ntx_all, nty_all, tile_w_all, tile_h_all,
+                 stride, pc_part, pc_loss_part, offsets, n_single, nblk, quat_c, pc_loss, g_position, g_orientation,
+                 g_scale);
+}
 
 // ---------------------------------------------------------------------------------------------
 // What the loop does besides the two image losses (simple_setup.py):
@@ -228,10 +248,9 @@ __global__ __launch_bounds__(256) void views_to_pose_grad_deferred_kernel(
 // ---------------------------------------------------------------------------------------------
 // r = q (s,0) conj(q) = (w^2 - u.u) s + 2 (u.s) u + 2 w (u x s);  loss = weight |r - t|;  the gradient
 // w.r.t. q is ADDED to g_orientation (the image terms have been written there before).
-__global__ void point_constraint_kernel(const float* __restrict__ q, const float* __restrict__ src,
-                                        const float* __restrict__ tgt, float weight,
-                                        float* __restrict__ loss, float* __restrict__ g_orientation) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+__device__ __forceinline__ void point_constraint_one(const float* __restrict__ q, const float* __restrict__ src,
+                                                     const float* __restrict__ tgt, float weight,
+                                                     float* __restrict__ loss, float* __restrict__ g_orientation) {
   const V3 u = mk(q[0], q[1], q[2]), s = mk(src[0], src[1], src[2]);
   const float w = q[3];
   const float us = dot(u, s), uu = dot(u, u);
@@ -249,6 +268,11 @@ __global__ void point_constraint_kernel(const float* __restrict__ q, const float
   g_orientation[1] += -2.0f * u.y * ns + 2.0f * s.y * nu + 2.0f * us * n.y + 2.0f * w * sxn.y;
   g_orientation[2] += -2.0f * u.z * ns + 2.0f * s.z * nu + 2.0f * us * n.z + 2.0f * w * sxn.z;
   g_orientation[3] += 2.0f * w * ns + 2.0f * dot(n, uxs);
+}
+__global__ void point_constraint_kernel(const float* __restrict__ q, const float* __restrict__ src,
+                                        const float* __restrict__ tgt, float weight,
+                                        float* __restrict__ loss, float* __restrict__ g_orientation) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) point_constraint_one(q, src, tgt, weight, loss, g_orientation);
 }
 
 // counts[0] += #(|in - est| / in < thr), counts[1] += #(in != 0) over one chunk of pixels.  The
@@ -460,10 +484,11 @@ __global__ void add_inplace_kernel(float* __restrict__ a, const float* __restric
 //   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 // One thread per scalar of the four groups laid out [position 3 | orientation 4 | scale 1 | latent L];
 // `step` lives on the device so that a captured graph advances it on every replay.
-__global__ void adam_step_kernel(float* __restrict__ params, const float* __restrict__ grads,
-                                 float* __restrict__ m, float* __restrict__ v,
-                                 int* __restrict__ step, int n, float lr_pos, float lr_quat,
-                                 float lr_scale, float lr_latent, int update_latent) {
+// (every thread of the workgroup calls it: two barriers inside)
+__device__ __forceinline__ void adam_step_block(float* __restrict__ params, const float* __restrict__ grads,
+                                                float* __restrict__ m, float* __restrict__ v,
+                                                int* __restrict__ step, int n, float lr_pos, float lr_quat,
+                                                float lr_scale, float lr_latent, int update_latent) {
   __shared__ float qnorm2;
   const int i = threadIdx.x;
   const int t = step[0] + 1;
@@ -486,6 +511,40 @@ __global__ void adam_step_kernel(float* __restrict__ params, const float* __rest
   __syncthreads();
   if (i < n) params[i] = (i >= 3 && i < 7) ? p / sqrtf(qnorm2) : p;  // :462 renormalise the quaternion
   if (i == 0) step[0] = t;
+}
+__global__ void adam_step_kernel(float* __restrict__ params, const float* __restrict__ grads,
+                                 float* __restrict__ m, float* __restrict__ v,
+                                 int* __restrict__ step, int n, float lr_pos, float lr_quat,
+                                 float lr_scale, float lr_latent, int update_latent) {
+  adam_step_block(params, grads, m, v, step, n, lr_pos, lr_quat, lr_scale, lr_latent, update_latent);
+}
+
+// The tail of one iteration of the captured loop in ONE launch (one workgroup): the gradient chain with the two
+// per-view reductions (deferred_chain), the point constraint, Adam on the 8 + L parameters, and the camera-frame
+// poses of the NEXT iteration (pose_to_view) -- four launches of ~5.7 us each in the replayed graph, none of which
+// can fill more than one workgroup.  Same functions, same order, same numbers as the separate launches.
+struct LoopTailArgs {
+  float* params; float* grads; float* m; float* v; int* step; int n;
+  float lr_pos, lr_quat, lr_scale, lr_latent; int update_latent;
+  const float* cam_pos; const float* cam_quat; int V;
+  const ViewSetup* setup; const float* tile_part; int W, H, ntx, nty, tile_w, tile_h, stride;
+  const float* pc_part; const float* pc_loss_part; const int* offsets; int n_single, nblk;
+  float* pos_c; float* quat_c; float* inv_scale; float* scale_v; float* pc_loss;
+  const float* con_source; const float* con_target; float con_weight; float* con_loss;
+};
+__global__ __launch_bounds__(256) void loop_tail_kernel(LoopTailArgs a) {
+  float* g = a.grads;
+  deferred_chain(a.params + 3, a.params + 7, a.cam_quat, a.V, a.setup, a.tile_part, a.W, a.H, a.ntx, a.nty, a.tile_w,
+                 a.tile_h, a.stride, a.pc_part, a.pc_loss_part, a.offsets, a.n_single, a.nblk, a.quat_c, a.pc_loss, g,
+                 g + 3, g + 7);
+  if (threadIdx.x == 0 && a.con_source)
+    point_constraint_one(a.params + 3, a.con_source, a.con_target, a.con_weight, a.con_loss, g + 3);
+  __syncthreads();   // the pose gradients thread 0 wrote are visible to the Adam threads
+  adam_step_block(a.params, g, a.m, a.v, a.step, a.n, a.lr_pos, a.lr_quat, a.lr_scale, a.lr_latent, a.update_latent);
+  __syncthreads();   // the updated parameters are visible to the pose chain
+  for (int v = threadIdx.x; v < a.V; v += 256)
+    pose_to_view(v, a.params, a.params + 3, a.params + 7, a.cam_pos, a.cam_quat, a.pos_c, a.quat_c, a.inv_scale,
+                 a.scale_v);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -637,6 +696,51 @@ extern "C" int sdfr_views_to_pose_grad_deferred(const float* orientation, const 
                      scale, cam_quat, V, setup, tile_part, W, H, ntx, nty, geom.w(), geom.h(), stride, pc_part,
                      pc_loss_part,
                      offsets, max_view_points, nblk, quat_c, pc_loss, g_position, g_orientation, g_scale);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfr_loop_tail(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int* step, int n_params,
+                              float lr_position, float lr_orientation, float lr_scale, float lr_latent,
+                              int update_latent, const float* cam_pos, const float* cam_quat, int V,
+                              const void* render_workspace, size_t render_partials_offset, int W, int H,
+                              const void* pc_workspace, const int* offsets, int max_view_points, float* pos_c,
+                              float* quat_c, float* inv_scale, float* scale_v, float* pc_loss,
+                              const float* con_source, const float* con_target, float con_weight, float* con_loss,
+                              int device, void* stream) {
+  const char* fn = "sdfr_loop_tail";
+  if (V < 1 || V > kDeferredMaxViews) return fail(SDFR_E_INVALID, "%s: V=%d out of range [1,%d]", fn, V, kDeferredMaxViews);
+  if (n_params < 8 || n_params > 256) return fail(SDFR_E_INVALID, "%s: n_params=%d out of range [8,256]", fn, n_params);
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !step || !cam_pos || !cam_quat || !pos_c || !quat_c ||
+      !inv_scale || !scale_v)
+    return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
+  if (render_workspace && (W <= 0 || H <= 0)) return fail(SDFR_E_INVALID, "%s: W=%d H=%d", fn, W, H);
+  if (pc_workspace && (max_view_points <= 0 || (!offsets && V > 1)))
+    return fail(SDFR_E_INVALID, "%s: bad sampler arguments", fn);
+  if (con_source && !con_target) return fail(SDFR_E_NULL, "%s: constraint target is NULL", fn);
+  if (render_workspace && ((uintptr_t)render_workspace % alignof(ViewSetup) || render_partials_offset % 16))
+    return fail(SDFR_E_INVALID, "%s: render_workspace / partials offset misaligned", fn);
+  SDFR_HIP_TRY(hipSetDevice(device));
+  const TileGeom geom = render_workspace ? backward_geom(V, W, H) : kSmallTile;
+  const int nblk = pc_workspace ? (max_view_points + kSamplerPts - 1) / kSamplerPts : 0;
+  const float* pc_part = (const float*)pc_workspace;
+  LoopTailArgs a{};
+  a.params = params; a.grads = grads; a.m = exp_avg; a.v = exp_avg_sq; a.step = step; a.n = n_params;
+  a.lr_pos = lr_position; a.lr_quat = lr_orientation; a.lr_scale = lr_scale; a.lr_latent = lr_latent;
+  a.update_latent = update_latent;
+  a.cam_pos = cam_pos; a.cam_quat = cam_quat; a.V = V;
+  a.setup = (const ViewSetup*)render_workspace;
+  a.tile_part = render_workspace ? (const float*)((const char*)render_workspace + render_partials_offset) : nullptr;
+  a.W = W; a.H = H;
+  a.ntx = render_workspace ? geom.nx(W) : 0; a.nty = render_workspace ? geom.ny(H) : 0;
+  a.tile_w = geom.w(); a.tile_h = geom.h();
+  a.stride = (render_workspace && geom.sx * geom.sy > 1) ? backward_tile_stride(W, H) : 0;
+  a.pc_part = pc_part;
+  a.pc_loss_part = (pc_workspace && pc_loss) ? pc_part + (size_t)V * nblk * 8 : nullptr;
+  a.offsets = offsets; a.n_single = max_view_points; a.nblk = nblk;
+  a.pos_c = pos_c; a.quat_c = quat_c; a.inv_scale = inv_scale; a.scale_v = scale_v; a.pc_loss = pc_loss;
+  a.con_source = con_source; a.con_target = con_target; a.con_weight = con_weight; a.con_loss = con_loss;
+  hipLaunchKernelGGL(loop_tail_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }

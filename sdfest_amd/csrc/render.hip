@@ -1330,6 +1330,12 @@ extern "C" size_t sdfr_render_fixed_volume_offset(int R, int B, int W, int H, in
   return (step_layout ? step_partials_offset(R, B, H) : scratch_offset(B, H)) + partials_bytes(B, W, H);
 }
 
+extern "C" size_t sdfr_render_partials_offset(int R, int B, int W, int H, int step_layout) {
+  (void)W;
+  if (R < 2 || B <= 0) return 0;
+  return step_layout ? step_partials_offset(R, B, H) : scratch_offset(B, H);
+}
+
 extern "C" int sdfr_fixed_to_float(const long long* fixed, size_t n, float* out, int device, void* stream) {
   if (n == 0) return 0;
   if (!fixed || !out) return fail(SDFR_E_NULL, "sdfr_fixed_to_float: NULL pointer argument");
@@ -1353,9 +1359,15 @@ extern "C" size_t sdfr_render_forward_l1_workspace_bytes(int R, int B, int W, in
   return n;
 }
 
+// (behind the int64 volume: the (sum, count) tile records of the loss-fused step, sdfr_render_step_forward_l1)
+size_t step_loss_offset(int R, int B, int W, int H) {
+  return step_partials_offset(R, B, H) + partials_bytes(B, W, H) + fixed_bytes(R);
+}
 extern "C" size_t sdfr_render_step_workspace_bytes(int R, int B, int W, int H) {
   if (R < 2 || B <= 0) return 256;
-  return step_partials_offset(R, B, H) + partials_bytes(B, W, H) + fixed_bytes(R);
+  size_t n = step_loss_offset(R, B, W, H);
+  if (W > 0 && H > 0) n += (size_t)B * kSmallTile.nx(W) * kSmallTile.ny(H) * 2 * sizeof(float);
+  return n;
 }
 
 extern "C" size_t sdfr_render_backward_workspace_bytes(int R, int B, int W, int H) {
@@ -1416,7 +1428,7 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
   const TileGeom geom = forward_geom(B, W, H);
   // (small tiles: the set-up each workgroup repeats is amortised over one 32 x 8 tile, so only where launches are
   // what a call costs)
-  const bool inline_setup = g_zero && !packed && !with_loss && geom.sx * geom.sy == 1 && B <= kInlineSetupMaxViews;
+  const bool inline_setup = g_zero && !packed && geom.sx * geom.sy == 1 && B <= kInlineSetupMaxViews;
   unsigned* epoch = nullptr;
   // (the one-launch prologue reads the grid with 16-byte loads: other grids take the two-launch form)
   if (packed && (R & 3) == 0 && ((uintptr_t)sdf & 15) == 0) {
@@ -1469,14 +1481,13 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
   } while (0)
   if (inline_setup) {
     const InlineSetup in{pos, quat, inv_scale, fx, fy, setup, g_zero, n_zero};
-    if (R == 64)
-      hipLaunchKernelGGL((render_forward_kernel<64, false, 1, 1, false, 4, true>), grid_tile, dim3(256), 0, st, sdf, R,
-                         sdf_view_stride, setup, W, H, ntx, nty, cx, cy, rfx, rfy, threshold, vec_ok, depth, target,
-                         loss_part, epoch, lay.spans, in);
-    else
-      hipLaunchKernelGGL((render_forward_kernel<0, false, 1, 1, false, 4, true>), grid_tile, dim3(256), 0, st, sdf, R,
-                         sdf_view_stride, setup, W, H, ntx, nty, cx, cy, rfx, rfy, threshold, vec_ok, depth, target,
-                         loss_part, epoch, lay.spans, in);
+#define SDFR_LAUNCH_INLINE(RT, LOSS)                                                                              \
+  hipLaunchKernelGGL((render_forward_kernel<RT, false, 1, 1, LOSS, 4, true>), grid_tile, dim3(256), 0, st, sdf, R, \
+                     sdf_view_stride, setup, W, H, ntx, nty, cx, cy, rfx, rfy, threshold, vec_ok, depth, target,  \
+                     loss_part, epoch, lay.spans, in)
+    if (R == 64) { if (with_loss) SDFR_LAUNCH_INLINE(64, true); else SDFR_LAUNCH_INLINE(64, false); }
+    else { if (with_loss) SDFR_LAUNCH_INLINE(0, true); else SDFR_LAUNCH_INLINE(0, false); }
+#undef SDFR_LAUNCH_INLINE
   } else if (packed) {
     if (R == 64) SDFR_LAUNCH_FWD(64, true, cells, 0LL); else SDFR_LAUNCH_FWD(0, true, cells, 0LL);
   } else {
@@ -1678,6 +1689,33 @@ extern "C" int sdfr_render_step_forward(const float* sdf, int R, long long sdf_v
                       sdfr_render_step_workspace_bytes(R, B, W, H), lay, g_sdf, g_words, device, stream);
 }
 
+extern "C" int sdfr_render_step_forward_l1(const float* sdf, int R, long long sdf_view_stride, const float* pos,
+                                           const float* quat, const float* inv_scale, int B, int W, int H, float cx,
+                                           float cy, float fx, float fy, float threshold, const float* target,
+                                           float* depth, float* loss, float* loss_stats, float* g_sdf,
+                                           long long g_sdf_view_stride, void* workspace, size_t workspace_bytes,
+                                           int device, void* stream) {
+  const char* fn = "sdfr_render_step_forward_l1";
+  const long long vox = (long long)R * R * R;
+  if (R >= 2 && R <= 1023 && g_sdf_view_stride != 0 && g_sdf_view_stride != vox)
+    return fail(SDFR_E_INVALID, "g_sdf_view_stride must be 0 or R^3");
+  if (B > 0 && !g_sdf) return fail(SDFR_E_NULL, "%s: g_sdf is NULL", fn);
+  if (B > 0 && W > 0 && H > 0 && (!target || !loss || !loss_stats)) return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
+  ForwardLayout lay{};
+  if (workspace && R >= 2 && R <= 1023 && B > 0) {
+    char* w = (char*)workspace;
+    lay.setup = (ViewSetup*)w;
+    lay.sync = (unsigned*)(w + sync_offset(B));
+    lay.spans = (unsigned*)(w + spans_offset_bytes(B));
+    lay.cells = (float*)(w + scratch_offset(B, H));
+    lay.loss_part = (float*)(w + step_loss_offset(R, B, W, H));
+  }
+  const size_t g_words = (R >= 2 && R <= 1023) ? (size_t)vox * (g_sdf_view_stride ? (size_t)(B > 0 ? B : 1) : 1) : 0;
+  return forward_impl(fn, sdf, R, sdf_view_stride, pos, quat, inv_scale, B, W, H, cx, cy, fx, fy, threshold, depth,
+                      target, loss, loss_stats, workspace, workspace_bytes,
+                      sdfr_render_step_workspace_bytes(R, B, W, H), lay, g_sdf, g_words, device, stream);
+}
+
 extern "C" int sdfr_render_step_backward(const float* grad_depth, const float* depth, const float* sdf, int R,
                                          long long sdf_view_stride, int B, int W, int H, float cx, float cy,
                                          float fx, float fy, int sdf_grad_mode, float* g_sdf,
@@ -1717,14 +1755,14 @@ extern "C" int sdfr_render_backward_l1(const float* loss_grad, float loss_weight
                        workspace_bytes, device, stream);
 }
 
-extern "C" int sdfr_render_backward_l1_pc(
+namespace {
+int backward_l1_pc_impl(const char* fn, bool prepared,
     const float* loss_grad, float loss_weight, const float* loss_stats, const float* target, const float* depth,
     const float* sdf, int R, long long sdf_view_stride, const float* pos, const float* quat, const float* inv_scale,
     int B, int W, int H, float cx, float cy, float fx, float fy, int sdf_grad_mode, float* g_sdf,
     long long g_sdf_view_stride, void* workspace, size_t workspace_bytes, float pc_weight, const float* points,
     const int* offsets, int max_view_points, const float* scale, void* pc_workspace, size_t pc_workspace_bytes,
     int device, void* stream) {
-  const char* fn = "sdfr_render_backward_l1_pc";
   if (B <= 0 || W <= 0 || H <= 0 || max_view_points <= 0)
     return fail(SDFR_E_INVALID, "%s: needs B, W, H, max_view_points > 0 (B=%d W=%d H=%d points=%d)", fn, B, W, H,
                 max_view_points);
@@ -1739,7 +1777,35 @@ extern "C" int sdfr_render_backward_l1_pc(
   float* pc_part = (float*)pc_workspace;
   const PcBackwardArgs pa{nullptr, points, offsets, max_view_points, pos, quat, scale, sdf, R, sdf_view_stride,
                           g_sdf, g_sdf_view_stride, pc_part, nblk, pc_weight, pc_part + (size_t)B * nblk * 8};
+  if (!pos || !quat || !inv_scale) return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
   return backward_impl(fn, target, depth, sdf, R, sdf_view_stride, pos, quat, inv_scale, B, W, H, cx, cy, fx, fy,
                        sdf_grad_mode, g_sdf, g_sdf_view_stride, nullptr, nullptr, nullptr, loss_grad, loss_stats,
-                       loss_weight, workspace, workspace_bytes, device, stream, &pa);
+                       loss_weight, workspace, workspace_bytes, device, stream, &pa, prepared);
+}
+}  // namespace
+
+extern "C" int sdfr_render_backward_l1_pc(
+    const float* loss_grad, float loss_weight, const float* loss_stats, const float* target, const float* depth,
+    const float* sdf, int R, long long sdf_view_stride, const float* pos, const float* quat, const float* inv_scale,
+    int B, int W, int H, float cx, float cy, float fx, float fy, int sdf_grad_mode, float* g_sdf,
+    long long g_sdf_view_stride, void* workspace, size_t workspace_bytes, float pc_weight, const float* points,
+    const int* offsets, int max_view_points, const float* scale, void* pc_workspace, size_t pc_workspace_bytes,
+    int device, void* stream) {
+  return backward_l1_pc_impl("sdfr_render_backward_l1_pc", false, loss_grad, loss_weight, loss_stats, target, depth, sdf,
+                             R, sdf_view_stride, pos, quat, inv_scale, B, W, H, cx, cy, fx, fy, sdf_grad_mode, g_sdf,
+                             g_sdf_view_stride, workspace, workspace_bytes, pc_weight, points, offsets, max_view_points,
+                             scale, pc_workspace, pc_workspace_bytes, device, stream);
+}
+
+extern "C" int sdfr_render_step_backward_l1_pc(
+    const float* loss_grad, float loss_weight, const float* loss_stats, const float* target, const float* depth,
+    const float* sdf, int R, long long sdf_view_stride, const float* pos, const float* quat, const float* inv_scale,
+    int B, int W, int H, float cx, float cy, float fx, float fy, int sdf_grad_mode, float* g_sdf,
+    long long g_sdf_view_stride, void* workspace, size_t workspace_bytes, float pc_weight, const float* points,
+    const int* offsets, int max_view_points, const float* scale, void* pc_workspace, size_t pc_workspace_bytes,
+    int device, void* stream) {
+  return backward_l1_pc_impl("sdfr_render_step_backward_l1_pc", true, loss_grad, loss_weight, loss_stats, target, depth,
+                             sdf, R, sdf_view_stride, pos, quat, inv_scale, B, W, H, cx, cy, fx, fy, sdf_grad_mode, g_sdf,
+                             g_sdf_view_stride, workspace, workspace_bytes, pc_weight, points, offsets, max_view_points,
+                             scale, pc_workspace, pc_workspace_bytes, device, stream);
 }

@@ -452,6 +452,8 @@ class BatchRenderPlan:
         self._g_sdf_next = 0
         self._step = None   # what the last forward prepared: (tensor ids / versions, depth tensor)
         self._fixed_layout = None   # deterministic mode: which workspace layout holds the last int64 volume
+        self._step_l1 = None        # the volume a forward_l1(prepare_backward=True) zero-filled
+        self.partials_offset = 0    # where the last backward_l1_pc left its tile partials (sdfr_loop_tail)
         self.loss = torch.empty((B,), **f32)
         self.loss_stats = torch.empty((B, 2), **f32)
         # zero-filled once: the sync region's counter of prologue fall-backs (include/sdfr.h) then counts from 0
@@ -596,10 +598,26 @@ class BatchRenderPlan:
         n = self.R ** 3 * 8
         return self.workspace[off:off + n].view(torch.int64).view(self.R, self.R, self.R)
 
-    def forward_l1(self, sdf, pos, quat, inv_scale, threshold: float, target):
-        """forward + masked depth-L1 against ``target`` (B,H,W): returns (depth, loss (B,))."""
+    def forward_l1(self, sdf, pos, quat, inv_scale, threshold: float, target, prepare_backward: bool = False):
+        """forward + masked depth-L1 against ``target`` (B,H,W): returns (depth, loss (B,)).
+
+        ``prepare_backward``: first half of a step whose second half is ``backward_l1_pc``
+        (``sdfr_render_step_forward_l1`` / ``sdfr_render_step_backward_l1_pc``): the gradient volume is zero-filled
+        and the view records are left for the backward, which then has no prologue launch."""
         self._step = None   # the workspace is about to be re-used
         self._check(sdf, pos, quat, inv_scale, target=target)
+        if prepare_backward:
+            nxt = self._g_sdf_ring[self._g_sdf_next]
+            rc = self._L.sdfr_render_step_forward_l1(
+                sdf.data_ptr(), self.R, self.sdf_stride, pos.data_ptr(), quat.data_ptr(), inv_scale.data_ptr(),
+                self.B, self.W, self.H, self.cx, self.cy, self.fx, self.fy, threshold, target.data_ptr(),
+                self.depth.data_ptr(), self.loss.data_ptr(), self.loss_stats.data_ptr(), nxt.data_ptr(),
+                self.sdf_stride, self.workspace.data_ptr(), self.workspace.numel(), self.device.index,
+                _stream(self.device))
+            _lib.check(rc, "sdfr_render_step_forward_l1")
+            self._step_l1 = nxt
+            return self.depth, self.loss
+        self._step_l1 = None
         rc = self._L.sdfr_render_forward_l1(
             sdf.data_ptr(), self.R, self.sdf_stride, pos.data_ptr(), quat.data_ptr(),
             inv_scale.data_ptr(), self.B, self.W, self.H, self.cx, self.cy, self.fx, self.fy,
@@ -653,7 +671,15 @@ class BatchRenderPlan:
             raise RuntimeError(f"offsets must be a contiguous int32 tensor of shape ({self.B + 1},) on {dev}")
         if pc_workspace.device != dev or not pc_workspace.is_contiguous() or pc_workspace.dtype is not torch.uint8:
             raise RuntimeError(f"pc_workspace must be a contiguous uint8 tensor on {dev}")
-        rc = self._L.sdfr_render_backward_l1_pc(
+        prepared, self._step_l1 = getattr(self, "_step_l1", None), None
+        if prepared is not None:   # second half of a step begun by forward_l1(prepare_backward=True)
+            self.g_sdf = prepared
+            self._g_sdf_next = (self._g_sdf_next + 1) % len(self._g_sdf_ring)
+            self.partials_offset = self._L.sdfr_render_partials_offset(self.R, self.B, self.W, self.H, 1)
+        else:
+            self.partials_offset = self._L.sdfr_render_partials_offset(self.R, self.B, self.W, self.H, 0)
+        fn = self._L.sdfr_render_step_backward_l1_pc if prepared is not None else self._L.sdfr_render_backward_l1_pc
+        rc = fn(
             loss_grad.data_ptr() if loss_grad is not None else None, weight,
             self.loss_stats.data_ptr(), target.data_ptr(), self.depth.data_ptr(), sdf.data_ptr(),
             self.R, self.sdf_stride, pos.data_ptr(), quat.data_ptr(), inv_scale.data_ptr(), self.B,
@@ -662,5 +688,5 @@ class BatchRenderPlan:
             pc_weight, points.data_ptr(), offsets.data_ptr() if offsets is not None else None, max_view_points,
             scale.data_ptr(), pc_workspace.data_ptr(), pc_workspace.numel(),
             self.device.index, _stream(self.device))
-        _lib.check(rc, "sdfr_render_backward_l1_pc")
+        _lib.check(rc, "sdfr_render_backward_l1_pc" if prepared is None else "sdfr_render_step_backward_l1_pc")
         return self.g_sdf

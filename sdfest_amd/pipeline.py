@@ -234,6 +234,9 @@ class FusedRenderAndCompare:
         V, H, W = depth_images.shape
         self.V, self.H, self.W = V, H, W
         self.defer_pose = bool(merge_launches) and V <= 64
+        # the iteration's tail -- gradient chain, point constraint, Adam and the next iteration's view poses -- in
+        # one launch (sdfr_loop_tail), the render pair in its step form: 26 -> 22 launches per iteration
+        self.merge_tail = bool(merge_launches) and V <= 64
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.target = depth_images.to(**f32).contiguous()
         self.cam_pos = (torch.zeros((V, 3), **f32) if camera_positions is None
@@ -326,11 +329,32 @@ class FusedRenderAndCompare:
         g = self.grads.data_ptr()
         if self.shape_opt:
             self._decode(st, True)
-        self.check(L.sdfr_pose_to_views(pos, quat, scale, self.cam_pos.data_ptr(), self.cam_quat.data_ptr(),
-                                        self.V, self.pos_c.data_ptr(), self.quat_c.data_ptr(),
-                                        self.inv_scale.data_ptr(), self.scale_v.data_ptr(), d, st),
-                   "sdfr_pose_to_views")
         sdf = self.sdf[0, 0]
+        if self._tail_form():
+            # [decoder] -> render pair as a step -> [decoder VJP] -> sdfr_loop_tail; the camera-frame poses of THIS
+            # iteration were left by the previous tail (or by _poses_to_views before the first one)
+            self.plan.forward_l1(sdf, self.pos_c, self.quat_c, self.inv_scale, self.cfg["threshold"], self.target,
+                                 prepare_backward=True)
+            self.loss_depth = self.plan.loss
+            g_sdf = self.plan.backward_l1_pc(self.target, sdf, self.pos_c, self.quat_c, self.inv_scale,
+                                             self.scale_v, self.points, self.offsets, self.max_pts, self.ws_pc,
+                                             weight=self.cfg["depth_weight"], pc_weight=self.cfg["pc_weight"])
+            if self.shape_opt:
+                self.check(L.sdfr_decoder_backward_latent(self.dec._h, self.latent.data_ptr(), self.tape.data_ptr(),
+                                                          g_sdf.data_ptr(), 1, g + 32, self.ws_dec.data_ptr(),
+                                                          self.ws_dec.numel(), st), "sdfr_decoder_backward_latent")
+            con = self.pc_source is not None
+            self.check(L.sdfr_loop_tail(
+                p, g, self.m.data_ptr(), self.v.data_ptr(), self.step.data_ptr(), 8 + self.Lz, 1e-3, 1e-2, 1e-3, 1e-2,
+                int(self.shape_opt), self.cam_pos.data_ptr(), self.cam_quat.data_ptr(), self.V,
+                self.plan.workspace.data_ptr(), self.plan.partials_offset, self.W, self.H, self.ws_pc.data_ptr(),
+                self.offsets.data_ptr(), self.max_pts, self.pos_c.data_ptr(), self.quat_c.data_ptr(),
+                self.inv_scale.data_ptr(), self.scale_v.data_ptr(), self.loss_pc.data_ptr(),
+                self.pc_source.data_ptr() if con else None, self.pc_target.data_ptr() if con else None,
+                self.pc_weight if con else 0.0, self.loss_con.data_ptr() if con else None, d, st), "sdfr_loop_tail")
+            self._inliers(L, p, d, st)
+            return
+        self._poses_to_views(st)
         # the renderer's and the sampler's per-view reductions run inside the gradient chain's launch
         # (sdfr_views_to_pose_grad_deferred: two launches less per iteration)
         defer = self.defer_pose
@@ -420,6 +444,20 @@ class FusedRenderAndCompare:
         self.check(L.sdfr_adam_step(p, g, self.m.data_ptr(), self.v.data_ptr(), self.step.data_ptr(),
                                     8 + self.Lz, 1e-3, 1e-2, 1e-3, 1e-2, int(self.shape_opt), d, st),
                    "sdfr_adam_step")
+        self._inliers(L, p, d, st)
+
+    def _tail_form(self) -> bool:
+        return (self.merge_tail and self.fuse_depth_loss and self.defer_pose and self.max_pts > 0
+                and 8 + self.Lz <= 256)
+
+    def _poses_to_views(self, st):
+        p = self.params.data_ptr()
+        self.check(self.L.sdfr_pose_to_views(p, p + 12, p + 28, self.cam_pos.data_ptr(), self.cam_quat.data_ptr(),
+                                             self.V, self.pos_c.data_ptr(), self.quat_c.data_ptr(),
+                                             self.inv_scale.data_ptr(), self.scale_v.data_ptr(), self.dev.index, st),
+                   "sdfr_pose_to_views")
+
+    def _inliers(self, L, p, d, st):
         if self.track_inliers:
             # :463-470 -- the LAST view's input and the estimate rendered before this step, against the
             # parameters after it
@@ -443,6 +481,8 @@ class FusedRenderAndCompare:
             self.inlier_counts.zero_(); self.best_state.zero_(); self.inlier_history.zero_()
         if not self.shape_opt:
             self._decode(self._stream(), False)
+        if self._tail_form():
+            self._poses_to_views(self._stream())   # every later iteration gets its view poses from the tail before it
         n_iter = self.cfg["max_iterations"]
         if use_graph and self.graph is None:
             # warm up on a side stream (lazy module loads), restore the state, then capture
@@ -461,6 +501,8 @@ class FusedRenderAndCompare:
                 self.iteration()
             for t, c in zip(state, saved):
                 t.copy_(c)   # the capture itself does not execute, but keep the state explicit
+            if self._tail_form():
+                self._poses_to_views(self._stream())   # the warm-up's tail left the poses of ITS updated parameters
         for _ in range(n_iter):
             if use_graph:
                 self.graph.replay()

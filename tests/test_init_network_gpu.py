@@ -109,3 +109,16 @@ def test_nn_init_frames_and_strategies(gold, mug_net):
         nn_init(mug_net, cam, torch.zeros((1, H, W), device="cuda"), cam_pos[:1], cq[:1], {"init_view": "first"})
     with pytest.raises(NotImplementedError):
         nn_init(mug_net, cam, depth, cam_pos, cq, {"init_view": "median"})
+
+
+def test_nan_points_reach_the_outputs(gold, mug_net):
+    """torch's relu and max propagate NaN (pointnet.py:64-96): a NaN coordinate (or weight) must come out as NaN, not
+    as a plausible pose computed from `fmaxf(NaN, 0) = 0` (round-2 advisor finding)."""
+    pts = torch.tensor(gold["mug0_points"], device="cuda").clone()
+    ok = mug_net.features(pts)
+    assert torch.isfinite(ok).all()
+    pts[5, 1] = float("nan")
+    feat = mug_net.features(pts)
+    assert torch.isnan(feat).any()
+    latent, position, scale, orientation = mug_net(pts[None])
+    assert torch.isnan(latent).any() or torch.isnan(position).any() or torch.isnan(orientation).any()
