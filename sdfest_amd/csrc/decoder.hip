@@ -782,6 +782,121 @@ __global__ __launch_bounds__(256) void resize_x_backward_pad_kernel(const float*
   out[idx] = acc;
 }
 
+// The three passes of the transposed resize in ONE launch for BATCHES (round 3).  As three gather launches the
+// transposed resizes were the largest item of a batched VJP (945 of ~2 200 us per 256 latents: every pass re-reads
+// what the one before wrote, and forms the weight of every term with the full source-index arithmetic).  Here a
+// workgroup owns TC x TC columns of the (zero-padded) result: it stages the fine rows that feed them in LDS once
+// (coalesced z-rows), builds the three axes' weight tables once (a few dozen entries: first source index + up to
+// kBtTaps weights per coarse index), and runs z-, y- and x-pass on the staged block -- each term one LDS read and one
+// fma, the same terms in the same order as the three launches (zero weights skipped), so the result is bit-identical
+// to them.  The last pass applies the ReLU mask and writes straight into the padded tensor the next transposed
+// convolution reads, like resize_x_backward_pad_kernel.
+//   g_out [outer][no][no][no] -> out [outer][np][np][np], np = ni + 2 pad (pad 0, act NULL: the plain transpose)
+// grid: (tiles * tiles, outer), tiles = ceil(np / TC);  LDS: max_f^2 (no + ni) floats (+ tables)
+constexpr int kBtTaps = 12, kBtTile = 4;
+// exact range of fine indices d that carry weight on coarse index i (empty: d0 > d1)
+__device__ __forceinline__ void resize_sources_exact(int i, float ratio, int n_in, int n_out, int& d0, int& d1) {
+  resize_sources(i, n_in, n_out, d0, d1);
+  while (d0 <= d1 && resize_weight(d0, i, ratio, n_in) == 0.0f) ++d0;
+  while (d1 >= d0 && resize_weight(d1, i, ratio, n_in) == 0.0f) --d1;
+}
+__global__ __launch_bounds__(256) void resize3_backward_tiled_kernel(const float* __restrict__ g_out, int n_in, int n_out,
+                                                                     const float* __restrict__ act, int pad, int max_f,
+                                                                     float* __restrict__ out) {
+  constexpr int TC = kBtTile;
+  extern __shared__ float lds[];
+  __shared__ float w_tab[2 * TC + 64][kBtTaps];   // rows: x (TC), y (TC), z (n_in <= 64)
+  __shared__ int d_tab[2 * TC + 64];              // first source index, relative to the tile's first fine row / 0 for z
+  __shared__ int n_tab[2 * TC + 64];              // number of taps
+  const int tid = threadIdx.x;
+  const int np = n_in + 2 * pad, tiles = (np + TC - 1) / TC;
+  const int xp0 = ((int)blockIdx.x / tiles) * TC, yp0 = ((int)blockIdx.x % tiles) * TC;
+  const size_t o = blockIdx.y;
+  const float ratio = (float)n_in / (float)n_out;
+  float* dst = out + o * (size_t)np * np * np;
+  // coarse columns of this tile that exist (the rest of the tile is padding: zeros)
+  const int cx0 = max(xp0 - pad, 0), cx1 = min(xp0 + TC - 1 - pad, n_in - 1);
+  const int cy0 = max(yp0 - pad, 0), cy1 = min(yp0 + TC - 1 - pad, n_in - 1);
+  const bool any = cx0 <= cx1 && cy0 <= cy1;
+  int fx0 = 0, fx1 = -1, fy0 = 0, fy1 = -1;
+  if (any) {
+    int t;
+    resize_sources_exact(cx0, ratio, n_in, n_out, fx0, t);
+    resize_sources_exact(cx1, ratio, n_in, n_out, t, fx1);
+    resize_sources_exact(cy0, ratio, n_in, n_out, fy0, t);
+    resize_sources_exact(cy1, ratio, n_in, n_out, t, fy1);
+  }
+  const int fnx = fx1 - fx0 + 1, fny = fy1 - fy0 + 1;
+  // weight tables
+  if (tid < 2 * TC + n_in) {
+    int i, base;
+    if (tid < TC) { i = xp0 + tid - pad; base = fx0; }
+    else if (tid < 2 * TC) { i = yp0 + tid - TC - pad; base = fy0; }
+    else { i = tid - 2 * TC; base = 0; }
+    int d0 = 0, d1 = -1;
+    if (i >= 0 && i < n_in) resize_sources_exact(i, ratio, n_in, n_out, d0, d1);
+    const int nt = min(d1 - d0 + 1, kBtTaps);
+    d_tab[tid] = d0 - base;
+    n_tab[tid] = nt > 0 ? nt : 0;
+    for (int k = 0; k < kBtTaps; ++k) w_tab[tid][k] = (k < nt) ? resize_weight(d0 + k, i, ratio, n_in) : 0.0f;
+  }
+  float* F = lds;                                      // [fnx * fny][n_out]   fine rows
+  float* Z = lds + (size_t)max_f * max_f * n_out;      // [fnx * fny][n_in]    after the z pass
+  float* Y = lds;                                      // [fnx][TC][n_in]      after the y pass (F is dead by then)
+  if (any) {
+    const float* src = g_out + o * (size_t)n_out * n_out * n_out;
+    const int rows = fnx * fny;
+    for (int e = tid; e < rows * n_out; e += 256) {
+      const int row = e / n_out, z = e - row * n_out;
+      F[e] = src[((size_t)(fx0 + row / fny) * n_out + (fy0 + row % fny)) * n_out + z];
+    }
+  }
+  __syncthreads();
+  if (any) {
+    const int rows = fnx * fny;
+    for (int e = tid; e < rows * n_in; e += 256) {     // z pass
+      const int row = e / n_in, iz = e - row * n_in;
+      const float* f = F + row * n_out + d_tab[2 * TC + iz];
+      const float* w = w_tab[2 * TC + iz];
+      const int nt = n_tab[2 * TC + iz];
+      float acc = 0.0f;
+      for (int k = 0; k < nt; ++k) acc = (w[k] != 0.0f) ? fmaf(w[k], f[k], acc) : acc;
+      Z[e] = acc;
+    }
+  }
+  __syncthreads();
+  if (any) {
+    for (int e = tid; e < fnx * TC * n_in; e += 256) {  // y pass
+      const int iz = e % n_in, jy = (e / n_in) % TC, fx = e / (n_in * TC);
+      const int nt = n_tab[TC + jy];
+      const float* zc = Z + ((size_t)fx * fny + d_tab[TC + jy]) * n_in + iz;
+      const float* w = w_tab[TC + jy];
+      float acc = 0.0f;
+      for (int k = 0; k < nt; ++k) acc = (w[k] != 0.0f) ? fmaf(w[k], zc[(size_t)k * n_in], acc) : acc;
+      Y[e] = acc;
+    }
+  }
+  __syncthreads();
+  // x pass, mask, store (whole z-rows of the padded tensor, zeros in the padding)
+  for (int e = tid; e < TC * TC * np; e += 256) {
+    const int zp = e % np, jy = (e / np) % TC, jx = e / (np * TC);
+    const int xp = xp0 + jx, yp = yp0 + jy;
+    if (xp >= np || yp >= np) continue;
+    const int ix = xp - pad, iy = yp - pad, iz = zp - pad;
+    float acc = 0.0f;
+    if (ix >= 0 && ix < n_in && iy >= 0 && iy < n_in && iz >= 0 && iz < n_in) {
+      const size_t a = o * (size_t)n_in * n_in * n_in + ((size_t)ix * n_in + iy) * n_in + iz;
+      if (!act || act[a] > 0.0f) {
+        const int nt = n_tab[jx];
+        const float* yc = Y + ((size_t)d_tab[jx] * TC + jy) * n_in + iz;
+        const float* w = w_tab[jx];
+        for (int k = 0; k < nt; ++k) acc = (w[k] != 0.0f) ? fmaf(w[k], yc[(size_t)k * TC * n_in], acc) : acc;
+      }
+    }
+    dst[((size_t)xp * np + yp) * np + zp] = acc;
+  }
+}
+
 // Backward of the last (wide) Linear layer: t[n][i] = sum_o Wt[i][o] * g_last[n][o], one workgroup
 // per (i, sample) -- a 50 x 8192 GEMV spread over 50 workgroups instead of one.
 // `act`: the layer's forward output; its ReLU' is applied to g_last on the fly (no mask launch).
@@ -1402,6 +1517,48 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
         const int d0 = std::max((int)floorf(((float)i - 0.5f) * inv - 0.5f) - 1, 0);
         const int d1 = std::min((int)ceilf(((float)i + 1.5f) * inv - 0.5f) + 1, n_out - 1);
         few = d1 - d0 + 1 <= kZyTaps;
+      }
+    }
+    if (!few && !mix_w && n_in <= 64 && n_out <= 1024 && nc <= 65535) {
+      // batches: the three passes in one launch on an LDS-staged block (resize3_backward_tiled_kernel)
+      const float ratio = (float)n_in / (float)n_out;
+      auto weight = [&](int dd, int i) {   // resize_weight on the host, same float arithmetic
+        float sp = fmaf(ratio, (float)dd + 0.5f, -0.5f);
+        sp = sp < 0.0f ? 0.0f : sp;
+        const int i0 = std::min((int)sp, n_in - 1), i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+        const float l1 = sp - (float)i0;
+        return (i0 == i ? 1.0f - l1 : 0.0f) + (i1 == i ? l1 : 0.0f);
+      };
+      const float inv = (float)n_out / (float)n_in;
+      auto exact = [&](int i, int& d0, int& d1) {
+        d0 = std::max((int)floorf(((float)i - 0.5f) * inv - 0.5f) - 1, 0);
+        d1 = std::min((int)ceilf(((float)i + 1.5f) * inv - 0.5f) + 1, n_out - 1);
+        while (d0 <= d1 && weight(d0, i) == 0.0f) ++d0;
+        while (d1 >= d0 && weight(d1, i) == 0.0f) --d1;
+      };
+      const int padv = pad >= 0 ? pad : 0, npad = n_in + 2 * padv;
+      int max_f = 1, max_taps = 1;
+      for (int i = 0; i < n_in; ++i) {
+        int d0, d1;
+        exact(i, d0, d1);
+        max_taps = std::max(max_taps, d1 - d0 + 1);
+      }
+      for (int t0 = 0; t0 < npad; t0 += kBtTile) {   // the tile's coarse range -> its fine span, worst tile
+        const int c0 = std::max(t0 - padv, 0), c1 = std::min(t0 + kBtTile - 1 - padv, n_in - 1);
+        if (c0 > c1) continue;
+        int a0, a1, t;
+        exact(c0, a0, t);
+        exact(c1, t, a1);
+        max_f = std::max(max_f, a1 - a0 + 1);
+      }
+      const size_t lds = (size_t)max_f * max_f * (n_out + n_in) * sizeof(float);
+      if (max_taps <= kBtTaps && lds <= 56 * 1024) {
+        const int tiles = (npad + kBtTile - 1) / kBtTile;
+        hipLaunchKernelGGL(resize3_backward_tiled_kernel, dim3(tiles * tiles, (unsigned)nc), dim3(256), lds, st, g, n_in,
+                           n_out, pad >= 0 ? act : nullptr, padv, max_f, buf[cur]);
+        g = buf[cur];
+        cur ^= 1;
+        return;
       }
     }
     struct Pass { size_t outer; size_t inner; } passes[3] = {
