@@ -310,6 +310,11 @@ SDFR_API int sdfr_decoder_backward_latent(const sdfr_decoder* decoder, const flo
                                  const float* grad_out, int N, float* g_z, void* workspace,
                                  size_t workspace_bytes, void* stream);
 
+/* TEST HOOK: batches take the transposed resizes of the VJP in one launch each (an LDS-staged block per workgroup,
+ * bit-identical to the three single-axis launches it replaces); 0 switches back to the three launches so that a
+ * test can compare the two bit for bit.  Process-wide; returns the old value. */
+SDFR_API int sdfr_debug_set_decoder_tiled_vjp(int on);
+
 /* ---- glue of one render-and-compare iteration (SDFPipeline.__call__, simple_setup.py:408-470) --- */
 /* Small kernels that replace the reference's per-iteration torch-op soup so that a whole
  * iteration is a fixed launch sequence (graph-capturable).  All pointers are device pointers. */

@@ -28,7 +28,10 @@
 // A single decode is latency-, not FLOP-bound: what matters there is 8 launches instead of the
 // reference's ~20 eager ops, no host synchronisation, and that everything can be graph-captured.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "common.hpp"
@@ -785,115 +788,228 @@ __global__ __launch_bounds__(256) void resize_x_backward_pad_kernel(const float*
 // The three passes of the transposed resize in ONE launch for BATCHES (round 3).  As three gather launches the
 // transposed resizes were the largest item of a batched VJP (945 of ~2 200 us per 256 latents: every pass re-reads
 // what the one before wrote, and forms the weight of every term with the full source-index arithmetic).  Here a
-// workgroup owns TC x TC columns of the (zero-padded) result: it stages the fine rows that feed them in LDS once
-// (coalesced z-rows), builds the three axes' weight tables once (a few dozen entries: first source index + up to
-// kBtTaps weights per coarse index), and runs z-, y- and x-pass on the staged block -- each term one LDS read and one
-// fma, the same terms in the same order as the three launches (zero weights skipped), so the result is bit-identical
-// to them.  The last pass applies the ReLU mask and writes straight into the padded tensor the next transposed
-// convolution reads, like resize_x_backward_pad_kernel.
-//   g_out [outer][no][no][no] -> out [outer][np][np][np], np = ni + 2 pad (pad 0, act NULL: the plain transpose)
-// grid: (tiles * tiles, outer), tiles = ceil(np / TC);  LDS: max_f^2 (no + ni) floats (+ tables)
-constexpr int kBtTaps = 12, kBtTile = 4;
+// workgroup owns a tc x tc tile of coarse (x, y) columns and walks over CHANNELS with it: the three axes' weight
+// tables (first source index + up to kBtTaps weights per coarse index) and every address are formed once, then per
+// channel the fine rows that feed the tile are staged in LDS (16-byte loads, the NEXT channel's rows already in
+// flight into registers while this channel's passes run -- a workgroup is a chain of load -> barrier -> z -> barrier
+// -> y -> barrier -> x, and with two or three workgroups per CU nothing else hides that chain), and z-, y- and x-pass
+// run on the staged block: each term one LDS read and one fma, the same terms in the same order as the three
+// launches (zero weights skipped), so the result is bit-identical to them.  The z pass writes its results over the
+// head of each fine row IN PLACE (a row is read and written by one wave in one step).  The last pass applies the
+// ReLU mask and writes straight into the zero-padded tensor the next transposed convolution reads, like
+// resize_x_backward_pad_kernel; with COUT > 0 it also runs the transposed 1x1 layer that was swapped with the resize
+// (one source channel -> COUT channels, conv1x1_kernel's chain and "+ 0" bias), like
+// resize_x_backward_mix_pad_kernel (conv1x1 and pad_mask launches and their traffic saved).
+//   g_out [nc][no][no][no] -> out [nc (* COUT)][np][np][np], np = ni + 2 pad (pad 0, act NULL: the plain transpose)
+// Tiles are laid over the COARSE index range (tiles = ceil(ni / tc) per axis); the first and last tile of an axis
+// also write that side's padding.  Grid: 1-D, tiles^2 * slots workgroups, slots % 8 == 0; workgroup L works for
+// channel slot (L / 8 / tiles^2) * 8 + L % 8 on tile (L / 8) % tiles^2 -- workgroups are dealt to the 8 XCDs
+// round-robin, so all tiles of a channel (whose fine blocks overlap by the taps' reach) run on ONE XCD, at the same
+// time, and the overlap is served by that XCD's L2.  Slot s takes channels s, s + slots, ...
+// LDS: max_f^2 * no + max_f * tc * ni floats (+ tables).
+#ifndef SDFR_BT_LOADS
+#define SDFR_BT_LOADS 4
+#endif
+#ifndef SDFR_BT_OUT
+#define SDFR_BT_OUT 3
+#endif
+constexpr int kBtTaps = 12, kBtLoads = SDFR_BT_LOADS, kBtOut = SDFR_BT_OUT, kBtMaxTile = 16, kBtMaxThreads = 1024;
 // exact range of fine indices d that carry weight on coarse index i (empty: d0 > d1)
 __device__ __forceinline__ void resize_sources_exact(int i, float ratio, int n_in, int n_out, int& d0, int& d1) {
   resize_sources(i, n_in, n_out, d0, d1);
   while (d0 <= d1 && resize_weight(d0, i, ratio, n_in) == 0.0f) ++d0;
   while (d1 >= d0 && resize_weight(d1, i, ratio, n_in) == 0.0f) --d1;
 }
-__global__ __launch_bounds__(256) void resize3_backward_tiled_kernel(const float* __restrict__ g_out, int n_in, int n_out,
-                                                                     const float* __restrict__ act, int pad, int max_f,
-                                                                     float* __restrict__ out) {
-  constexpr int TC = kBtTile;
+// x / d == umulhi(x, magic_of(d)) for x < 2^16 and 2 <= d < 2^16; d == 1 has no 32-bit reciprocal: div_by() tests for it
+__device__ __forceinline__ unsigned magic_of(int d) { return 0xffffffffu / (unsigned)d + 1u; }
+__device__ __forceinline__ int div_by(int x, unsigned m) { return m ? (int)__umulhi((unsigned)x, m) : x; }   // (magic_of(1) == 0)
+// (index arithmetic: a lane is a z index in the passes, several rows per wave when the coarse row is short; divisions
+// are multiplications by a reciprocal formed once, and everything that does not depend on the channel -- addresses
+// of the loads, of the stores, of the mask -- is formed once per workgroup.  TAPS >= the longest source range of the
+// resize: the tap loops are unrolled, ALL of a step's LDS reads are issued before the first fma (read one tap, wait,
+// test its weight, read the next: the passes were chains of LDS latencies, 3/4 of the kernel's time); a tap beyond a
+// row's range has weight 0 and re-reads the row's last source.  The mask values of a channel are loaded before its
+// z pass and used after its y pass.)
+template <int COUT, int TAPS>
+__global__ __launch_bounds__(kBtMaxThreads) void resize3_backward_tiled_kernel(
+    const float* __restrict__ g_out, int n_in, int n_out, const float* __restrict__ act, int pad, int tc, int max_f,
+    int nc, int slots, const float* __restrict__ wmat, const float* __restrict__ bias, float* __restrict__ out) {
+  constexpr int CO = COUT > 0 ? COUT : 1;
   extern __shared__ float lds[];
-  __shared__ float w_tab[2 * TC + 64][kBtTaps];   // rows: x (TC), y (TC), z (n_in <= 64)
-  __shared__ int d_tab[2 * TC + 64];              // first source index, relative to the tile's first fine row / 0 for z
-  __shared__ int n_tab[2 * TC + 64];              // number of taps
-  const int tid = threadIdx.x;
-  const int np = n_in + 2 * pad, tiles = (np + TC - 1) / TC;
-  const int xp0 = ((int)blockIdx.x / tiles) * TC, yp0 = ((int)blockIdx.x % tiles) * TC;
-  const size_t o = blockIdx.y;
+  __shared__ float w_tab[2 * kBtMaxTile + 64][kBtTaps];   // rows: x (tc), y (tc), z (n_in <= 64)
+  __shared__ int d_tab[2 * kBtMaxTile + 64];              // first source index, relative to the tile's first fine row / 0 for z
+  __shared__ int f_rng[4];
+  const int tid = threadIdx.x, nthr = blockDim.x, wave = tid >> 6, nw = nthr >> 6, lane = tid & 63;
+  const int np = n_in + 2 * pad, tiles = (n_in + tc - 1) / tc, tt = tiles * tiles;
+  const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+  const int tile = idx % tt, slot0 = (idx / tt) * 8 + xcd;
+  if (slot0 >= nc) return;
+  const int tile_x = tile / tiles, tile_y = tile - tile_x * tiles;
   const float ratio = (float)n_in / (float)n_out;
-  float* dst = out + o * (size_t)np * np * np;
-  // coarse columns of this tile that exist (the rest of the tile is padding: zeros)
-  const int cx0 = max(xp0 - pad, 0), cx1 = min(xp0 + TC - 1 - pad, n_in - 1);
-  const int cy0 = max(yp0 - pad, 0), cy1 = min(yp0 + TC - 1 - pad, n_in - 1);
-  const bool any = cx0 <= cx1 && cy0 <= cy1;
-  int fx0 = 0, fx1 = -1, fy0 = 0, fy1 = -1;
-  if (any) {
-    int t;
-    resize_sources_exact(cx0, ratio, n_in, n_out, fx0, t);
-    resize_sources_exact(cx1, ratio, n_in, n_out, t, fx1);
-    resize_sources_exact(cy0, ratio, n_in, n_out, fy0, t);
-    resize_sources_exact(cy1, ratio, n_in, n_out, t, fy1);
+  // coarse columns of this tile, and the columns of the padded tensor it writes
+  const int cx0 = tile_x * tc, cx1 = min(cx0 + tc, n_in) - 1, cy0 = tile_y * tc, cy1 = min(cy0 + tc, n_in) - 1;
+  const int ncx = cx1 - cx0 + 1, ncy = cy1 - cy0 + 1;
+  const int ox0 = tile_x == 0 ? 0 : cx0 + pad, ox1 = tile_x == tiles - 1 ? np : cx1 + 1 + pad;
+  const int oy0 = tile_y == 0 ? 0 : cy0 + pad, oy1 = tile_y == tiles - 1 ? np : cy1 + 1 + pad;
+  if (tid < 4) {   // the tile's fine rows: four lanes find one bound each
+    int d0, d1;
+    resize_sources_exact(tid == 0 ? cx0 : (tid == 1 ? cx1 : (tid == 2 ? cy0 : cy1)), ratio, n_in, n_out, d0, d1);
+    f_rng[tid] = (tid & 1) ? d1 : d0;
   }
+  __syncthreads();
+  const int fx0 = f_rng[0], fx1 = f_rng[1], fy0 = f_rng[2], fy1 = f_rng[3];
   const int fnx = fx1 - fx0 + 1, fny = fy1 - fy0 + 1;
-  // weight tables
-  if (tid < 2 * TC + n_in) {
+  if (tid < 2 * kBtMaxTile + n_in) {   // weight tables
     int i, base;
-    if (tid < TC) { i = xp0 + tid - pad; base = fx0; }
-    else if (tid < 2 * TC) { i = yp0 + tid - TC - pad; base = fy0; }
-    else { i = tid - 2 * TC; base = 0; }
+    if (tid < kBtMaxTile) { i = tid < ncx ? cx0 + tid : -1; base = fx0; }
+    else if (tid < 2 * kBtMaxTile) { i = tid - kBtMaxTile < ncy ? cy0 + tid - kBtMaxTile : -1; base = fy0; }
+    else { i = tid - 2 * kBtMaxTile; base = 0; }
     int d0 = 0, d1 = -1;
-    if (i >= 0 && i < n_in) resize_sources_exact(i, ratio, n_in, n_out, d0, d1);
-    const int nt = min(d1 - d0 + 1, kBtTaps);
+    if (i >= 0) resize_sources_exact(i, ratio, n_in, n_out, d0, d1);
+    const int nt = d1 - d0 + 1;
     d_tab[tid] = d0 - base;
-    n_tab[tid] = nt > 0 ? nt : 0;
     for (int k = 0; k < kBtTaps; ++k) w_tab[tid][k] = (k < nt) ? resize_weight(d0 + k, i, ratio, n_in) : 0.0f;
   }
-  float* F = lds;                                      // [fnx * fny][n_out]   fine rows
-  float* Z = lds + (size_t)max_f * max_f * n_out;      // [fnx * fny][n_in]    after the z pass
-  float* Y = lds;                                      // [fnx][TC][n_in]      after the y pass (F is dead by then)
-  if (any) {
-    const float* src = g_out + o * (size_t)n_out * n_out * n_out;
-    const int rows = fnx * fny;
-    for (int e = tid; e < rows * n_out; e += 256) {
-      const int row = e / n_out, z = e - row * n_out;
-      F[e] = src[((size_t)(fx0 + row / fny) * n_out + (fy0 + row % fny)) * n_out + z];
+  float* F = lds;                                      // [fnx][fny][n_out], heads overwritten by the z pass
+  float* Y = lds + (size_t)max_f * max_f * n_out;      // [fnx][ncy][n_in]
+  // a thread's vectors of the fine block (n_out % 4 == 0, <= kBtLoads * nthr vectors: host)
+  const int q4 = n_out >> 2, total4 = fnx * fny * q4;
+  int off[kBtLoads];
+  {
+    const unsigned m_q = magic_of(q4), m_y = magic_of(fny);
+#pragma unroll
+    for (int j = 0; j < kBtLoads; ++j) {
+      const int e = min(tid + nthr * j, total4 - 1);
+      const int row = div_by(e, m_q), q = e - row * q4;
+      const int fx = div_by(row, m_y), fy = row - fx * fny;
+      off[j] = ((fx0 + fx) * n_out + (fy0 + fy)) * n_out + 4 * q;
     }
   }
-  __syncthreads();
-  if (any) {
-    const int rows = fnx * fny;
-    for (int e = tid; e < rows * n_in; e += 256) {     // z pass
-      const int row = e / n_in, iz = e - row * n_in;
-      const float* f = F + row * n_out + d_tab[2 * TC + iz];
-      const float* w = w_tab[2 * TC + iz];
-      const int nt = n_tab[2 * TC + iz];
-      float acc = 0.0f;
-      for (int k = 0; k < nt; ++k) acc = (w[k] != 0.0f) ? fmaf(w[k], f[k], acc) : acc;
-      Z[e] = acc;
+  const size_t fine_vol = (size_t)n_out * n_out * n_out, coarse_vol = (size_t)n_in * n_in * n_in, pad_vol = (size_t)np * np * np;
+  f32x4 pre[kBtLoads];
+  {
+    const float* src = g_out + (size_t)slot0 * fine_vol;
+#pragma unroll
+    for (int j = 0; j < kBtLoads; ++j)
+      if (nthr * j < total4) pre[j] = *reinterpret_cast<const f32x4*>(src + off[j]);
+  }
+  // a thread's elements of the tile's part of the padded tensor (<= kBtOut * nthr: host): where each goes, its mask
+  // value, its Y column and its x weights (-1: padding, a zero)
+  const int ocx = ox1 - ox0, ocy = oy1 - oy0, n_store = ocx * ocy * np;
+  int st_r[kBtOut], st_a[kBtOut], st_y[kBtOut];
+  {
+    const unsigned m_np = magic_of(np), m_ocy = magic_of(ocy);
+#pragma unroll
+    for (int j = 0; j < kBtOut; ++j) {
+      const int e = min(tid + nthr * j, n_store - 1);
+      const int col = div_by(e, m_np), zp = e - col * np;
+      const int jx = div_by(col, m_ocy), jy = col - jx * ocy;
+      const int xp = ox0 + jx, yp = oy0 + jy;
+      const int ix = xp - pad, iy = yp - pad, izz = zp - pad;
+      const bool inside = ix >= cx0 && ix <= cx1 && iy >= cy0 && iy <= cy1 && izz >= 0 && izz < n_in;
+      st_r[j] = (xp * np + yp) * np + zp;
+      st_a[j] = inside ? (ix * n_in + iy) * n_in + izz : -1;
+      st_y[j] = inside ? (((iy - cy0) * n_in + izz) << 4) | (ix - cx0) : 0;   // (Y column, x-table row < 16)
     }
   }
-  __syncthreads();
-  if (any) {
-    for (int e = tid; e < fnx * TC * n_in; e += 256) {  // y pass
-      const int iz = e % n_in, jy = (e / n_in) % TC, fx = e / (n_in * TC);
-      const int nt = n_tab[TC + jy];
-      const float* zc = Z + ((size_t)fx * fny + d_tab[TC + jy]) * n_in + iz;
-      const float* w = w_tab[TC + jy];
-      float acc = 0.0f;
-      for (int k = 0; k < nt; ++k) acc = (w[k] != 0.0f) ? fmaf(w[k], zc[(size_t)k * n_in], acc) : acc;
-      Y[e] = acc;
-    }
+  __syncthreads();   // tables
+  // lane -> (slot, iz): 64 / nl rows per wave-step, nl = the power of two that holds a coarse row
+  const int nl = n_in <= 8 ? 8 : (n_in <= 16 ? 16 : (n_in <= 32 ? 32 : 64));
+  const int spw = 64 / nl, slot = lane / nl, iz = lane - slot * nl;
+  const bool zok = iz < n_in;
+  const int dz = zok ? d_tab[2 * kBtMaxTile + iz] : 0;
+  float wz[TAPS];
+  int oz[TAPS];
+#pragma unroll
+  for (int k = 0; k < TAPS; ++k) {
+    wz[k] = zok ? w_tab[2 * kBtMaxTile + iz][k] : 0.0f;
+    oz[k] = min(dz + k, n_out - 1);
   }
-  __syncthreads();
-  // x pass, mask, store (whole z-rows of the padded tensor, zeros in the padding)
-  for (int e = tid; e < TC * TC * np; e += 256) {
-    const int zp = e % np, jy = (e / np) % TC, jx = e / (np * TC);
-    const int xp = xp0 + jx, yp = yp0 + jy;
-    if (xp >= np || yp >= np) continue;
-    const int ix = xp - pad, iy = yp - pad, iz = zp - pad;
-    float acc = 0.0f;
-    if (ix >= 0 && ix < n_in && iy >= 0 && iy < n_in && iz >= 0 && iz < n_in) {
-      const size_t a = o * (size_t)n_in * n_in * n_in + ((size_t)ix * n_in + iy) * n_in + iz;
-      if (!act || act[a] > 0.0f) {
-        const int nt = n_tab[jx];
-        const float* yc = Y + ((size_t)d_tab[jx] * TC + jy) * n_in + iz;
-        const float* w = w_tab[jx];
-        for (int k = 0; k < nt; ++k) acc = (w[k] != 0.0f) ? fmaf(w[k], yc[(size_t)k * TC * n_in], acc) : acc;
+  const unsigned m_ncy = magic_of(ncy);
+  const int y_stride = ncy * n_in;
+  for (int o = slot0; o < nc; o += slots) {
+#pragma unroll
+    for (int j = 0; j < kBtLoads; ++j)
+      if (tid + nthr * j < total4) reinterpret_cast<f32x4*>(F)[tid + nthr * j] = pre[j];
+    __syncthreads();
+    // this channel's mask values, then the next channel's block: both in flight during this channel's passes
+    float mask[kBtOut][CO];
+    if (act) {
+#pragma unroll
+      for (int j = 0; j < kBtOut; ++j)
+#pragma unroll
+        for (int co = 0; co < CO; ++co)
+          mask[j][co] = (nthr * j < n_store && st_a[j] >= 0) ? act[((size_t)o * CO + co) * coarse_vol + st_a[j]] : 0.0f;
+    }
+    if (o + slots < nc) {
+      const float* src = g_out + (size_t)(o + slots) * fine_vol;
+#pragma unroll
+      for (int j = 0; j < kBtLoads; ++j)
+        if (nthr * j < total4) pre[j] = *reinterpret_cast<const f32x4*>(src + off[j]);
+    }
+    {   // z pass, in place
+      const int rows = fnx * fny;
+      for (int row = wave * spw + slot; row < rows; row += nw * spw) {
+        const float* f = F + row * n_out;
+        float v[TAPS];
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) v[k] = f[oz[k]];
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) acc = (wz[k] != 0.0f) ? fmaf(wz[k], v[k], acc) : acc;
+        if (zok) F[row * n_out + iz] = acc;
       }
     }
-    dst[((size_t)xp * np + yp) * np + zp] = acc;
+    __syncthreads();
+    {   // y pass: pairs (fx, jy), jy fastest
+      const int pairs = fnx * ncy;
+      for (int pr = wave * spw + slot; pr < pairs; pr += nw * spw) {
+        const int fx = div_by(pr, m_ncy), jy = pr - fx * ncy;
+        const int d0 = d_tab[kBtMaxTile + jy];
+        const float* zc = F + (size_t)fx * fny * n_out + (zok ? iz : 0);
+        float w[TAPS], v[TAPS];
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) {
+          w[k] = w_tab[kBtMaxTile + jy][k];
+          v[k] = zc[min(d0 + k, fny - 1) * n_out];
+        }
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) acc = (w[k] != 0.0f) ? fmaf(w[k], v[k], acc) : acc;
+        if (zok) Y[pr * n_in + iz] = acc;
+      }
+    }
+    __syncthreads();
+    // x pass, (mix,) mask, store: the tile's columns of the padded tensor, zeros in the padding
+#pragma unroll
+    for (int j = 0; j < kBtOut; ++j) {
+      if (tid + nthr * j >= n_store) break;
+      float acc = 0.0f;
+      const bool inside = st_a[j] >= 0;
+      if (inside) {
+        const int xr = st_y[j] & 15, d0 = d_tab[xr];
+        const float* yc = Y + (st_y[j] >> 4);
+        float w[TAPS], v[TAPS];
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) {
+          w[k] = w_tab[xr][k];
+          v[k] = yc[min(d0 + k, fnx - 1) * y_stride];
+        }
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) acc = (w[k] != 0.0f) ? fmaf(w[k], v[k], acc) : acc;
+      }
+      if (COUT == 0) {
+        if (act && !(mask[j][0] > 0.0f)) acc = 0.0f;   // (padding: acc is 0 already)
+        out[(size_t)o * pad_vol + st_r[j]] = acc;
+      } else {
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+          const float v = fmaf(acc, wmat[co], 0.0f) + bias[co];
+          out[((size_t)o * CO + co) * pad_vol + st_r[j]] = (inside && (!act || mask[j][co] > 0.0f)) ? v : 0.0f;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);   // (one element's taps at a time: six elements' worth of reads in flight cost 40 VGPRs)
+    }
   }
 }
 
@@ -1475,6 +1591,14 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
   return 0;
 }
 
+namespace sdfr { namespace {
+std::atomic<int> g_tiled_resize_vjp{1};   // tests switch the one-launch transposed resize off: sdfr_debug_set_decoder_tiled_vjp
+} }
+
+extern "C" int sdfr_debug_set_decoder_tiled_vjp(int on) {
+  return sdfr::g_tiled_resize_vjp.exchange(on ? 1 : 0, std::memory_order_relaxed);
+}
+
 extern "C" size_t sdfr_decoder_backward_workspace_bytes(const sdfr_decoder* d, int N) {
   if (!d || N <= 0) return 0;
   return 2 * (size_t)N * d->max_bwd * sizeof(float) + 512;
@@ -1519,7 +1643,9 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
         few = d1 - d0 + 1 <= kZyTaps;
       }
     }
-    if (!few && !mix_w && n_in <= 64 && n_out <= 1024 && nc <= 65535) {
+    // (n_in <= n_out: the z pass writes a row's n_in results over the row's own n_out sources)
+    if (!few && g_tiled_resize_vjp.load(std::memory_order_relaxed) && (!mix_w || (C == 1 && pad >= 0)) && n_in <= 64 &&
+        n_in <= n_out && n_out <= 1024 && nc < (1u << 24)) {
       // batches: the three passes in one launch on an LDS-staged block (resize3_backward_tiled_kernel)
       const float ratio = (float)n_in / (float)n_out;
       auto weight = [&](int dd, int i) {   // resize_weight on the host, same float arithmetic
@@ -1536,26 +1662,99 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
         while (d0 <= d1 && weight(d0, i) == 0.0f) ++d0;
         while (d1 >= d0 && weight(d1, i) == 0.0f) --d1;
       };
-      const int padv = pad >= 0 ? pad : 0, npad = n_in + 2 * padv;
-      int max_f = 1, max_taps = 1;
+      const int padv = pad >= 0 ? pad : 0;
+      int max_taps = 1;
       for (int i = 0; i < n_in; ++i) {
         int d0, d1;
         exact(i, d0, d1);
         max_taps = std::max(max_taps, d1 - d0 + 1);
       }
-      for (int t0 = 0; t0 < npad; t0 += kBtTile) {   // the tile's coarse range -> its fine span, worst tile
-        const int c0 = std::max(t0 - padv, 0), c1 = std::min(t0 + kBtTile - 1 - padv, n_in - 1);
-        if (c0 > c1) continue;
-        int a0, a1, t;
-        exact(c0, a0, t);
-        exact(c1, t, a1);
-        max_f = std::max(max_f, a1 - a0 + 1);
+      // tile edge and workgroup size: the pair that stages the fewest fine rows over the launch, among those whose
+      // block fits the registers of the prefetch (kBtLoads vectors per thread) and leaves two workgroups on a CU
+      struct Pick { int tc = 0, threads = 0, max_f = 0, wgs = 0; size_t lds = 0; double cost = 0; } best;
+      const bool aligned = (n_out & 3) == 0 && ((uintptr_t)g & 15) == 0 && max_taps <= kBtTaps;
+      const void* fn = nullptr;   // the instantiation this call takes
+      {
+#define SDFR_BT_FN(CO) (max_taps <= 6 ? reinterpret_cast<const void*>(&resize3_backward_tiled_kernel<CO, 6>)    \
+                        : max_taps <= 8 ? reinterpret_cast<const void*>(&resize3_backward_tiled_kernel<CO, 8>)  \
+                                        : reinterpret_cast<const void*>(&resize3_backward_tiled_kernel<CO, 12>))
+        fn = !mix_w ? SDFR_BT_FN(0) : mix_cout == 1 ? SDFR_BT_FN(1) : mix_cout == 2 ? SDFR_BT_FN(2) : mix_cout == 3 ? SDFR_BT_FN(3) : SDFR_BT_FN(4);
+#undef SDFR_BT_FN
       }
-      const size_t lds = (size_t)max_f * max_f * (n_out + n_in) * sizeof(float);
-      if (max_taps <= kBtTaps && lds <= 56 * 1024) {
-        const int tiles = (npad + kBtTile - 1) / kBtTile;
-        hipLaunchKernelGGL(resize3_backward_tiled_kernel, dim3(tiles * tiles, (unsigned)nc), dim3(256), lds, st, g, n_in,
-                           n_out, pad >= 0 ? act : nullptr, padv, max_f, buf[cur]);
+      static std::map<const void*, int> vgpr_waves;   // waves per SIMD the instantiation's registers allow
+      static std::mutex vgpr_mutex;
+      int waves_simd = 0;
+      if (aligned) {
+        std::lock_guard<std::mutex> lock(vgpr_mutex);
+        auto it = vgpr_waves.find(fn);
+        if (it == vgpr_waves.end()) {
+          // (a block above 64 KiB of dynamic LDS needs the kernel's limit raised: once per instantiation)
+          hipFuncAttributes fa;
+          int waves = 0;   // (0: the runtime refused; the three-launch form below is taken)
+          if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
+              hipFuncGetAttributes(&fa, fn) == hipSuccess)
+            waves = std::max(1, std::min(8, 512 / ((std::max(fa.numRegs, 1) + 7) / 8 * 8)));
+          it = vgpr_waves.emplace(fn, waves).first;
+        }
+        waves_simd = it->second;
+      }
+      for (int tc = 2; aligned && tc <= std::min(kBtMaxTile, n_in); ++tc) {
+#ifdef SDFR_BT_FORCE_TC
+        if (tc != std::min(SDFR_BT_FORCE_TC, n_in)) continue;
+#endif
+        int max_f = 1;
+        for (int c0 = 0; c0 < n_in; c0 += tc) {
+          int a0, a1, t;
+          exact(c0, a0, t);
+          exact(std::min(c0 + tc, n_in) - 1, t, a1);
+          max_f = std::max(max_f, a1 - a0 + 1);
+        }
+        const int tiles = (n_in + tc - 1) / tc;
+        const size_t lds = ((size_t)max_f * max_f * n_out + (size_t)max_f * tc * n_in) * sizeof(float);
+        if (lds > 150 * 1024) continue;
+        for (int threads = 256; threads <= kBtMaxThreads; threads *= 2) {
+#ifdef SDFR_BT_FORCE_THREADS
+          if (threads != SDFR_BT_FORCE_THREADS) continue;
+#endif
+          if ((size_t)max_f * max_f * (n_out >> 2) > (size_t)kBtLoads * threads) continue;
+          const size_t oc = tiles == 1 ? n_in + 2 * padv : tc + padv;   // columns of the padded tensor a tile writes, per axis
+          if (oc * oc * (n_in + 2 * padv) > (size_t)kBtOut * threads) continue;
+          // workgroups a CU holds (LDS, registers), and the cost: rows staged over the launch, with a charge for a
+          // thin CU (few waves to hide the chain of a workgroup behind)
+          const int wgs = (int)std::min<size_t>((160 * 1024) / (lds + 6 * 1024), (size_t)(4 * waves_simd) / (threads / 64));
+          if (wgs < 1) continue;
+          const double waves = (double)wgs * threads / 64;
+          const double cost = (double)tiles * tiles * max_f * max_f * (1.0 + 4.0 / waves);
+          if (!best.tc || cost < best.cost) { best.tc = tc; best.threads = threads; best.max_f = max_f; best.lds = lds; best.wgs = wgs; best.cost = cost; }
+        }
+      }
+      if (best.tc) {
+        const int tiles = (n_in + best.tc - 1) / best.tc, tt = tiles * tiles;
+        // channel slots: each workgroup walks over `per` channels (tables and addresses once, the next channel's
+        // rows prefetched); `per` so that the workgroups come in whole rounds of what the chip holds
+        const long long cap = 256LL * best.wgs;
+        int slots = 8;
+        double best_t = 0;
+        for (int per = 1; per <= 32; ++per) {
+          const int sl = (int)(((nc + per - 1) / per + 7) / 8 * 8);
+          const long long rounds = ((long long)tt * sl + cap - 1) / cap;
+          const double t = (double)rounds * (per + 0.7);   // (+ the set-up of a workgroup, in channels)
+          if (per == 1 || t < best_t) { best_t = t; slots = sl; }
+        }
+        const float* wm = mix_w ? mix_w : nullptr;
+        const float* zb = d->d_params + d->zero_bias_off;
+#define SDFR_BT(CO, TAPS)                                                                                             \
+  hipLaunchKernelGGL((resize3_backward_tiled_kernel<CO, TAPS>), dim3((unsigned)(tt * slots)), dim3(best.threads),     \
+                     best.lds, st, g, n_in, n_out, pad >= 0 ? act : nullptr, padv, best.tc, best.max_f, (int)nc,      \
+                     slots, wm, zb, buf[cur]);
+#define SDFR_BT_TAPS(CO) { if (max_taps <= 6) SDFR_BT(CO, 6) else if (max_taps <= 8) SDFR_BT(CO, 8) else SDFR_BT(CO, 12) }
+        if (!mix_w) SDFR_BT_TAPS(0)
+        else if (mix_cout == 1) SDFR_BT_TAPS(1)
+        else if (mix_cout == 2) SDFR_BT_TAPS(2)
+        else if (mix_cout == 3) SDFR_BT_TAPS(3)
+        else SDFR_BT_TAPS(4)
+#undef SDFR_BT_TAPS
+#undef SDFR_BT
         g = buf[cur];
         cur ^= 1;
         return;
@@ -1621,7 +1820,7 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
     // the transposed convolution below (conv1x1 + pad_mask launches saved)
     const bool mix = swap && !act && k == 1 && ci_n <= 4 && l > 0 && !d->conv_swap[l - 1] && out_n[l - 1] == prev &&
                      d->conv_cout[l - 1] == ci_n && prev != nin &&
-                     (size_t)N * co_n * nin * nin * nin <= kFewElements;
+                     ((size_t)N * co_n * nin * nin * nin <= kFewElements || co_n == 1);
     if (mix) {
       resize_backward(co_n, prev, nin, d->conv_k[l - 1] - 1,
                       d->conv_relu[l - 1] ? tape + (size_t)N * d->tape_conv_off[l - 1] : nullptr,

@@ -276,3 +276,66 @@ def test_batched_decoder_kernels_equal_single_decodes(mug):
     with torch.no_grad():
         o = dec.decode(torch.zeros(N, 8, device="cuda"))
     assert np.max(np.abs(o[N - 1, 0].cpu().numpy() - ref0)) <= 1e-4 * np.max(np.abs(ref0))
+
+
+def _random_state(rng, case):
+    state, width = {}, case["latent"]
+    for i, l in enumerate(case["fc"]):
+        state[f"decoder._fc_layers.{i}.weight"] = rng.normal(size=(l["out"], width)).astype(np.float32) / np.sqrt(width)
+        state[f"decoder._fc_layers.{i}.bias"] = rng.normal(size=l["out"]).astype(np.float32) * 0.1
+        width = l["out"]
+    for i, l in enumerate(case["conv"]):
+        k = l["kernel_size"]
+        fan = l["in_channels"] * k ** 3
+        state[f"decoder._conv_layers.{i}.weight"] = rng.normal(
+            size=(l["out_channels"], l["in_channels"], k, k, k)).astype(np.float32) / np.sqrt(fan)
+        state[f"decoder._conv_layers.{i}.bias"] = rng.normal(size=l["out_channels"]).astype(np.float32) * 0.1
+    return state
+
+
+def test_tiled_transposed_resize_is_bitwise_the_three_launches(mug):
+    """Batched VJP: each transposed resize as ONE launch on an LDS-staged block (channel loop, register prefetch, fused
+    mask / padding / swapped 1x1 layer) against the three single-axis launches (+ conv1x1 + pad_mask) it replaces --
+    the same fmaf chains in the same order, so the latent gradients must agree bit for bit.  Shapes: the mug decoder
+    (ratios 64/30, 32/14, 16/6; padded + masked, and the swapped last layer), up- and DOWN-sizing resizes, a coarse
+    size that leaves a one-column tile, a channel count that is not a multiple of 8, 2 ... 4 mixed channels."""
+    from sdfest_amd import SDFDecoder
+    from sdfest_amd._lib import lib
+    L = lib()
+    d, wts = mug
+    rng = np.random.default_rng(5)
+    cases = [("mug", mug_config(d), wts, 64, 8, 70)]
+    extra = [
+        dict(volume=32, latent=4, batch=80, fc=[{"out": 3 * 6 ** 3}],
+             conv=[dict(in_size=6, in_channels=3, out_channels=5, kernel_size=3, relu=True),      # -> 4
+                   dict(in_size=13, in_channels=5, out_channels=3, kernel_size=3, relu=True),     # 4 -> 13 -> 11
+                   dict(in_size=24, in_channels=3, out_channels=1, kernel_size=1, relu=False)]),  # 1x1, 11 -> 24 (swapped), -> 32
+        dict(volume=40, latent=4, batch=80, fc=[{"out": 2 * 8 ** 3}],
+             conv=[dict(in_size=8, in_channels=2, out_channels=6, kernel_size=1, relu=False),
+                   dict(in_size=28, in_channels=6, out_channels=2, kernel_size=3, relu=True),     # 8 -> 28 (9 taps) -> 26
+                   dict(in_size=24, in_channels=2, out_channels=1, kernel_size=3, relu=False)]),  # 26 -> 24 (down) -> 22 -> 40
+        dict(volume=48, latent=3, batch=70, fc=[{"out": 4 * 5 ** 3}],
+             conv=[dict(in_size=5, in_channels=4, out_channels=4, kernel_size=1, relu=True),
+                   dict(in_size=20, in_channels=4, out_channels=2, kernel_size=3, relu=True),     # 5 -> 20 (11 taps) -> 18
+                   dict(in_size=36, in_channels=2, out_channels=1, kernel_size=1, relu=False)]),  # 1x1, 18 -> 36 (swapped), -> 48
+    ]
+    for case in extra:
+        cfg = {"latent_size": case["latent"], "tsdf": False, "sdf_size": case["volume"],
+               "decoder": {"fc_layers": case["fc"], "conv_layers": case["conv"]}}
+        cases.append((f"volume {case['volume']}", cfg, _random_state(rng, case), case["volume"], case["latent"], case["batch"]))
+    for name, cfg, state, volume, latent, N in cases:
+        dec = SDFDecoder.from_config(cfg, state, sdf_size=volume) if name != "mug" else SDFDecoder.from_config(cfg, state)
+        z_np = rng.normal(size=(N, latent)).astype(np.float32)
+        G = torch.tensor(rng.normal(size=(N, 1, volume, volume, volume)).astype(np.float32), device="cuda")
+        grads = []
+        for on in (1, 0):
+            old = L.sdfr_debug_set_decoder_tiled_vjp(on)
+            try:
+                z = torch.tensor(z_np, device="cuda", requires_grad=True)
+                dec.decode(z).backward(G)
+                torch.cuda.synchronize()
+                grads.append(z.grad.clone())
+            finally:
+                L.sdfr_debug_set_decoder_tiled_vjp(old)
+        assert torch.isfinite(grads[0]).all() and grads[0].abs().max() > 0, name
+        assert torch.equal(grads[0], grads[1]), (name, (grads[0] - grads[1]).abs().max().item())
