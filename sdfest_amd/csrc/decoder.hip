@@ -465,6 +465,10 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
 }
 
 
+// x / d == umulhi(x, magic_of(d)) for x < 2^16 and 2 <= d < 2^16; d == 1 has no 32-bit reciprocal: div_by() tests for it
+__device__ __forceinline__ unsigned magic_of(int d) { return 0xffffffffu / (unsigned)d + 1u; }
+__device__ __forceinline__ int div_by(int x, unsigned m) { return m ? (int)__umulhi((unsigned)x, m) : x; }   // (magic_of(1) == 0)
+
 // Batched 3x3x3 convolution on the vector ALUs.  For the decoder's narrow layers (4 .. 16 output
 // channels) the matrix cores are the wrong tool: a 16-column MFMA tile is mostly padding, and both
 // MFMA forms above are bound by how they fetch their operands (560 us gather-bound, 772 us LDS-staged
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
 //   * per (ci, a, b) it reads its 6-float z-run once (ds_read_b128 + b64) and issues 3 x 4 x COUT FMAs
 //     whose weight operands are wave-uniform -> scalar registers (no operand traffic at all).
 // wd: [Cin][3][3][3][COUT].   grid: (tiles_x * tiles_y, 1, N), block 256 = TX*TY columns x ZC chunks
-template <int COUT>
+template <int COUT, bool VEC4>
 __global__ __launch_bounds__(256) void conv3d_direct_kernel(
     const float* __restrict__ in, const float* __restrict__ wd, const float* __restrict__ bias,
     float* __restrict__ out, int Cin, int n, int m, int relu, int TX, int TY, int CK) {
@@ -498,22 +502,37 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(
 #pragma unroll
     for (int co = 0; co < COUT; ++co) acc[z][co] = 0.0f;
   const int run = IY * n, y_valid = (n - ty0) * n;
-  // 16-byte loads when every run starts and ends on a 16-byte boundary (n % 4 == 0; TY is even)
-  const bool vec4 = (n & 3) == 0 && ((uintptr_t)in & 15) == 0;
+  // VEC4: 16-byte loads -- every run starts and ends on a 16-byte boundary (n % 4 == 0; TY is even; host).
   // 16-byte path: the patch of chunk i+1 is fetched into registers while chunk i is being
-  // convolved (<= 6 loads per thread: a chunk is <= 24 KB), so a workgroup waits for memory once
+  // convolved (<= 6 loads per thread: a chunk is <= 24 KB), so a workgroup waits for memory once.
+  // (Where each of a thread's <= 6 vectors of a chunk comes from does not depend on the chunk: channel within the
+  // chunk and offset are formed once, packed into one register -- two integer divisions per vector per chunk were
+  // 1/3 of the kernel's VALU instructions, and the kernel is VALU-bound.)
+  constexpr bool vec4 = VEC4;
   const int run4 = run >> 2;
-  f32x4 pre[6];
-  auto prefetch = [&](int c0) {
-    const int e4 = min(CK, Cin - c0) * IX * run4;
+  constexpr int kPre = VEC4 ? 6 : 1;
+  f32x4 pre[kPre];
+  int pf[kPre];   // (channel within the chunk << 24) | float offset (0xffffff: zeros); channel 127: not part of any chunk
+  if (VEC4) {
+    const unsigned m_run = magic_of(run4), m_ix = magic_of(IX);
+    const int e4_full = CK * IX * run4;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int e = min(tid + 256 * j, e4 - 1);
-      const int slab = e / run4, off = (e - slab * run4) << 2;
-      const int ci = slab / IX, x = tx0 + slab - ci * IX;
-      const float* row = src + (size_t)(c0 + ci) * nv + ((size_t)min(x, n - 1) * n + ty0) * n;
-      pre[j] = (x < n && off < y_valid) ? *reinterpret_cast<const f32x4*>(row + off)
-                                         : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int j = 0; j < kPre; ++j) {
+      const int e = tid + 256 * j;
+      const int slab = div_by(min(e, e4_full - 1), m_run), off = (e - slab * run4) << 2;
+      const int ci = div_by(slab, m_ix), x = tx0 + slab - ci * IX;
+      const int where = (x < n && off < y_valid) ? (int)(ci * nv) + (x * n + ty0) * n + off : 0xffffff;
+      pf[j] = ((e < e4_full ? ci : 127) << 24) | where;
+    }
+  }
+  auto prefetch = [&](int c0) {
+    const int ck = min(CK, Cin - c0);
+    const float* base = src + (size_t)c0 * nv;
+#pragma unroll
+    for (int j = 0; j < kPre; ++j) {
+      const int where = pf[j] & 0xffffff;
+      pre[j] = ((pf[j] >> 24) < ck && where != 0xffffff) ? *reinterpret_cast<const f32x4*>(base + where)
+                                                         : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
   };
   if (vec4) prefetch(0);
@@ -521,10 +540,9 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(
     const int ck = min(CK, Cin - c0), n_slab = ck * IX;
     __syncthreads();  // the previous chunk has been consumed
     if (vec4) {
-      const int e4 = n_slab * run4;
 #pragma unroll
-      for (int j = 0; j < 6; ++j)
-        if (tid + 256 * j < e4) reinterpret_cast<f32x4*>(tile)[tid + 256 * j] = pre[j];
+      for (int j = 0; j < kPre; ++j)
+        if ((pf[j] >> 24) < ck) reinterpret_cast<f32x4*>(tile)[tid + 256 * j] = pre[j];
     } else {
       for (int off = tid; off < run; off += 256) {
         for (int s0 = 0; s0 < n_slab; s0 += 8) {
@@ -813,6 +831,9 @@ __global__ __launch_bounds__(256) void resize_x_backward_pad_kernel(const float*
 #ifndef SDFR_BT_OUT
 #define SDFR_BT_OUT 3
 #endif
+#ifndef SDFR_BT_SKIP
+#define SDFR_BT_SKIP 0   // (timing experiments: leave phases out)
+#endif
 constexpr int kBtTaps = 12, kBtLoads = SDFR_BT_LOADS, kBtOut = SDFR_BT_OUT, kBtMaxTile = 16, kBtMaxThreads = 1024;
 // exact range of fine indices d that carry weight on coarse index i (empty: d0 > d1)
 __device__ __forceinline__ void resize_sources_exact(int i, float ratio, int n_in, int n_out, int& d0, int& d1) {
@@ -820,9 +841,6 @@ __device__ __forceinline__ void resize_sources_exact(int i, float ratio, int n_i
   while (d0 <= d1 && resize_weight(d0, i, ratio, n_in) == 0.0f) ++d0;
   while (d1 >= d0 && resize_weight(d1, i, ratio, n_in) == 0.0f) --d1;
 }
-// x / d == umulhi(x, magic_of(d)) for x < 2^16 and 2 <= d < 2^16; d == 1 has no 32-bit reciprocal: div_by() tests for it
-__device__ __forceinline__ unsigned magic_of(int d) { return 0xffffffffu / (unsigned)d + 1u; }
-__device__ __forceinline__ int div_by(int x, unsigned m) { return m ? (int)__umulhi((unsigned)x, m) : x; }   // (magic_of(1) == 0)
 // (index arithmetic: a lane is a z index in the passes, several rows per wave when the coarse row is short; divisions
 // are multiplications by a reciprocal formed once, and everything that does not depend on the channel -- addresses
 // of the loads, of the stores, of the mask -- is formed once per workgroup.  TAPS >= the longest source range of the
@@ -934,20 +952,20 @@ __global__ __launch_bounds__(kBtMaxThreads) void resize3_backward_tiled_kernel(
     __syncthreads();
     // this channel's mask values, then the next channel's block: both in flight during this channel's passes
     float mask[kBtOut][CO];
-    if (act) {
+    if (!(SDFR_BT_SKIP & 16) && act) {
 #pragma unroll
       for (int j = 0; j < kBtOut; ++j)
 #pragma unroll
         for (int co = 0; co < CO; ++co)
           mask[j][co] = (nthr * j < n_store && st_a[j] >= 0) ? act[((size_t)o * CO + co) * coarse_vol + st_a[j]] : 0.0f;
     }
-    if (o + slots < nc) {
+    if (!(SDFR_BT_SKIP & 8) && o + slots < nc) {
       const float* src = g_out + (size_t)(o + slots) * fine_vol;
 #pragma unroll
       for (int j = 0; j < kBtLoads; ++j)
         if (nthr * j < total4) pre[j] = *reinterpret_cast<const f32x4*>(src + off[j]);
     }
-    {   // z pass, in place
+    if (!(SDFR_BT_SKIP & 1)) {   // z pass, in place
       const int rows = fnx * fny;
       for (int row = wave * spw + slot; row < rows; row += nw * spw) {
         const float* f = F + row * n_out;
@@ -961,7 +979,7 @@ __global__ __launch_bounds__(kBtMaxThreads) void resize3_backward_tiled_kernel(
       }
     }
     __syncthreads();
-    {   // y pass: pairs (fx, jy), jy fastest
+    if (!(SDFR_BT_SKIP & 2)) {   // y pass: pairs (fx, jy), jy fastest
       const int pairs = fnx * ncy;
       for (int pr = wave * spw + slot; pr < pairs; pr += nw * spw) {
         const int fx = div_by(pr, m_ncy), jy = pr - fx * ncy;
@@ -983,7 +1001,7 @@ __global__ __launch_bounds__(kBtMaxThreads) void resize3_backward_tiled_kernel(
     // x pass, (mix,) mask, store: the tile's columns of the padded tensor, zeros in the padding
 #pragma unroll
     for (int j = 0; j < kBtOut; ++j) {
-      if (tid + nthr * j >= n_store) break;
+      if ((SDFR_BT_SKIP & 4) || tid + nthr * j >= n_store) break;
       float acc = 0.0f;
       const bool inside = st_a[j] >= 0;
       if (inside) {
@@ -1138,8 +1156,14 @@ bool launch_direct(const sdfr_decoder* d, size_t w_off, const float* src, const 
   const size_t lds = ((size_t)CK * per_ch + 8) * sizeof(float);  // + the over-read of the last z-run
   const dim3 grid(tiles, 1, N);
   const float* w = d->d_params + w_off;
-#define SDFR_DIRECT(CO) hipLaunchKernelGGL((conv3d_direct_kernel<CO>), grid, dim3(256), lds, st, src, w, bias, dst, cin, n, m, relu, TX, TY, CK)
-  if (cout == 4) SDFR_DIRECT(4); else if (cout == 8) SDFR_DIRECT(8); else SDFR_DIRECT(16);
+  // 16-byte loads: runs start and end on 16-byte boundaries, offsets and channel fit the packed word of the prefetch
+  const bool vec4 = (n & 3) == 0 && ((uintptr_t)src & 15) == 0 && (size_t)CK * n * n * n < 0xffffff && CK < 127;
+#define SDFR_DIRECT(CO)                                                                                          \
+  if (vec4) hipLaunchKernelGGL((conv3d_direct_kernel<CO, true>), grid, dim3(256), lds, st, src, w, bias, dst,   \
+                               cin, n, m, relu, TX, TY, CK);                                                    \
+  else hipLaunchKernelGGL((conv3d_direct_kernel<CO, false>), grid, dim3(256), lds, st, src, w, bias, dst, cin,  \
+                          n, m, relu, TX, TY, CK)
+  if (cout == 4) { SDFR_DIRECT(4); } else if (cout == 8) { SDFR_DIRECT(8); } else { SDFR_DIRECT(16); }
 #undef SDFR_DIRECT
   return true;
 }
