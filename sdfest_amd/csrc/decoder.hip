@@ -158,6 +158,10 @@ __global__ __launch_bounds__(256) void resize3_kernel(const float* __restrict__ 
   out[((size_t)n * C + c) * vo + r] = v;
 }
 
+// x / d == umulhi(x, magic_of(d)) for x < 2^16 and 2 <= d < 2^16; d == 1 has no 32-bit reciprocal: div_by() tests for it
+__device__ __forceinline__ unsigned magic_of(int d) { return 0xffffffffu / (unsigned)d + 1u; }
+__device__ __forceinline__ int div_by(int x, unsigned m) { return m ? (int)__umulhi((unsigned)x, m) : x; }   // (magic_of(1) == 0)
+
 // The same resize for up-sampling (ratio <= 1), tiled through LDS.  resize3_kernel issues 8 gathers
 // per output and is bound by the per-CU gather rate (0.8 TB/s of stores at 30^3 -> 64^3); here a
 // workgroup owns an 8 x 8 (x, y) patch of output columns, loads the few input columns under it
@@ -201,9 +205,15 @@ __global__ __launch_bounds__(256) void resize3_tiled_kernel(const float* __restr
   float* col_in = lds;                            // [cols][n_in]
   float* col_z = lds + (size_t)max_cols * n_in;   // [cols][n_out], interpolated along z
   const float* src = in + ((size_t)n * C + c) * n_in * n_in * n_in;
-  for (int i = tid; i < cols * n_in; i += 256) {
-    const int col = i / n_in, z = i - col * n_in;
-    col_in[i] = src[((size_t)(a0 + col / ry) * n_in + (b0 + col % ry)) * n_in + z];
+  {
+    // (the kernel is bound by its VALU instruction count -- 61 per output before this form, PMC: VALU 100 % busy --
+    // so: no integer divisions, nothing per output that is the same for a whole column or tile row)
+    const unsigned m_nin = magic_of(n_in), m_ry = magic_of(ry);
+    for (int i = tid; i < cols * n_in; i += 256) {
+      const int col = div_by(i, m_nin), z = i - col * n_in;
+      const int cx = div_by(col, m_ry), cy = col - cx * ry;
+      col_in[i] = src[((a0 + cx) * n_in + (b0 + cy)) * n_in + z];
+    }
   }
   __syncthreads();
   const int z = tid & zmask;
@@ -215,18 +225,38 @@ __global__ __launch_bounds__(256) void resize3_tiled_kernel(const float* __restr
   }
   __syncthreads();
   float* dst = out + ((size_t)n * C + c) * n_out * n_out * n_out;
-  for (int xy = tid >> LOG_NO; xy < kResizeTile * kResizeTile; xy += 256 >> LOG_NO) {
-    const int jx = xy >> 3, jy = xy & 7;
-    const int x = tx0 + jx, y = ty0 + jy;
-    if (x >= n_out || y >= n_out) continue;
-    const float lx = t_l[jx], ly = t_l[8 + jy], wx0 = 1.0f - lx, wy0 = 1.0f - ly;
-    const int r0 = t_i0[jx] * ry, r1 = t_i1[jx] * ry, c0 = t_i0[8 + jy], c1 = t_i1[8 + jy];
-#define COLZ(r, cc) col_z[(((r) + (cc)) << LOG_NO) + z]
-    float v = blend(wx0, blend(wy0, COLZ(r0, c0), ly, COLZ(r0, c1)), lx, blend(wy0, COLZ(r1, c0), ly, COLZ(r1, c1)));
-#undef COLZ
-    if (relu) v = fmaxf(v, 0.0f);
-    if (clamp > 0.0f) v = fminf(fmaxf(v, -clamp), clamp);
-    dst[(((((size_t)x) << LOG_NO) + y) << LOG_NO) + z] = v;
+  // a thread's outputs: its z, the tile's x, and the y = sub, sub + P, ... of its wave part (P = 256 / n_out threads
+  // share a z): the y terms once per y, the x terms once per thread
+  constexpr int P = 256 >> LOG_NO, PY = P < kResizeTile ? P : kResizeTile;   // distinct y per pass
+  constexpr int XS = P / PY;                                                 // x handled side by side (P > 8)
+  const int sub = tid >> LOG_NO, jy0 = sub % PY, jx0 = sub / PY;
+  float lxs[kResizeTile / XS];
+  int r0s[kResizeTile / XS], r1s[kResizeTile / XS];
+#pragma unroll
+  for (int i = 0; i < kResizeTile / XS; ++i) {
+    const int jx = jx0 + XS * i;
+    lxs[i] = t_l[jx];
+    r0s[i] = (t_i0[jx] * ry) << LOG_NO;
+    r1s[i] = (t_i1[jx] * ry) << LOG_NO;
+  }
+#pragma unroll
+  for (int h = 0; h < kResizeTile / PY; ++h) {
+    const int jy = jy0 + PY * h, y = ty0 + jy;
+    if (y >= n_out) continue;
+    const float ly = t_l[8 + jy], wy0 = 1.0f - ly;
+    const float* cz0 = col_z + (t_i0[8 + jy] << LOG_NO) + z;
+    const float* cz1 = col_z + (t_i1[8 + jy] << LOG_NO) + z;
+    float* drow = dst + ((((size_t)tx0 << LOG_NO) + y) << LOG_NO) + z;
+#pragma unroll
+    for (int i = 0; i < kResizeTile / XS; ++i) {
+      const int jx = jx0 + XS * i;
+      if (tx0 + jx >= n_out) continue;
+      const float lx = lxs[i], wx0 = 1.0f - lx;
+      float v = blend(wx0, blend(wy0, cz0[r0s[i]], ly, cz1[r0s[i]]), lx, blend(wy0, cz0[r1s[i]], ly, cz1[r1s[i]]));
+      if (relu) v = fmaxf(v, 0.0f);
+      if (clamp > 0.0f) v = fminf(fmaxf(v, -clamp), clamp);
+      drow[(size_t)jx << (2 * LOG_NO)] = v;
+    }
   }
 }
 
@@ -464,10 +494,6 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
   }
 }
 
-
-// x / d == umulhi(x, magic_of(d)) for x < 2^16 and 2 <= d < 2^16; d == 1 has no 32-bit reciprocal: div_by() tests for it
-__device__ __forceinline__ unsigned magic_of(int d) { return 0xffffffffu / (unsigned)d + 1u; }
-__device__ __forceinline__ int div_by(int x, unsigned m) { return m ? (int)__umulhi((unsigned)x, m) : x; }   // (magic_of(1) == 0)
 
 // Batched 3x3x3 convolution on the vector ALUs.  For the decoder's narrow layers (4 .. 16 output
 // channels) the matrix cores are the wrong tool: a 16-column MFMA tile is mostly padding, and both
