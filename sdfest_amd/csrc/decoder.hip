@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(
     float* __restrict__ out, int Cin, int n, int m, int relu, int TX, int TY, int CK) {
   constexpr int K = 3, ZR = 4;
   constexpr int kUnrollB = COUT >= 8 ? 1 : K;  // keep a step's weights within the scalar registers
-  extern __shared__ float tile[];  // [CK][IX][IY][n]
+  extern __shared__ float tile[];  // [CK][IX][IY][np4]
   const int tid = threadIdx.x;
   const int IX = TX + K - 1, IY = TY + K - 1, ZC = 256 / (TX * TY);
   const int tiles_y = (m + TY - 1) / TY;
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(
   for (int z = 0; z < ZR; ++z)
 #pragma unroll
     for (int co = 0; co < COUT; ++co) acc[z][co] = 0.0f;
-  const int run = IY * n, y_valid = (n - ty0) * n;
+  const int run = IY * n, y_valid = (n - ty0) * n, np4 = (n + 3) & ~3;   // np4: LDS row pitch
   // VEC4: 16-byte loads -- every run starts and ends on a 16-byte boundary (n % 4 == 0; TY is even; host).
   // 16-byte path: the patch of chunk i+1 is fetched into registers while chunk i is being
   // convolved (<= 6 loads per thread: a chunk is <= 24 KB), so a workgroup waits for memory once.
@@ -570,7 +570,10 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(
       for (int j = 0; j < kPre; ++j)
         if ((pf[j] >> 24) < ck) reinterpret_cast<f32x4*>(tile)[tid + 256 * j] = pre[j];
     } else {
+      // (LDS rows are np4 = n rounded up to 4 floats apart, so that the z-runs below are 16-byte aligned whatever n)
+      const unsigned m_n = magic_of(n);
       for (int off = tid; off < run; off += 256) {
+        const int l_off = off + div_by(off, m_n) * (np4 - n);
         for (int s0 = 0; s0 < n_slab; s0 += 8) {
           float v[8];
 #pragma unroll
@@ -581,7 +584,7 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(
           }
 #pragma unroll
           for (int u = 0; u < 8; ++u)
-            if (s0 + u < n_slab) tile[(s0 + u) * run + off] = v[u];
+            if (s0 + u < n_slab) tile[(s0 + u) * IY * np4 + l_off] = v[u];
         }
       }
     }
@@ -595,18 +598,16 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(
         for (int a = 0; a < K; ++a)
 #pragma unroll kUnrollB
           for (int b = 0; b < K; ++b) {
-            const float* p = tile + ((ci * IX + lx + a) * IY + ly + b) * n + z0;
+            const float* p = tile + ((ci * IX + lx + a) * IY + ly + b) * np4 + z0;
             // the 6-float z-run as one 16-byte and one 8-byte LDS read (the runs of a wave then cover
             // all banks evenly; six 4-byte reads hit 8 banks 8 ways each: 3.7x slower, measured).  Values
-            // past the end of a row belong to outputs z >= m, which are never stored.
+            // past the end of a row (the next row's, or the unwritten floats between n and np4) belong to
+            // outputs z >= m, which are never stored.
             float v[ZR + K - 1];
-            if (vec4) {
+            {
               const f32x4 q = *reinterpret_cast<const f32x4*>(p);
               const float2 r = *reinterpret_cast<const float2*>(p + 4);
               v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3]; v[4] = r.x; v[5] = r.y;
-            } else {
-#pragma unroll
-              for (int t = 0; t < ZR + K - 1; ++t) v[t] = (z0 + t < n) ? p[t] : 0.0f;
             }
             const float* w = wd + ((((size_t)(c0 + ci) * K + a) * K + b) * K) * COUT;  // wave-uniform
 #pragma unroll
@@ -1177,7 +1178,7 @@ bool launch_direct(const sdfr_decoder* d, size_t w_off, const float* src, const 
   const int tiles = ((m + TX - 1) / TX) * ((m + TY - 1) / TY);
   if ((long long)tiles * N < 512) return false;
   // channels per LDS chunk: patch of CK channels <= 24 KB
-  const int per_ch = (TX + 2) * (TY + 2) * n;
+  const int per_ch = (TX + 2) * (TY + 2) * ((n + 3) & ~3);   // (LDS rows are padded to 16 bytes)
   int CK = std::max(1, std::min(cin, (24 * 1024 / 4) / per_ch));
   const size_t lds = ((size_t)CK * per_ch + 8) * sizeof(float);  // + the over-read of the last z-run
   const dim3 grid(tiles, 1, N);
