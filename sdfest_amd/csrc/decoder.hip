@@ -509,7 +509,8 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
 template <int COUT, bool VEC4>
 __global__ __launch_bounds__(256) void conv3d_direct_kernel(
     const float* __restrict__ in, const float* __restrict__ wd, const float* __restrict__ bias,
-    float* __restrict__ out, int Cin, int n, int m, int relu, int TX, int TY, int CK) {
+    float* __restrict__ out, int Cin, int n, int pz, int m, int relu, int TX, int TY, int CK) {
+  // (pz: floats between z-rows of `in`, >= n -- the padded tensors of the backward pass have their rows 16 bytes apart)
   constexpr int K = 3, ZR = 4;
   constexpr int kUnrollB = COUT >= 8 ? 1 : K;  // keep a step's weights within the scalar registers
   extern __shared__ float tile[];  // [CK][IX][IY][np4]
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(
   const int tiles_y = (m + TY - 1) / TY;
   const int tx0 = (blockIdx.x / tiles_y) * TX, ty0 = (blockIdx.x % tiles_y) * TY;
   const int nb = blockIdx.z;
-  const size_t nv = (size_t)n * n * n, mv = (size_t)m * m * m;
+  const size_t nv = (size_t)n * n * pz, mv = (size_t)m * m * m;
   const float* src = in + (size_t)nb * Cin * nv;
   const int col = tid / ZC, zc = tid - col * ZC;
   const int lx = col / TY, ly = col - lx * TY, z0 = zc * ZR;
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(
   for (int z = 0; z < ZR; ++z)
 #pragma unroll
     for (int co = 0; co < COUT; ++co) acc[z][co] = 0.0f;
-  const int run = IY * n, y_valid = (n - ty0) * n, np4 = (n + 3) & ~3;   // np4: LDS row pitch
+  const int run = IY * pz, y_valid = (n - ty0) * pz, np4 = (pz + 3) & ~3;   // np4: LDS row pitch
   // VEC4: 16-byte loads -- every run starts and ends on a 16-byte boundary (n % 4 == 0; TY is even; host).
   // 16-byte path: the patch of chunk i+1 is fetched into registers while chunk i is being
   // convolved (<= 6 loads per thread: a chunk is <= 24 KB), so a workgroup waits for memory once.
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(
       const int e = tid + 256 * j;
       const int slab = div_by(min(e, e4_full - 1), m_run), off = (e - slab * run4) << 2;
       const int ci = div_by(slab, m_ix), x = tx0 + slab - ci * IX;
-      const int where = (x < n && off < y_valid) ? (int)(ci * nv) + (x * n + ty0) * n + off : 0xffffff;
+      const int where = (x < n && off < y_valid) ? (int)(ci * nv) + (x * n + ty0) * pz + off : 0xffffff;
       pf[j] = ((e < e4_full ? ci : 127) << 24) | where;
     }
   }
@@ -571,15 +572,15 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(
         if ((pf[j] >> 24) < ck) reinterpret_cast<f32x4*>(tile)[tid + 256 * j] = pre[j];
     } else {
       // (LDS rows are np4 = n rounded up to 4 floats apart, so that the z-runs below are 16-byte aligned whatever n)
-      const unsigned m_n = magic_of(n);
+      const unsigned m_n = magic_of(pz);
       for (int off = tid; off < run; off += 256) {
-        const int l_off = off + div_by(off, m_n) * (np4 - n);
+        const int l_off = off + div_by(off, m_n) * (np4 - pz);
         for (int s0 = 0; s0 < n_slab; s0 += 8) {
           float v[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
             const int slab = min(s0 + u, n_slab - 1), ci = slab / IX, x = tx0 + slab - ci * IX;
-            const float* row = src + (size_t)(c0 + ci) * nv + ((size_t)min(x, n - 1) * n + ty0) * n;
+            const float* row = src + (size_t)(c0 + ci) * nv + ((size_t)min(x, n - 1) * n + ty0) * pz;
             v[u] = (x < n && off < y_valid) ? row[off] : 0.0f;
           }
 #pragma unroll
@@ -639,20 +640,20 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(
 
 // ---- backward (VJP to the latent; weights are constants) -------------------------------------
 
-// out[N][C][np^3] = zero-padded (by `pad` on every side) copy of g[N][C][m^3], multiplied by the
+// out[N][C][np][np][pz] = zero-padded (by `pad` on every side) copy of g[N][C][m^3], multiplied by the
 // ReLU mask of the layer's forward output when `act` is given.  The padded tensor turns the
 // data-gradient of a valid convolution into another valid convolution (with flipped weights).
 __global__ __launch_bounds__(256) void pad_mask_kernel(const float* __restrict__ g,
                                                        const float* __restrict__ act, int C, int m,
-                                                       int pad, float* __restrict__ out) {
-  const int np = m + 2 * pad;
-  const size_t vp = (size_t)np * np * np, vm = (size_t)m * m * m;
+                                                       int pad, int pz, float* __restrict__ out) {
+  const int np = m + 2 * pad;   // rows are pz >= np floats apart (floats np .. pz - 1 of a row: zeros)
+  const size_t vp = (size_t)np * np * pz, vm = (size_t)m * m * m;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (size_t)C * vp) return;
   const int n = blockIdx.y;
   const int c = (int)(idx / vp);
   const int r = (int)(idx - (size_t)c * vp);
-  const int z = r % np - pad, y = (r / np) % np - pad, x = r / (np * np) - pad;
+  const int z = r % pz - pad, y = (r / pz) % np - pad, x = r / (pz * np) - pad;
   float v = 0.0f;
   if (x >= 0 && x < m && y >= 0 && y < m && z >= 0 && z < m) {
     const size_t src = ((size_t)n * C + c) * vm + ((size_t)x * m + y) * m + z;
@@ -756,13 +757,13 @@ __global__ __launch_bounds__(256) void resize_zy_backward_kernel(const float* __
 template <int COUT>
 __global__ __launch_bounds__(256) void resize_x_backward_mix_pad_kernel(
     const float* __restrict__ g_out, int Cin, int n_in, int n_out, const float* __restrict__ wmat,
-    const float* __restrict__ bias, const float* __restrict__ act, int pad, float* __restrict__ out) {
-  const int np = n_in + 2 * pad;
-  const size_t vp = (size_t)np * np * np, vin = (size_t)n_in * n_in * n_in;
+    const float* __restrict__ bias, const float* __restrict__ act, int pad, int pz, float* __restrict__ out) {
+  const int np = n_in + 2 * pad;   // rows of `out` are pz >= np floats apart (floats np .. pz - 1: zeros)
+  const size_t vp = (size_t)np * np * pz, vin = (size_t)n_in * n_in * n_in;
   const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= vp) return;
   const int n = blockIdx.y;
-  const int z = (int)(r % np) - pad, y = (int)((r / np) % np) - pad, i = (int)(r / ((size_t)np * np)) - pad;
+  const int z = (int)(r % pz) - pad, y = (int)((r / pz) % np) - pad, i = (int)(r / ((size_t)pz * np)) - pad;
   float res[COUT];
 #pragma unroll
   for (int co = 0; co < COUT; ++co) res[co] = 0.0f;
@@ -801,15 +802,15 @@ __global__ __launch_bounds__(256) void resize_x_backward_mix_pad_kernel(
 //   out[o][x + pad][y + pad][z + pad] = (act[o][x][y][z] > 0 or no act) ? sum_d w(d -> x) g_out[o][d][y][z] : 0
 __global__ __launch_bounds__(256) void resize_x_backward_pad_kernel(const float* __restrict__ g_out, size_t outer,
                                                                     int n_in, int n_out,
-                                                                    const float* __restrict__ act, int pad,
+                                                                    const float* __restrict__ act, int pad, int pz,
                                                                     float* __restrict__ out) {
-  const int np = n_in + 2 * pad;
-  const size_t vp = (size_t)np * np * np;
+  const int np = n_in + 2 * pad;   // rows of `out` are pz >= np floats apart (floats np .. pz - 1: zeros)
+  const size_t vp = (size_t)np * np * pz;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= outer * vp) return;
   const size_t o = idx / vp;
   const int r = (int)(idx - o * vp);
-  const int z = r % np - pad, y = (r / np) % np - pad, i = r / (np * np) - pad;
+  const int z = r % pz - pad, y = (r / pz) % np - pad, i = r / (pz * np) - pad;
   float acc = 0.0f;
   if (i >= 0 && i < n_in && y >= 0 && y < n_in && z >= 0 && z < n_in) {
     const size_t inner = (size_t)n_in * n_in, rr = (size_t)y * n_in + z;
@@ -877,8 +878,8 @@ __device__ __forceinline__ void resize_sources_exact(int i, float ratio, int n_i
 // z pass and used after its y pass.)
 template <int COUT, int TAPS>
 __global__ __launch_bounds__(kBtMaxThreads) void resize3_backward_tiled_kernel(
-    const float* __restrict__ g_out, int n_in, int n_out, const float* __restrict__ act, int pad, int tc, int max_f,
-    int nc, int slots, const float* __restrict__ wmat, const float* __restrict__ bias, float* __restrict__ out) {
+    const float* __restrict__ g_out, int n_in, int n_out, const float* __restrict__ act, int pad, int pz, int tc,
+    int max_f, int nc, int slots, const float* __restrict__ wmat, const float* __restrict__ bias, float* __restrict__ out) {
   constexpr int CO = COUT > 0 ? COUT : 1;
   extern __shared__ float lds[];
   __shared__ float w_tab[2 * kBtMaxTile + 64][kBtTaps];   // rows: x (tc), y (tc), z (n_in <= 64)
@@ -930,7 +931,7 @@ __global__ __launch_bounds__(kBtMaxThreads) void resize3_backward_tiled_kernel(
       off[j] = ((fx0 + fx) * n_out + (fy0 + fy)) * n_out + 4 * q;
     }
   }
-  const size_t fine_vol = (size_t)n_out * n_out * n_out, coarse_vol = (size_t)n_in * n_in * n_in, pad_vol = (size_t)np * np * np;
+  const size_t fine_vol = (size_t)n_out * n_out * n_out, coarse_vol = (size_t)n_in * n_in * n_in, pad_vol = (size_t)np * np * pz;
   f32x4 pre[kBtLoads];
   {
     const float* src = g_out + (size_t)slot0 * fine_vol;
@@ -940,19 +941,19 @@ __global__ __launch_bounds__(kBtMaxThreads) void resize3_backward_tiled_kernel(
   }
   // a thread's elements of the tile's part of the padded tensor (<= kBtOut * nthr: host): where each goes, its mask
   // value, its Y column and its x weights (-1: padding, a zero)
-  const int ocx = ox1 - ox0, ocy = oy1 - oy0, n_store = ocx * ocy * np;
+  const int ocx = ox1 - ox0, ocy = oy1 - oy0, n_store = ocx * ocy * pz;   // (rows pz >= np floats apart, the rest zeros)
   int st_r[kBtOut], st_a[kBtOut], st_y[kBtOut];
   {
-    const unsigned m_np = magic_of(np), m_ocy = magic_of(ocy);
+    const unsigned m_np = magic_of(pz), m_ocy = magic_of(ocy);
 #pragma unroll
     for (int j = 0; j < kBtOut; ++j) {
       const int e = min(tid + nthr * j, n_store - 1);
-      const int col = div_by(e, m_np), zp = e - col * np;
+      const int col = div_by(e, m_np), zp = e - col * pz;
       const int jx = div_by(col, m_ocy), jy = col - jx * ocy;
       const int xp = ox0 + jx, yp = oy0 + jy;
       const int ix = xp - pad, iy = yp - pad, izz = zp - pad;
       const bool inside = ix >= cx0 && ix <= cx1 && iy >= cy0 && iy <= cy1 && izz >= 0 && izz < n_in;
-      st_r[j] = (xp * np + yp) * np + zp;
+      st_r[j] = (xp * np + yp) * pz + zp;
       st_a[j] = inside ? (ix * n_in + iy) * n_in + izz : -1;
       st_y[j] = inside ? (((iy - cy0) * n_in + izz) << 4) | (ix - cx0) : 0;   // (Y column, x-table row < 16)
     }
@@ -1165,8 +1166,8 @@ int use_split_k(bool zgrp, int n_tiles, int co_tiles, int N, int kpad) {
 
 // The direct convolution is for batches (enough tiles to fill the chip); returns false when the
 // layer / batch does not qualify and the caller falls back to the MFMA kernel.
-bool launch_direct(const sdfr_decoder* d, size_t w_off, const float* src, const float* bias, float* dst,
-                   int cin, int cout, int n, int m, int relu, int N, hipStream_t st) {
+// Does a layer / batch qualify for it?  (n: input size, m: output size)
+bool direct_ok(size_t w_off, int n, int m, int N, int* tx = nullptr, int* ty = nullptr) {
   if (w_off == 0 || n > 64 || m < 4) return false;
   const int ZC = (m + 3) / 4;                       // z chunks of 4 outputs per column
   int zc_pow = 1;
@@ -1177,19 +1178,30 @@ bool launch_direct(const sdfr_decoder* d, size_t w_off, const float* src, const 
   while (TY > 2 * TX) { TX <<= 1; TY >>= 1; }       // as square as powers of two allow
   const int tiles = ((m + TX - 1) / TX) * ((m + TY - 1) / TY);
   if ((long long)tiles * N < 512) return false;
+  if (tx) *tx = TX;
+  if (ty) *ty = TY;
+  return true;
+}
+// pz: floats between the z-rows of src (n, or more: the padded tensors of the backward pass)
+bool launch_direct(const sdfr_decoder* d, size_t w_off, const float* src, const float* bias, float* dst,
+                   int cin, int cout, int n, int pz, int m, int relu, int N, hipStream_t st) {
+  int TX, TY;
+  if (!direct_ok(w_off, n, m, N, &TX, &TY)) return false;
+  const int tiles = ((m + TX - 1) / TX) * ((m + TY - 1) / TY);
   // channels per LDS chunk: patch of CK channels <= 24 KB
-  const int per_ch = (TX + 2) * (TY + 2) * ((n + 3) & ~3);   // (LDS rows are padded to 16 bytes)
+  const int per_ch = (TX + 2) * (TY + 2) * ((pz + 3) & ~3);   // (LDS rows are padded to 16 bytes)
   int CK = std::max(1, std::min(cin, (24 * 1024 / 4) / per_ch));
   const size_t lds = ((size_t)CK * per_ch + 8) * sizeof(float);  // + the over-read of the last z-run
   const dim3 grid(tiles, 1, N);
   const float* w = d->d_params + w_off;
   // 16-byte loads: runs start and end on 16-byte boundaries, offsets and channel fit the packed word of the prefetch
-  const bool vec4 = (n & 3) == 0 && ((uintptr_t)src & 15) == 0 && (size_t)CK * n * n * n < 0xffffff && CK < 127;
+  const bool vec4 = (pz & 3) == 0 && ((uintptr_t)src & 15) == 0 && (size_t)CK * n * n * pz < 0xffffff && CK < 127;
+  if (!vec4 && pz != n) return false;   // (the scalar-load form takes dense rows only; callers pad rows only to 16 bytes)
 #define SDFR_DIRECT(CO)                                                                                          \
   if (vec4) hipLaunchKernelGGL((conv3d_direct_kernel<CO, true>), grid, dim3(256), lds, st, src, w, bias, dst,   \
-                               cin, n, m, relu, TX, TY, CK);                                                    \
+                               cin, n, pz, m, relu, TX, TY, CK);                                                \
   else hipLaunchKernelGGL((conv3d_direct_kernel<CO, false>), grid, dim3(256), lds, st, src, w, bias, dst, cin,  \
-                          n, m, relu, TX, TY, CK)
+                          n, pz, m, relu, TX, TY, CK)
   if (cout == 4) { SDFR_DIRECT(4); } else if (cout == 8) { SDFR_DIRECT(8); } else { SDFR_DIRECT(16); }
 #undef SDFR_DIRECT
   return true;
@@ -1359,7 +1371,7 @@ extern "C" int sdfr_decoder_create(const float* h_params, size_t n_params, int l
         img.push_back(f);
       }
       q += (size_t)co_n * ci_n * k3 + co_n;
-      d->max_bwd = std::max(d->max_bwd, (size_t)co_n * np * np * np);
+      d->max_bwd = std::max(d->max_bwd, (size_t)co_n * np * np * ((np + 3) & ~3));   // (z pitch padded to 16 bytes)
       d->max_bwd = std::max(d->max_bwd, (size_t)co_n * n * n * n);
       d->max_bwd = std::max(d->max_bwd, (size_t)ci_n * n * n * n);
       d->max_bwd = std::max(d->max_bwd, (size_t)ci_n * prev_n * prev_n * prev_n);
@@ -1367,6 +1379,7 @@ extern "C" int sdfr_decoder_create(const float* h_params, size_t n_params, int l
       tape += (size_t)co_n * m * m * m;
       prev_n = m;
     }
+    d->max_bwd = (d->max_bwd + 3) & ~(size_t)3;   // both halves of the backward workspace 16-byte aligned
     d->tape_floats = tape;
     align();
     d->zero_bias_off = img.size();
@@ -1599,7 +1612,7 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
 #define SDFR_CONV1(CO) hipLaunchKernelGGL((conv1x1_kernel<CO>), g1, dim3(256), 0, st, act_in, wm, bs, c, voxn, conv_relu, conv_dst)
       if (co_n == 1) SDFR_CONV1(1); else if (co_n == 2) SDFR_CONV1(2); else if (co_n == 3) SDFR_CONV1(3); else SDFR_CONV1(4);
 #undef SDFR_CONV1
-    } else if (!swap && launch_direct(d, d->fwd_direct_off[l], act_in, bs, conv_dst, c, co_n, n, m, conv_relu, N, st)) {
+    } else if (!swap && launch_direct(d, d->fwd_direct_off[l], act_in, bs, conv_dst, c, co_n, n, n, m, conv_relu, N, st)) {
       // (batched: direct VALU convolution)
     } else {
       const sdfr_decoder::ZPlan& zp = d->fwd_z[l];
@@ -1682,8 +1695,10 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
   // Single latents (the captured loop) are bound by the launch count: there the z and y passes share a launch.
   // mix_w != nullptr: the x pass also applies the transposed 1x1 layer C -> mix_cout channels
   // (resize_x_backward_mix_pad_kernel; needs pad >= 0).
+  // pz: floats between the z-rows of the padded tensor written (pad >= 0), >= n_in + 2 pad
   auto resize_backward = [&](int C, int n_in, int n_out, int pad = -1, const float* act = nullptr,
-                             const float* mix_w = nullptr, int mix_cout = 0) {
+                             const float* mix_w = nullptr, int mix_cout = 0, int pz = 0) {
+    if (pz == 0) pz = n_in + 2 * std::max(pad, 0);
     const size_t nc = (size_t)N * C;
     bool few = nc * n_out * n_out * n_out <= kFewElements;
     if (few) {  // longest source range, same arithmetic as resize_sources
@@ -1769,7 +1784,7 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
 #endif
           if ((size_t)max_f * max_f * (n_out >> 2) > (size_t)kBtLoads * threads) continue;
           const size_t oc = tiles == 1 ? n_in + 2 * padv : tc + padv;   // columns of the padded tensor a tile writes, per axis
-          if (oc * oc * (n_in + 2 * padv) > (size_t)kBtOut * threads) continue;
+          if (oc * oc * pz > (size_t)kBtOut * threads) continue;
           // workgroups a CU holds (LDS, registers), and the cost: rows staged over the launch, with a charge for a
           // thin CU (few waves to hide the chain of a workgroup behind)
           const int wgs = (int)std::min<size_t>((160 * 1024) / (lds + 6 * 1024), (size_t)(4 * waves_simd) / (threads / 64));
@@ -1796,7 +1811,7 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
         const float* zb = d->d_params + d->zero_bias_off;
 #define SDFR_BT(CO, TAPS)                                                                                             \
   hipLaunchKernelGGL((resize3_backward_tiled_kernel<CO, TAPS>), dim3((unsigned)(tt * slots)), dim3(best.threads),     \
-                     best.lds, st, g, n_in, n_out, pad >= 0 ? act : nullptr, padv, best.tc, best.max_f, (int)nc,      \
+                     best.lds, st, g, n_in, n_out, pad >= 0 ? act : nullptr, padv, pz, best.tc, best.max_f, (int)nc,  \
                      slots, wm, zb, buf[cur]);
 #define SDFR_BT_TAPS(CO) { if (max_taps <= 6) SDFR_BT(CO, 6) else if (max_taps <= 8) SDFR_BT(CO, 8) else SDFR_BT(CO, 12) }
         if (!mix_w) SDFR_BT_TAPS(0)
@@ -1823,15 +1838,15 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
         a = 1;
       } else if (a == 2 && mix_w) {
         const size_t np = (size_t)n_in + 2 * pad;
-        const dim3 gm((unsigned)((np * np * np + 255) / 256), N);
+        const dim3 gm((unsigned)((np * np * pz + 255) / 256), N);
         const float* zb = d->d_params + d->zero_bias_off;
-#define SDFR_MIX(CO) hipLaunchKernelGGL((resize_x_backward_mix_pad_kernel<CO>), gm, dim3(256), 0, st, g, C, n_in, n_out, mix_w, zb, act, pad, buf[cur])
+#define SDFR_MIX(CO) hipLaunchKernelGGL((resize_x_backward_mix_pad_kernel<CO>), gm, dim3(256), 0, st, g, C, n_in, n_out, mix_w, zb, act, pad, pz, buf[cur])
         if (mix_cout == 1) SDFR_MIX(1); else if (mix_cout == 2) SDFR_MIX(2); else if (mix_cout == 3) SDFR_MIX(3); else SDFR_MIX(4);
 #undef SDFR_MIX
       } else if (a == 2 && pad >= 0) {
-        const size_t np = (size_t)n_in + 2 * pad, cnt = nc * np * np * np;
+        const size_t np = (size_t)n_in + 2 * pad, cnt = nc * np * np * pz;
         hipLaunchKernelGGL(resize_x_backward_pad_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, g, nc,
-                           n_in, n_out, act, pad, buf[cur]);
+                           n_in, n_out, act, pad, pz, buf[cur]);
       } else {
         const size_t cnt = passes[a].outer * n_in * passes[a].inner;
         hipLaunchKernelGGL(resize_axis_backward_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st,
@@ -1840,6 +1855,15 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
       g = buf[cur];
       cur ^= 1;
     }
+  };
+  // z-row pitch of the padded tensor layer l's transposed convolution reads: rows 16 bytes apart when the direct
+  // convolution takes it (its 16-byte loads and register prefetch then apply whatever the size; 34 -> 36 floats)
+  const bool ws_aligned = ((uintptr_t)wsp & 15) == 0;
+  auto pitch_of = [&](int l) {
+    const int k = d->conv_k[l], np = out_n[l] + 2 * (k - 1);
+    const bool direct = ws_aligned && !d->conv_swap[l] && !(k == 1 && d->conv_cin[l] <= 4) &&
+                        direct_ok(d->bwd_direct_off[l], np, d->conv_in_size[l], N);
+    return direct ? (np + 3) & ~3 : np;
   };
   bool padded = false;  // g already is layer l's padded, masked output gradient (written by the resize above)
   int n = d->volume;
@@ -1855,14 +1879,15 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
     const int prev = d->conv_prev[l];
     const int np = swap ? prev : m + 2 * (k - 1);   // size of the tensor the transposed conv reads
     const int nconv = swap ? prev : nin;            // ... and of the one it produces
+    const int pz = swap ? np : pitch_of(l);         // ... and the floats between its z-rows
     // 1. ReLU' and zero padding of the output gradient
     const float* act = d->conv_relu[l] ? tape + (size_t)N * d->tape_conv_off[l] : nullptr;
     if (padded) {
       padded = false;
     } else if (!swap || act) {
-      const size_t cntp = (size_t)co_n * (swap ? m : np) * (swap ? m : np) * (swap ? m : np);
+      const size_t cntp = (size_t)co_n * (swap ? m : np) * (swap ? m : np) * (swap ? m : pz);
       hipLaunchKernelGGL(pad_mask_kernel, dim3((unsigned)((cntp + 255) / 256), N), dim3(256), 0, st, g, act,
-                         co_n, m, swap ? 0 : k - 1, buf[cur]);
+                         co_n, m, swap ? 0 : k - 1, swap ? m : pz, buf[cur]);
       g = buf[cur];
       cur ^= 1;
     }
@@ -1875,7 +1900,7 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
     if (mix) {
       resize_backward(co_n, prev, nin, d->conv_k[l - 1] - 1,
                       d->conv_relu[l - 1] ? tape + (size_t)N * d->tape_conv_off[l - 1] : nullptr,
-                      d->d_params + d->bwd_w_off[l], ci_n);
+                      d->d_params + d->bwd_w_off[l], ci_n, pitch_of(l - 1));
       padded = true;
       n = prev;
       continue;
@@ -1893,8 +1918,10 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
       if (ci_n == 1) SDFR_CONV1(1); else if (ci_n == 2) SDFR_CONV1(2); else if (ci_n == 3) SDFR_CONV1(3); else SDFR_CONV1(4);
 #undef SDFR_CONV1
     } else if (!swap && launch_direct(d, d->bwd_direct_off[l], g, d->d_params + d->zero_bias_off, buf[cur], co_n, ci_n, np,
-                               nconv, 0, N, st)) {
+                               pz, nconv, 0, N, st)) {
       // (batched: direct VALU convolution)
+    } else if (pz != np) {
+      return fail(SDFR_E_INVALID, "sdfr_decoder_backward_latent: padded rows without the direct convolution (internal)");
     } else {
       const sdfr_decoder::ZPlan& zp = d->bwd_z[l];
       const int split = use_split_k(false, (nconv * nconv * nconv + 15) / 16, (ci_n + 15) / 16, N, kpad);
@@ -1920,7 +1947,8 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
       const bool fuse = l > 0 && !d->conv_swap[l - 1] && out_n[l - 1] == prev && d->conv_cout[l - 1] == ci_n;
       if (fuse) {
         resize_backward(ci_n, prev, nin, d->conv_k[l - 1] - 1,
-                        d->conv_relu[l - 1] ? tape + (size_t)N * d->tape_conv_off[l - 1] : nullptr);
+                        d->conv_relu[l - 1] ? tape + (size_t)N * d->tape_conv_off[l - 1] : nullptr, nullptr, 0,
+                        pitch_of(l - 1));
         padded = true;
       } else {
         resize_backward(ci_n, prev, nin);
