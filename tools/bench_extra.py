@@ -398,7 +398,7 @@ def c5_config(hbm_peak):
             "final_position_error_mm": round(float((out[0] - sc["p_true"]).norm()) * 1e3, 3),
             "final_orientation_error_deg": round(float(np.degrees(2 * np.arccos(dot))), 3),
             "final_scale_error_rel": round(float(abs(out[2] - sc["s_true"]) / sc["s_true"]), 4),
-            "roofline": {"bound": "launch latency (about 26 dependent launches); HBM figure for reference",
+            "roofline": {"bound": "launch latency (22 dependent launches); HBM figure for reference",
                          "bytes_per_iteration": bytes_it, "achieved": round(bytes_it / (ms * 1e-3) / 1e9, 2),
                          "unit": "GB/s", "frac": round(bytes_it / (ms * 1e-3) / hbm_peak, 6)}}
 
@@ -419,11 +419,16 @@ def extra_configs(sdf_np, dev, hbm_peak):
     return out
 
 
+RENDER_SOURCES = ("render.hip", "device.hpp", "common.hpp", "tuning.hpp")
+
+
 def kernel_sources_sha():
-    """sha256 over the kernel sources (sdfest_amd/csrc): ties committed counter profiles to a build."""
+    """sha256 over the sources of the render kernels (the ones the committed counter profile is about): ties
+    profiles/pmc_traffic.json to a build.  The decoder / loop / init-network sources do not enter: they changed
+    several times in round 3 without touching a render kernel."""
     import hashlib
     h = hashlib.sha256()
-    for p in sorted(glob.glob(os.path.join(ROOT, "sdfest_amd", "csrc", "*"))):
+    for p in sorted(os.path.join(ROOT, "sdfest_amd", "csrc", f) for f in RENDER_SOURCES):
         if os.path.isfile(p):
             h.update(os.path.basename(p).encode())
             h.update(open(p, "rb").read())
