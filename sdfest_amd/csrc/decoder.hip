@@ -1713,9 +1713,10 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
       }
     }
     // (n_in <= n_out: the z pass writes a row's n_in results over the row's own n_out sources)
-    if (!few && g_tiled_resize_vjp.load(std::memory_order_relaxed) && (!mix_w || (C == 1 && pad >= 0)) && n_in <= 64 &&
+    // (single latents too: one launch of ~9 us instead of two of 6 + 5 in the captured loop, C5 0.144 -> 0.1375 ms)
+    if (g_tiled_resize_vjp.load(std::memory_order_relaxed) && (!mix_w || (C == 1 && pad >= 0)) && n_in <= 64 &&
         n_in <= n_out && n_out <= 1024 && nc < (1u << 24)) {
-      // batches: the three passes in one launch on an LDS-staged block (resize3_backward_tiled_kernel)
+      // the three passes in one launch on an LDS-staged block (resize3_backward_tiled_kernel)
       const float ratio = (float)n_in / (float)n_out;
       auto weight = [&](int dd, int i) {   // resize_weight on the host, same float arithmetic
         float sp = fmaf(ratio, (float)dd + 0.5f, -0.5f);

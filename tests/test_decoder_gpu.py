@@ -296,7 +296,8 @@ def _random_state(rng, case):
 def test_tiled_transposed_resize_is_bitwise_the_three_launches(mug):
     """Batched VJP: each transposed resize as ONE launch on an LDS-staged block (channel loop, register prefetch, fused
     mask / padding / swapped 1x1 layer) against the three single-axis launches (+ conv1x1 + pad_mask) it replaces --
-    the same fmaf chains in the same order, so the latent gradients must agree bit for bit.  Shapes: the mug decoder
+    the same fmaf chains in the same order, so the latent gradients must agree bit for bit (single latents, whose
+    captured loop takes the one-launch form too, included).  Shapes: the mug decoder
     (ratios 64/30, 32/14, 16/6; padded + masked, and the swapped last layer), up- and DOWN-sizing resizes, a coarse
     size that leaves a one-column tile, a channel count that is not a multiple of 8, 2 ... 4 mixed channels."""
     from sdfest_amd import SDFDecoder
@@ -304,7 +305,7 @@ def test_tiled_transposed_resize_is_bitwise_the_three_launches(mug):
     L = lib()
     d, wts = mug
     rng = np.random.default_rng(5)
-    cases = [("mug", mug_config(d), wts, 64, 8, 70)]
+    cases = [("mug", mug_config(d), wts, 64, 8, 70), ("mug", mug_config(d), wts, 64, 8, 1), ("mug", mug_config(d), wts, 64, 8, 3)]
     extra = [
         dict(volume=32, latent=4, batch=80, fc=[{"out": 3 * 6 ** 3}],
              conv=[dict(in_size=6, in_channels=3, out_channels=5, kernel_size=3, relu=True),      # -> 4
@@ -338,4 +339,4 @@ def test_tiled_transposed_resize_is_bitwise_the_three_launches(mug):
             finally:
                 L.sdfr_debug_set_decoder_tiled_vjp(old)
         assert torch.isfinite(grads[0]).all() and grads[0].abs().max() > 0, name
-        assert torch.equal(grads[0], grads[1]), (name, (grads[0] - grads[1]).abs().max().item())
+        assert torch.equal(grads[0], grads[1]), (name, N, (grads[0] - grads[1]).abs().max().item())

@@ -14,7 +14,7 @@ for f in glob.glob("$OUT/trace/**/*kernel_trace.csv", recursive=True):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
                      int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])))
 rows.sort()
-ends = [i for i, r in enumerate(rows) if "adam_step_kernel" in r[2]]
+ends = [i for i, r in enumerate(rows) if "adam_step_kernel" in r[2] or "loop_tail_kernel" in r[2]]
 a, b = ends[-2] + 1, ends[-1] + 1
 print("| # | kernel | threads | duration us | gap before us |\n|---|---|---|---|---|")
 tot = gap = 0.0
