@@ -113,6 +113,61 @@ __global__ __launch_bounds__(kFcBlock) void fc_stack_kernel(const float* __restr
   }
 }
 
+// The same stack for batches: a workgroup takes S samples and 256 outputs of the last layer.  The per-sample form
+// above walks four dependent round trips (z -> w0 -> w1 -> wt) per 256 outputs of ONE sample: 8192 workgroups, 36 us
+// per 256 mug latents, all of it latency.  Here the hidden layers of S samples are formed together and every weight
+// of the last layer is loaded once per S samples (the activations come from LDS as broadcasts, [unit][sample]):
+// the same fmaf chains (bias first, inputs in ascending order), so bit-identical to the per-sample form.
+// grid (ceil(out_last / 256), ceil(N / S));  LDS: 2 * hid * S floats, hid = widest layer input
+template <int S>
+__global__ __launch_bounds__(kFcBlock) void fc_stack_batch_kernel(const float* __restrict__ params, FcDesc d,
+                                                                  const float* __restrict__ z, int N, int hid,
+                                                                  float* __restrict__ out) {
+  extern __shared__ float fc_act[];   // [2][hid][S]
+  const int tid = threadIdx.x, n0 = blockIdx.y * S, ns = min(S, N - n0);
+  float* cur = fc_act;
+  float* nxt = fc_act + (size_t)hid * S;
+  {
+    const int w0 = d.width[0];
+    for (int e = tid; e < S * w0; e += kFcBlock) {
+      const int i = e / S, sm = e - i * S;
+      cur[e] = sm < ns ? z[(size_t)(n0 + sm) * w0 + i] : 0.0f;
+    }
+  }
+  __syncthreads();
+  for (int l = 0; l < d.n_fc - 1; ++l) {
+    const int win = d.width[l], wout = d.width[l + 1];
+    const float* w = params + d.w_off[l];
+    const float* b = params + d.b_off[l];
+    for (int e = tid; e < S * wout; e += kFcBlock) {
+      const int o = e / S, sm = e - o * S;
+      float acc = b[o];
+      for (int i = 0; i < win; ++i) acc = fmaf(w[(size_t)o * win + i], cur[i * S + sm], acc);
+      nxt[e] = fmaxf(acc, 0.0f);
+    }
+    __syncthreads();
+    float* t = cur; cur = nxt; nxt = t;
+  }
+  const int l = d.n_fc - 1, win = d.width[l], wout = d.width[l + 1];
+  const int o = blockIdx.x * kFcBlock + tid;
+  if (o < wout) {
+    const float* wt = params + d.w_off[l];  // transposed: [in][out]
+    float acc[S];
+    const float b = params[d.b_off[l] + o];
+#pragma unroll
+    for (int sm = 0; sm < S; ++sm) acc[sm] = b;
+#pragma unroll 4
+    for (int i = 0; i < win; ++i) {
+      const float w = wt[(size_t)i * wout + o];
+#pragma unroll
+      for (int sm = 0; sm < S; ++sm) acc[sm] = fmaf(w, cur[i * S + sm], acc[sm]);
+    }
+#pragma unroll
+    for (int sm = 0; sm < S; ++sm)
+      if (sm < ns) out[(size_t)(n0 + sm) * wout + o] = fmaxf(acc[sm], 0.0f);
+  }
+}
+
 // trilinear resize, ATen upsample_trilinear3d semantics with align_corners=False:
 //   src = max(ratio * (dst + 0.5) - 0.5, 0), ratio = float(in) / out; i0 = int(src);
 //   i1 = i0 + (i0 < in - 1); l1 = src - i0; l0 = 1 - l1
@@ -1105,6 +1160,75 @@ __global__ __launch_bounds__(kFcBlock) void fc_last_backward_kernel(const float*
   }
 }
 
+// The same for batches: a workgroup takes IB input units x S samples, so that a sample's g / act row is read once per
+// IB units and a weight row once per S samples (20.8 instead of 96 KB per (unit, sample) pair at 5 x 4).  Every pair
+// keeps the per-sample form's thread -> column map, four partial sums and reduction tree: bit-identical to it.
+// 16-byte form only (wout % 4 == 0, aligned: host).   grid (ceil(win / IB), ceil(N / S))
+template <int IB, int S>
+__global__ __launch_bounds__(kFcBlock) void fc_last_backward_batch_kernel(const float* __restrict__ params, FcDesc d,
+                                                                          const float* __restrict__ g_last,
+                                                                          const float* __restrict__ act, int N,
+                                                                          float* __restrict__ t_out) {
+  __shared__ float red[IB * S][kFcBlock / 64];
+  const int i0 = blockIdx.x * IB, n0 = blockIdx.y * S, tid = threadIdx.x;
+  const int l = d.n_fc - 1, win = d.width[l], wout = d.width[l + 1];
+  const float4* w4[IB];
+  const float4 *g4[S], *a4[S];
+#pragma unroll
+  for (int k = 0; k < IB; ++k) w4[k] = reinterpret_cast<const float4*>(params + d.w_off[l] + (size_t)min(i0 + k, win - 1) * wout);
+#pragma unroll
+  for (int sm = 0; sm < S; ++sm) {
+    g4[sm] = reinterpret_cast<const float4*>(g_last + (size_t)min(n0 + sm, N - 1) * wout);
+    a4[sm] = reinterpret_cast<const float4*>(act + (size_t)min(n0 + sm, N - 1) * wout);
+  }
+  float p[IB][S][4];
+#pragma unroll
+  for (int k = 0; k < IB; ++k)
+#pragma unroll
+    for (int sm = 0; sm < S; ++sm)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) p[k][sm][c] = 0.0f;
+#pragma unroll 2
+  for (int o = tid; o < wout / 4; o += kFcBlock) {
+    float4 m[S];
+#pragma unroll
+    for (int sm = 0; sm < S; ++sm) {
+      const float4 gv = g4[sm][o], av = a4[sm][o];
+      m[sm] = float4{(av.x > 0.0f) ? gv.x : 0.0f, (av.y > 0.0f) ? gv.y : 0.0f, (av.z > 0.0f) ? gv.z : 0.0f,
+                     (av.w > 0.0f) ? gv.w : 0.0f};
+    }
+#pragma unroll
+    for (int k = 0; k < IB; ++k) {
+      const float4 w = w4[k][o];
+#pragma unroll
+      for (int sm = 0; sm < S; ++sm) {
+        p[k][sm][0] = fmaf(w.x, m[sm].x, p[k][sm][0]);
+        p[k][sm][1] = fmaf(w.y, m[sm].y, p[k][sm][1]);
+        p[k][sm][2] = fmaf(w.z, m[sm].z, p[k][sm][2]);
+        p[k][sm][3] = fmaf(w.w, m[sm].w, p[k][sm][3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < IB; ++k)
+#pragma unroll
+    for (int sm = 0; sm < S; ++sm) {
+      float part = (p[k][sm][0] + p[k][sm][1]) + (p[k][sm][2] + p[k][sm][3]);
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+      if ((tid & 63) == 0) red[k * S + sm][tid >> 6] = part;
+    }
+  __syncthreads();
+  if (tid < IB * S) {
+    const int k = tid / S, sm = tid - k * S;
+    if (i0 + k < win && n0 + sm < N) {
+      float t = 0.0f;
+      for (int q = 0; q < kFcBlock / 64; ++q) t += red[tid][q];
+      t_out[(size_t)(n0 + sm) * win + i0 + k] = t;
+    }
+  }
+}
+
 // Backward of the small leading layers, one workgroup per sample: t (gradient w.r.t. the input of
 // the last layer, not yet ReLU-masked) -> g_z.  Hidden activations are recomputed in LDS.
 __global__ __launch_bounds__(kFcBlock) void fc_stack_backward_kernel(const float* __restrict__ params,
@@ -1526,8 +1650,17 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
   const float* act_in;
   {
     float* fc_dst = tape ? tape + (size_t)N * d->tape_fc_off : buf[cur];
-    hipLaunchKernelGGL(fc_stack_kernel, dim3((last + kFcBlock - 1) / kFcBlock, N), dim3(kFcBlock), 0, st,
-                       d->d_params, fd, z, fc_dst);
+    int hid = d->latent;   // widest input of a layer
+    for (int l = 0; l + 1 < d->n_fc; ++l) hid = std::max(hid, d->fc_out[l]);
+    constexpr int kFcSamples = 8;
+    const size_t fc_lds = 2 * (size_t)hid * kFcSamples * sizeof(float);
+    if (N >= 4 * kFcSamples && fc_lds <= 48 * 1024)   // batches (small ones keep the form of a single decode)
+      hipLaunchKernelGGL((fc_stack_batch_kernel<kFcSamples>),
+                         dim3((last + kFcBlock - 1) / kFcBlock, (N + kFcSamples - 1) / kFcSamples), dim3(kFcBlock),
+                         fc_lds, st, d->d_params, fd, z, N, hid, fc_dst);
+    else
+      hipLaunchKernelGGL(fc_stack_kernel, dim3((last + kFcBlock - 1) / kFcBlock, N), dim3(kFcBlock), 0, st,
+                         d->d_params, fd, z, fc_dst);
     act_in = fc_dst;
   }
 
@@ -1972,8 +2105,18 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
   // g == buf[cur ^ 1] here (every step above ends with g = buf[cur]; cur ^= 1): the transposed wide layer
   // must write the FREE buffer -- other workgroups still read g while this one stores.
   float* t_mid = buf[cur];
-  hipLaunchKernelGGL(fc_last_backward_kernel, dim3(fd.width[d->n_fc - 1], N), dim3(kFcBlock), 0, st,
-                     d->d_params, fd, g, tape + (size_t)N * d->tape_fc_off, t_mid);
+  {
+    const int win = fd.width[d->n_fc - 1], wout = fd.width[d->n_fc];
+    const float* act_fc = tape + (size_t)N * d->tape_fc_off;
+    const float* wl = d->d_params + fd.w_off[d->n_fc - 1];
+    constexpr int kIb = 5, kSb = 4;
+    if (N >= 32 && (wout & 3) == 0 && (((uintptr_t)wl | (uintptr_t)g | (uintptr_t)act_fc) & 15) == 0)   // batches
+      hipLaunchKernelGGL((fc_last_backward_batch_kernel<kIb, kSb>), dim3((win + kIb - 1) / kIb, (N + kSb - 1) / kSb),
+                         dim3(kFcBlock), 0, st, d->d_params, fd, g, act_fc, N, t_mid);
+    else
+      hipLaunchKernelGGL(fc_last_backward_kernel, dim3(win, N), dim3(kFcBlock), 0, st, d->d_params, fd, g, act_fc,
+                         t_mid);
+  }
   hipLaunchKernelGGL(fc_stack_backward_kernel, dim3(N), dim3(kFcBlock), 0, st, d->d_params, fd, z, t_mid, g_z);
   SDFR_HIP_TRY(hipGetLastError());
   (void)n;
