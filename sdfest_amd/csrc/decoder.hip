@@ -476,6 +476,12 @@ __device__ __forceinline__ void stage_to_lds(float* __restrict__ dst, const floa
 // (An LDS-staged variant -- input patch of a 4 x 4 column tile in LDS, operands from ds_read --
 // was built and measured on the same layer: 772 us vs 860 us for the plain gather kernel; patch
 // load 319 + MFMA 220 + stores 58 + staging 120, serialised by 2 workgroups per CU.  Not kept.)
+// RESIDENT (batches of small layers, e.g. 16 x 8^3 -> 16 x 6^3: 14 tiles per sample): one workgroup per (sample,
+// column tile) stages the sample's whole input in LDS beside the weights and walks over all of the sample's tiles, the
+// A operands read from LDS.  The plain form staged 27 KB of weights per FOUR tiles and gathered every A operand from
+// global memory: 27.6 us per 256 mug latents where the MFMAs need 5; RESIDENT: see DESIGN 9.5.  Same MFMA sequence
+// per tile: bit-identical.   grid: (1, co_tiles, N);  LDS: kpad * 17 + Cin * n^3 floats (Cin * n^3 % 4 == 0, aligned: host)
+template <bool RESIDENT>
 __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
     const float* __restrict__ in, const float* __restrict__ wmat, const int* __restrict__ taps,
     const float* __restrict__ bias, float* __restrict__ out, int Cin, int Cout, int n, int m,
@@ -484,11 +490,13 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
   float* w_l = lds;                                       // [kpad][16]
   int* tap_l = reinterpret_cast<int*>(lds + (size_t)kpad * 16);  // [kpad]
   float* red = lds + (size_t)kpad * 17;                   // split_k: [4 waves][64 lanes][4]
+  float* in_l = lds + (size_t)kpad * 17;                  // RESIDENT (never with split_k): [Cin][n][n][n]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int co_tile = blockIdx.y, nb = blockIdx.z;
   const float* wsrc = wmat + (size_t)co_tile * kpad * 16;
   stage_to_lds(w_l, wsrc, kpad * 16, tid);
   stage_to_lds(reinterpret_cast<float*>(tap_l), reinterpret_cast<const float*>(taps), kpad, tid);
+  if (RESIDENT) stage_to_lds(in_l, in + (size_t)nb * Cin * n * n * n, Cin * n * n * n, tid);
   __syncthreads();
 
   const int zgn = m / zg, mrows = m * m * zgn;  // positions: (x, y, z-group), z-group fastest
@@ -546,6 +554,60 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
       float v = ((a0[r] + a1[r]) + (a2[r] + a3[r])) + bv;
       if (relu) v = fmaxf(v, 0.0f);
       dst[(size_t)pxy * m + pg * zg] = v;
+    }
+    return;
+  }
+  if (RESIDENT) {
+    // two tiles per wave and pass: two independent accumulator chains (a wave alone on its SIMD otherwise waits out
+    // every MFMA's latency), the weight operand read once for both
+    for (int t = wave; t < n_tiles; t += 8) {
+      const int t1 = t + 4;
+      const float* base[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int pos = min((q ? t1 : t) * 16 + row, mrows - 1);
+        const int xy = pos / zgn, g = pos - xy * zgn, x = xy / m, y = xy - x * m;
+        base[q] = in_l + ((size_t)x * n + y) * n + g * zg;
+      }
+      f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
+      // (fetching the next group of operands while this group's MFMAs run -- written out as a two-stage loop -- was
+      // measured: 19.4 -> 23.8 us; the compiler's waits serialise it)
+      int kk0 = 0;
+      for (; kk0 + 16 <= kpad; kk0 += 16) {
+        float a0[4], a1[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int kk = kk0 + 4 * u + kq, tp = tap_l[kk];
+          a0[u] = base[0][tp];
+          a1[u] = base[1][tp];
+          b[u] = w_l[kk * 16 + row];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], b[u], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], b[u], acc1, 0, 0, 0);
+        }
+      }
+      for (; kk0 < kpad; kk0 += 4) {
+        const int kk = kk0 + kq, tp = tap_l[kk];
+        const float b = w_l[kk * 16 + row];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(base[0][tp], b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(base[1][tp], b, acc1, 0, 0, 0);
+      }
+      if (col_ok) {
+        float* dst = out + ((size_t)nb * Cout + co) * mv + dz;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int p = (q ? t1 : t) * 16 + kq * 4 + r;
+            if (p >= mrows) continue;
+            const int pxy = p / zgn, pg = p - pxy * zgn;
+            float v = (q ? acc1[r] : acc0[r]) + bv;
+            if (relu) v = fmaxf(v, 0.0f);
+            dst[(size_t)pxy * m + pg * zg] = v;
+          }
+      }
     }
     return;
   }
@@ -1329,6 +1391,28 @@ int use_split_k(bool zgrp, int n_tiles, int co_tiles, int N, int kpad) {
 
 // The direct convolution is for batches (enough tiles to fill the chip); returns false when the
 // layer / batch does not qualify and the caller falls back to the MFMA kernel.
+// conv3d_mfma_kernel in the form the layer / batch takes (plain, z-grouped, split-K, input resident in LDS)
+void launch_mfma(const float* src, const float* w, const int* tab, const float* bias, float* dst, int cin, int cout,
+                 int n, int m, int kp, int relu, int nt, int co_tiles, int zg, int split, int N, hipStream_t st) {
+  const int tw = nt >= 32768 ? 4 : 1;
+  const size_t in_floats = (size_t)cin * n * n * n, lds_res = ((size_t)kp * 17 + in_floats) * sizeof(float);
+  // (resident: the whole grid is then N * co_tiles workgroups -- only where that still fills the chip)
+  const bool resident = !split && zg == 1 && N * co_tiles >= 128 && nt >= 8 && nt <= 64 && lds_res <= 120 * 1024 &&
+                        (in_floats & 3) == 0 && ((uintptr_t)src & 15) == 0;
+  if (resident) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_mfma_kernel<true>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    if (attr == hipSuccess) {
+      hipLaunchKernelGGL(conv3d_mfma_kernel<true>, dim3(1, co_tiles, N), dim3(256), lds_res, st, src, w, tab, bias, dst,
+                         cin, cout, n, m, kp, relu, 1, 1, 0);
+      return;
+    }
+  }
+  hipLaunchKernelGGL(conv3d_mfma_kernel<false>, dim3(split ? nt : (nt + 4 * tw - 1) / (4 * tw), co_tiles, N), dim3(256),
+                     (size_t)kp * 17 * sizeof(float) + (split ? 4096 : 0), st, src, w, tab, bias, dst, cin, cout, n, m,
+                     kp, relu, tw, zg, split);
+}
+
 // Does a layer / batch qualify for it?  (n: input size, m: output size)
 bool direct_ok(size_t w_off, int n, int m, int N, int* tx = nullptr, int* ty = nullptr) {
   if (w_off == 0 || n > 64 || m < 4) return false;
@@ -1798,13 +1882,10 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
       const int split = use_split_k(false, (m * m * m + 15) / 16, (co_n + 15) / 16, N, kpad);
       const bool zgrp = !split && zp.zg > 1 && !swap && (long long)m * m * (m / zp.zg) * N >= kZGroupMinRows;
       const int kp = zgrp ? zp.kpad : kpad, rows = m * m * (m / (zgrp ? zp.zg : 1));
-      const int nt = (rows + 15) / 16, tw = nt >= 32768 ? 4 : 1;
-      hipLaunchKernelGGL(conv3d_mfma_kernel,
-                         dim3(split ? nt : (nt + 4 * tw - 1) / (4 * tw), zgrp ? 1 : (co_n + 15) / 16, N),
-                         dim3(256), (size_t)kp * 17 * sizeof(float) + (split ? 4096 : 0), st, act_in,
-                         zgrp ? d->d_params + zp.w_off : wm,
-                         reinterpret_cast<const int*>(d->d_params + (zgrp ? zp.tab_off : d->conv_tab_off[l])),
-                         bs, conv_dst, c, co_n, n, m, kp, conv_relu, tw, zgrp ? zp.zg : 1, split);
+      const int nt = (rows + 15) / 16;
+      launch_mfma(act_in, zgrp ? d->d_params + zp.w_off : wm,
+                  reinterpret_cast<const int*>(d->d_params + (zgrp ? zp.tab_off : d->conv_tab_off[l])), bs, conv_dst, c,
+                  co_n, n, m, kp, conv_relu, nt, zgrp ? 1 : (co_n + 15) / 16, zgrp ? zp.zg : 1, split, N, st);
     }
     if (conv_dst == buf[cur ^ 1]) cur ^= 1;
     act_in = conv_dst;
@@ -2106,14 +2187,11 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
       const bool zgrp = !split && zp.zg > 1 && !swap &&
                         (long long)nconv * nconv * (nconv / zp.zg) * N >= kZGroupMinRows;
       const int kp = zgrp ? zp.kpad : kpad, rows = nconv * nconv * (nconv / (zgrp ? zp.zg : 1));
-      const int nt = (rows + 15) / 16, tw = nt >= 32768 ? 4 : 1;
-      hipLaunchKernelGGL(conv3d_mfma_kernel,
-                         dim3(split ? nt : (nt + 4 * tw - 1) / (4 * tw), zgrp ? 1 : (ci_n + 15) / 16, N),
-                         dim3(256), (size_t)kp * 17 * sizeof(float) + (split ? 4096 : 0), st, g,
-                         d->d_params + (zgrp ? zp.w_off : d->bwd_w_off[l]),
-                         reinterpret_cast<const int*>(d->d_params + (zgrp ? zp.tab_off : d->bwd_tab_off[l])),
-                         d->d_params + d->zero_bias_off, buf[cur], co_n, ci_n, np, nconv, kp, 0, tw,
-                         zgrp ? zp.zg : 1, split);
+      const int nt = (rows + 15) / 16;
+      launch_mfma(g, d->d_params + (zgrp ? zp.w_off : d->bwd_w_off[l]),
+                  reinterpret_cast<const int*>(d->d_params + (zgrp ? zp.tab_off : d->bwd_tab_off[l])),
+                  d->d_params + d->zero_bias_off, buf[cur], co_n, ci_n, np, nconv, kp, 0, nt,
+                  zgrp ? 1 : (ci_n + 15) / 16, zgrp ? zp.zg : 1, split, N, st);
     }
     g = buf[cur];
     cur ^= 1;
