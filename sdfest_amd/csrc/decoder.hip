@@ -1009,15 +1009,6 @@ __global__ __launch_bounds__(256) void resize_x_backward_pad_kernel(const float*
 // round-robin, so all tiles of a channel (whose fine blocks overlap by the taps' reach) run on ONE XCD, at the same
 // time, and the overlap is served by that XCD's L2.  Slot s takes channels s, s + slots, ...
 // LDS: max_f^2 * no + max_f * tc * ni floats (+ tables).
-#ifndef SDFR_BT_LOADS
-#define SDFR_BT_LOADS 4
-#endif
-#ifndef SDFR_BT_OUT
-#define SDFR_BT_OUT 3
-#endif
-#ifndef SDFR_BT_SKIP
-#define SDFR_BT_SKIP 0   // (timing experiments: leave phases out)
-#endif
 constexpr int kBtTaps = 12, kBtLoads = SDFR_BT_LOADS, kBtOut = SDFR_BT_OUT, kBtMaxTile = 16, kBtMaxThreads = 1024;
 // exact range of fine indices d that carry weight on coarse index i (empty: d0 > d1)
 __device__ __forceinline__ void resize_sources_exact(int i, float ratio, int n_in, int n_out, int& d0, int& d1) {
@@ -1136,20 +1127,20 @@ __global__ __launch_bounds__(kBtMaxThreads) void resize3_backward_tiled_kernel(
     __syncthreads();
     // this channel's mask values, then the next channel's block: both in flight during this channel's passes
     float mask[kBtOut][CO];
-    if (!(SDFR_BT_SKIP & 16) && act) {
+    if (act) {
 #pragma unroll
       for (int j = 0; j < kBtOut; ++j)
 #pragma unroll
         for (int co = 0; co < CO; ++co)
           mask[j][co] = (nthr * j < n_store && st_a[j] >= 0) ? act[((size_t)o * CO + co) * coarse_vol + st_a[j]] : 0.0f;
     }
-    if (!(SDFR_BT_SKIP & 8) && o + slots < nc) {
+    if (o + slots < nc) {
       const float* src = g_out + (size_t)(o + slots) * fine_vol;
 #pragma unroll
       for (int j = 0; j < kBtLoads; ++j)
         if (nthr * j < total4) pre[j] = *reinterpret_cast<const f32x4*>(src + off[j]);
     }
-    if (!(SDFR_BT_SKIP & 1)) {   // z pass, in place
+    {   // z pass, in place
       const int rows = fnx * fny;
       for (int row = wave * spw + slot; row < rows; row += nw * spw) {
         const float* f = F + row * n_out;
@@ -1163,7 +1154,7 @@ __global__ __launch_bounds__(kBtMaxThreads) void resize3_backward_tiled_kernel(
       }
     }
     __syncthreads();
-    if (!(SDFR_BT_SKIP & 2)) {   // y pass: pairs (fx, jy), jy fastest
+    {   // y pass: pairs (fx, jy), jy fastest
       const int pairs = fnx * ncy;
       for (int pr = wave * spw + slot; pr < pairs; pr += nw * spw) {
         const int fx = div_by(pr, m_ncy), jy = pr - fx * ncy;
@@ -1185,7 +1176,7 @@ __global__ __launch_bounds__(kBtMaxThreads) void resize3_backward_tiled_kernel(
     // x pass, (mix,) mask, store: the tile's columns of the padded tensor, zeros in the padding
 #pragma unroll
     for (int j = 0; j < kBtOut; ++j) {
-      if ((SDFR_BT_SKIP & 4) || tid + nthr * j >= n_store) break;
+      if (tid + nthr * j >= n_store) break;
       float acc = 0.0f;
       const bool inside = st_a[j] >= 0;
       if (inside) {
@@ -2024,9 +2015,7 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
         waves_simd = it->second;
       }
       for (int tc = 2; aligned && tc <= std::min(kBtMaxTile, n_in); ++tc) {
-#ifdef SDFR_BT_FORCE_TC
-        if (tc != std::min(SDFR_BT_FORCE_TC, n_in)) continue;
-#endif
+        if (SDFR_BT_TILE > 0 && tc != std::min(SDFR_BT_TILE, n_in)) continue;
         int max_f = 1;
         for (int c0 = 0; c0 < n_in; c0 += tc) {
           int a0, a1, t;
@@ -2038,9 +2027,7 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
         const size_t lds = ((size_t)max_f * max_f * n_out + (size_t)max_f * tc * n_in) * sizeof(float);
         if (lds > 150 * 1024) continue;
         for (int threads = 256; threads <= kBtMaxThreads; threads *= 2) {
-#ifdef SDFR_BT_FORCE_THREADS
-          if (threads != SDFR_BT_FORCE_THREADS) continue;
-#endif
+          if (SDFR_BT_THREADS > 0 && threads != SDFR_BT_THREADS) continue;
           if ((size_t)max_f * max_f * (n_out >> 2) > (size_t)kBtLoads * threads) continue;
           const size_t oc = tiles == 1 ? n_in + 2 * padv : tc + padv;   // columns of the padded tensor a tile writes, per axis
           if (oc * oc * pz > (size_t)kBtOut * threads) continue;

@@ -51,3 +51,18 @@
 #ifndef SDFR_BWD_WAVES_PER_EU
 #define SDFR_BWD_WAVES_PER_EU 8
 #endif
+// decoder VJP, resize3_backward_tiled_kernel: 16-byte vectors a thread prefetches per channel, elements it stores per
+// channel (together ~100 VGPRs at 4 / 3: 1024 threads per workgroup), and tile edge / workgroup size forced for
+// timing (0: picked per resize from LDS and register occupancy)
+#ifndef SDFR_BT_LOADS
+#define SDFR_BT_LOADS 4
+#endif
+#ifndef SDFR_BT_OUT
+#define SDFR_BT_OUT 3
+#endif
+#ifndef SDFR_BT_TILE
+#define SDFR_BT_TILE 0
+#endif
+#ifndef SDFR_BT_THREADS
+#define SDFR_BT_THREADS 0
+#endif

@@ -15,7 +15,8 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 OVERRIDES = {"SDFR_MACRO_SX": "2", "SDFR_MACRO_SY": "1", "SDFR_FWD_SX": "4", "SDFR_FWD_SY": "1",
              "SDFR_BWD_MACRO_MIN": "8192", "SDFR_FWD_MACRO_MIN": "8192", "SDFR_FWD_WIDE": "0", "SDFR_FWD_WAVES": "4",
              "SDFR_BWD_BIG_MIN_RATIO": "2.4f", "SDFR_PACKED_MIN_VIEWS": "2", "SDFR_BWD_SLOTS": "256",
-             "SDFR_DENSE_CAP": "3072", "SDFR_BWD_WAVES_PER_EU": "0"}
+             "SDFR_DENSE_CAP": "3072", "SDFR_BWD_WAVES_PER_EU": "0", "SDFR_BT_LOADS": "6", "SDFR_BT_OUT": "4",
+             "SDFR_BT_TILE": "4", "SDFR_BT_THREADS": "512"}
 
 
 def test_every_tunable_is_listed_and_overridable():
@@ -33,7 +34,7 @@ def test_every_tunable_is_listed_and_overridable():
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_a_build_with_every_tunable_changed_compiles():
     flags = [f"-D{k}={v}" for k, v in OVERRIDES.items()]
-    for src in ("render.hip", "sampler.hip"):
+    for src in ("render.hip", "sampler.hip", "decoder.hip"):
         cmd = [HIPCC, "-O1", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-fsyntax-only",
                f"-I{os.path.join(ROOT, 'include')}", "-x", "hip", os.path.join(CSRC, src)] + flags
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
