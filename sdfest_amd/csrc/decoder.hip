@@ -665,27 +665,28 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
 template <int COUT, bool VEC4>
 __global__ __launch_bounds__(256) void conv3d_direct_kernel(
     const float* __restrict__ in, const float* __restrict__ wd, const float* __restrict__ bias,
-    float* __restrict__ out, int Cin, int n, int pz, int m, int relu, int TX, int TY, int CK) {
+    float* __restrict__ out, int Cin, int n, int pz, int m, int relu, int TX, int TY, int ZC, int CK) {
   // (pz: floats between z-rows of `in`, >= n -- the padded tensors of the backward pass have their rows 16 bytes apart)
   constexpr int K = 3, ZR = 4;
   constexpr int kUnrollB = COUT >= 8 ? 1 : K;  // keep a step's weights within the scalar registers
   extern __shared__ float tile[];  // [CK][IX][IY][np4]
   const int tid = threadIdx.x;
-  const int IX = TX + K - 1, IY = TY + K - 1, ZC = 256 / (TX * TY);
+  // ZC threads per column (a power of two), TX * TY <= 256 / ZC columns: threads beyond them only help to load
+  const int IX = TX + K - 1, IY = TY + K - 1;
   const int tiles_y = (m + TY - 1) / TY;
   const int tx0 = (blockIdx.x / tiles_y) * TX, ty0 = (blockIdx.x % tiles_y) * TY;
   const int nb = blockIdx.z;
   const size_t nv = (size_t)n * n * pz, mv = (size_t)m * m * m;
   const float* src = in + (size_t)nb * Cin * nv;
   const int col = tid / ZC, zc = tid - col * ZC;
-  const int lx = col / TY, ly = col - lx * TY, z0 = zc * ZR;
+  const int lx = col / TY, ly = col - lx * TY, z0 = col < TX * TY ? zc * ZR : m;   // (z0 = m: no outputs)
   float acc[ZR][COUT];
 #pragma unroll
   for (int z = 0; z < ZR; ++z)
 #pragma unroll
     for (int co = 0; co < COUT; ++co) acc[z][co] = 0.0f;
   const int run = IY * pz, y_valid = (n - ty0) * pz, np4 = (pz + 3) & ~3;   // np4: LDS row pitch
-  // VEC4: 16-byte loads -- every run starts and ends on a 16-byte boundary (n % 4 == 0; TY is even; host).
+  // VEC4: 16-byte loads -- every run starts and ends on a 16-byte boundary (rows pz % 4 == 0 floats apart; host).
   // 16-byte path: the patch of chunk i+1 is fetched into registers while chunk i is being
   // convolved (<= 6 loads per thread: a chunk is <= 24 KB), so a workgroup waits for memory once.
   // (Where each of a thread's <= 6 vectors of a chunk comes from does not depend on the chunk: channel within the
@@ -1405,26 +1406,35 @@ void launch_mfma(const float* src, const float* w, const int* tab, const float* 
 }
 
 // Does a layer / batch qualify for it?  (n: input size, m: output size)
-bool direct_ok(size_t w_off, int n, int m, int N, int* tx = nullptr, int* ty = nullptr) {
+bool direct_ok(size_t w_off, int n, int m, int N, int* tx = nullptr, int* ty = nullptr, int* zc = nullptr) {
   if (w_off == 0 || n > 64 || m < 4) return false;
   const int ZC = (m + 3) / 4;                       // z chunks of 4 outputs per column
   int zc_pow = 1;
   while (zc_pow < ZC) zc_pow <<= 1;                 // threads per column (power of two <= 16)
   if (zc_pow > 16) return false;
-  const int cols = 256 / zc_pow;                    // columns per workgroup
+  const int cols = 256 / zc_pow;                    // columns per workgroup, at most
+  // TX x TY <= cols columns per workgroup: the fewest tiles, then the smallest staged patch (30^3 outputs: 5 x 6
+  // columns cover them exactly in 30 tiles of 7 x 8 patch columns; the power-of-two 4 x 8 takes 32 tiles of 6 x 10)
   int TX = 1, TY = cols;
-  while (TY > 2 * TX) { TX <<= 1; TY >>= 1; }       // as square as powers of two allow
+  long long best = -1;
+  for (int a = 1; a <= std::min(cols, m); ++a) {
+    const int b = std::min(cols / a, m);
+    const long long tiles = (long long)((m + a - 1) / a) * ((m + b - 1) / b);
+    const long long cost = tiles * 4096 + (a + 2) * (b + 2);
+    if (best < 0 || cost < best) { best = cost; TX = a; TY = b; }
+  }
   const int tiles = ((m + TX - 1) / TX) * ((m + TY - 1) / TY);
   if ((long long)tiles * N < 512) return false;
   if (tx) *tx = TX;
   if (ty) *ty = TY;
+  if (zc) *zc = zc_pow;
   return true;
 }
 // pz: floats between the z-rows of src (n, or more: the padded tensors of the backward pass)
 bool launch_direct(const sdfr_decoder* d, size_t w_off, const float* src, const float* bias, float* dst,
                    int cin, int cout, int n, int pz, int m, int relu, int N, hipStream_t st) {
-  int TX, TY;
-  if (!direct_ok(w_off, n, m, N, &TX, &TY)) return false;
+  int TX, TY, ZC;
+  if (!direct_ok(w_off, n, m, N, &TX, &TY, &ZC)) return false;
   const int tiles = ((m + TX - 1) / TX) * ((m + TY - 1) / TY);
   // channels per LDS chunk: patch of CK channels <= 24 KB
   const int per_ch = (TX + 2) * (TY + 2) * ((pz + 3) & ~3);   // (LDS rows are padded to 16 bytes)
@@ -1437,9 +1447,9 @@ bool launch_direct(const sdfr_decoder* d, size_t w_off, const float* src, const 
   if (!vec4 && pz != n) return false;   // (the scalar-load form takes dense rows only; callers pad rows only to 16 bytes)
 #define SDFR_DIRECT(CO)                                                                                          \
   if (vec4) hipLaunchKernelGGL((conv3d_direct_kernel<CO, true>), grid, dim3(256), lds, st, src, w, bias, dst,   \
-                               cin, n, pz, m, relu, TX, TY, CK);                                                \
+                               cin, n, pz, m, relu, TX, TY, ZC, CK);                                            \
   else hipLaunchKernelGGL((conv3d_direct_kernel<CO, false>), grid, dim3(256), lds, st, src, w, bias, dst, cin,  \
-                          n, pz, m, relu, TX, TY, CK)
+                          n, pz, m, relu, TX, TY, ZC, CK)
   if (cout == 4) { SDFR_DIRECT(4); } else if (cout == 8) { SDFR_DIRECT(8); } else { SDFR_DIRECT(16); }
 #undef SDFR_DIRECT
   return true;
