@@ -103,9 +103,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------------
 // The march's sample: trilinear SDF value at a grid-space point, written for the VALU.
 //
-// rocprofv3 showed the forward kernel issuing VALU instructions in ~97 % of its SIMD cycles
-// (SQ_ACTIVE_INST_VALU x 4 vs. busy cycles): at 8 waves per SIMD the record loads are hidden and
-// the march is bound by its instruction count, 49 VALU per step.  This version does the same
+// In round 1 rocprofv3 showed the forward kernel issuing VALU instructions in ~97 % of its SIMD cycles
+// (SQ_ACTIVE_INST_VALU x 4 vs. busy cycles) at 49 VALU per step; with ~30 per step the VALU is now second to the
+// two gathers.  This version does the same
 // arithmetic, bit for bit (same floor/clamp, same (1-f)*a + f*b lerps in the order x, y, z), in
 // 2-wide packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 run two fp32 lanes per issue
 // slot on gfx950) and forms the record index in float (exact below 2^24) with a bit permute

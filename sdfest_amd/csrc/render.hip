@@ -524,9 +524,10 @@ __device__ __forceinline__ bool overlaps(const Rect& r, int px, int py, int w, i
 // forward.  grid = (macro-tiles x, macro-tiles y, views)
 // ---------------------------------------------------------------------------------------------
 // One ray per lane.  (K rays per lane -- K independent load chains to hide the gather latency --
-// was built and measured: slower at every K; the march is bound by its VALU
-// instruction count, so the loop below is written for that: packed fp32 in march_sample, and a
-// loop whose only per-step bookkeeping is two compares and one add.)
+// was built and measured in rounds 1 and 3: slower at every K, see DESIGN.md.  Where the march stands at the end of
+// round 3 (slopes): its two 16-byte gathers per step come first -- one more costs +34 us per 256 views,
+// 16 more VALU instructions +9 -- with the VALU at 70-85 % close behind; the loop below keeps both small: packed fp32
+// in march_sample, and per-step bookkeeping of two compares and one add.)
 //
 // LOSS: the masked depth-L1 of simple_setup.py:129-135 is folded in: a hit pixel
 // also reads the observed depth and the tile leaves (sum |est - obs|, count) over the overlap
