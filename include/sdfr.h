@@ -309,6 +309,12 @@ SDFR_API size_t sdfr_decoder_backward_workspace_bytes(const sdfr_decoder* decode
 SDFR_API int sdfr_decoder_backward_latent(const sdfr_decoder* decoder, const float* z, const float* tape,
                                  const float* grad_out, int N, float* g_z, void* workspace,
                                  size_t workspace_bytes, void* stream);
+/* The same for ONE latent without its last launch (the backward of the small leading Linear layers, one workgroup):
+ * *t_mid receives where, inside `workspace`, the gradient w.r.t. the wide layer's input lies; sdfr_loop_tail finishes
+ * the product rule in its own launch.  Nothing else may use the workspace in between. */
+SDFR_API int sdfr_decoder_backward_latent_deferred(const sdfr_decoder* decoder, const float* z, const float* tape,
+                                          const float* grad_out, void* workspace, size_t workspace_bytes,
+                                          void* stream, const float** t_mid);
 
 /* TEST HOOK: batches take the transposed resizes of the VJP in one launch each (an LDS-staged block per workgroup,
  * bit-identical to the three single-axis launches it replaces); 0 switches back to the three launches so that a
@@ -354,14 +360,16 @@ SDFR_API int sdfr_views_to_pose_grad_deferred(const float* orientation, const fl
  * already), and sdfr_pose_to_views for the NEXT iteration (pos_c / quat_c / inv_scale / scale_v are read by the
  * chain as this iteration's and then overwritten with the next one's).  Same arithmetic in the same order as the
  * four calls.  render_partials_offset: sdfr_render_partials_offset (the tile partials of a stand-alone or of a
- * step's backward). */
+ * step's backward).  decoder / decoder_t_mid (both or neither): the tail first runs the last stage of the decoder's
+ * VJP that sdfr_decoder_backward_latent_deferred left out -- grads[8..] = d/d latent from decoder_t_mid, the latent
+ * being params[8..] -- one launch less per iteration, same arithmetic. */
 SDFR_API int sdfr_loop_tail(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int* step, int n_params,
                    float lr_position, float lr_orientation, float lr_scale, float lr_latent, int update_latent,
                    const float* cam_pos, const float* cam_quat, int V, const void* render_workspace,
                    size_t render_partials_offset, int W, int H, const void* pc_workspace, const int* offsets,
                    int max_view_points, float* pos_c, float* quat_c, float* inv_scale, float* scale_v, float* pc_loss,
-                   const float* con_source, const float* con_target, float con_weight, float* con_loss, int device,
-                   void* stream);
+                   const float* con_source, const float* con_target, float con_weight, float* con_loss,
+                   const sdfr_decoder* decoder, const float* decoder_t_mid, int device, void* stream);
 
 /* sdfr_render_backward_l1 and sdfr_pc_l1_backward_accumulate of one loop iteration in ONE launch (they are
  * independent and neither fills the chip for a handful of views): arguments as in those two calls -- the per-view

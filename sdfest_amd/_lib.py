@@ -36,7 +36,7 @@ SIGNATURES = {
                                                 c_f, c_fp, c_fp, c_int, c_fp, c_fp, c_sz, c_int, c_fp]),
     "sdfr_loop_tail": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_f, c_f, c_f, c_f, c_int, c_fp, c_fp, c_int,
                                c_fp, c_sz, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
-                               c_f, c_fp, c_int, c_fp]),
+                               c_f, c_fp, c_fp, c_fp, c_int, c_fp]),
     "sdfr_render_fixed_volume_offset": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
     "sdfr_fixed_to_float": (c_int, [c_fp, c_sz, c_fp, c_int, c_fp]),
     "sdfr_render_forward": (c_int, [c_fp, c_int, c_ll, c_fp, c_fp, c_fp, c_int, c_int, c_int,
@@ -75,6 +75,7 @@ SIGNATURES = {
     "sdfr_decoder_forward": (c_int, [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_sz, c_fp]),
     "sdfr_decoder_backward_workspace_bytes": (c_sz, [c_fp, c_int]),
     "sdfr_decoder_backward_latent": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_sz, c_fp]),
+    "sdfr_decoder_backward_latent_deferred": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_fp, c_fp]),
     "sdfr_pose_to_views": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp]),
     "sdfr_views_to_pose_grad": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                         c_fp, c_fp, c_fp, c_int, c_fp]),

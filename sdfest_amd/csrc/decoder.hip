@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "decoder_fc.hpp"
 
 struct sdfr_decoder {
   int device;
@@ -70,18 +71,10 @@ struct sdfr_decoder {
 namespace sdfr {
 namespace {
 
-constexpr int kFcBlock = 256;
 constexpr long long kZGroupMinRows = 64 * 1024;  // z-grouped conv only when it still fills the chip
-constexpr int kMaxHidden = 2048;  // widest Linear layer other than the last
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct FcDesc {
-  int n_fc;
-  int width[9];         // width[0] = latent, width[l+1] = out of layer l
-  long long w_off[8];   // float offsets into params
-  long long b_off[8];
-};
 
 // grid (ceil(out_last / 256), N)
 __global__ __launch_bounds__(kFcBlock) void fc_stack_kernel(const float* __restrict__ params,
@@ -1319,51 +1312,15 @@ __global__ __launch_bounds__(kFcBlock) void fc_last_backward_batch_kernel(const 
   }
 }
 
-// Backward of the small leading layers, one workgroup per sample: t (gradient w.r.t. the input of
-// the last layer, not yet ReLU-masked) -> g_z.  Hidden activations are recomputed in LDS.
+// Backward of the small leading layers, one workgroup per sample (decoder_fc.hpp: fc_stack_backward_sample).
 __global__ __launch_bounds__(kFcBlock) void fc_stack_backward_kernel(const float* __restrict__ params,
                                                                      FcDesc d,
                                                                      const float* __restrict__ z,
                                                                      const float* __restrict__ t_in,
                                                                      float* __restrict__ g_z) {
-  __shared__ float act[8][kMaxHidden];   // act[l] = input of layer l (act[0] = z)
-  __shared__ float gbuf[2][kMaxHidden];
-  const int tid = threadIdx.x, n = blockIdx.x;
-  for (int i = tid; i < d.width[0]; i += kFcBlock) act[0][i] = z[(size_t)n * d.width[0] + i];
-  __syncthreads();
-  for (int l = 0; l < d.n_fc - 1; ++l) {
-    const int win = d.width[l], wout = d.width[l + 1];
-    const float* w = params + d.w_off[l];
-    const float* b = params + d.b_off[l];
-    for (int o = tid; o < wout; o += kFcBlock) {
-      float acc = b[o];
-      for (int i = 0; i < win; ++i) acc = fmaf(w[(size_t)o * win + i], act[l][i], acc);
-      act[l + 1][o] = fmaxf(acc, 0.0f);
-    }
-    __syncthreads();
-  }
-  int cur = 0;
-  {
-    const int l = d.n_fc - 1, win = d.width[l];
-    // ReLU' of the layer that produced act[l] (l >= 1); the latent itself has no ReLU
-    for (int i = tid; i < win; i += kFcBlock) {
-      const float t = t_in[(size_t)n * win + i];
-      gbuf[cur][i] = (l == 0 || act[l][i] > 0.0f) ? t : 0.0f;
-    }
-    __syncthreads();
-  }
-  for (int l = d.n_fc - 2; l >= 0; --l) {
-    const int win = d.width[l], wout = d.width[l + 1];
-    const float* w = params + d.w_off[l];  // [out][in]
-    for (int i = tid; i < win; i += kFcBlock) {
-      float t = 0.0f;
-      for (int o = 0; o < wout; ++o) t = fmaf(w[(size_t)o * win + i], gbuf[cur][o], t);
-      gbuf[cur ^ 1][i] = (l == 0 || act[l][i] > 0.0f) ? t : 0.0f;
-    }
-    __syncthreads();
-    cur ^= 1;
-  }
-  for (int i = tid; i < d.width[0]; i += kFcBlock) g_z[(size_t)n * d.width[0] + i] = gbuf[cur][i];
+  const int n = blockIdx.x, l = d.n_fc - 1;
+  fc_stack_backward_sample(params, d, z + (size_t)n * d.width[0], t_in + (size_t)n * d.width[l],
+                           g_z + (size_t)n * d.width[0]);
 }
 
 }  // namespace
@@ -1927,13 +1884,30 @@ extern "C" size_t sdfr_decoder_backward_workspace_bytes(const sdfr_decoder* d, i
   return 2 * (size_t)N * d->max_bwd * sizeof(float) + 512;
 }
 
-extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* z, const float* tape,
-                                            const float* grad_out, int N, float* g_z,
-                                            void* workspace, size_t workspace_bytes, void* stream) {
+namespace sdfr {
+void decoder_fc_desc(const sdfr_decoder* d, FcDesc* out, const float** d_params, size_t* tape_fc_off) {
+  out->n_fc = d->n_fc;
+  out->width[0] = d->latent;
+  for (int l = 0; l < d->n_fc; ++l) {
+    out->width[l + 1] = d->fc_out[l];
+    out->w_off[l] = (long long)d->fc_w_off[l];
+    out->b_off[l] = (long long)d->fc_b_off[l];
+  }
+  if (d_params) *d_params = d->d_params;
+  if (tape_fc_off) *tape_fc_off = d->tape_fc_off;
+}
+}  // namespace sdfr
+
+namespace {
+// t_mid_out != nullptr: the last launch (the small leading layers, fc_stack_backward_kernel) is left to the caller --
+// *t_mid_out is where the gradient w.r.t. the input of the wide layer lies ([N][width], inside the workspace).
+int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* tape, const float* grad_out, int N,
+                          float* g_z, void* workspace, size_t workspace_bytes, void* stream,
+                          const float** t_mid_out) {
   if (!d) return fail(SDFR_E_NULL, "sdfr_decoder_backward_latent: NULL decoder");
   if (N < 0 || N > 65535) return fail(SDFR_E_INVALID, "N=%d out of range", N);
   if (N == 0) return 0;
-  if (!z || !tape || !grad_out || !g_z || !workspace)
+  if (!z || !tape || !grad_out || (!g_z && !t_mid_out) || !workspace)
     return fail(SDFR_E_NULL, "sdfr_decoder_backward_latent: NULL pointer argument");
   if (workspace_bytes < sdfr_decoder_backward_workspace_bytes(d, N))
     return fail(SDFR_E_WORKSPACE, "sdfr_decoder_backward_latent: workspace %zu < %zu bytes",
@@ -2233,8 +2207,23 @@ extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* 
       hipLaunchKernelGGL(fc_last_backward_kernel, dim3(win, N), dim3(kFcBlock), 0, st, d->d_params, fd, g, act_fc,
                          t_mid);
   }
-  hipLaunchKernelGGL(fc_stack_backward_kernel, dim3(N), dim3(kFcBlock), 0, st, d->d_params, fd, z, t_mid, g_z);
+  if (t_mid_out) *t_mid_out = t_mid;
+  else hipLaunchKernelGGL(fc_stack_backward_kernel, dim3(N), dim3(kFcBlock), 0, st, d->d_params, fd, z, t_mid, g_z);
   SDFR_HIP_TRY(hipGetLastError());
   (void)n;
   return 0;
+}
+}  // namespace
+
+extern "C" int sdfr_decoder_backward_latent(const sdfr_decoder* d, const float* z, const float* tape,
+                                            const float* grad_out, int N, float* g_z,
+                                            void* workspace, size_t workspace_bytes, void* stream) {
+  return decoder_backward_impl(d, z, tape, grad_out, N, g_z, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int sdfr_decoder_backward_latent_deferred(const sdfr_decoder* d, const float* z, const float* tape,
+                                                     const float* grad_out, void* workspace, size_t workspace_bytes,
+                                                     void* stream, const float** t_mid) {
+  if (!t_mid) return fail(SDFR_E_NULL, "sdfr_decoder_backward_latent_deferred: NULL pointer argument");
+  return decoder_backward_impl(d, z, tape, grad_out, 1, nullptr, workspace, workspace_bytes, stream, t_mid);
 }

@@ -12,6 +12,7 @@
 //                 orientation / scale / latent;  :462 orientation /= |orientation|
 // and the reverse-mode chain of the first two items (what autograd does in the reference).
 #include "common.hpp"
+#include "decoder_fc.hpp"
 #include "device.hpp"
 
 namespace sdfr {
@@ -531,9 +532,15 @@ struct LoopTailArgs {
   const float* pc_part; const float* pc_loss_part; const int* offsets; int n_single, nblk;
   float* pos_c; float* quat_c; float* inv_scale; float* scale_v; float* pc_loss;
   const float* con_source; const float* con_target; float con_weight; float* con_loss;
+  const float* dec_params; const float* t_mid; FcDesc fc;   // t_mid != NULL: the decoder VJP's last stage runs here
 };
+static_assert(kFcBlock == 256, "the tail's workgroup runs the decoder's Linear-stack backward");
 __global__ __launch_bounds__(256) void loop_tail_kernel(LoopTailArgs a) {
   float* g = a.grads;
+  if (a.t_mid) {   // d loss / d latent (grads[8 ...]) from the gradient w.r.t. the wide Linear layer's input
+    fc_stack_backward_sample(a.dec_params, a.fc, a.params + 8, a.t_mid, g + 8);
+    __syncthreads();
+  }
   deferred_chain(a.params + 3, a.params + 7, a.cam_quat, a.V, a.setup, a.tile_part, a.W, a.H, a.ntx, a.nty, a.tile_w,
                  a.tile_h, a.stride, a.pc_part, a.pc_loss_part, a.offsets, a.n_single, a.nblk, a.quat_c, a.pc_loss, g,
                  g + 3, g + 7);
@@ -707,8 +714,10 @@ extern "C" int sdfr_loop_tail(float* params, float* grads, float* exp_avg, float
                               const void* pc_workspace, const int* offsets, int max_view_points, float* pos_c,
                               float* quat_c, float* inv_scale, float* scale_v, float* pc_loss,
                               const float* con_source, const float* con_target, float con_weight, float* con_loss,
-                              int device, void* stream) {
+                              const sdfr_decoder* decoder, const float* decoder_t_mid, int device, void* stream) {
   const char* fn = "sdfr_loop_tail";
+  if ((decoder != nullptr) != (decoder_t_mid != nullptr))
+    return fail(SDFR_E_NULL, "%s: decoder and decoder_t_mid go together", fn);
   if (V < 1 || V > kDeferredMaxViews) return fail(SDFR_E_INVALID, "%s: V=%d out of range [1,%d]", fn, V, kDeferredMaxViews);
   if (n_params < 8 || n_params > 256) return fail(SDFR_E_INVALID, "%s: n_params=%d out of range [8,256]", fn, n_params);
   if (!params || !grads || !exp_avg || !exp_avg_sq || !step || !cam_pos || !cam_quat || !pos_c || !quat_c ||
@@ -740,6 +749,13 @@ extern "C" int sdfr_loop_tail(float* params, float* grads, float* exp_avg, float
   a.offsets = offsets; a.n_single = max_view_points; a.nblk = nblk;
   a.pos_c = pos_c; a.quat_c = quat_c; a.inv_scale = inv_scale; a.scale_v = scale_v; a.pc_loss = pc_loss;
   a.con_source = con_source; a.con_target = con_target; a.con_weight = con_weight; a.con_loss = con_loss;
+  if (decoder) {
+    decoder_fc_desc(decoder, &a.fc, &a.dec_params, nullptr);
+    if (a.fc.width[0] != n_params - 8)
+      return fail(SDFR_E_INVALID, "%s: the decoder's latent has %d entries, the parameter vector %d", fn, a.fc.width[0],
+                  n_params - 8);
+    a.t_mid = decoder_t_mid;
+  }
   hipLaunchKernelGGL(loop_tail_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;

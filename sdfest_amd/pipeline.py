@@ -9,6 +9,7 @@ point-cloud sample for all views (and their two backward launches); the per-view
 Adam are a handful of torch ops on tiny tensors.  The initialisation network, logging,
 visualisation and mesh export of the reference are out of scope.
 """
+import ctypes
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -210,8 +211,10 @@ class FusedRenderAndCompare:
                  camera_orientations: Optional[torch.Tensor] = None,
                  shape_optimization: bool = True, device="cuda", fuse_depth_loss: bool = True,
                  point_constraint: Optional[Sequence] = None, track_inliers: Optional[bool] = None,
-                 merge_launches: bool = True):
+                 merge_launches: bool = True, graph_iterations: int = 5):
         """point_constraint: (source (3,), target (3,), weight), simple_setup.py:164-175.
+        graph_iterations: iterations per replayed hipGraph (a graph launch costs ~5-8 us between iterations; the
+        remainder of max_iterations and runs with ``history`` replay the one-iteration graph).
         merge_launches: the per-view reductions of both backward passes run inside the gradient chain's launch
         (``sdfr_views_to_pose_grad_deferred``, up to 64 views); False: one launch each.  Same numbers.
         track_inliers: run the inlier-ratio bookkeeping of :177-211 every iteration (two small launches);
@@ -222,6 +225,8 @@ class FusedRenderAndCompare:
         # point-cloud L1 inside the sampler's backward (sdfr_pc_l1_backward);
         # False: every loss is a kernel of its own between a forward and a backward.  Same results.
         self.fuse_depth_loss = bool(fuse_depth_loss)
+        self.graph_iterations = max(1, int(graph_iterations))
+        self.graph_many = None
         self.L = _lib.lib()
         self.check = _lib.check
         self.dec = decoder
@@ -339,10 +344,13 @@ class FusedRenderAndCompare:
             g_sdf = self.plan.backward_l1_pc(self.target, sdf, self.pos_c, self.quat_c, self.inv_scale,
                                              self.scale_v, self.points, self.offsets, self.max_pts, self.ws_pc,
                                              weight=self.cfg["depth_weight"], pc_weight=self.cfg["pc_weight"])
+            t_mid = None
             if self.shape_opt:
-                self.check(L.sdfr_decoder_backward_latent(self.dec._h, self.latent.data_ptr(), self.tape.data_ptr(),
-                                                          g_sdf.data_ptr(), 1, g + 32, self.ws_dec.data_ptr(),
-                                                          self.ws_dec.numel(), st), "sdfr_decoder_backward_latent")
+                # the VJP's last launch (one workgroup) runs inside the tail's launch
+                t_mid = ctypes.c_void_p()
+                self.check(L.sdfr_decoder_backward_latent_deferred(
+                    self.dec._h, self.latent.data_ptr(), self.tape.data_ptr(), g_sdf.data_ptr(), self.ws_dec.data_ptr(),
+                    self.ws_dec.numel(), st, ctypes.byref(t_mid)), "sdfr_decoder_backward_latent_deferred")
             con = self.pc_source is not None
             self.check(L.sdfr_loop_tail(
                 p, g, self.m.data_ptr(), self.v.data_ptr(), self.step.data_ptr(), 8 + self.Lz, 1e-3, 1e-2, 1e-3, 1e-2,
@@ -351,7 +359,8 @@ class FusedRenderAndCompare:
                 self.offsets.data_ptr(), self.max_pts, self.pos_c.data_ptr(), self.quat_c.data_ptr(),
                 self.inv_scale.data_ptr(), self.scale_v.data_ptr(), self.loss_pc.data_ptr(),
                 self.pc_source.data_ptr() if con else None, self.pc_target.data_ptr() if con else None,
-                self.pc_weight if con else 0.0, self.loss_con.data_ptr() if con else None, d, st), "sdfr_loop_tail")
+                self.pc_weight if con else 0.0, self.loss_con.data_ptr() if con else None,
+                self.dec._h if t_mid is not None else None, t_mid, d, st), "sdfr_loop_tail")
             self._inliers(L, p, d, st)
             return
         self._poses_to_views(st)
@@ -499,11 +508,21 @@ class FusedRenderAndCompare:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.iteration()
+            if self.graph_iterations > 1:
+                self.graph_many = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_many):
+                    for _ in range(self.graph_iterations):
+                        self.iteration()
             for t, c in zip(state, saved):
                 t.copy_(c)   # the capture itself does not execute, but keep the state explicit
             if self._tail_form():
                 self._poses_to_views(self._stream())   # the warm-up's tail left the poses of ITS updated parameters
-        for _ in range(n_iter):
+        done = 0
+        if use_graph and history is None and self.graph_many is not None:
+            for _ in range(n_iter // self.graph_iterations):
+                self.graph_many.replay()
+            done = n_iter - n_iter % self.graph_iterations
+        for _ in range(n_iter - done):
             if use_graph:
                 self.graph.replay()
             else:
