@@ -310,6 +310,18 @@ def test_graph_replays_are_repeatable_without_host_work_between_them(mug_decoder
         assert graph.step.item() == 20
         for a, b, tol in zip(out, ref, (2e-5, 2e-4, 2e-5, 5e-4)):
             assert torch.isfinite(a).all() and (a - b).abs().max().item() <= tol, (call, a, b)
+    # several iterations per replayed graph (graph_iterations, default 5) with a remainder: 7 = 5 + 2 x 1, and one
+    # iteration per graph, give the run of 7 eager iterations
+    cfg7 = dict(cfg, max_iterations=7)
+    ref7 = [t.clone() for t in FusedRenderAndCompare(dec, cam, cfg7, target[None].contiguous())(*args, use_graph=False)]
+    for per_graph in (5, 3, 1):
+        loop = FusedRenderAndCompare(dec, cam, cfg7, target[None].contiguous(), graph_iterations=per_graph)
+        for call in range(2):
+            out = loop(*args, use_graph=True)
+            torch.cuda.synchronize()
+            assert loop.step.item() == 7
+            for a, b, tol in zip(out, ref7, (2e-5, 2e-4, 2e-5, 5e-4)):
+                assert torch.isfinite(a).all() and (a - b).abs().max().item() <= tol, (per_graph, call, a, b)
 
 
 def test_empty_overlap_view_gives_nan_loss_and_finite_steps(mug_decoder):
