@@ -283,33 +283,43 @@ __global__ __launch_bounds__(256) void resize3_tiled_kernel(const float* __restr
   constexpr int P = 256 >> LOG_NO, PY = P < kResizeTile ? P : kResizeTile;   // distinct y per pass
   constexpr int XS = P / PY;                                                 // x handled side by side (P > 8)
   const int sub = tid >> LOG_NO, jy0 = sub % PY, jx0 = sub / PY;
-  float lxs[kResizeTile / XS];
+  static_assert(n_out % kResizeTile == 0, "tiles are whole: no bounds checks below");
+  float lxs[kResizeTile / XS], wxs[kResizeTile / XS];
   int r0s[kResizeTile / XS], r1s[kResizeTile / XS];
 #pragma unroll
   for (int i = 0; i < kResizeTile / XS; ++i) {
     const int jx = jx0 + XS * i;
     lxs[i] = t_l[jx];
+    wxs[i] = 1.0f - lxs[i];
     r0s[i] = (t_i0[jx] * ry) << LOG_NO;
     r1s[i] = (t_i1[jx] * ry) << LOG_NO;
   }
+  // (relu / clamp: workgroup-uniform branches around the whole store loop, not selects per output)
+  float* dst_tile = dst + ((size_t)tx0 << (2 * LOG_NO));
+  auto emit = [&](auto post) {
 #pragma unroll
-  for (int h = 0; h < kResizeTile / PY; ++h) {
-    const int jy = jy0 + PY * h, y = ty0 + jy;
-    if (y >= n_out) continue;
-    const float ly = t_l[8 + jy], wy0 = 1.0f - ly;
-    const float* cz0 = col_z + (t_i0[8 + jy] << LOG_NO) + z;
-    const float* cz1 = col_z + (t_i1[8 + jy] << LOG_NO) + z;
-    float* drow = dst + ((((size_t)tx0 << LOG_NO) + y) << LOG_NO) + z;
+    for (int h = 0; h < kResizeTile / PY; ++h) {
+      const int jy = jy0 + PY * h;
+      const float ly = t_l[8 + jy], wy0 = 1.0f - ly;
+      const float* cz0 = col_z + (t_i0[8 + jy] << LOG_NO) + z;
+      const float* cz1 = col_z + (t_i1[8 + jy] << LOG_NO) + z;
+      const unsigned at = ((unsigned)(ty0 + jy) << LOG_NO) + (unsigned)z;   // 32-bit offsets from a uniform base
 #pragma unroll
-    for (int i = 0; i < kResizeTile / XS; ++i) {
-      const int jx = jx0 + XS * i;
-      if (tx0 + jx >= n_out) continue;
-      const float lx = lxs[i], wx0 = 1.0f - lx;
-      float v = blend(wx0, blend(wy0, cz0[r0s[i]], ly, cz1[r0s[i]]), lx, blend(wy0, cz0[r1s[i]], ly, cz1[r1s[i]]));
-      if (relu) v = fmaxf(v, 0.0f);
-      if (clamp > 0.0f) v = fminf(fmaxf(v, -clamp), clamp);
-      drow[(size_t)jx << (2 * LOG_NO)] = v;
+      for (int i = 0; i < kResizeTile / XS; ++i) {
+        const unsigned jx = (unsigned)(jx0 + XS * i);
+        const float v = blend(wxs[i], blend(wy0, cz0[r0s[i]], ly, cz1[r0s[i]]), lxs[i],
+                              blend(wy0, cz0[r1s[i]], ly, cz1[r1s[i]]));
+        dst_tile[at + (jx << (2 * LOG_NO))] = post(v);
+      }
     }
+  };
+  if (clamp > 0.0f) {
+    if (relu) emit([clamp](float v) { return fminf(fmaxf(fmaxf(v, 0.0f), -clamp), clamp); });
+    else emit([clamp](float v) { return fminf(fmaxf(v, -clamp), clamp); });
+  } else if (relu) {
+    emit([](float v) { return fmaxf(v, 0.0f); });
+  } else {
+    emit([](float v) { return v; });
   }
 }
 
