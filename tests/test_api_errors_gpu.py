@@ -172,3 +172,55 @@ def test_nan_upstream_gradient_reaches_the_outputs():
         assert torch.isnan(out[1][0]).all() and torch.isnan(out[2][0]).all() and torch.isnan(out[3][0])
         if B > 1:                                                 # the other views are untouched
             assert torch.equal(out[1][1:], ref[1][1:]) and torch.equal(out[3][1:], ref[3][1:])
+
+
+def test_loop_tail_and_deferred_decoder_vjp_reject_bad_arguments():
+    """Round-3 entry points: sdfr_decoder_backward_latent_deferred needs somewhere to leave its pointer;
+    sdfr_loop_tail takes the decoder and that pointer together or not at all, and checks the latent's size."""
+    import ctypes
+    import os
+    from sdfest_amd import SDFDecoder, _lib
+    L = _lib.lib()
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    d = np.load(os.path.join(g, "decoder_mug.npz"))
+    w = np.load(os.path.join(g, "mug_decoder_weights.npz"))
+    cfg = {"latent_size": int(d["latent_size"]), "tsdf": False, "decoder": {
+        "fc_layers": [{"out": int(o)} for o in d["fc_out"]],
+        "conv_layers": [{"in_size": int(a), "in_channels": int(b), "out_channels": int(c), "kernel_size": int(k),
+                         "relu": bool(r)}
+                        for a, b, c, k, r in zip(d["conv_in_size"], d["conv_cin"], d["conv_cout"], d["conv_k"],
+                                                 d["conv_relu"])]}}
+    dec = SDFDecoder.from_config(cfg, {k: w[k] for k in w.files})
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    z = torch.zeros(1, 8, device=dev)
+    tape = torch.zeros(L.sdfr_decoder_tape_bytes(dec._h, 1), dtype=torch.uint8, device=dev)
+    gout = torch.zeros(64 ** 3, device=dev)
+    ws = torch.zeros(L.sdfr_decoder_backward_workspace_bytes(dec._h, 1), dtype=torch.uint8, device=dev)
+    assert L.sdfr_decoder_backward_latent_deferred(dec._h, z.data_ptr(), tape.data_ptr(), gout.data_ptr(), ws.data_ptr(),
+                                                   ws.numel(), st, None) == -2
+    t_mid = ctypes.c_void_p()
+    assert L.sdfr_decoder_backward_latent_deferred(dec._h, z.data_ptr(), tape.data_ptr(), gout.data_ptr(), ws.data_ptr(),
+                                                   16, st, ctypes.byref(t_mid)) == -3
+    # the tail: 8 pose parameters + a latent of 8
+    params = torch.zeros(16, device=dev); params[6] = 1.0; params[7] = 0.1
+    grads, m, v = torch.zeros(16, device=dev), torch.zeros(16, device=dev), torch.zeros(16, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    cam_pos, cam_quat = torch.zeros(1, 3, device=dev), torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=dev)
+    pos_c, quat_c = torch.zeros(1, 3, device=dev), torch.zeros(1, 4, device=dev)
+    isc, sc = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    some = torch.zeros(64, device=dev)
+
+    def tail(n_params, decoder, tm):
+        return L.sdfr_loop_tail(params.data_ptr(), grads.data_ptr(), m.data_ptr(), v.data_ptr(), step.data_ptr(),
+                                n_params, 1e-3, 1e-2, 1e-3, 1e-2, 1, cam_pos.data_ptr(), cam_quat.data_ptr(), 1, None, 0,
+                                0, 0, None, None, 0, pos_c.data_ptr(), quat_c.data_ptr(), isc.data_ptr(), sc.data_ptr(),
+                                None, None, None, 0.0, None, decoder, tm, 0, st)
+    assert tail(16, dec._h, None) == -2            # decoder without its intermediate
+    assert tail(16, None, some.data_ptr()) == -2   # ... and the other way round
+    assert tail(12, dec._h, some.data_ptr()) == -1 and b"latent" in L.sdfr_last_error()
+    torch.cuda.synchronize()
+    assert int(step.item()) == 0                   # none of them launched anything
+    assert tail(16, None, None) == 0               # the plain tail still runs: one Adam step on zero gradients
+    torch.cuda.synchronize()
+    assert int(step.item()) == 1
