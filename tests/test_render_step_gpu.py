@@ -96,6 +96,35 @@ def test_step_with_one_grid_per_view():
     assert_same(step, ref)
 
 
+def test_batch_tiles_with_one_grid_per_view_against_the_oracle():
+    """One SDF per view at a size that takes the 64 x 8 batch tiles (>= 16 384 of them: the view generator's shape,
+    plain grids through the batch kernels -- no face records, no plane minima): the step equals the two stand-alone
+    calls, and sampled views equal the oracle (depth, d/dSDF of the view's own volume, pose gradients)."""
+    B, W, H, f = 132, 320, 240, 200.0
+    (p_step, p_ref), pose, g, (pos, quat, isc) = make(B, W, H, f, seed=31, per_view_sdf=True)
+    grids = [oracle.blobs_sdf(k) for k in range(3)]
+    sdf = dev(np.stack([grids[k % 3] for k in range(B)]))
+    step, ref = run_step(p_step, sdf, pose, g), run_separate(p_ref, sdf, pose, g)
+    assert step[1][0].shape == (B, 64, 64, 64)
+    assert_same(step, ref)
+    d, (gs, gp, gq, gi) = step
+    g_np = g.cpu().numpy()
+    for v in (0, 57, 131):
+        o = oracle.render_forward(grids[v % 3], pos[v:v + 1], quat[v:v + 1], isc[v:v + 1], W, H, W / 2.0, H / 2.0, f, f,
+                                  0.005)[0]
+        dv = d[v].cpu().numpy()
+        assert ((o > 0) != (dv > 0)).sum() <= 2
+        both = (o > 0) & (dv > 0)
+        assert both.sum() > 200 and np.max(np.abs(o[both] - dv[both]) / o[both]) <= 2e-5
+        og = oracle.render_backward(g_np[v:v + 1], dv[None], grids[v % 3], pos[v:v + 1], quat[v:v + 1], isc[v:v + 1],
+                                    W / 2.0, H / 2.0, f, f, dtype=np.float64)
+        assert rel_err(gs[v].cpu().numpy(), og[0]) <= 2e-4
+        # (random-sign upstream gradient: the pose sums cancel heavily -- the scale is the largest component)
+        scale = max(np.abs(og[1]).max(), np.abs(og[2]).max(), np.abs(og[3]).max(), 1.0)
+        for a, b_ in ((gp[v], og[1][0]), (gq[v], og[2][0]), (gi[v:v + 1], og[3])):
+            assert np.max(np.abs(a.cpu().numpy() - b_)) <= 2e-3 * scale
+
+
 def test_step_replayed_from_a_graph_sees_each_replays_grid():
     """A captured step is replayed with the SAME kernel arguments: the epoch that separates one launch's plane
     minima from the next lives in the workspace and advances on the device."""
