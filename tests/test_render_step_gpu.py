@@ -125,6 +125,30 @@ def test_batch_tiles_with_one_grid_per_view_against_the_oracle():
             assert np.max(np.abs(a.cpu().numpy() - b_)) <= 2e-3 * scale
 
 
+@pytest.mark.parametrize("R", [32, 100, 33])
+def test_batch_step_at_other_resolutions(R):
+    """The batch tiles with a shared grid of another size: 32 and 100 (records, one-launch prologue, the generic
+    kernels), 33 (odd: two-launch prologue).  Step = stand-alone pair; a view's depth against the oracle."""
+    from sdfest_amd import BatchRenderPlan, Camera
+    B, W, H, f = 128, 320, 240, 200.0
+    cam = Camera(W, H, f, f, W / 2.0, H / 2.0, pixel_center=0.5)
+    pos, quat, isc = oracle.random_poses(B, seed=40 + R, width=W, height=H, f=f)
+    pose = (dev(pos), dev(quat), dev(isc))
+    g = dev(np.random.default_rng(R).uniform(-1, 1, (B, H, W)))
+    grid = oracle.blobs_sdf(1, R=R)
+    sdf = dev(grid)
+    p_step, p_ref = BatchRenderPlan(R, B, cam), BatchRenderPlan(R, B, cam)
+    step, ref = run_step(p_step, sdf, pose, g), run_separate(p_ref, sdf, pose, g)
+    assert step[1][0].shape == (R, R, R)
+    assert_same(step, ref, f"R={R}")
+    for v in (3, 90):
+        o = oracle.render_forward(grid, pos[v:v + 1], quat[v:v + 1], isc[v:v + 1], W, H, W / 2.0, H / 2.0, f, f, 0.005)[0]
+        dv = step[0][v].cpu().numpy()
+        assert ((o > 0) != (dv > 0)).sum() <= 2
+        both = (o > 0) & (dv > 0)
+        assert both.sum() > 200 and np.max(np.abs(o[both] - dv[both]) / o[both]) <= 2e-5
+
+
 def test_step_replayed_from_a_graph_sees_each_replays_grid():
     """A captured step is replayed with the SAME kernel arguments: the epoch that separates one launch's plane
     minima from the next lives in the workspace and advances on the device."""
