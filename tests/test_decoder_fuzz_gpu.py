@@ -1,6 +1,6 @@
 """GPU: seeded random decoder architectures -- Linear stacks of 1 ... 4 layers, 2 ... 4 Conv3d layers with channel
 counts that are no multiple of the MFMA tile (1 ... 24), kernel sizes 1 / 3 / 5, resize targets above and below
-the incoming size, volume sizes 9 ... 40, batches of 1 ... 20 latents, tsdf clamps -- forward and latent VJP against
+the incoming size, volume sizes 9 ... 40, batches of 1 ... 48 latents, tsdf clamps -- forward and latent VJP against
 the layers written out in torch (float64 on the CPU, test_decoder_gpu.torch_decoder: the layer sequence of
 sdf_vae.py:171-259).  The fixed tests pin the mug architecture and two hand-picked ones; which kernel a layer
 takes (MFMA im2col, split-K, z-grouped columns, direct convolution, fused resizes, swapped 1x1) depends on its
@@ -46,7 +46,7 @@ def draw(seed):
     fc.append({"out": chans[0] * conv[0]["in_size"] ** 3})
     volume = int(np.clip(cur + rng.integers(-2, 12), 2, 40))
     tsdf = [False, False, 0.1, True][int(rng.integers(0, 4))]
-    N = int(rng.choice([1, 1, 2, 5, 20]))
+    N = int(rng.choice([1, 1, 2, 5, 20, 48]))   # 48: the batch forms of the small launches (Linear stack, 1x1, resident MFMA)
     state = {}
     cin = latent
     for i, l in enumerate(fc):
