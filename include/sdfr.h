@@ -70,7 +70,8 @@ extern "C" {
  * sharded batch add their 64-bit volumes (sdfr_render_fixed_volume_offset) and convert afterwards
  * (sdfr_fixed_to_float) -- on how the views are spread over GPUs.  For tests and reproducible runs: several
  * times slower than the default (64-bit LDS table, no dense box).  Shared gradient volume only
- * (g_sdf_view_stride = 0), R <= 128, sdfr_render_backward / sdfr_render_step_backward only.  Representable range:
+ * (g_sdf_view_stride = 0), R <= 128; every backward form takes it (the loss-fused ones and the sampler's blocks of
+ * sdfr_render_backward_l1_pc add into the same 64-bit volume).  Representable range:
  * |sum| < 2^(63 - 40) = 8.4e6 per voxel; contributions that are not finite count as 0 (NaN) or saturate. */
 #define SDFR_SDF_GRAD_DETERMINISTIC 0x100
 #define SDFR_FIXED_QUANTUM_BITS 40
@@ -85,6 +86,12 @@ extern "C" {
  * slower with it (objects of ~1 pixel per voxel: 103 -> 174 us).  The poses live in device memory, so only the
  * caller can know; ignored for small calls and for the loss-fused and deterministic forms. */
 #define SDFR_BWD_HALF_GRID 0x200
+/* Flag bit, OR-ed into sdf_grad_mode: the backward always uses its 32 x 8 tiling, whatever the batch size.  A
+ * view's pose gradients are fixed-order sums over ITS tiles, so with this flag they do not depend on how many
+ * other views share the launch: a batch sharded over ranks (sdfest_amd.pipeline, the sharded render-and-compare
+ * loop) then gets, together with SDFR_SDF_GRAD_DETERMINISTIC, bitwise the single-process gradients.  Slower for
+ * large batches (more, smaller tiles).  Pass the same flag to sdfr_loop_view_records. */
+#define SDFR_BWD_SMALL_TILES 0x400
 
 SDFR_API int sdfr_version(void);
 SDFR_API const char* sdfr_last_error(void);
@@ -370,6 +377,49 @@ SDFR_API int sdfr_loop_tail(float* params, float* grads, float* exp_avg, float* 
                    int max_view_points, float* pos_c, float* quat_c, float* inv_scale, float* scale_v, float* pc_loss,
                    const float* con_source, const float* con_target, float con_weight, float* con_loss,
                    const sdfr_decoder* decoder, const float* decoder_t_mid, int device, void* stream);
+
+/* ---- the loop sharded over ranks (one process per GPU) ------------------------------------------------
+ * The reference's multi-view iteration is one Python loop over the views with ONE shared pose and ONE shared SDF
+ * (simple_setup.py:420-446, update :456-462).  Sharded, every rank renders and samples a contiguous shard of the
+ * views and the iteration has exactly one exchange, an all-reduce (sum) of one bucket
+ *     [ d loss / d SDF, R^3 words ][ V_total view records of SDFR_VIEW_RECORD_FLOATS floats ]
+ * after which every rank runs the same decoder VJP and the same Adam step on replicated state (no broadcast).
+ * A view's record: [0..7] the renderer's pose sums (g_pos 3, g_quat 4, g_inv_scale), [8..15] the sampler's (g_pos 3,
+ * g_quat 4 through the normalisation's Jacobian, g_scale), [16] its depth loss, [17] its point-cloud loss, rest 0.
+ * Records instead of the 8 summed pose gradients: each is non-zero on exactly one rank, so the sum over ranks
+ * reproduces it exactly, and the chain adds the views in index order on every rank -- the pose gradient does not
+ * depend on how the views were spread (with SDFR_SDF_GRAD_DETERMINISTIC | SDFR_BWD_SMALL_TILES the whole iteration
+ * is bitwise the single-process one; exchange the bucket as 64-bit integers then, the volume being the int64 one).
+ *
+ * sdfr_loop_view_records: one launch, one wave per view of the whole list: records[v] for this rank's views
+ * [view_begin, view_begin + V_local) from the partials the deferred backward calls left (as
+ * sdfr_views_to_pose_grad_deferred: render_workspace + sdfr_render_partials_offset, pc_workspace; either may be NULL;
+ * with_pc_loss: the sampler ran in its L1 form and left loss partials), zeros for every other view.  loss_depth
+ * [V_local] (or NULL): per-view depth losses to carry along.  sdf_grad_mode: the backward's (SDFR_BWD_SMALL_TILES). */
+#define SDFR_VIEW_RECORD_FLOATS 20
+SDFR_API int sdfr_loop_view_records(const void* render_workspace, size_t render_partials_offset, int W, int H,
+                           int sdf_grad_mode, const void* pc_workspace, int with_pc_loss, const int* offsets,
+                           int max_view_points, const float* quat_c, const float* loss_depth, int view_begin,
+                           int V_local, int V_total, float* records, int device, void* stream);
+/* sdfr_loop_tail working from the exchanged records of ALL views: (decoder VJP's last stage,) the chain over the
+ * V_total records with cam_quat [V_total][4], the point constraint, Adam, and the next iteration's view poses for
+ * this rank's shard (cam_pos / cam_quat are the whole lists; pos_c / quat_c / inv_scale / scale_v [V_local]). */
+/* The inlier bookkeeping of sdfr_inlier_ratio split around the exchange: the rank that owns the LAST view counts
+ * (sdfr_inlier_counts_record: the two counts, as floats -- exact below 2^24 pixels -- into words 18 and 19 of that
+ * view's record, after sdfr_loop_view_records), every rank updates from the exchanged record after the tail
+ * (sdfr_inlier_update_record: ratio, history, best-so-far state and parameters as sdfr_inlier_ratio). */
+SDFR_API int sdfr_inlier_counts_record(const float* depth_input, const float* depth_estimate, int W, int H,
+                              float relative_threshold, int* counts, float* record, int device, void* stream);
+SDFR_API int sdfr_inlier_update_record(const float* record, const int* step, float* history, int max_history,
+                              float* state, const float* params, int n_params, float* best_params, int device,
+                              void* stream);
+SDFR_API int sdfr_loop_tail_records(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int* step, int n_params,
+                           float lr_position, float lr_orientation, float lr_scale, float lr_latent,
+                           int update_latent, const float* cam_pos, const float* cam_quat, int V_total,
+                           int view_begin, int V_local, const float* records, float* pos_c, float* quat_c,
+                           float* inv_scale, float* scale_v, const float* con_source, const float* con_target,
+                           float con_weight, float* con_loss, const sdfr_decoder* decoder,
+                           const float* decoder_t_mid, int device, void* stream);
 
 /* sdfr_render_backward_l1 and sdfr_pc_l1_backward_accumulate of one loop iteration in ONE launch (they are
  * independent and neither fills the chip for a handful of views): arguments as in those two calls -- the per-view

@@ -37,6 +37,13 @@ SIGNATURES = {
     "sdfr_loop_tail": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_f, c_f, c_f, c_f, c_int, c_fp, c_fp, c_int,
                                c_fp, c_sz, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                c_f, c_fp, c_fp, c_fp, c_int, c_fp]),
+    "sdfr_loop_view_records": (c_int, [c_fp, c_sz, c_int, c_int, c_int, c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_int,
+                                       c_int, c_int, c_fp, c_int, c_fp]),
+    "sdfr_loop_tail_records": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_f, c_f, c_f, c_f, c_int, c_fp, c_fp,
+                                       c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp,
+                                       c_fp, c_int, c_fp]),
+    "sdfr_inlier_counts_record": (c_int, [c_fp, c_fp, c_int, c_int, c_f, c_fp, c_fp, c_int, c_fp]),
+    "sdfr_inlier_update_record": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_int, c_fp, c_int, c_fp]),
     "sdfr_render_fixed_volume_offset": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
     "sdfr_fixed_to_float": (c_int, [c_fp, c_sz, c_fp, c_int, c_fp]),
     "sdfr_render_forward": (c_int, [c_fp, c_int, c_ll, c_fp, c_fp, c_fp, c_int, c_int, c_int,

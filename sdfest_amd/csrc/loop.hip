@@ -118,6 +118,119 @@ __global__ void views_to_pose_grad_kernel(const float* __restrict__ orientation,
 // The same chain with the two per-view reductions in front of it folded in (pose_reduce_kernel of render.hip,
 // pc_loss_reduce_kernel of sampler.hip: same order of additions, so the same numbers): one launch instead of
 // three.  One workgroup; wave w reduces views w, w + 4, ... into LDS, thread 0 then runs the chain.
+//
+// One wave: the 16 sums of view v -- dst[0..7] the renderer's (pos, quat, inv_scale: its tile partials in the order
+// pose_reduce_kernel adds them), dst[8..15] the sampler's (pos, quat through the Jacobian of q^ = q / |q|, scale: its
+// block partials as pc_loss_reduce_kernel) -- and, with pc_loss_part, the view's point-cloud loss to *pc_loss_out.
+__device__ __forceinline__ void reduce_view_wave(
+    int v, int lane, const ViewSetup* __restrict__ setup, const float* __restrict__ tile_part, int W, int H,
+    int ntx_all, int nty_all, int tile_w_all, int tile_h_all, int stride, const float* __restrict__ pc_part,
+    const float* __restrict__ pc_loss_part, const int* __restrict__ offsets, int n_single, int nblk,
+    const float* __restrict__ quat_c, float* __restrict__ pc_loss_out, float* __restrict__ dst) {
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (tile_part) {
+    const ViewSetup& s = setup[v];
+    // the view's tiling, as pose_reduce_kernel (render.hip): a batch backward picks it per view
+    int ntx = ntx_all, nty = nty_all, tile_w = tile_w_all, tile_h = tile_h_all;
+    size_t first = (size_t)v * ntx * nty;
+    const bool big = stride > 0 && s.bwd_big;
+    if (stride > 0) first = (size_t)v * stride;
+    if (big) { tile_w = kBwdBigTile.w(); tile_h = kBwdBigTile.h(); }
+    (void)nty;
+    const int x0 = s.rect[0], y0 = s.rect[1], x1 = s.rect[2], y1 = s.rect[3];
+    if (x1 > x0 && y1 > y0) {
+      const int tx0 = x0 / tile_w, tx1 = (x1 - 1) / tile_w, ty0 = y0 / tile_h, ty1 = (y1 - 1) / tile_h;
+      const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1);
+      const float* base = tile_part + first * 8;
+      for (int i = lane; i < n; i += 64) {
+        const int ty = ty0 + i / nx, tx = tx0 + i % nx;
+        const size_t rec = big ? (size_t)backward_big_record(tx, ty, W) : (size_t)ty * ntx + tx;
+        const float4* p = reinterpret_cast<const float4*>(base + rec * 8);
+        const float4 a = p[0], c = p[1];
+        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+        acc[4] += c.x; acc[5] += c.y; acc[6] += c.z; acc[7] += c.w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = wave_sum(acc[k]);
+  }
+  if (lane < 8) {
+    float r = acc[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) r = (lane == k) ? acc[k] : r;
+    dst[lane] = r;
+  }
+  float pcs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (pc_part) {
+    const int len = offsets ? offsets[v + 1] - offsets[v] : n_single;
+    const int nb = (len + kSamplerPts - 1) / kSamplerPts;
+    if (pc_loss_part) {
+      float sa = 0.0f;
+      for (int i = lane; i < nb; i += 64) sa += pc_loss_part[(size_t)v * nblk + i];
+      sa = wave_sum(sa);
+      if (lane == 0) *pc_loss_out = sa / (float)len;
+    }
+    for (int i = lane; i < nb; i += 64) {
+      const float4* p = reinterpret_cast<const float4*>(pc_part + ((size_t)v * nblk + i) * 8);
+      const float4 a = p[0], c = p[1];
+      pcs[0] += a.x; pcs[1] += a.y; pcs[2] += a.z; pcs[3] += a.w;
+      pcs[4] += c.x; pcs[5] += c.y; pcs[6] += c.z; pcs[7] += c.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pcs[k] = wave_sum(pcs[k]);
+    // Jacobian of q^ = q / |q| on the view's quaternion, as pc_loss_reduce_kernel
+    const float x = quat_c[4 * v], y = quat_c[4 * v + 1], z = quat_c[4 * v + 2], w = quat_c[4 * v + 3];
+    const float inv_norm = 1.0f / sqrtf(x * x + y * y + z * z + w * w);
+    const float qn[4] = {x * inv_norm, y * inv_norm, z * inv_norm, w * inv_norm};
+    const float dq = qn[0] * pcs[3] + qn[1] * pcs[4] + qn[2] * pcs[5] + qn[3] * pcs[6];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pcs[3 + k] = (pcs[3 + k] - qn[k] * dq) * inv_norm;
+  }
+  if (lane < 8) {
+    float r = pcs[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) r = (lane == k) ? pcs[k] : r;
+    dst[8 + lane] = r;
+  }
+}
+
+// One thread: the V views' 16 sums (rec + v * rec_stride; [0..7] renderer, [8..15] sampler) back to the world-frame
+// parameters -- the reverse of pose_to_view -- and through the normalisation of the orientation.  Views are added
+// in index order: the result depends on the records alone, not on where they were computed.
+__device__ __forceinline__ void pose_chain(const float* __restrict__ orientation, const float* __restrict__ scale,
+                                           const float* __restrict__ cam_quat, int V, const float* rec,
+                                           int rec_stride, bool use_a, bool use_b, float* __restrict__ g_position,
+                                           float* __restrict__ g_orientation, float* __restrict__ g_scale) {
+  const float q[4] = {orientation[0], orientation[1], orientation[2], orientation[3]};
+  const float inv_n = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const float nq[4] = {q[0] * inv_n, q[1] * inv_n, q[2] * inv_n, q[3] * inv_n};
+  float gp[3] = {0, 0, 0}, gn[4] = {0, 0, 0, 0}, gs = 0.0f;
+  const float s = scale[0];
+  for (int v = 0; v < V; ++v) {
+    const float a[4] = {-cam_quat[4 * v], -cam_quat[4 * v + 1], -cam_quat[4 * v + 2], cam_quat[4 * v + 3]};
+    float m[9];
+    quat_matrix(a, m);
+    const float* ga = rec + (size_t)v * rec_stride;
+    const float* gb = ga + 8;
+    float gpc[3], gqc[4];
+    for (int k = 0; k < 3; ++k) gpc[k] = (use_a ? ga[k] : 0.0f) + (use_b ? gb[k] : 0.0f);
+    for (int k = 0; k < 4; ++k) gqc[k] = (use_a ? ga[3 + k] : 0.0f) + (use_b ? gb[3 + k] : 0.0f);
+    gp[0] += m[0] * gpc[0] + m[3] * gpc[1] + m[6] * gpc[2];
+    gp[1] += m[1] * gpc[0] + m[4] * gpc[1] + m[7] * gpc[2];
+    gp[2] += m[2] * gpc[0] + m[5] * gpc[1] + m[8] * gpc[2];
+    const float ax = a[0], ay = a[1], az = a[2], aw = a[3];
+    gn[0] += aw * gqc[0] + az * gqc[1] - ay * gqc[2] - ax * gqc[3];
+    gn[1] += -az * gqc[0] + aw * gqc[1] + ax * gqc[2] - ay * gqc[3];
+    gn[2] += ay * gqc[0] - ax * gqc[1] + aw * gqc[2] - az * gqc[3];
+    gn[3] += ax * gqc[0] + ay * gqc[1] + az * gqc[2] + aw * gqc[3];
+    gs += (use_a ? -ga[7] / (s * s) : 0.0f) + (use_b ? gb[7] : 0.0f);
+  }
+  const float d = nq[0] * gn[0] + nq[1] * gn[1] + nq[2] * gn[2] + nq[3] * gn[3];
+  for (int k = 0; k < 3; ++k) g_position[k] = gp[k];
+  for (int k = 0; k < 4; ++k) g_orientation[k] = (gn[k] - nq[k] * d) * inv_n;
+  g_scale[0] = gs;
+}
+
 __device__ __forceinline__ void deferred_chain(
     const float* __restrict__ orientation, const float* __restrict__ scale, const float* __restrict__ cam_quat,
     int V, const ViewSetup* __restrict__ setup, const float* __restrict__ tile_part, int W, int H, int ntx_all,
@@ -128,103 +241,39 @@ __device__ __forceinline__ void deferred_chain(
     float* __restrict__ g_scale) {
   __shared__ float view_g[kDeferredMaxViews][16];  // [0..7] renderer: pos, quat, inv_scale; [8..15] sampler
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int v = wave; v < V; v += 4) {
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (tile_part) {
-      const ViewSetup& s = setup[v];
-      // the view's tiling, as pose_reduce_kernel (render.hip): a batch backward picks it per view
-      int ntx = ntx_all, nty = nty_all, tile_w = tile_w_all, tile_h = tile_h_all;
-      size_t first = (size_t)v * ntx * nty;
-      const bool big = stride > 0 && s.bwd_big;
-      if (stride > 0) first = (size_t)v * stride;
-      if (big) { tile_w = kBwdBigTile.w(); tile_h = kBwdBigTile.h(); }
-      (void)nty;
-      const int x0 = s.rect[0], y0 = s.rect[1], x1 = s.rect[2], y1 = s.rect[3];
-      if (x1 > x0 && y1 > y0) {
-        const int tx0 = x0 / tile_w, tx1 = (x1 - 1) / tile_w, ty0 = y0 / tile_h, ty1 = (y1 - 1) / tile_h;
-        const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1);
-        const float* base = tile_part + first * 8;
-        for (int i = lane; i < n; i += 64) {
-          const int ty = ty0 + i / nx, tx = tx0 + i % nx;
-          const size_t rec = big ? (size_t)backward_big_record(tx, ty, W) : (size_t)ty * ntx + tx;
-          const float4* p = reinterpret_cast<const float4*>(base + rec * 8);
-          const float4 a = p[0], c = p[1];
-          acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
-          acc[4] += c.x; acc[5] += c.y; acc[6] += c.z; acc[7] += c.w;
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) acc[k] = wave_sum(acc[k]);
-    }
-    if (lane < 8) {
-      float r = acc[0];
-#pragma unroll
-      for (int k = 1; k < 8; ++k) r = (lane == k) ? acc[k] : r;
-      view_g[v][lane] = r;
-    }
-    float pcs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (pc_part) {
-      const int len = offsets ? offsets[v + 1] - offsets[v] : n_single;
-      const int nb = (len + kSamplerPts - 1) / kSamplerPts;
-      if (pc_loss_part) {
-        float sa = 0.0f;
-        for (int i = lane; i < nb; i += 64) sa += pc_loss_part[(size_t)v * nblk + i];
-        sa = wave_sum(sa);
-        if (lane == 0) pc_loss[v] = sa / (float)len;
-      }
-      for (int i = lane; i < nb; i += 64) {
-        const float4* p = reinterpret_cast<const float4*>(pc_part + ((size_t)v * nblk + i) * 8);
-        const float4 a = p[0], c = p[1];
-        pcs[0] += a.x; pcs[1] += a.y; pcs[2] += a.z; pcs[3] += a.w;
-        pcs[4] += c.x; pcs[5] += c.y; pcs[6] += c.z; pcs[7] += c.w;
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) pcs[k] = wave_sum(pcs[k]);
-      // Jacobian of q^ = q / |q| on the view's quaternion, as pc_loss_reduce_kernel
-      const float x = quat_c[4 * v], y = quat_c[4 * v + 1], z = quat_c[4 * v + 2], w = quat_c[4 * v + 3];
-      const float inv_norm = 1.0f / sqrtf(x * x + y * y + z * z + w * w);
-      const float qn[4] = {x * inv_norm, y * inv_norm, z * inv_norm, w * inv_norm};
-      const float dq = qn[0] * pcs[3] + qn[1] * pcs[4] + qn[2] * pcs[5] + qn[3] * pcs[6];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) pcs[3 + k] = (pcs[3 + k] - qn[k] * dq) * inv_norm;
-    }
-    if (lane < 8) {
-      float r = pcs[0];
-#pragma unroll
-      for (int k = 1; k < 8; ++k) r = (lane == k) ? pcs[k] : r;
-      view_g[v][8 + lane] = r;
-    }
-  }
+  for (int v = wave; v < V; v += 4)
+    reduce_view_wave(v, lane, setup, tile_part, W, H, ntx_all, nty_all, tile_w_all, tile_h_all, stride, pc_part,
+                     pc_loss_part, offsets, n_single, nblk, quat_c, pc_loss ? pc_loss + v : nullptr, view_g[v]);
   __syncthreads();
   if (threadIdx.x != 0) return;   // (callers that go on afterwards: every thread reaches the barrier above)
-  const float q[4] = {orientation[0], orientation[1], orientation[2], orientation[3]};
-  const float inv_n = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  const float nq[4] = {q[0] * inv_n, q[1] * inv_n, q[2] * inv_n, q[3] * inv_n};
-  float gp[3] = {0, 0, 0}, gn[4] = {0, 0, 0, 0}, gs = 0.0f;
-  const float s = scale[0];
-  for (int v = 0; v < V; ++v) {
-    const float a[4] = {-cam_quat[4 * v], -cam_quat[4 * v + 1], -cam_quat[4 * v + 2], cam_quat[4 * v + 3]};
-    float m[9];
-    quat_matrix(a, m);
-    const float* ga = view_g[v];
-    const float* gb = view_g[v] + 8;
-    float gpc[3], gqc[4];
-    for (int k = 0; k < 3; ++k) gpc[k] = (tile_part ? ga[k] : 0.0f) + (pc_part ? gb[k] : 0.0f);
-    for (int k = 0; k < 4; ++k) gqc[k] = (tile_part ? ga[3 + k] : 0.0f) + (pc_part ? gb[3 + k] : 0.0f);
-    gp[0] += m[0] * gpc[0] + m[3] * gpc[1] + m[6] * gpc[2];
-    gp[1] += m[1] * gpc[0] + m[4] * gpc[1] + m[7] * gpc[2];
-    gp[2] += m[2] * gpc[0] + m[5] * gpc[1] + m[8] * gpc[2];
-    const float ax = a[0], ay = a[1], az = a[2], aw = a[3];
-    gn[0] += aw * gqc[0] + az * gqc[1] - ay * gqc[2] - ax * gqc[3];
-    gn[1] += -az * gqc[0] + aw * gqc[1] + ax * gqc[2] - ay * gqc[3];
-    gn[2] += ay * gqc[0] - ax * gqc[1] + aw * gqc[2] - az * gqc[3];
-    gn[3] += ax * gqc[0] + ay * gqc[1] + az * gqc[2] + aw * gqc[3];
-    gs += (tile_part ? -ga[7] / (s * s) : 0.0f) + (pc_part ? gb[7] : 0.0f);
+  pose_chain(orientation, scale, cam_quat, V, &view_g[0][0], 16, tile_part != nullptr, pc_part != nullptr, g_position,
+             g_orientation, g_scale);
+}
+
+// The sharded loop's exchange record of one view (include/sdfr.h, sdfr_loop_view_records): one wave per view of the
+// WHOLE list; a view of another rank's shard gets zeros, so that the sum over ranks is every view's own record.
+constexpr int kViewRecord = SDFR_VIEW_RECORD_FLOATS;
+static_assert(kViewRecord >= 18 && kViewRecord % 4 == 0 && kViewRecord <= 64, "record: 16 sums + 2 losses, 16-byte multiple");
+__global__ __launch_bounds__(64) void view_records_kernel(
+    const ViewSetup* __restrict__ setup, const float* __restrict__ tile_part, int W, int H, int ntx_all, int nty_all,
+    int tile_w_all, int tile_h_all, int stride, const float* __restrict__ pc_part,
+    const float* __restrict__ pc_loss_part, const int* __restrict__ offsets, int n_single, int nblk,
+    const float* __restrict__ quat_c, const float* __restrict__ loss_depth, int view_begin, int V_local,
+    float* __restrict__ records) {
+  const int v = blockIdx.x, lane = threadIdx.x;
+  float* rec = records + (size_t)v * kViewRecord;
+  const int lv = v - view_begin;
+  if (lv < 0 || lv >= V_local) {
+    if (lane < kViewRecord) rec[lane] = 0.0f;
+    return;
   }
-  const float d = nq[0] * gn[0] + nq[1] * gn[1] + nq[2] * gn[2] + nq[3] * gn[3];
-  for (int k = 0; k < 3; ++k) g_position[k] = gp[k];
-  for (int k = 0; k < 4; ++k) g_orientation[k] = (gn[k] - nq[k] * d) * inv_n;
-  g_scale[0] = gs;
+  if (lane == 0) {
+    rec[16] = loss_depth ? loss_depth[lv] : 0.0f;
+    if (!pc_loss_part) rec[17] = 0.0f;
+  }
+  if (lane >= 18 && lane < kViewRecord) rec[lane] = 0.0f;
+  reduce_view_wave(lv, lane, setup, tile_part, W, H, ntx_all, nty_all, tile_w_all, tile_h_all, stride, pc_part,
+                   pc_loss_part, offsets, n_single, nblk, quat_c, rec + 17, rec);
 }
 __global__ __launch_bounds__(256) void views_to_pose_grad_deferred_kernel(
     const float* __restrict__ orientation, const float* __restrict__ scale, const float* __restrict__ cam_quat,
@@ -301,22 +350,30 @@ __global__ __launch_bounds__(256) void inlier_count_kernel(const float* __restri
 // ratio = inliers / valid; history[step - 1] = ratio; a strictly better ratio (or the first) takes
 // the current parameters as the best estimate (:203-211).  state = {best ratio, its iteration
 // (1-based), has_best}; counts are cleared for the next iteration.
+// counts_rec (the sharded loop): the two counts as floats in the last view's exchanged record (exact: < 2^24)
 __global__ void inlier_update_kernel(int* __restrict__ counts, const int* __restrict__ step,
                                      float* __restrict__ history, int max_history,
                                      float* __restrict__ state, const float* __restrict__ params,
-                                     int n_params, float* __restrict__ best_params) {
+                                     int n_params, float* __restrict__ best_params,
+                                     const float* __restrict__ counts_rec) {
   __shared__ int better;
   if (threadIdx.x == 0) {
-    const float ratio = (float)counts[0] / (float)counts[1];
+    const float ratio = counts_rec ? counts_rec[0] / counts_rec[1] : (float)counts[0] / (float)counts[1];
     const int it = step[0];  // steps taken so far: Adam has run for this iteration already
     if (history && it >= 1 && it <= max_history) history[it - 1] = ratio;
     better = (state[2] == 0.0f) || (ratio > state[0]);
     if (better) { state[0] = ratio; state[1] = (float)it; state[2] = 1.0f; }
-    counts[0] = 0; counts[1] = 0;
+    if (counts) { counts[0] = 0; counts[1] = 0; }
   }
   __syncthreads();
   if (better && best_params)
     for (int i = threadIdx.x; i < n_params; i += blockDim.x) best_params[i] = params[i];
+}
+__global__ void inlier_counts_to_record_kernel(int* __restrict__ counts, float* __restrict__ rec) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    rec[0] = (float)counts[0]; rec[1] = (float)counts[1];
+    counts[0] = 0; counts[1] = 0;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -533,6 +590,9 @@ struct LoopTailArgs {
   float* pos_c; float* quat_c; float* inv_scale; float* scale_v; float* pc_loss;
   const float* con_source; const float* con_target; float con_weight; float* con_loss;
   const float* dec_params; const float* t_mid; FcDesc fc;   // t_mid != NULL: the decoder VJP's last stage runs here
+  // records != NULL (sdfr_loop_tail_records): the chain runs over the V_all exchanged view records instead of this
+  // rank's partials; cam_pos / cam_quat / V above are then this rank's shard (the next iteration's view poses)
+  const float* records; int V_all; const float* cam_quat_all;
 };
 static_assert(kFcBlock == 256, "the tail's workgroup runs the decoder's Linear-stack backward");
 __global__ __launch_bounds__(256) void loop_tail_kernel(LoopTailArgs a) {
@@ -541,9 +601,15 @@ __global__ __launch_bounds__(256) void loop_tail_kernel(LoopTailArgs a) {
     fc_stack_backward_sample(a.dec_params, a.fc, a.params + 8, a.t_mid, g + 8);
     __syncthreads();
   }
-  deferred_chain(a.params + 3, a.params + 7, a.cam_quat, a.V, a.setup, a.tile_part, a.W, a.H, a.ntx, a.nty, a.tile_w,
-                 a.tile_h, a.stride, a.pc_part, a.pc_loss_part, a.offsets, a.n_single, a.nblk, a.quat_c, a.pc_loss, g,
-                 g + 3, g + 7);
+  if (a.records) {
+    if (threadIdx.x == 0)
+      pose_chain(a.params + 3, a.params + 7, a.cam_quat_all, a.V_all, a.records, kViewRecord, true, true, g, g + 3,
+                 g + 7);
+  } else {
+    deferred_chain(a.params + 3, a.params + 7, a.cam_quat, a.V, a.setup, a.tile_part, a.W, a.H, a.ntx, a.nty,
+                   a.tile_w, a.tile_h, a.stride, a.pc_part, a.pc_loss_part, a.offsets, a.n_single, a.nblk, a.quat_c,
+                   a.pc_loss, g, g + 3, g + 7);
+  }
   if (threadIdx.x == 0 && a.con_source)
     point_constraint_one(a.params + 3, a.con_source, a.con_target, a.con_weight, a.con_loss, g + 3);
   __syncthreads();   // the pose gradients thread 0 wrote are visible to the Adam threads
@@ -761,6 +827,74 @@ extern "C" int sdfr_loop_tail(float* params, float* grads, float* exp_avg, float
   return 0;
 }
 
+extern "C" int sdfr_loop_view_records(const void* render_workspace, size_t render_partials_offset, int W, int H,
+                                      int sdf_grad_mode, const void* pc_workspace, int with_pc_loss, const int* offsets,
+                                      int max_view_points, const float* quat_c, const float* loss_depth, int view_begin,
+                                      int V_local, int V_total, float* records, int device, void* stream) {
+  const char* fn = "sdfr_loop_view_records";
+  if (V_total < 1 || V_total > 65535 || V_local < 0 || view_begin < 0 || view_begin + V_local > V_total)
+    return fail(SDFR_E_INVALID, "%s: shard [%d, %d) of %d views", fn, view_begin, view_begin + V_local, V_total);
+  if (!records) return fail(SDFR_E_NULL, "%s: records is NULL", fn);
+  if (render_workspace && (W <= 0 || H <= 0)) return fail(SDFR_E_INVALID, "%s: W=%d H=%d", fn, W, H);
+  if (pc_workspace && (max_view_points <= 0 || !quat_c || (!offsets && V_local > 1)))
+    return fail(SDFR_E_INVALID, "%s: bad sampler arguments", fn);
+  if (render_workspace && ((uintptr_t)render_workspace % alignof(ViewSetup) || render_partials_offset % 16))
+    return fail(SDFR_E_INVALID, "%s: render_workspace / partials offset misaligned", fn);
+  SDFR_HIP_TRY(hipSetDevice(device));
+  const bool have = render_workspace && V_local > 0;
+  const TileGeom geom = !have ? kSmallTile
+                        : (sdf_grad_mode & SDFR_BWD_SMALL_TILES) ? kSmallTile : backward_geom(V_local, W, H);
+  const int nblk = pc_workspace ? (max_view_points + kSamplerPts - 1) / kSamplerPts : 0;
+  const float* pc_part = V_local > 0 ? (const float*)pc_workspace : nullptr;
+  const float* tile_part = have ? (const float*)((const char*)render_workspace + render_partials_offset) : nullptr;
+  const int stride = (have && geom.sx * geom.sy > 1) ? backward_tile_stride(W, H) : 0;
+  hipLaunchKernelGGL(view_records_kernel, dim3(V_total), dim3(64), 0, (hipStream_t)stream,
+                     (const ViewSetup*)render_workspace, tile_part, W, H, have ? geom.nx(W) : 0, have ? geom.ny(H) : 0,
+                     geom.w(), geom.h(), stride, pc_part,
+                     (pc_part && with_pc_loss) ? pc_part + (size_t)V_local * nblk * 8 : nullptr, offsets,
+                     max_view_points, nblk, quat_c, loss_depth, view_begin, V_local, records);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfr_loop_tail_records(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int* step,
+                                      int n_params, float lr_position, float lr_orientation, float lr_scale,
+                                      float lr_latent, int update_latent, const float* cam_pos, const float* cam_quat,
+                                      int V_total, int view_begin, int V_local, const float* records, float* pos_c,
+                                      float* quat_c, float* inv_scale, float* scale_v, const float* con_source,
+                                      const float* con_target, float con_weight, float* con_loss,
+                                      const sdfr_decoder* decoder, const float* decoder_t_mid, int device, void* stream) {
+  const char* fn = "sdfr_loop_tail_records";
+  if ((decoder != nullptr) != (decoder_t_mid != nullptr))
+    return fail(SDFR_E_NULL, "%s: decoder and decoder_t_mid go together", fn);
+  if (V_total < 1 || V_total > 65535 || V_local < 0 || view_begin < 0 || view_begin + V_local > V_total)
+    return fail(SDFR_E_INVALID, "%s: shard [%d, %d) of %d views", fn, view_begin, view_begin + V_local, V_total);
+  if (n_params < 8 || n_params > 256) return fail(SDFR_E_INVALID, "%s: n_params=%d out of range [8,256]", fn, n_params);
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !step || !cam_pos || !cam_quat || !records ||
+      (V_local > 0 && (!pos_c || !quat_c || !inv_scale || !scale_v)))
+    return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
+  if (con_source && !con_target) return fail(SDFR_E_NULL, "%s: constraint target is NULL", fn);
+  SDFR_HIP_TRY(hipSetDevice(device));
+  LoopTailArgs a{};
+  a.params = params; a.grads = grads; a.m = exp_avg; a.v = exp_avg_sq; a.step = step; a.n = n_params;
+  a.lr_pos = lr_position; a.lr_quat = lr_orientation; a.lr_scale = lr_scale; a.lr_latent = lr_latent;
+  a.update_latent = update_latent;
+  a.cam_pos = cam_pos + 3 * (size_t)view_begin; a.cam_quat = cam_quat + 4 * (size_t)view_begin; a.V = V_local;
+  a.records = records; a.V_all = V_total; a.cam_quat_all = cam_quat;
+  a.pos_c = pos_c; a.quat_c = quat_c; a.inv_scale = inv_scale; a.scale_v = scale_v;
+  a.con_source = con_source; a.con_target = con_target; a.con_weight = con_weight; a.con_loss = con_loss;
+  if (decoder) {
+    decoder_fc_desc(decoder, &a.fc, &a.dec_params, nullptr);
+    if (a.fc.width[0] != n_params - 8)
+      return fail(SDFR_E_INVALID, "%s: the decoder's latent has %d entries, the parameter vector %d", fn, a.fc.width[0],
+                  n_params - 8);
+    a.t_mid = decoder_t_mid;
+  }
+  hipLaunchKernelGGL(loop_tail_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 extern "C" size_t sdfr_depth_l1_workspace_bytes(int V, int W, int H) {
   if (V <= 0 || W <= 0 || H <= 0) return 0;
   const int nchunk = (W * H + kLossChunk - 1) / kLossChunk;
@@ -854,7 +988,37 @@ extern "C" int sdfr_inlier_ratio(const float* depth_input, const float* depth_es
     hipLaunchKernelGGL(inlier_count_kernel, dim3((npix + 1023) / 1024), dim3(256), 0, st, depth_input,
                        depth_estimate, npix, relative_threshold, counts);
   hipLaunchKernelGGL(inlier_update_kernel, dim3(1), dim3(256), 0, st, counts, step, history, max_history, state,
-                     params, n_params, best_params);
+                     params, n_params, best_params, (const float*)nullptr);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfr_inlier_counts_record(const float* depth_input, const float* depth_estimate, int W, int H,
+                                         float relative_threshold, int* counts, float* record, int device,
+                                         void* stream) {
+  if (W < 0 || H < 0 || (long long)W * H >= (1 << 24)) return fail(SDFR_E_INVALID, "sdfr_inlier_counts_record: bad sizes");
+  if (!depth_input || !depth_estimate || !counts || !record)
+    return fail(SDFR_E_NULL, "sdfr_inlier_counts_record: NULL pointer argument");
+  SDFR_HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  const int npix = W * H;
+  if (npix > 0)
+    hipLaunchKernelGGL(inlier_count_kernel, dim3((npix + 1023) / 1024), dim3(256), 0, st, depth_input,
+                       depth_estimate, npix, relative_threshold, counts);
+  hipLaunchKernelGGL(inlier_counts_to_record_kernel, dim3(1), dim3(64), 0, st, counts, record + 18);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfr_inlier_update_record(const float* record, const int* step, float* history, int max_history,
+                                         float* state, const float* params, int n_params, float* best_params,
+                                         int device, void* stream) {
+  if (n_params < 0 || max_history < 0) return fail(SDFR_E_INVALID, "sdfr_inlier_update_record: bad sizes");
+  if (!record || !step || !state || (n_params > 0 && best_params && !params))
+    return fail(SDFR_E_NULL, "sdfr_inlier_update_record: NULL pointer argument");
+  SDFR_HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(inlier_update_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (int*)nullptr, step, history,
+                     max_history, state, params, n_params, best_params, record + 18);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }

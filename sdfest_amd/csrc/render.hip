@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__(kBlock) SDFR_BWD_OCC void render_backward_kernel(
 // and in the captured loop each is a launch of its own that cannot fill the chip (1 200 small tiles, 13 blocks
 // of points): side by side they take max(12, 14) us instead of 12 + 14.  The first `pc_rows` rows of the grid
 // are the sampler's blocks (they take longest, so they start first), the rest the image tiles.
-template <int RT, bool BATCH>
+template <int RT, bool BATCH, bool DET = false>
 __global__ __launch_bounds__(kBlock) void render_backward_pc_kernel(
     const float* __restrict__ target, const float* __restrict__ depth,
     const float* __restrict__ sdf, int R, long long sdf_view_stride,
@@ -1180,16 +1180,18 @@ __global__ __launch_bounds__(kBlock) void render_backward_pc_kernel(
     float rfx, float rfy, int sdf_grad_mode, float* __restrict__ g_sdf,
     long long g_sdf_view_stride, float* __restrict__ partials, const float* __restrict__ loss_grad,
     const float* __restrict__ loss_stats, float loss_weight, int pc_rows, PcBackwardArgs pa) {
-  constexpr size_t kTileLds = BATCH ? sizeof(BackwardLds<BatchTable>) : sizeof(BackwardLds<SmallHash>);
+  constexpr size_t kBatchLds = (DET && sizeof(BackwardLds<BatchHash>) > sizeof(BackwardLds<BatchTable>))
+                                   ? sizeof(BackwardLds<BatchHash>) : sizeof(BackwardLds<BatchTable>);
+  constexpr size_t kTileLds = BATCH ? kBatchLds : sizeof(BackwardLds<SmallHash>);
   constexpr size_t kLdsBytes = kTileLds > sizeof(PcBackwardLds) ? kTileLds : sizeof(PcBackwardLds);
   __shared__ __attribute__((aligned(16))) unsigned char raw[kLdsBytes];
   const int b = blockIdx.z;
   if ((int)blockIdx.y < pc_rows) {
     const int bx = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
-    if (bx < pa.nblk) pc_backward_block<RT, true>(*reinterpret_cast<PcBackwardLds*>(raw), pa, bx, b);
+    if (bx < pa.nblk) pc_backward_block<RT, true, DET>(*reinterpret_cast<PcBackwardLds*>(raw), pa, bx, b);
     return;
   }
-  backward_dispatch<RT, BATCH, true>(raw, blockIdx.x, (int)blockIdx.y - pc_rows, ntx, nty, stride, b, target, depth,
+  backward_dispatch<RT, BATCH, true, DET>(raw, blockIdx.x, (int)blockIdx.y - pc_rows, ntx, nty, stride, b, target, depth,
                                      sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf,
                                      g_sdf_view_stride, partials, loss_grad, loss_stats, loss_weight);
 }
@@ -1553,12 +1555,13 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
     return fail(SDFR_E_INVALID, "g_sdf_view_stride must be 0 or R^3");
   const bool det = (sdf_grad_mode & SDFR_SDF_GRAD_DETERMINISTIC) != 0;
   const bool half_hint = (sdf_grad_mode & SDFR_BWD_HALF_GRID) != 0;
-  sdf_grad_mode &= ~(SDFR_SDF_GRAD_DETERMINISTIC | SDFR_BWD_HALF_GRID);
+  const bool small_tiles = (sdf_grad_mode & SDFR_BWD_SMALL_TILES) != 0;
+  sdf_grad_mode &= ~(SDFR_SDF_GRAD_DETERMINISTIC | SDFR_BWD_HALF_GRID | SDFR_BWD_SMALL_TILES);
   if (sdf_grad_mode != SDFR_SDF_GRAD_EXACT && sdf_grad_mode != SDFR_SDF_GRAD_CUDA_COMPAT)
     return fail(SDFR_E_INVALID, "unknown sdf_grad_mode %d", sdf_grad_mode);
-  if (det && (g_sdf_view_stride != 0 || R > kDetMaxR || loss_stats || pc))
+  if (det && (g_sdf_view_stride != 0 || R > kDetMaxR))
     return fail(SDFR_E_INVALID, "%s: SDFR_SDF_GRAD_DETERMINISTIC needs one shared gradient volume "
-                "(g_sdf_view_stride = 0), R <= %d and the plain (not loss-fused) backward", fn, kDetMaxR);
+                "(g_sdf_view_stride = 0) and R <= %d", fn, kDetMaxR);
   if (!g_sdf) return fail(SDFR_E_NULL, "%s: g_sdf is NULL", fn);
   SDFR_HIP_TRY(hipSetDevice(device));
   hipStream_t st = (hipStream_t)stream;
@@ -1604,8 +1607,15 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
     zero_words_async((float*)fixed, (size_t)vox * 2, st);
     g_sdf = (float*)fixed;
   }
+  PcBackwardArgs pc_det;
+  if (det && pc) {   // the sampler's blocks add into the same 64-bit volume
+    pc_det = *pc;
+    pc_det.g_sdf = (float*)fixed;
+    pc = &pc_det;
+  }
   // batch: `stride` workgroups per view, each view in its own tiling (common.hpp, kBwdBigTile); else 32 x 8 tiles
-  const TileGeom geom = backward_geom(B, W, H);
+  // (SDFR_BWD_SMALL_TILES: always those -- a view's pose sums then do not depend on how many views share the launch)
+  const TileGeom geom = small_tiles ? kSmallTile : backward_geom(B, W, H);
   const bool batch = geom.sx * geom.sy > 1;
   const int ntx = geom.nx(W), nty = geom.ny(H);
   const int stride = batch ? backward_tile_stride(W, H) : 0;
@@ -1621,9 +1631,15 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
   // loads in front of every tile of the rectangle cost more than the culled tiles' depth loads, step +3.5 us)
 #define SDFR_LAUNCH_BWD(RT, BATCH)                                                                   \
   do {                                                                                               \
-    if (pc)                                                                                          \
+    if (pc && det)                                                                                   \
+      hipLaunchKernelGGL((render_backward_pc_kernel<RT, BATCH, true>), grid_tile, dim3(kBlock), 0, st, \
+                         SDFR_BWD_ARGS, pc_rows, *pc);                                               \
+    else if (pc)                                                                                     \
       hipLaunchKernelGGL((render_backward_pc_kernel<RT, BATCH>), grid_tile, dim3(kBlock), 0, st,     \
                          SDFR_BWD_ARGS, pc_rows, *pc);                                               \
+    else if (with_loss && det)                                                                       \
+      hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, true, true>), grid_tile, dim3(kBlock), 0, st, \
+                         SDFR_BWD_ARGS);                                                      \
     else if (with_loss)                                                                              \
       hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, true>), grid_tile, dim3(kBlock), 0, st,  \
                          SDFR_BWD_ARGS);                                                      \

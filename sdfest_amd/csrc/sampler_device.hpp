@@ -89,7 +89,10 @@ struct PcBackwardLds {
 // the view's points (simple_setup.py:144): go = +-weight / M_v by the sign of the point's value, and
 // the block's sum of |value| goes to `loss_part` -- the loop then needs neither the sampler's
 // forward launch nor the loss launch.
-template <int RT, bool L1>
+// DET (SDFR_SDF_GRAD_DETERMINISTIC, render.hip): `g_sdf` is the 64-bit fixed-point volume; every point's eight
+// contributions are rounded once to the quantum 2^-SDFR_FIXED_QUANTUM_BITS and added as integers, straight to the
+// volume (no LDS table: the mode is for reproducible runs, not for speed).
+template <int RT, bool L1, bool DET = false>
 __device__ __forceinline__ void pc_backward_block(PcBackwardLds& lds, const PcBackwardArgs& a, int bx, int v) {
   SamplerHash& hash = lds.hash;
   float (&wave_part)[kPts / 64][8] = lds.wave_part;
@@ -119,7 +122,7 @@ __device__ __forceinline__ void pc_backward_block(PcBackwardLds& lds, const PcBa
   const float* vol = sdf + (size_t)v * sdf_view_stride;
   float* gvol = g_sdf + (size_t)v * g_sdf_view_stride;
 
-  hash.clear(tid, kPts);
+  if (!DET) hash.clear(tid, kPts);
   if (tid == 0) blk_max_bits = 0;
 
   bool live = false;
@@ -189,7 +192,18 @@ __device__ __forceinline__ void pc_backward_block(PcBackwardLds& lds, const PcBa
     const float w4 = x1w * ay * az, w5 = x1w * ay * c.oz, w6 = x1w * c.oy * az, w7 = x1w * c.oy * c.oz;
     // (a NaN upstream gradient can be dropped by the block's fmaxf-based maximum: such a lane, like
     // any lane beyond the fixed-point range, adds in float, so NaN/Inf reach g_sdf as in autograd)
-    if (fixed_ok && fabsf(gs) * to_fixed < SamplerHash::kWeightLimit) {
+    if (DET) {
+      // (not finite: the conversion saturates, NaN counts as 0 -- include/sdfr.h)
+      if (go != 0.0f) {
+        unsigned long long* g0 = reinterpret_cast<unsigned long long*>(gvol) + c.lin;
+        const float wk[8] = {w0, w1, w2, w3, w4, w5, w6, w7};
+        const float q = (float)(1ll << SDFR_FIXED_QUANTUM_BITS);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          atomicAdd(g0 + ((j & 4) ? Rr * Rr : 0) + ((j & 2) ? Rr : 0) + (j & 1),
+                    (unsigned long long)__float2ll_rn(wk[j] * q));
+      }
+    } else if (fixed_ok && fabsf(gs) * to_fixed < SamplerHash::kWeightLimit) {
       const float wk[8] = {w0, w1, w2, w3, w4, w5, w6, w7};
       hash.add_cell(gvol, c.lin, Rr, wk, to_fixed);
     } else if (go != 0.0f) {
@@ -225,7 +239,7 @@ __device__ __forceinline__ void pc_backward_block(PcBackwardLds& lds, const PcBa
   int e2;
   (void)frexpf(bound, &e2);
   const float from_fixed = ldexpf(1.0f, e2 - SamplerHash::kBits);
-  hash.flush(gvol, Rr * Rr * Rr, from_fixed, tid, kPts);
+  if (!DET) hash.flush(gvol, Rr * Rr * Rr, from_fixed, tid, kPts);
 }
 
 

@@ -45,6 +45,8 @@ SDF_GRAD_CUDA_COMPAT = 1
 SDF_GRAD_DETERMINISTIC = 0x100    # flag bit: integer accumulation of d/dSDF, bitwise reproducible
 FIXED_QUANTUM_BITS = 40
 BWD_HALF_GRID = 0x200             # flag bit: performance hint "every view is close" (views_are_close)
+BWD_SMALL_TILES = 0x400           # flag bit: 32 x 8 backward tiles whatever the batch (pose sums independent of it)
+VIEW_RECORD_FLOATS = 20           # SDFR_VIEW_RECORD_FLOATS: the sharded loop's exchange record of one view
 
 
 def close_view_fraction(position, inv_scale, camera: "Camera", R: int) -> float:
@@ -419,11 +421,17 @@ class BatchRenderPlan:
     """
 
     def __init__(self, R: int, B: int, camera: Camera, device="cuda", per_view_sdf: bool = False,
-                 sdf_grad_mode: int = 0, grad_volumes: int = 2, close_views: bool = False):
+                 sdf_grad_mode: int = 0, grad_volumes: int = 2, close_views: bool = False,
+                 grad_tail_words: int = 0):
         """close_views: the caller's hint that (nearly) all views are close (``views_are_close``); the backward
-        then launches half the workgroups.  Same results either way; views that are not close are slower with it."""
+        then launches half the workgroups.  Same results either way; views that are not close are slower with it.
+        grad_tail_words: every gradient volume of the ring is followed by this many float32 words of the caller's
+        (``g_tail``): volume and tail are one contiguous bucket (``g_bucket``), e.g. ONE all-reduce over the ranks of a
+        sharded batch carries d/dSDF and whatever small per-view results ride along."""
         if grad_volumes < 2:
             raise ValueError("grad_volumes must be >= 2")
+        if grad_tail_words < 0 or (grad_tail_words and per_view_sdf):
+            raise ValueError("grad_tail_words needs the shared gradient volume")
         self.device = torch.device(device)
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
@@ -446,10 +454,18 @@ class BatchRenderPlan:
         # forward's prologue: `grad_volumes` volumes take turns, so the g_sdf of the previous grad_volumes - 1
         # steps (e.g. still being all-reduced) are not touched by the next forward
         # (one contiguous buffer, ``grad_ring``: several steps' volumes can then go into ONE all-reduce)
-        self.grad_ring = torch.empty((grad_volumes,) + tuple(self.g_sdf.shape), **f32)
-        self._g_sdf_ring = list(self.grad_ring.unbind(0))
+        if grad_tail_words:
+            # 16-byte multiple per bucket: every volume of the ring stays aligned for the kernels' vector stores
+            self._bucket_ring = torch.zeros((grad_volumes, R * R * R + (grad_tail_words + 3) // 4 * 4), **f32)
+            self.grad_ring = None
+            self._g_sdf_ring = [b[:R * R * R].view(R, R, R) for b in self._bucket_ring.unbind(0)]
+        else:
+            self._bucket_ring = None
+            self.grad_ring = torch.empty((grad_volumes,) + tuple(self.g_sdf.shape), **f32)
+            self._g_sdf_ring = list(self.grad_ring.unbind(0))
         self.g_sdf = self._g_sdf_ring[-1]
         self._g_sdf_next = 0
+        self._g_sdf_index = grad_volumes - 1   # which volume of the ring self.g_sdf is
         self._step = None   # what the last forward prepared: (tensor ids / versions, depth tensor)
         self._fixed_layout = None   # deterministic mode: which workspace layout holds the last int64 volume
         self._step_l1 = None        # the volume a forward_l1(prepare_backward=True) zero-filled
@@ -497,6 +513,30 @@ class BatchRenderPlan:
         """The next step writes ``grad_ring[0]`` again (a caller that exchanges halves of the ring aligns them)."""
         self._g_sdf_next = 0
         self._step = None
+        self._step_l1 = None
+
+    def select_volume(self, index: int) -> None:
+        """Make ring volume `index` the one the next stand-alone backward writes (``self.g_sdf``); a step's backward
+        writes the volume its forward prepared instead."""
+        self.g_sdf = self._g_sdf_ring[index]
+        self._g_sdf_index = index
+
+    @property
+    def g_bucket(self) -> torch.Tensor:
+        """The flat bucket [R^3 words of ``g_sdf`` | tail] of the volume the last backward wrote (``grad_tail_words``)."""
+        if self._bucket_ring is None:
+            raise RuntimeError("the plan was made without grad_tail_words")
+        return self._bucket_ring[self._g_sdf_index]
+
+    @property
+    def g_tail(self) -> torch.Tensor:
+        return self.g_bucket[self.R ** 3:]
+
+    def next_bucket(self) -> torch.Tensor:
+        """The bucket the NEXT step (``forward*(prepare_backward=True)`` + its backward) will write."""
+        if self._bucket_ring is None:
+            raise RuntimeError("the plan was made without grad_tail_words")
+        return self._bucket_ring[self._g_sdf_next]
 
     def prologue_fallbacks(self) -> int:
         """How many view set-ups of this plan's forwards so far had to do without the grid's plane minima
@@ -524,6 +564,7 @@ class BatchRenderPlan:
         if out is not None and (out.shape != self.depth.shape or out.dtype != torch.float32
                                 or not out.is_contiguous() or out.device != self.depth.device):
             raise RuntimeError("out must be a contiguous float32 tensor of shape (B, H, W) on the plan's device")
+        self._step_l1 = None   # a forward_l1(prepare_backward=True) whose backward never came: its view records are gone
         if prepare_backward:
             nxt = self._g_sdf_ring[self._g_sdf_next]
             rc = self._L.sdfr_render_step_forward(
@@ -555,6 +596,7 @@ class BatchRenderPlan:
         between the halves of a step."""
         self._check(sdf, pos, quat, inv_scale, grad_depth=grad_depth)
         step, self._step = self._step, None
+        self._step_l1 = None
         if step is not None and not defer_pose and step[0] == self._key(sdf, pos, quat, inv_scale):
             _, depth, g_sdf = step
             rc = self._L.sdfr_render_step_backward(
@@ -565,6 +607,7 @@ class BatchRenderPlan:
                 self.device.index, _stream(self.device))
             _lib.check(rc, "sdfr_render_step_backward")
             self.g_sdf = g_sdf
+            self._g_sdf_index = self._g_sdf_next
             self._g_sdf_next = (self._g_sdf_next + 1) % len(self._g_sdf_ring)
             self._fixed_layout = 1
             return self.g_sdf, self.g_pos, self.g_quat, self.g_inv_scale
@@ -574,6 +617,7 @@ class BatchRenderPlan:
             # stand-alone backward, but into the volume the forward prepared -- the previous step's volume may
             # still be in an asynchronous all-reduce -- and of the images that forward rendered
             _, depth, self.g_sdf = step
+            self._g_sdf_index = self._g_sdf_next
             self._g_sdf_next = (self._g_sdf_next + 1) % len(self._g_sdf_ring)
         rc = self._L.sdfr_render_backward(
             grad_depth.data_ptr(), depth.data_ptr(), sdf.data_ptr(), self.R, self.sdf_stride,
@@ -615,7 +659,7 @@ class BatchRenderPlan:
                 self.sdf_stride, self.workspace.data_ptr(), self.workspace.numel(), self.device.index,
                 _stream(self.device))
             _lib.check(rc, "sdfr_render_step_forward_l1")
-            self._step_l1 = nxt
+            self._step_l1 = (self._key(sdf, pos, quat, inv_scale), nxt)
             return self.depth, self.loss
         self._step_l1 = None
         rc = self._L.sdfr_render_forward_l1(
@@ -632,6 +676,7 @@ class BatchRenderPlan:
         """gradients of sum_b weight * loss_grad[b] * loss[b] (after ``forward_l1``); ``defer_pose`` as in
         ``backward``."""
         self._step = None   # the workspace is about to be re-used
+        self._step_l1 = None
         self._check(sdf, pos, quat, inv_scale, target=target)
         if loss_grad is not None:
             _check_input(loss_grad, "loss_grad")
@@ -671,13 +716,22 @@ class BatchRenderPlan:
             raise RuntimeError(f"offsets must be a contiguous int32 tensor of shape ({self.B + 1},) on {dev}")
         if pc_workspace.device != dev or not pc_workspace.is_contiguous() or pc_workspace.dtype is not torch.uint8:
             raise RuntimeError(f"pc_workspace must be a contiguous uint8 tensor on {dev}")
-        prepared, self._step_l1 = getattr(self, "_step_l1", None), None
-        if prepared is not None:   # second half of a step begun by forward_l1(prepare_backward=True)
-            self.g_sdf = prepared
+        prepared, self._step_l1 = self._step_l1, None
+        if prepared is not None:
+            # second half of a step begun by forward_l1(prepare_backward=True): its backward writes the volume that
+            # forward zero-filled.  As a step's backward (no prologue, the forward's view records and rectangles)
+            # only for the very tensors the forward saw, judged like ``backward`` does (address and version counter)
+            key, self.g_sdf = prepared
+            self._g_sdf_index = self._g_sdf_next
             self._g_sdf_next = (self._g_sdf_next + 1) % len(self._g_sdf_ring)
+            if key != self._key(sdf, pos, quat, inv_scale):
+                prepared = None
+        if prepared is not None:
             self.partials_offset = self._L.sdfr_render_partials_offset(self.R, self.B, self.W, self.H, 1)
+            self._fixed_layout = 1
         else:
             self.partials_offset = self._L.sdfr_render_partials_offset(self.R, self.B, self.W, self.H, 0)
+            self._fixed_layout = 0
         fn = self._L.sdfr_render_step_backward_l1_pc if prepared is not None else self._L.sdfr_render_backward_l1_pc
         rc = fn(
             loss_grad.data_ptr() if loss_grad is not None else None, weight,

@@ -27,6 +27,38 @@ def _dist():
     return dist if dist.is_available() and dist.is_initialized() else None
 
 
+def resolve_group(process_group):
+    """(group, rank, world_size) of a caller's ``process_group`` argument: None -> single process (no exchange at
+    all); "world" -> the default group of an initialised torch.distributed; otherwise a ProcessGroup."""
+    if process_group is None:
+        return None, 0, 1
+    dist = _dist()
+    if dist is None:
+        raise RuntimeError("a process group was given but torch.distributed is not initialised "
+                           "(call torch.distributed.init_process_group first: backend 'nccl' is RCCL on ROCm)")
+    group = dist.group.WORLD if isinstance(process_group, str) and process_group == "world" else process_group
+    return group, dist.get_rank(group), dist.get_world_size(group)
+
+
+def allreduce_bucket(bucket: torch.Tensor, group=None, integer: bool = False) -> torch.Tensor:
+    """The sharded loop's ONE exchange per iteration: sum `bucket` over the ranks of `group`, in place.
+
+    integer=True: the bucket is summed as 64-bit integers (its bytes reinterpreted) -- exact and order-independent
+    for the deterministic mode's fixed-point volume, and for float words that are non-zero on one rank only (the view
+    records): x + 0 + ... + 0 reproduces x bit for bit whatever it holds."""
+    dist = _dist()
+    if dist is None or group is None:
+        return bucket
+    flat = bucket.view(-1)
+    if integer:
+        if flat.dtype != torch.int64:
+            if (flat.numel() * flat.element_size()) % 8:
+                raise RuntimeError("an integer exchange needs a bucket of a multiple of 8 bytes")
+            flat = flat.view(torch.int64)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return bucket
+
+
 class _Done:
     """Handle of an exchange that needed no communication."""
 

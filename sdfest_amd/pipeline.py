@@ -89,11 +89,18 @@ class RenderAndCompare:
     ``depth_weight``, ``pc_weight``; learning rates are the reference's (simple_setup.py:400-405).
     """
 
-    def __init__(self, decoder, camera: Camera, config: Dict, device="cuda"):
+    def __init__(self, decoder, camera: Camera, config: Dict, device="cuda", process_group=None):
+        """process_group (None | "world" | a torch.distributed group): the V views of a call are sharded over the
+        group's ranks (``parallel.shard_views``); every rank passes the SAME full list and the same initial estimate,
+        renders its shard, and the four parameter gradients (3 + 4 + 1 + L floats: autograd has already run the
+        decoder's VJP on the rank's own d/dSDF, and the VJP is linear) are summed by ONE all-reduce before the
+        replicated Adam step.  No broadcast: every rank ends with the same estimate."""
+        from .parallel import resolve_group
         self.decoder = decoder
         self.cam = camera
         self.config = config
         self.device = torch.device(device)
+        self.group, self.rank, self.world = resolve_group(process_group)
 
     def prepare_views(self, depth_images: torch.Tensor):
         """Observed point clouds of all views, concatenated, with their segment offsets.  Done once
@@ -149,12 +156,22 @@ class RenderAndCompare:
         _selection_strategy(self.config)
         rel_thr = self.config.get("relative_inlier_threshold", 0.03)
         self.best = _BestEstimate()
-        V = depth_images.shape[0]
+        V_all = depth_images.shape[0]
         dev = self.device
         if camera_positions is None:
-            camera_positions = torch.zeros((V, 3), device=dev)
+            camera_positions = torch.zeros((V_all, 3), device=dev)
         if camera_orientations is None:
-            camera_orientations = torch.tensor([0.0, 0.0, 0.0, 1.0], device=dev).repeat(V, 1)
+            camera_orientations = torch.tensor([0.0, 0.0, 0.0, 1.0], device=dev).repeat(V_all, 1)
+        if self.group is not None:
+            import torch.distributed as dist
+            from .parallel import shard_views
+            b, e = shard_views(V_all, self.rank, self.world)
+            if e == b:
+                raise ValueError(f"{V_all} view(s) cannot be sharded over {self.world} ranks: every rank needs one")
+            owns_last = e == V_all
+            depth_images, camera_positions, camera_orientations = (depth_images[b:e], camera_positions[b:e],
+                                                                   camera_orientations[b:e])
+        V = depth_images.shape[0]
         position = position.detach().clone().requires_grad_()
         orientation = orientation.detach().clone().requires_grad_()
         scale = scale.detach().clone().requires_grad_()
@@ -177,15 +194,40 @@ class RenderAndCompare:
                                                        tgt.to(dev, torch.float32))
             else:
                 loss_con = orientation.new_tensor(0.0)
+            if self.group is not None:
+                loss_con = loss_con / self.world   # the constraint is not a per-view term: once over the ranks
             loss = (self.config["depth_weight"] * loss_depth + self.config["pc_weight"] * loss_pc
                     + loss_con)
             loss.backward()
+            if self.group is not None:
+                # the iteration's ONE exchange: [d/d position | orientation | scale | latent | loss terms | inlier counts]
+                with torch.no_grad():
+                    last_in, last_est = depth_images[V - 1], est[V - 1].detach()
+                    rel = torch.abs(last_in - last_est) / last_in
+                    counts = torch.stack((torch.count_nonzero(rel < rel_thr), torch.count_nonzero(last_in))).float()
+                    lat_g = latent.grad if latent.grad is not None else torch.zeros_like(latent)
+                    flat = torch.cat([position.grad.reshape(-1), orientation.grad.reshape(-1), scale.grad.reshape(-1),
+                                      lat_g.reshape(-1), torch.stack((loss_depth.detach(), loss_pc.detach(),
+                                                                      loss_con.detach())),
+                                      counts * float(owns_last)])
+                    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                    n = 0
+                    for prm in (position, orientation, scale, latent):
+                        if prm.grad is not None:
+                            prm.grad.copy_(flat[n:n + prm.numel()].view_as(prm))
+                        n += prm.numel()
+                    loss_depth, loss_pc, loss_con = flat[n], flat[n + 1], flat[n + 2]
+                    loss = (self.config["depth_weight"] * loss_depth + self.config["pc_weight"] * loss_pc + loss_con)
+                    counts = flat[n + 3:n + 5]
             optimizer.step()
             with torch.no_grad():
                 orientation /= torch.sqrt(torch.sum(orientation ** 2))
                 # the reference passes the loop variables that survive its `for` over the views: the
                 # LAST view's input and estimate, rendered before this step (:463-470)
-                ratio = compute_inlier_ratio(depth_images[V - 1], est[V - 1].detach(), rel_thr)
+                if self.group is not None:
+                    ratio = counts[0] / counts[1]
+                else:
+                    ratio = compute_inlier_ratio(depth_images[V - 1], est[V - 1].detach(), rel_thr)
                 self.best.update(ratio, it + 1, (position, orientation, scale, latent))
             if history is not None:
                 history.append({"loss": loss.detach(), "loss_depth": loss_depth.detach(),
@@ -211,8 +253,22 @@ class FusedRenderAndCompare:
                  camera_orientations: Optional[torch.Tensor] = None,
                  shape_optimization: bool = True, device="cuda", fuse_depth_loss: bool = True,
                  point_constraint: Optional[Sequence] = None, track_inliers: Optional[bool] = None,
-                 merge_launches: bool = True, graph_iterations: int = 5):
+                 merge_launches: bool = True, graph_iterations: int = 5, process_group=None,
+                 exchange: str = "sdf", sdf_grad_mode: int = 0):
         """point_constraint: (source (3,), target (3,), weight), simple_setup.py:164-175.
+        process_group (None | "world" | a torch.distributed group): the loop SHARDED over the group's ranks, one process
+        per GPU.  Every rank is given the same full view list, cameras and initial estimate and keeps its contiguous
+        shard of the views (``parallel.shard_views``).  An iteration then has exactly ONE exchange, an all-reduce of one
+        bucket, between the two backward passes and the update (include/sdfr.h, "the loop sharded over ranks"):
+          exchange="sdf"     [d loss / d SDF, R^3 words | one 20-float record per view]: every rank then
+                             runs the identical decoder VJP, chain and Adam step on the summed volume;
+          exchange="latent"  every rank runs the decoder VJP on ITS d/dSDF (the VJP is linear) and the bucket is
+                             [view records | d loss / d latent]: 80 V + 4 L bytes instead of 1 MiB.  Same result up to
+                             the rounding of the sum.
+        Parameters and Adam state are replicated and stay identical on every rank; nothing is broadcast.
+        sdf_grad_mode: flag bits for the renderer's backward (differentiable_renderer.SDF_GRAD_*, BWD_*).  With
+        ``SDF_GRAD_DETERMINISTIC | BWD_SMALL_TILES`` and exchange="sdf" the bucket is summed as integers and the
+        trajectory is bitwise the same however the views are spread over ranks (and as a single process).
         graph_iterations: iterations per replayed hipGraph (a graph launch costs ~5-8 us between iterations; the
         remainder of max_iterations and runs with ``history`` replay the one-iteration graph).
         merge_launches: the per-view reductions of both backward passes run inside the gradient chain's launch
@@ -236,6 +292,37 @@ class FusedRenderAndCompare:
         if self.dev.index is None:
             self.dev = torch.device("cuda", torch.cuda.current_device())
         self.shape_opt = bool(shape_optimization)
+        from .differentiable_renderer import BWD_SMALL_TILES, SDF_GRAD_DETERMINISTIC, VIEW_RECORD_FLOATS
+        from .parallel import resolve_group, shard_views
+        if exchange not in ("sdf", "latent"):
+            raise ValueError(f"exchange must be 'sdf' or 'latent', got {exchange!r}")
+        self.group, self.rank, self.world = resolve_group(process_group)
+        self.exchange = exchange
+        self.sdf_grad_mode = int(sdf_grad_mode)
+        self.det = bool(self.sdf_grad_mode & SDF_GRAD_DETERMINISTIC)
+        # the records form of the iteration: head (decoder .. both backward passes .. view records), [exchange],
+        # tail (decoder VJP, chain over ALL views' records, Adam, next poses).  A single process takes it too when
+        # the pose sums are asked to be independent of the batch (BWD_SMALL_TILES): same arithmetic as the ranks'.
+        self.records_form = self.group is not None or bool(self.sdf_grad_mode & BWD_SMALL_TILES)
+        self.V_all = int(depth_images.shape[0])
+        self.view_begin, self.view_end = shard_views(self.V_all, self.rank, self.world)
+        if self.view_end == self.view_begin:
+            raise ValueError(f"{self.V_all} view(s) cannot be sharded over {self.world} ranks: every rank needs one")
+        if self.records_form and not fuse_depth_loss:
+            raise ValueError("the sharded loop runs the loss-fused kernels (fuse_depth_loss=True)")
+        if self.det and not self.records_form:
+            raise ValueError("SDF_GRAD_DETERMINISTIC in the loop goes with BWD_SMALL_TILES (or a process group)")
+        self.cam_pos_all = self.cam_quat_all = None
+        if self.group is not None:
+            n_all = self.V_all
+            f32a = dict(dtype=torch.float32, device=self.dev)
+            self.cam_pos_all = (torch.zeros((n_all, 3), **f32a) if camera_positions is None
+                                else camera_positions.to(**f32a).contiguous())
+            self.cam_quat_all = (torch.tensor([0.0, 0.0, 0.0, 1.0], **f32a).repeat(n_all, 1)
+                                 if camera_orientations is None else camera_orientations.to(**f32a).contiguous())
+            camera_positions = self.cam_pos_all[self.view_begin:self.view_end]
+            camera_orientations = self.cam_quat_all[self.view_begin:self.view_end]
+            depth_images = depth_images[self.view_begin:self.view_end]
         V, H, W = depth_images.shape
         self.V, self.H, self.W = V, H, W
         self.defer_pose = bool(merge_launches) and V <= 64
@@ -260,7 +347,28 @@ class FusedRenderAndCompare:
         self.step = torch.zeros(1, dtype=torch.int32, device=self.dev)
         R = decoder._volume_size
         self.R = R
-        self.plan = BatchRenderPlan(R, V, camera, device=self.dev)
+        n_rec = self.V_all * VIEW_RECORD_FLOATS
+        self.big_exchange = self.records_form and self.shape_opt and exchange == "sdf"
+        self.plan = BatchRenderPlan(R, V, camera, device=self.dev, sdf_grad_mode=self.sdf_grad_mode,
+                                    grad_tail_words=n_rec if (self.big_exchange and not self.det) else 0)
+        self.xbuf = self.records = None
+        if self.records_form:
+            if self.cam_pos_all is None:
+                self.cam_pos_all, self.cam_quat_all = self.cam_pos, self.cam_quat
+            if self.big_exchange and self.det:     # [int64 volume | records]
+                self.xbuf = torch.zeros(R ** 3 + n_rec // 2, dtype=torch.int64, device=self.dev)
+                self.records = self.xbuf[R ** 3:].view(torch.float32)
+            elif self.big_exchange:                # the plan's bucket [float volume | records]
+                self.xbuf = self.plan._bucket_ring[0]
+                self.records = self.xbuf[R ** 3:R ** 3 + n_rec]
+            else:                                  # [records | gradient vector] (the latter only travels for "latent")
+                with_g = self.shape_opt and exchange == "latent"
+                n_x = n_rec + (n + n % 2 if with_g else 0)
+                self.xbuf = torch.zeros(n_x, **f32)
+                self.records = self.xbuf[:n_rec]
+                if with_g:
+                    self.grads = self.xbuf[n_rec:n_rec + n]
+            self.owns_last = self.view_end == self.V_all
         self.pos_c = torch.empty((V, 3), **f32)
         self.quat_c = torch.empty((V, 4), **f32)
         self.inv_scale = torch.empty((V,), **f32)
@@ -455,6 +563,149 @@ class FusedRenderAndCompare:
                    "sdfr_adam_step")
         self._inliers(L, p, d, st)
 
+    # ---- the records form: head | exchange | tail (the loop sharded over ranks) -----------------------------------
+
+    def _head(self):
+        """This rank's share of simple_setup.py:408-446: the (replicated) decoder, the render / compare / sample of its
+        own views with both backward passes, and its views' exchange records."""
+        from .differentiable_renderer import VIEW_RECORD_FLOATS
+        L, d, st = self.L, self.dev.index, self._stream()
+        if self.shape_opt:
+            self._decode(st, True)
+        sdf = self.sdf[0, 0]
+        self.plan.ring_reset()       # always the plan's first volume: the bucket's address is part of captured graphs
+        have_pts = self.max_pts > 0
+        self.plan.forward_l1(sdf, self.pos_c, self.quat_c, self.inv_scale, self.cfg["threshold"], self.target,
+                             prepare_backward=have_pts)
+        if have_pts:
+            g_sdf = self.plan.backward_l1_pc(self.target, sdf, self.pos_c, self.quat_c, self.inv_scale, self.scale_v,
+                                             self.points, self.offsets, self.max_pts, self.ws_pc,
+                                             weight=self.cfg["depth_weight"], pc_weight=self.cfg["pc_weight"])
+        else:       # none of this rank's views has an observed point: the depth term alone
+            self.plan.select_volume(0)
+            g_sdf = self.plan.backward_l1(self.target, sdf, self.pos_c, self.quat_c, self.inv_scale,
+                                          weight=self.cfg["depth_weight"], defer_pose=True)[0]
+            self.plan.partials_offset = L.sdfr_render_partials_offset(self.R, self.V, self.W, self.H, 0)
+        if self.shape_opt and self.exchange == "latent":
+            # the whole VJP on this rank's volume: d loss / d latent is what travels
+            self.check(L.sdfr_decoder_backward_latent(self.dec._h, self.latent.data_ptr(), self.tape.data_ptr(),
+                                                      g_sdf.data_ptr(), 1, self.grads.data_ptr() + 32,
+                                                      self.ws_dec.data_ptr(), self.ws_dec.numel(), st),
+                       "sdfr_decoder_backward_latent")
+        elif self.big_exchange and self.det:
+            self.xbuf[:self.R ** 3].copy_(self.plan.g_sdf_fixed().view(-1))
+        self.check(L.sdfr_loop_view_records(
+            self.plan.workspace.data_ptr(), self.plan.partials_offset, self.W, self.H, self.sdf_grad_mode,
+            self.ws_pc.data_ptr() if have_pts else None, 1 if have_pts else 0,
+            self.offsets.data_ptr() if have_pts else None, self.max_pts, self.quat_c.data_ptr(),
+            self.plan.loss.data_ptr(), self.view_begin, self.V, self.V_all, self.records.data_ptr(), d, st),
+            "sdfr_loop_view_records")
+        if self.track_inliers and self.owns_last:
+            # :463-470 -- the LAST view's input and the estimate rendered before this step
+            self.check(L.sdfr_inlier_counts_record(
+                self.target[self.V - 1].data_ptr(), self.plan.depth[self.V - 1].data_ptr(), self.W, self.H, self.rel_thr,
+                self.inlier_counts.data_ptr(), self.records.data_ptr() + 4 * VIEW_RECORD_FLOATS * (self.V_all - 1), d, st),
+                "sdfr_inlier_counts_record")
+
+    def _exchange(self):
+        """The iteration's one collective (RCCL over xGMI with backend "nccl"); nothing without a group."""
+        from .parallel import allreduce_bucket
+        if self.group is not None:
+            allreduce_bucket(self.xbuf, self.group, integer=self.det)
+
+    def _tail(self):
+        """simple_setup.py:448-462 on every rank alike: decoder VJP of the summed volume, the chain over all views'
+        records, point constraint, Adam, renormalisation -- and this rank's view poses for the next iteration."""
+        from .differentiable_renderer import VIEW_RECORD_FLOATS
+        L, d, st = self.L, self.dev.index, self._stream()
+        p, g = self.params.data_ptr(), self.grads.data_ptr()
+        t_mid = None
+        if self.big_exchange:
+            g_sdf = self.plan.g_sdf
+            if self.det:
+                self.check(L.sdfr_fixed_to_float(self.xbuf.data_ptr(), self.R ** 3, g_sdf.data_ptr(), d, st),
+                           "sdfr_fixed_to_float")
+            t_mid = ctypes.c_void_p()
+            self.check(L.sdfr_decoder_backward_latent_deferred(
+                self.dec._h, self.latent.data_ptr(), self.tape.data_ptr(), g_sdf.data_ptr(), self.ws_dec.data_ptr(),
+                self.ws_dec.numel(), st, ctypes.byref(t_mid)), "sdfr_decoder_backward_latent_deferred")
+        con = self.pc_source is not None
+        self.check(L.sdfr_loop_tail_records(
+            p, g, self.m.data_ptr(), self.v.data_ptr(), self.step.data_ptr(), 8 + self.Lz, 1e-3, 1e-2, 1e-3, 1e-2,
+            int(self.shape_opt), self.cam_pos_all.data_ptr(), self.cam_quat_all.data_ptr(), self.V_all,
+            self.view_begin, self.V, self.records.data_ptr(), self.pos_c.data_ptr(), self.quat_c.data_ptr(),
+            self.inv_scale.data_ptr(), self.scale_v.data_ptr(),
+            self.pc_source.data_ptr() if con else None, self.pc_target.data_ptr() if con else None,
+            self.pc_weight if con else 0.0, self.loss_con.data_ptr() if con else None,
+            self.dec._h if t_mid is not None else None, t_mid, d, st), "sdfr_loop_tail_records")
+        if self.track_inliers:
+            self.check(L.sdfr_inlier_update_record(
+                self.records.data_ptr() + 4 * VIEW_RECORD_FLOATS * (self.V_all - 1), self.step.data_ptr(),
+                self.inlier_history.data_ptr(), self.max_history, self.best_state.data_ptr(), p, 8 + self.Lz,
+                self.best_params.data_ptr(), d, st), "sdfr_inlier_update_record")
+
+    def view_losses(self):
+        """(depth loss, point-cloud loss) of every view of the last iteration, (V_all,) each -- on every rank after
+        the exchange of the records form; this process's own views otherwise."""
+        if self.records_form:
+            from .differentiable_renderer import VIEW_RECORD_FLOATS
+            rec = self.records.view(self.V_all, VIEW_RECORD_FLOATS)
+            return rec[:, 16], rec[:, 17]
+        return self.loss_depth, self.loss_pc
+
+    def _run_records(self, n_iter, use_graph, history):
+        state = (self.params, self.m, self.v, self.step, self.inlier_counts, self.best_state, self.inlier_history,
+                 self.best_params)
+        if use_graph and self.graph is None:
+            # warm up on a side stream (lazy module loads; every rank takes part in the exchange), restore, capture:
+            # the collective stays outside the graphs -- head | all-reduce | tail+head | all-reduce | ... | tail
+            saved = [t.clone() for t in state]
+            side = torch.cuda.Stream(self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                self._head()
+                self._exchange()
+                self._tail()
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+            for t, c in zip(state, saved):
+                t.copy_(c)
+            # (thread-local capture: the process group's watchdog thread may query events while this thread captures)
+            mode = dict(capture_error_mode="thread_local") if self.group is not None else {}
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, **mode):
+                self._head()
+            self.graph_tail = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_tail, **mode):
+                self._tail()
+            self.graph_many = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_many, **mode):
+                self._tail()
+                self._head()
+            for t, c in zip(state, saved):
+                t.copy_(c)
+            self._poses_to_views(self._stream())
+        fused = use_graph and history is None
+        for it in range(n_iter):
+            if not use_graph:
+                self._head()
+            elif not fused or it == 0:
+                self.graph.replay()
+            self._exchange()
+            if not use_graph:
+                self._tail()
+            elif fused and it + 1 < n_iter:
+                self.graph_many.replay()     # this iteration's tail and the next one's head
+            else:
+                self.graph_tail.replay()
+            if history is not None:
+                ld, lp = self.view_losses()
+                history.append({"loss": (self.cfg["depth_weight"] * ld.sum() + self.cfg["pc_weight"] * lp.sum()
+                                         + self.loss_con.sum()).clone(),
+                                "loss_depth": ld.clone(), "loss_pc": lp.clone(),
+                                "position": self.position.clone()[None],
+                                "orientation": self.orientation.clone()[None],
+                                "scale": self.scale.clone(), "latent": self.latent.clone()[None]})
+
     def _tail_form(self) -> bool:
         return (self.merge_tail and self.fuse_depth_loss and self.defer_pose and self.max_pts > 0
                 and 8 + self.Lz <= 256)
@@ -490,9 +741,14 @@ class FusedRenderAndCompare:
             self.inlier_counts.zero_(); self.best_state.zero_(); self.inlier_history.zero_()
         if not self.shape_opt:
             self._decode(self._stream(), False)
+        n_iter = self.cfg["max_iterations"]
+        if self.records_form:
+            self._poses_to_views(self._stream())
+            self._run_records(n_iter, use_graph, history)
+            return (self.position.clone()[None], self.orientation.clone()[None], self.scale.clone(),
+                    self.latent.clone()[None])
         if self._tail_form():
             self._poses_to_views(self._stream())   # every later iteration gets its view poses from the tail before it
-        n_iter = self.cfg["max_iterations"]
         if use_graph and self.graph is None:
             # warm up on a side stream (lazy module loads), restore the state, then capture
             state = (self.params, self.m, self.v, self.step, self.inlier_counts, self.best_state,

@@ -1,0 +1,63 @@
+"""Worker of tests/test_loop_sharded_gpu.py: one rank of the render-and-compare loop sharded over ranks
+(sdfest_amd.pipeline, ``process_group``).  The ranks of the test share the box's one GPU, so the process group is gloo
+on device tensors; on a multi-GPU node the same code runs over RCCL (backend "nccl").  Rank 0 writes the trajectory
+for the test to compare with a single process."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import _loop_scenes  # noqa: E402
+
+
+def main():
+    out_path, scene, flavour, exchange, graph, form = sys.argv[1:7]
+    backend = sys.argv[7] if len(sys.argv) > 7 else "gloo"
+    from sdfest_amd.differentiable_renderer import BWD_SMALL_TILES, SDF_GRAD_DETERMINISTIC
+    from sdfest_amd.pipeline import FusedRenderAndCompare, RenderAndCompare
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    sc = _loop_scenes.build(scene)
+    mode = (SDF_GRAD_DETERMINISTIC | BWD_SMALL_TILES) if flavour == "det" else 0
+    hist = []
+    if form == "fused":
+        loop = FusedRenderAndCompare(sc["decoder"], sc["camera"], sc["config"], sc["depth"], camera_positions=sc["cam_pos"],
+                                     camera_orientations=sc["cam_quat"], shape_optimization=True, process_group="world",
+                                     exchange=exchange, sdf_grad_mode=mode, track_inliers=True)
+        out = loop(*sc["init"], use_graph=(graph == "graph"), history=hist)
+        inl = loop.inlier_history.cpu().numpy()
+        shard = (loop.view_begin, loop.view_end)
+    else:
+        loop = RenderAndCompare(sc["decoder"], sc["camera"], sc["config"], process_group="world")
+        out = loop(sc["depth"], *sc["init"], camera_positions=sc["cam_pos"], camera_orientations=sc["cam_quat"],
+                   shape_optimization=True, history=hist)
+        inl = np.array([float(h["inlier_ratio"]) for h in hist], dtype=np.float32)
+        shard = (-1, -1)
+    torch.cuda.synchronize()
+    final = np.concatenate([o.detach().cpu().numpy().ravel() for o in out])
+    traj = _loop_scenes.history_array(hist)
+    loss = np.array([float(h["loss"]) for h in hist])
+    parts = [None] * world
+    dist.all_gather_object(parts, (rank, final, traj, loss, inl, shard))
+    if rank == 0:
+        parts.sort(key=lambda p: p[0])
+        same = all(np.array_equal(p[1], parts[0][1]) and np.array_equal(p[2], parts[0][2], equal_nan=True)
+                   and np.array_equal(p[3], parts[0][3], equal_nan=True) and np.array_equal(p[4], parts[0][4], equal_nan=True)
+                   for p in parts)
+        np.savez(out_path, final=final, traj=traj, loss=loss, inlier=inl, ranks_identical=same,
+                 shards=np.array([p[5] for p in parts]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

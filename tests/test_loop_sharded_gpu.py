@@ -1,0 +1,121 @@
+"""GPU: the render-and-compare loop sharded over ranks (simple_setup.py:408-470 with the views of :420-446 spread
+over processes, ONE exchange per iteration) against the same loop in a single process.  Two ranks share the test
+box's one GPU (gloo on device tensors; on a node the same code path runs over RCCL).
+  * deterministic mode (SDF_GRAD_DETERMINISTIC | BWD_SMALL_TILES, exchange "sdf", integer bucket): the trajectory
+    is BITWISE the single-process one;
+  * default mode: within 2e-5 of an Adam step's scale per iteration (float atomics, rounding of the summed bucket);
+  * every rank ends with the same bits (replicated state, nothing broadcast)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import _loop_scenes
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _spawn(tmp_path, scene, flavour, exchange, graph, form="fused", world=2, backend="gloo"):
+    from sdfest_amd.parallel import spawn_ranks
+    out = str(tmp_path / f"loop_{scene}_{flavour}_{exchange}_{graph}_{form}.npz")
+    rc = spawn_ranks([sys.executable, os.path.join(HERE, "_loop_worker.py"), out, scene, flavour, exchange, graph, form,
+                      backend], world, timeout=400)
+    assert rc == 0
+    r = np.load(out)
+    assert bool(r["ranks_identical"]), "the ranks' replicated states differ"
+    return r
+
+
+def _single(scene, mode=0, graph=False, **kw):
+    from sdfest_amd.pipeline import FusedRenderAndCompare
+    sc = _loop_scenes.build(scene)
+    loop = FusedRenderAndCompare(sc["decoder"], sc["camera"], sc["config"], sc["depth"], camera_positions=sc["cam_pos"],
+                                 camera_orientations=sc["cam_quat"], shape_optimization=True, sdf_grad_mode=mode,
+                                 track_inliers=True, **kw)
+    hist = []
+    loop(*sc["init"], use_graph=graph, history=hist)
+    torch.cuda.synchronize()
+    return (_loop_scenes.history_array(hist), np.array([float(h["loss"]) for h in hist]),
+            loop.inlier_history.cpu().numpy())
+
+
+def _steps(traj_a, traj_b):
+    """largest parameter difference per iteration in units of that parameter group's Adam step (its learning rate)"""
+    n = traj_a.shape[1]
+    lr = np.array([1e-3] * 3 + [1e-2] * 4 + [1e-3] + [1e-2] * (n - 8))
+    return (np.abs(traj_a - traj_b) / lr).max(axis=1)
+
+
+@pytest.mark.parametrize("scene", ["g7a", "seven"])
+@pytest.mark.parametrize("graph", ["eager", "graph"])
+def test_sharded_loop_is_bitwise_the_single_process_loop_in_the_deterministic_mode(tmp_path, scene, graph):
+    from sdfest_amd.differentiable_renderer import BWD_SMALL_TILES, SDF_GRAD_DETERMINISTIC
+    r = _spawn(tmp_path, scene, "det", "sdf", graph)
+    V = 2 if scene == "g7a" else 7
+    assert r["shards"].tolist() == [[0, (V + 1) // 2], [(V + 1) // 2, V]]
+    traj, loss, inl = _single(scene, SDF_GRAD_DETERMINISTIC | BWD_SMALL_TILES, graph == "graph")
+    assert np.isfinite(traj).all() and np.abs(traj[-1] - traj[0]).max() > 1e-4      # the loop moved
+    assert np.array_equal(traj, r["traj"]), _steps(traj, r["traj"])
+    assert np.array_equal(inl, r["inlier"])
+    # the loss VALUES are fixed-order sums over the forward's tiles, whose shape follows the batch size: they agree
+    # to rounding, not to the bit (they do not enter the gradients)
+    assert np.allclose(loss, r["loss"], rtol=2e-6, atol=0)
+    # and against the default single-process loop (float atomics, batch tiles, one-launch tail)
+    traj0, loss0, _ = _single(scene)
+    assert _steps(traj0, r["traj"]).max() < 2e-3 and np.allclose(loss0, r["loss"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("scene", ["g7a", "seven"])
+@pytest.mark.parametrize("exchange", ["sdf", "latent"])
+def test_sharded_loop_matches_the_single_process_loop(tmp_path, scene, exchange):
+    r = _spawn(tmp_path, scene, "float", exchange, "graph")
+    traj, loss, inl = _single(scene, graph=True)
+    # per iteration: 2e-5 of the parameter's scale ~ 2e-3 of one Adam step at these learning rates; differences
+    # come from the order of float atomics and of the bucket's sum, and Adam's normalisation keeps them from growing
+    steps = _steps(traj, r["traj"])
+    assert steps.max() < 5e-3, steps
+    scale = np.maximum(np.abs(traj), 1e-2)
+    assert np.max(np.abs(traj - r["traj"]) / scale) < 2e-5 * traj.shape[0], np.max(np.abs(traj - r["traj"]) / scale)
+    assert np.allclose(loss, r["loss"], rtol=1e-4) and np.max(np.abs(inl - r["inlier"])) < 2.5 / 300
+
+
+def test_sharded_loop_matches_g7_run_a(tmp_path):
+    """the sharded loop against the reference-derived golden itself (same bounds as the single-process G7 test)"""
+    g7 = np.load(os.path.join(_loop_scenes.GOLDEN, "loop_g7.npz"))
+    r = _spawn(tmp_path, "g7a", "float", "sdf", "eager")
+    traj = g7["a_traj"]
+    lr = np.array([1e-3] * 3 + [1e-2] * 4 + [1e-3] + [1e-2] * (traj.shape[1] - 8))
+    for it in range(traj.shape[0]):
+        assert (np.abs(r["traj"][it] - traj[it]) / lr).max() < 0.02 * (it + 1)
+        assert abs(r["loss"][it] - g7["a_terms"][it, 3]) < 2e-4 * abs(g7["a_terms"][it, 3]) + 1e-6
+    assert np.max(np.abs(r["inlier"][:len(g7["a_inlier"])] - g7["a_inlier"])) < 2.5 / 300.0
+
+
+def test_sharded_autograd_loop_matches_the_single_process_one(tmp_path):
+    from sdfest_amd.pipeline import RenderAndCompare
+    r = _spawn(tmp_path, "seven", "float", "latent", "eager", form="autograd")
+    sc = _loop_scenes.build("seven")
+    hist = []
+    RenderAndCompare(sc["decoder"], sc["camera"], sc["config"])(
+        sc["depth"], *sc["init"], camera_positions=sc["cam_pos"], camera_orientations=sc["cam_quat"],
+        shape_optimization=True, history=hist)
+    traj = _loop_scenes.history_array(hist)
+    assert _steps(traj, r["traj"]).max() < 5e-3
+    assert np.allclose([float(h["loss"]) for h in hist], r["loss"], rtol=1e-4)
+
+
+def test_three_ranks_on_seven_views(tmp_path):
+    """an uneven split (3 + 2 + 2 views) in the deterministic mode: still the single-process bits"""
+    from sdfest_amd.differentiable_renderer import BWD_SMALL_TILES, SDF_GRAD_DETERMINISTIC
+    r = _spawn(tmp_path, "seven", "det", "sdf", "eager", world=3)
+    assert r["shards"].tolist() == [[0, 3], [3, 5], [5, 7]]
+    traj, _, inl = _single("seven", SDF_GRAD_DETERMINISTIC | BWD_SMALL_TILES)
+    assert np.array_equal(traj, r["traj"]) and np.array_equal(inl, r["inlier"])
+
+
+def test_more_ranks_than_views_is_refused():
+    from sdfest_amd.parallel import shard_views
+    assert shard_views(2, 2, 3) == (2, 2)          # an empty shard: the loop refuses it (every rank needs a view)
