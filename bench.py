@@ -2,14 +2,16 @@
 """Benchmark of the hot path: sphere-tracing depth render forward + backward.
 
 Metric (BASELINE.json): depth renders/sec fwd+bwd, 640x480 @ 64^3 SDF; grad max-abs-err vs ref.
-The line carries both halves: `value` (renders/s) and `grad_max_abs_err` / `grad_max_rel_err` (+ `parity`), the
-errors of the benchmarked build's last step against the oracle.  After the headline it appends BASELINE.json's
+The line carries both halves: `value` (renders/s) and `grad_max_abs_err` (d/dSDF, + the `grad_*` keys beside it and
+`parity`), the errors of the benchmarked build's last step against the oracle.  After the headline it appends BASELINE.json's
 other single-GPU configurations (`configs`: C1, C2 with the CPU port beside them, C5).
 
 Workload per GPU ("C3", BASELINE.json configs[2]): 256 seeded random
 poses of the synthetic blobs(0) 64^3 SDF at 640x480, threshold 0.005, upstream gradient
 U(-1,1).  One step = forward of the 256 views + backward of the 256 views (+ the RCCL
-all-reduce of the shared d/dSDF when N > 1).  N GPUs = N shards of 256 views of one
+all-reduce of the shared d/dSDF when N > 1: `--exchange ring` batches it over M/2 steps beside the
+following steps, `--exchange sync` finishes it before the next forward; both are measured and
+reported, `value` is the one asked for).  N GPUs = N shards of 256 views of one
 256*N-view batch (configs[3] at N=8), so scaling is weak.  Everything is resident in HBM
 before the timed region.  `--batch 1` gives configs[1] (one view per launch).
 
@@ -46,7 +48,54 @@ def parse():
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed steps before the warm-up steps until this much wall time has passed (clock ramp)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="views in the CPU sample (0 = auto)")
+    ap.add_argument("--exchange", choices=("ring", "sync"), default="ring",
+                    help="N > 1: which exchange of d/dSDF `value` is measured with.  ring: one all-reduce of M/2 "
+                         "volumes per M/2 steps, waited for when the ring wraps (independent steps); sync: every "
+                         "step's volume is summed before the next forward starts (the dependency of "
+                         "render-and-compare).  The other one is measured too and reported beside it.")
+    ap.add_argument("--watchdog-s", type=float, default=30.0,
+                    help="N > 1: a rank that has not come out of process-group start-up / its first collective after "
+                         "this many seconds reports its stage and exits non-zero (0: no watchdog)")
     return ap.parse_args()
+
+
+class Watchdog:
+    """First-contact guard for the multi-GPU start-up: `with Watchdog(rank, "stage", seconds)` around a call that may
+    hang (rendezvous, communicator set-up, the first collective).  When the time is up the rank says where it was
+    and exits with status 3, so the launcher (torch.distributed.run, or spawn_ranks) ends the other ranks instead of
+    the whole job sitting in a collective until the driver's limit.  Two timers: a Python thread that prints the
+    stage, and -- should the hung call hold the interpreter lock -- faulthandler's C-level one two seconds later,
+    which needs no lock (it dumps the stacks and exits 1).  Nothing is re-executed and no child is started."""
+
+    def __init__(self, rank, stage, seconds):
+        self.rank, self.stage, self.seconds = rank, stage, seconds
+
+    def __enter__(self):
+        import faulthandler
+        import threading
+        if self.seconds <= 0:
+            return self
+        print(f"[bench rank {self.rank}] stage: {self.stage}", file=sys.stderr, flush=True)
+
+        def fire():
+            print(f"[bench rank {self.rank}] WATCHDOG: still in '{self.stage}' after {self.seconds:.0f} s -- giving up "
+                  f"(MASTER_ADDR={os.environ.get('MASTER_ADDR')} MASTER_PORT={os.environ.get('MASTER_PORT')} "
+                  f"WORLD_SIZE={os.environ.get('WORLD_SIZE')} LOCAL_RANK={os.environ.get('LOCAL_RANK')} "
+                  f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')})",
+                  file=sys.stderr, flush=True)
+            os._exit(3)
+        self.timer = threading.Timer(self.seconds, fire)
+        self.timer.daemon = True
+        self.timer.start()
+        faulthandler.dump_traceback_later(self.seconds + 2.0, exit=True)
+        return self
+
+    def __exit__(self, *exc):
+        import faulthandler
+        if self.seconds > 0:
+            self.timer.cancel()
+            faulthandler.cancel_dump_traceback_later()
+        return False
 
 
 def synthetic_inputs(B_total, rank, B, W, H, device):
@@ -150,10 +199,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # rehearsal on a box with fewer GPUs than ranks (never a measurement): SDFR_BENCH_SHARE_GPU=1 puts every rank on
+    # GPU 0 and SDFR_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device)
+    share_gpu = os.environ.get("SDFR_BENCH_SHARE_GPU") == "1"
+    n_dev = torch.cuda.device_count()          # (counting devices does not initialise the GPU)
     if "RANK" not in os.environ and N > 1:
         # plain `python bench.py --gpus N`: this process has not touched the GPU; it starts the N
         # ranks as child processes (what torch.distributed.run would do), relays their output
         # (rank 0 prints the result line) and exits with their status.
+        if 0 < n_dev < N and not share_gpu:
+            raise SystemExit(f"bench.py --gpus {N}: this node shows {n_dev} GPU(s) (torch.cuda.device_count()); "
+                             f"one rank per GPU needs {N}.  (A rehearsal on fewer GPUs: SDFR_BENCH_SHARE_GPU=1 "
+                             f"SDFR_BENCH_BACKEND=gloo -- marked REHEARSAL in the line, never a measurement.)")
         from sdfest_amd.parallel import spawn_ranks
         raise SystemExit(spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], N))
     if world != N:
@@ -161,11 +218,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False); "
                          "the product has no CPU path")
-    # rehearsal on a box with fewer GPUs than ranks (never a measurement): SDFR_BENCH_SHARE_GPU=1 puts every rank on
-    # GPU 0 and SDFR_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device)
-    share_gpu = os.environ.get("SDFR_BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local_rank = 0
+    elif local_rank >= n_dev:
+        raise SystemExit(f"bench.py rank {rank}: LOCAL_RANK={local_rank} but this node shows {n_dev} GPU(s) "
+                         f"(torch.cuda.device_count()); start one rank per GPU (--nproc-per-node <= {n_dev})")
     backend = os.environ.get("SDFR_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -183,13 +240,24 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            if backend == "nccl":
-                dist.init_process_group("nccl", rank=rank, world_size=N, device_id=device)
-            else:
-                dist.init_process_group(backend, rank=rank, world_size=N)
-            warm = torch.zeros(1, device=device)
-            dist.all_reduce(warm)
-            torch.cuda.synchronize()
+            import datetime
+            with Watchdog(rank, f"init_process_group({backend}, world_size={N})", args.watchdog_s):
+                kw = dict(rank=rank, world_size=N, timeout=datetime.timedelta(seconds=max(60.0, 4 * args.watchdog_s)))
+                if backend == "nccl":
+                    dist.init_process_group("nccl", device_id=device, **kw)
+                else:
+                    dist.init_process_group(backend, **kw)
+            with Watchdog(rank, "first all-reduce (communicator set-up over xGMI)", args.watchdog_s):
+                warm = torch.ones(1, device=device)
+                dist.all_reduce(warm)
+                torch.cuda.synchronize()
+                if int(warm.item()) != N:
+                    raise SystemExit(f"bench.py rank {rank}: the first all-reduce over {N} ranks summed to "
+                                     f"{warm.item()}, expected {N}")
+            with Watchdog(rank, "first 1 MiB all-reduce", args.watchdog_s):
+                warm = torch.ones(64 ** 3, device=device)
+                dist.all_reduce(warm)
+                torch.cuda.synchronize()
         finally:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
@@ -214,13 +282,13 @@ def main():
     M = max(2, int(os.environ.get("SDFR_BENCH_GRAD_VOLUMES", "8" if use_dist else "2")))
     M += M % 2
     half = M // 2
-    # the hint of include/sdfr.h (SDFR_BWD_HALF_GRID): the generator's poses are on the host, where "the objects span
-    # >= 2 pixels per voxel" is one numpy expression -- 99 % of C3's views at 640x480, none at 320x240
-    from sdfest_amd.differentiable_renderer import close_view_fraction
-    close_share = close_view_fraction(poses_np[0], poses_np[2], cam, 64)
-    close = close_share >= 0.9
-    plan = BatchRenderPlan(64, B, cam, device=device, grad_volumes=M, close_views=close)
-    state = {"k": 0, "pending": [None, None]}
+    # The SDFR_BWD_HALF_GRID hint of include/sdfr.h is chosen by the plan itself (close_views="auto", its default):
+    # the forward's prologue counts the close views on the device into a pinned host word and each backward reads
+    # whatever count has arrived -- this file never looks at the poses.
+    plan = BatchRenderPlan(64, B, cam, device=device, grad_volumes=M)
+    state = {"k": 0, "pending": [None, None], "mode": args.exchange if use_dist else "none"}
+    coll_stream = torch.cuda.Stream(device) if use_dist else None
+    coll_events = []      # (begin, end) on the collective's stream, sync mode, timed region only
 
     def finish_exchanges():
         for i, w in enumerate(state["pending"]):
@@ -228,7 +296,34 @@ def main():
                 w.wait()
                 state["pending"][i] = None
 
-    def step(ev=None):
+    def step_sync(ev=None, time_collective=False):
+        """forward, backward, and the all-reduce of THIS step's volume finished before the next forward may start:
+        the dependency structure of render-and-compare (the next SDF needs this gradient).  The collective runs on a
+        stream of its own so that its span can be read off events on that stream."""
+        if ev:
+            ev[0].record()
+        plan.forward(sdf, pos, quat, isc, thr, prepare_backward=True)
+        if ev:
+            ev[1].record()
+        g_sdf = plan.backward(g, sdf, pos, quat, isc)[0]
+        if ev:
+            ev[2].record()
+        cur = torch.cuda.current_stream(device)
+        coll_stream.wait_stream(cur)
+        with torch.cuda.stream(coll_stream):
+            if time_collective:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            dist.all_reduce(g_sdf, op=dist.ReduceOp.SUM)
+            if time_collective:
+                e1.record()
+                coll_events.append((e0, e1))
+        cur.wait_stream(coll_stream)
+        state["k"] += 1
+
+    def step(ev=None, time_collective=False):
+        if state["mode"] == "sync":
+            return step_sync(ev, time_collective)
         k = state["k"]
         if ev:
             ev[0].record()
@@ -253,6 +348,8 @@ def main():
     def flush_tail():
         """exchange the volumes of the steps since the last full half (K need not be a multiple of M/2)"""
         k = state["k"]
+        if state["mode"] == "sync":
+            return
         if use_dist and k % half:
             h = (k // half) % 2
             if state["pending"][h] is not None:
@@ -292,20 +389,41 @@ def main():
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] if k % stride == 0 else None
               for k in range(args.steps)]
     fallbacks0 = plan.prologue_fallbacks()
-    barrier()
-    tele.mark("t0")
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(events[k])
-    t_enqueued = time.perf_counter() - t0      # host time to issue the K steps (GPU-bound if below `elapsed`)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    tele.mark("t1")
+    half0 = plan.half_grid_steps
+
+    def timed(mode, evs, time_collective=False, mark=False):
+        """EXACTLY args.steps steps between two barrier + synchronize pairs; the max over ranks"""
+        state["mode"] = mode
+        for _ in range(min(args.warmup, 2) if mode != state.get("warmed") else 0):
+            step()
+        barrier()
+        if mark:
+            tele.mark("t0")
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(evs[k] if evs else None, time_collective)
+        t_issue = time.perf_counter() - t0
+        barrier()
+        el = time.perf_counter() - t0
+        if mark:
+            tele.mark("t1")
+        if use_dist:
+            tt = torch.tensor([el], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el, t_issue
+
+    main_mode = state["mode"]
+    state["warmed"] = main_mode
+    # (t_enqueued: host time to issue the K steps -- GPU-bound if below `elapsed`)
+    elapsed, t_enqueued = timed(main_mode, events, time_collective=True, mark=True)
     events = [e for e in events if e is not None]
+    # the other exchange, K steps of its own after the headline's region (N > 1 only)
+    elapsed_other = None
     if use_dist:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        other_mode = "sync" if main_mode == "ring" else "ring"
+        elapsed_other, _ = timed(other_mode, None, time_collective=True)
+        state["mode"] = main_mode
     time.sleep(0.005)
     tele.stop()
 
@@ -320,9 +438,18 @@ def main():
         per_rank = [None] * N
         dist.all_gather_object(per_rank, {"rank": rank, "hit_pixels": hits, "device": torch.cuda.get_device_name(device),
                                           "local_device_index": local_rank, "prologue_fallbacks": fallbacks})
+        ar_us = [e0.elapsed_time(e1) * 1e3 for e0, e1 in coll_events]
         collective = {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(),
-                      "exchange": f"one all-reduce (sum, fp32) of {half} x 1 MiB d/dSDF volumes per {half} steps, "
-                                  f"ring of {M} volumes", "per_rank": per_rank}
+                      "exchange_of_value": main_mode,
+                      "exchange_ring": f"one all-reduce (sum, fp32) of {half} x 1 MiB d/dSDF volumes per {half} steps, "
+                                       f"waited for {half} steps later (ring of {M} volumes): steps are independent",
+                      "exchange_sync": "one all-reduce (sum, fp32) of the step's 1 MiB d/dSDF volume, finished before "
+                                       "the next step's forward starts (the dependency of render-and-compare)",
+                      # span of the per-step all-reduce on its own stream, from the backward's end (events on that
+                      # stream; the sync-exchange region)
+                      "allreduce_us": ({"median": round(float(np.median(ar_us)), 1), "min": round(min(ar_us), 1),
+                                        "max": round(max(ar_us), 1), "n": len(ar_us)} if ar_us else None),
+                      "per_rank": per_rank}
 
     if rank == 0:
         views = B * N * args.steps
@@ -352,12 +479,18 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"C3: {B} seeded random poses per GPU of the blobs(0) 64^3 SDF, "
                                    f"{W}x{H}, threshold 0.005, forward+backward"
-                                   + (", RCCL all-reduce of dSDF" if N > 1 and backend == "nccl" else "")
+                                   + ((", RCCL all-reduce of dSDF "
+                                       + (f"batched over {half} steps and overlapped with the following ones"
+                                          if main_mode == "ring" else "after every step, before the next forward"))
+                                      if N > 1 and backend == "nccl" else "")
                                    + (f", REHEARSAL: {backend} backend" if backend != "nccl" else "")
                                    + (", REHEARSAL: all ranks on GPU 0" if share_gpu else ""),
                        "views_per_gpu": B, "width": W, "height": H, "sdf_resolution": 64,
                        "parallelism": f"views sharded over {N} GPU(s)",
-                       "backward_half_grid_hint": bool(close), "close_view_share": round(close_share, 4),
+                       "backward_half_grid": {"chosen_by": "device-side count of close views (pinned word), "
+                                                           "previous steps' value; no host poses",
+                                              "timed_steps_with_hint": plan.half_grid_steps - half0,
+                                              "close_views_last_counted": plan.close_views_seen()[1]},
                        "hit_pixels_rank0": hits},
             "roofline": {"bound": "hbm", "kernel": dominant,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
@@ -383,6 +516,11 @@ def main():
         }
         if collective:
             line["collective"] = collective
+            v_other = views / elapsed_other
+            line["value_ring_exchange"] = round(value if main_mode == "ring" else v_other, 1)
+            line["value_sync_exchange"] = round(value if main_mode == "sync" else v_other, 1)
+            line["ms_per_step_sync_exchange"] = round((elapsed if main_mode == "sync" else elapsed_other)
+                                                      / args.steps * 1e3, 4)
         if N == 1 and not args.no_parity:
             # the other half of the metric: errors of the benchmarked build's last step against the reference
             # semantics (sdf_renderer_cuda.cu:334-467, simple_renderer.py:317-458) through the pinned oracle
@@ -390,9 +528,14 @@ def main():
             line["parity"] = par
             # the metric's second half: d/dSDF of the benchmarked step (max-abs, and relative to its maximum), and
             # the plain relative error of the well-conditioned pose-gradient components (`parity` has the rest)
+            # (named for what they are -- ADVICE r3: the filtered relative error is not "the maximum")
             line["grad_max_abs_err"] = par["grad_sdf"]["max_abs_err"]
-            line["grad_max_rel_err"] = max(par["grad_sdf"]["max_err_over_max"],
-                                           par["ones_upstream"]["grad_pose_max_rel_err_well_conditioned"] or 0.0)
+            line["grad_sdf_max_err_over_max"] = par["grad_sdf"]["max_err_over_max"]
+            line["grad_pose_max_rel_err_well_conditioned_ones_upstream"] = \
+                par["ones_upstream"]["grad_pose_max_rel_err_well_conditioned"]
+            line["grad_pose_max_abs_err_benchmark_upstream"] = par["grad_pose_benchmark_upstream"]["max_abs_err"]
+            line["grad_pose_max_err_over_sum_of_term_magnitudes"] = \
+                par["grad_pose_benchmark_upstream"]["max_err_over_sum_of_term_magnitudes"]
         if N == 1 and not args.no_cpu_baseline:
             sample = args.cpu_sample or min(B, 256)
             line["cpu_baseline"] = cpu_baseline(sdf_np, poses_np, W, H, thr, sample)

@@ -83,8 +83,9 @@ extern "C" {
  * launch has to provide workgroups for the finer tiling although close views use half of them; with the hint the
  * grid has half the rows (backward of the benchmark 125 -> 112 us) and a view that is NOT close takes its tiles two
  * per workgroup, one after the other -- results are the same whether the hint is true or not, but such views are
- * slower with it (objects of ~1 pixel per voxel: 103 -> 174 us).  The poses live in device memory, so only the
- * caller can know; ignored for small calls and for the loss-fused and deterministic forms. */
+ * slower with it (objects of ~1 pixel per voxel: 103 -> 174 us).  The poses live in device memory: a caller that
+ * does not know them asks the forward to count the close views (sdfr_render_step_forward_counted) and sets the
+ * hint from an earlier step's count.  Ignored for small calls and for the loss-fused and deterministic forms. */
 #define SDFR_BWD_HALF_GRID 0x200
 /* Flag bit, OR-ed into sdf_grad_mode: the backward always uses its 32 x 8 tiling, whatever the batch size.  A
  * view's pose gradients are fixed-order sums over ITS tiles, so with this flag they do not depend on how many
@@ -178,6 +179,22 @@ SDFR_API int sdfr_render_step_forward(const float* sdf, int R, long long sdf_vie
                              float cy, float fx, float fy, float threshold, float* depth, float* g_sdf,
                              long long g_sdf_view_stride, void* workspace, size_t workspace_bytes,
                              int device, void* stream);
+/* sdfr_render_step_forward that also REPORTS how many of its views are close -- the fact behind the
+ * SDFR_BWD_HALF_GRID hint -- without anybody looking at the poses on the host: the set-up that walks every view on
+ * the device counts the views it gives 32 x 32 backward tiles and, when the last view has been counted, stores
+ *     (forwards counted on this workspace << 32) | close views of this forward
+ * into *close_views_word with one 64-bit store.  The word must be visible to the device AND readable by the host
+ * without a synchronisation (pinned host memory: hipHostMalloc / a pinned torch tensor; 8-byte aligned; NULL: no
+ * report).  The caller reads it whenever it likes -- it then holds the count of some earlier, complete forward --
+ * and sets the hint of its next backward from it: stale by a step or more is fine for a hint that cannot change
+ * results.  Counted by the batch forms of the set-up (B >= 4 views of one shared grid; smaller calls have no batch
+ * backward to hint); the workspace's sync region must have been zero-filled once before its first use.
+ * Sync header words 4 / 5 hold the same two numbers on the device. */
+SDFR_API int sdfr_render_step_forward_counted(const float* sdf, int R, long long sdf_view_stride, const float* pos,
+                                     const float* quat, const float* inv_scale, int B, int W, int H, float cx,
+                                     float cy, float fx, float fy, float threshold, float* depth, float* g_sdf,
+                                     long long g_sdf_view_stride, void* workspace, size_t workspace_bytes,
+                                     unsigned long long* close_views_word, int device, void* stream);
 /* The same pair for the loss-fused forms (below): sdfr_render_step_forward_l1 = sdfr_render_forward_l1 that also
  * zero-fills g_sdf and leaves the view records; sdfr_render_step_backward_l1_pc = sdfr_render_backward_l1_pc without
  * its prologue launch.  For a few views of the plain grid the forward has no prologue launch either (every

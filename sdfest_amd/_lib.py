@@ -55,6 +55,9 @@ SIGNATURES = {
     "sdfr_render_step_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
     "sdfr_render_step_forward": (c_int, [c_fp, c_int, c_ll, c_fp, c_fp, c_fp, c_int, c_int, c_int,
                                          c_f, c_f, c_f, c_f, c_f, c_fp, c_fp, c_ll, c_fp, c_sz, c_int, c_fp]),
+    "sdfr_render_step_forward_counted": (c_int, [c_fp, c_int, c_ll, c_fp, c_fp, c_fp, c_int, c_int, c_int,
+                                                 c_f, c_f, c_f, c_f, c_f, c_fp, c_fp, c_ll, c_fp, c_sz, c_fp, c_int,
+                                                 c_fp]),
     "sdfr_render_step_backward": (c_int, [c_fp, c_fp, c_fp, c_int, c_ll, c_int, c_int, c_int,
                                           c_f, c_f, c_f, c_f, c_int, c_fp, c_ll, c_fp, c_fp, c_fp,
                                           c_fp, c_sz, c_int, c_fp]),

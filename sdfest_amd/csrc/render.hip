@@ -274,15 +274,45 @@ __device__ __forceinline__ void compute_view_setup(int b, const float* __restric
   if (!WAVE || (threadIdx.x & 63) == 0) out[b] = s;
 }
 
+// How many of a forward's views are CLOSE (ViewSetup::bwd_big: the views the batch backward gives 32 x 32 tiles) --
+// the fact behind the SDFR_BWD_HALF_GRID hint, counted where the views are set up so that no caller has to look at
+// poses that live in device memory.  Called by one lane per view; sync header words 2 / 3: close views / views of
+// the running launch (the launch's last view resets them), word 4: launches counted, word 5: close views of the
+// last complete launch.  `word` (nullable, a kernel ARGUMENT, never an address kept in memory): the caller's
+// host-visible 64-bit word, which receives (launches counted << 32 | close views) in ONE store when the last view
+// has been counted; a host that reads it any time later gets some complete launch's count, never a torn one.
+__device__ __forceinline__ void count_close_view(unsigned* __restrict__ sync, int B, bool close,
+                                                 unsigned long long* __restrict__ word) {
+  if (close) atomicAdd(&sync[2], 1u);
+  __threadfence();
+  if (atomicAdd(&sync[3], 1u) + 1u != (unsigned)B) return;
+  __threadfence();
+  const unsigned c = atomicExch(&sync[2], 0u);
+  atomicExch(&sync[3], 0u);
+  const unsigned seq = sync[4] + 1u;
+  sync[4] = seq;
+  sync[5] = c;
+  if (word) __hip_atomic_store(word, ((unsigned long long)seq << 32) | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ void view_setup_kernel(const float* __restrict__ pos, const float* __restrict__ quat,
                                   const float* __restrict__ inv_scale, int B, int R, int W, int H,
                                   float cx, float cy, float fx, float fy,
                                   ViewSetup* __restrict__ out, const float* __restrict__ plane_min,
-                                  float threshold, unsigned* __restrict__ spans) {
+                                  float threshold, unsigned* __restrict__ spans, unsigned* __restrict__ sync,
+                                  unsigned long long* __restrict__ close_word) {
   // one wave per view (the wave shares the scan of the plane minima, lane 0 writes the record)
   const int b = blockIdx.x;
-  if (b < B)
+  if (b < B) {
     compute_view_setup<true>(b, pos, quat, inv_scale, R, W, H, cx, cy, fx, fy, out, plane_min, threshold, spans);
+    if (sync && (threadIdx.x & 63) == 0) {
+      // (the same expression as setup_pose's: this lane wrote the record and holds nothing of it any more)
+      const float px = pos[3 * b], py = pos[3 * b + 1], pz = pos[3 * b + 2];
+      const float dist = sqrtf(px * px + py * py + pz * pz);
+      const float r = sqrtf(fabsf(fx * fy)) * ((1.0f / inv_scale[b]) / (0.5f * (float)(R - 1))) / fmaxf(dist, 1e-20f);
+      count_close_view(sync, B, r >= SDFR_BWD_BIG_MIN_RATIO, close_word);
+    }
+  }
 }
 
 // The plane minima reach the set-up waves of the SAME launch (forward_prologue_kernel) as tagged entries: 16 bytes
@@ -462,7 +492,7 @@ __global__ __launch_bounds__(256) void forward_prologue_kernel(
     unsigned* __restrict__ sync, const float* __restrict__ pos, const float* __restrict__ quat,
     const float* __restrict__ inv_scale, int B, int W, int H, float cx, float cy, float fx, float fy,
     ViewSetup* __restrict__ out, float threshold, float* __restrict__ g_zero, size_t n_zero, int max_polls,
-    unsigned* __restrict__ spans) {
+    unsigned* __restrict__ spans, unsigned long long* __restrict__ close_word) {
   const unsigned tag = sync[0] + 1u;  // the epoch the last forward on this workspace left, + 1
   PlaneEntry* ent = reinterpret_cast<PlaneEntry*>(sync + kSyncHeaderWords);
   int blk = (int)blockIdx.x;
@@ -502,6 +532,7 @@ __global__ __launch_bounds__(256) void forward_prologue_kernel(
       if ((tid & 63) == 0) {
         out[b] = s;
         if (!ready) atomicAdd(&sync[1], 1u);
+        count_close_view(sync, B, s.bwd_big != 0, close_word);
       }
     }
     return;
@@ -1404,7 +1435,7 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
                  const float* quat, const float* inv_scale, int B, int W, int H, float cx, float cy,
                  float fx, float fy, float threshold, float* depth, const float* target, float* loss,
                  float* loss_stats, void* workspace, size_t workspace_bytes, size_t need, const ForwardLayout& lay,
-                 float* g_zero, size_t n_zero, int device, void* stream) {
+                 float* g_zero, size_t n_zero, int device, void* stream, unsigned long long* close_word = nullptr) {
   const bool with_loss = target != nullptr;
   if (int rc = check_common(R, B, W, H, fx, fy)) return rc;
   if (sdf_view_stride != 0 && sdf_view_stride < (long long)R * R * R)
@@ -1439,7 +1470,7 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
     hipLaunchKernelGGL(forward_prologue_kernel, dim3(3 * R + n_setup + n_pack), dim3(256), 0, st, sdf, R,
                        (float4*)cells, 3 * R, n_setup, lay.sync, pos, quat, inv_scale, B, W, H, cx, cy, fx, fy,
                        setup, threshold, g_zero, n_zero, g_prologue_max_polls.load(std::memory_order_relaxed),
-                       lay.spans);
+                       lay.spans, close_word);
     epoch = lay.sync;
   } else if (g_zero && !packed && inline_setup) {
     // a step over a few views of the plain grid: no prologue launch at all (render_forward_kernel, INLINE)
@@ -1459,7 +1490,7 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
                          (float4*)cells, n_pack, plane_min);
     }
     hipLaunchKernelGGL(view_setup_kernel, dim3(B), dim3(64), 0, st, pos, quat, inv_scale, B, R,
-                       W, H, cx, cy, fx, fy, setup, plane_min, threshold, lay.spans);
+                       W, H, cx, cy, fx, fy, setup, plane_min, threshold, lay.spans, lay.sync, close_word);
   }
   const bool macro = geom.sx * geom.sy > 1;
   const int ntx = geom.nx(W), nty = geom.ny(H);
@@ -1686,7 +1717,19 @@ extern "C" int sdfr_render_step_forward(const float* sdf, int R, long long sdf_v
                                         float cy, float fx, float fy, float threshold, float* depth, float* g_sdf,
                                         long long g_sdf_view_stride, void* workspace, size_t workspace_bytes,
                                         int device, void* stream) {
+  return sdfr_render_step_forward_counted(sdf, R, sdf_view_stride, pos, quat, inv_scale, B, W, H, cx, cy, fx, fy,
+                                          threshold, depth, g_sdf, g_sdf_view_stride, workspace, workspace_bytes,
+                                          nullptr, device, stream);
+}
+
+extern "C" int sdfr_render_step_forward_counted(const float* sdf, int R, long long sdf_view_stride, const float* pos,
+                                                const float* quat, const float* inv_scale, int B, int W, int H,
+                                                float cx, float cy, float fx, float fy, float threshold, float* depth,
+                                                float* g_sdf, long long g_sdf_view_stride, void* workspace,
+                                                size_t workspace_bytes, unsigned long long* close_views_word,
+                                                int device, void* stream) {
   const char* fn = "sdfr_render_step_forward";
+  if ((uintptr_t)close_views_word % 8) return fail(SDFR_E_INVALID, "%s: close_views_word must be 8-byte aligned", fn);
   const long long vox = (long long)R * R * R;
   if (R >= 2 && R <= 1023 && g_sdf_view_stride != 0 && g_sdf_view_stride != vox)
     return fail(SDFR_E_INVALID, "g_sdf_view_stride must be 0 or R^3");
@@ -1703,7 +1746,8 @@ extern "C" int sdfr_render_step_forward(const float* sdf, int R, long long sdf_v
   const size_t g_words = (R >= 2 && R <= 1023) ? (size_t)vox * (g_sdf_view_stride ? (size_t)(B > 0 ? B : 1) : 1) : 0;
   return forward_impl(fn, sdf, R, sdf_view_stride, pos, quat, inv_scale, B, W, H, cx, cy, fx, fy, threshold, depth,
                       nullptr, nullptr, nullptr, workspace, workspace_bytes,
-                      sdfr_render_step_workspace_bytes(R, B, W, H), lay, g_sdf, g_words, device, stream);
+                      sdfr_render_step_workspace_bytes(R, B, W, H), lay, g_sdf, g_words, device, stream,
+                      close_views_word);
 }
 
 extern "C" int sdfr_render_step_forward_l1(const float* sdf, int R, long long sdf_view_stride, const float* pos,

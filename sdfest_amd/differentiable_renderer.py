@@ -421,10 +421,14 @@ class BatchRenderPlan:
     """
 
     def __init__(self, R: int, B: int, camera: Camera, device="cuda", per_view_sdf: bool = False,
-                 sdf_grad_mode: int = 0, grad_volumes: int = 2, close_views: bool = False,
+                 sdf_grad_mode: int = 0, grad_volumes: int = 2, close_views="auto",
                  grad_tail_words: int = 0):
-        """close_views: the caller's hint that (nearly) all views are close (``views_are_close``); the backward
-        then launches half the workgroups.  Same results either way; views that are not close are slower with it.
+        """close_views: the ``SDFR_BWD_HALF_GRID`` hint of a step's backward -- half the workgroups when (nearly) all
+        views are close (``views_are_close``); same results either way, views that are not close are slower with it.
+        True / False: the caller knows.  "auto" (default): nobody looks at the poses on the host -- the step's
+        forward counts its close views on the device (``sdfr_render_step_forward_counted``) into a pinned host word,
+        and every backward reads what the word holds at that moment: the count of some earlier step (stale by one or
+        a few: the hint cannot change results), none before the first forward has finished -> the full grid.
         grad_tail_words: every gradient volume of the ring is followed by this many float32 words of the caller's
         (``g_tail``): volume and tail are one contiguous bucket (``g_bucket``), e.g. ONE all-reduce over the ranks of a
         sharded batch carries d/dSDF and whatever small per-view results ride along."""
@@ -439,7 +443,13 @@ class BatchRenderPlan:
         self.fx, self.fy, self.cx, self.cy, _ = camera.get_pinhole_camera_parameters(0.5)
         self.W, self.H = camera.width, camera.height
         self.sdf_stride = R * R * R if per_view_sdf else 0
-        self.sdf_grad_mode = sdf_grad_mode | (BWD_HALF_GRID if close_views else 0)
+        if close_views not in (True, False, "auto"):
+            raise ValueError("close_views must be True, False or 'auto'")
+        self._close_auto = close_views == "auto"
+        self.sdf_grad_mode = sdf_grad_mode | (BWD_HALF_GRID if close_views is True else 0)
+        # pinned: the device stores into it (one 64-bit word per forward), the host reads it without synchronising
+        self._close_word = torch.zeros(1, dtype=torch.int64).pin_memory() if self._close_auto else None
+        self.half_grid_steps = 0     # step backwards that went out with the hint ("auto": decided from the word)
         f32 = dict(dtype=torch.float32, device=self.device)
         self.depth = torch.empty((B, self.H, self.W), **f32)
         self.g_sdf = torch.empty((B, R, R, R) if per_view_sdf else (R, R, R), **f32)
@@ -515,6 +525,14 @@ class BatchRenderPlan:
         self._step = None
         self._step_l1 = None
 
+    def close_views_seen(self):
+        """(forwards counted so far, close views of the latest counted one) as the pinned word holds them right now
+        -- no synchronisation: the forward whose count this is finished some time ago ("auto" plans only)."""
+        if self._close_word is None:
+            return 0, 0
+        v = int(self._close_word[0])
+        return (v >> 32) & 0xffffffff, v & 0xffffffff
+
     def select_volume(self, index: int) -> None:
         """Make ring volume `index` the one the next stand-alone backward writes (``self.g_sdf``); a step's backward
         writes the volume its forward prepared instead."""
@@ -567,11 +585,12 @@ class BatchRenderPlan:
         self._step_l1 = None   # a forward_l1(prepare_backward=True) whose backward never came: its view records are gone
         if prepare_backward:
             nxt = self._g_sdf_ring[self._g_sdf_next]
-            rc = self._L.sdfr_render_step_forward(
+            rc = self._L.sdfr_render_step_forward_counted(
                 sdf.data_ptr(), self.R, self.sdf_stride, pos.data_ptr(), quat.data_ptr(),
                 inv_scale.data_ptr(), self.B, self.W, self.H, self.cx, self.cy, self.fx, self.fy,
                 threshold, dst.data_ptr(), nxt.data_ptr(), self.sdf_stride, self.workspace.data_ptr(),
-                self.workspace.numel(), self.device.index, _stream(self.device))
+                self.workspace.numel(), self._close_word.data_ptr() if self._close_auto else None,
+                self.device.index, _stream(self.device))
             _lib.check(rc, "sdfr_render_step_forward")
             self._step = (self._key(sdf, pos, quat, inv_scale), dst, nxt)
             return dst
@@ -599,9 +618,15 @@ class BatchRenderPlan:
         self._step_l1 = None
         if step is not None and not defer_pose and step[0] == self._key(sdf, pos, quat, inv_scale):
             _, depth, g_sdf = step
+            mode = self.sdf_grad_mode
+            if self._close_auto:
+                seen, close = self.close_views_seen()
+                if seen and close >= 0.9 * self.B:
+                    mode |= BWD_HALF_GRID
+            self.half_grid_steps += 1 if mode & BWD_HALF_GRID else 0
             rc = self._L.sdfr_render_step_backward(
                 grad_depth.data_ptr(), depth.data_ptr(), sdf.data_ptr(), self.R, self.sdf_stride,
-                self.B, self.W, self.H, self.cx, self.cy, self.fx, self.fy, self.sdf_grad_mode,
+                self.B, self.W, self.H, self.cx, self.cy, self.fx, self.fy, mode,
                 g_sdf.data_ptr(), self.sdf_stride, self.g_pos.data_ptr(), self.g_quat.data_ptr(),
                 self.g_inv_scale.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(),
                 self.device.index, _stream(self.device))

@@ -65,23 +65,31 @@ def test_two_ranks_equal_one_process_bitwise_in_the_deterministic_mode(tmp_path,
     assert np.abs(ref).max() > 0 and np.array_equal(ref, r["g_sdf"])
 
 
-def test_bench_py_with_two_ranks_in_rehearsal_mode(tmp_path):
+@pytest.mark.parametrize("exchange", ["ring", "sync"])
+def test_bench_py_with_two_ranks_in_rehearsal_mode(tmp_path, exchange):
     """bench.py --gpus 2 itself, both ranks on the one GPU of the test box over gloo (marked REHEARSAL in its line):
-    the rank spawn, the pose shards, the batched exchange of the gradient ring and the single result line."""
+    the rank spawn, the start-up watchdog, the pose shards, both exchanges of the gradient volumes -- batched over
+    the ring, and finished after every step before the next forward -- and the single result line with both values."""
     import json
     import subprocess
     root = os.path.dirname(HERE)
     env = dict(os.environ, SDFR_BENCH_SHARE_GPU="1", SDFR_BENCH_BACKEND="gloo", SDFR_BENCH_GRAD_VOLUMES="4")
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
-                          "--batch", "24", "--width", "320", "--height", "240", "--prewarm-ms", "0"],
+                          "--batch", "24", "--width", "320", "--height", "240", "--prewarm-ms", "0",
+                          "--exchange", exchange],
                          capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
+    assert "stage: init_process_group" in res.stderr and "WATCHDOG" not in res.stderr
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 5 and line["value"] > 0
     assert "REHEARSAL" in line["config"]["workload"]
     col = line["collective"]
+    assert col["exchange_of_value"] == exchange
+    assert line["value_ring_exchange"] > 0 and line["value_sync_exchange"] > 0
+    assert line["value"] == line[f"value_{exchange}_exchange"]
+    assert col["allreduce_us"]["n"] == 5 and col["allreduce_us"]["median"] > 0
     assert col["world_size_seen"] == 2 and col["backend"] == "gloo"
     assert sorted(r["rank"] for r in col["per_rank"]) == [0, 1]
     assert all(r["hit_pixels"] > 1000 and r["prologue_fallbacks"] == 0 for r in col["per_rank"])

@@ -77,3 +77,69 @@ def test_allreduce_shared_gradients_world2():
         p.join(120)
         assert p.exitcode == 0
     assert list(out) == [1, 1]
+
+
+def _bucket_worker(rank, world, port, out):
+    """the sharded loop's exchange (sdfest_amd.parallel.allreduce_bucket) on CPU tensors over gloo"""
+    from sdfest_amd.parallel import allreduce_bucket, resolve_group
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        group, r, w = resolve_group("world")
+        ok = (r, w) == (rank, world) and resolve_group(None) == (None, 0, 1)
+        V, REC = 5, 20
+        b, e = shard_views(V, rank, world)
+        rng = np.random.default_rng(3)
+        full = rng.normal(size=(V, REC)).astype(np.float32)
+        full[1, 16] = np.nan              # an empty overlap's loss
+        full[3, 2] = -0.0                 # a sign only the integer sum keeps
+        full[4, 7] = np.float32(1e-42)    # a denormal
+        vol = rng.integers(-2 ** 40, 2 ** 40, size=64, dtype=np.int64)
+        # integer bucket: [int64 volume | float records reinterpreted]: exact, whatever the records hold
+        rec = np.zeros((V, REC), np.float32)
+        rec[b:e] = full[b:e]
+        bucket = torch.cat([torch.tensor(vol * (rank + 1)), torch.tensor(rec).view(-1).view(torch.int64)])
+        allreduce_bucket(bucket, group, integer=True)
+        got_rec = bucket[64:].view(torch.float32).view(V, REC).numpy()
+        ok = ok and np.array_equal(bucket[:64].numpy(), vol * sum(range(1, world + 1)))
+        ok = ok and np.array_equal(got_rec.view(np.uint32), full.view(np.uint32))      # bit for bit, NaN and -0 included
+        # float bucket: sums of a record with zeros reproduce it (up to the sign of zero)
+        fb = torch.cat([torch.full((8,), float(rank + 1)), torch.tensor(rec).view(-1)])
+        allreduce_bucket(fb, group, integer=False)
+        got = fb[8:].view(V, REC).numpy()
+        ok = ok and np.all(fb[:8].numpy() == sum(range(1, world + 1)))
+        ok = ok and np.array_equal(got, full, equal_nan=True)
+        # no group: nothing happens
+        x = torch.ones(4)
+        ok = ok and allreduce_bucket(x, None) is x and float(x.sum()) == 4.0
+        try:
+            allreduce_bucket(torch.ones(3), group, integer=True)
+            ok = False
+        except RuntimeError:
+            pass
+        dist.barrier()
+        out[rank] = int(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_bucket_world2_is_exact_in_integer_mode():
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Array("i", [0] * world)
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert list(out) == [1, 1]
+
+
+def test_resolve_group_needs_an_initialised_process_group():
+    from sdfest_amd.parallel import resolve_group
+    assert resolve_group(None) == (None, 0, 1)
+    with pytest.raises(RuntimeError):
+        resolve_group("world")

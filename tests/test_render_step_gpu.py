@@ -338,3 +338,45 @@ def test_half_grid_hint_changes_nothing_but_the_launch(seed):
         assert torch.equal(d0, d1) and (d0 > 0).sum().item() > 10000
         assert torch.equal(gp0, gp1) and torch.equal(gq0, gq1) and torch.equal(gi0, gi1)
         assert rel_err(gs1.cpu().numpy(), gs0.cpu().numpy()) <= 1e-5
+
+
+def test_half_grid_is_chosen_on_the_device_count_without_host_poses():
+    """close_views="auto" (the plan's default): the step's forward counts its close views where it sets the views up
+    and leaves the count in a pinned host word; a backward issued later reads the word -- no synchronisation, no
+    host-side look at the poses -- and takes the half grid when >= 90 % of the views were close.  Before the first
+    count has arrived the full grid runs.  Results do not depend on any of it."""
+    from sdfest_amd import BatchRenderPlan, Camera
+    from sdfest_amd.differentiable_renderer import close_view_fraction
+    B, W, H, f = 64, 640, 480, 320.0
+    cam = Camera(W, H, f, f, W / 2.0, H / 2.0, pixel_center=0.5)
+    pos, quat, isc = oracle.random_poses(B, seed=33, width=W, height=H, f=f)
+    n_close = int(round(close_view_fraction(pos, isc, cam, 64) * B))
+    assert n_close >= 0.9 * B
+    far = isc.copy()
+    far[::3] *= 3.0
+    n_close_far = int(round(close_view_fraction(pos, far, cam, 64) * B))
+    assert n_close_far < 0.9 * B
+    g = dev(np.random.default_rng(33).uniform(-1, 1, (B, H, W)).astype(np.float32))
+    sdf = dev(oracle.blobs_sdf(0))
+    for scales, count, expect_half in ((isc, n_close, True), (far, n_close_far, False)):
+        pose = (dev(pos), dev(quat), dev(scales))
+        ref_plan = BatchRenderPlan(64, B, cam, close_views=False)
+        ref_plan.forward(sdf, *pose, 0.005, prepare_backward=True)
+        ref = [o.clone() for o in ref_plan.backward(g, sdf, *pose)]
+        plan = BatchRenderPlan(64, B, cam)
+        assert plan.close_views_seen() == (0, 0)
+        for k in range(3):
+            plan.forward(sdf, *pose, 0.005, prepare_backward=True)
+            if k == 0:
+                # nothing has been counted when the first backward is issued... unless the GPU was quicker than the
+                # host: either way the result is the same, so only the later steps are pinned down
+                pass
+            else:
+                torch.cuda.synchronize()      # (the test wants a definite state; a real loop never waits)
+                assert plan.close_views_seen() == (k + 1, count)
+            before = plan.half_grid_steps
+            out = plan.backward(g, sdf, *pose)
+            if k > 0:
+                assert plan.half_grid_steps - before == (1 if expect_half else 0)
+            assert torch.equal(out[1], ref[1]) and torch.equal(out[2], ref[2]) and torch.equal(out[3], ref[3])
+            assert rel_err(out[0].cpu().numpy(), ref[0].cpu().numpy()) <= 1e-5

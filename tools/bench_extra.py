@@ -69,7 +69,11 @@ class Telemetry:
              "temp_c": ("temp1_input", 1e-3), "temp_hbm_c": ("temp3_input", 1e-3),
              "power_w": ("power1_average", 1e-6), "power_w_in": ("power1_input", 1e-6)}
 
-    def __init__(self, device_index=0, period_s=0.002):
+    # 20 ms: the sampler thread takes the interpreter lock for every read of its six sysfs files and so competes
+    # with the thread that issues the launches; SDFR_BENCH_TELEMETRY_MS overrides (e.g. 2 for a trace)
+    def __init__(self, device_index=0, period_s=None):
+        if period_s is None:
+            period_s = float(os.environ.get("SDFR_BENCH_TELEMETRY_MS", "20")) * 1e-3
         self.hw, self.how = _card_of_device(device_index)
         self.period = period_s
         self.samples = []      # (t, {key: value})
@@ -109,6 +113,7 @@ class Telemetry:
         self._stop.set()
         if self._thread:
             self._thread.join(timeout=1.0)
+            self.joined = not self._thread.is_alive()
 
     def summary(self, t0_name, t1_name):
         """min / median / max of every quantity over [mark t0, mark t1] (+ the last sample before it)."""
@@ -121,7 +126,8 @@ class Telemetry:
         if not inside:   # a timed region shorter than one period: the neighbours
             inside = before[-1:] + after[:1]
         out = {"source": f"{self.hw} ({self.how}) sampled every {self.period * 1e3:.0f} ms by a host thread",
-               "samples_in_timed_region": len(inside)}
+               "samples_in_timed_region": len(inside), "sampler_thread_active_during_timed_region": True,
+               "sampler_thread_joined": getattr(self, "joined", None)}
         for key in self.paths:
             v = [s[key] for s in inside if key in s]
             if v:
