@@ -497,6 +497,11 @@ def main():
                          "frac": round(achieved * 1e9 / HBM_PEAK, 5),
                          "traffic": (traffic or {}).get(dominant),
                          "traffic_source": traffic_source,
+                         # the resource that BINDS this kernel (it is not an HBM kernel): the CU's vector-memory
+                         # pipeline, from the same committed counter passes (tools/summarize_pmc.py has the formulas:
+                         # bytes = 16 B x 64 lane slots x vector read instructions; unit busy = *_BUSY / (cycles x CUs);
+                         # valu_busy_frac = 4 x SQ_ACTIVE_INST_VALU / (SIMDs x cycles))
+                         "binding": ((traffic or {}).get("binding") or {}).get(dominant),
                          "algorithmic_bytes_per_launch": int(k_bytes),
                          "avg_launch_ms": round(k_ms, 4)},
             "roofline_step": {"bytes_per_view": bytes_per_view,

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Run ON the GPU box (through gpurun): kernel trace + separate PMC passes of one bench command.
 #   tools/profile_gpu.sh <tag> [bench args...]
+# (the TA block takes two counters per pass: "TA_TA_BUSY_sum" + one more; a set the hardware cannot collect makes
+# rocprofv3 abort and then sit until the timeout -- r04: two such passes cost 300 s of box time)
 # Writes gpurun_out/<tag>/{trace,pmc_*}/... ; tools/summarize_pmc.py turns them into profiles/.
 set -u
 TAG=${1:-prof}; shift || true
@@ -21,7 +23,8 @@ for SET in \
   "FETCH_SIZE" \
   "WRITE_SIZE" \
   "TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum TCC_REQ_sum" \
-  "GRBM_GUI_ACTIVE GRBM_COUNT SQ_INSTS_LDS_ATOMIC SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA"; do
+  "GRBM_GUI_ACTIVE GRBM_COUNT SQ_INSTS_LDS_ATOMIC SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA" \
+  "TCP_TOTAL_READ_sum TCP_TOTAL_WRITE_sum TA_TA_BUSY_sum TD_TD_BUSY_sum"; do
   i=$((i+1))
   timeout 150 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d "$OUT/pmc_$i" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_$i.log" 2>&1 || echo "pass $i failed"
 done
