@@ -479,6 +479,20 @@ SDFR_API int sdfr_depth_count(const float* depth, int V, int W, int H, int* coun
 SDFR_API int sdfr_depth_to_points(const float* depth, int V, int W, int H, float rfx, float rfy, float cx0,
                          float cy0, const int* offsets, const void* workspace, float* points,
                          int device, void* stream);
+/* The same with the ORDER of a view's points chosen by the caller.  SDFR_POINT_ORDER_ROW_MAJOR is the reference's
+ * (torch.nonzero).  SDFR_POINT_ORDER_TILED enumerates the image in tiles of 64 x 16 pixels, a tile in four 16 x 16
+ * sub-tiles, a sub-tile row-major: the same points, permuted within their view, so that 256 consecutive points are a
+ * compact patch of the surface.  For consumers that only sum over a view's points -- the point-cloud loss and its
+ * gradients (losses.py:32-135 has no order): the sampler's backward pre-sums the d/dSDF of 256 consecutive points
+ * in LDS before its global atomics, and compact patches share more voxels (global atomics per point of
+ * back-projected depth images: 0.55 row-major, ~0.3 tiled).  Use the same order in both calls. */
+#define SDFR_POINT_ORDER_ROW_MAJOR 0
+#define SDFR_POINT_ORDER_TILED 1
+SDFR_API int sdfr_depth_count_ordered(const float* depth, int V, int W, int H, int order, int* counts, void* workspace,
+                             size_t workspace_bytes, int device, void* stream);
+SDFR_API int sdfr_depth_to_points_ordered(const float* depth, int V, int W, int H, int order, float rfx, float rfy,
+                                 float cx0, float cy0, const int* offsets, const void* workspace, float* points,
+                                 int device, void* stream);
 
 /* a += b  (sums the renderer's and the sampler's d/dSDF) */
 SDFR_API int sdfr_add_inplace(float* a, const float* b, size_t n, int device, void* stream);

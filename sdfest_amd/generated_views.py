@@ -139,10 +139,11 @@ def smooth_depth(depth: torch.Tensor, kernel: torch.Tensor, apply: torch.Tensor)
     return depth
 
 
-def depth_to_pointsets(depth: torch.Tensor, camera: Camera):
+def depth_to_pointsets(depth: torch.Tensor, camera: Camera, tiled: bool = False):
     """Back-projection of every non-zero pixel of a (B,H,W) batch (pointset_utils.py:57-77,
     convention "opengl", pixel-centre-0 intrinsics): packed points (N,3) in view-major, row-major
-    order and the per-view counts."""
+    order and the per-view counts.  tiled (GPU only): the same points of each view in the order of
+    ``SDFR_POINT_ORDER_TILED`` (include/sdfr.h) -- for consumers that only sum over a view's points."""
     fx, fy, cx, cy, _ = camera.get_pinhole_camera_parameters(0.0)
     if depth.is_cuda:
         # two passes over the images (count, then a stable compaction) instead of torch.nonzero and
@@ -155,16 +156,19 @@ def depth_to_pointsets(depth: torch.Tensor, camera: Camera):
         counts = torch.empty(V, dtype=torch.int32, device=dev)
         ws = torch.empty(max(L.sdfr_depth_points_workspace_bytes(V, W, H), 256), dtype=torch.uint8, device=dev)
         st = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(L.sdfr_depth_count(depth.data_ptr(), V, W, H, counts.data_ptr(), ws.data_ptr(), ws.numel(),
-                                      dev.index, st), "sdfr_depth_count")
+        order = 1 if tiled else 0
+        _lib.check(L.sdfr_depth_count_ordered(depth.data_ptr(), V, W, H, order, counts.data_ptr(), ws.data_ptr(),
+                                              ws.numel(), dev.index, st), "sdfr_depth_count")
         counts64 = counts.to(torch.int64)
         offsets = (counts64.cumsum(0) - counts64).to(torch.int32)
         pts = torch.empty((int(counts64.sum()), 3), dtype=torch.float32, device=dev)   # (the one sync)
         if pts.shape[0]:
-            _lib.check(L.sdfr_depth_to_points(depth.data_ptr(), V, W, H, 1.0 / fx, 1.0 / fy, cx, cy, offsets.data_ptr(),
-                                              ws.data_ptr(), pts.data_ptr(), dev.index, st),
+            _lib.check(L.sdfr_depth_to_points_ordered(depth.data_ptr(), V, W, H, order, 1.0 / fx, 1.0 / fy, cx, cy,
+                                                      offsets.data_ptr(), ws.data_ptr(), pts.data_ptr(), dev.index, st),
                        "sdfr_depth_to_points")
         return pts, counts64
+    if tiled:
+        raise RuntimeError("the tiled point order is the GPU path's")
     b, rows, cols = torch.nonzero(depth, as_tuple=True)
     z = depth[b, rows, cols]
     pts = torch.stack(((cols.float() - cx) * z / fx, -(rows.float() - cy) * z / fy, -z), dim=1)

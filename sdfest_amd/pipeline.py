@@ -68,14 +68,15 @@ def quaternion_apply(q: torch.Tensor, points: torch.Tensor) -> torch.Tensor:
     return quaternion_multiply(quaternion_multiply(q, pq), quaternion_invert(q))[..., :3]
 
 
-def depth_to_pointcloud(depth_image: torch.Tensor, camera: Camera) -> torch.Tensor:
+def depth_to_pointcloud(depth_image: torch.Tensor, camera: Camera, tiled: bool = False) -> torch.Tensor:
     """(H,W) depth -> (N,3) OpenGL-frame points of the non-zero pixels, row-major order.
 
     Reference: pointset_utils.depth_to_pointcloud (:57-77, convention "opengl", no mask, no
-    normalisation) -- note the pixel-centre-0 intrinsics."""
+    normalisation) -- note the pixel-centre-0 intrinsics.  tiled: the same points in 16 x 16-pixel patches
+    (``generated_views.depth_to_pointsets``)."""
     if depth_image.is_cuda and depth_image.dtype == torch.float32:
         from .generated_views import depth_to_pointsets   # sdfr_depth_count / sdfr_depth_to_points
-        return depth_to_pointsets(depth_image[None], camera)[0]
+        return depth_to_pointsets(depth_image[None], camera, tiled=tiled)[0]
     fx, fy, cx, cy, _ = camera.get_pinhole_camera_parameters(0.0)
     rows, cols = torch.nonzero(depth_image, as_tuple=True)
     z = depth_image[rows, cols]
@@ -102,10 +103,11 @@ class RenderAndCompare:
         self.device = torch.device(device)
         self.group, self.rank, self.world = resolve_group(process_group)
 
-    def prepare_views(self, depth_images: torch.Tensor):
+    def prepare_views(self, depth_images: torch.Tensor, tiled: bool = False):
         """Observed point clouds of all views, concatenated, with their segment offsets.  Done once
-        per call (the reference recomputes it every iteration, simple_setup.py:134-136)."""
-        clouds = [depth_to_pointcloud(d, self.cam) for d in depth_images]
+        per call (the reference recomputes it every iteration, simple_setup.py:134-136).  tiled: every view's
+        points in compact patches instead of image rows (the point-cloud loss is a mean over them: any order)."""
+        clouds = [depth_to_pointcloud(d, self.cam, tiled=tiled) for d in depth_images]
         lens = [c.shape[0] for c in clouds]
         offsets = torch.tensor([0] + list(torch.tensor(lens).cumsum(0).tolist()), dtype=torch.int32,
                                device=self.device)
@@ -336,7 +338,8 @@ class FusedRenderAndCompare:
         self.cam_quat = (torch.tensor([0.0, 0.0, 0.0, 1.0], **f32).repeat(V, 1) if camera_orientations is None
                          else camera_orientations.to(**f32).contiguous())
         helper = RenderAndCompare(decoder, camera, config, self.dev)
-        self.points, self.offsets, lens = helper.prepare_views(self.target)
+        # compact patches: the sampler's backward pre-sums 256 consecutive points before its global atomics
+        self.points, self.offsets, lens = helper.prepare_views(self.target, tiled=True)
         self.max_pts = max(lens) if lens else 0
         self.Lz = decoder.latent_size
         n = 8 + self.Lz

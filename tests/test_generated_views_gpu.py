@@ -161,6 +161,66 @@ def test_batched_back_projection_kernel_equals_torch_expression():
             assert torch.equal(parts[v], depth_to_pointcloud(depth[v], cam))
 
 
+def test_tiled_point_order_is_a_permutation_in_16x16_patches():
+    """SDFR_POINT_ORDER_TILED: every view's points are the row-major ones, permuted -- bit-identical coordinates,
+    enumerated tile by tile (64 x 16), sub-tile by sub-tile (16 x 16), row by row -- for ragged image sizes too."""
+    from sdfest_amd import Camera
+    from sdfest_amd.generated_views import depth_to_pointsets
+    rng = np.random.default_rng(6)
+    for W, H, V in ((640, 480, 3), (37, 29, 4), (1, 1, 2), (1030, 3, 3), (64, 16, 2), (65, 17, 2)):
+        cam = Camera(W, H, 0.9 * W + 3.3, 1.1 * W + 1.7, 0.47 * W, 0.55 * H, pixel_center=0.5)
+        d = rng.uniform(0.3, 2.0, (V, H, W)).astype(np.float32)
+        d[rng.uniform(size=d.shape) < 0.6] = 0
+        d[1] = 0
+        depth = torch.tensor(d, device="cuda")
+        pts, counts = depth_to_pointsets(depth, cam)
+        tpts, tcounts = depth_to_pointsets(depth, cam, tiled=True)
+        assert torch.equal(counts, tcounts)
+        fx, fy, cx, cy, _ = cam.get_pinhole_camera_parameters(0.0)
+        for v, (a, b) in enumerate(zip(torch.split(pts, counts.tolist()), torch.split(tpts, counts.tolist()))):
+            rows, cols = np.nonzero(d[v])
+            key = (((rows // 16) * ((W + 63) // 64) + cols // 64) * 4 + (cols % 64) // 16) * 256 + (rows % 16) * 16 + cols % 16
+            order = np.argsort(key, kind="stable")
+            assert torch.equal(b, a[torch.tensor(order, device="cuda")]), (W, H, v)
+
+
+def test_point_cloud_loss_does_not_depend_on_the_point_order():
+    """the loss-fused sampler backward on row-major and on tiled points of the same depth images: loss and pose
+    gradients agree to rounding (other summation order), d/dSDF to the order of its atomics."""
+    from sdfest_amd import BatchRenderPlan, Camera, _lib
+    from sdfest_amd.generated_views import depth_to_pointsets
+    import oracle
+    dev = torch.device("cuda")
+    V, W, H = 6, 320, 240
+    cam = Camera(W, H, 160.0, 160.0, 160.0, 120.0, pixel_center=0.5)
+    sdf = torch.tensor(oracle.blobs_sdf(0), device=dev)
+    pos, quat, isc = (torch.tensor(a, device=dev) for a in oracle.random_poses(V, seed=4, width=W, height=H, f=160.0))
+    depth = BatchRenderPlan(64, V, cam).forward(sdf, pos, quat, isc, 0.005).clone()
+    pos2 = (pos + 0.01).contiguous()          # sample the observed clouds at a perturbed pose: non-zero values
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    res = []
+    for tiled in (False, True):
+        pts, counts = depth_to_pointsets(depth, cam, tiled=tiled)
+        offs = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), counts.cumsum(0)]).to(torch.int32)
+        M = int(counts.max())
+        loss = torch.zeros(V, device=dev)
+        gs = torch.zeros(64, 64, 64, device=dev)
+        gp, gq, gsc = torch.zeros(V, 3, device=dev), torch.zeros(V, 4, device=dev), torch.zeros(V, device=dev)
+        ws = torch.empty(max(L.sdfr_pc_loss_backward_workspace_bytes(V, M), 256), dtype=torch.uint8, device=dev)
+        _lib.check(L.sdfr_pc_l1_backward(3.0, loss.data_ptr(), pts.data_ptr(), offs.data_ptr(), V, M, pos2.data_ptr(),
+                                         quat.data_ptr(), (1.0 / isc).contiguous().data_ptr(), sdf.data_ptr(), 64, 0,
+                                         gs.data_ptr(), 0, gp.data_ptr(), gq.data_ptr(), gsc.data_ptr(), ws.data_ptr(),
+                                         ws.numel(), 0, st), "sdfr_pc_l1_backward")
+        torch.cuda.synchronize()
+        res.append([t.cpu().numpy().astype(np.float64) for t in (loss, gs, gp, gq, gsc)])
+    a, b = res
+    assert np.all(a[0] > 0) and np.allclose(a[0], b[0], rtol=2e-6)
+    assert np.max(np.abs(a[1] - b[1])) <= 1e-5 * np.max(np.abs(a[1]))
+    for k in (2, 3, 4):
+        assert np.max(np.abs(a[k] - b[k])) <= 2e-5 * max(np.max(np.abs(a[k])), 1e-12), k
+
+
 def _torchvision_affine_nearest(mask_f, matrix):
     """What torchvision 0.12's functional_tensor.affine does with an (H,W) float image and the 6 numbers
     of _get_inverse_affine_matrix, written with the torch calls it makes (_gen_affine_grid: pixel-centre

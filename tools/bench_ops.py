@@ -52,16 +52,17 @@ def main():
     pr, qr, ir = (torch.tensor(a, device=dev) for a in oracle.random_poses(Vr, seed=1))
     plan_r = BatchRenderPlan(64, Vr, cam_r, device=dev)
     depth_r = plan_r.forward(sdf, pr, qr, ir, 0.005)
-    pts_r, counts_r = depth_to_pointsets(depth_r, cam_r)
-    offs_r = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), counts_r.cumsum(0)]).to(torch.int32)
-    Mr = int(counts_r.max())
-    sc_r = 1.0 / ir
-    go_r = torch.rand(pts_r.shape[0], device=dev) * 2 - 1
-    tf = timeit(lambda: _forward_raw(pts_r, offs_r, Mr, pr, qr, sc_r, sdf))
-    tb = timeit(lambda: _backward_raw(go_r, pts_r, offs_r, Mr, pr, qr, sc_r, sdf))
-    out[f"pc_loss on {Vr} back-projected views ({pts_r.shape[0]} points)"] = {
-        "forward_us": round(tf, 1), "backward_us": round(tb, 1),
-        "Mpoints_per_s_fwd+bwd": round(pts_r.shape[0] / (tf + tb), 1)}
+    for tiled in (False, True):   # row-major (the reference's order) and SDFR_POINT_ORDER_TILED (what the loop feeds)
+        pts_r, counts_r = depth_to_pointsets(depth_r, cam_r, tiled=tiled)
+        offs_r = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), counts_r.cumsum(0)]).to(torch.int32)
+        Mr = int(counts_r.max())
+        sc_r = 1.0 / ir
+        go_r = torch.rand(pts_r.shape[0], device=dev) * 2 - 1
+        tf = timeit(lambda: _forward_raw(pts_r, offs_r, Mr, pr, qr, sc_r, sdf))
+        tb = timeit(lambda: _backward_raw(go_r, pts_r, offs_r, Mr, pr, qr, sc_r, sdf))
+        out[f"pc_loss on {Vr} back-projected views ({pts_r.shape[0]} points)" + (", tiled order" if tiled else "")] = {
+            "forward_us": round(tf, 1), "backward_us": round(tb, 1),
+            "Mpoints_per_s_fwd+bwd": round(pts_r.shape[0] / (tf + tb), 1)}
     # decoder
     g = os.path.join(ROOT, "tests", "golden")
     d = np.load(os.path.join(g, "decoder_mug.npz"))

@@ -13,7 +13,7 @@ cam = Camera(640, 480, 320.0, 320.0, 320.0, 240.0, pixel_center=0.5)
 V = 64
 pr, qr, ir = (torch.tensor(a, device=dev) for a in random_poses(V, seed=1))
 depth = BatchRenderPlan(64, V, cam, device=dev).forward(sdf, pr, qr, ir, 0.005)
-pts, counts = depth_to_pointsets(depth, cam)
+pts, counts = depth_to_pointsets(depth, cam, tiled=os.environ.get("TILED", "0") == "1")
 offs = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), counts.cumsum(0)]).to(torch.int32)
 M = int(counts.max())
 go = torch.rand(pts.shape[0], device=dev) * 2 - 1
