@@ -493,6 +493,21 @@ SDFR_API int sdfr_depth_count_ordered(const float* depth, int V, int W, int H, i
 SDFR_API int sdfr_depth_to_points_ordered(const float* depth, int V, int W, int H, int order, float rfx, float rfy,
                                  float cx0, float cy0, const int* offsets, const void* workspace, float* points,
                                  int device, void* stream);
+/* The synthetic-view generator's point sets are normalised by their centroid (generated_dataset.py:318-326:
+ * pointset -= mean(pointset), position -= mean; optionally + a noise vector).  Both passes over the images do that
+ * on the way: sdfr_depth_count_centroid = sdfr_depth_count_ordered that also leaves centroid[v] = mean of view v's
+ * back-projected points (fixed-order sums; 0 for an empty view) and, with `offsets` [V] (nullable), the exclusive
+ * prefix of the counts that sdfr_depth_to_points_* takes -- the caller reads the counts (to size `points`), forms
+ * shift[v] = centroid[v] - noise[v] on the device -- and sdfr_depth_to_points_shifted writes points - shift[v]
+ * (shift NULL: the plain points).  No pass over the packed points, no per-point owner index, no atomics.
+ * Workspace: sdfr_depth_centroid_workspace_bytes, 16-byte aligned, the same for both calls. */
+SDFR_API size_t sdfr_depth_centroid_workspace_bytes(int V, int W, int H);
+SDFR_API int sdfr_depth_count_centroid(const float* depth, int V, int W, int H, int order, float rfx, float rfy,
+                              float cx0, float cy0, int* counts, int* offsets, float* centroid, void* workspace,
+                              size_t workspace_bytes, int device, void* stream);
+SDFR_API int sdfr_depth_to_points_shifted(const float* depth, int V, int W, int H, int order, float rfx, float rfy,
+                                 float cx0, float cy0, const int* offsets, const void* workspace, const float* shift,
+                                 float* points, int device, void* stream);
 
 /* a += b  (sums the renderer's and the sampler's d/dSDF) */
 SDFR_API int sdfr_add_inplace(float* a, const float* b, size_t n, int device, void* stream);

@@ -44,6 +44,12 @@ def set_threads(n: int) -> None:
     lib().sdfo_set_threads(ctypes.c_int(int(n)))
 
 
+def set_margin_mode(hit_tests_only: bool) -> None:
+    """What ``render_forward(..., with_aux=True)``'s margin covers: every branch decision of the ray (default), or
+    the hit tests alone -- the decisions that can change a pixel's depth (oracle/sdfr_oracle.c)."""
+    lib().sdfo_set_margin_mode(ctypes.c_int(1 if hit_tests_only else 0))
+
+
 def max_threads() -> int:
     return int(lib().sdfo_max_threads())
 

@@ -15,6 +15,13 @@
 #include <stdlib.h>
 #include <stddef.h>
 
+/* Which decisions `margin` of sdfo_render_forward covers: 0 (default) every branch of the pixel's ray -- slab tests,
+ * hit tests, the march's loop bound; 1 the HIT TESTS alone (|dist - threshold * t| of every sample): the decisions
+ * that change a pixel's depth.  (A ray that grazes the cube's silhouette or takes one sample more before it leaves
+ * the cube flips the other decisions without changing anything it returns.) */
+static int g_margin_hit_tests_only = 0;
+void sdfo_set_margin_mode(int hit_tests_only) { g_margin_hit_tests_only = hit_tests_only != 0; }
+
 #define REAL float
 #define SUFFIX _f32
 #define SQRT sqrtf

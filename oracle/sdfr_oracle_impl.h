@@ -198,7 +198,7 @@ void FN(sdfo_render_forward)(const REAL* sdf, int R, const REAL* pos, const REAL
         int n = 0;
         FN(v3) d = FN(pixel_ray)(row, col, cx, cy, fx, fy);
         REAL t, t_far;
-        if (FN(slab_clip)(d, p, rot, scale, &t, &t_far, margin ? &mg : 0)) {
+        if (FN(slab_clip)(d, p, rot, scale, &t, &t_far, (margin && !g_margin_hit_tests_only) ? &mg : 0)) {
           FN(v3) dobj = FN(mat_apply_t)(rot, d);
           while (t < t_far) {
             if (max_steps > 0 && n >= max_steps) break;
@@ -212,7 +212,7 @@ void FN(sdfo_render_forward)(const REAL* sdf, int R, const REAL* pos, const REAL
             if (dist < thr * t) { out = -t * d.z; break; }
             t += dist;
             m = FABS(t - t_far);
-            if (m < mg) mg = m;
+            if (m < mg && !g_margin_hit_tests_only) mg = m;
           }
         }
         depth[pix] = out;

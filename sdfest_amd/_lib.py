@@ -104,6 +104,11 @@ SIGNATURES = {
     "sdfr_depth_count_ordered": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp, c_sz, c_int, c_fp]),
     "sdfr_depth_to_points_ordered": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_fp, c_fp, c_fp,
                                              c_int, c_fp]),
+    "sdfr_depth_centroid_workspace_bytes": (c_sz, [c_int, c_int, c_int]),
+    "sdfr_depth_count_centroid": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_fp, c_fp, c_fp, c_fp,
+                                          c_sz, c_int, c_fp]),
+    "sdfr_depth_to_points_shifted": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_fp, c_fp, c_fp,
+                                             c_fp, c_int, c_fp]),
     "sdfr_add_inplace": (c_int, [c_fp, c_fp, c_sz, c_int, c_fp]),
     "sdfr_adam_step": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_f, c_f, c_f, c_f, c_int, c_int, c_fp]),
     "sdfr_point_constraint": (c_int, [c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_int, c_fp]),

@@ -667,10 +667,15 @@ __device__ __forceinline__ void load_four(const float* __restrict__ img, const P
   for (int k = 0; k < 4; ++k) z[k] = (row < po.H && col + k < po.W) ? img[(size_t)row * po.W + col + k] : 0.0f;
 }
 
+// SUMS: also the block's sums of the back-projected coordinates (block_sum [v][blk][4]: x, y, z, unused), for the
+// view's centroid (generated_dataset.py:318-320 normalises the point set by its mean) -- fixed order: lanes, waves.
+template <bool SUMS>
 __global__ __launch_bounds__(256) void depth_count_kernel(const float* __restrict__ depth, PixelOrder po, int nblk,
                                                           int* __restrict__ block_count,
-                                                          int* __restrict__ count) {
+                                                          int* __restrict__ count, float rfx, float rfy, float cx0,
+                                                          float cy0, float* __restrict__ block_sum) {
   __shared__ int wsum[4];
+  __shared__ float wxyz[4][3];
   const int v = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
   const float* img = depth + (size_t)v * po.W * po.H;
   const int p0 = blk * kCompactPix + tid * 4;
@@ -680,6 +685,20 @@ __global__ __launch_bounds__(256) void depth_count_kernel(const float* __restric
   load_four(img, po, p0, z4, row, col);
 #pragma unroll
   for (int k = 0; k < 4; ++k) c += (z4[k] != 0.0f) ? 1 : 0;
+  if (SUMS) {
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (z4[k] == 0.0f) continue;
+      const int p = p0 + k;
+      const int r = po.tiled ? row : p / po.W, cc = po.tiled ? col + k : p - (p / po.W) * po.W;
+      sx += ((float)cc - cx0) * z4[k] * rfx;     // the expressions of depth_compact_kernel
+      sy += -((float)r - cy0) * z4[k] * rfy;
+      sz += -z4[k];
+    }
+    sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+    if ((tid & 63) == 0) { wxyz[tid >> 6][0] = sx; wxyz[tid >> 6][1] = sy; wxyz[tid >> 6][2] = sz; }
+  }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
   if ((tid & 63) == 0) wsum[tid >> 6] = c;
@@ -689,6 +708,47 @@ __global__ __launch_bounds__(256) void depth_count_kernel(const float* __restric
     block_count[(size_t)v * nblk + blk] = t;
     if (t) atomicAdd(&count[v], t);
   }
+  if (SUMS && tid < 3)
+    block_sum[((size_t)v * nblk + blk) * 4 + tid] = (wxyz[0][tid] + wxyz[1][tid]) + (wxyz[2][tid] + wxyz[3][tid]);
+}
+
+// one wave: offsets[v] = number of points of the views before v (exclusive prefix of the counts), 64 views per round
+__global__ __launch_bounds__(64) void count_prefix_kernel(const int* __restrict__ count, int V, int* __restrict__ offsets) {
+  const int lane = threadIdx.x;
+  int base = 0;
+  for (int v0 = 0; v0 < V; v0 += 64) {
+    const int v = v0 + lane;
+    const int c = v < V ? count[v] : 0;
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (v < V) offsets[v] = base + incl - c;
+    base += __shfl(incl, 63, 64);
+  }
+}
+
+// one wave per view: centroid[v] = (sum of the block sums, lane-strided then a butterfly) / count; 0 for an empty view
+__global__ __launch_bounds__(64) void centroid_reduce_kernel(const float* __restrict__ block_sum, int nblk,
+                                                             const int* __restrict__ count,
+                                                             float* __restrict__ centroid) {
+  const int v = blockIdx.x, lane = threadIdx.x;
+  float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+  for (int i = lane; i < nblk; i += 64) {
+    const float4 q = *reinterpret_cast<const float4*>(block_sum + ((size_t)v * nblk + i) * 4);
+    sx += q.x; sy += q.y; sz += q.z;
+  }
+  sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+  if (lane == 0) {
+    const int n = count[v];
+    const float inv = n > 0 ? 1.0f / (float)n : 0.0f;
+    centroid[3 * v] = n > 0 ? sx / (float)n : 0.0f;
+    centroid[3 * v + 1] = n > 0 ? sy / (float)n : 0.0f;
+    centroid[3 * v + 2] = n > 0 ? sz / (float)n : 0.0f;
+    (void)inv;
+  }
 }
 
 // grid (nblk, V): points[offsets[v] + rank of the pixel within its view] = back-projection
@@ -696,6 +756,7 @@ __global__ __launch_bounds__(256) void depth_compact_kernel(const float* __restr
                                                             int nblk, const int* __restrict__ block_count,
                                                             const int* __restrict__ offsets, float rfx,
                                                             float rfy, float cx0, float cy0,
+                                                            const float* __restrict__ shift,
                                                             float* __restrict__ points) {
   __shared__ int wsum[4];
   __shared__ int base_s;
@@ -730,14 +791,16 @@ __global__ __launch_bounds__(256) void depth_compact_kernel(const float* __restr
   int before = incl - c;
   for (int w = 0; w < wave; ++w) before += wsum[w];
   float* out = points + 3 * (size_t)(base_s + before);
+  // (x - 0.0f == x bit for bit, so the plain form is this one with a zero shift)
+  const V3 sh = shift ? mk(shift[3 * v], shift[3 * v + 1], shift[3 * v + 2]) : mk(0.0f, 0.0f, 0.0f);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (z[k] == 0.0f) continue;
     const int p = p0 + k;
     const int row = po.tiled ? trow : p / W, col = po.tiled ? tcol + k : p - (p / W) * W;
-    out[0] = ((float)col - cx0) * z[k] * rfx;   // torch divides by a scalar as "* (1 / scalar)" on the GPU
-    out[1] = -((float)row - cy0) * z[k] * rfy;
-    out[2] = -z[k];
+    out[0] = ((float)col - cx0) * z[k] * rfx - sh.x;   // torch divides by a scalar as "* (1 / scalar)" on the GPU
+    out[1] = -((float)row - cy0) * z[k] * rfy - sh.y;
+    out[2] = -z[k] - sh.z;
     out += 3;
   }
 }
@@ -1143,8 +1206,46 @@ extern "C" int sdfr_depth_count_ordered(const float* depth, int V, int W, int H,
     return fail(SDFR_E_WORKSPACE, "sdfr_depth_count: workspace too small");
   const PixelOrder po = pixel_order(W, H, order);
   const int nblk = (po.count() + kCompactPix - 1) / kCompactPix;
-  hipLaunchKernelGGL(depth_count_kernel, dim3(nblk, V), dim3(256), 0, st, depth, po, nblk, (int*)workspace,
-                     counts);
+  hipLaunchKernelGGL(depth_count_kernel<false>, dim3(nblk, V), dim3(256), 0, st, depth, po, nblk, (int*)workspace,
+                     counts, 0.0f, 0.0f, 0.0f, 0.0f, (float*)nullptr);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" size_t sdfr_depth_centroid_workspace_bytes(int V, int W, int H) {
+  // [block counts][block sums, 16 bytes each, 16-byte aligned]
+  const size_t n = (sdfr_depth_points_workspace_bytes(V, W, H) + 15) & ~(size_t)15;
+  return n + 4 * n;
+}
+
+extern "C" int sdfr_depth_count_centroid(const float* depth, int V, int W, int H, int order, float rfx, float rfy,
+                                         float cx0, float cy0, int* counts, int* offsets, float* centroid,
+                                         void* workspace, size_t workspace_bytes, int device, void* stream) {
+  const char* fn = "sdfr_depth_count_centroid";
+  if (order != SDFR_POINT_ORDER_ROW_MAJOR && order != SDFR_POINT_ORDER_TILED)
+    return fail(SDFR_E_INVALID, "%s: unknown point order %d", fn, order);
+  if (V < 0 || W < 0 || H < 0 || V > 65535 || (long long)(W + 63) * (H + 15) > 0x7fffffffLL)
+    return fail(SDFR_E_INVALID, "%s: bad sizes", fn);
+  if (V == 0) return 0;
+  if (!counts || !centroid) return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
+  SDFR_HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  zero_words_async(reinterpret_cast<float*>(counts), (size_t)V, st);
+  if (W == 0 || H == 0) {
+    zero_words_async(centroid, (size_t)V * 3, st);
+    if (offsets) zero_words_async(reinterpret_cast<float*>(offsets), (size_t)V, st);
+    return 0;
+  }
+  if (!depth || !workspace) return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
+  if (workspace_bytes < sdfr_depth_centroid_workspace_bytes(V, W, H) || (uintptr_t)workspace % 16)
+    return fail(SDFR_E_WORKSPACE, "%s: workspace too small or not 16-byte aligned", fn);
+  const PixelOrder po = pixel_order(W, H, order);
+  const int nblk = (po.count() + kCompactPix - 1) / kCompactPix;
+  float* sums = (float*)((char*)workspace + ((sdfr_depth_points_workspace_bytes(V, W, H) + 15) & ~(size_t)15));
+  hipLaunchKernelGGL(depth_count_kernel<true>, dim3(nblk, V), dim3(256), 0, st, depth, po, nblk, (int*)workspace,
+                     counts, rfx, rfy, cx0, cy0, sums);
+  hipLaunchKernelGGL(centroid_reduce_kernel, dim3(V), dim3(64), 0, st, sums, nblk, counts, centroid);
+  if (offsets) hipLaunchKernelGGL(count_prefix_kernel, dim3(1), dim3(64), 0, st, counts, V, offsets);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1152,6 +1253,13 @@ extern "C" int sdfr_depth_count_ordered(const float* depth, int V, int W, int H,
 extern "C" int sdfr_depth_to_points_ordered(const float* depth, int V, int W, int H, int order, float rfx, float rfy,
                                             float cx0, float cy0, const int* offsets, const void* workspace,
                                             float* points, int device, void* stream) {
+  return sdfr_depth_to_points_shifted(depth, V, W, H, order, rfx, rfy, cx0, cy0, offsets, workspace, nullptr, points,
+                                      device, stream);
+}
+
+extern "C" int sdfr_depth_to_points_shifted(const float* depth, int V, int W, int H, int order, float rfx, float rfy,
+                                            float cx0, float cy0, const int* offsets, const void* workspace,
+                                            const float* shift, float* points, int device, void* stream) {
   if (order != SDFR_POINT_ORDER_ROW_MAJOR && order != SDFR_POINT_ORDER_TILED)
     return fail(SDFR_E_INVALID, "sdfr_depth_to_points: unknown point order %d", order);
   if (V < 0 || W < 0 || H < 0 || V > 65535 || (long long)(W + 63) * (H + 15) > 0x7fffffffLL)
@@ -1163,7 +1271,7 @@ extern "C" int sdfr_depth_to_points_ordered(const float* depth, int V, int W, in
   const PixelOrder po = pixel_order(W, H, order);
   const int nblk = (po.count() + kCompactPix - 1) / kCompactPix;
   hipLaunchKernelGGL(depth_compact_kernel, dim3(nblk, V), dim3(256), 0, (hipStream_t)stream, depth, po,
-                     nblk, (const int*)workspace, offsets, rfx, rfy, cx0, cy0, points);
+                     nblk, (const int*)workspace, offsets, rfx, rfy, cx0, cy0, shift, points);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -175,13 +175,85 @@ def depth_to_pointsets(depth: torch.Tensor, camera: Camera, tiled: bool = False)
     return pts, torch.bincount(b, minlength=depth.shape[0])
 
 
+class PointSets:
+    """The per-view point sets of a packed batch as a read-only sequence: ``sets[b]`` is the (N_b, 3) view of
+    ``points`` that ``torch.split`` would return, made when it is asked for (a batch of 256 views costs ~0.1 ms of
+    host time to split eagerly, whether or not anybody reads the views)."""
+
+    def __init__(self, points: torch.Tensor, counts_host):
+        self.points = points
+        self.bounds = np.concatenate([[0], np.cumsum(np.asarray(counts_host, dtype=np.int64))])
+
+    def __len__(self):
+        return len(self.bounds) - 1
+
+    def __getitem__(self, b):
+        if isinstance(b, slice):
+            return [self[i] for i in range(*b.indices(len(self)))]
+        if b < 0:
+            b += len(self)
+        if not 0 <= b < len(self):
+            raise IndexError(b)
+        return self.points[int(self.bounds[b]):int(self.bounds[b + 1])]
+
+    def __iter__(self):
+        return (self[b] for b in range(len(self)))
+
+
+def depth_to_centred_pointsets(depth: torch.Tensor, camera: Camera, noise: Optional[torch.Tensor] = None,
+                               while_waiting=None):
+    """``depth_to_pointsets`` for the generator's normalised samples (generated_dataset.py:318-326): every view's
+    points minus their centroid (plus ``noise`` (B,3), if given), without a pass over the packed points -- the count
+    pass leaves the centroids (``sdfr_depth_count_centroid``), the compaction subtracts them
+    (``sdfr_depth_to_points_shifted``).  Returns (points (N,3), counts (B,) int64 on the device, counts on the host,
+    centroid (B,3)); one synchronisation (the caller sizes the output).  ``while_waiting``: called on the host
+    after the count pass has been issued and before its result is waited for (CPU work that hides behind the GPU's)."""
+    from . import _lib
+    L = _lib.lib()
+    fx, fy, cx, cy, _ = camera.get_pinhole_camera_parameters(0.0)
+    depth = depth.contiguous()
+    V, H, W = depth.shape
+    dev = depth.device
+    counts_offsets = torch.empty((2, V), dtype=torch.int32, device=dev)
+    counts, offsets = counts_offsets[0], counts_offsets[1]
+    centroid = torch.empty((V, 3), dtype=torch.float32, device=dev)
+    ws = torch.empty(max(L.sdfr_depth_centroid_workspace_bytes(V, W, H), 256), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(L.sdfr_depth_count_centroid(depth.data_ptr(), V, W, H, 0, 1.0 / fx, 1.0 / fy, cx, cy, counts.data_ptr(),
+                                           offsets.data_ptr(), centroid.data_ptr(), ws.data_ptr(), ws.numel(),
+                                           dev.index, st), "sdfr_depth_count_centroid")
+    shift = centroid if noise is None else centroid - noise.to(centroid)
+    host = torch.empty(V, dtype=torch.int32).pin_memory()
+    host.copy_(counts, non_blocking=True)
+    done = torch.cuda.Event()
+    done.record()
+    if while_waiting is not None:
+        while_waiting()
+    done.synchronize()                                                  # (the one sync)
+    counts_host = host.numpy()
+    counts64 = counts.to(torch.int64)
+    pts = torch.empty((int(counts_host.sum()), 3), dtype=torch.float32, device=dev)
+    if pts.shape[0]:
+        _lib.check(L.sdfr_depth_to_points_shifted(depth.data_ptr(), V, W, H, 0, 1.0 / fx, 1.0 / fy, cx, cy,
+                                                  offsets.data_ptr(), ws.data_ptr(), shift.contiguous().data_ptr(),
+                                                  pts.data_ptr(), dev.index, st), "sdfr_depth_to_points_shifted")
+    return pts, counts64, counts_host, centroid
+
+
 class SDFVAEViewGenerator:
     """Batched ``SDFVAEViewDataset`` (generated_dataset.py:26-342).
 
     ``decoder`` is a :class:`sdfest_amd.SDFDecoder`; ``config`` uses the reference's keys (see
     DEFAULT_CONFIG; ``z_min``, ``z_max``, ``extent_mean``, ``extent_std`` are required)."""
 
-    def __init__(self, config: Dict, decoder, batch_size: int = 64, device="cuda", seed: Optional[int] = None):
+    def __init__(self, config: Dict, decoder, batch_size: int = 64, device="cuda", seed: Optional[int] = None,
+                 prefetch_draws: bool = False):
+        """prefetch_draws: a ``generate()`` that draws its own latents and poses also draws the NEXT batch's while the
+        GPU is busy with this one (the numbers and their order in the generator's stream stay what they were; a call
+        that is given a latent or a pose discards what was drawn ahead for it).  For consumers that call
+        ``generate()`` over and over -- iteration turns it on."""
+        self.prefetch_draws = bool(prefetch_draws)
+        self._ahead = None
         cfg = dict(DEFAULT_CONFIG)
         cfg.update(config)
         for k in ("z_min", "z_max", "extent_mean", "extent_std"):
@@ -227,13 +299,36 @@ class SDFVAEViewGenerator:
         and with ``pointcloud``: "pointset" (list of (N_b,3) views of the packed "points") and
         "valid" (B,) = the reference's _is_valid (at least one depth pixel)."""
         cfg, B, dev = self.cfg, self.B, self.device
-        if latent is None:
-            latent = torch.randn((B, self.decoder.latent_size), generator=self.gen)     # SDFVAE.sample
-        p, q, s = sample_poses(B, self.camera, cfg["z_min"], cfg["z_max"], cfg["extent_mean"],
-                               cfg["extent_std"], self.gen)
-        position = (p if position is None else position).to(dev).clone()
-        quaternion = (q if quaternion is None else quaternion).to(dev)
-        scale = (s if scale is None else scale).to(dev).clone()
+        ahead, self._ahead = self._ahead, None
+        draws_all = latent is None and position is None and quaternion is None and scale is None
+        if ahead is not None:
+            z0, p, q, s = ahead
+            latent = z0 if latent is None else latent
+        else:
+            if latent is None:
+                latent = torch.randn((B, self.decoder.latent_size), generator=self.gen)     # SDFVAE.sample
+            p, q, s = sample_poses(B, self.camera, cfg["z_min"], cfg["z_max"], cfg["extent_mean"],
+                                   cfg["extent_std"], self.gen)
+
+        def draw_ahead():
+            # (after every draw of THIS batch, so the stream's order is the one of back-to-back calls)
+            if self.prefetch_draws and draws_all:
+                self._ahead = (torch.randn((B, self.decoder.latent_size), generator=self.gen),) + tuple(
+                    sample_poses(B, self.camera, cfg["z_min"], cfg["z_max"], cfg["extent_mean"], cfg["extent_std"],
+                                 self.gen))
+        position, quaternion, scale = (p if position is None else position, q if quaternion is None else quaternion,
+                                       s if scale is None else scale)
+        host = [t for t in (latent, position, quaternion, scale) if not t.is_cuda]
+        if len(host) == 4 and all(t.dtype == torch.float32 for t in host):
+            # one packed transfer instead of four small ones (each costs ~15 us of host time)
+            Lz = latent.shape[1]
+            packed = torch.cat((latent, position, quaternion, scale[:, None]), 1).to(dev, non_blocking=True)
+            latent, position, quaternion, scale = (packed[:, :Lz], packed[:, Lz:Lz + 3].clone(),
+                                                   packed[:, Lz + 3:Lz + 7], packed[:, Lz + 7].clone())
+        else:
+            position = position.to(dev).clone()
+            quaternion = quaternion.to(dev)
+            scale = scale.to(dev).clone()
         depth = self.render(latent, position, quaternion, scale,
                             out=torch.empty((B, cfg["height"], cfg["width"]), dtype=torch.float32, device=dev))
         final_mask = None
@@ -253,7 +348,21 @@ class SDFVAEViewGenerator:
         if final_mask is not None:
             depth = (depth * final_mask).contiguous()                                  # :310  depth[~final_mask] = 0
         out = {"depth": depth, "latent_shape": latent.to(dev)}
-        if cfg["pointcloud"]:                                                          # :312-334
+        if cfg["pointcloud"] and cfg["normalize_pose"] and not cfg["scale_to_unit_ball"] and depth.is_cuda:
+            # :312-326 with the centroid formed and subtracted inside the two passes over the images
+            noise = None
+            if cfg["norm_noise"]:
+                lo, hi = cfg["norm_noise_min"], cfg["norm_noise_max"]
+                noise = (lo + (hi - lo) * torch.rand((B, 3), generator=self.gen)).to(dev)
+            pts, counts, counts_host, centroid = depth_to_centred_pointsets(depth, self.camera, noise,
+                                                                            while_waiting=draw_ahead)
+            out["valid"] = counts > 0
+            position -= centroid
+            if noise is not None:
+                position += noise
+            out["points"], out["counts"] = pts, counts
+            out["pointset"] = PointSets(pts, counts_host)
+        elif cfg["pointcloud"]:                                                        # :312-334
             pts, counts = depth_to_pointsets(depth, self.camera)
             out["valid"] = counts > 0          # = the reference's depth.max() != 0, from the counts
             owner = torch.repeat_interleave(torch.arange(B, device=dev), counts)
@@ -299,6 +408,7 @@ class SDFVAEViewGenerator:
         return res
 
     def __iter__(self):
+        self.prefetch_draws = True
         while True:
             for s in self.samples(self.generate()):
                 yield s

@@ -109,6 +109,65 @@ def test_normalisation_noise_and_smoothing_options(mug_decoder):
         assert torch.allclose(o2["position"][b], plain["position"][b] - ref_c + c, atol=1e-5)
 
 
+def test_centred_point_sets_come_out_of_the_two_image_passes(mug_decoder):
+    """normalize_pose without the unit ball (the generator's fast path, generated_dataset.py:318-326): the centroid
+    is formed in the count pass and subtracted in the compaction -- against the per-sample torch expressions, and
+    the kernels alone on ragged images with an empty view, with and without the noise vector."""
+    from sdfest_amd import Camera
+    from sdfest_amd.generated_views import PointSets, SDFVAEViewGenerator, depth_to_centred_pointsets
+    from sdfest_amd.pipeline import depth_to_pointcloud
+    dec, d = mug_decoder
+    B = 5
+    plain = SDFVAEViewGenerator(CFG, dec, batch_size=B, seed=7).generate()
+    gen = SDFVAEViewGenerator({**CFG, "normalize_pose": True}, dec, batch_size=B, seed=8)
+    out = gen.generate(latent=plain["latent_shape"].cpu(), position=plain["position"].cpu(),
+                       quaternion=plain["quaternion"].cpu(), scale=plain["scale"].cpu())
+    assert isinstance(out["pointset"], PointSets) and len(out["pointset"]) == B
+    assert torch.equal(out["depth"], plain["depth"])
+    for b in range(B):
+        pts = depth_to_pointcloud(plain["depth"][b], gen.camera)
+        c = pts.double().mean(0).float()
+        assert out["pointset"][b].shape == pts.shape
+        assert torch.allclose(out["pointset"][b], pts - c, rtol=1e-5, atol=2e-6)
+        assert torch.allclose(out["position"][b], plain["position"][b] - c, rtol=1e-5, atol=2e-6)
+    assert sum(p.shape[0] for p in out["pointset"]) == out["points"].shape[0] == int(out["counts"].sum())
+    assert len(gen.samples(out)) == int(out["valid"].sum())
+    rng = np.random.default_rng(9)
+    for W, H, V in ((37, 29, 4), (640, 480, 3), (1030, 3, 3)):
+        cam = Camera(W, H, 0.9 * W + 3.3, 1.1 * W + 1.7, 0.47 * W, 0.55 * H, pixel_center=0.5)
+        dd = rng.uniform(0.3, 2.0, (V, H, W)).astype(np.float32)
+        dd[rng.uniform(size=dd.shape) < 0.7] = 0
+        dd[1] = 0
+        depth = torch.tensor(dd, device="cuda")
+        for noise in (None, torch.tensor(rng.uniform(-0.2, 0.2, (V, 3)).astype(np.float32), device="cuda")):
+            pts, counts, counts_host, centroid = depth_to_centred_pointsets(depth, cam, noise)
+            assert counts.tolist() == counts_host.tolist() == [(dd[v] != 0).sum() for v in range(V)]
+            assert torch.equal(centroid[1], torch.zeros(3, device="cuda"))          # the empty view
+            for v, part in enumerate(torch.split(pts, counts.tolist())):
+                ref = torch_points(depth[v], cam)
+                if ref.shape[0] == 0:
+                    continue
+                c = ref.double().mean(0)
+                assert torch.allclose(centroid[v].double(), c, rtol=2e-6, atol=1e-7), (W, H, v)
+                want = ref.double() - centroid[v].double() + (0 if noise is None else noise[v].double())
+                assert torch.allclose(part.double(), want, rtol=0, atol=3e-7 * float(ref.abs().max()))
+
+
+def test_prefetched_draws_are_the_same_numbers(mug_decoder):
+    """prefetch_draws: batch k + 1's latents and poses are drawn while the GPU works on batch k -- the same numbers
+    from the same stream as back-to-back calls draw."""
+    from sdfest_amd.generated_views import SDFVAEViewGenerator
+    dec, d = mug_decoder
+    cfg = {**CFG, "normalize_pose": True, "norm_noise": True}
+    a = SDFVAEViewGenerator(cfg, dec, batch_size=4, seed=21)
+    b = SDFVAEViewGenerator(cfg, dec, batch_size=4, seed=21, prefetch_draws=True)
+    for _ in range(3):
+        oa, ob = a.generate(), b.generate()
+        for k in ("latent_shape", "position", "quaternion", "scale", "depth", "points"):
+            assert torch.equal(oa[k], ob[k]), k
+    assert b._ahead is not None and a._ahead is None
+
+
 def test_empty_views_are_flagged_not_returned(mug_decoder):
     from sdfest_amd.generated_views import SDFVAEViewGenerator
     dec, _ = mug_decoder

@@ -109,11 +109,14 @@ def main():
             gb, gen.camera, 0.3, 0.7, 0.15, 0.02, gen.gen))
         zl = zl.to(dev)
         t_r = timeit(lambda: gen.render(zl, gp, gq, gs), 10)
-        t_g = timeit(lambda: gen.generate(), 5)
+        t_g = timeit(lambda: gen.generate(), 10)
+        gen.prefetch_draws = True      # what iterating over the generator does: the next batch is drawn while the GPU works
+        t_p = timeit(lambda: gen.generate(), 10)
         out[f"view generator B={gb} 640x480"] = {"decode+render_us": round(t_r, 1),
                                                  "decode+render_views_per_s": round(gb / t_r * 1e6, 1),
-                                                 "full_sample_us": round(t_g, 1),
-                                                 "samples_per_s": round(gb / t_g * 1e6, 1)}
+                                                 "full_sample_us": round(t_p, 1),
+                                                 "full_sample_us_draws_not_prefetched": round(t_g, 1),
+                                                 "samples_per_s": round(gb / t_p * 1e6, 1)}
     # batched render-and-compare step on the depth term (C3 poses): forward -> masked L1 -> backward,
     # with the loss as its own kernel vs folded into the render kernels
     from sdfest_amd import _lib
