@@ -2,7 +2,12 @@
 assembled from IMPORTED reference pieces (numpy twin renderer + its reduction, losses.pc_loss,
 losses.point_constraint_loss, quaternion_utils, SDFVAE.decode with the mug weights, torch.optim.Adam)
 by tools/make_goldens.py::make_loop_g7 -> tests/golden/loop_g7.npz.  Run A: 2 views with camera
-extrinsics, shape optimisation on; run B: 1 view, point constraint, shape optimisation off.
+extrinsics, shape optimisation on; run B: 1 view, point constraint, shape optimisation off; run C (round 4): the
+CLEAN scene -- 160x120, 2 views, shape optimisation on, the first seeded scene in which no sample of any ray of any
+iteration lies within 2e-7 of its hit test (fp32 against the twin's float64 moves that comparison by ~1e-8), so
+nothing has to be allowed for pixels that flip between hit and miss: loss terms to 5e-5, first gradients to 2e-4 of
+their group's scale, the trajectory to 0.5 % of an Adam step per iteration.  Runs A and B are FRAGILE (pixels down to
+6e-8 of their hit test; the golden carries the counts) and keep the looser bounds.
 Checked per iteration: parameters, first-iteration gradients, loss terms, the inlier ratio of the LAST
 view's loop variables (:463-470); plus nn_loss / point_constraint_loss on seeded inputs."""
 import os
@@ -31,10 +36,21 @@ def mug():
     return SDFDecoder.from_config(mug_config(d), {k: w[k] for k in w.files})
 
 
+CLEAN = {"c"}      # scenes without a pixel near its hit test (tools/make_goldens.py::make_loop_g7)
+
+
+def _fragility(g7, tag):
+    """for assertion messages: how close the twin's pixels came to flipping in this run"""
+    return (f"run {tag}: smallest hit-test margin {g7[f'{tag}_margin_min'].min():.1e}; pixels within 1e-6 per "
+            f"(iteration, view) {g7[f'{tag}_fragile_1e-6'].tolist()}, within 1e-5 {g7[f'{tag}_fragile_1e-5'].tolist()}")
+
+
 def _setup(g7, tag):
     from sdfest_amd import Camera
-    W, H = int(g7["W"]), int(g7["H"])
-    cam = Camera(W, H, float(g7["fx"]), float(g7["fy"]), float(g7["cx"]), float(g7["cy"]), pixel_center=0.5)
+    pre = f"{tag}_" if f"{tag}_W" in g7 else ""
+    W, H = int(g7[pre + "W"]), int(g7[pre + "H"])
+    cam = Camera(W, H, float(g7[pre + "fx"]), float(g7[pre + "fy"]), float(g7[pre + "cx"]), float(g7[pre + "cy"]),
+                 pixel_center=0.5)
     t = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device="cuda")
     init = g7[f"{tag}_init"]
     n_iter = g7[f"{tag}_traj"].shape[0]
@@ -54,31 +70,36 @@ def _check_trajectory(g7, tag, hist, tol_scale=1.0):
         h = hist[it]
         got = np.concatenate([h["position"].cpu().numpy().ravel(), h["orientation"].cpu().numpy().ravel(),
                               h["scale"].cpu().numpy().ravel(), h["latent"].cpu().numpy().ravel()])
-        # Adam's steps are ~lr (1e-3 position / scale, 1e-2 orientation / latent): agree to 2 % of a step per
-        # iteration (the twin marches in float64, the kernels in fp32; a pixel on the hit threshold moves a mean)
+        # Adam's steps are ~lr (1e-3 position / scale, 1e-2 orientation / latent).  Clean scene: 0.5 % of a step
+        # per iteration (fp32 kernels against the float64 twin).  Fragile scenes: 2 % (a pixel on the hit threshold
+        # moves a mean)
         lr = np.array([1e-3] * 3 + [1e-2] * 4 + [1e-3] + [1e-2] * (len(got) - 8))
         err = np.abs(got - traj[it]) / lr
-        assert err.max() < 0.02 * (it + 1) * tol_scale, (tag, it, err)
+        step_tol, loss_tol = (0.005, 5e-5) if tag in CLEAN else (0.02, 2e-4)
+        assert err.max() < step_tol * (it + 1) * tol_scale, (tag, it, err, _fragility(g7, tag))
         if "loss" in h:
-            assert abs(float(h["loss"]) - terms[it, 3]) < 2e-4 * abs(terms[it, 3]) + 1e-6, (tag, it)
+            assert abs(float(h["loss"]) - terms[it, 3]) < loss_tol * abs(terms[it, 3]) + 1e-6, (tag, it, _fragility(g7, tag))
         if "inlier_ratio" in h:
-            assert abs(float(h["inlier_ratio"]) - inl[it]) < 2.5 / 300.0, (tag, it, float(h["inlier_ratio"]), inl[it])
+            n_valid = float((g7[f"{tag}_depth_images"][-1] > 0).sum())
+            assert abs(float(h["inlier_ratio"]) - inl[it]) < (1.5 if tag in CLEAN else 2.5) / n_valid + 1e-6, (
+                tag, it, float(h["inlier_ratio"]), inl[it])
 
 
-@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_autograd_loop_matches_g7(g7, mug, tag):
     from sdfest_amd.pipeline import RenderAndCompare
     cam, cfg, a, con = _setup(g7, tag)
     loop = RenderAndCompare(mug, cam, cfg)
     hist = []
     out = loop(a["depth"], a["p0"], a["q0"], a["s0"], a["z0"], camera_positions=a["cam_pos"],
-               camera_orientations=a["cam_quat"], shape_optimization=(tag == "a"), history=hist,
+               camera_orientations=a["cam_quat"], shape_optimization=(tag != "b"), history=hist,
                point_constraint=con)
     _check_trajectory(g7, tag, hist)
     terms = g7[f"{tag}_terms"]
+    term_tol = 5e-5 if tag in CLEAN else 3e-4
     for it, h in enumerate(hist):
-        assert abs(float(h["loss_depth"]) - terms[it, 0]) < 3e-4 * terms[it, 0]
-        assert abs(float(h["loss_pc"]) - terms[it, 1]) < 3e-4 * terms[it, 1]
+        assert abs(float(h["loss_depth"]) - terms[it, 0]) < term_tol * terms[it, 0], (tag, it, _fragility(g7, tag))
+        assert abs(float(h["loss_pc"]) - terms[it, 1]) < term_tol * terms[it, 1], (tag, it, _fragility(g7, tag))
         assert abs(float(h["loss_point_constraint"]) - terms[it, 2]) < 1e-5 + 1e-5 * terms[it, 2]
     # best_inlier_ratio: the reference hands back the tensors it stored -- the live parameters, i.e. the last
     # iterate -- while the ratio that won may belong to an earlier iteration
@@ -90,13 +111,13 @@ def test_autograd_loop_matches_g7(g7, mug, tag):
         assert torch.equal(out[3], a["z0"])      # shape optimisation off: the latent does not move
 
 
-@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_fused_loop_matches_g7(g7, mug, tag, use_graph):
     from sdfest_amd.pipeline import FusedRenderAndCompare
     cam, cfg, a, con = _setup(g7, tag)
     loop = FusedRenderAndCompare(mug, cam, cfg, a["depth"], camera_positions=a["cam_pos"],
-                                 camera_orientations=a["cam_quat"], shape_optimization=(tag == "a"),
+                                 camera_orientations=a["cam_quat"], shape_optimization=(tag != "b"),
                                  point_constraint=con)
     hist = []
     out = loop(a["p0"], a["q0"], a["s0"], a["z0"], use_graph=use_graph, history=hist)
@@ -104,7 +125,8 @@ def test_fused_loop_matches_g7(g7, mug, tag, use_graph):
     _check_trajectory(g7, tag, hist)
     inl = g7[f"{tag}_inlier"]
     got = loop.inlier_history.cpu().numpy()[:len(inl)]
-    assert np.max(np.abs(got - inl)) < 2.5 / 300.0, (got, inl)
+    n_valid = float((g7[f"{tag}_depth_images"][-1] > 0).sum())
+    assert np.max(np.abs(got - inl)) < (1.5 if tag in CLEAN else 2.5) / n_valid + 1e-6, (got, inl)
     ratio, it, params = loop.best_estimate()
     assert abs(ratio - got.max()) < 1e-7 and it == int(np.argmax(got)) + 1
     # the snapshot is the parameter vector after iteration `it`
@@ -112,11 +134,13 @@ def test_fused_loop_matches_g7(g7, mug, tag, use_graph):
     assert torch.equal(out[0], hist[-1]["position"])
 
 
-def test_first_gradient_matches_g7(g7, mug):
-    """Iteration 1 of run A before Adam: d loss / d (position, orientation, scale, latent) as autograd gave
-    them to the reference pieces (the chain through both cameras, the normalisation and the decoder)."""
+@pytest.mark.parametrize("tag,tol", [("a", 2e-3), ("c", 2e-4)])
+def test_first_gradient_matches_g7(g7, mug, tag, tol):
+    """Iteration 1 before Adam: d loss / d (position, orientation, scale, latent) as autograd gave them to the
+    reference pieces (the chain through both cameras, the normalisation and the decoder).  The clean scene C at
+    2e-4 of each group's largest component; the fragile scene A keeps 2e-3 (a flipped pixel moves a masked mean)."""
     from sdfest_amd.pipeline import RenderAndCompare
-    cam, cfg, a, _ = _setup(g7, "a")
+    cam, cfg, a, _ = _setup(g7, tag)
     loop = RenderAndCompare(mug, cam, cfg)
     p, q, s, z = (x.clone().requires_grad_() for x in (a["p0"], a["q0"], a["s0"], a["z0"]))
     points, offsets, lens = loop.prepare_views(a["depth"])
@@ -124,10 +148,10 @@ def test_first_gradient_matches_g7(g7, mug):
     ld, lp, _ = loop.losses(a["depth"], points, offsets, lens, a["cam_pos"], a["cam_quat"], p, q, s, sdf)
     (1.0 * ld + 3.0 * lp).backward()
     got = np.concatenate([x.grad.cpu().numpy().ravel() for x in (p, q, s, z)])
-    ref = g7["a_grads"][0]
+    ref = g7[f"{tag}_grads"][0]
     scale = np.array([np.abs(ref[0:3]).max()] * 3 + [np.abs(ref[3:7]).max()] * 4 + [abs(ref[7])]
                      + [np.abs(ref[8:]).max()] * (len(ref) - 8))
-    assert np.all(np.abs(got - ref) < 2e-3 * scale), (got, ref)
+    assert np.all(np.abs(got - ref) < tol * scale), (np.abs(got - ref) / scale, _fragility(g7, tag))
 
 
 def test_nn_loss_matches_reference(g7):

@@ -119,3 +119,18 @@ def test_three_ranks_on_seven_views(tmp_path):
 def test_more_ranks_than_views_is_refused():
     from sdfest_amd.parallel import shard_views
     assert shard_views(2, 2, 3) == (2, 2)          # an empty shard: the loop refuses it (every rank needs a view)
+
+
+@pytest.mark.parametrize("graph", ["eager", "graph"])
+def test_sharded_loop_over_rccl_with_one_rank(tmp_path, graph):
+    """The same worker over the backend the multi-GPU node uses -- "nccl" is RCCL on ROCm -- with the one rank a
+    one-GPU box allows: process-group start-up, the bucket's all-reduce on device memory, the captured head / tail
+    graphs around the collective (thread-local capture beside the process group's watchdog thread).  A one-rank sum
+    changes nothing, so the trajectory is the single-process one."""
+    from sdfest_amd.differentiable_renderer import BWD_SMALL_TILES, SDF_GRAD_DETERMINISTIC
+    r = _spawn(tmp_path, "g7a", "det", "sdf", graph, world=1, backend="nccl")
+    traj, _, inl = _single("g7a", SDF_GRAD_DETERMINISTIC | BWD_SMALL_TILES, graph == "graph")
+    assert np.array_equal(traj, r["traj"]) and np.array_equal(inl, r["inlier"])
+    r = _spawn(tmp_path, "g7a", "float", "latent", graph, world=1, backend="nccl")
+    traj, _, _ = _single("g7a", graph=graph == "graph")
+    assert _steps(traj, r["traj"]).max() < 5e-3
