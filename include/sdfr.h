@@ -324,6 +324,11 @@ SDFR_API int sdfr_decoder_forward(const sdfr_decoder* decoder, const float* z, i
                          float* out, float* tape, void* workspace, size_t workspace_bytes,
                          void* stream);
 
+/* TEST HOOK: how batched forwards treat an up-sampling resize in front of a 3x3x3 layer: 1 (default) inside that
+ * layer's patch load where that is faster (fine sizes up to 16), 2 wherever the folded form exists (fine sizes 16, 32,
+ * 64), 0 always as its own launch.  Same results bit for bit: tests compare 2 against 0.  Process-wide; returns the old
+ * value. */
+SDFR_API int sdfr_debug_set_decoder_fused_resize(int on);
 /* Vector-Jacobian product of the decoder w.r.t. the latent, weights held constant: what
  * loss.backward() propagates to latent_shape in SDFPipeline.__call__
  * (sdfest/estimation/simple_setup.py:413-414, :456) through SDFDecoder.forward

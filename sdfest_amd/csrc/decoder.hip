@@ -798,6 +798,184 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(
   }
 }
 
+// conv3d_direct_kernel with the trilinear resize IN FRONT of the layer folded into its patch load (round 4): the
+// up-sampled tensor (8 x 32^3 floats per sample for the mug decoder's third layer -- 268 MB per 256 latents, written
+// by resize3_tiled_kernel and read back here) never exists.  A workgroup stages, per chunk of CK channels, the few
+// COARSE columns under its patch (all of z; prefetched into registers during the previous chunk's FMAs) and forms the
+// fine patch from them in LDS with the expression tree of resize3_kernel -- z innermost, then y, then x, every blend
+// one product and one fma -- so the layer's output is bit for bit the two-launch result.
+//   thread <-> (fine z, patch row py): its z and y terms live in registers for the whole kernel; it walks the patch's
+//   x, holding the y- and z-blended values of the two coarse x-columns around it and advancing them as x crosses a
+//   coarse cell (the advance is workgroup-uniform): per fine element 2 LDS table reads, 2 VALU, 1 LDS write, and per
+//   coarse column 4 LDS reads + 6 VALU.
+// n (the fine size) is a power of two <= 64 (np4 == n; 256 / n patch rows are served side by side).
+//   in: [N][Cin][ni^3];  LDS (dynamic): tile [CK][IX][IY][n] + 8 | coarse [CK][max_cols][ni];  grid as conv3d_direct_kernel
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3d_direct_up_kernel(
+    const float* __restrict__ in, int ni, const float* __restrict__ wd, const float* __restrict__ bias,
+    float* __restrict__ out, int Cin, int n, int log_n, int m, int relu, int TX, int TY, int ZC, int CK, int max_cols) {
+  constexpr int K = 3, ZR = 4;
+  constexpr int kUnrollB = COUT >= 8 ? 1 : K;
+  constexpr int kMaxPatch = 40;   // IX, IY <= 34 (host)
+  extern __shared__ float tile[];  // [CK][IX][IY][n] (+ 8), then the coarse columns
+  __shared__ int x_i0[kMaxPatch], x_i1[kMaxPatch], y_i0[kMaxPatch], y_i1[kMaxPatch];
+  __shared__ float x_l[kMaxPatch], y_l[kMaxPatch];
+  const int tid = threadIdx.x;
+  const int IX = TX + K - 1, IY = TY + K - 1;
+  const int tiles_y = (m + TY - 1) / TY;
+  const int tx0 = (blockIdx.x / tiles_y) * TX, ty0 = (blockIdx.x % tiles_y) * TY;
+  const int nb = blockIdx.z;
+  const size_t vi = (size_t)ni * ni * ni, mv = (size_t)m * m * m;
+  const float* src = in + (size_t)nb * Cin * vi;
+  const int col = tid / ZC, zc = tid - col * ZC;
+  const int lx = col / TY, ly = col - lx * TY, z0 = col < TX * TY ? zc * ZR : m;
+  float acc[ZR][COUT];
+#pragma unroll
+  for (int z = 0; z < ZR; ++z)
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[z][co] = 0.0f;
+  const float ratio = (float)ni / (float)n;
+  // coarse columns under the patch: x in [a0, a1], y in [b0, b1] (patch pixels beyond the tensor are zeros)
+  int a0, a1, b0, b1, t0, t1;
+  float fl;
+  resize_axis(tx0, ratio, ni, a0, t1, fl);
+  resize_axis(min(tx0 + IX, n) - 1, ratio, ni, t0, a1, fl);
+  resize_axis(ty0, ratio, ni, b0, t1, fl);
+  resize_axis(min(ty0 + IY, n) - 1, ratio, ni, t0, b1, fl);
+  const int rx = a1 - a0 + 1, ry = b1 - b0 + 1, cols = rx * ry;
+  if (tid < IX) {
+    resize_axis(min(tx0 + tid, n - 1), ratio, ni, t0, t1, fl);
+    x_i0[tid] = tx0 + tid < n ? t0 - a0 : -1;   // -1: outside the tensor
+    x_i1[tid] = t1 - a0;
+    x_l[tid] = fl;
+  } else if (tid >= 64 && tid < 64 + IY) {
+    const int j = tid - 64;
+    resize_axis(min(ty0 + j, n - 1), ratio, ni, t0, t1, fl);
+    y_i0[j] = ty0 + j < n ? t0 - b0 : -1;
+    y_i1[j] = t1 - b0;
+    y_l[j] = fl;
+  }
+  float* coarse = tile + (size_t)CK * IX * IY * n + 8;   // [CK][max_cols][ni]
+  // this thread's fine z and its terms
+  const int fz = tid & (n - 1), slot = tid >> log_n, slots = 256 >> log_n;
+  int cz0, cz1;
+  float lz;
+  resize_axis(fz, ratio, ni, cz0, cz1, lz);
+  const float wz0 = 1.0f - lz;
+  // the coarse values of a chunk: <= kPre per thread, where from does not depend on the chunk
+  constexpr int kPre = 8;
+  float pre[kPre];
+  int pf[kPre];   // (channel within the chunk << 24) | float offset within the channel; channel 127: none
+  {
+    const unsigned m_cn = magic_of(cols * ni), m_ni = magic_of(ni), m_ry = magic_of(ry);
+    const int e_full = CK * cols * ni;
+#pragma unroll
+    for (int j = 0; j < kPre; ++j) {
+      const int e = tid + 256 * j;
+      const int ch = div_by(min(e, e_full - 1), m_cn), r = min(e, e_full - 1) - ch * cols * ni;
+      const int cc = div_by(r, m_ni), z = r - cc * ni;
+      const int cx = div_by(cc, m_ry), cy = cc - cx * ry;
+      pf[j] = ((e < e_full ? ch : 127) << 24) | (((a0 + cx) * ni + (b0 + cy)) * ni + z);
+    }
+  }
+  auto prefetch = [&](int c0) {
+    const int ck = min(CK, Cin - c0);
+    const float* base = src + (size_t)c0 * vi;
+#pragma unroll
+    for (int j = 0; j < kPre; ++j) {
+      const int ch = pf[j] >> 24;
+      pre[j] = ch < ck ? base[(size_t)ch * vi + (pf[j] & 0xffffff)] : 0.0f;
+    }
+  };
+  prefetch(0);
+  for (int c0 = 0; c0 < Cin; c0 += CK) {
+    const int ck = min(CK, Cin - c0);
+    __syncthreads();  // the previous chunk has been consumed (and, first time round, the tables are written)
+#pragma unroll
+    for (int j = 0; j < kPre; ++j)
+      if ((pf[j] >> 24) < ck) {
+        // [ch][cc][z] with max_cols columns per channel
+        const int e = tid + 256 * j, ch = pf[j] >> 24;
+        coarse[(ch * max_cols) * ni + (e - ch * cols * ni)] = pre[j];
+      }
+    __syncthreads();
+    if (c0 + CK < Cin) prefetch(c0 + CK);
+    // the fine patch of the chunk
+    for (int py = slot; py < IY; py += slots) {
+      const int yi0 = y_i0[py], yi1 = y_i1[py];
+      const float lyv = y_l[py], wy0 = 1.0f - lyv;
+      const bool y_in = yi0 >= 0;
+      // the four corner offsets of this thread within a coarse x-column (clamped for rows outside the tensor)
+      const int o00 = max(yi0, 0) * ni + cz0, o01 = max(yi0, 0) * ni + cz1, o10 = yi1 * ni + cz0, o11 = yi1 * ni + cz1;
+      const int xstride = ry * ni;
+      for (int ch = 0; ch < ck; ++ch) {
+        const float* cc = coarse + ch * max_cols * ni;
+        float* row = tile + (ch * IX * IY + py) * n + fz;
+        // value of the coarse x-column cx at (this y, this z): z innermost, then y (resize3_kernel's tree)
+        auto column = [&](int cx) {
+          const float* p = cc + cx * xstride;   // (cx: scalar)
+          return blend(wy0, blend(wz0, p[o00], lz, p[o01]), lyv, blend(wz0, p[o10], lz, p[o11]));
+        };
+        int cur = -2;   // scalar: the x tables are the same for every thread
+        float ya = 0.0f, yb = 0.0f;
+        for (int px = 0; px < IX; ++px) {
+          const int xi0 = __builtin_amdgcn_readfirstlane(x_i0[px]), xi1 = __builtin_amdgcn_readfirstlane(x_i1[px]);
+          float v = 0.0f;
+          if (xi0 >= 0) {
+            if (xi0 != cur) {
+              ya = (xi0 == cur + 1) ? yb : column(xi0);
+              cur = xi0;
+              yb = column(min(xi0 + 1, rx - 1));
+            }
+            const float lxv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x_l[px])));
+            v = blend(1.0f - lxv, ya, lxv, xi1 == xi0 ? ya : yb);
+          }
+          row[px * IY * n] = y_in ? v : 0.0f;
+        }
+      }
+    }
+    __syncthreads();
+    if (z0 < m) {
+      for (int ci = 0; ci < ck; ++ci) {
+#pragma unroll 1
+        for (int a = 0; a < K; ++a)
+#pragma unroll kUnrollB
+          for (int b = 0; b < K; ++b) {
+            const float* p = tile + ((ci * IX + lx + a) * IY + ly + b) * n + z0;
+            float v[ZR + K - 1];
+            {
+              const f32x4 q = *reinterpret_cast<const f32x4*>(p);
+              const float2 r = *reinterpret_cast<const float2*>(p + 4);
+              v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3]; v[4] = r.x; v[5] = r.y;
+            }
+            const float* w = wd + ((((size_t)(c0 + ci) * K + a) * K + b) * K) * COUT;  // wave-uniform
+#pragma unroll
+            for (int c = 0; c < K; ++c)
+#pragma unroll
+              for (int z = 0; z < ZR; ++z)
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[z][co] = fmaf(v[z + c], w[c * COUT + co], acc[z][co]);
+          }
+      }
+    }
+  }
+  const int x = tx0 + lx, y = ty0 + ly;
+  if (x < m && y < m && z0 < m) {
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+      float* dst = out + ((size_t)nb * COUT + co) * mv + ((size_t)x * m + y) * m + z0;
+      const float bv = bias[co];
+#pragma unroll
+      for (int z = 0; z < ZR; ++z)
+        if (z0 + z < m) {
+          float r = acc[z][co] + bv;
+          if (relu) r = fmaxf(r, 0.0f);
+          dst[z] = r;
+        }
+    }
+  }
+}
+
 // ---- backward (VJP to the latent; weights are constants) -------------------------------------
 
 // out[N][C][np][np][pz] = zero-padded (by `pad` on every side) copy of g[N][C][m^3], multiplied by the
@@ -1421,7 +1599,67 @@ bool launch_direct(const sdfr_decoder* d, size_t w_off, const float* src, const 
 #undef SDFR_DIRECT
   return true;
 }
+std::atomic<int> g_fused_resize{1};   // tests switch the resize-in-the-patch-load form off: sdfr_debug_set_decoder_fused_resize
+
+// resize ni -> n (up-sampling) folded into the direct convolution that follows it (conv3d_direct_up_kernel): true if
+// launched.  Same tiling as launch_direct; the chunk is also bounded by the coarse columns a thread prefetches.
+bool launch_direct_up(const sdfr_decoder* d, size_t w_off, const float* src, int ni, const float* bias, float* dst,
+                      int cin, int cout, int n, int m, int relu, int N, hipStream_t st) {
+  const int mode = g_fused_resize.load(std::memory_order_relaxed);
+  if (!mode) return false;
+  if (n < 16 || n > 64 || (n & (n - 1)) != 0 || ni > n || ni < 2) return false;
+  // Measured on 256 mug latents (profiles/r04_decoder_fused_resize.txt): 6 -> 16 in front of the 16 -> 8 layer,
+  // 112 us folded against 96 + 26 as two launches; 14 -> 32 in front of the 8 -> 4 layer, 268 us folded against
+  // 170 + 77 -- there the patch's 1.87x overlap makes every workgroup interpolate what its neighbours interpolate
+  // too, in a kernel that is VALU-bound already.  So: folded up to a fine size of 16 (mode 2, the tests': always).
+  if (mode == 1 && n > 16) return false;
+  int TX, TY, ZC;
+  if (!direct_ok(w_off, n, m, N, &TX, &TY, &ZC)) return false;
+  const int IX = TX + 2, IY = TY + 2;
+  if (IX > 34 || IY > 34) return false;
+  // coarse columns under a patch, worst tile (the kernel's float arithmetic)
+  const float ratio = (float)ni / (float)n;
+  auto first_last = [&](int dd, int& i0, int& i1) {
+    float sp = fmaf(ratio, (float)dd + 0.5f, -0.5f);
+    sp = sp < 0.0f ? 0.0f : sp;
+    i0 = std::min((int)sp, ni - 1);
+    i1 = i0 + (i0 < ni - 1 ? 1 : 0);
+  };
+  auto span = [&](int T, int I) {
+    int worst = 0;
+    for (int t0 = 0; t0 < m; t0 += T) {
+      int lo, hi, tmp;
+      first_last(t0, lo, tmp);
+      first_last(std::min(t0 + I, n) - 1, tmp, hi);
+      worst = std::max(worst, hi - lo + 1);
+    }
+    return worst;
+  };
+  const int max_cols = span(TX, IX) * span(TY, IY);
+  const int per_ch = IX * IY * n;
+  int CK = std::max(1, std::min(cin, (24 * 1024 / 4) / per_ch));
+  CK = std::min(CK, 2048 / (max_cols * ni));      // <= 8 prefetched values per thread
+  if (CK < 1 || CK >= 127 || (size_t)CK * ni * ni * ni >= 0xffffff) return false;
+  const size_t lds = ((size_t)CK * per_ch + 8 + (size_t)CK * max_cols * ni) * sizeof(float);
+  if (lds > 60 * 1024) return false;
+  int log_n = 0;
+  while ((1 << log_n) < n) ++log_n;
+  const int tiles = ((m + TX - 1) / TX) * ((m + TY - 1) / TY);
+  const dim3 grid(tiles, 1, N);
+  const float* w = d->d_params + w_off;
+#define SDFR_DIRECT_UP(CO)                                                                                           \
+  hipLaunchKernelGGL((conv3d_direct_up_kernel<CO>), grid, dim3(256), lds, st, src, ni, w, bias, dst, cin, n, log_n, \
+                     m, relu, TX, TY, ZC, CK, max_cols)
+  if (cout == 4) { SDFR_DIRECT_UP(4); } else if (cout == 8) { SDFR_DIRECT_UP(8); } else if (cout == 16) { SDFR_DIRECT_UP(16); }
+  else return false;
+#undef SDFR_DIRECT_UP
+  return true;
+}
 }  // namespace
+
+extern "C" int sdfr_debug_set_decoder_fused_resize(int on) {
+  return g_fused_resize.exchange(on < 0 ? 0 : (on > 2 ? 2 : on), std::memory_order_relaxed);
+}
 
 extern "C" int sdfr_decoder_create(const float* h_params, size_t n_params, int latent, int n_fc,
                                    const int* fc_out, int n_conv, const int* conv_in_size,
@@ -1789,6 +2027,18 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
   for (int l = 0; l < d->n_conv; ++l) {
     const bool swap = d->conv_swap[l] != 0, is_last = (l == d->n_conv - 1);
     const int k = d->conv_k[l], co_n = d->conv_cout[l], kpad = d->conv_kpad[l];
+    // (batches: an up-sampling resize in front of a 3x3x3 layer is folded into that layer's patch load --
+    // conv3d_direct_up_kernel -- and the up-sampled tensor is never written)
+    bool fused_up = false;
+    if (!swap && n != d->conv_in_size[l] && k == 3 && d->fwd_direct_off[l] != 0) {
+      const int nf = d->conv_in_size[l], mf = nf - k + 1;
+      const bool to_out_f = is_last && mf == d->volume && clampv == 0.0f;
+      float* ldst = to_out_f ? out : (tape ? tape + (size_t)N * d->tape_conv_off[l] : nullptr);
+      float* cdst = ldst ? ldst : buf[cur ^ 1];
+      fused_up = launch_direct_up(d, d->fwd_direct_off[l], act_in, n, d->d_params + d->conv_b_off[l], cdst, c, co_n,
+                                  nf, mf, d->conv_relu[l], N, st);
+      if (fused_up) n = nf;   // (act_in stays the coarse tensor: the launch has consumed it)
+    }
     if (!swap && n != d->conv_in_size[l]) {
       resize(act_in, c, n, d->conv_in_size[l], 0, 0.0f, buf[cur ^ 1]);
       cur ^= 1;
@@ -1830,7 +2080,9 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
       }
       continue;
     }
-    if (k == 1 && co_n <= 4) {
+    if (fused_up) {
+      // (launched above)
+    } else if (k == 1 && co_n <= 4) {
       const int voxn = n * n * n;
       const dim3 g1((voxn + 255) / 256, N);
       const bool v4 = N >= 32 && (voxn & 3) == 0 && (((uintptr_t)act_in | (uintptr_t)conv_dst) & 15) == 0;

@@ -340,3 +340,56 @@ def test_tiled_transposed_resize_is_bitwise_the_three_launches(mug):
                 L.sdfr_debug_set_decoder_tiled_vjp(old)
         assert torch.isfinite(grads[0]).all() and grads[0].abs().max() > 0, name
         assert torch.equal(grads[0], grads[1]), (name, N, (grads[0] - grads[1]).abs().max().item())
+
+
+def test_resize_folded_into_the_patch_load_is_bitwise_the_two_launches(mug):
+    """Batched forward: an up-sampling trilinear resize in front of a 3x3x3 layer runs inside that layer's patch load
+    (conv3d_direct_up_kernel: coarse columns staged in LDS, the fine patch formed with resize3_kernel's expression
+    tree) against the resize launch + the direct convolution it replaces: outputs bit for bit, and the VJP through the
+    taped forward as well.  Shapes: the mug decoder (6 -> 16 and 14 -> 32), a fine size of 64 (fewer patch-row slots
+    than patch rows), 5 -> 16 and 7 -> 16, 16 output channels, channel counts that leave a short last chunk."""
+    from sdfest_amd import SDFDecoder
+    from sdfest_amd._lib import lib
+    L = lib()
+    d, wts = mug
+    rng = np.random.default_rng(11)
+    cases = [("mug", mug_config(d), wts, 64, 8, 140), ("mug", mug_config(d), wts, 64, 8, 20)]
+    extra = [
+        # (the first layer takes the Linear stack's output as it is, sdf_vae.py:207-215: resizes come after it)
+        dict(volume=32, latent=4, batch=130, fc=[{"out": 5 * 5 ** 3}],
+             conv=[dict(in_size=5, in_channels=5, out_channels=6, kernel_size=1, relu=True),      # 5^3
+                   dict(in_size=16, in_channels=6, out_channels=16, kernel_size=3, relu=True),    # 5 -> 16 -> 14
+                   dict(in_size=32, in_channels=16, out_channels=4, kernel_size=3, relu=True),    # 14 -> 32 -> 30
+                   dict(in_size=30, in_channels=4, out_channels=1, kernel_size=1, relu=False)]),  # 1x1 (swapped) -> 32
+        dict(volume=64, latent=3, batch=6, fc=[{"out": 2 * 11 ** 3}],
+             conv=[dict(in_size=11, in_channels=2, out_channels=3, kernel_size=3, relu=True),     # 11 -> 9
+                   dict(in_size=64, in_channels=3, out_channels=4, kernel_size=3, relu=False),    # 9 -> 64 -> 62
+                   dict(in_size=62, in_channels=4, out_channels=1, kernel_size=1, relu=False)]),
+        dict(volume=16, latent=5, batch=140, fc=[{"out": 3 * 7 ** 3}],
+             conv=[dict(in_size=7, in_channels=3, out_channels=7, kernel_size=1, relu=False),     # 7^3
+                   dict(in_size=16, in_channels=7, out_channels=8, kernel_size=3, relu=True),     # 7 -> 16 -> 14
+                   dict(in_size=14, in_channels=8, out_channels=1, kernel_size=1, relu=False)]),
+    ]
+    for case in extra:
+        cfg = {"latent_size": case["latent"], "tsdf": False, "sdf_size": case["volume"],
+               "decoder": {"fc_layers": case["fc"], "conv_layers": case["conv"]}}
+        cases.append((f"volume {case['volume']}", cfg, _random_state(rng, case), case["volume"], case["latent"], case["batch"]))
+    for name, cfg, state, volume, latent, N in cases:
+        dec = SDFDecoder.from_config(cfg, state, sdf_size=volume) if name != "mug" else SDFDecoder.from_config(cfg, state)
+        z_np = rng.normal(size=(N, latent)).astype(np.float32)
+        G = torch.tensor(rng.normal(size=(N, 1, volume, volume, volume)).astype(np.float32), device="cuda")
+        outs, grads = [], []
+        for on in (2, 0):      # folded wherever the form exists / never (the default folds fine sizes up to 16)
+            old = L.sdfr_debug_set_decoder_fused_resize(on)
+            try:
+                z = torch.tensor(z_np, device="cuda", requires_grad=True)
+                o = dec.decode(z)
+                o.backward(G)
+                torch.cuda.synchronize()
+                outs.append(o.detach().clone())
+                grads.append(z.grad.clone())
+            finally:
+                L.sdfr_debug_set_decoder_fused_resize(old)
+        assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0, name
+        assert torch.equal(outs[0], outs[1]), (name, N, (outs[0] - outs[1]).abs().max().item())
+        assert torch.equal(grads[0], grads[1]), (name, N)
