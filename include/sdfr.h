@@ -180,15 +180,16 @@ SDFR_API int sdfr_render_step_forward(const float* sdf, int R, long long sdf_vie
                              long long g_sdf_view_stride, void* workspace, size_t workspace_bytes,
                              int device, void* stream);
 /* sdfr_render_step_forward that also REPORTS how many of its views are close -- the fact behind the
- * SDFR_BWD_HALF_GRID hint -- without anybody looking at the poses on the host: the set-up that walks every view on
- * the device counts the views it gives 32 x 32 backward tiles and, when the last view has been counted, stores
+ * SDFR_BWD_HALF_GRID hint -- without anybody looking at the poses on the host: the forward counts, on the device,
+ * the views whose set-up gave them 32 x 32 backward tiles and, when the last view has been counted, stores
  *     (forwards counted on this workspace << 32) | close views of this forward
  * into *close_views_word with one 64-bit store.  The word must be visible to the device AND readable by the host
  * without a synchronisation (pinned host memory: hipHostMalloc / a pinned torch tensor; 8-byte aligned; NULL: no
  * report).  The caller reads it whenever it likes -- it then holds the count of some earlier, complete forward --
  * and sets the hint of its next backward from it: stale by a step or more is fine for a hint that cannot change
- * results.  Counted by the batch forms of the set-up (B >= 4 views of one shared grid; smaller calls have no batch
- * backward to hint); the workspace's sync region must have been zero-filled once before its first use.
+ * results.  Counted by batch launches (the forward's macro-tile form: smaller calls have no batch backward to
+ * hint) -- by the image kernel, one atomic per view, off the critical path; the workspace's sync region must have
+ * been zero-filled once before its first use.
  * Sync header words 4 / 5 hold the same two numbers on the device. */
 SDFR_API int sdfr_render_step_forward_counted(const float* sdf, int R, long long sdf_view_stride, const float* pos,
                                      const float* quat, const float* inv_scale, int B, int W, int H, float cx,

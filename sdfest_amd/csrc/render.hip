@@ -275,20 +275,22 @@ __device__ __forceinline__ void compute_view_setup(int b, const float* __restric
 }
 
 // How many of a forward's views are CLOSE (ViewSetup::bwd_big: the views the batch backward gives 32 x 32 tiles) --
-// the fact behind the SDFR_BWD_HALF_GRID hint, counted where the views are set up so that no caller has to look at
-// poses that live in device memory.  Called by one lane per view; sync header words 2 / 3: close views / views of
-// the running launch (the launch's last view resets them), word 4: launches counted, word 5: close views of the
-// last complete launch.  `word` (nullable, a kernel ARGUMENT, never an address kept in memory): the caller's
-// host-visible 64-bit word, which receives (launches counted << 32 | close views) in ONE store when the last view
-// has been counted; a host that reads it any time later gets some complete launch's count, never a torn one.
+// the fact behind the SDFR_BWD_HALF_GRID hint, counted on the device so that no caller has to look at poses that
+// live in device memory.  Called by one lane per view -- of the view's first workgroup in the forward kernel, after
+// its tile: the prologue launch is a few us long and a returning atomic per view at its end showed (9.9 -> 13.4 us);
+// in the 150 us image kernel it is free.  Sync header word 2: (views counted << 16 | close
+// views) of the running launch, ONE atomic per view -- the view that finds B - 1 before it is the last, knows the
+// total from the value the atomic returned, and resets the word: no fence anywhere (a __threadfence() is an L2
+// write-back on this part: two per view made the prologue 16 instead of 10 us) -- word 4: launches counted, word 5:
+// close views of the last complete launch.  `word` (nullable, a kernel ARGUMENT, never an address kept in memory):
+// the caller's host-visible 64-bit word, which receives (launches counted << 32 | close views) in ONE store when the
+// last view has been counted; a host that reads it any time later gets some complete launch's count, never a torn one.
 __device__ __forceinline__ void count_close_view(unsigned* __restrict__ sync, int B, bool close,
                                                  unsigned long long* __restrict__ word) {
-  if (close) atomicAdd(&sync[2], 1u);
-  __threadfence();
-  if (atomicAdd(&sync[3], 1u) + 1u != (unsigned)B) return;
-  __threadfence();
-  const unsigned c = atomicExch(&sync[2], 0u);
-  atomicExch(&sync[3], 0u);
+  const unsigned old = atomicAdd(&sync[2], 0x10000u | (close ? 1u : 0u));   // B <= 65535 (check_common)
+  if ((old >> 16) + 1u != (unsigned)B) return;
+  const unsigned c = (old & 0xffffu) + (close ? 1u : 0u);
+  atomicExch(&sync[2], 0u);
   const unsigned seq = sync[4] + 1u;
   sync[4] = seq;
   sync[5] = c;
@@ -299,20 +301,11 @@ __global__ void view_setup_kernel(const float* __restrict__ pos, const float* __
                                   const float* __restrict__ inv_scale, int B, int R, int W, int H,
                                   float cx, float cy, float fx, float fy,
                                   ViewSetup* __restrict__ out, const float* __restrict__ plane_min,
-                                  float threshold, unsigned* __restrict__ spans, unsigned* __restrict__ sync,
-                                  unsigned long long* __restrict__ close_word) {
+                                  float threshold, unsigned* __restrict__ spans) {
   // one wave per view (the wave shares the scan of the plane minima, lane 0 writes the record)
   const int b = blockIdx.x;
-  if (b < B) {
+  if (b < B)
     compute_view_setup<true>(b, pos, quat, inv_scale, R, W, H, cx, cy, fx, fy, out, plane_min, threshold, spans);
-    if (sync && (threadIdx.x & 63) == 0) {
-      // (the same expression as setup_pose's: this lane wrote the record and holds nothing of it any more)
-      const float px = pos[3 * b], py = pos[3 * b + 1], pz = pos[3 * b + 2];
-      const float dist = sqrtf(px * px + py * py + pz * pz);
-      const float r = sqrtf(fabsf(fx * fy)) * ((1.0f / inv_scale[b]) / (0.5f * (float)(R - 1))) / fmaxf(dist, 1e-20f);
-      count_close_view(sync, B, r >= SDFR_BWD_BIG_MIN_RATIO, close_word);
-    }
-  }
 }
 
 // The plane minima reach the set-up waves of the SAME launch (forward_prologue_kernel) as tagged entries: 16 bytes
@@ -492,7 +485,7 @@ __global__ __launch_bounds__(256) void forward_prologue_kernel(
     unsigned* __restrict__ sync, const float* __restrict__ pos, const float* __restrict__ quat,
     const float* __restrict__ inv_scale, int B, int W, int H, float cx, float cy, float fx, float fy,
     ViewSetup* __restrict__ out, float threshold, float* __restrict__ g_zero, size_t n_zero, int max_polls,
-    unsigned* __restrict__ spans, unsigned long long* __restrict__ close_word) {
+    unsigned* __restrict__ spans) {
   const unsigned tag = sync[0] + 1u;  // the epoch the last forward on this workspace left, + 1
   PlaneEntry* ent = reinterpret_cast<PlaneEntry*>(sync + kSyncHeaderWords);
   int blk = (int)blockIdx.x;
@@ -532,7 +525,6 @@ __global__ __launch_bounds__(256) void forward_prologue_kernel(
       if ((tid & 63) == 0) {
         out[b] = s;
         if (!ready) atomicAdd(&sync[1], 1u);
-        count_close_view(sync, B, s.bwd_big != 0, close_word);
       }
     }
     return;
@@ -761,7 +753,8 @@ __global__ __launch_bounds__(NW * 64) void render_forward_kernel(
     const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, float cx, float cy,
     float rfx, float rfy, float threshold, int vec_ok, float* __restrict__ depth,
     const float* __restrict__ target, float* __restrict__ loss_part, unsigned* __restrict__ epoch,
-    const unsigned* __restrict__ spans, InlineSetup in) {
+    const unsigned* __restrict__ spans, InlineSetup in, unsigned* __restrict__ count_sync,
+    unsigned long long* __restrict__ close_word) {
   if (INLINE) {
     const int b = blockIdx.z;
     ViewSetup s;
@@ -779,6 +772,8 @@ __global__ __launch_bounds__(NW * 64) void render_forward_kernel(
   forward_tile<RT, PACKED, SX, SY, LOSS, PACKED, NW>(blockIdx.x, blockIdx.y, ntx, nty, blockIdx.z, src, R,
                                          src_view_stride, setup[blockIdx.z], W, H, cx, cy, rfx, rfy, threshold,
                                          vec_ok, depth, target, loss_part, spans);
+  if (count_sync && (blockIdx.x | blockIdx.y) == 0 && threadIdx.x == 0)
+    count_close_view(count_sync, (int)gridDim.z, setup[blockIdx.z].bwd_big != 0, close_word);
   // The workspace's epoch advances once per forward call, after its prologue launch (forward_prologue_kernel), and
   // the entries that launch published are wiped (equal words never read as an entry: the payloads of a valid one
   // are complementary).  Either alone keeps an entry of this call from reading as ready in a later one; the wipe
@@ -1470,7 +1465,7 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
     hipLaunchKernelGGL(forward_prologue_kernel, dim3(3 * R + n_setup + n_pack), dim3(256), 0, st, sdf, R,
                        (float4*)cells, 3 * R, n_setup, lay.sync, pos, quat, inv_scale, B, W, H, cx, cy, fx, fy,
                        setup, threshold, g_zero, n_zero, g_prologue_max_polls.load(std::memory_order_relaxed),
-                       lay.spans, close_word);
+                       lay.spans);
     epoch = lay.sync;
   } else if (g_zero && !packed && inline_setup) {
     // a step over a few views of the plain grid: no prologue launch at all (render_forward_kernel, INLINE)
@@ -1490,18 +1485,20 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
                          (float4*)cells, n_pack, plane_min);
     }
     hipLaunchKernelGGL(view_setup_kernel, dim3(B), dim3(64), 0, st, pos, quat, inv_scale, B, R,
-                       W, H, cx, cy, fx, fy, setup, plane_min, threshold, lay.spans, lay.sync, close_word);
+                       W, H, cx, cy, fx, fy, setup, plane_min, threshold, lay.spans);
   }
   const bool macro = geom.sx * geom.sy > 1;
   const int ntx = geom.nx(W), nty = geom.ny(H);
   const dim3 grid_tile((unsigned)ntx, (unsigned)nty, (unsigned)B);
   const float rfx = (float)(1.0 / (double)fx), rfy = (float)(1.0 / (double)fy);
+  // a step's forward over a batch counts its close views (count_close_view): what the backward's half-grid hint needs
+  unsigned* count_sync = (g_zero && !inline_setup && macro) ? lay.sync : nullptr;
   const int vec_ok = (W % 4 == 0) && ((uintptr_t)depth % 16 == 0);
 #define SDFR_LAUNCH_FWD_L(RT, PK, SRC, STRIDE, SX, SY, LOSS)                                          \
   hipLaunchKernelGGL((render_forward_kernel<RT, PK, SX, SY, LOSS, (SX * SY > 1 && SX < 4 ? kFwdWaves : 4)>), grid_tile, \
                      dim3((SX * SY > 1 && SX < 4 ? kFwdWaves : 4) * 64), 0, st, \
                      SRC, R, STRIDE, setup, W, H, ntx, nty, cx, cy, rfx, rfy, threshold, vec_ok,      \
-                     depth, target, loss_part, epoch, lay.spans, InlineSetup{})
+                     depth, target, loss_part, epoch, lay.spans, InlineSetup{}, count_sync, close_word)
 #define SDFR_LAUNCH_FWD_G(RT, PK, SRC, STRIDE, SX, SY)                                               \
   do {                                                                                               \
     if (with_loss) SDFR_LAUNCH_FWD_L(RT, PK, SRC, STRIDE, SX, SY, true);                             \
@@ -1518,7 +1515,7 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
 #define SDFR_LAUNCH_INLINE(RT, LOSS)                                                                              \
   hipLaunchKernelGGL((render_forward_kernel<RT, false, 1, 1, LOSS, 4, true>), grid_tile, dim3(256), 0, st, sdf, R, \
                      sdf_view_stride, setup, W, H, ntx, nty, cx, cy, rfx, rfy, threshold, vec_ok, depth, target,  \
-                     loss_part, epoch, lay.spans, in)
+                     loss_part, epoch, lay.spans, in, (unsigned*)nullptr, (unsigned long long*)nullptr)
     if (R == 64) { if (with_loss) SDFR_LAUNCH_INLINE(64, true); else SDFR_LAUNCH_INLINE(64, false); }
     else { if (with_loss) SDFR_LAUNCH_INLINE(0, true); else SDFR_LAUNCH_INLINE(0, false); }
 #undef SDFR_LAUNCH_INLINE
