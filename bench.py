@@ -287,8 +287,10 @@ def main():
     # whatever count has arrived -- this file never looks at the poses.
     plan = BatchRenderPlan(64, B, cam, device=device, grad_volumes=M)
     state = {"k": 0, "pending": [None, None], "mode": args.exchange if use_dist else "none"}
-    coll_stream = torch.cuda.Stream(device) if use_dist else None
-    coll_events = []      # (begin, end) on the collective's stream, sync mode, timed region only
+    # (begin, end) around every synchronous exchange of one timed region, made before it (no allocation inside)
+    coll_pool = ([(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                  for _ in range(args.steps)] if use_dist else [])
+    state["n_coll_events"] = 0
 
     def finish_exchanges():
         for i, w in enumerate(state["pending"]):
@@ -298,8 +300,7 @@ def main():
 
     def step_sync(ev=None, time_collective=False):
         """forward, backward, and the all-reduce of THIS step's volume finished before the next forward may start:
-        the dependency structure of render-and-compare (the next SDF needs this gradient).  The collective runs on a
-        stream of its own so that its span can be read off events on that stream."""
+        the dependency structure of render-and-compare (the next SDF needs this gradient)."""
         if ev:
             ev[0].record()
         plan.forward(sdf, pos, quat, isc, thr, prepare_backward=True)
@@ -308,17 +309,19 @@ def main():
         g_sdf = plan.backward(g, sdf, pos, quat, isc)[0]
         if ev:
             ev[2].record()
-        cur = torch.cuda.current_stream(device)
-        coll_stream.wait_stream(cur)
-        with torch.cuda.stream(coll_stream):
-            if time_collective:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            dist.all_reduce(g_sdf, op=dist.ReduceOp.SUM)
-            if time_collective:
-                e1.record()
-                coll_events.append((e0, e1))
-        cur.wait_stream(coll_stream)
+        # Issued on the compute stream: c10d makes its own collective stream wait for the backward and the compute
+        # stream wait for the sum.  (A side stream of this file's own around the call was measured first: two more
+        # stream crossings per step, and stalls of up to 19 ms in single steps -- 0.30 ... 0.44 ms per step against
+        # 0.267 this way, one rank under torch.distributed.run.)  The two events bracket the collective on the compute
+        # stream: the time from the end of the backward until the next forward may start.
+        ev_pair = None
+        if time_collective and state["n_coll_events"] < len(coll_pool):
+            ev_pair = coll_pool[state["n_coll_events"]]
+            state["n_coll_events"] += 1
+            ev_pair[0].record()
+        dist.all_reduce(g_sdf, op=dist.ReduceOp.SUM)
+        if ev_pair:
+            ev_pair[1].record()
         state["k"] += 1
 
     def step(ev=None, time_collective=False):
@@ -394,8 +397,14 @@ def main():
     def timed(mode, evs, time_collective=False, mark=False):
         """EXACTLY args.steps steps between two barrier + synchronize pairs; the max over ranks"""
         state["mode"] = mode
-        for _ in range(min(args.warmup, 2) if mode != state.get("warmed") else 0):
-            step()
+        if mode != state.get("warmed"):
+            # the other exchange gets its own untimed run-in (its first collectives on a fresh stream grow c10d's and
+            # HIP's event pools: measured cold, 200 sync steps took twice the time they take after 100 ms of the same)
+            t_w = time.perf_counter()
+            while (time.perf_counter() - t_w) * 1e3 < min(100.0, max(args.prewarm_ms, 1.0)):
+                for _ in range(8):
+                    step()
+                torch.cuda.synchronize()
         barrier()
         if mark:
             tele.mark("t0")
@@ -438,15 +447,15 @@ def main():
         per_rank = [None] * N
         dist.all_gather_object(per_rank, {"rank": rank, "hit_pixels": hits, "device": torch.cuda.get_device_name(device),
                                           "local_device_index": local_rank, "prologue_fallbacks": fallbacks})
-        ar_us = [e0.elapsed_time(e1) * 1e3 for e0, e1 in coll_events]
+        ar_us = [e0.elapsed_time(e1) * 1e3 for e0, e1 in coll_pool[:state["n_coll_events"]]]
         collective = {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(),
                       "exchange_of_value": main_mode,
                       "exchange_ring": f"one all-reduce (sum, fp32) of {half} x 1 MiB d/dSDF volumes per {half} steps, "
                                        f"waited for {half} steps later (ring of {M} volumes): steps are independent",
                       "exchange_sync": "one all-reduce (sum, fp32) of the step's 1 MiB d/dSDF volume, finished before "
                                        "the next step's forward starts (the dependency of render-and-compare)",
-                      # span of the per-step all-reduce on its own stream, from the backward's end (events on that
-                      # stream; the sync-exchange region)
+                      # span of the per-step all-reduce as the compute stream sees it: from the end of the backward
+                      # until the next forward may start (events on that stream; the sync-exchange region)
                       "allreduce_us": ({"median": round(float(np.median(ar_us)), 1), "min": round(min(ar_us), 1),
                                         "max": round(max(ar_us), 1), "n": len(ar_us)} if ar_us else None),
                       "per_rank": per_rank}
