@@ -29,10 +29,13 @@ def main():
     sc = _loop_scenes.build(scene)
     mode = (SDF_GRAD_DETERMINISTIC | BWD_SMALL_TILES) if flavour == "det" else 0
     hist = []
-    if form == "fused":
+    if form in ("fused", "fused_pose_only"):
+        # "fused_pose_only": shape optimisation off (the exchange is the view records alone) and a point constraint
+        con = (torch.tensor([0.0, 1.0, 0.0]), torch.tensor([0.1, 0.9, -0.2]), 0.05) if form == "fused_pose_only" else None
         loop = FusedRenderAndCompare(sc["decoder"], sc["camera"], sc["config"], sc["depth"], camera_positions=sc["cam_pos"],
-                                     camera_orientations=sc["cam_quat"], shape_optimization=True, process_group="world",
-                                     exchange=exchange, sdf_grad_mode=mode, track_inliers=True)
+                                     camera_orientations=sc["cam_quat"], shape_optimization=(form == "fused"),
+                                     process_group="world", exchange=exchange, sdf_grad_mode=mode, track_inliers=True,
+                                     point_constraint=con)
         out = loop(*sc["init"], use_graph=(graph == "graph"), history=hist)
         inl = loop.inlier_history.cpu().numpy()
         shard = (loop.view_begin, loop.view_end)

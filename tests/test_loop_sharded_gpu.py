@@ -107,6 +107,31 @@ def test_sharded_autograd_loop_matches_the_single_process_one(tmp_path):
     assert np.allclose([float(h["loss"]) for h in hist], r["loss"], rtol=1e-4)
 
 
+def test_sharded_pose_only_loop_with_a_point_constraint(tmp_path):
+    """shape optimisation off (the SDF is decoded once, the exchange is the view records alone, d/dSDF is computed and
+    dropped as in simple_setup.py:413-414) with the point constraint of :164-175: bitwise in the deterministic mode"""
+    from sdfest_amd.differentiable_renderer import BWD_SMALL_TILES, SDF_GRAD_DETERMINISTIC
+    from sdfest_amd.pipeline import FusedRenderAndCompare
+    r = _spawn(tmp_path, "seven", "det", "sdf", "graph", form="fused_pose_only")
+    sc = _loop_scenes.build("seven")
+    con = (torch.tensor([0.0, 1.0, 0.0]), torch.tensor([0.1, 0.9, -0.2]), 0.05)
+    loop = FusedRenderAndCompare(sc["decoder"], sc["camera"], sc["config"], sc["depth"], camera_positions=sc["cam_pos"],
+                                 camera_orientations=sc["cam_quat"], shape_optimization=False,
+                                 sdf_grad_mode=SDF_GRAD_DETERMINISTIC | BWD_SMALL_TILES, track_inliers=True,
+                                 point_constraint=con)
+    hist = []
+    loop(*sc["init"], use_graph=True, history=hist)
+    torch.cuda.synchronize()
+    traj = _loop_scenes.history_array(hist)
+    assert np.array_equal(traj, r["traj"]) and np.array_equal(traj[:, 8:], np.zeros_like(traj[:, 8:]))   # the latent stays
+    # and the default single-process loop with the same constraint agrees to rounding
+    ref = FusedRenderAndCompare(sc["decoder"], sc["camera"], sc["config"], sc["depth"], camera_positions=sc["cam_pos"],
+                                camera_orientations=sc["cam_quat"], shape_optimization=False, point_constraint=con)
+    h2 = []
+    ref(*sc["init"], use_graph=True, history=h2)
+    assert _steps(_loop_scenes.history_array(h2), r["traj"]).max() < 2e-3
+
+
 def test_three_ranks_on_seven_views(tmp_path):
     """an uneven split (3 + 2 + 2 views) in the deterministic mode: still the single-process bits"""
     from sdfest_amd.differentiable_renderer import BWD_SMALL_TILES, SDF_GRAD_DETERMINISTIC
