@@ -407,7 +407,7 @@ def main():
                 torch.cuda.synchronize()
         barrier()
         if mark:
-            tele.mark("t0")
+            tele.mark("t0")      # (also reads the clocks here, just outside the timed region)
         t0 = time.perf_counter()
         for k in range(args.steps):
             step(evs[k] if evs else None, time_collective)

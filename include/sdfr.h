@@ -410,7 +410,8 @@ SDFR_API int sdfr_loop_tail(float* params, float* grads, float* exp_avg, float* 
  * A view's record: [0..7] the renderer's pose sums (g_pos 3, g_quat 4, g_inv_scale), [8..15] the sampler's (g_pos 3,
  * g_quat 4 through the normalisation's Jacobian, g_scale), [16] its depth loss, [17] its point-cloud loss, rest 0.
  * Records instead of the 8 summed pose gradients: each is non-zero on exactly one rank, so the sum over ranks
- * reproduces it exactly, and the chain adds the views in index order on every rank -- the pose gradient does not
+ * reproduces it exactly, and the chain adds the views in one fixed order on every rank (thread t of the tail's
+ * workgroup the views t, t + 256, ..., then a fixed tree: any number of views) -- the pose gradient does not
  * depend on how the views were spread (with SDFR_SDF_GRAD_DETERMINISTIC | SDFR_BWD_SMALL_TILES the whole iteration
  * is bitwise the single-process one; exchange the bucket as 64-bit integers then, the volume being the int64 one).
  *

@@ -231,6 +231,57 @@ __device__ __forceinline__ void pose_chain(const float* __restrict__ orientation
   g_scale[0] = gs;
 }
 
+// pose_chain by the whole workgroup, for view lists of any length (the sharded loop's tail: V is the number of views
+// of ALL ranks): thread t adds the views t, t + 256, ... in that order, the 256 partial sums meet in a fixed tree.  The
+// result depends on the records and on V alone -- not on which rank computed which record.  Every thread calls it.
+__device__ __forceinline__ void pose_chain_block(const float* __restrict__ orientation, const float* __restrict__ scale,
+                                                 const float* __restrict__ cam_quat, int V, const float* rec,
+                                                 int rec_stride, float* __restrict__ g_position,
+                                                 float* __restrict__ g_orientation, float* __restrict__ g_scale) {
+  __shared__ float part[8][256];
+  const int tid = threadIdx.x;
+  float gp[3] = {0, 0, 0}, gn[4] = {0, 0, 0, 0}, gs = 0.0f;
+  const float s = scale[0];
+  for (int v = tid; v < V; v += 256) {
+    const float a[4] = {-cam_quat[4 * v], -cam_quat[4 * v + 1], -cam_quat[4 * v + 2], cam_quat[4 * v + 3]};
+    float m[9];
+    quat_matrix(a, m);
+    const float* ga = rec + (size_t)v * rec_stride;
+    const float* gb = ga + 8;
+    float gpc[3], gqc[4];
+    for (int k = 0; k < 3; ++k) gpc[k] = ga[k] + gb[k];
+    for (int k = 0; k < 4; ++k) gqc[k] = ga[3 + k] + gb[3 + k];
+    gp[0] += m[0] * gpc[0] + m[3] * gpc[1] + m[6] * gpc[2];
+    gp[1] += m[1] * gpc[0] + m[4] * gpc[1] + m[7] * gpc[2];
+    gp[2] += m[2] * gpc[0] + m[5] * gpc[1] + m[8] * gpc[2];
+    const float ax = a[0], ay = a[1], az = a[2], aw = a[3];
+    gn[0] += aw * gqc[0] + az * gqc[1] - ay * gqc[2] - ax * gqc[3];
+    gn[1] += -az * gqc[0] + aw * gqc[1] + ax * gqc[2] - ay * gqc[3];
+    gn[2] += ay * gqc[0] - ax * gqc[1] + aw * gqc[2] - az * gqc[3];
+    gn[3] += ax * gqc[0] + ay * gqc[1] + az * gqc[2] + aw * gqc[3];
+    gs += -ga[7] / (s * s) + gb[7];
+  }
+  part[0][tid] = gp[0]; part[1][tid] = gp[1]; part[2][tid] = gp[2];
+  part[3][tid] = gn[0]; part[4][tid] = gn[1]; part[5][tid] = gn[2]; part[6][tid] = gn[3];
+  part[7][tid] = gs;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (tid < off) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) part[k][tid] += part[k][tid + off];
+    }
+    __syncthreads();
+  }
+  if (tid != 0) return;   // (every thread has passed the last barrier)
+  const float q[4] = {orientation[0], orientation[1], orientation[2], orientation[3]};
+  const float inv_n = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const float nq[4] = {q[0] * inv_n, q[1] * inv_n, q[2] * inv_n, q[3] * inv_n};
+  const float d = nq[0] * part[3][0] + nq[1] * part[4][0] + nq[2] * part[5][0] + nq[3] * part[6][0];
+  for (int k = 0; k < 3; ++k) g_position[k] = part[k][0];
+  for (int k = 0; k < 4; ++k) g_orientation[k] = (part[3 + k][0] - nq[k] * d) * inv_n;
+  g_scale[0] = part[7][0];
+}
+
 __device__ __forceinline__ void deferred_chain(
     const float* __restrict__ orientation, const float* __restrict__ scale, const float* __restrict__ cam_quat,
     int V, const ViewSetup* __restrict__ setup, const float* __restrict__ tile_part, int W, int H, int ntx_all,
@@ -602,9 +653,7 @@ __global__ __launch_bounds__(256) void loop_tail_kernel(LoopTailArgs a) {
     __syncthreads();
   }
   if (a.records) {
-    if (threadIdx.x == 0)
-      pose_chain(a.params + 3, a.params + 7, a.cam_quat_all, a.V_all, a.records, kViewRecord, true, true, g, g + 3,
-                 g + 7);
+    pose_chain_block(a.params + 3, a.params + 7, a.cam_quat_all, a.V_all, a.records, kViewRecord, g, g + 3, g + 7);
   } else {
     deferred_chain(a.params + 3, a.params + 7, a.cam_quat, a.V, a.setup, a.tile_part, a.W, a.H, a.ntx, a.nty,
                    a.tile_w, a.tile_h, a.stride, a.pc_part, a.pc_loss_part, a.offsets, a.n_single, a.nblk, a.quat_c,

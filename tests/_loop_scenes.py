@@ -3,7 +3,8 @@ same numbers, in every process.
   "g7a"    run A of G7 (tests/golden/loop_g7.npz: 2 views with camera extrinsics, assembled from imported reference
            pieces by tools/make_goldens.py::make_loop_g7)
   "seven"  7 cameras on an arc around one mug-decoder shape at 160x120, the observed depth rendered at the true
-           pose by the forward kernel (bitwise reproducible), a perturbed initial estimate"""
+           pose by the forward kernel (bitwise reproducible), a perturbed initial estimate
+  "many"   80 cameras at 96x72 (3 iterations): a view list longer than one round of the tail's chain"""
 import os
 
 import numpy as np
@@ -53,9 +54,10 @@ def build(name, iterations=None, dev="cuda"):
         return dict(decoder=dec, camera=cam, config=cfg, depth=t(g7["a_depth_images"]), cam_pos=t(g7["a_cam_pos"]),
                     cam_quat=t(g7["a_cam_quat"]),
                     init=(t(init[None, 0:3]), t(init[None, 3:7]), t(init[7:8]), t(init[None, 8:])))
-    if name != "seven":
+    if name not in ("seven", "many"):
         raise ValueError(name)
-    V, W, H, f = 7, 160, 120, 160.0
+    # "many": 80 small views -- more than the single-process tail's 64, several rounds of the tail's 256-thread chain
+    V, W, H, f = (7, 160, 120, 160.0) if name == "seven" else (80, 96, 72, 96.0)
     cam = Camera(W, H, f, f, W / 2.0, H / 2.0, pixel_center=0.5)
     z_true = d["z"][9:10] * 0.5
     p_true = np.array([0.02, -0.01, -0.5])
@@ -63,7 +65,7 @@ def build(name, iterations=None, dev="cuda"):
     s_true = 0.055
     cam_pos, cam_quat = [], []
     for i in range(V):
-        a = (i - 3) * np.deg2rad(2.5)                       # yaw about the world's y axis, object stays in view
+        a = (i - 3) * np.deg2rad(2.5) if name == "seven" else (i % 9 - 4) * np.deg2rad(2.0)   # yaw about the world's y axis
         cam_pos.append([0.5 * np.sin(a) * 0.3, 0.01 * (i % 3 - 1), 0.02 * (i % 2)])
         cam_quat.append([0.01 * (i % 2), np.sin(0.15 * a), 0.0, np.cos(0.15 * a)])
     cam_pos = np.array(cam_pos)
@@ -77,7 +79,7 @@ def build(name, iterations=None, dev="cuda"):
                                           t(1.0 / s_true), None, None, None, 0.005, cam))
         depth = torch.stack(depth).contiguous()
     q0 = q_true + np.array([0.05, -0.04, 0.03, 0.0])
-    cfg = {"threshold": 0.005, "max_iterations": iterations or 6, "depth_weight": 1.0, "pc_weight": 3.0,
+    cfg = {"threshold": 0.005, "max_iterations": iterations or (6 if name == "seven" else 3), "depth_weight": 1.0, "pc_weight": 3.0,
            "result_selection_strategy": "best_inlier_ratio"}
     return dict(decoder=dec, camera=cam, config=cfg, depth=depth, cam_pos=t(cam_pos), cam_quat=t(cam_quat),
                 init=(t(p_true[None] + 0.008), t((q0 / np.linalg.norm(q0))[None]), t([0.06]),

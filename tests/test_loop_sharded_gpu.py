@@ -141,6 +141,23 @@ def test_three_ranks_on_seven_views(tmp_path):
     assert np.array_equal(traj, r["traj"]) and np.array_equal(inl, r["inlier"])
 
 
+def test_eighty_views_on_two_ranks(tmp_path):
+    """a view list longer than the single-process tail takes (64) and than one round of the records tail's chain:
+    2 x 40 views, bitwise the single-process records form in the deterministic mode, and the autograd loop to rounding"""
+    from sdfest_amd.differentiable_renderer import BWD_SMALL_TILES, SDF_GRAD_DETERMINISTIC
+    from sdfest_amd.pipeline import RenderAndCompare
+    r = _spawn(tmp_path, "many", "det", "sdf", "graph")
+    assert r["shards"].tolist() == [[0, 40], [40, 80]]
+    traj, _, inl = _single("many", SDF_GRAD_DETERMINISTIC | BWD_SMALL_TILES, True)
+    assert np.array_equal(traj, r["traj"]) and np.array_equal(inl, r["inlier"])
+    sc = _loop_scenes.build("many")
+    hist = []
+    RenderAndCompare(sc["decoder"], sc["camera"], sc["config"])(
+        sc["depth"], *sc["init"], camera_positions=sc["cam_pos"], camera_orientations=sc["cam_quat"],
+        shape_optimization=True, history=hist)
+    assert _steps(_loop_scenes.history_array(hist), r["traj"]).max() < 5e-3
+
+
 def test_more_ranks_than_views_is_refused():
     from sdfest_amd.parallel import shard_views
     assert shard_views(2, 2, 3) == (2, 2)          # an empty shard: the loop refuses it (every rank needs a view)

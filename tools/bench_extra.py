@@ -107,7 +107,12 @@ class Telemetry:
         self._thread.start()
 
     def mark(self, name):
+        """time stamp + one reading taken right here by the calling thread (the timed region of the driver's
+        `--steps 20` is 5 ms long: the sampler thread may not see it at all, these two readings bracket it)"""
         self.marks[name] = time.perf_counter()
+        if self.paths:
+            self.at = getattr(self, "at", {})
+            self.at[name] = self.read()
 
     def stop(self):
         self._stop.set()
@@ -128,6 +133,10 @@ class Telemetry:
         out = {"source": f"{self.hw} ({self.how}) sampled every {self.period * 1e3:.0f} ms by a host thread",
                "samples_in_timed_region": len(inside), "sampler_thread_active_during_timed_region": True,
                "sampler_thread_joined": getattr(self, "joined", None)}
+        for name in (t0_name, t1_name):
+            rd = getattr(self, "at", {}).get(name)
+            if rd:
+                out["at_" + name] = {k: round(v, 1) for k, v in rd.items()}
         for key in self.paths:
             v = [s[key] for s in inside if key in s]
             if v:

@@ -23,7 +23,8 @@ def main():
     from _loop_scene import c5_scene
     from sdfest_amd.pipeline import FusedRenderAndCompare
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    # (SDFR_BENCH_SHARE_GPU=1 SDFR_BENCH_BACKEND=gloo: a rehearsal with every rank on GPU 0, never a measurement)
+    dev = torch.device("cuda", 0 if os.environ.get("SDFR_BENCH_SHARE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group(os.environ.get("SDFR_BENCH_BACKEND", "nccl"), rank=rank, world_size=world,
