@@ -3,10 +3,14 @@
 The reference is single-process single-GPU and loops over views in Python
 (estimation/simple_setup.py:420-446).  Here each rank (one process per GPU) renders a
 contiguous shard of the views; forward needs no communication at all, and backward has
-exactly one exchange: the d/dSDF volume (and, when the object pose is shared by all
-cameras, the 8 chain-ruled pose gradients) is summed over ranks with ONE all-reduce
-(RCCL over xGMI on GPUs: torch.distributed backend "nccl"; gloo in the CPU tests).
-1 MiB + 32 B is latency-bound on 7x153 GB/s links, so it is sent as a single flat bucket.
+exactly one exchange: the d/dSDF volume is summed over ranks with ONE all-reduce (RCCL over
+xGMI on GPUs: torch.distributed backend "nccl"; gloo in the tests).  1 MiB is latency-bound on
+7x153 GB/s links, so whatever else must be shared rides in the same flat bucket: in the sharded
+render-and-compare loop (``pipeline.FusedRenderAndCompare(process_group=...)``) one 20-float record per
+view -- its pose sums and loss values, non-zero on the rank that owns the view -- behind the volume
+(``allreduce_bucket``; as 64-bit integers in the deterministic mode, where the sum is then exact and the
+whole trajectory bitwise independent of the split).  Parameters and optimiser state are replicated and
+never broadcast.
 """
 from typing import Optional, Sequence, Tuple
 
