@@ -256,7 +256,7 @@ class FusedRenderAndCompare:
                  shape_optimization: bool = True, device="cuda", fuse_depth_loss: bool = True,
                  point_constraint: Optional[Sequence] = None, track_inliers: Optional[bool] = None,
                  merge_launches: bool = True, graph_iterations: int = 5, process_group=None,
-                 exchange: str = "sdf", sdf_grad_mode: int = 0):
+                 exchange: str = "sdf", sdf_grad_mode: int = 0, form: str = "auto"):
         """point_constraint: (source (3,), target (3,), weight), simple_setup.py:164-175.
         process_group (None | "world" | a torch.distributed group): the loop SHARDED over the group's ranks, one process
         per GPU.  Every rank is given the same full view list, cameras and initial estimate and keeps its contiguous
@@ -268,6 +268,13 @@ class FusedRenderAndCompare:
                              [view records | d loss / d latent]: 80 V + 4 L bytes instead of 1 MiB.  Same result up to
                              the rounding of the sum.
         Parameters and Adam state are replicated and stay identical on every rank; nothing is broadcast.
+        form: how the per-view results reach the update.  "tail": ONE workgroup reduces every view's partial sums and
+        runs the chain and Adam (``sdfr_loop_tail``: the fewest launches -- best for a handful of views, at most 64);
+        "records": one wave per view writes the view's record (``sdfr_loop_view_records``), the tail works from the
+        records (``sdfr_loop_tail_records``) -- one launch more, any number of views, and the only form a process
+        group can use; "auto": records with a process group or from 8 views on (ms per iteration on one MI355X, 640x480
+        views, tail / records: 1 view 0.135 / 0.139, 4: 0.152 / 0.152, 8: 0.165 / 0.161, 16: 0.199 / 0.175, 64: 0.304 /
+        0.226), the tail otherwise.
         sdf_grad_mode: flag bits for the renderer's backward (differentiable_renderer.SDF_GRAD_*, BWD_*).  With
         ``SDF_GRAD_DETERMINISTIC | BWD_SMALL_TILES`` and exchange="sdf" the bucket is summed as integers and the
         trajectory is bitwise the same however the views are spread over ranks (and as a single process).
@@ -305,8 +312,13 @@ class FusedRenderAndCompare:
         # the records form of the iteration: head (decoder .. both backward passes .. view records), [exchange],
         # tail (decoder VJP, chain over ALL views' records, Adam, next poses).  A single process takes it too when
         # the pose sums are asked to be independent of the batch (BWD_SMALL_TILES): same arithmetic as the ranks'.
-        self.records_form = self.group is not None or bool(self.sdf_grad_mode & BWD_SMALL_TILES)
         self.V_all = int(depth_images.shape[0])
+        if form not in ("auto", "tail", "records"):
+            raise ValueError(f"form must be 'auto', 'tail' or 'records', got {form!r}")
+        must = self.group is not None or bool(self.sdf_grad_mode & BWD_SMALL_TILES)
+        if form == "tail" and must:
+            raise ValueError("a process group (and BWD_SMALL_TILES) needs the records form")
+        self.records_form = must or form == "records" or (form == "auto" and self.V_all >= 8 and bool(fuse_depth_loss))
         self.view_begin, self.view_end = shard_views(self.V_all, self.rank, self.world)
         if self.view_end == self.view_begin:
             raise ValueError(f"{self.V_all} view(s) cannot be sharded over {self.world} ranks: every rank needs one")
@@ -659,6 +671,8 @@ class FusedRenderAndCompare:
     def _run_records(self, n_iter, use_graph, history):
         state = (self.params, self.m, self.v, self.step, self.inlier_counts, self.best_state, self.inlier_history,
                  self.best_params)
+        if self.group is None:
+            return self._run_records_single(n_iter, use_graph, history, state)
         if use_graph and self.graph is None:
             # warm up on a side stream (lazy module loads; every rank takes part in the exchange), restore, capture:
             # the collective stays outside the graphs -- head | all-reduce | tail+head | all-reduce | ... | tail
@@ -701,13 +715,55 @@ class FusedRenderAndCompare:
             else:
                 self.graph_tail.replay()
             if history is not None:
-                ld, lp = self.view_losses()
-                history.append({"loss": (self.cfg["depth_weight"] * ld.sum() + self.cfg["pc_weight"] * lp.sum()
-                                         + self.loss_con.sum()).clone(),
-                                "loss_depth": ld.clone(), "loss_pc": lp.clone(),
-                                "position": self.position.clone()[None],
-                                "orientation": self.orientation.clone()[None],
-                                "scale": self.scale.clone(), "latent": self.latent.clone()[None]})
+                self._record_history(history)
+
+    def _record_history(self, history):
+        ld, lp = self.view_losses()
+        history.append({"loss": (self.cfg["depth_weight"] * ld.sum() + self.cfg["pc_weight"] * lp.sum()
+                                 + self.loss_con.sum()).clone(),
+                        "loss_depth": ld.clone(), "loss_pc": lp.clone(),
+                        "position": self.position.clone()[None], "orientation": self.orientation.clone()[None],
+                        "scale": self.scale.clone(), "latent": self.latent.clone()[None]})
+
+    def _run_records_single(self, n_iter, use_graph, history, state):
+        """the records form without a process group: no collective, so whole iterations are captured -- one graph per
+        iteration, and one of ``graph_iterations`` iterations, as in the tail form"""
+        if use_graph and self.graph is None:
+            saved = [t.clone() for t in state]
+            side = torch.cuda.Stream(self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                self._head()
+                self._tail()
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+            for t, c in zip(state, saved):
+                t.copy_(c)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._head()
+                self._tail()
+            if self.graph_iterations > 1:
+                self.graph_many = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_many):
+                    for _ in range(self.graph_iterations):
+                        self._head()
+                        self._tail()
+            for t, c in zip(state, saved):
+                t.copy_(c)
+            self._poses_to_views(self._stream())
+        done = 0
+        if use_graph and history is None and self.graph_many is not None:
+            for _ in range(n_iter // self.graph_iterations):
+                self.graph_many.replay()
+            done = n_iter - n_iter % self.graph_iterations
+        for _ in range(n_iter - done):
+            if use_graph:
+                self.graph.replay()
+            else:
+                self._head()
+                self._tail()
+            if history is not None:
+                self._record_history(history)
 
     def _tail_form(self) -> bool:
         return (self.merge_tail and self.fuse_depth_loss and self.defer_pose and self.max_pts > 0

@@ -176,3 +176,36 @@ def test_sharded_loop_over_rccl_with_one_rank(tmp_path, graph):
     r = _spawn(tmp_path, "g7a", "float", "latent", graph, world=1, backend="nccl")
     traj, _, _ = _single("g7a", graph=graph == "graph")
     assert _steps(traj, r["traj"]).max() < 5e-3
+
+
+def test_single_process_forms_agree_and_auto_picks_by_view_count():
+    """form="tail" (one workgroup reduces every view) and form="records" (one wave per view; what a process group
+    uses) are the same loop: trajectories agree to rounding, eager and captured; "auto" takes the records form from 8
+    views on (the faster one there) and the tail below."""
+    from sdfest_amd.pipeline import FusedRenderAndCompare
+    sc = _loop_scenes.build("seven")
+    kw = dict(camera_positions=sc["cam_pos"], camera_orientations=sc["cam_quat"], shape_optimization=True,
+              track_inliers=True)
+    trajs = {}
+    for form in ("tail", "records"):
+        for graph in (False, True):
+            loop = FusedRenderAndCompare(sc["decoder"], sc["camera"], sc["config"], sc["depth"], form=form, **kw)
+            assert loop.records_form == (form == "records")
+            hist = []
+            loop(*sc["init"], use_graph=graph, history=hist)
+            torch.cuda.synchronize()
+            trajs[form, graph] = (_loop_scenes.history_array(hist), loop.inlier_history.cpu().numpy())
+    base, inl = trajs["tail", False]
+    for key, (t, i) in trajs.items():
+        assert _steps(base, t).max() < 2e-3, key
+        assert np.max(np.abs(i - inl)) < 2.5 / 300, key
+    # captured == eager within a form (the same launches)
+    assert np.array_equal(trajs["records", False][0], trajs["records", True][0]) or \
+        _steps(trajs["records", False][0], trajs["records", True][0]).max() < 1e-3
+    auto7 = FusedRenderAndCompare(sc["decoder"], sc["camera"], sc["config"], sc["depth"], **kw)
+    many = _loop_scenes.build("many")
+    auto80 = FusedRenderAndCompare(many["decoder"], many["camera"], many["config"], many["depth"],
+                                   camera_positions=many["cam_pos"], camera_orientations=many["cam_quat"])
+    assert not auto7.records_form and auto80.records_form
+    with pytest.raises(ValueError):
+        FusedRenderAndCompare(sc["decoder"], sc["camera"], sc["config"], sc["depth"], form="sideways", **kw)

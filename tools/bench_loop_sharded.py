@@ -53,12 +53,12 @@ def main():
         ms, res = time_loop(loop)
         out[f"ms_per_iteration_sharded_exchange_{exchange}"] = ms
         out[f"final_position_error_mm_{exchange}"] = round((res[0] - s["p_true"]).norm().item() * 1e3, 3)
-    if rank == 0:
-        single = FusedRenderAndCompare(s["decoder"], s["camera"], s["config"], s["targets"])
-        out["ms_per_iteration_single_process"], _ = time_loop(single)
-    else:
-        for _ in range(5):
-            dist.barrier()
+    # the single-process loop of the same views, in both of its forms (every rank runs them: time_loop has barriers)
+    for form in ("tail", "records"):
+        if form == "tail" and views > 64:
+            continue
+        single = FusedRenderAndCompare(s["decoder"], s["camera"], s["config"], s["targets"], form=form)
+        out[f"ms_per_iteration_single_process_{form}_form"], _ = time_loop(single)
     if rank == 0:
         print(json.dumps(out), flush=True)
     dist.barrier()
