@@ -11,8 +11,9 @@ from _loop_scene import c5_scene  # noqa: E402
 
 def main():
     from sdfest_amd.pipeline import FusedRenderAndCompare
-    s = c5_scene(max_iterations=10)
-    loop = FusedRenderAndCompare(s["decoder"], s["camera"], s["config"], s["targets"])
+    s = c5_scene(views=int(os.environ.get("VIEWS", "1")), max_iterations=10)
+    loop = FusedRenderAndCompare(s["decoder"], s["camera"], s["config"], s["targets"],
+                                 form=os.environ.get("FORM", "auto"))
     for _ in range(3):
         loop(*s["init"], use_graph=True)
     torch.cuda.synchronize()
