@@ -626,7 +626,10 @@ class FusedRenderAndCompare:
         """The iteration's one collective (RCCL over xGMI with backend "nccl"); nothing without a group."""
         from .parallel import allreduce_bucket
         if self.group is not None:
-            allreduce_bucket(self.xbuf, self.group, integer=self.det)
+            # as integers only where that is a sum: the int64 volume, and records (non-zero on one rank each) -- not
+            # the latent gradients of exchange="latent", which every rank contributes to
+            with_g = self.shape_opt and self.exchange == "latent"
+            allreduce_bucket(self.xbuf, self.group, integer=self.det and not with_g)
 
     def _tail(self):
         """simple_setup.py:448-462 on every rank alike: decoder VJP of the summed volume, the chain over all views'

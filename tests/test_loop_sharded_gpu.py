@@ -82,6 +82,17 @@ def test_sharded_loop_matches_the_single_process_loop(tmp_path, scene, exchange)
     assert np.allclose(loss, r["loss"], rtol=1e-4) and np.max(np.abs(inl - r["inlier"])) < 2.5 / 300
 
 
+def test_deterministic_backward_with_the_latent_exchange(tmp_path):
+    """SDF_GRAD_DETERMINISTIC with exchange="latent": every rank's d/d latent is a float contribution, so this bucket
+    is summed as floats (summing its bits as integers would be no sum at all) -- the trajectory follows the
+    single-process one to rounding, not to the bit"""
+    from sdfest_amd.differentiable_renderer import BWD_SMALL_TILES, SDF_GRAD_DETERMINISTIC
+    r = _spawn(tmp_path, "seven", "det", "latent", "graph")
+    traj, loss, _ = _single("seven", SDF_GRAD_DETERMINISTIC | BWD_SMALL_TILES, True)
+    assert _steps(traj, r["traj"]).max() < 2e-3 and np.allclose(loss, r["loss"], rtol=1e-4)
+    assert np.isfinite(r["traj"]).all() and np.abs(r["traj"][-1, 8:]).max() > 1e-4      # the latent moved
+
+
 def test_sharded_loop_matches_g7_run_a(tmp_path):
     """the sharded loop against the reference-derived golden itself (same bounds as the single-process G7 test)"""
     g7 = np.load(os.path.join(_loop_scenes.GOLDEN, "loop_g7.npz"))
