@@ -511,6 +511,10 @@ def main():
                          # bytes = 16 B x 64 lane slots x vector read instructions; unit busy = *_BUSY / (cycles x CUs);
                          # valu_busy_frac = 4 x SQ_ACTIVE_INST_VALU / (SIMDs x cycles))
                          "binding": ((traffic or {}).get("binding") or {}).get(dominant),
+                         # the kernel alone (the call above includes the forward's prologue launch): its average
+                         # duration in the committed rocprofv3 kernel trace of the same command
+                         "kernel_trace": (lambda us: {"avg_launch_us": us, "frac": round(k_bytes / (us * 1e-6) / HBM_PEAK, 5)}
+                                          if us else None)(((traffic or {}).get("kernel_avg_us_from_trace") or {}).get(dominant)),
                          "algorithmic_bytes_per_launch": int(k_bytes),
                          "avg_launch_ms": round(k_ms, 4)},
             "roofline_step": {"bytes_per_view": bytes_per_view,

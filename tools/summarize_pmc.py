@@ -116,6 +116,8 @@ def main():
     for k, v in out.items():
         if "hbm_bytes" in v:
             traffic[k.split("<")[0]] = int(v["hbm_bytes"])
+        if k.startswith(("render_forward_kernel", "render_backward_kernel", "forward_prologue_kernel", "pose_reduce_kernel")):
+            traffic.setdefault("kernel_avg_us_from_trace", {})[k.split("<")[0]] = round(v["avg_ns"] / 1e3, 2)
         if "binding" in v and k.startswith(("render_forward_kernel", "render_backward_kernel")):
             traffic.setdefault("binding", {})[k.split("<")[0]] = v["binding"]
     if len(traffic) > 2:
