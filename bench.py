@@ -285,7 +285,10 @@ def main():
     # The SDFR_BWD_HALF_GRID hint of include/sdfr.h is chosen by the plan itself (close_views="auto", its default):
     # the forward's prologue counts the close views on the device into a pinned host word and each backward reads
     # whatever count has arrived -- this file never looks at the poses.
-    plan = BatchRenderPlan(64, B, cam, device=device, grad_volumes=M)
+    # (SDFR_BENCH_CLOSE_VIEWS=1 / 0 forces the hint on / off: the counter passes of tools/profile_gpu.sh run 5 cold
+    # steps under a serialising profiler, too few for the count to arrive -- they force what the steady state chooses)
+    cv = {"1": True, "0": False}.get(os.environ.get("SDFR_BENCH_CLOSE_VIEWS", ""), "auto")
+    plan = BatchRenderPlan(64, B, cam, device=device, grad_volumes=M, close_views=cv)
     state = {"k": 0, "pending": [None, None], "mode": args.exchange if use_dist else "none"}
     # (begin, end) around every synchronous exchange of one timed region, made before it (no allocation inside)
     coll_pool = ([(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -496,8 +499,9 @@ def main():
                                    + (", REHEARSAL: all ranks on GPU 0" if share_gpu else ""),
                        "views_per_gpu": B, "width": W, "height": H, "sdf_resolution": 64,
                        "parallelism": f"views sharded over {N} GPU(s)",
-                       "backward_half_grid": {"chosen_by": "device-side count of close views (pinned word), "
-                                                           "previous steps' value; no host poses",
+                       "backward_half_grid": {"chosen_by": ("device-side count of close views (pinned word), "
+                                                            "previous steps' value; no host poses") if cv == "auto"
+                                              else f"forced {cv} by SDFR_BENCH_CLOSE_VIEWS (profiling)",
                                               "timed_steps_with_hint": plan.half_grid_steps - half0,
                                               "close_views_last_counted": plan.close_views_seen()[1]},
                        "hit_pixels_rank0": hits},
