@@ -65,6 +65,40 @@ def test_two_ranks_equal_one_process_bitwise_in_the_deterministic_mode(tmp_path,
     assert np.abs(ref).max() > 0 and np.array_equal(ref, r["g_sdf"])
 
 
+def test_half_of_c4_at_the_real_shard_size(tmp_path):
+    """BASELINE configs[3] is 2048 views as 8 shards of 256 over RCCL; a one-GPU box can hold half of it: FOUR ranks
+    (gloo, sharing the GPU) of 256 views of 640x480 each against ONE process rendering the 1024 views -- contiguous
+    shards of the real size, the real image size, the batch kernels, the integer exchange: depth images equal
+    (checksums of their bits and hit counts), per-view pose gradients bit for bit, and the summed d/dSDF BITWISE the
+    single-process volume (deterministic mode)."""
+    from sdfest_amd import BatchRenderPlan, Camera
+    from sdfest_amd.parallel import spawn_ranks
+    from sdfest_amd.synthetic import blobs_sdf, random_poses
+    n_views, W, H = 1024, 640, 480
+    out = str(tmp_path / "c4half.npz")
+    rc = spawn_ranks([sys.executable, os.path.join(HERE, "_c4_worker.py"), out, str(n_views), str(W), str(H), "det_light"],
+                     4, timeout=500)
+    assert rc == 0
+    r = np.load(out)
+    assert r["spans"].tolist() == [[256 * k, 256 * (k + 1)] for k in range(4)]
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    pos, quat, isc = random_poses(n_views, seed=1, width=W, height=H, f=W / 2.0)
+    sdf = t(blobs_sdf(0))
+    g_all = torch.rand((n_views, H, W), generator=torch.Generator().manual_seed(77)) * 2 - 1
+    cam = Camera(W, H, W / 2.0, W / 2.0, W / 2.0, H / 2.0, pixel_center=0.5)
+    plan = BatchRenderPlan(64, n_views, cam, device=dev, sdf_grad_mode=0x100)
+    depth = plan.forward(sdf, t(pos), t(quat), t(isc), 0.005)
+    bits = depth.view(torch.int32).to(torch.int64).sum(dim=(1, 2)).cpu().numpy()
+    hits = (depth > 0).sum(dim=(1, 2)).cpu().numpy()
+    assert np.array_equal(bits, r["depth"][0]) and np.array_equal(hits, r["depth"][1]) and hits.sum() > 10_000_000
+    g_sdf, g_pos, g_quat, g_is = plan.backward(g_all.to(dev).contiguous(), sdf, t(pos), t(quat), t(isc))
+    assert np.array_equal(g_pos.cpu().numpy(), r["g_pos"]) and np.array_equal(g_quat.cpu().numpy(), r["g_quat"])
+    assert np.array_equal(g_is.cpu().numpy(), r["g_is"])
+    ref = g_sdf.cpu().numpy()
+    assert np.abs(ref).max() > 0 and np.array_equal(ref, r["g_sdf"])
+
+
 @pytest.mark.parametrize("exchange", ["ring", "sync"])
 def test_bench_py_with_two_ranks_in_rehearsal_mode(tmp_path, exchange):
     """bench.py --gpus 2 itself, both ranks on the one GPU of the test box over gloo (marked REHEARSAL in its line):
