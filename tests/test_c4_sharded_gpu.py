@@ -99,6 +99,44 @@ def test_half_of_c4_at_the_real_shard_size(tmp_path):
     assert np.abs(ref).max() > 0 and np.array_equal(ref, r["g_sdf"])
 
 
+def test_c4_full_size_equals_the_sum_of_its_eight_shards():
+    """All of BASELINE configs[3] on one GPU, one shard after the other: the 2048 seeded views of 640x480 as ONE batch
+    against their 8 contiguous shards of 256 (what each of the 8 ranks renders) -- depth images and per-view pose
+    gradients bit for bit; the shards' int64 d/dSDF volumes, added as the integer all-reduce adds them and converted
+    once (sdfr_fixed_to_float), bitwise the full batch's volume.  What this cannot show is the exchange itself."""
+    from sdfest_amd import BatchRenderPlan, Camera
+    from sdfest_amd.parallel import allreduce_fixed_gradients, shard_views
+    from sdfest_amd.synthetic import blobs_sdf, random_poses
+    n_views, W, H, world = 2048, 640, 480, 8
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    pos, quat, isc = (t(a) for a in random_poses(n_views, seed=1, width=W, height=H, f=W / 2.0))
+    sdf = t(blobs_sdf(0))
+    cam = Camera(W, H, W / 2.0, W / 2.0, W / 2.0, H / 2.0, pixel_center=0.5)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    g_all = torch.rand((n_views, H, W), device=dev, generator=gen) * 2 - 1
+    full = BatchRenderPlan(64, n_views, cam, device=dev, sdf_grad_mode=0x100)
+    depth = full.forward(sdf, pos, quat, isc, 0.005)
+    bits_full = depth.view(torch.int32).to(torch.int64).sum(dim=(1, 2))
+    g_sdf, g_pos, g_quat, g_is = (x.clone() for x in full.backward(g_all, sdf, pos, quat, isc))
+    assert int((depth > 0).sum()) > 25_000_000
+    del full, depth
+    torch.cuda.empty_cache()
+    shard = BatchRenderPlan(64, n_views // world, cam, device=dev, sdf_grad_mode=0x100)
+    total = torch.zeros((64, 64, 64), dtype=torch.int64, device=dev)
+    for r in range(world):
+        b, e = shard_views(n_views, r, world)
+        assert (b, e) == (256 * r, 256 * (r + 1))
+        d = shard.forward(sdf, pos[b:e].contiguous(), quat[b:e].contiguous(), isc[b:e].contiguous(), 0.005)
+        assert torch.equal(d.view(torch.int32).to(torch.int64).sum(dim=(1, 2)), bits_full[b:e])
+        _, sp, sq, si = shard.backward(g_all[b:e], sdf, pos[b:e].contiguous(), quat[b:e].contiguous(), isc[b:e].contiguous())
+        assert torch.equal(sp, g_pos[b:e]) and torch.equal(sq, g_quat[b:e]) and torch.equal(si, g_is[b:e])
+        total += shard.g_sdf_fixed()
+    out = torch.empty((64, 64, 64), device=dev)
+    allreduce_fixed_gradients(total, out)        # (no process group: the conversion alone)
+    assert out.abs().max() > 0 and torch.equal(out, g_sdf)
+
+
 @pytest.mark.parametrize("exchange", ["ring", "sync"])
 def test_bench_py_with_two_ranks_in_rehearsal_mode(tmp_path, exchange):
     """bench.py --gpus 2 itself, both ranks on the one GPU of the test box over gloo (marked REHEARSAL in its line):
