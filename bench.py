@@ -377,9 +377,19 @@ def main():
     # ramp (round 2: 855 k renders/s on the driver's box against 903 k in a longer session).  The steady state is
     # what the metric means, so the GPU runs the same steps for `--prewarm-ms` before the W warm-up steps; the
     # telemetry in the line shows the clocks of the timed region.
+    def ranks_agree(go_on):
+        """A loop that ends by the CLOCK must end after the same number of rounds on every rank -- each round issues
+        collectives, and ranks that disagree by one round would wait for each other in different collectives for
+        ever.  Rank 0's clock decides (one tiny broadcast per round, untimed regions only)."""
+        if not use_dist:
+            return go_on
+        flag = torch.tensor([1 if go_on else 0], device=device, dtype=torch.int32)
+        dist.broadcast(flag, src=0)
+        return bool(flag.item())
+
     t_pre = time.perf_counter()
     n_pre = 0
-    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+    while ranks_agree((time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms):
         for _ in range(16):
             step()
         n_pre += 16
@@ -404,7 +414,7 @@ def main():
             # the other exchange gets its own untimed run-in (its first collectives on a fresh stream grow c10d's and
             # HIP's event pools: measured cold, 200 sync steps took twice the time they take after 100 ms of the same)
             t_w = time.perf_counter()
-            while (time.perf_counter() - t_w) * 1e3 < min(100.0, max(args.prewarm_ms, 1.0)):
+            while ranks_agree((time.perf_counter() - t_w) * 1e3 < min(100.0, max(args.prewarm_ms, 1.0))):
                 for _ in range(8):
                     step()
                 torch.cuda.synchronize()
