@@ -388,12 +388,13 @@ class FusedRenderAndCompare:
         self.quat_c = torch.empty((V, 4), **f32)
         self.inv_scale = torch.empty((V,), **f32)
         self.scale_v = torch.empty((V,), **f32)
-        self.grad_est = torch.empty((V, H, W), **f32)
+        # (the gradient image and the per-point arrays exist only when the losses run as kernels of their own)
+        self.grad_est = None if self.fuse_depth_loss else torch.empty((V, H, W), **f32)
         self.loss_depth = torch.zeros((V,), **f32)
         self.loss_pc = torch.zeros((V,), **f32)
         N = self.points.shape[0]
-        self.vals = torch.empty((max(N, 1),), **f32)
-        self.grad_vals = torch.empty((max(N, 1),), **f32)
+        self.vals = None if self.fuse_depth_loss else torch.empty((max(N, 1),), **f32)
+        self.grad_vals = None if self.fuse_depth_loss else torch.empty((max(N, 1),), **f32)
         self.g_sdf_pc = torch.empty((R, R, R), **f32)
         self.g_pos_pc = torch.empty((V, 3), **f32)
         self.g_quat_pc = torch.empty((V, 4), **f32)
