@@ -95,7 +95,13 @@ class Watchdog:
         if self.seconds > 0:
             self.timer.cancel()
             faulthandler.cancel_dump_traceback_later()
+            if Watchdog.job_deadline is not None:     # re-arm the whole-job backstop this stage's timer replaced
+                left = Watchdog.job_deadline - time.monotonic()
+                if left > 1.0:
+                    faulthandler.dump_traceback_later(left, exit=True)
         return False
+
+    job_deadline = None
 
 
 def synthetic_inputs(B_total, rank, B, W, H, device):
@@ -231,7 +237,13 @@ def main():
     # so a 1-GPU torchrun exercises exactly the code the multi-GPU runs execute
     use_dist = N > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
     if use_dist:
+        import faulthandler
         import torch.distributed as dist
+        # backstop for the whole multi-rank run: a rank still here after 15 minutes dumps every thread's stack and
+        # exits 1 (C-level timer, needs no interpreter lock), so a hang past start-up also says where it is
+        job_s = float(os.environ.get("SDFR_BENCH_JOB_WATCHDOG_S", "900"))
+        Watchdog.job_deadline = time.monotonic() + job_s
+        faulthandler.dump_traceback_later(job_s, exit=True)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # RCCL prints a version banner on STDOUT when its communicator comes up; stdout is for the one result
@@ -580,6 +592,7 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+        faulthandler.cancel_dump_traceback_later()
 
 
 if __name__ == "__main__":
