@@ -350,6 +350,11 @@ SDFR_API int sdfr_decoder_backward_latent_deferred(const sdfr_decoder* decoder, 
  * bit-identical to the three single-axis launches it replaces); 0 switches back to the three launches so that a
  * test can compare the two bit for bit.  Process-wide; returns the old value. */
 SDFR_API int sdfr_debug_set_decoder_tiled_vjp(int on);
+/* TEST HOOK: the backward of a NARROW Linear stack (every layer input <= 64 wide, e.g. the mug decoder's 8 -> 20 -> 50)
+ * runs as one wave out of LDS -- in sdfr_decoder_backward_latent and inside sdfr_loop_tail[_records] --, bit-identical
+ * to the one-workgroup form wider stacks take; 0 switches to that form so that a test can compare the two bit for
+ * bit.  Process-wide; returns the old value. */
+SDFR_API int sdfr_debug_set_decoder_fc_one_wave(int on);
 
 /* ---- glue of one render-and-compare iteration (SDFPipeline.__call__, simple_setup.py:408-470) --- */
 /* Small kernels that replace the reference's per-iteration torch-op soup so that a whole

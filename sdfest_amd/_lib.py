@@ -27,6 +27,7 @@ SIGNATURES = {
     "sdfr_render_sync_offset": (c_sz, [c_int]),
     "sdfr_debug_set_prologue_polls": (c_int, [c_int]),
     "sdfr_debug_set_decoder_tiled_vjp": (c_int, [c_int]),
+    "sdfr_debug_set_decoder_fc_one_wave": (c_int, [c_int]),
     "sdfr_debug_set_decoder_fused_resize": (c_int, [c_int]),
     "sdfr_render_partials_offset": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
     "sdfr_render_step_forward_l1": (c_int, [c_fp, c_int, c_ll, c_fp, c_fp, c_fp, c_int, c_int, c_int,

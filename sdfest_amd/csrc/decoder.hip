@@ -77,25 +77,70 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 
 // grid (ceil(out_last / 256), N)
+// NARROW (fc_one_wave_ok: every leading layer at most 64 wide, the mug decoder's 8 -> 20 -> 50): the leading layers'
+// parameters are copied to LDS first, all loads in flight at once, and wave 0 runs the layers out of LDS -- the general
+// form pays a runtime-length loop of dependent global loads per layer (1.0 + 1.8 us of the single decode's 6.7 us
+// launch; tools/microbench/tail_stamps.py measured the same loops in the backward).  Same fmaf chains, same numbers.
+template <bool NARROW>
 __global__ __launch_bounds__(kFcBlock) void fc_stack_kernel(const float* __restrict__ params,
                                                             FcDesc d, const float* __restrict__ z,
                                                             float* __restrict__ out) {
-  __shared__ float act[2][kMaxHidden];
+  __shared__ float act[2][NARROW ? kFcWaveWidth : kMaxHidden];
   const int tid = threadIdx.x, n = blockIdx.y;
-  for (int i = tid; i < d.width[0]; i += kFcBlock) act[0][i] = z[(size_t)n * d.width[0] + i];
-  __syncthreads();
   int cur = 0;
-  for (int l = 0; l < d.n_fc - 1; ++l) {
-    const int win = d.width[l], wout = d.width[l + 1];
-    const float* w = params + d.w_off[l];
-    const float* b = params + d.b_off[l];
-    for (int o = tid; o < wout; o += kFcBlock) {
-      float acc = b[o];
-      for (int i = 0; i < win; ++i) acc = fmaf(w[(size_t)o * win + i], act[cur][i], acc);
-      act[cur ^ 1][o] = fmaxf(acc, 0.0f);
+  if (NARROW) {
+    __shared__ float p_lds[kFcWaveSpan];
+    const long long base = d.w_off[0];
+    const int span = (int)fc_wave_span(d);
+    const float z_t = tid < d.width[0] ? z[(size_t)n * d.width[0] + tid] : 0.0f;
+    {
+      constexpr int U = kFcWaveSpan / kFcBlock;   // 24 loads per thread cover the largest span
+      float r[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = u * kFcBlock + tid;
+        r[u] = e < span ? params[base + e] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = u * kFcBlock + tid;
+        if (e < span) p_lds[e] = r[u];
+      }
+    }
+    if (tid < d.width[0]) act[0][tid] = z_t;
+    __syncthreads();
+    if (tid < 64) {
+      for (int l = 0; l < d.n_fc - 1; ++l) {
+        const int win = d.width[l], wout = d.width[l + 1];
+        if (tid < wout) {
+          float acc = p_lds[d.b_off[l] - base + tid];
+          const float* w = p_lds + (d.w_off[l] - base) + tid * win;
+#pragma unroll 8
+          for (int i = 0; i < win; ++i) acc = fmaf(w[i], act[cur][i], acc);
+          act[cur ^ 1][tid] = fmaxf(acc, 0.0f);
+        }
+        __builtin_amdgcn_wave_barrier();
+        cur ^= 1;
+      }
+    } else {
+      cur = (d.n_fc - 1) & 1;
     }
     __syncthreads();
-    cur ^= 1;
+  } else {
+    for (int i = tid; i < d.width[0]; i += kFcBlock) act[0][i] = z[(size_t)n * d.width[0] + i];
+    __syncthreads();
+    for (int l = 0; l < d.n_fc - 1; ++l) {
+      const int win = d.width[l], wout = d.width[l + 1];
+      const float* w = params + d.w_off[l];
+      const float* b = params + d.b_off[l];
+      for (int o = tid; o < wout; o += kFcBlock) {
+        float acc = b[o];
+        for (int i = 0; i < win; ++i) acc = fmaf(w[(size_t)o * win + i], act[cur][i], acc);
+        act[cur ^ 1][o] = fmaxf(acc, 0.0f);
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
   }
   const int l = d.n_fc - 1;
   const int win = d.width[l], wout = d.width[l + 1];
@@ -1510,6 +1555,15 @@ __global__ __launch_bounds__(kFcBlock) void fc_stack_backward_kernel(const float
   fc_stack_backward_sample(params, d, z + (size_t)n * d.width[0], t_in + (size_t)n * d.width[l],
                            g_z + (size_t)n * d.width[0]);
 }
+// ... one wave per sample when the leading layers are narrow (fc_one_wave_ok): the same numbers
+__global__ __launch_bounds__(64) void fc_stack_backward_wave_kernel(const float* __restrict__ params, FcDesc d,
+                                                                    const float* __restrict__ z,
+                                                                    const float* __restrict__ t_in,
+                                                                    float* __restrict__ g_z) {
+  const int n = blockIdx.x, l = d.n_fc - 1;
+  fc_stack_backward_one_wave(params, d, z + (size_t)n * d.width[0], t_in + (size_t)n * d.width[l],
+                             g_z + (size_t)n * d.width[0], threadIdx.x);
+}
 
 }  // namespace
 }  // namespace sdfr
@@ -1984,8 +2038,11 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
       hipLaunchKernelGGL((fc_stack_batch_kernel<kFcSamples>),
                          dim3((last + kFcBlock - 1) / kFcBlock, (N + kFcSamples - 1) / kFcSamples), dim3(kFcBlock),
                          fc_lds, st, d->d_params, fd, z, N, hid, fc_dst);
+    else if (decoder_fc_one_wave(fd))
+      hipLaunchKernelGGL(fc_stack_kernel<true>, dim3((last + kFcBlock - 1) / kFcBlock, N), dim3(kFcBlock), 0, st,
+                         d->d_params, fd, z, fc_dst);
     else
-      hipLaunchKernelGGL(fc_stack_kernel, dim3((last + kFcBlock - 1) / kFcBlock, N), dim3(kFcBlock), 0, st,
+      hipLaunchKernelGGL(fc_stack_kernel<false>, dim3((last + kFcBlock - 1) / kFcBlock, N), dim3(kFcBlock), 0, st,
                          d->d_params, fd, z, fc_dst);
     act_in = fc_dst;
   }
@@ -2139,6 +2196,13 @@ std::atomic<int> g_tiled_resize_vjp{1};   // tests switch the one-launch transpo
 
 extern "C" int sdfr_debug_set_decoder_tiled_vjp(int on) {
   return sdfr::g_tiled_resize_vjp.exchange(on ? 1 : 0, std::memory_order_relaxed);
+}
+namespace sdfr {
+namespace { std::atomic<int> g_fc_one_wave{1}; }   // tests switch the one-wave Linear-stack backward off
+bool decoder_fc_one_wave(const FcDesc& d) { return g_fc_one_wave.load() != 0 && fc_one_wave_ok(d); }
+}
+extern "C" int sdfr_debug_set_decoder_fc_one_wave(int on) {
+  return sdfr::g_fc_one_wave.exchange(on ? 1 : 0);
 }
 
 extern "C" size_t sdfr_decoder_backward_workspace_bytes(const sdfr_decoder* d, int N) {
@@ -2470,6 +2534,8 @@ int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* ta
                          t_mid);
   }
   if (t_mid_out) *t_mid_out = t_mid;
+  else if (decoder_fc_one_wave(fd))
+    hipLaunchKernelGGL(fc_stack_backward_wave_kernel, dim3(N), dim3(64), 0, st, d->d_params, fd, z, t_mid, g_z);
   else hipLaunchKernelGGL(fc_stack_backward_kernel, dim3(N), dim3(kFcBlock), 0, st, d->d_params, fd, z, t_mid, g_z);
   SDFR_HIP_TRY(hipGetLastError());
   (void)n;

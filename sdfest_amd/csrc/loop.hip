@@ -37,27 +37,33 @@ __device__ __forceinline__ void quat_matrix(const float* q, float* m) {
 // The reference rotates with quaternion_apply = q * (v,0) * conj(q) (quaternion_utils.py:36-54),
 // which for a non-unit q scales by |q|^2; camera orientations are unit quaternions, for which
 // this equals the matrix product.  The gradient chain below assumes unit camera quaternions.
-__device__ __forceinline__ void pose_to_view(int v, const float* __restrict__ position,
-                                             const float* __restrict__ orientation,
-                                             const float* __restrict__ scale,
-                                             const float* __restrict__ cam_pos,
-                                             const float* __restrict__ cam_quat,
-                                             float* __restrict__ pos_c, float* __restrict__ quat_c,
-                                             float* __restrict__ inv_scale, float* __restrict__ scale_v) {
+// (the core takes the view's camera pose by value: the loop's tail has loaded it long before the parameters exist)
+__device__ __forceinline__ void pose_to_view_core(int v, const float* position, const float* orientation,
+                                                  const float* scale, const float (&cp)[3], const float (&cq)[4],
+                                                  float* __restrict__ pos_c, float* __restrict__ quat_c,
+                                                  float* __restrict__ inv_scale, float* __restrict__ scale_v) {
   const float q[4] = {orientation[0], orientation[1], orientation[2], orientation[3]};
   const float inv_n = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   const float nq[4] = {q[0] * inv_n, q[1] * inv_n, q[2] * inv_n, q[3] * inv_n};
-  const float qc[4] = {-cam_quat[4 * v], -cam_quat[4 * v + 1], -cam_quat[4 * v + 2], cam_quat[4 * v + 3]};
+  const float qc[4] = {-cq[0], -cq[1], -cq[2], cq[3]};
   float m[9];
   quat_matrix(qc, m);
-  const float dx = position[0] - cam_pos[3 * v], dy = position[1] - cam_pos[3 * v + 1],
-              dz = position[2] - cam_pos[3 * v + 2];
+  const float dx = position[0] - cp[0], dy = position[1] - cp[1], dz = position[2] - cp[2];
   pos_c[3 * v] = m[0] * dx + m[1] * dy + m[2] * dz;
   pos_c[3 * v + 1] = m[3] * dx + m[4] * dy + m[5] * dz;
   pos_c[3 * v + 2] = m[6] * dx + m[7] * dy + m[8] * dz;
   quat_mul(qc, nq, quat_c + 4 * v);
   inv_scale[v] = 1.0f / scale[0];
   scale_v[v] = scale[0];
+}
+__device__ __forceinline__ void pose_to_view(int v, const float* position, const float* orientation,
+                                             const float* scale, const float* __restrict__ cam_pos,
+                                             const float* __restrict__ cam_quat,
+                                             float* __restrict__ pos_c, float* __restrict__ quat_c,
+                                             float* __restrict__ inv_scale, float* __restrict__ scale_v) {
+  const float cp[3] = {cam_pos[3 * v], cam_pos[3 * v + 1], cam_pos[3 * v + 2]};
+  const float cq[4] = {cam_quat[4 * v], cam_quat[4 * v + 1], cam_quat[4 * v + 2], cam_quat[4 * v + 3]};
+  pose_to_view_core(v, position, orientation, scale, cp, cq, pos_c, quat_c, inv_scale, scale_v);
 }
 __global__ void pose_to_views_kernel(const float* __restrict__ position,
                                      const float* __restrict__ orientation,
@@ -122,22 +128,44 @@ __global__ void views_to_pose_grad_kernel(const float* __restrict__ orientation,
 // One wave: the 16 sums of view v -- dst[0..7] the renderer's (pos, quat, inv_scale: its tile partials in the order
 // pose_reduce_kernel adds them), dst[8..15] the sampler's (pos, quat through the Jacobian of q^ = q / |q|, scale: its
 // block partials as pc_loss_reduce_kernel) -- and, with pc_loss_part, the view's point-cloud loss to *pc_loss_out.
+// Every load whose address does not depend on another load is issued first (the rectangle, the length of the point
+// set, the quaternion), and the sampler's first 64 blocks are in flight together with the renderer's first 64 tiles:
+// three dependent round trips instead of six -- the sums, and the order of their additions, are the same.
 __device__ __forceinline__ void reduce_view_wave(
     int v, int lane, const ViewSetup* __restrict__ setup, const float* __restrict__ tile_part, int W, int H,
     int ntx_all, int nty_all, int tile_w_all, int tile_h_all, int stride, const float* __restrict__ pc_part,
     const float* __restrict__ pc_loss_part, const int* __restrict__ offsets, int n_single, int nblk,
     const float* __restrict__ quat_c, float* __restrict__ pc_loss_out, float* __restrict__ dst) {
-  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int x0 = 0, y0 = 0, x1 = 0, y1 = 0, big_flag = 0;
   if (tile_part) {
     const ViewSetup& s = setup[v];
+    x0 = s.rect[0]; y0 = s.rect[1]; x1 = s.rect[2]; y1 = s.rect[3];
+    big_flag = s.bwd_big;
+  }
+  int len = n_single;
+  float qx = 0.0f, qy = 0.0f, qz = 0.0f, qw = 1.0f;
+  if (pc_part) {
+    if (offsets) len = offsets[v + 1] - offsets[v];
+    qx = quat_c[4 * v]; qy = quat_c[4 * v + 1]; qz = quat_c[4 * v + 2]; qw = quat_c[4 * v + 3];
+  }
+  const int nb = pc_part ? (len + kSamplerPts - 1) / kSamplerPts : 0;
+  // the sampler's first block of this lane
+  float4 pa0 = make_float4(0, 0, 0, 0), pc0 = pa0;
+  float sl0 = 0.0f;
+  if (lane < nb) {
+    const float4* p = reinterpret_cast<const float4*>(pc_part + ((size_t)v * nblk + lane) * 8);
+    pa0 = p[0]; pc0 = p[1];
+    if (pc_loss_part) sl0 = pc_loss_part[(size_t)v * nblk + lane];
+  }
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (tile_part) {
     // the view's tiling, as pose_reduce_kernel (render.hip): a batch backward picks it per view
     int ntx = ntx_all, nty = nty_all, tile_w = tile_w_all, tile_h = tile_h_all;
     size_t first = (size_t)v * ntx * nty;
-    const bool big = stride > 0 && s.bwd_big;
+    const bool big = stride > 0 && big_flag;
     if (stride > 0) first = (size_t)v * stride;
     if (big) { tile_w = kBwdBigTile.w(); tile_h = kBwdBigTile.h(); }
     (void)nty;
-    const int x0 = s.rect[0], y0 = s.rect[1], x1 = s.rect[2], y1 = s.rect[3];
     if (x1 > x0 && y1 > y0) {
       const int tx0 = x0 / tile_w, tx1 = (x1 - 1) / tile_w, ty0 = y0 / tile_h, ty1 = (y1 - 1) / tile_h;
       const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1);
@@ -162,15 +190,18 @@ __device__ __forceinline__ void reduce_view_wave(
   }
   float pcs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (pc_part) {
-    const int len = offsets ? offsets[v + 1] - offsets[v] : n_single;
-    const int nb = (len + kSamplerPts - 1) / kSamplerPts;
     if (pc_loss_part) {
       float sa = 0.0f;
-      for (int i = lane; i < nb; i += 64) sa += pc_loss_part[(size_t)v * nblk + i];
+      if (lane < nb) sa += sl0;
+      for (int i = lane + 64; i < nb; i += 64) sa += pc_loss_part[(size_t)v * nblk + i];
       sa = wave_sum(sa);
       if (lane == 0) *pc_loss_out = sa / (float)len;
     }
-    for (int i = lane; i < nb; i += 64) {
+    if (lane < nb) {
+      pcs[0] += pa0.x; pcs[1] += pa0.y; pcs[2] += pa0.z; pcs[3] += pa0.w;
+      pcs[4] += pc0.x; pcs[5] += pc0.y; pcs[6] += pc0.z; pcs[7] += pc0.w;
+    }
+    for (int i = lane + 64; i < nb; i += 64) {
       const float4* p = reinterpret_cast<const float4*>(pc_part + ((size_t)v * nblk + i) * 8);
       const float4 a = p[0], c = p[1];
       pcs[0] += a.x; pcs[1] += a.y; pcs[2] += a.z; pcs[3] += a.w;
@@ -179,7 +210,7 @@ __device__ __forceinline__ void reduce_view_wave(
 #pragma unroll
     for (int k = 0; k < 8; ++k) pcs[k] = wave_sum(pcs[k]);
     // Jacobian of q^ = q / |q| on the view's quaternion, as pc_loss_reduce_kernel
-    const float x = quat_c[4 * v], y = quat_c[4 * v + 1], z = quat_c[4 * v + 2], w = quat_c[4 * v + 3];
+    const float x = qx, y = qy, z = qz, w = qw;
     const float inv_norm = 1.0f / sqrtf(x * x + y * y + z * z + w * w);
     const float qn[4] = {x * inv_norm, y * inv_norm, z * inv_norm, w * inv_norm};
     const float dq = qn[0] * pcs[3] + qn[1] * pcs[4] + qn[2] * pcs[5] + qn[3] * pcs[6];
@@ -197,10 +228,10 @@ __device__ __forceinline__ void reduce_view_wave(
 // One thread: the V views' 16 sums (rec + v * rec_stride; [0..7] renderer, [8..15] sampler) back to the world-frame
 // parameters -- the reverse of pose_to_view -- and through the normalisation of the orientation.  Views are added
 // in index order: the result depends on the records alone, not on where they were computed.
-__device__ __forceinline__ void pose_chain(const float* __restrict__ orientation, const float* __restrict__ scale,
-                                           const float* __restrict__ cam_quat, int V, const float* rec,
-                                           int rec_stride, bool use_a, bool use_b, float* __restrict__ g_position,
-                                           float* __restrict__ g_orientation, float* __restrict__ g_scale) {
+__device__ __forceinline__ void pose_chain(const float* orientation, const float* scale,
+                                           const float* cam_quat, int V, const float* rec,
+                                           int rec_stride, bool use_a, bool use_b, float* g_position,
+                                           float* g_orientation, float* g_scale) {
   const float q[4] = {orientation[0], orientation[1], orientation[2], orientation[3]};
   const float inv_n = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   const float nq[4] = {q[0] * inv_n, q[1] * inv_n, q[2] * inv_n, q[3] * inv_n};
@@ -234,10 +265,10 @@ __device__ __forceinline__ void pose_chain(const float* __restrict__ orientation
 // pose_chain by the whole workgroup, for view lists of any length (the sharded loop's tail: V is the number of views
 // of ALL ranks): thread t adds the views t, t + 256, ... in that order, the 256 partial sums meet in a fixed tree.  The
 // result depends on the records and on V alone -- not on which rank computed which record.  Every thread calls it.
-__device__ __forceinline__ void pose_chain_block(const float* __restrict__ orientation, const float* __restrict__ scale,
+__device__ __forceinline__ void pose_chain_block(const float* orientation, const float* scale,
                                                  const float* __restrict__ cam_quat, int V, const float* rec,
-                                                 int rec_stride, float* __restrict__ g_position,
-                                                 float* __restrict__ g_orientation, float* __restrict__ g_scale) {
+                                                 int rec_stride, float* g_position,
+                                                 float* g_orientation, float* g_scale) {
   __shared__ float part[8][256];
   const int tid = threadIdx.x;
   float gp[3] = {0, 0, 0}, gn[4] = {0, 0, 0, 0}, gs = 0.0f;
@@ -282,23 +313,31 @@ __device__ __forceinline__ void pose_chain_block(const float* __restrict__ orien
   g_scale[0] = part[7][0];
 }
 
+// first_wave .. 3 are the waves that reduce (the tail keeps wave 0 for the decoder's Linear stack meanwhile); which wave
+// reduces which view changes nothing.  params_lds (or NULL): a copy of the parameters in LDS the caller has made.
 __device__ __forceinline__ void deferred_chain(
-    const float* __restrict__ orientation, const float* __restrict__ scale, const float* __restrict__ cam_quat,
+    const float* orientation, const float* scale, const float* __restrict__ cam_quat,
     int V, const ViewSetup* __restrict__ setup, const float* __restrict__ tile_part, int W, int H, int ntx_all,
     int nty_all, int tile_w_all, int tile_h_all, int stride, const float* __restrict__ pc_part,
     const float* __restrict__ pc_loss_part,
     const int* __restrict__ offsets, int n_single, int nblk, const float* __restrict__ quat_c,
-    float* __restrict__ pc_loss, float* __restrict__ g_position, float* __restrict__ g_orientation,
-    float* __restrict__ g_scale) {
+    float* __restrict__ pc_loss, float* g_position, float* g_orientation, float* g_scale, int first_wave = 0) {
   __shared__ float view_g[kDeferredMaxViews][16];  // [0..7] renderer: pos, quat, inv_scale; [8..15] sampler
+  __shared__ float view_cq[kDeferredMaxViews][4];  // the views' camera orientations (the chain's thread reads them here)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int v = wave; v < V; v += 4)
-    reduce_view_wave(v, lane, setup, tile_part, W, H, ntx_all, nty_all, tile_w_all, tile_h_all, stride, pc_part,
-                     pc_loss_part, offsets, n_single, nblk, quat_c, pc_loss ? pc_loss + v : nullptr, view_g[v]);
+  if (wave >= first_wave) {
+    const int n_waves = 4 - first_wave;
+    for (int v = wave - first_wave; v < V; v += n_waves) {
+      const float cq = lane < 4 ? cam_quat[4 * v + lane] : 0.0f;
+      reduce_view_wave(v, lane, setup, tile_part, W, H, ntx_all, nty_all, tile_w_all, tile_h_all, stride, pc_part,
+                       pc_loss_part, offsets, n_single, nblk, quat_c, pc_loss ? pc_loss + v : nullptr, view_g[v]);
+      if (lane < 4) view_cq[v][lane] = cq;
+    }
+  }
   __syncthreads();
   if (threadIdx.x != 0) return;   // (callers that go on afterwards: every thread reaches the barrier above)
-  pose_chain(orientation, scale, cam_quat, V, &view_g[0][0], 16, tile_part != nullptr, pc_part != nullptr, g_position,
-             g_orientation, g_scale);
+  pose_chain(orientation, scale, &view_cq[0][0], V, &view_g[0][0], 16, tile_part != nullptr, pc_part != nullptr,
+             g_position, g_orientation, g_scale);
 }
 
 // The sharded loop's exchange record of one view (include/sdfr.h, sdfr_loop_view_records): one wave per view of the
@@ -349,9 +388,8 @@ __global__ __launch_bounds__(256) void views_to_pose_grad_deferred_kernel(
 // ---------------------------------------------------------------------------------------------
 // r = q (s,0) conj(q) = (w^2 - u.u) s + 2 (u.s) u + 2 w (u x s);  loss = weight |r - t|;  the gradient
 // w.r.t. q is ADDED to g_orientation (the image terms have been written there before).
-__device__ __forceinline__ void point_constraint_one(const float* __restrict__ q, const float* __restrict__ src,
-                                                     const float* __restrict__ tgt, float weight,
-                                                     float* __restrict__ loss, float* __restrict__ g_orientation) {
+__device__ __forceinline__ void point_constraint_one(const float* q, const float* src, const float* tgt, float weight,
+                                                     float* __restrict__ loss, float* g_orientation) {
   const V3 u = mk(q[0], q[1], q[2]), s = mk(src[0], src[1], src[2]);
   const float w = q[3];
   const float us = dot(u, s), uu = dot(u, u);
@@ -594,32 +632,51 @@ __global__ void add_inplace_kernel(float* __restrict__ a, const float* __restric
 // One thread per scalar of the four groups laid out [position 3 | orientation 4 | scale 1 | latent L];
 // `step` lives on the device so that a captured graph advances it on every replay.
 // (every thread of the workgroup calls it: two barriers inside)
+// (the core takes thread i's parameter, moments and the step count by value and returns the new ones: the loop's tail
+// loads the old ones at its very start, long before the gradients exist, and stores the new ones at its very end --
+// a global store in front of a workgroup barrier is a store round trip the barrier waits for.  Optionally leaves a
+// copy of the new parameters in LDS.)
+__device__ __forceinline__ void adam_step_core(const float* grads, int n, float lr_pos, float lr_quat, float lr_scale,
+                                               float lr_latent, int update_latent, float p_old, float m_old,
+                                               float v_old, int step_old, float* params_lds, float& p_out,
+                                               float& m_out, float& v_out) {
+  __shared__ float qnorm2;
+  const int i = threadIdx.x;
+  const int t = step_old + 1;
+  if (i == 0) qnorm2 = 0.0f;
+  __syncthreads();
+  float p = 0.0f;
+  m_out = m_old;
+  v_out = v_old;
+  if (i < n && (i < 8 || update_latent)) {
+    const float lr = i < 3 ? lr_pos : (i < 7 ? lr_quat : (i < 8 ? lr_scale : lr_latent));
+    const float g = grads[i];
+    const float mi = 0.9f * m_old + 0.1f * g;
+    const float vi = 0.999f * v_old + 0.001f * g * g;
+    m_out = mi;
+    v_out = vi;
+    const float bc1 = 1.0f - powf(0.9f, (float)t), bc2 = 1.0f - powf(0.999f, (float)t);
+    p = p_old - (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + 1e-8f);
+    if (i >= 3 && i < 7) atomicAdd(&qnorm2, p * p);
+  } else if (i < n) {
+    p = p_old;
+  }
+  __syncthreads();
+  p_out = (i >= 3 && i < 7) ? p / sqrtf(qnorm2) : p;  // :462 renormalise the quaternion
+  if (i < n && params_lds) params_lds[i] = p_out;
+}
 __device__ __forceinline__ void adam_step_block(float* __restrict__ params, const float* __restrict__ grads,
                                                 float* __restrict__ m, float* __restrict__ v,
                                                 int* __restrict__ step, int n, float lr_pos, float lr_quat,
                                                 float lr_scale, float lr_latent, int update_latent) {
-  __shared__ float qnorm2;
   const int i = threadIdx.x;
-  const int t = step[0] + 1;
-  if (i == 0) qnorm2 = 0.0f;
-  __syncthreads();
-  float p = 0.0f;
-  if (i < n && (i < 8 || update_latent)) {
-    const float lr = i < 3 ? lr_pos : (i < 7 ? lr_quat : (i < 8 ? lr_scale : lr_latent));
-    const float g = grads[i];
-    const float mi = 0.9f * m[i] + 0.1f * g;
-    const float vi = 0.999f * v[i] + 0.001f * g * g;
-    m[i] = mi;
-    v[i] = vi;
-    const float bc1 = 1.0f - powf(0.9f, (float)t), bc2 = 1.0f - powf(0.999f, (float)t);
-    p = params[i] - (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + 1e-8f);
-    if (i >= 3 && i < 7) atomicAdd(&qnorm2, p * p);
-  } else if (i < n) {
-    p = params[i];
-  }
-  __syncthreads();
-  if (i < n) params[i] = (i >= 3 && i < 7) ? p / sqrtf(qnorm2) : p;  // :462 renormalise the quaternion
-  if (i == 0) step[0] = t;
+  const bool mine = i < n;
+  const int step_old = step[0];
+  float p, mi, vi;
+  adam_step_core(grads, n, lr_pos, lr_quat, lr_scale, lr_latent, update_latent, mine ? params[i] : 0.0f,
+                 mine ? m[i] : 0.0f, mine ? v[i] : 0.0f, step_old, nullptr, p, mi, vi);
+  if (mine) { params[i] = p; m[i] = mi; v[i] = vi; }
+  if (i == 0) step[0] = step_old + 1;
 }
 __global__ void adam_step_kernel(float* __restrict__ params, const float* __restrict__ grads,
                                  float* __restrict__ m, float* __restrict__ v,
@@ -644,29 +701,84 @@ struct LoopTailArgs {
   // records != NULL (sdfr_loop_tail_records): the chain runs over the V_all exchanged view records instead of this
   // rank's partials; cam_pos / cam_quat / V above are then this rank's shard (the next iteration's view poses)
   const float* records; int V_all; const float* cam_quat_all;
+  int fc_one_wave;   // the Linear stack is narrow enough for fc_stack_backward_one_wave (decoder_fc_one_wave)
 };
 static_assert(kFcBlock == 256, "the tail's workgroup runs the decoder's Linear-stack backward");
+#ifdef SDFR_TAIL_STAMPS   // timing experiment (tools/microbench): where the tail's time goes, in 10 ns ticks
+__device__ unsigned long long g_tail_stamps[8];
+#define SDFR_STAMP(k) do { if (threadIdx.x == 0) g_tail_stamps[k] = wall_clock64(); } while (0)
+#else
+#define SDFR_STAMP(k) do { } while (0)
+#endif
+// A dependent chain by construction -- what it pays is memory round trips (~0.5 us each), not arithmetic: 14.7 us as
+// first written (tools/microbench/tail_stamps.py: 8.0 us in the Linear stack's backward, 4.6 us in the per-view
+// reductions and the chain, 1.4 us Adam, 0.6 us the next poses).  Hence (a) everything that depends on nothing
+// computed here is loaded FIRST (parameters, Adam's moments and step count, the first 256 views' camera poses, the
+// constraint's points); (b) a narrow Linear stack is one wave's work out of LDS (fc_stack_backward_one_wave), and the
+// other three waves reduce the views meanwhile; (c) gradients and the updated parameters pass between the stages in
+// LDS (g_l, p_new) instead of through global memory.  Same arithmetic, same order: the numbers do not change.
 __global__ __launch_bounds__(256) void loop_tail_kernel(LoopTailArgs a) {
-  float* g = a.grads;
-  if (a.t_mid) {   // d loss / d latent (grads[8 ...]) from the gradient w.r.t. the wide Linear layer's input
-    fc_stack_backward_sample(a.dec_params, a.fc, a.params + 8, a.t_mid, g + 8);
+  __shared__ float g_l[256];      // the gradients, laid out as a.grads (copied there at the end)
+  __shared__ float p_cur[256];    // the parameters of this iteration ...
+  __shared__ float p_new[256];    // ... and after the Adam step
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  SDFR_STAMP(0);
+  const bool mine = tid < a.n;
+  const float p_old = mine ? a.params[tid] : 0.0f, m_old = mine ? a.m[tid] : 0.0f, v_old = mine ? a.v[tid] : 0.0f;
+  const int step_old = a.step[0];
+  const float g_given = (mine && tid >= 8 && !a.t_mid) ? a.grads[tid] : 0.0f;   // the latent's gradient is the caller's
+  float cp[3] = {0, 0, 0}, cq[4] = {0, 0, 0, 1};
+  if (tid < a.V) {
+    cp[0] = a.cam_pos[3 * tid]; cp[1] = a.cam_pos[3 * tid + 1]; cp[2] = a.cam_pos[3 * tid + 2];
+    cq[0] = a.cam_quat[4 * tid]; cq[1] = a.cam_quat[4 * tid + 1]; cq[2] = a.cam_quat[4 * tid + 2];
+    cq[3] = a.cam_quat[4 * tid + 3];
+  }
+  float con[6] = {0, 0, 0, 0, 0, 0};
+  if (tid == 0 && a.con_source) {
+    for (int k = 0; k < 3; ++k) { con[k] = a.con_source[k]; con[3 + k] = a.con_target[k]; }
+  }
+  const bool fc_wave = a.t_mid && a.fc_one_wave;
+  if (a.t_mid && !fc_wave) {   // d loss / d latent (g[8 ...]) from the gradient w.r.t. the wide Linear layer's input
+    fc_stack_backward_sample(a.dec_params, a.fc, a.params + 8, a.t_mid, g_l + 8);
     __syncthreads();
   }
+  if (fc_wave && wave == 0) fc_stack_backward_one_wave(a.dec_params, a.fc, a.params + 8, a.t_mid, g_l + 8, lane);
+  // (only now: an LDS store of a loaded value waits for the load, and the Linear stack's loads should not queue
+  // behind that wait)
+  if (mine) p_cur[tid] = p_old;
+  if (mine && tid >= 8 && !a.t_mid) g_l[tid] = g_given;
+  SDFR_STAMP(1);
   if (a.records) {
-    pose_chain_block(a.params + 3, a.params + 7, a.cam_quat_all, a.V_all, a.records, kViewRecord, g, g + 3, g + 7);
+    pose_chain_block(a.params + 3, a.params + 7, a.cam_quat_all, a.V_all, a.records, kViewRecord, g_l, g_l + 3,
+                     g_l + 7);
   } else {
-    deferred_chain(a.params + 3, a.params + 7, a.cam_quat, a.V, a.setup, a.tile_part, a.W, a.H, a.ntx, a.nty,
+    deferred_chain(p_cur + 3, p_cur + 7, a.cam_quat, a.V, a.setup, a.tile_part, a.W, a.H, a.ntx, a.nty,
                    a.tile_w, a.tile_h, a.stride, a.pc_part, a.pc_loss_part, a.offsets, a.n_single, a.nblk, a.quat_c,
-                   a.pc_loss, g, g + 3, g + 7);
+                   a.pc_loss, g_l, g_l + 3, g_l + 7, fc_wave ? 1 : 0);
   }
-  if (threadIdx.x == 0 && a.con_source)
-    point_constraint_one(a.params + 3, a.con_source, a.con_target, a.con_weight, a.con_loss, g + 3);
-  __syncthreads();   // the pose gradients thread 0 wrote are visible to the Adam threads
-  adam_step_block(a.params, g, a.m, a.v, a.step, a.n, a.lr_pos, a.lr_quat, a.lr_scale, a.lr_latent, a.update_latent);
+  SDFR_STAMP(2);
+  if (tid == 0 && a.con_source)   // (p_cur: thread 0 has passed a barrier of the chain above since it was written)
+    point_constraint_one(p_cur + 3, con, con + 3, a.con_weight, a.con_loss, g_l + 3);
+  __syncthreads();   // the gradients (thread 0's, wave 0's) are visible to the Adam threads
+  SDFR_STAMP(3);
+  float p_i, m_i, v_i;
+  adam_step_core(g_l, a.n, a.lr_pos, a.lr_quat, a.lr_scale, a.lr_latent, a.update_latent, p_old, m_old, v_old,
+                 step_old, p_new, p_i, m_i, v_i);
   __syncthreads();   // the updated parameters are visible to the pose chain
-  for (int v = threadIdx.x; v < a.V; v += 256)
-    pose_to_view(v, a.params, a.params + 3, a.params + 7, a.cam_pos, a.cam_quat, a.pos_c, a.quat_c, a.inv_scale,
-                 a.scale_v);
+  SDFR_STAMP(4);
+  if (tid < a.V)
+    pose_to_view_core(tid, p_new, p_new + 3, p_new + 7, cp, cq, a.pos_c, a.quat_c, a.inv_scale, a.scale_v);
+  for (int v = tid + 256; v < a.V; v += 256)
+    pose_to_view(v, p_new, p_new + 3, p_new + 7, a.cam_pos, a.cam_quat, a.pos_c, a.quat_c, a.inv_scale, a.scale_v);
+  // the stores nothing in this launch waits for
+  if (mine) {
+    a.grads[tid] = g_l[tid];
+    a.params[tid] = p_i;
+    a.m[tid] = m_i;
+    a.v[tid] = v_i;
+  }
+  if (tid == 0) a.step[0] = step_old + 1;
+  SDFR_STAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -970,6 +1082,7 @@ extern "C" int sdfr_loop_tail(float* params, float* grads, float* exp_avg, float
   a.con_source = con_source; a.con_target = con_target; a.con_weight = con_weight; a.con_loss = con_loss;
   if (decoder) {
     decoder_fc_desc(decoder, &a.fc, &a.dec_params, nullptr);
+    a.fc_one_wave = decoder_fc_one_wave(a.fc) ? 1 : 0;
     if (a.fc.width[0] != n_params - 8)
       return fail(SDFR_E_INVALID, "%s: the decoder's latent has %d entries, the parameter vector %d", fn, a.fc.width[0],
                   n_params - 8);
@@ -1038,6 +1151,7 @@ extern "C" int sdfr_loop_tail_records(float* params, float* grads, float* exp_av
   a.con_source = con_source; a.con_target = con_target; a.con_weight = con_weight; a.con_loss = con_loss;
   if (decoder) {
     decoder_fc_desc(decoder, &a.fc, &a.dec_params, nullptr);
+    a.fc_one_wave = decoder_fc_one_wave(a.fc) ? 1 : 0;
     if (a.fc.width[0] != n_params - 8)
       return fail(SDFR_E_INVALID, "%s: the decoder's latent has %d entries, the parameter vector %d", fn, a.fc.width[0],
                   n_params - 8);
@@ -1324,3 +1438,9 @@ extern "C" int sdfr_depth_to_points_shifted(const float* depth, int V, int W, in
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }
+
+#ifdef SDFR_TAIL_STAMPS
+extern "C" __attribute__((visibility("default"))) int sdfr_debug_tail_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sdfr::g_tail_stamps), 8 * sizeof(unsigned long long));
+}
+#endif

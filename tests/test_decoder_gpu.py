@@ -393,3 +393,46 @@ def test_resize_folded_into_the_patch_load_is_bitwise_the_two_launches(mug):
         assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0, name
         assert torch.equal(outs[0], outs[1]), (name, N, (outs[0] - outs[1]).abs().max().item())
         assert torch.equal(grads[0], grads[1]), (name, N)
+
+
+def test_one_wave_linear_backward_is_bitwise_the_workgroup_form(mug):
+    """The VJP's last launch for a narrow Linear stack (the mug decoder's 8 -> 20 -> 50 in front of the wide layer):
+    one wave per latent with the weights staged in LDS (fc_stack_backward_wave_kernel) against the one-workgroup form
+    that reloads them layer by layer -- the same fmaf chains, so the latent gradients agree bit for bit -- and the
+    forward's stack of a single decode likewise (fc_stack_kernel<true>); a stack with a 70-wide layer does not qualify
+    and must not be affected by the switch."""
+    from sdfest_amd import SDFDecoder
+    from sdfest_amd._lib import lib
+    L = lib()
+    d, wts = mug
+    rng = np.random.default_rng(17)
+    wide = dict(volume=32, latent=5, batch=3, fc=[{"out": 70}, {"out": 33}, {"out": 3 * 6 ** 3}],
+                conv=[dict(in_size=6, in_channels=3, out_channels=4, kernel_size=3, relu=True),
+                      dict(in_size=16, in_channels=4, out_channels=1, kernel_size=3, relu=False)])
+    narrow = dict(volume=32, latent=64, batch=5, fc=[{"out": 64}, {"out": 7}, {"out": 64}, {"out": 2 * 5 ** 3}],
+                  conv=[dict(in_size=5, in_channels=2, out_channels=3, kernel_size=3, relu=True),
+                        dict(in_size=12, in_channels=3, out_channels=1, kernel_size=3, relu=False)])
+    cases = [("mug", mug_config(d), wts, 64, 8, n) for n in (1, 3, 40)]
+    for name, case in (("70 wide", wide), ("64 wide, four layers", narrow)):
+        cfg = {"latent_size": case["latent"], "tsdf": False, "sdf_size": case["volume"],
+               "decoder": {"fc_layers": case["fc"], "conv_layers": case["conv"]}}
+        cases.append((name, cfg, _random_state(rng, case), case["volume"], case["latent"], case["batch"]))
+    for name, cfg, state, volume, latent, N in cases:
+        dec = SDFDecoder.from_config(cfg, state, sdf_size=volume) if name != "mug" else SDFDecoder.from_config(cfg, state)
+        z_np = rng.normal(size=(N, latent)).astype(np.float32)
+        G = torch.tensor(rng.normal(size=(N, 1, volume, volume, volume)).astype(np.float32), device="cuda")
+        grads, outs = [], []
+        for on in (1, 0):
+            old = L.sdfr_debug_set_decoder_fc_one_wave(on)
+            try:
+                z = torch.tensor(z_np, device="cuda", requires_grad=True)
+                o = dec.decode(z)
+                o.backward(G)
+                torch.cuda.synchronize()
+                grads.append(z.grad.clone())
+                outs.append(o.detach().clone())
+            finally:
+                L.sdfr_debug_set_decoder_fc_one_wave(old)
+        assert torch.isfinite(grads[0]).all() and grads[0].abs().max() > 0, name
+        assert torch.equal(outs[0], outs[1]), (name, N, (outs[0] - outs[1]).abs().max().item())   # (the forward's stack too)
+        assert torch.equal(grads[0], grads[1]), (name, N, (grads[0] - grads[1]).abs().max().item())

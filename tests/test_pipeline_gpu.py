@@ -352,3 +352,69 @@ def test_empty_overlap_view_gives_nan_loss_and_finite_steps(mug_decoder):
             assert torch.isfinite(a[k]).all() and torch.isfinite(b[k]).all()
             assert torch.allclose(a[k].reshape(-1), b[k].reshape(-1), rtol=0, atol=2e-4), k
     assert (h1[-1]["position"] - p0).abs().max() > 1e-3       # and the first view did move the estimate
+
+
+@pytest.mark.parametrize("views", [1, 9])
+def test_one_wave_linear_backward_in_the_tail_is_bitwise_the_workgroup_form(mug_decoder, views):
+    """The tail's backward of the mug decoder's narrow Linear stack (8 -> 20 -> 50) as ONE wave out of LDS, the other
+    waves reducing the views meanwhile (fc_stack_backward_one_wave), against the one-workgroup form of wider stacks
+    (sdfr_debug_set_decoder_fc_one_wave(0)): same fmaf chains in the same order.  Nine views (records form: the tail
+    works from the records) in the deterministic d/dSDF mode -- no float atomics anywhere on the way --: a
+    shape-optimising run agrees bit for bit, every iteration, eager and replayed.  One view (the tail reduces the view
+    itself, three waves beside the Linear stack's one): the float atomics of d/dSDF leave their ~1e-7 of noise, as
+    between any two runs of that form; tests/test_decoder_gpu.py compares the two Linear backward forms bit for bit."""
+    from sdfest_amd import Camera, render_depth_gpu
+    from sdfest_amd.differentiable_renderer import SDF_GRAD_DETERMINISTIC
+    from sdfest_amd.pipeline import FusedRenderAndCompare
+    from sdfest_amd._lib import lib
+    L = lib()
+    dec, d = mug_decoder
+    cam = Camera(160, 120, 150.0, 150.0, 80.0, 60.0, pixel_center=0.5)
+    dev = "cuda"
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device=dev)
+    rng = np.random.default_rng(21)
+    cp = rng.uniform(-0.04, 0.04, (views, 3)); cp[0] = 0.0
+    cqs = np.concatenate([rng.uniform(-0.04, 0.04, (views, 3)), np.ones((views, 1))], axis=1); cqs[0] = [0, 0, 0, 1]
+    cam_pos, cam_quat = t(cp), t(cqs / np.linalg.norm(cqs, axis=1, keepdims=True))
+    z_true = t(d["z"][9:10]) * 0.5
+    p_true = t([[0.02, -0.01, -0.5]]); s_true = t([0.055])
+    q_true = t([[0.2, 0.6, -0.15, 0.75]]); q_true = q_true / q_true.norm()
+    with torch.no_grad():
+        sdf = dec.decode(z_true)[0, 0]
+        obs = torch.stack([render_depth_gpu(sdf, *_to_camera(p_true[0], q_true[0], cam_pos[v], cam_quat[v]),
+                                            1 / s_true[0], None, None, None, 0.005, cam) for v in range(views)])
+    assert (obs > 0).sum(dim=(1, 2)).min() > 200
+    cfg = {"threshold": 0.005, "max_iterations": 6, "depth_weight": 1.0, "pc_weight": 3.0}
+    q0 = q_true + t([[0.05, -0.04, 0.03, 0.0]])
+    args = (p_true + 0.008, q0 / q0.norm(), t([0.058]), torch.zeros(1, 8, device=dev))
+    runs = {}
+    for on in (1, 0):
+        old = L.sdfr_debug_set_decoder_fc_one_wave(on)
+        try:
+            loop = FusedRenderAndCompare(dec, cam, cfg, obs.contiguous(), cam_pos, cam_quat,
+                                         sdf_grad_mode=SDF_GRAD_DETERMINISTIC if views >= 8 else 0)
+            assert loop.records_form == (views >= 8)
+            for use_graph in (False, True):
+                h = []
+                loop(*args, use_graph=use_graph, history=h)
+                torch.cuda.synchronize()
+                runs[(on, use_graph)] = h
+        finally:
+            L.sdfr_debug_set_decoder_fc_one_wave(old)
+    ref = runs[(0, False)]
+    assert (ref[-1]["latent"]).abs().max().item() > 1e-3 and (ref[-1]["position"] - args[0]).abs().max().item() > 1e-3
+    for key, h in runs.items():
+        for it in range(cfg["max_iterations"]):
+            for name in ("position", "orientation", "scale", "latent", "loss"):
+                if views >= 8:
+                    assert torch.equal(h[it][name], ref[it][name]), (key, it, name, h[it][name], ref[it][name])
+                else:
+                    err = (h[it][name] - ref[it][name]).abs().max().item()
+                    assert err <= 2e-6 * (it + 1) * max(1.0, ref[it][name].abs().max().item()), (key, it, name, err)
+
+
+def _to_camera(p, q, cam_p, cam_q):
+    """object pose in the frame of a camera at (cam_p, cam_q), as simple_setup.py:424-430"""
+    from sdfest_amd import pipeline as Q
+    qc = cam_q * torch.tensor([-1.0, -1.0, -1.0, 1.0], device=cam_q.device)
+    return Q.quaternion_apply(qc, p - cam_p), Q.quaternion_multiply(qc, q / q.norm())
