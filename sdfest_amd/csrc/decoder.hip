@@ -270,19 +270,25 @@ __device__ __forceinline__ int div_by(int x, unsigned m) { return m ? (int)__umu
 constexpr int kResizeTile = 8;
 // tensors up to this many elements take the launch-count-saving fused forms (single decodes, up to 8 latents)
 constexpr size_t kFewElements = (size_t)1 << 21;
-template <int LOG_NO>  // n_out = 1 << LOG_NO (16 .. 128): index splits are shifts, z is fixed per thread
-__global__ __launch_bounds__(256) void resize3_tiled_kernel(const float* __restrict__ in, int C, int n_in,
+// A workgroup takes its tile of `ipw` consecutive (sample, channel) volumes one after the other (round 4): the tables,
+// where each thread's staged elements come from and its x / y / z terms are formed ONCE -- they were two thirds of the
+// 36 VALU instructions per output of a kernel that is VALU-bound (0.98 busy, profiles/r04_decoder_batched_pmc.md) --
+// and the next volume's columns are in flight while this one is interpolated.   grid: (tiles^2, ceil(items / ipw))
+// VEC: a thread owns FOUR consecutive z of its columns -- 16-byte LDS reads and 16-byte stores (a wave's store is 1 KB of
+// one z-row instead of 256 bytes), a quarter of the address arithmetic; needs `out` 16-byte aligned.
+template <int LOG_NO, bool VEC>  // n_out = 1 << LOG_NO (16 .. 128): index splits are shifts, z is fixed per thread
+__global__ __launch_bounds__(256) void resize3_tiled_kernel(const float* __restrict__ in, int items, int ipw, int n_in,
                                                             int relu, float clamp, int max_cols,
                                                             float* __restrict__ out) {
   constexpr int n_out = 1 << LOG_NO, zmask = n_out - 1;
-  extern __shared__ float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   // per-axis interpolation tables of this tile: entries 0..7 x, 8..15 y (indices relative to a0 / b0)
   __shared__ int t_i0[16], t_i1[16], z_i0[n_out], z_i1[n_out];
   __shared__ float t_l[16], z_l[n_out];
   const int tid = threadIdx.x;
   constexpr int tiles = (n_out + kResizeTile - 1) / kResizeTile;
   const int tx0 = (blockIdx.x / tiles) * kResizeTile, ty0 = (blockIdx.x % tiles) * kResizeTile;
-  const int c = blockIdx.y, n = blockIdx.z;
+  const int it0 = (int)blockIdx.y * ipw, it1 = min(it0 + ipw, items);
   const float ratio = (float)n_in / (float)n_out;
   int a0, a1, b0, b1, t0, t1;
   float fl;
@@ -301,70 +307,110 @@ __global__ __launch_bounds__(256) void resize3_tiled_kernel(const float* __restr
     t_i0[j] = t0 - ((j < 8) ? a0 : b0); t_i1[j] = t1 - ((j < 8) ? a0 : b0); t_l[j] = fl;
   }
   float* col_in = lds;                            // [cols][n_in]
-  float* col_z = lds + (size_t)max_cols * n_in;   // [cols][n_out], interpolated along z
-  const float* src = in + ((size_t)n * C + c) * n_in * n_in * n_in;
-  {
-    // (the kernel is bound by its VALU instruction count -- 61 per output before this form, PMC: VALU 100 % busy --
-    // so: no integer divisions, nothing per output that is the same for a whole column or tile row)
-    const unsigned m_nin = magic_of(n_in), m_ry = magic_of(ry);
-    for (int i = tid; i < cols * n_in; i += 256) {
-      const int col = div_by(i, m_nin), z = i - col * n_in;
-      const int cx = div_by(col, m_ry), cy = col - cx * ry;
-      col_in[i] = src[((a0 + cx) * n_in + (b0 + cy)) * n_in + z];
-    }
-  }
-  __syncthreads();
-  const int z = tid & zmask;
-  {
-    const int z0 = z_i0[z], z1 = z_i1[z];
-    const float lz = z_l[z], wz0 = 1.0f - lz;
-    for (int col = tid >> LOG_NO; col < cols; col += 256 >> LOG_NO)
-      col_z[(col << LOG_NO) + z] = blend(wz0, col_in[col * n_in + z0], lz, col_in[col * n_in + z1]);
-  }
-  __syncthreads();
-  float* dst = out + ((size_t)n * C + c) * n_out * n_out * n_out;
-  // a thread's outputs: its z, the tile's x, and the y = sub, sub + P, ... of its wave part (P = 256 / n_out threads
-  // share a z): the y terms once per y, the x terms once per thread
-  constexpr int P = 256 >> LOG_NO, PY = P < kResizeTile ? P : kResizeTile;   // distinct y per pass
-  constexpr int XS = P / PY;                                                 // x handled side by side (P > 8)
-  const int sub = tid >> LOG_NO, jy0 = sub % PY, jx0 = sub / PY;
-  static_assert(n_out % kResizeTile == 0, "tiles are whole: no bounds checks below");
-  float lxs[kResizeTile / XS], wxs[kResizeTile / XS];
-  int r0s[kResizeTile / XS], r1s[kResizeTile / XS];
+  float* col_z = lds + (((size_t)max_cols * n_in + 3) & ~(size_t)3);   // [cols][n_out], interpolated along z (16-byte aligned)
+  const size_t vin = (size_t)n_in * n_in * n_in, vout = (size_t)1 << (3 * LOG_NO);
+  // where this thread's staged elements come from (the first kStage x 256 of the tile's cols * n_in; more: the loop below)
+  constexpr int kStage = 4;
+  const int total = cols * n_in;
+  const unsigned m_nin = magic_of(n_in), m_ry = magic_of(ry);
+  auto source = [&](int i) {
+    const int col = div_by(i, m_nin), z = i - col * n_in;
+    const int cx = div_by(col, m_ry), cy = col - cx * ry;
+    return ((a0 + cx) * n_in + (b0 + cy)) * n_in + z;
+  };
+  int soff[kStage];
 #pragma unroll
-  for (int i = 0; i < kResizeTile / XS; ++i) {
+  for (int j = 0; j < kStage; ++j) soff[j] = tid + 256 * j < total ? source(tid + 256 * j) : -1;
+  float pre[kStage];
+  auto fetch = [&](int it) {
+    const float* src = in + (size_t)it * vin;
+#pragma unroll
+    for (int j = 0; j < kStage; ++j) pre[j] = soff[j] >= 0 ? src[soff[j]] : 0.0f;
+  };
+  fetch(it0);
+  __syncthreads();   // tables
+  const int z = tid & zmask;
+  const int z0 = z_i0[z], z1 = z_i1[z];
+  const float lz = z_l[z], wz0 = 1.0f - lz;
+  // a thread's outputs: its z (VEC: its four z), the tile's x, and the y = sub, sub + P, ... of its wave part (P threads
+  // share a z): the y terms once per y, the x terms once per thread
+  constexpr int LOG_Q = VEC ? LOG_NO - 2 : LOG_NO;                           // threads per z-row
+  constexpr int P = 256 >> LOG_Q, PY = P < kResizeTile ? P : kResizeTile;    // distinct y per pass
+  constexpr int XS = P / PY;                                                 // x handled side by side (P > 8)
+  static_assert(XS <= kResizeTile, "a tile row per thread at least");
+  constexpr int NX = kResizeTile / XS, NY = kResizeTile / PY;
+  const int sub = tid >> LOG_Q, jy0 = sub % PY, jx0 = sub / PY;
+  const int ze = VEC ? (tid & ((1 << LOG_Q) - 1)) << 2 : z;                  // first z of the thread's outputs
+  static_assert(n_out % kResizeTile == 0, "tiles are whole: no bounds checks below");
+  float lxs[NX], wxs[NX];
+  int r0s[NX], r1s[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
     const int jx = jx0 + XS * i;
     lxs[i] = t_l[jx];
     wxs[i] = 1.0f - lxs[i];
     r0s[i] = (t_i0[jx] * ry) << LOG_NO;
     r1s[i] = (t_i1[jx] * ry) << LOG_NO;
   }
-  // (relu / clamp: workgroup-uniform branches around the whole store loop, not selects per output)
-  float* dst_tile = dst + ((size_t)tx0 << (2 * LOG_NO));
-  auto emit = [&](auto post) {
+  float lys[NY], wys[NY];
+  int c0s[NY], c1s[NY];
 #pragma unroll
-    for (int h = 0; h < kResizeTile / PY; ++h) {
-      const int jy = jy0 + PY * h;
-      const float ly = t_l[8 + jy], wy0 = 1.0f - ly;
-      const float* cz0 = col_z + (t_i0[8 + jy] << LOG_NO) + z;
-      const float* cz1 = col_z + (t_i1[8 + jy] << LOG_NO) + z;
-      const unsigned at = ((unsigned)(ty0 + jy) << LOG_NO) + (unsigned)z;   // 32-bit offsets from a uniform base
+  for (int h = 0; h < NY; ++h) {
+    const int jy = jy0 + PY * h;
+    lys[h] = t_l[8 + jy];
+    wys[h] = 1.0f - lys[h];
+    c0s[h] = (t_i0[8 + jy] << LOG_NO) + ze;
+    c1s[h] = (t_i1[8 + jy] << LOG_NO) + ze;
+  }
+  for (int it = it0; it < it1; ++it) {
 #pragma unroll
-      for (int i = 0; i < kResizeTile / XS; ++i) {
-        const unsigned jx = (unsigned)(jx0 + XS * i);
-        const float v = blend(wxs[i], blend(wy0, cz0[r0s[i]], ly, cz1[r0s[i]]), lxs[i],
-                              blend(wy0, cz0[r1s[i]], ly, cz1[r1s[i]]));
-        dst_tile[at + (jx << (2 * LOG_NO))] = post(v);
-      }
+    for (int j = 0; j < kStage; ++j)
+      if (soff[j] >= 0) col_in[tid + 256 * j] = pre[j];
+    if (total > 256 * kStage) {
+      const float* src = in + (size_t)it * vin;
+      for (int i = tid + 256 * kStage; i < total; i += 256) col_in[i] = src[source(i)];
     }
-  };
-  if (clamp > 0.0f) {
-    if (relu) emit([clamp](float v) { return fminf(fmaxf(fmaxf(v, 0.0f), -clamp), clamp); });
-    else emit([clamp](float v) { return fminf(fmaxf(v, -clamp), clamp); });
-  } else if (relu) {
-    emit([](float v) { return fmaxf(v, 0.0f); });
-  } else {
-    emit([](float v) { return v; });
+    __syncthreads();   // (and: every thread has left the previous volume's store loop, which reads col_z)
+    if (it + 1 < it1) fetch(it + 1);
+    for (int col = tid >> LOG_NO; col < cols; col += 256 >> LOG_NO)
+      col_z[(col << LOG_NO) + z] = blend(wz0, col_in[col * n_in + z0], lz, col_in[col * n_in + z1]);
+    __syncthreads();
+    // (relu / clamp: workgroup-uniform branches around the whole store loop, not selects per output)
+    float* dst_tile = out + (size_t)it * vout + ((size_t)tx0 << (2 * LOG_NO));
+    auto emit = [&](auto post) {
+#pragma unroll
+      for (int h = 0; h < NY; ++h) {
+        const float ly = lys[h], wy0 = wys[h];
+        const float* cz0 = col_z + c0s[h];
+        const float* cz1 = col_z + c1s[h];
+        const unsigned at = ((unsigned)(ty0 + jy0 + PY * h) << LOG_NO) + (unsigned)ze;   // 32-bit offsets from a uniform base
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          const unsigned jx = (unsigned)(jx0 + XS * i);
+          if (VEC) {
+            const f32x4 q00 = *reinterpret_cast<const f32x4*>(cz0 + r0s[i]), q01 = *reinterpret_cast<const f32x4*>(cz1 + r0s[i]);
+            const f32x4 q10 = *reinterpret_cast<const f32x4*>(cz0 + r1s[i]), q11 = *reinterpret_cast<const f32x4*>(cz1 + r1s[i]);
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              v[k] = post(blend(wxs[i], blend(wy0, q00[k], ly, q01[k]), lxs[i], blend(wy0, q10[k], ly, q11[k])));
+            *reinterpret_cast<f32x4*>(dst_tile + at + (jx << (2 * LOG_NO))) = v;
+          } else {
+            const float v = blend(wxs[i], blend(wy0, cz0[r0s[i]], ly, cz1[r0s[i]]), lxs[i],
+                                  blend(wy0, cz0[r1s[i]], ly, cz1[r1s[i]]));
+            dst_tile[at + (jx << (2 * LOG_NO))] = post(v);
+          }
+        }
+      }
+    };
+    if (clamp > 0.0f) {
+      if (relu) emit([clamp](float v) { return fminf(fmaxf(fmaxf(v, 0.0f), -clamp), clamp); });
+      else emit([clamp](float v) { return fminf(fmaxf(v, -clamp), clamp); });
+    } else if (relu) {
+      emit([](float v) { return fmaxf(v, 0.0f); });
+    } else {
+      emit([](float v) { return v; });
+    }
   }
 }
 
@@ -2066,13 +2112,26 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
       first_last(std::min(t0 + kResizeTile, no) - 1, tmp, hi);
       max_r = std::max(max_r, hi - lo + 1);
     }
-    const size_t lds = (size_t)max_r * max_r * (ni + no) * sizeof(float);
+    const size_t lds = ((size_t)max_r * max_r * (ni + no) + 3) * sizeof(float);   // (+3: the second array starts 16-byte aligned)
     const int tiles = (no + kResizeTile - 1) / kResizeTile;
     const bool pow2 = no >= 16 && no <= 128 && (no & (no - 1)) == 0;
     // (a single decode has too few tiles to fill the chip: the gather kernel is faster there)
-    if (pow2 && ni <= no && lds <= 48 * 1024 && C <= 65535 && (long long)tiles * tiles * C * N >= 2048) {
-      const dim3 grid(tiles * tiles, C, N);
-#define SDFR_RESIZE_T(LOG) hipLaunchKernelGGL((resize3_tiled_kernel<LOG>), grid, dim3(256), lds, st, src, C, ni, relu, clamp, max_r * max_r, dst)
+    const long long tile_items = (long long)tiles * tiles * C * N;
+    if (pow2 && ni <= no && lds <= 48 * 1024 && (long long)C * N < (1ll << 30) && tile_items >= 2048) {
+      // volumes per workgroup: as many as still leave ~8 workgroups per CU
+      const int items = C * N;
+      // (256 mug latents, us: 14 -> 32 x 8 channels 68.6 / 52.9 / 55.4 / 53.3 at 1 / 2 / 4 / 8 volumes per workgroup,
+      // 30 -> 64 x 1 channel 68.5 / 60.3 / 55.8 / 63.6 -- profiles/r04_decoder_resize_ipw.txt; before this form 70.8 / 66.7)
+      const int ipw = std::max((int)std::min<long long>(4, tile_items / 2048), (items + 65534) / 65535);
+      const dim3 grid(tiles * tiles, (items + ipw - 1) / ipw, 1);
+      const bool vec = ((uintptr_t)dst & 15) == 0;
+#define SDFR_RESIZE_T(LOG)                                                                                              \
+  do {                                                                                                                  \
+    if (vec) hipLaunchKernelGGL((resize3_tiled_kernel<LOG, true>), grid, dim3(256), lds, st, src, items, ipw, ni, relu, \
+                                clamp, max_r * max_r, dst);                                                             \
+    else hipLaunchKernelGGL((resize3_tiled_kernel<LOG, false>), grid, dim3(256), lds, st, src, items, ipw, ni, relu,    \
+                            clamp, max_r * max_r, dst);                                                                 \
+  } while (0)
       if (no == 16) SDFR_RESIZE_T(4); else if (no == 32) SDFR_RESIZE_T(5); else if (no == 64) SDFR_RESIZE_T(6); else SDFR_RESIZE_T(7);
 #undef SDFR_RESIZE_T
       return;
