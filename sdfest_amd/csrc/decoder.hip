@@ -745,6 +745,47 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
 }
 
 
+// The direct convolutions' epilogue: bias, ReLU, store of a thread's ZR x COUT outputs -- and (mix_out != NULL) the
+// 1x1x1 layer that follows, applied while they are in registers (see conv3d_direct_kernel).
+template <int COUT, int ZR>
+__device__ __forceinline__ void direct_epilogue(float (&acc)[ZR][COUT], const float* __restrict__ bias, int relu,
+                                                float* __restrict__ out, const float* __restrict__ mix_w,
+                                                const float* __restrict__ mix_b, int mix_co, float* __restrict__ mix_out,
+                                                int nb, size_t mv, int x, int y, int z0, int m) {
+  if (x < m && y < m && z0 < m) {
+    const size_t col = ((size_t)x * m + y) * m + z0;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+      const float bv = bias[co];
+#pragma unroll
+      for (int z = 0; z < ZR; ++z) {
+        float r = acc[z][co] + bv;
+        if (relu) r = fmaxf(r, 0.0f);
+        acc[z][co] = r;
+      }
+      if (out) {
+        float* dst = out + ((size_t)nb * COUT + co) * mv + col;
+#pragma unroll
+        for (int z = 0; z < ZR; ++z)
+          if (z0 + z < m) dst[z] = acc[z][co];
+      }
+    }
+    if (mix_out) {
+      for (int c2 = 0; c2 < mix_co; ++c2) {
+        float* dst = mix_out + ((size_t)nb * mix_co + c2) * mv + col;
+        const float b2 = mix_b[c2];
+#pragma unroll
+        for (int z = 0; z < ZR; ++z) {
+          float a2 = 0.0f;
+#pragma unroll
+          for (int co = 0; co < COUT; ++co) a2 = fmaf(acc[z][co], mix_w[co * 16 + c2], a2);
+          if (z0 + z < m) dst[z] = a2 + b2;
+        }
+      }
+    }
+  }
+}
+
 // Batched 3x3x3 convolution on the vector ALUs.  For the decoder's narrow layers (4 .. 16 output
 // channels) the matrix cores are the wrong tool: a 16-column MFMA tile is mostly padding, and both
 // MFMA forms above are bound by how they fetch their operands (560 us gather-bound, 772 us LDS-staged
@@ -759,8 +800,14 @@ __global__ __launch_bounds__(256) void conv3d_mfma_kernel(
 template <int COUT, bool VEC4>
 __global__ __launch_bounds__(256) void conv3d_direct_kernel(
     const float* __restrict__ in, const float* __restrict__ wd, const float* __restrict__ bias,
-    float* __restrict__ out, int Cin, int n, int pz, int m, int relu, int TX, int TY, int ZC, int CK) {
+    float* __restrict__ out, int Cin, int n, int pz, int m, int relu, int TX, int TY, int ZC, int CK,
+    const float* __restrict__ mix_w, const float* __restrict__ mix_b, int mix_co, float* __restrict__ mix_out) {
   // (pz: floats between z-rows of `in`, >= n -- the padded tensors of the backward pass have their rows 16 bytes apart)
+  // mix_out != NULL: the 1x1x1 layer that FOLLOWS this one (mix_co <= 4 output channels, its [Kpad][16] matrix and
+  // bias; no ReLU: it is a layer whose resize comes after it) is applied to this layer's outputs while they are in
+  // registers -- conv1x1_kernel's chain, channel by channel, "+ bias" last, so the same numbers -- and written to
+  // mix_out [N][mix_co][m^3]: the conv1x1 launch and its read of this layer's output are saved (22 us and 110 MB per
+  // 256 mug latents); `out` may then be NULL (a forward without a tape needs this layer's output nowhere else).
   constexpr int K = 3, ZR = 4;
   constexpr int kUnrollB = COUT >= 8 ? 1 : K;  // keep a step's weights within the scalar registers
   extern __shared__ float tile[];  // [CK][IX][IY][np4]
@@ -872,21 +919,7 @@ __global__ __launch_bounds__(256) void conv3d_direct_kernel(
       }
     }
   }
-  const int x = tx0 + lx, y = ty0 + ly;
-  if (x < m && y < m && z0 < m) {
-#pragma unroll
-    for (int co = 0; co < COUT; ++co) {
-      float* dst = out + ((size_t)nb * COUT + co) * mv + ((size_t)x * m + y) * m + z0;
-      const float bv = bias[co];
-#pragma unroll
-      for (int z = 0; z < ZR; ++z)
-        if (z0 + z < m) {
-          float r = acc[z][co] + bv;
-          if (relu) r = fmaxf(r, 0.0f);
-          dst[z] = r;
-        }
-    }
-  }
+  direct_epilogue<COUT, ZR>(acc, bias, relu, out, mix_w, mix_b, mix_co, mix_out, nb, mv, tx0 + lx, ty0 + ly, z0, m);
 }
 
 // conv3d_direct_kernel with the trilinear resize IN FRONT of the layer folded into its patch load (round 4): the
@@ -1050,21 +1083,7 @@ __global__ __launch_bounds__(256) void conv3d_direct_up_kernel(
       }
     }
   }
-  const int x = tx0 + lx, y = ty0 + ly;
-  if (x < m && y < m && z0 < m) {
-#pragma unroll
-    for (int co = 0; co < COUT; ++co) {
-      float* dst = out + ((size_t)nb * COUT + co) * mv + ((size_t)x * m + y) * m + z0;
-      const float bv = bias[co];
-#pragma unroll
-      for (int z = 0; z < ZR; ++z)
-        if (z0 + z < m) {
-          float r = acc[z][co] + bv;
-          if (relu) r = fmaxf(r, 0.0f);
-          dst[z] = r;
-        }
-    }
-  }
+  direct_epilogue<COUT, ZR>(acc, bias, relu, out, nullptr, nullptr, 0, nullptr, nb, mv, tx0 + lx, ty0 + ly, z0, m);
 }
 
 // ---- backward (VJP to the latent; weights are constants) -------------------------------------
@@ -1676,8 +1695,10 @@ bool direct_ok(size_t w_off, int n, int m, int N, int* tx = nullptr, int* ty = n
   return true;
 }
 // pz: floats between the z-rows of src (n, or more: the padded tensors of the backward pass)
+// mix_*: the 1x1x1 layer applied in the epilogue (conv3d_direct_kernel), or mix_out == NULL
 bool launch_direct(const sdfr_decoder* d, size_t w_off, const float* src, const float* bias, float* dst,
-                   int cin, int cout, int n, int pz, int m, int relu, int N, hipStream_t st) {
+                   int cin, int cout, int n, int pz, int m, int relu, int N, hipStream_t st,
+                   const float* mix_w = nullptr, const float* mix_b = nullptr, int mix_co = 0, float* mix_out = nullptr) {
   int TX, TY, ZC;
   if (!direct_ok(w_off, n, m, N, &TX, &TY, &ZC)) return false;
   const int tiles = ((m + TX - 1) / TX) * ((m + TY - 1) / TY);
@@ -1692,9 +1713,9 @@ bool launch_direct(const sdfr_decoder* d, size_t w_off, const float* src, const 
   if (!vec4 && pz != n) return false;   // (the scalar-load form takes dense rows only; callers pad rows only to 16 bytes)
 #define SDFR_DIRECT(CO)                                                                                          \
   if (vec4) hipLaunchKernelGGL((conv3d_direct_kernel<CO, true>), grid, dim3(256), lds, st, src, w, bias, dst,   \
-                               cin, n, pz, m, relu, TX, TY, ZC, CK);                                            \
+                               cin, n, pz, m, relu, TX, TY, ZC, CK, mix_w, mix_b, mix_co, mix_out);             \
   else hipLaunchKernelGGL((conv3d_direct_kernel<CO, false>), grid, dim3(256), lds, st, src, w, bias, dst, cin,  \
-                          n, pz, m, relu, TX, TY, ZC, CK)
+                          n, pz, m, relu, TX, TY, ZC, CK, mix_w, mix_b, mix_co, mix_out)
   if (cout == 4) { SDFR_DIRECT(4); } else if (cout == 8) { SDFR_DIRECT(8); } else { SDFR_DIRECT(16); }
 #undef SDFR_DIRECT
   return true;
@@ -2140,6 +2161,7 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
     hipLaunchKernelGGL(resize3_kernel, dim3((unsigned)((cnt + 255) / 256), N), dim3(256), 0, st, src, C,
                        ni, no, relu, clamp, dst);
   };
+  bool premixed = false;   // the previous layer's epilogue has applied this (1x1x1) layer already: act_in is its output
   for (int l = 0; l < d->n_conv; ++l) {
     const bool swap = d->conv_swap[l] != 0, is_last = (l == d->n_conv - 1);
     const int k = d->conv_k[l], co_n = d->conv_cout[l], kpad = d->conv_kpad[l];
@@ -2196,7 +2218,24 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
       }
       continue;
     }
-    if (fused_up) {
+    // batches: a swapped 1x1x1 layer behind this one is applied in this layer's epilogue (conv3d_direct_kernel)
+    bool mix_next = false;
+    if (!swap && !fused_up && k == 3 && l + 1 < d->n_conv && d->conv_swap[l + 1] && d->conv_k[l + 1] == 1 &&
+        d->conv_cout[l + 1] <= 4 && d->fwd_direct_off[l] != 0) {
+      const int mo = d->conv_in_size[l + 1], co2 = d->conv_cout[l + 1];
+      const bool few_next = mo != m && (size_t)N * co2 * mo * mo * mo <= kFewElements;   // (takes resize3_mix_kernel)
+      float* act_dst = tape ? tape + (size_t)N * d->tape_conv_off[l] : nullptr;
+      mix_next = !few_next && launch_direct(d, d->fwd_direct_off[l], act_in, bs, act_dst, c, co_n, n, n, m, conv_relu,
+                                            N, st, d->d_params + d->conv_w_off[l + 1], d->d_params + d->conv_b_off[l + 1],
+                                            co2, buf[cur ^ 1]);
+      if (mix_next) conv_dst = buf[cur ^ 1];
+    }
+    if (premixed) {
+      conv_dst = const_cast<float*>(act_in);   // (nothing to launch, no buffer taken)
+      premixed = false;
+    } else if (mix_next) {
+      premixed = true;
+    } else if (fused_up) {
       // (launched above)
     } else if (k == 1 && co_n <= 4) {
       const int voxn = n * n * n;
