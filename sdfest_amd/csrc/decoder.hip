@@ -148,6 +148,8 @@ __global__ __launch_bounds__(kFcBlock) void fc_stack_kernel(const float* __restr
   if (o < wout) {
     const float* wt = params + d.w_off[l];  // transposed: [in][out]
     float acc = params[d.b_off[l] + o];
+    // (sixteen of the column's weights in flight at a time: the chain is bound by their round trips)
+#pragma unroll 16
     for (int i = 0; i < win; ++i) acc = fmaf(wt[(size_t)i * wout + o], act[cur][i], acc);
     out[(size_t)n * wout + o] = fmaxf(acc, 0.0f);
   }
@@ -159,14 +161,33 @@ __global__ __launch_bounds__(kFcBlock) void fc_stack_kernel(const float* __restr
 // of the last layer is loaded once per S samples (the activations come from LDS as broadcasts, [unit][sample]):
 // the same fmaf chains (bias first, inputs in ascending order), so bit-identical to the per-sample form.
 // grid (ceil(out_last / 256), ceil(N / S));  LDS: 2 * hid * S floats, hid = widest layer input
-template <int S>
+// NARROW (fc_one_wave_ok): the leading layers' parameters come from an LDS copy made with all loads in flight at once
+// (as fc_stack_kernel<true>), not from a runtime-length loop of dependent global loads per layer.
+template <int S, bool NARROW>
 __global__ __launch_bounds__(kFcBlock) void fc_stack_batch_kernel(const float* __restrict__ params, FcDesc d,
                                                                   const float* __restrict__ z, int N, int hid,
                                                                   float* __restrict__ out) {
   extern __shared__ float fc_act[];   // [2][hid][S]
+  __shared__ float p_lds[NARROW ? kFcWaveSpan : 1];
   const int tid = threadIdx.x, n0 = blockIdx.y * S, ns = min(S, N - n0);
   float* cur = fc_act;
   float* nxt = fc_act + (size_t)hid * S;
+  const long long base = d.w_off[0];
+  if (NARROW) {
+    const int span = (int)fc_wave_span(d);
+    constexpr int U = kFcWaveSpan / kFcBlock;
+    float r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = u * kFcBlock + tid;
+      r[u] = e < span ? params[base + e] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = u * kFcBlock + tid;
+      if (e < span) p_lds[e] = r[u];
+    }
+  }
   {
     const int w0 = d.width[0];
     for (int e = tid; e < S * w0; e += kFcBlock) {
@@ -177,11 +198,12 @@ __global__ __launch_bounds__(kFcBlock) void fc_stack_batch_kernel(const float* _
   __syncthreads();
   for (int l = 0; l < d.n_fc - 1; ++l) {
     const int win = d.width[l], wout = d.width[l + 1];
-    const float* w = params + d.w_off[l];
-    const float* b = params + d.b_off[l];
+    const float* w = NARROW ? p_lds + (d.w_off[l] - base) : params + d.w_off[l];
+    const float* b = NARROW ? p_lds + (d.b_off[l] - base) : params + d.b_off[l];
     for (int e = tid; e < S * wout; e += kFcBlock) {
       const int o = e / S, sm = e - o * S;
       float acc = b[o];
+#pragma unroll 8
       for (int i = 0; i < win; ++i) acc = fmaf(w[(size_t)o * win + i], cur[i * S + sm], acc);
       nxt[e] = fmaxf(acc, 0.0f);
     }
@@ -196,7 +218,7 @@ __global__ __launch_bounds__(kFcBlock) void fc_stack_batch_kernel(const float* _
     const float b = params[d.b_off[l] + o];
 #pragma unroll
     for (int sm = 0; sm < S; ++sm) acc[sm] = b;
-#pragma unroll 4
+#pragma unroll 16
     for (int i = 0; i < win; ++i) {
       const float w = wt[(size_t)i * wout + o];
 #pragma unroll
@@ -2101,8 +2123,12 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
     for (int l = 0; l + 1 < d->n_fc; ++l) hid = std::max(hid, d->fc_out[l]);
     constexpr int kFcSamples = 8;
     const size_t fc_lds = 2 * (size_t)hid * kFcSamples * sizeof(float);
-    if (N >= 4 * kFcSamples && fc_lds <= 48 * 1024)   // batches (small ones keep the form of a single decode)
-      hipLaunchKernelGGL((fc_stack_batch_kernel<kFcSamples>),
+    if (N >= 4 * kFcSamples && fc_lds <= 32 * 1024 && decoder_fc_one_wave(fd))   // batches (small ones keep the form of a single decode)
+      hipLaunchKernelGGL((fc_stack_batch_kernel<kFcSamples, true>),
+                         dim3((last + kFcBlock - 1) / kFcBlock, (N + kFcSamples - 1) / kFcSamples), dim3(kFcBlock),
+                         fc_lds, st, d->d_params, fd, z, N, hid, fc_dst);
+    else if (N >= 4 * kFcSamples && fc_lds <= 48 * 1024)
+      hipLaunchKernelGGL((fc_stack_batch_kernel<kFcSamples, false>),
                          dim3((last + kFcBlock - 1) / kFcBlock, (N + kFcSamples - 1) / kFcSamples), dim3(kFcBlock),
                          fc_lds, st, d->d_params, fd, z, N, hid, fc_dst);
     else if (decoder_fc_one_wave(fd))
