@@ -313,26 +313,23 @@ __device__ __forceinline__ void pose_chain_block(const float* orientation, const
   g_scale[0] = part[7][0];
 }
 
-// first_wave .. 3 are the waves that reduce (the tail keeps wave 0 for the decoder's Linear stack meanwhile); which wave
-// reduces which view changes nothing.  params_lds (or NULL): a copy of the parameters in LDS the caller has made.
+// (The tail keeps wave 0 busy with the decoder's Linear stack first; which wave reduces which view changes nothing.)
 __device__ __forceinline__ void deferred_chain(
     const float* orientation, const float* scale, const float* __restrict__ cam_quat,
     int V, const ViewSetup* __restrict__ setup, const float* __restrict__ tile_part, int W, int H, int ntx_all,
     int nty_all, int tile_w_all, int tile_h_all, int stride, const float* __restrict__ pc_part,
     const float* __restrict__ pc_loss_part,
     const int* __restrict__ offsets, int n_single, int nblk, const float* __restrict__ quat_c,
-    float* __restrict__ pc_loss, float* g_position, float* g_orientation, float* g_scale, int first_wave = 0) {
+    float* __restrict__ pc_loss, float* g_position, float* g_orientation, float* g_scale) {
   __shared__ float view_g[kDeferredMaxViews][16];  // [0..7] renderer: pos, quat, inv_scale; [8..15] sampler
   __shared__ float view_cq[kDeferredMaxViews][4];  // the views' camera orientations (the chain's thread reads them here)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (wave >= first_wave) {
-    const int n_waves = 4 - first_wave;
-    for (int v = wave - first_wave; v < V; v += n_waves) {
-      const float cq = lane < 4 ? cam_quat[4 * v + lane] : 0.0f;
-      reduce_view_wave(v, lane, setup, tile_part, W, H, ntx_all, nty_all, tile_w_all, tile_h_all, stride, pc_part,
-                       pc_loss_part, offsets, n_single, nblk, quat_c, pc_loss ? pc_loss + v : nullptr, view_g[v]);
-      if (lane < 4) view_cq[v][lane] = cq;
-    }
+  // view v is wave (v + 1) % 4's: wave 0, which may arrive late, takes the fourth, eighth, ... view only
+  for (int v = (wave + 3) & 3; v < V; v += 4) {
+    const float cq = lane < 4 ? cam_quat[4 * v + lane] : 0.0f;
+    reduce_view_wave(v, lane, setup, tile_part, W, H, ntx_all, nty_all, tile_w_all, tile_h_all, stride, pc_part,
+                     pc_loss_part, offsets, n_single, nblk, quat_c, pc_loss ? pc_loss + v : nullptr, view_g[v]);
+    if (lane < 4) view_cq[v][lane] = cq;
   }
   __syncthreads();
   if (threadIdx.x != 0) return;   // (callers that go on afterwards: every thread reaches the barrier above)
@@ -754,7 +751,7 @@ __global__ __launch_bounds__(256) void loop_tail_kernel(LoopTailArgs a) {
   } else {
     deferred_chain(p_cur + 3, p_cur + 7, a.cam_quat, a.V, a.setup, a.tile_part, a.W, a.H, a.ntx, a.nty,
                    a.tile_w, a.tile_h, a.stride, a.pc_part, a.pc_loss_part, a.offsets, a.n_single, a.nblk, a.quat_c,
-                   a.pc_loss, g_l, g_l + 3, g_l + 7, fc_wave ? 1 : 0);
+                   a.pc_loss, g_l, g_l + 3, g_l + 7);
   }
   SDFR_STAMP(2);
   if (tid == 0 && a.con_source)   // (p_cur: thread 0 has passed a barrier of the chain above since it was written)
