@@ -247,13 +247,22 @@ class SDFVAEViewGenerator:
     DEFAULT_CONFIG; ``z_min``, ``z_max``, ``extent_mean``, ``extent_std`` are required)."""
 
     def __init__(self, config: Dict, decoder, batch_size: int = 64, device="cuda", seed: Optional[int] = None,
-                 prefetch_draws: bool = False):
+                 prefetch_draws: bool = False, decode_ahead: bool = False):
         """prefetch_draws: a ``generate()`` that draws its own latents and poses also draws the NEXT batch's while the
         GPU is busy with this one (the numbers and their order in the generator's stream stay what they were; a call
         that is given a latent or a pose discards what was drawn ahead for it).  For consumers that call
-        ``generate()`` over and over -- iteration turns it on."""
+        ``generate()`` over and over -- iteration turns it on.
+        decode_ahead (with prefetch_draws): the next batch's latents are also uploaded and DECODED ahead, on a second
+        HIP stream, while this batch's render, noise and point-set kernels run on the caller's stream -- the decoder's
+        kernels are bound by the vector ALUs, the march by the CU's vector-memory pipeline, the point-set passes by
+        HBM, and the host's wait for the point counts no longer leaves the GPU idle.  Same kernels on the same
+        numbers: the samples do not change."""
         self.prefetch_draws = bool(prefetch_draws)
+        self.decode_ahead = bool(decode_ahead)
         self._ahead = None
+        self._side = None          # the second stream, the event after this stream's last decode, the batch decoded ahead
+        self._decoded = None
+        self._decode_done = None
         cfg = dict(DEFAULT_CONFIG)
         cfg.update(config)
         for k in ("z_min", "z_max", "extent_mean", "extent_std"):
@@ -289,6 +298,24 @@ class SDFVAEViewGenerator:
             return self.plan.forward(sdf, position.to(**f32).contiguous(), quaternion.to(**f32).contiguous(),
                                      (1.0 / scale.to(**f32)).contiguous(), self.cfg["render_threshold"], out=out)
 
+    def _decode_ahead(self):
+        """Upload and decode the batch drawn ahead on the second stream (see ``decode_ahead``)."""
+        dev = self.device
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        z0, p, q, s = self._ahead
+        Lz = z0.shape[1]
+        with torch.cuda.stream(self._side), torch.no_grad():
+            if self._decode_done is not None:       # this stream's last decode shares the decoder's workspace
+                self._side.wait_event(self._decode_done)
+            packed = torch.cat((z0, p, q, s[:, None]), 1).to(dev, non_blocking=True)
+            latent, position, quaternion, scale = (packed[:, :Lz], packed[:, Lz:Lz + 3].clone(),
+                                                   packed[:, Lz + 3:Lz + 7], packed[:, Lz + 7].clone())
+            sdf = self.decoder.decode(latent.contiguous())[:, 0].contiguous()
+            ready = torch.cuda.Event()
+            ready.record(self._side)
+        self._decoded = (latent, position, quaternion, scale, sdf, ready)
+
     def generate(self, latent=None, position=None, quaternion=None, scale=None, smooth=None,
                  mask_affine=None, mask_noise_value=None) -> Dict:
         """One batch of samples; any of the sampled quantities may be given instead of drawn
@@ -300,7 +327,10 @@ class SDFVAEViewGenerator:
         "valid" (B,) = the reference's _is_valid (at least one depth pixel)."""
         cfg, B, dev = self.cfg, self.B, self.device
         ahead, self._ahead = self._ahead, None
+        decoded, self._decoded = self._decoded, None
         draws_all = latent is None and position is None and quaternion is None and scale is None
+        if not draws_all:
+            decoded = None          # (a caller's latent or pose: what was decoded ahead is not this batch)
         if ahead is not None:
             z0, p, q, s = ahead
             latent = z0 if latent is None else latent
@@ -316,10 +346,19 @@ class SDFVAEViewGenerator:
                 self._ahead = (torch.randn((B, self.decoder.latent_size), generator=self.gen),) + tuple(
                     sample_poses(B, self.camera, cfg["z_min"], cfg["z_max"], cfg["extent_mean"], cfg["extent_std"],
                                  self.gen))
+                if self.decode_ahead and dev.type == "cuda":
+                    self._decode_ahead()
         position, quaternion, scale = (p if position is None else position, q if quaternion is None else quaternion,
                                        s if scale is None else scale)
         host = [t for t in (latent, position, quaternion, scale) if not t.is_cuda]
-        if len(host) == 4 and all(t.dtype == torch.float32 for t in host):
+        sdf_ahead = None
+        if decoded is not None:
+            # decoded ahead on the second stream: the device copies of the draws and the volumes; this stream waits
+            latent, position, quaternion, scale, sdf_ahead, ready = decoded
+            torch.cuda.current_stream(dev).wait_event(ready)
+            for t in (latent, position, quaternion, scale, sdf_ahead):
+                t.record_stream(torch.cuda.current_stream(dev))
+        elif len(host) == 4 and all(t.dtype == torch.float32 for t in host):
             # one packed transfer instead of four small ones (each costs ~15 us of host time)
             Lz = latent.shape[1]
             packed = torch.cat((latent, position, quaternion, scale[:, None]), 1).to(dev, non_blocking=True)
@@ -329,8 +368,18 @@ class SDFVAEViewGenerator:
             position = position.to(dev).clone()
             quaternion = quaternion.to(dev)
             scale = scale.to(dev).clone()
-        depth = self.render(latent, position, quaternion, scale,
-                            out=torch.empty((B, cfg["height"], cfg["width"]), dtype=torch.float32, device=dev))
+        depth_out = torch.empty((B, cfg["height"], cfg["width"]), dtype=torch.float32, device=dev)
+        if sdf_ahead is not None:
+            with torch.no_grad():
+                depth = self.plan.forward(sdf_ahead, position.contiguous(), quaternion.contiguous(),
+                                          (1.0 / scale).contiguous(), cfg["render_threshold"], out=depth_out)
+        else:
+            if self._side is not None:   # (a decode still running ahead -- discarded or not -- uses the same workspace)
+                torch.cuda.current_stream(dev).wait_stream(self._side)
+            depth = self.render(latent, position, quaternion, scale, out=depth_out)
+            if self.decode_ahead and dev.type == "cuda":   # (the decoder's workspace is free from here on)
+                self._decode_done = torch.cuda.Event()
+                self._decode_done.record(torch.cuda.current_stream(dev))
         final_mask = None
         if cfg["mask_noise"]:                                                          # :286-291
             if mask_affine is None:
@@ -409,6 +458,7 @@ class SDFVAEViewGenerator:
 
     def __iter__(self):
         self.prefetch_draws = True
+        self.decode_ahead = True
         while True:
             for s in self.samples(self.generate()):
                 yield s

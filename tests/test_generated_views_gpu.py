@@ -168,6 +168,32 @@ def test_prefetched_draws_are_the_same_numbers(mug_decoder):
     assert b._ahead is not None and a._ahead is None
 
 
+def test_decode_ahead_on_a_second_stream_gives_the_same_samples(mug_decoder):
+    """decode_ahead: batch k + 1 is uploaded and decoded on a second HIP stream while batch k's render / noise /
+    point-set kernels run -- the same kernels on the same numbers, so every sample is bit for bit the plain
+    generator's; a call with a caller's latent in between discards what was decoded ahead and goes on correctly."""
+    from sdfest_amd.generated_views import SDFVAEViewGenerator
+    dec, d = mug_decoder
+    cfg = {**CFG, "normalize_pose": True, "norm_noise": True}
+    a = SDFVAEViewGenerator(cfg, dec, batch_size=5, seed=33, prefetch_draws=True)   # (same draws: see the test above)
+    b = SDFVAEViewGenerator(cfg, dec, batch_size=5, seed=33, prefetch_draws=True, decode_ahead=True)
+    keys = ("latent_shape", "position", "quaternion", "scale", "depth", "points", "counts")
+    for it in range(4):
+        oa, ob = a.generate(), b.generate()
+        torch.cuda.synchronize()
+        for k in keys:
+            assert torch.equal(oa[k], ob[k]), (it, k)
+        assert b._decoded is not None and (it == 0 or b._side is not None)
+    z = torch.tensor(d["z"][:5]) * 0.4
+    oa, ob = a.generate(latent=z), b.generate(latent=z)     # (the batch decoded ahead is dropped, its draws too)
+    for k in keys:
+        assert torch.equal(oa[k], ob[k]), ("given latent", k)
+    for it in range(2):
+        oa, ob = a.generate(), b.generate()
+        for k in keys:
+            assert torch.equal(oa[k], ob[k]), ("after", it, k)
+
+
 def test_empty_views_are_flagged_not_returned(mug_decoder):
     from sdfest_amd.generated_views import SDFVAEViewGenerator
     dec, _ = mug_decoder

@@ -112,11 +112,15 @@ def main():
         t_g = timeit(lambda: gen.generate(), 10)
         gen.prefetch_draws = True      # what iterating over the generator does: the next batch is drawn while the GPU works
         t_p = timeit(lambda: gen.generate(), 10)
+        gen.decode_ahead = True        # ... and decoded, on a second stream
+        t_d = timeit(lambda: gen.generate(), 10)
         out[f"view generator B={gb} 640x480"] = {"decode+render_us": round(t_r, 1),
                                                  "decode+render_views_per_s": round(gb / t_r * 1e6, 1),
                                                  "full_sample_us": round(t_p, 1),
                                                  "full_sample_us_draws_not_prefetched": round(t_g, 1),
-                                                 "samples_per_s": round(gb / t_p * 1e6, 1)}
+                                                 "full_sample_us_decoded_ahead": round(t_d, 1),
+                                                 "samples_per_s": round(gb / t_p * 1e6, 1),
+                                                 "samples_per_s_decoded_ahead": round(gb / t_d * 1e6, 1)}
     # batched render-and-compare step on the depth term (C3 poses): forward -> masked L1 -> backward,
     # with the loss as its own kernel vs folded into the render kernels
     from sdfest_amd import _lib
