@@ -1337,12 +1337,41 @@ __device__ __forceinline__ void resize_sources_exact(int i, float ratio, int n_i
 // test its weight, read the next: the passes were chains of LDS latencies, 3/4 of the kernel's time); a tap beyond a
 // row's range has weight 0 and re-reads the row's last source.  The mask values of a channel are loaded before its
 // z pass and used after its y pass.)
+// The exact source range [d0, d0 + nt) of coarse index i (i < 0: empty) and the weight of its tap k, by the SIXTEEN lanes
+// k = 0 .. 15 of a 16-lane group (all of them active; group_shift = the group's first lane within the wave): every lane
+// weighs one candidate of resize_sources' superset range (<= 16 long: host), a ballot finds the first and the last
+// non-zero one.  resize_sources_exact + a loop over the taps are ~17 dependent evaluations of resize_weight on one
+// lane -- 4 us of set-up per launch of the kernel below (stamped: 1.5 us for the tile's bounds, 2.5 us for the
+// tables), a third of a single latent's launch; this is two evaluations deep.
+__device__ __forceinline__ void resize_row16(int i, int k, int group_shift, float ratio, int n_in, int n_out, int& d0,
+                                             int& nt, float& w_k) {
+  int d0s = 0, d1s = -1;
+  if (i >= 0) resize_sources(i, n_in, n_out, d0s, d1s);
+  const int d = d0s + k;
+  const float w = (i >= 0 && d <= d1s) ? resize_weight(d, i, ratio, n_in) : 0.0f;
+  const unsigned m16 = (unsigned)(__ballot(w != 0.0f) >> group_shift) & 0xffffu;
+  d0 = d0s;
+  nt = 0;
+  if (m16) {
+    const int first = __ffs(m16) - 1, last = 31 - __clz(m16);
+    d0 = d0s + first;
+    nt = last - first + 1;
+  }
+  w_k = (k < nt) ? resize_weight(d0 + k, i, ratio, n_in) : 0.0f;
+}
 template <int COUT, int TAPS>
 __global__ __launch_bounds__(kBtMaxThreads) void resize3_backward_tiled_kernel(
     const float* __restrict__ g_out, int n_in, int n_out, const float* __restrict__ act, int pad, int pz, int tc,
     int max_f, int nc, int slots, const float* __restrict__ wmat, const float* __restrict__ bias, float* __restrict__ out) {
   constexpr int CO = COUT > 0 ? COUT : 1;
   extern __shared__ float lds[];
+#ifdef SDFR_BT_STAMPS   // timing experiment (tools/microbench/tail_stamps.py prints them): the stages of a workgroup, 10 ns ticks
+  unsigned long long bts[8]; int btk = 0;
+#define BTS() do { if (btk < 8) bts[btk++] = wall_clock64(); } while (0)
+#else
+#define BTS() do { } while (0)
+#endif
+  BTS();
   __shared__ float w_tab[2 * kBtMaxTile + 64][kBtTaps];   // rows: x (tc), y (tc), z (n_in <= 64)
   __shared__ int d_tab[2 * kBtMaxTile + 64];              // first source index, relative to the tile's first fine row / 0 for z
   __shared__ int f_rng[4];
@@ -1358,25 +1387,18 @@ __global__ __launch_bounds__(kBtMaxThreads) void resize3_backward_tiled_kernel(
   const int ncx = cx1 - cx0 + 1, ncy = cy1 - cy0 + 1;
   const int ox0 = tile_x == 0 ? 0 : cx0 + pad, ox1 = tile_x == tiles - 1 ? np : cx1 + 1 + pad;
   const int oy0 = tile_y == 0 ? 0 : cy0 + pad, oy1 = tile_y == tiles - 1 ? np : cy1 + 1 + pad;
-  if (tid < 4) {   // the tile's fine rows: four lanes find one bound each
-    int d0, d1;
-    resize_sources_exact(tid == 0 ? cx0 : (tid == 1 ? cx1 : (tid == 2 ? cy0 : cy1)), ratio, n_in, n_out, d0, d1);
-    f_rng[tid] = (tid & 1) ? d1 : d0;
+  const int k16 = tid & 15, g16 = lane & 48;   // (16-lane groups: resize_row16)
+  if (tid < 64) {   // the tile's fine rows: the first wave's four groups find one bound each
+    const int q = tid >> 4;
+    int d0, nt;
+    float w;
+    resize_row16(q == 0 ? cx0 : (q == 1 ? cx1 : (q == 2 ? cy0 : cy1)), k16, g16, ratio, n_in, n_out, d0, nt, w);
+    if (k16 == 0) f_rng[q] = (q & 1) ? d0 + nt - 1 : d0;
   }
   __syncthreads();
+  BTS();
   const int fx0 = f_rng[0], fx1 = f_rng[1], fy0 = f_rng[2], fy1 = f_rng[3];
   const int fnx = fx1 - fx0 + 1, fny = fy1 - fy0 + 1;
-  if (tid < 2 * kBtMaxTile + n_in) {   // weight tables
-    int i, base;
-    if (tid < kBtMaxTile) { i = tid < ncx ? cx0 + tid : -1; base = fx0; }
-    else if (tid < 2 * kBtMaxTile) { i = tid - kBtMaxTile < ncy ? cy0 + tid - kBtMaxTile : -1; base = fy0; }
-    else { i = tid - 2 * kBtMaxTile; base = 0; }
-    int d0 = 0, d1 = -1;
-    if (i >= 0) resize_sources_exact(i, ratio, n_in, n_out, d0, d1);
-    const int nt = d1 - d0 + 1;
-    d_tab[tid] = d0 - base;
-    for (int k = 0; k < kBtTaps; ++k) w_tab[tid][k] = (k < nt) ? resize_weight(d0 + k, i, ratio, n_in) : 0.0f;
-  }
   float* F = lds;                                      // [fnx][fny][n_out], heads overwritten by the z pass
   float* Y = lds + (size_t)max_f * max_f * n_out;      // [fnx][ncy][n_in]
   // a thread's vectors of the fine block (n_out % 4 == 0, <= kBtLoads * nthr vectors: host)
@@ -1400,6 +1422,18 @@ __global__ __launch_bounds__(kBtMaxThreads) void resize3_backward_tiled_kernel(
     for (int j = 0; j < kBtLoads; ++j)
       if (nthr * j < total4) pre[j] = *reinterpret_cast<const f32x4*>(src + off[j]);
   }
+  // weight tables, a row per 16-lane group (while the block's first vectors are on their way)
+  for (int row = tid >> 4; row < 2 * kBtMaxTile + n_in; row += nthr >> 4) {
+    int i, base;
+    if (row < kBtMaxTile) { i = row < ncx ? cx0 + row : -1; base = fx0; }
+    else if (row < 2 * kBtMaxTile) { i = row - kBtMaxTile < ncy ? cy0 + row - kBtMaxTile : -1; base = fy0; }
+    else { i = row - 2 * kBtMaxTile; base = 0; }
+    int d0, nt;
+    float w;
+    resize_row16(i, k16, g16, ratio, n_in, n_out, d0, nt, w);
+    if (k16 == 0) d_tab[row] = d0 - base;
+    if (k16 < kBtTaps) w_tab[row][k16] = w;
+  }
   // a thread's elements of the tile's part of the padded tensor (<= kBtOut * nthr: host): where each goes, its mask
   // value, its Y column and its x weights (-1: padding, a zero)
   const int ocx = ox1 - ox0, ocy = oy1 - oy0, n_store = ocx * ocy * pz;   // (rows pz >= np floats apart, the rest zeros)
@@ -1420,6 +1454,7 @@ __global__ __launch_bounds__(kBtMaxThreads) void resize3_backward_tiled_kernel(
     }
   }
   __syncthreads();   // tables
+  BTS();
   // lane -> (slot, iz): 64 / nl rows per wave-step, nl = the power of two that holds a coarse row
   const int nl = n_in <= 8 ? 8 : (n_in <= 16 ? 16 : (n_in <= 32 ? 32 : 64));
   const int spw = 64 / nl, slot = lane / nl, iz = lane - slot * nl;
@@ -1439,6 +1474,7 @@ __global__ __launch_bounds__(kBtMaxThreads) void resize3_backward_tiled_kernel(
     for (int j = 0; j < kBtLoads; ++j)
       if (tid + nthr * j < total4) reinterpret_cast<f32x4*>(F)[tid + nthr * j] = pre[j];
     __syncthreads();
+    BTS();
     // this channel's mask values, then the next channel's block: both in flight during this channel's passes
     float mask[kBtOut][CO];
     if (act) {
@@ -1468,6 +1504,7 @@ __global__ __launch_bounds__(kBtMaxThreads) void resize3_backward_tiled_kernel(
       }
     }
     __syncthreads();
+    BTS();
     {   // y pass: pairs (fx, jy), jy fastest
       const int pairs = fnx * ncy;
       for (int pr = wave * spw + slot; pr < pairs; pr += nw * spw) {
@@ -1487,6 +1524,7 @@ __global__ __launch_bounds__(kBtMaxThreads) void resize3_backward_tiled_kernel(
       }
     }
     __syncthreads();
+    BTS();
     // x pass, (mix,) mask, store: the tile's columns of the padded tensor, zeros in the padding
 #pragma unroll
     for (int j = 0; j < kBtOut; ++j) {
@@ -1517,6 +1555,13 @@ __global__ __launch_bounds__(kBtMaxThreads) void resize3_backward_tiled_kernel(
       }
       __builtin_amdgcn_sched_barrier(0);   // (one element's taps at a time: six elements' worth of reads in flight cost 40 VGPRs)
     }
+    BTS();
+#ifdef SDFR_BT_STAMPS
+    if (tid == 0 && blockIdx.x == 0 && o == slot0)
+      printf("rbt n_out %d threads %d: bounds %.2f tables %.2f stage %.2f z %.2f y %.2f x+store %.2f us\n", n_out, nthr,
+             (double)(bts[1] - bts[0]) * 0.01, (double)(bts[2] - bts[1]) * 0.01, (double)(bts[3] - bts[2]) * 0.01,
+             (double)(bts[4] - bts[3]) * 0.01, (double)(bts[5] - bts[4]) * 0.01, (double)(bts[6] - bts[5]) * 0.01);
+#endif
   }
 }
 
@@ -2413,16 +2458,19 @@ int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* ta
         while (d1 >= d0 && weight(d1, i) == 0.0f) --d1;
       };
       const int padv = pad >= 0 ? pad : 0;
-      int max_taps = 1;
+      int max_taps = 1, max_span = 1;   // longest exact source range; longest candidate range (resize_row16: <= 16)
       for (int i = 0; i < n_in; ++i) {
         int d0, d1;
         exact(i, d0, d1);
         max_taps = std::max(max_taps, d1 - d0 + 1);
+        const int s0 = std::max((int)floorf(((float)i - 0.5f) * inv - 0.5f) - 1, 0);
+        const int s1 = std::min((int)ceilf(((float)i + 1.5f) * inv - 0.5f) + 1, n_out - 1);
+        max_span = std::max(max_span, s1 - s0 + 1);
       }
       // tile edge and workgroup size: the pair that stages the fewest fine rows over the launch, among those whose
       // block fits the registers of the prefetch (kBtLoads vectors per thread) and leaves two workgroups on a CU
       struct Pick { int tc = 0, threads = 0, max_f = 0, wgs = 0; size_t lds = 0; double cost = 0; } best;
-      const bool aligned = (n_out & 3) == 0 && ((uintptr_t)g & 15) == 0 && max_taps <= kBtTaps;
+      const bool aligned = (n_out & 3) == 0 && ((uintptr_t)g & 15) == 0 && max_taps <= kBtTaps && max_span <= 16;
       const void* fn = nullptr;   // the instantiation this call takes
       {
 #define SDFR_BT_FN(CO) (max_taps <= 6 ? reinterpret_cast<const void*>(&resize3_backward_tiled_kernel<CO, 6>)    \

@@ -1,6 +1,8 @@
 """Where the time of loop_tail_kernel goes (C5 loop, 10 ns ticks between the stages of its last run).
 Needs a build with -DSDFR_TAIL_STAMPS:  tools/microbench/build_variant.sh stamps -DSDFR_TAIL_STAMPS
-                                        SDFR_LIB=build/variants/libsdfr_stamps.so python tools/microbench/tail_stamps.py"""
+                                        SDFR_LIB=build/variants/libsdfr_stamps.so python tools/microbench/tail_stamps.py
+A build with -DSDFR_BT_STAMPS prints the stages of the first workgroup of every transposed-resize launch of the same
+loop instead (device printf; the table at the end is then meaningless: the library has no tail stamps)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -20,6 +22,8 @@ def main():
     fused(*args)
     torch.cuda.synchronize()
     out = (ctypes.c_ulonglong * 8)()
+    if not hasattr(_lib.lib(), "sdfr_debug_tail_stamps"):
+        return
     fn = _lib.lib().sdfr_debug_tail_stamps
     fn.restype = ctypes.c_int
     assert fn(out) == 0
