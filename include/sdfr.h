@@ -521,6 +521,23 @@ SDFR_API int sdfr_depth_to_points_shifted(const float* depth, int V, int W, int 
                                  float cx0, float cy0, const int* offsets, const void* workspace, const float* shift,
                                  float* points, int device, void* stream);
 
+/* The same pair of passes WITHOUT the host in between, for a caller that re-uses its buffers from observation to
+ * observation (the captured render-and-compare loop, rebound to new depth images): `points` has room for every pixel
+ * (V * W * H points), so nobody has to read the counts to size it.  One call: block counts -> counts [V] and the
+ * exclusive prefix offsets [V + 1] (offsets[V] = all points; the format sdfr_pc_* take) -> compaction.  Consumers are
+ * then launched for `max_view_points` = W * H (an upper bound sizes their grids; blocks beyond a view's real count leave
+ * at once).  Workspace: sdfr_depth_points_workspace_bytes.  Same points, bit for bit, as the two-call form. */
+SDFR_API int sdfr_depth_to_points_resident(const float* depth, int V, int W, int H, int order, float rfx, float rfy,
+                                  float cx0, float cy0, int* counts, int* offsets, void* workspace,
+                                  size_t workspace_bytes, float* points, int device, void* stream);
+
+/* SDFPipeline._preprocess_depth (sdfest/estimation/simple_setup.py:671-693), IN PLACE like the reference:
+ *     depth[~mask] = 0;   if has_far_field: depth[depth > far_field] = 0
+ * depth [V][H][W]; mask [V][H][W] bytes (a torch.bool tensor's storage: 0 = outside).  copy_to (nullable): the
+ * preprocessed images are also written there (the loop's own target buffer: one pass instead of two). */
+SDFR_API int sdfr_preprocess_depth(float* depth, const unsigned char* mask, int V, int W, int H, float far_field,
+                          int has_far_field, float* copy_to, int device, void* stream);
+
 /* a += b  (sums the renderer's and the sampler's d/dSDF) */
 SDFR_API int sdfr_add_inplace(float* a, const float* b, size_t n, int device, void* stream);
 

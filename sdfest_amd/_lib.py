@@ -111,6 +111,9 @@ SIGNATURES = {
                                           c_sz, c_int, c_fp]),
     "sdfr_depth_to_points_shifted": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_fp, c_fp, c_fp,
                                              c_fp, c_int, c_fp]),
+    "sdfr_depth_to_points_resident": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_fp, c_fp, c_fp,
+                                              c_sz, c_fp, c_int, c_fp]),
+    "sdfr_preprocess_depth": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_f, c_int, c_fp, c_int, c_fp]),
     "sdfr_add_inplace": (c_int, [c_fp, c_fp, c_sz, c_int, c_fp]),
     "sdfr_adam_step": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_f, c_f, c_f, c_f, c_int, c_int, c_fp]),
     "sdfr_point_constraint": (c_int, [c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_int, c_fp]),

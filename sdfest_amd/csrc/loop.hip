@@ -864,7 +864,7 @@ __global__ __launch_bounds__(256) void depth_count_kernel(const float* __restric
   if (tid == 0) {
     const int t = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
     block_count[(size_t)v * nblk + blk] = t;
-    if (t) atomicAdd(&count[v], t);
+    if (t && count) atomicAdd(&count[v], t);
   }
   if (SUMS && tid < 3)
     block_sum[((size_t)v * nblk + blk) * 4 + tid] = (wxyz[0][tid] + wxyz[1][tid]) + (wxyz[2][tid] + wxyz[3][tid]);
@@ -885,6 +885,85 @@ __global__ __launch_bounds__(64) void count_prefix_kernel(const int* __restrict_
     }
     if (v < V) offsets[v] = base + incl - c;
     base += __shfl(incl, 63, 64);
+  }
+}
+
+// The same without a host in between (sdfr_depth_to_points_resident): ONE workgroup; wave w sums the block counts of the
+// views w, w + 4, ... (integers: any order) into count[v], wave 0 then writes the exclusive prefix offsets[0 .. V]
+// (V + 1 entries: offsets[V] = all points), 64 views per round.
+__global__ __launch_bounds__(256) void resident_offsets_kernel(const int* __restrict__ block_count, int nblk, int V,
+                                                               int* __restrict__ count, int* __restrict__ offsets) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int v = wave; v < V; v += 4) {
+    int s = 0;
+    for (int i = lane; i < nblk; i += 64) s += block_count[(size_t)v * nblk + i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) count[v] = s;
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (wave != 0) return;
+  int base = 0;
+  for (int v0 = 0; v0 < V; v0 += 64) {
+    const int v = v0 + lane;
+    const int c = v < V ? count[v] : 0;
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (v < V) offsets[v] = base + incl - c;
+    base += __shfl(incl, 63, 64);
+  }
+  if (lane == 0) offsets[V] = base;
+}
+
+// SDFPipeline._preprocess_depth (simple_setup.py:671-693), in place: depth[~mask] = 0, then (has_far) depth[depth >
+// far_field] = 0 -- a NaN depth is not "> far_field" and stays, as in torch.  Four pixels per thread; a value is stored
+// only where it changes.  copy_to (nullable): the preprocessed images also go there (the loop's own target buffer).
+__global__ __launch_bounds__(256) void preprocess_depth_kernel(float* __restrict__ depth,
+                                                               const unsigned char* __restrict__ mask, size_t n,
+                                                               float far_field, int has_far, int vec,
+                                                               float* __restrict__ copy_to) {
+  const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= n) return;
+  float z[4];
+  unsigned char m[4];
+  const bool full = vec && i0 + 4 <= n;
+  if (full) {
+    const float4 q = *reinterpret_cast<const float4*>(depth + i0);
+    const uchar4 mm = *reinterpret_cast<const uchar4*>(mask + i0);
+    z[0] = q.x; z[1] = q.y; z[2] = q.z; z[3] = q.w;
+    m[0] = mm.x; m[1] = mm.y; m[2] = mm.z; m[3] = mm.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      z[k] = (i0 + k < n) ? depth[i0 + k] : 0.0f;
+      m[k] = (i0 + k < n) ? mask[i0 + k] : (unsigned char)1;
+    }
+  }
+  float o[4];
+  bool changed = false;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float t = m[k] ? z[k] : 0.0f;
+    if (has_far && t > far_field) t = 0.0f;
+    o[k] = t;
+    changed = changed || (__float_as_uint(t) != __float_as_uint(z[k]));
+  }
+  if (full) {
+    const float4 q = make_float4(o[0], o[1], o[2], o[3]);
+    if (changed) *reinterpret_cast<float4*>(depth + i0) = q;
+    if (copy_to) *reinterpret_cast<float4*>(copy_to + i0) = q;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i0 + k >= n) break;
+      if (__float_as_uint(o[k]) != __float_as_uint(z[k])) depth[i0 + k] = o[k];
+      if (copy_to) copy_to[i0 + k] = o[k];
+    }
   }
 }
 
@@ -1432,6 +1511,55 @@ extern "C" int sdfr_depth_to_points_shifted(const float* depth, int V, int W, in
   const int nblk = (po.count() + kCompactPix - 1) / kCompactPix;
   hipLaunchKernelGGL(depth_compact_kernel, dim3(nblk, V), dim3(256), 0, (hipStream_t)stream, depth, po,
                      nblk, (const int*)workspace, offsets, rfx, rfy, cx0, cy0, shift, points);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfr_depth_to_points_resident(const float* depth, int V, int W, int H, int order, float rfx, float rfy,
+                                             float cx0, float cy0, int* counts, int* offsets, void* workspace,
+                                             size_t workspace_bytes, float* points, int device, void* stream) {
+  const char* fn = "sdfr_depth_to_points_resident";
+  if (order != SDFR_POINT_ORDER_ROW_MAJOR && order != SDFR_POINT_ORDER_TILED)
+    return fail(SDFR_E_INVALID, "%s: unknown point order %d", fn, order);
+  if (V < 0 || W < 0 || H < 0 || V > 65535 || (long long)(W + 63) * (H + 15) > 0x7fffffffLL ||
+      (long long)V * W * H > 0x7fffffffLL)
+    return fail(SDFR_E_INVALID, "%s: bad sizes", fn);
+  if (V == 0) return 0;
+  if (!counts || !offsets) return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
+  SDFR_HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  if (W == 0 || H == 0) {
+    zero_words_async(reinterpret_cast<float*>(counts), (size_t)V, st);
+    zero_words_async(reinterpret_cast<float*>(offsets), (size_t)V + 1, st);
+    return 0;
+  }
+  if (!depth || !workspace || !points) return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
+  if (workspace_bytes < sdfr_depth_points_workspace_bytes(V, W, H))
+    return fail(SDFR_E_WORKSPACE, "%s: workspace too small", fn);
+  const PixelOrder po = pixel_order(W, H, order);
+  const int nblk = (po.count() + kCompactPix - 1) / kCompactPix;
+  hipLaunchKernelGGL(depth_count_kernel<false>, dim3(nblk, V), dim3(256), 0, st, depth, po, nblk, (int*)workspace,
+                     (int*)nullptr, 0.0f, 0.0f, 0.0f, 0.0f, (float*)nullptr);
+  hipLaunchKernelGGL(resident_offsets_kernel, dim3(1), dim3(256), 0, st, (const int*)workspace, nblk, V, counts,
+                     offsets);
+  hipLaunchKernelGGL(depth_compact_kernel, dim3(nblk, V), dim3(256), 0, st, depth, po, nblk, (const int*)workspace,
+                     offsets, rfx, rfy, cx0, cy0, (const float*)nullptr, points);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfr_preprocess_depth(float* depth, const unsigned char* mask, int V, int W, int H, float far_field,
+                                     int has_far_field, float* copy_to, int device, void* stream) {
+  const char* fn = "sdfr_preprocess_depth";
+  if (V < 0 || W < 0 || H < 0) return fail(SDFR_E_INVALID, "%s: negative size V=%d W=%d H=%d", fn, V, W, H);
+  const size_t n = (size_t)V * (size_t)W * (size_t)H;
+  if (n == 0) return 0;
+  if (n > ((size_t)1 << 40)) return fail(SDFR_E_INVALID, "%s: image batch too large", fn);
+  if (!depth || !mask) return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
+  SDFR_HIP_TRY(hipSetDevice(device));
+  const int vec = ((uintptr_t)depth % 16 == 0) && ((uintptr_t)mask % 4 == 0) && (!copy_to || (uintptr_t)copy_to % 16 == 0);
+  hipLaunchKernelGGL(preprocess_depth_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream,
+                     depth, mask, n, far_field, has_far_field ? 1 : 0, vec, copy_to);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }

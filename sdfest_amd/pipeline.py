@@ -83,6 +83,44 @@ def depth_to_pointcloud(depth_image: torch.Tensor, camera: Camera, tiled: bool =
     return torch.stack(((cols.float() - cx) * z / fx, -(rows.float() - cy) * z / fy, -z), dim=1)
 
 
+def preprocess_depth(depth_images: torch.Tensor, masks: Optional[torch.Tensor], far_field: Optional[float] = None,
+                     copy_to=None) -> torch.Tensor:
+    """``SDFPipeline._preprocess_depth`` (simple_setup.py:671-693), in place like the reference:
+    ``depth_images[~masks] = 0`` and, with a far field, ``depth_images[depth_images > far_field] = 0`` -- one kernel
+    (``sdfr_preprocess_depth``) instead of two boolean-index assignments (each a mask conversion, a nonzero with
+    its host synchronisation, and an index_put).  depth_images (N,H,W) float32 CUDA contiguous; masks: bool (or
+    uint8) of the same shape, None = keep every pixel.  copy_to = (tensor (n,H,W), begin, end): the preprocessed
+    images [begin, end) are also written there in the same pass (whole batch only when begin, end span it)."""
+    from . import _lib
+    if not (isinstance(depth_images, torch.Tensor) and depth_images.is_cuda and depth_images.dtype is torch.float32
+            and depth_images.is_contiguous() and depth_images.dim() == 3):
+        raise RuntimeError("depth_images must be a contiguous float32 CUDA tensor of shape (N, H, W)")
+    N, H, W = depth_images.shape
+    dev = depth_images.device
+    if masks is None:
+        m8 = torch.ones((N, H, W), dtype=torch.uint8, device=dev)
+    else:
+        if tuple(masks.shape) != (N, H, W):
+            raise RuntimeError(f"masks must have the shape of depth_images {(N, H, W)}, got {tuple(masks.shape)}")
+        m8 = masks.to(device=dev)
+        m8 = (m8 if m8.dtype in (torch.bool, torch.uint8) else m8 != 0).contiguous()
+        m8 = m8.view(torch.uint8) if m8.dtype is torch.bool else m8
+    out, same = None, False
+    if copy_to is not None:
+        dst, b, e = copy_to
+        same = (b, e) == (0, N) and dst.is_contiguous() and dst.dtype is torch.float32 and dst.device == dev \
+            and tuple(dst.shape) == (N, H, W)
+        out = dst if same else None
+    L = _lib.lib()
+    _lib.check(L.sdfr_preprocess_depth(depth_images.data_ptr(), m8.data_ptr(), N, W, H,
+                                       float(far_field) if far_field is not None else 0.0,
+                                       int(far_field is not None), out.data_ptr() if out is not None else None,
+                                       dev.index, torch.cuda.current_stream(dev).cuda_stream), "sdfr_preprocess_depth")
+    if copy_to is not None and not same:
+        copy_to[0].copy_(depth_images[copy_to[1]:copy_to[2]])
+    return depth_images
+
+
 class RenderAndCompare:
     """Adam on (position, orientation, scale, latent) against V observed depth images.
 
@@ -250,14 +288,18 @@ class FusedRenderAndCompare:
     Parameters live in one device buffer ``[position 3 | orientation 4 | scale 1 | latent L]``.
     """
 
-    def __init__(self, decoder, camera: Camera, config: Dict, depth_images: torch.Tensor,
+    def __init__(self, decoder, camera: Camera, config: Dict, depth_images: Optional[torch.Tensor] = None,
                  camera_positions: Optional[torch.Tensor] = None,
                  camera_orientations: Optional[torch.Tensor] = None,
                  shape_optimization: bool = True, device="cuda", fuse_depth_loss: bool = True,
                  point_constraint: Optional[Sequence] = None, track_inliers: Optional[bool] = None,
                  merge_launches: bool = True, graph_iterations: int = 5, process_group=None,
-                 exchange: str = "sdf", sdf_grad_mode: int = 0, form: str = "auto"):
-        """point_constraint: (source (3,), target (3,), weight), simple_setup.py:164-175.
+                 exchange: str = "sdf", sdf_grad_mode: int = 0, form: str = "auto", views: Optional[int] = None):
+        """depth_images (V,H,W): the first observation (``rebind`` takes the next ones: the reference calls its
+        pipeline once per detected object with fresh images, simple_setup.py:213-225, and so re-uses nothing; this
+        object keeps every buffer and every captured graph across observations of the same V, W, H).  None with
+        ``views=V``: buffers only, ``rebind`` before the first run.
+        point_constraint: (source (3,), target (3,), weight), simple_setup.py:164-175.
         process_group (None | "world" | a torch.distributed group): the loop SHARDED over the group's ranks, one process
         per GPU.  Every rank is given the same full view list, cameras and initial estimate and keeps its contiguous
         shard of the views (``parallel.shard_views``).  An iteration then has exactly ONE exchange, an all-reduce of one
@@ -291,7 +333,6 @@ class FusedRenderAndCompare:
         # False: every loss is a kernel of its own between a forward and a backward.  Same results.
         self.fuse_depth_loss = bool(fuse_depth_loss)
         self.graph_iterations = max(1, int(graph_iterations))
-        self.graph_many = None
         self.L = _lib.lib()
         self.check = _lib.check
         self.dec = decoder
@@ -312,7 +353,11 @@ class FusedRenderAndCompare:
         # the records form of the iteration: head (decoder .. both backward passes .. view records), [exchange],
         # tail (decoder VJP, chain over ALL views' records, Adam, next poses).  A single process takes it too when
         # the pose sums are asked to be independent of the batch (BWD_SMALL_TILES): same arithmetic as the ranks'.
-        self.V_all = int(depth_images.shape[0])
+        if depth_images is None and views is None:
+            raise ValueError("give the first observation (depth_images) or the number of views (views=)")
+        self.V_all = int(depth_images.shape[0]) if depth_images is not None else int(views)
+        if views is not None and int(views) != self.V_all:
+            raise ValueError(f"views={views} but depth_images holds {self.V_all}")
         if form not in ("auto", "tail", "records"):
             raise ValueError(f"form must be 'auto', 'tail' or 'records', got {form!r}")
         must = self.group is not None or bool(self.sdf_grad_mode & BWD_SMALL_TILES)
@@ -326,40 +371,54 @@ class FusedRenderAndCompare:
             raise ValueError("the sharded loop runs the loss-fused kernels (fuse_depth_loss=True)")
         if self.det and not self.records_form:
             raise ValueError("SDF_GRAD_DETERMINISTIC in the loop goes with BWD_SMALL_TILES (or a process group)")
-        self.cam_pos_all = self.cam_quat_all = None
-        if self.group is not None:
-            n_all = self.V_all
-            f32a = dict(dtype=torch.float32, device=self.dev)
-            self.cam_pos_all = (torch.zeros((n_all, 3), **f32a) if camera_positions is None
-                                else camera_positions.to(**f32a).contiguous())
-            self.cam_quat_all = (torch.tensor([0.0, 0.0, 0.0, 1.0], **f32a).repeat(n_all, 1)
-                                 if camera_orientations is None else camera_orientations.to(**f32a).contiguous())
-            camera_positions = self.cam_pos_all[self.view_begin:self.view_end]
-            camera_orientations = self.cam_quat_all[self.view_begin:self.view_end]
-            depth_images = depth_images[self.view_begin:self.view_end]
-        V, H, W = depth_images.shape
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        # every rank keeps the WHOLE camera list (the records form's tail chains over all views); its own shard's is a
+        # view of it.  Allocated once: ``rebind`` copies a new observation's cameras in place
+        self.cam_pos_all = torch.zeros((self.V_all, 3), **f32)
+        self.cam_quat_all = torch.zeros((self.V_all, 4), **f32)
+        self.cam_pos = self.cam_pos_all[self.view_begin:self.view_end]
+        self.cam_quat = self.cam_quat_all[self.view_begin:self.view_end]
+        V, H, W = self.view_end - self.view_begin, int(camera.height), int(camera.width)
+        if depth_images is not None and tuple(depth_images.shape[1:]) != (H, W):
+            raise ValueError(f"depth_images must be (V, {H}, {W}) for this camera, got {tuple(depth_images.shape)}")
         self.V, self.H, self.W = V, H, W
         self.defer_pose = bool(merge_launches) and V <= 64
         # the iteration's tail -- gradient chain, point constraint, Adam and the next iteration's view poses -- in
         # one launch (sdfr_loop_tail), the render pair in its step form: 26 -> 22 launches per iteration
         self.merge_tail = bool(merge_launches) and V <= 64
-        f32 = dict(dtype=torch.float32, device=self.dev)
-        self.target = depth_images.to(**f32).contiguous()
-        self.cam_pos = (torch.zeros((V, 3), **f32) if camera_positions is None
-                        else camera_positions.to(**f32).contiguous())
-        self.cam_quat = (torch.tensor([0.0, 0.0, 0.0, 1.0], **f32).repeat(V, 1) if camera_orientations is None
-                         else camera_orientations.to(**f32).contiguous())
-        helper = RenderAndCompare(decoder, camera, config, self.dev)
-        # compact patches: the sampler's backward pre-sums 256 consecutive points before its global atomics
-        self.points, self.offsets, lens = helper.prepare_views(self.target, tiled=True)
-        self.max_pts = max(lens) if lens else 0
+        self.target = torch.zeros((V, H, W), **f32)
+        # The observed point clouds at CAPACITY -- room for every pixel of every view, counts and offsets on the
+        # device (sdfr_depth_to_points_resident) -- so that a new observation changes no address, no grid size and
+        # needs no host read: the captured graphs stay valid.  The sampler's grids are sized for W * H points per
+        # view; blocks beyond a view's count leave at once (sampler_device.hpp), the reducers take the real lengths
+        # from `offsets`: the same sums in the same order as with exactly-sized buffers.
+        # (compact patches: the sampler's backward pre-sums 256 consecutive points before its global atomics)
+        self.max_pts = W * H
+        self.points = torch.zeros((V * W * H, 3), **f32)
+        self.offsets = torch.zeros(V + 1, dtype=torch.int32, device=self.dev)
+        self.counts = torch.zeros(V, dtype=torch.int32, device=self.dev)
+        self.ws_points = torch.empty(max(self.L.sdfr_depth_points_workspace_bytes(V, W, H), 256), dtype=torch.uint8,
+                                     device=self.dev)
         self.Lz = decoder.latent_size
         n = 8 + self.Lz
-        self.params = torch.zeros(n, **f32)
+        # the run's state in ONE buffer, [params | everything a run starts from zero]: one fill resets a run
+        n4 = (n + 3) // 4 * 4
+        self.max_history = int(config["max_iterations"])
+        nh = (max(self.max_history, 1) + 3) // 4 * 4
+        self._state = torch.zeros(4 * n4 + nh + 8, **f32)
+        self.params = self._state[0:n]
+        self.m = self._state[n4:n4 + n]
+        self.v = self._state[2 * n4:2 * n4 + n]
+        self.best_params = self._state[3 * n4:3 * n4 + n]
+        self.inlier_history = self._state[4 * n4:4 * n4 + max(self.max_history, 1)]
+        o = 4 * n4 + nh
+        self.best_state = self._state[o:o + 3]        # best ratio, its 1-based iteration, has_best
+        self.loss_con = self._state[o + 3:o + 4]      # the point constraint's loss value (0 without one)
+        ints = self._state[o + 4:o + 8].view(torch.int32)
+        self.step = ints[0:1]
+        self.inlier_counts = ints[1:3]
+        self._state_zero = self._state[n4:]           # (everything but the parameters)
         self.grads = torch.zeros(n, **f32)
-        self.m = torch.zeros(n, **f32)
-        self.v = torch.zeros(n, **f32)
-        self.step = torch.zeros(1, dtype=torch.int32, device=self.dev)
         R = decoder._volume_size
         self.R = R
         n_rec = self.V_all * VIEW_RECORD_FLOATS
@@ -368,8 +427,6 @@ class FusedRenderAndCompare:
                                     grad_tail_words=n_rec if (self.big_exchange and not self.det) else 0)
         self.xbuf = self.records = None
         if self.records_form:
-            if self.cam_pos_all is None:
-                self.cam_pos_all, self.cam_quat_all = self.cam_pos, self.cam_quat
             if self.big_exchange and self.det:     # [int64 volume | records]
                 self.xbuf = torch.zeros(R ** 3 + n_rec // 2, dtype=torch.int64, device=self.dev)
                 self.records = self.xbuf[R ** 3:].view(torch.float32)
@@ -392,7 +449,7 @@ class FusedRenderAndCompare:
         self.grad_est = None if self.fuse_depth_loss else torch.empty((V, H, W), **f32)
         self.loss_depth = torch.zeros((V,), **f32)
         self.loss_pc = torch.zeros((V,), **f32)
-        N = self.points.shape[0]
+        N = self.points.shape[0]     # (capacity)
         self.vals = None if self.fuse_depth_loss else torch.empty((max(N, 1),), **f32)
         self.grad_vals = None if self.fuse_depth_loss else torch.empty((max(N, 1),), **f32)
         self.g_sdf_pc = torch.empty((R, R, R), **f32)
@@ -409,20 +466,74 @@ class FusedRenderAndCompare:
         self.strategy = _selection_strategy(config)
         self.track_inliers = (self.strategy == "best_inlier_ratio") if track_inliers is None else bool(track_inliers)
         self.rel_thr = float(config.get("relative_inlier_threshold", 0.03))
-        self.max_history = int(config["max_iterations"])
-        self.inlier_history = torch.zeros(max(self.max_history, 1), **f32)
-        self.inlier_counts = torch.zeros(2, dtype=torch.int32, device=self.dev)
-        self.best_state = torch.zeros(3, **f32)        # best ratio, its 1-based iteration, has_best
-        self.best_params = torch.zeros(n, **f32)
-        if point_constraint is not None:
-            src, tgt, wgt = point_constraint
-            self.pc_source = torch.as_tensor(src, dtype=torch.float32).to(self.dev).contiguous()
-            self.pc_target = torch.as_tensor(tgt, dtype=torch.float32).to(self.dev).contiguous()
-            self.pc_weight = float(wgt)
-        else:
-            self.pc_source = None
-        self.loss_con = torch.zeros(1, **f32)
-        self.graph = None
+        # the point constraint's two points live in buffers of this object (``rebind`` copies new ones in place);
+        # whether there is one, and its weight, are launch ARGUMENTS and so part of a captured graph: graphs are kept
+        # per (constraint present, weight) -- a caller alternating between "none" and one weight captures twice, once
+        self._con_points = torch.zeros(8, **f32)
+        self.pc_source = None
+        self.pc_weight = 0.0
+        self._graphs = {}
+        self.graph = self.graph_many = self.graph_tail = None
+        self.bound = False
+        if depth_images is not None:
+            self.rebind(depth_images, camera_positions, camera_orientations, point_constraint)
+
+    def rebind(self, depth_images: torch.Tensor, camera_positions: Optional[torch.Tensor] = None,
+               camera_orientations: Optional[torch.Tensor] = None, point_constraint: Optional[Sequence] = None,
+               masks: Optional[torch.Tensor] = None, far_field: Optional[float] = None) -> "FusedRenderAndCompare":
+        """A NEW observation for the same views, image size and decoder: what the reference does by calling its
+        pipeline again (simple_setup.py:213-225, :333-334, :420-446).  The images go into this object's target
+        buffer, their point clouds are rebuilt on the device into the buffers the captured graphs already point at
+        (no allocation, no host synchronisation, no capture), the cameras and the constraint's points are copied in
+        place.  The next ``__call__`` starts a fresh run (Adam state, step count and inlier bookkeeping are reset
+        there) and replays the EXISTING graphs.
+        depth_images (V_all,H,W), every rank the full list, on any device (a host tensor costs its upload).
+        masks / far_field: ``SDFPipeline._preprocess_depth`` (:671-693) on the way -- depth_images is then modified IN
+        PLACE like the reference's argument (it must be a float32 CUDA tensor; masks a bool tensor of its shape)."""
+        if tuple(depth_images.shape) != (self.V_all, self.H, self.W):
+            raise ValueError(f"depth_images must have shape {(self.V_all, self.H, self.W)}, "
+                             f"got {tuple(depth_images.shape)}")
+        L, d, st = self.L, self.dev.index, self._stream()
+        b, e = self.view_begin, self.view_end
+        with torch.no_grad():
+            if masks is not None or far_field is not None:
+                preprocess_depth(depth_images, masks, far_field, copy_to=(self.target, b, e))
+            else:
+                self.target.copy_(depth_images[b:e])
+            if camera_positions is None:
+                self.cam_pos_all.zero_()
+            else:
+                self.cam_pos_all.copy_(camera_positions.reshape(self.V_all, 3))
+            if camera_orientations is None:
+                self.cam_quat_all.zero_()
+                self.cam_quat_all[:, 3] = 1.0
+            else:
+                self.cam_quat_all.copy_(camera_orientations.reshape(self.V_all, 4))
+            fx, fy, cx0, cy0, _ = self.cam.get_pinhole_camera_parameters(0.0)
+            self.check(L.sdfr_depth_to_points_resident(
+                self.target.data_ptr(), self.V, self.W, self.H, 1, 1.0 / fx, 1.0 / fy, cx0, cy0,
+                self.counts.data_ptr(), self.offsets.data_ptr(), self.ws_points.data_ptr(), self.ws_points.numel(),
+                self.points.data_ptr(), d, st), "sdfr_depth_to_points_resident")
+            if point_constraint is not None:
+                src, tgt, wgt = point_constraint
+                self._con_points[0:3].copy_(torch.as_tensor(src).reshape(3))
+                self._con_points[4:7].copy_(torch.as_tensor(tgt).reshape(3))
+                self.pc_source, self.pc_target = self._con_points[0:3], self._con_points[4:7]
+                self.pc_weight = float(wgt)
+            else:
+                self.pc_source, self.pc_weight = None, 0.0
+        key = None if self.pc_source is None else self.pc_weight
+        self.graph, self.graph_many, self.graph_tail = self._graphs.get(key, (None, None, None))
+        self._graph_key = key
+        self.bound = True
+        return self
+
+    def _keep_graphs(self):
+        self._graphs[self._graph_key] = (self.graph, self.graph_many, self.graph_tail)
+
+    def view_point_counts(self) -> torch.Tensor:
+        """observed points per view of this rank's shard, (V,) int32 on the device (reading it synchronises)"""
+        return self.counts
 
     # views of the parameter buffer
     @property
@@ -590,18 +701,14 @@ class FusedRenderAndCompare:
             self._decode(st, True)
         sdf = self.sdf[0, 0]
         self.plan.ring_reset()       # always the plan's first volume: the bucket's address is part of captured graphs
-        have_pts = self.max_pts > 0
+        # (views without an observed point: their sampler blocks leave at once, their point-cloud loss is the NaN of
+        # torch.mean over nothing, simple_setup.py:144, and they contribute no gradient -- as in the reference)
+        have_pts = True
         self.plan.forward_l1(sdf, self.pos_c, self.quat_c, self.inv_scale, self.cfg["threshold"], self.target,
-                             prepare_backward=have_pts)
-        if have_pts:
-            g_sdf = self.plan.backward_l1_pc(self.target, sdf, self.pos_c, self.quat_c, self.inv_scale, self.scale_v,
-                                             self.points, self.offsets, self.max_pts, self.ws_pc,
-                                             weight=self.cfg["depth_weight"], pc_weight=self.cfg["pc_weight"])
-        else:       # none of this rank's views has an observed point: the depth term alone
-            self.plan.select_volume(0)
-            g_sdf = self.plan.backward_l1(self.target, sdf, self.pos_c, self.quat_c, self.inv_scale,
-                                          weight=self.cfg["depth_weight"], defer_pose=True)[0]
-            self.plan.partials_offset = L.sdfr_render_partials_offset(self.R, self.V, self.W, self.H, 0)
+                             prepare_backward=True)
+        g_sdf = self.plan.backward_l1_pc(self.target, sdf, self.pos_c, self.quat_c, self.inv_scale, self.scale_v,
+                                         self.points, self.offsets, self.max_pts, self.ws_pc,
+                                         weight=self.cfg["depth_weight"], pc_weight=self.cfg["pc_weight"])
         if self.shape_opt and self.exchange == "latent":
             # the whole VJP on this rank's volume: d loss / d latent is what travels
             self.check(L.sdfr_decoder_backward_latent(self.dec._h, self.latent.data_ptr(), self.tape.data_ptr(),
@@ -673,8 +780,7 @@ class FusedRenderAndCompare:
         return self.loss_depth, self.loss_pc
 
     def _run_records(self, n_iter, use_graph, history):
-        state = (self.params, self.m, self.v, self.step, self.inlier_counts, self.best_state, self.inlier_history,
-                 self.best_params)
+        state = (self._state,)
         if self.group is None:
             return self._run_records_single(n_iter, use_graph, history, state)
         if use_graph and self.graph is None:
@@ -705,6 +811,7 @@ class FusedRenderAndCompare:
             for t, c in zip(state, saved):
                 t.copy_(c)
             self._poses_to_views(self._stream())
+            self._keep_graphs()
         fused = use_graph and history is None
         for it in range(n_iter):
             if not use_graph:
@@ -755,6 +862,7 @@ class FusedRenderAndCompare:
             for t, c in zip(state, saved):
                 t.copy_(c)
             self._poses_to_views(self._stream())
+            self._keep_graphs()
         done = 0
         if use_graph and history is None and self.graph_many is not None:
             for _ in range(n_iter // self.graph_iterations):
@@ -795,13 +903,15 @@ class FusedRenderAndCompare:
                  history: Optional[List] = None):
         """Run config['max_iterations'] iterations from the given initial estimate; returns
         (position (1,3), orientation (1,4), scale (1,), latent (1,L))."""
+        if not self.bound:
+            raise RuntimeError("no observation bound: call rebind(depth_images, ...) first")
         with torch.no_grad():
             self.params[0:3] = position.reshape(3)
             self.params[3:7] = orientation.reshape(4)
             self.params[7:8] = scale.reshape(1)
             self.params[8:] = latent.reshape(-1)
-            self.m.zero_(); self.v.zero_(); self.step.zero_(); self.grads.zero_()
-            self.inlier_counts.zero_(); self.best_state.zero_(); self.inlier_history.zero_()
+            self._state_zero.zero_()     # Adam's moments and step count, inlier history, counts and best-so-far state
+            self.grads.zero_()
         if not self.shape_opt:
             self._decode(self._stream(), False)
         n_iter = self.cfg["max_iterations"]
@@ -814,8 +924,7 @@ class FusedRenderAndCompare:
             self._poses_to_views(self._stream())   # every later iteration gets its view poses from the tail before it
         if use_graph and self.graph is None:
             # warm up on a side stream (lazy module loads), restore the state, then capture
-            state = (self.params, self.m, self.v, self.step, self.inlier_counts, self.best_state,
-                     self.inlier_history, self.best_params)
+            state = (self._state,)
             saved = [t.clone() for t in state]
             s = torch.cuda.Stream(self.dev)
             s.wait_stream(torch.cuda.current_stream(self.dev))
@@ -836,6 +945,7 @@ class FusedRenderAndCompare:
                 t.copy_(c)   # the capture itself does not execute, but keep the state explicit
             if self._tail_form():
                 self._poses_to_views(self._stream())   # the warm-up's tail left the poses of ITS updated parameters
+            self._keep_graphs()
         done = 0
         if use_graph and history is None and self.graph_many is not None:
             for _ in range(n_iter // self.graph_iterations):

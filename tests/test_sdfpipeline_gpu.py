@@ -1,0 +1,175 @@
+"""GPU: ``sdfest_amd.SDFPipeline`` -- the reference's front door (simple_setup.py:35-89, :213-226, :583-596) on top of
+the re-bindable captured loop.  Driven the way a caller of the reference drives it: config dictionary of
+``estimation/configs/default.yaml`` + ``configs/models/mug.yaml`` keys, ``pipeline(depth_images, masks,
+color_images, ...)``, a 4-tuple back."""
+import copy
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN
+from sdfest_amd.synthetic import MUG_INIT_BACKBONE, MUG_INIT_HEAD, init_network_state
+
+pytestmark = pytest.mark.gpu
+
+T = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device="cuda")
+
+
+def mug_vae_config():
+    from test_decoder_gpu import mug_config
+    d = np.load(os.path.join(GOLDEN, "decoder_mug.npz"))
+    return mug_config(d)
+
+
+def mug_weights():
+    w = np.load(os.path.join(GOLDEN, "mug_decoder_weights.npz"))
+    return {k: w[k] for k in w.files}
+
+
+def plausible_init_state(seed=7):
+    """the seeded random SDFPoseNet weights (the trained ones are not in the reference repository) with a final layer
+    that answers like a trained network would: latent ~ 0, position ~ the centroid of the observed points, half-width
+    ~ 0.06 -- and whatever orientation cell its small logits favour"""
+    st = {k: v.copy() for k, v in init_network_state(seed).items()}
+    st["_head._final_layer.weight"] *= 0.01
+    b = st["_head._final_layer.bias"]
+    b *= 0.01
+    b[8:11] += np.array([0.004, -0.003, 0.005], dtype=np.float32)
+    b[11] = 0.06
+    return st
+
+
+def make_config(W, H, fx, fy, cx, cy, thr, n_iter, **extra):
+    """estimation/configs/default.yaml:1-19 + configs/models/mug.yaml (vae, init, far_field)"""
+    cfg = {"camera": {"width": W, "height": H, "fx": fx, "fy": fy, "cx": cx, "cy": cy, "pixel_center": 0.5},
+           "threshold": thr, "device": "cuda", "iso_threshold": 0.02, "max_iterations": n_iter, "depth_weight": 1.0,
+           "pc_weight": 3.0, "nn_weight": 0.0, "mean_shape": False, "init_view": "first", "shape_init": "prediction",
+           "vae": dict(mug_vae_config(), model="~/.sdfest/model_weights/mug_vae.pt"),
+           "init": {"backbone_type": "VanillaPointNet", "backbone": dict(MUG_INIT_BACKBONE), "head_type": "SDFPoseHead",
+                    "head": dict(MUG_INIT_HEAD), "normalize_pose": True, "model": "~/.sdfest/model_weights/mug_init.pt"},
+           "far_field": 2.0}
+    cfg.update(extra)
+    return cfg
+
+
+@pytest.fixture(scope="module")
+def g7():
+    d = np.load(os.path.join(GOLDEN, "loop_g7.npz"))
+    return {k: d[k] for k in d.files}
+
+
+def test_call_reproduces_g7_run_c(g7):
+    """G7 run C (2 views, 160x120, shape optimisation on: iterations of simple_setup.py:381-470 assembled from imported
+    reference pieces) through the front door: its images, all-true masks, a fixed stand-in for the initialisation
+    network -> the golden trajectory's end point, at the loop test's bound (0.5 % of an Adam step per iteration)."""
+    from sdfest_amd import SDFPipeline
+    W, H = int(g7["c_W"]), int(g7["c_H"])
+    n_iter = g7["c_traj"].shape[0]
+    cfg = make_config(W, H, float(g7["c_fx"]), float(g7["c_fy"]), float(g7["c_cx"]), float(g7["c_cy"]), float(g7["thr"]),
+                      n_iter, result_selection_strategy="best_inlier_ratio", far_field=50.0)
+    init = g7["c_init"]
+    seen = {}
+
+    def fixed_init(depth_images, cam_pos, cam_quat, prior, train_prior):
+        seen["shapes"] = (tuple(depth_images.shape), tuple(cam_pos.shape), tuple(cam_quat.shape))
+        return T(init[None, 8:]), T(init[None, 0:3]), T(init[7:8]), T(init[None, 3:7])       # latent, position, scale, q
+
+    pipe = SDFPipeline(cfg, vae_state_dict=mug_weights(), init_network=fixed_init)
+    depth = T(g7["c_depth_images"])
+    masks = torch.ones_like(depth, dtype=torch.bool)
+    color = torch.zeros(depth.shape + (3,), device="cuda")
+    out = pipe(depth.clone(), masks, color, camera_positions=T(g7["c_cam_pos"]), camera_orientations=T(g7["c_cam_quat"]))
+    torch.cuda.synchronize()
+    assert seen["shapes"] == ((2, H, W), (2, 3), (2, 4))
+    assert [tuple(t.shape) for t in out] == [(1, 3), (1, 4), (1,), (1, 8)]
+    got = np.concatenate([t.cpu().numpy().ravel() for t in out])
+    lr = np.array([1e-3] * 3 + [1e-2] * 4 + [1e-3] + [1e-2] * 8)
+    err = np.abs(got - g7["c_traj"][-1]) / lr
+    assert err.max() < 0.005 * n_iter, err
+    # the inlier bookkeeping of :463-470 ran (best_inlier_ratio) and agrees with the golden
+    inl = g7["c_inlier"]
+    hist = pipe._last_loop.inlier_history.cpu().numpy()[:len(inl)]
+    n_valid = float((g7["c_depth_images"][-1] > 0).sum())
+    assert np.max(np.abs(hist - inl)) < 1.5 / n_valid + 1e-6
+    ratio, it, params = pipe.best_estimate()
+    assert it == int(np.argmax(hist)) + 1
+    # the same object takes the next observation without building or capturing anything
+    loop, graph = pipe._last_loop, pipe._last_loop.graph
+    out2 = pipe(depth.clone(), masks, color, camera_positions=T(g7["c_cam_pos"]), camera_orientations=T(g7["c_cam_quat"]))
+    assert pipe._last_loop is loop and loop.graph is graph and len(pipe._loops) == 1
+    for a, b, tol in zip(out, out2, (2e-6, 2e-5, 2e-6, 5e-5)):       # (d/dSDF by float atomics: ~1e-7 per iteration)
+        assert (a - b).abs().max().item() <= tol
+
+
+def test_front_door_semantics_with_the_real_initialisation_network():
+    """one (H,W) image: batch dimension added (:306-318); depth masked and far-field-clipped IN PLACE (:333-334,
+    :671-693); the initialisation network's estimate is what the loop starts from (:352-359); pose-only runs keep the
+    latent (:413-414); ignored arguments warn once; an empty mask raises NoDepthError (:780-781)."""
+    from sdfest_amd import Camera, NoDepthError, SDFPipeline, render_depth_gpu
+    from sdfest_amd.init_network import nn_init
+    from sdfest_amd.pipeline import FusedRenderAndCompare
+    W, H = 160, 120
+    cfg = make_config(W, H, 150.0, 150.0, 80.0, 60.0, 0.005, 6, far_field=0.62)
+    pipe = SDFPipeline(cfg, vae_state_dict=mug_weights(), init_state_dict=plausible_init_state())
+    assert pipe.cam.width == W and pipe.resolution == 64 and callable(pipe.render)
+    d = np.load(os.path.join(GOLDEN, "decoder_mug.npz"))
+    z_true = T(d["z"][9:10]) * 0.5
+    q_true = T([0.2, 0.6, -0.15, 0.75]); q_true = q_true / q_true.norm()
+    with torch.no_grad():
+        scene = pipe.generate_depth(T([0.02, -0.01, -0.5]), q_true, T(0.055), z_true)        # :609-619
+        ref = render_depth_gpu(pipe.vae.decode(z_true)[0, 0], T([0.02, -0.01, -0.5]), q_true, 1 / T(0.055), None, None,
+                               None, 0.005, pipe.cam)
+    assert torch.equal(scene, ref) and (scene > 0).sum() > 400
+    depth = scene.clone()
+    depth[depth == 0] = 1.0                      # a background wall the mask must remove
+    depth[0:4, 0:4] = 0.7                        # inside the mask, beyond the far field
+    mask = scene > 0
+    mask[0:4, 0:4] = True
+    expect = depth.clone(); expect[~mask] = 0; expect[expect > 0.62] = 0
+    assert (expect > 0).sum() == (scene > 0).sum()
+    color = torch.zeros((H, W, 3), device="cuda")
+    arg = depth.clone()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = pipe(arg, mask, color, visualize=True, log_path="/nonexistent/log.pkl", shape_optimization=False)
+        out_again = pipe(depth.clone(), mask, color, visualize=True, shape_optimization=False)
+    assert len([x for x in w if "ignored" in str(x.message)]) == 1
+    assert torch.equal(arg, expect)                                                    # preprocessed in place
+    # what the call did, step by step
+    cam_pos, cam_quat = torch.zeros(1, 3, device="cuda"), T([[0, 0, 0, 1.0]])
+    z0, p0, s0, q0 = nn_init(pipe.init_network, pipe.cam, expect[None], cam_pos, cam_quat, cfg, normalize_pose=True)
+    assert abs(float(q0.norm()) - 1.0) < 1e-5 and z0.shape == (1, 8)
+    assert 0.04 < float(s0) < 0.08 and (p0 - T([[0.02, -0.01, -0.5]])).abs().max() < 0.06     # a usable starting point
+    loop = FusedRenderAndCompare(pipe.vae, pipe.cam, cfg, expect[None].contiguous(), shape_optimization=False)
+    want = loop(p0, q0, s0, z0)
+    for a, b, c in zip(out, want, out_again):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    assert torch.equal(out[3], z0)                                                     # pose only: the latent stays
+    assert (out[0] - p0).abs().max() > 1e-3                                            # ... and the pose moved
+    # with shape optimisation: another loop object beside the first, the latent moves
+    out_s = pipe(depth.clone(), mask, color)
+    assert len(pipe._loops) == 2 and (out_s[3] - z0).abs().max() > 1e-3
+    with pytest.raises(NoDepthError):
+        pipe(depth.clone(), torch.zeros_like(mask), color)
+    # weights are never downloaded
+    with pytest.raises(FileNotFoundError):
+        SDFPipeline(cfg, init_state_dict=plausible_init_state())
+    bad = copy.deepcopy(cfg); bad["result_selection_strategy"] = "median"
+    with pytest.raises(ValueError):
+        SDFPipeline(bad, vae_state_dict=mug_weights(), init_state_dict=plausible_init_state())
+
+
+def test_adjust_categorical_posterior_known_answers_of_the_reference_suite():
+    """tests/estimation/test_simple_setup.py:6-26, the reference's only test of this module, on the front door's
+    static method"""
+    from sdfest_amd import SDFPipeline
+    posterior = torch.tensor([0.8, 0.2, 0.0, 0.0])
+    train_prior = torch.tensor([0.4, 0.4, 0.1, 0.1])
+    same = SDFPipeline._adjust_categorical_posterior(posterior, torch.tensor([0.25, 0.25, 0.25, 0.25]), train_prior)
+    assert torch.allclose(same, posterior)
+    adj = SDFPipeline._adjust_categorical_posterior(posterior, torch.tensor([0.1, 0.4, 0.25, 0.25]), train_prior)
+    exp = torch.tensor([0.8 * 0.1 / 0.4, 0.2 * 0.4 / 0.4, 0.0, 0.0])
+    assert torch.allclose(adj, exp / exp.sum())

@@ -389,27 +389,66 @@ def c5_scene(views=1, max_iterations=50):
 
 def c5_config(hbm_peak):
     """C5: the whole render-and-compare loop (simple_setup.py:408-470) as one hipGraph per iteration, 50 Adam
-    iterations, mug decoder; ms per iteration and the final pose error."""
+    iterations, mug decoder; ms per iteration, the final pose error, and TIME TO RESULT the way the reference is used
+    -- one call per detected object with fresh depth images (simple_setup.py:213-225): the first call of a process
+    (buffers, warm-up iteration, graph captures, 50 iterations) and every later observation (rebind + 50 iterations on
+    the existing graphs)."""
+    from sdfest_amd import render_depth_gpu
     from sdfest_amd.pipeline import FusedRenderAndCompare
     sc = c5_scene()
-    fused = FusedRenderAndCompare(sc["decoder"], sc["camera"], sc["config"], sc["targets"])
-    fused(*sc["init"])   # builds the graph
+    n_it = sc["config"]["max_iterations"]
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fused = FusedRenderAndCompare(sc["decoder"], sc["camera"], sc["config"], sc["targets"])
+    fused(*sc["init"])   # warm-up iteration, captures, 50 iterations
+    torch.cuda.synchronize()
+    ms_first = (time.perf_counter() - t0) * 1e3
     times = []
     out = None
     for _ in range(5):
         t0 = time.perf_counter()
         out = fused(*sc["init"])
         torch.cuda.synchronize()
-        times.append((time.perf_counter() - t0) / sc["config"]["max_iterations"] * 1e3)
+        times.append((time.perf_counter() - t0) / n_it * 1e3)
     ms = float(np.median(times))
+    # a NEW observation per run: the same object seen from two other poses, alternating with the first image
+    dev = sc["targets"].device
+    others = []
+    with torch.no_grad():
+        z = torch.tensor(np.load(os.path.join(ROOT, "tests", "golden", "decoder_mug.npz"))["z"][10:11], device=dev) * 0.4
+        sdf = sc["decoder"].decode(z)[0, 0]
+        for dp, dq in (((0.03, 0.02, -0.02), (0.1, -0.2, 0.05, 0.0)), ((-0.04, 0.01, 0.05), (-0.15, 0.1, 0.2, 0.0))):
+            q = sc["q_true"] + torch.tensor([dq], device=dev)
+            others.append(render_depth_gpu(sdf, (sc["p_true"] + torch.tensor([dp], device=dev))[0], (q / q.norm())[0],
+                                           1 / sc["s_true"][0], None, None, None, 0.005, sc["camera"])[None].contiguous())
+    obs = [others[0], sc["targets"], others[1], sc["targets"], others[0], others[1], sc["targets"]]
+    totals, rebinds = [], []
+    graph = fused.graph
+    for o in obs:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fused.rebind(o)
+        t1 = time.perf_counter()
+        out = fused(*sc["init"])
+        torch.cuda.synchronize()
+        totals.append((time.perf_counter() - t0) * 1e3)
+        rebinds.append((t1 - t0) * 1e3)
+    assert fused.graph is graph     # nothing was captured again
     q = out[1] / out[1].norm()
     dot = float(torch.abs((q * sc["q_true"]).sum()).clamp(max=1.0))
     # algorithmic bytes of one iteration (SURVEY 8d): render fwd+bwd of one view + decoder weights + volume
     bytes_it = 12 * 640 * 480 + 12 * 64 ** 3 + 32 + 1721148 + 4 * 64 ** 3
     return {"workload": "C5: decoder(z) -> 64^3 SDF -> render-and-compare of one 640x480 view, 50 Adam iterations, "
-                        "mug decoder weights (tests/golden), one hipGraph replay per iteration",
-            "ms_per_iteration": round(ms, 4), "iterations": sc["config"]["max_iterations"],
+                        "mug decoder weights (tests/golden), one hipGraph replay per 5 iterations",
+            "ms_per_iteration": round(ms, 4), "iterations": n_it,
+            "ms_first_call_total": round(ms_first, 2),
+            "ms_new_observation_total": round(float(np.median(totals)), 3),
+            "ms_new_observation_all": [round(t, 3) for t in totals],
+            "ms_rebind_host": round(float(np.median(rebinds)), 3),
+            "time_to_result": "ms_first_call_total = constructor (buffers at capacity) + warm-up iteration + graph "
+                              "captures + 50 iterations, first use of these kernels in the process; "
+                              "ms_new_observation_total = rebind(new 640x480 image already in HBM) + 50 iterations "
+                              "+ synchronize, existing graphs, wall clock, median of 7 alternating observations",
             "final_position_error_mm": round(float((out[0] - sc["p_true"]).norm()) * 1e3, 3),
             "final_orientation_error_deg": round(float(np.degrees(2 * np.arccos(dot))), 3),
             "final_scale_error_rel": round(float(abs(out[2] - sc["s_true"]) / sc["s_true"]), 4),
