@@ -4,7 +4,7 @@
 Metric (BASELINE.json): depth renders/sec fwd+bwd, 640x480 @ 64^3 SDF; grad max-abs-err vs ref.
 The line carries both halves: `value` (renders/s) and `grad_max_abs_err` (d/dSDF, + the `grad_*` keys beside it and
 `parity`), the errors of the benchmarked build's last step against the oracle.  After the headline it appends BASELINE.json's
-other single-GPU configurations (`configs`: C1, C2 with the CPU port beside them, C5).
+other single-GPU configurations (`configs`: C1, C2 with the CPU port beside them, C5 with its time to result, C3_l1).
 
 Workload per GPU ("C3", BASELINE.json configs[2]): 256 seeded random
 poses of the synthetic blobs(0) 64^3 SDF at 640x480, threshold 0.005, upstream gradient
@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the gradient-error report against the oracle")
-    ap.add_argument("--no-configs", action="store_true", help="skip the C1 / C2 / C5 side measurements")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C1 / C2 / C5 / C3_l1 side measurements")
     ap.add_argument("--prewarm-ms", type=float, default=300.0,
                     help="untimed steps before the warm-up steps until this much wall time has passed (clock ramp)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="views in the CPU sample (0 = auto)")

@@ -36,6 +36,32 @@
  *                        sdf_renderer.py:116-133)
  *   B views share one SDF (sdf_view_stride = 0) or have one each
  *   (sdf_view_stride = R*R*R elements).
+ *
+ * CONTENTS -- four groups; a binding from another language needs group 1 only
+ *   1. CORE: the reference boundary (what sdf_renderer_cpp, losses.pc_loss and SDFDecoder.forward are replaced by)
+ *        sdfr_version, sdfr_last_error
+ *        sdfr_render_forward[_workspace_bytes], sdfr_render_backward[_workspace_bytes]
+ *        sdfr_pc_loss_forward, sdfr_pc_loss_backward[_workspace_bytes]
+ *        sdfr_decoder_create / _destroy / _forward / _workspace_bytes / _tape_bytes,
+ *        sdfr_decoder_backward_latent[_workspace_bytes], sdfr_decoder_set_option
+ *   2. BATCHED / STEP forms of the same arithmetic (fewer launches, fewer bytes; same results)
+ *        sdfr_render_step_forward[_counted] / _step_backward / _step_workspace_bytes, sdfr_render_sync_offset,
+ *        sdfr_render_partials_offset, sdfr_render_fixed_volume_offset, sdfr_fixed_to_float
+ *        sdfr_render_forward_l1[_workspace_bytes], sdfr_render_backward_l1, sdfr_render_step_forward_l1,
+ *        sdfr_render_step_backward_l1, sdfr_render_backward_l1_pc, sdfr_render_step_backward_l1_pc
+ *        sdfr_pc_l1_backward[_accumulate]
+ *   3. LOOP: one render-and-compare iteration (SDFPipeline.__call__) as a fixed launch sequence
+ *        sdfr_preprocess_depth, sdfr_depth_to_points_resident, sdfr_depth_count[_ordered|_centroid],
+ *        sdfr_depth_to_points[_ordered|_shifted], sdfr_depth_points_workspace_bytes, sdfr_depth_centroid_workspace_bytes
+ *        sdfr_pose_to_views, sdfr_views_to_pose_grad[_deferred], sdfr_decoder_backward_latent_deferred,
+ *        sdfr_loop_tail, sdfr_adam_step, sdfr_point_constraint, sdfr_add_inplace
+ *        sdfr_depth_l1_loss[_workspace_bytes], sdfr_pc_l1_loss, sdfr_inlier_ratio, sdfr_nn_loss_forward / _backward
+ *        sharded over ranks: sdfr_loop_view_records, sdfr_loop_tail_records, sdfr_inlier_counts_record,
+ *        sdfr_inlier_update_record
+ *   4. GENERATOR / INITIALISATION (the forward-only callers around the loop)
+ *        sdfr_affine_mask; sdfr_pointnet_layer, sdfr_linear_vec, sdfr_orientation_posterior
+ * (Within the file the groups follow the order in which the reference's code runs; every declaration carries the
+ * reference file:line it replaces.)
  */
 #ifndef SDFR_H_
 #define SDFR_H_
@@ -85,7 +111,8 @@ extern "C" {
  * per workgroup, one after the other -- results are the same whether the hint is true or not, but such views are
  * slower with it (objects of ~1 pixel per voxel: 103 -> 174 us).  The poses live in device memory: a caller that
  * does not know them asks the forward to count the close views (sdfr_render_step_forward_counted) and sets the
- * hint from an earlier step's count.  Ignored for small calls and for the loss-fused and deterministic forms. */
+ * hint from an earlier step's count.  Ignored for small calls, for the deterministic forms and where the sampler's
+ * blocks share the launch (sdfr_render_*backward_l1_pc). */
 #define SDFR_BWD_HALF_GRID 0x200
 /* Flag bit, OR-ed into sdf_grad_mode: the backward always uses its 32 x 8 tiling, whatever the batch size.  A
  * view's pose gradients are fixed-order sums over ITS tiles, so with this flag they do not depend on how many
@@ -97,6 +124,7 @@ extern "C" {
 SDFR_API int sdfr_version(void);
 SDFR_API const char* sdfr_last_error(void);
 
+/* ==== 1. CORE ================================================================================= */
 /* ---- sphere-tracing depth render -------------------------------------------------------- */
 
 /* Scratch for sdfr_render_forward (per-view set-up records + the re-packed grid, see
@@ -107,7 +135,12 @@ SDFR_API const char* sdfr_last_error(void);
  *   word 1 (uint32)  count of view set-ups that did NOT receive the plane minima in time and fell back to the
  *                    whole cube as their may-hit box (same depth, slower march); it only ever grows, so a caller
  *                    that zero-fills the workspace once can read "how often did that happen" at any time.
+ *   words 6, 7       {SDFR_SYNC_POLLS_MAGIC, rounds}: the caller's bound of the prologue's wait for the plane minima,
+ *                    in polling rounds, for the forwards on THIS workspace (default 65536; 0: every view set-up takes
+ *                    the fall-back path -- tests reach it this way).  Any other word 6 -- a zero-filled or an
+ *                    uninitialised workspace -- means the default.  The library only reads them.
  * No call writes into another call's part of a shared workspace's sync region. */
+#define SDFR_SYNC_POLLS_MAGIC 0x504F4C4Cu
 SDFR_API size_t sdfr_render_forward_workspace_bytes(int R, int B, int W, int H);
 SDFR_API size_t sdfr_render_sync_offset(int B);
 
@@ -117,11 +150,6 @@ SDFR_API size_t sdfr_render_sync_offset(int B);
  * integer all-reduce over the ranks of a sharded batch). */
 SDFR_API size_t sdfr_render_fixed_volume_offset(int R, int B, int W, int H, int step_layout);
 SDFR_API int sdfr_fixed_to_float(const long long* fixed, size_t n, float* out, int device, void* stream);
-
-/* TEST HOOK: bound of the prologue's wait for the plane minima, in polling rounds (default 65536; 0 forces the
- * fall-back path described above for every view; negative restores the default).  Process-wide; returns the old
- * value. */
-SDFR_API int sdfr_debug_set_prologue_polls(int max_polls);
 
 /* Replaces sdf_renderer_cpp.forward (sdf_renderer.cpp:42-61 ->
  * sdf_renderer_cuda.cu:472-510, kernel :241-298), extended by a leading batch
@@ -155,6 +183,7 @@ SDFR_API int sdfr_render_backward(const float* grad_depth, const float* depth, c
                          float* g_inv_scale, void* workspace, size_t workspace_bytes, int device,
                          void* stream);
 
+/* ==== 2. BATCHED / STEP forms ================================================================= */
 /* ---- one step = forward + backward of the SAME views ---------------------------------------- */
 
 /* The reference's render-and-compare loop always runs the two halves as a pair:
@@ -199,19 +228,36 @@ SDFR_API int sdfr_render_step_forward_counted(const float* sdf, int R, long long
 /* The same pair for the loss-fused forms (below): sdfr_render_step_forward_l1 = sdfr_render_forward_l1 that also
  * zero-fills g_sdf and leaves the view records; sdfr_render_step_backward_l1_pc = sdfr_render_backward_l1_pc without
  * its prologue launch.  For a few views of the plain grid the forward has no prologue launch either (every
- * workgroup derives its view's record): the captured loop's iteration loses two launches. */
+ * workgroup derives its view's record): the captured loop's iteration loses two launches.  close_views_word
+ * (nullable): as in sdfr_render_step_forward_counted -- the half-grid hint of sdfr_render_step_backward_l1. */
 SDFR_API int sdfr_render_step_forward_l1(const float* sdf, int R, long long sdf_view_stride, const float* pos,
                                 const float* quat, const float* inv_scale, int B, int W, int H, float cx, float cy,
                                 float fx, float fy, float threshold, const float* target, float* depth, float* loss,
                                 float* loss_stats, float* g_sdf, long long g_sdf_view_stride, void* workspace,
-                                size_t workspace_bytes, int device, void* stream);
+                                size_t workspace_bytes, unsigned long long* close_views_word, int device,
+                                void* stream);
 SDFR_API int sdfr_render_step_backward_l1_pc(
     const float* loss_grad, float loss_weight, const float* loss_stats, const float* target, const float* depth,
     const float* sdf, int R, long long sdf_view_stride, const float* pos, const float* quat, const float* inv_scale,
     int B, int W, int H, float cx, float cy, float fx, float fy, int sdf_grad_mode, float* g_sdf,
     long long g_sdf_view_stride, void* workspace, size_t workspace_bytes, float pc_weight, const float* points,
     const int* offsets, int max_view_points, const float* scale, void* pc_workspace, size_t pc_workspace_bytes,
-    int device, void* stream);
+    float* loss, float* loss_stats_out, int device, void* stream);
+/* sdfr_render_step_backward_l1 = sdfr_render_backward_l1 as the second half of a step begun by
+ * sdfr_render_step_forward_l1 (no prologue launch, the forward's view records and rectangles; pos / quat / inv_scale
+ * are not passed again) -- the loss-fused form of sdfr_render_step_backward.
+ * DEFERRED LOSS (both step backward forms): a step's forward called with loss = loss_stats = NULL leaves its per-tile
+ * (sum, count) records unreduced -- no reduce launch between the two image kernels -- and the step's backward is then
+ * given loss_stats = NULL and the two OUTPUTS loss [B], loss_stats_out [B][2]: every backward tile with a hit pixel
+ * sums its view's counts itself (integers: exact in any order, so the upstream gradient is the same bit for bit) and
+ * one workgroup per view writes loss / loss_stats_out in the reduce launch's fixed order (the same bits too), valid
+ * after this call.  loss = loss_stats_out = NULL: loss_stats comes from the forward, as before. */
+SDFR_API int sdfr_render_step_backward_l1(const float* loss_grad, float loss_weight, const float* loss_stats,
+                                 const float* target, const float* depth, const float* sdf, int R,
+                                 long long sdf_view_stride, int B, int W, int H, float cx, float cy, float fx,
+                                 float fy, int sdf_grad_mode, float* g_sdf, long long g_sdf_view_stride, float* g_pos,
+                                 float* g_quat, float* g_inv_scale, void* workspace, size_t workspace_bytes,
+                                 float* loss, float* loss_stats_out, int device, void* stream);
 /* byte offset of the backward's tile partials in its workspace (step_layout: of a step's workspace) */
 SDFR_API size_t sdfr_render_partials_offset(int R, int B, int W, int H, int step_layout);
 SDFR_API int sdfr_render_step_backward(const float* grad_depth, const float* depth, const float* sdf, int R,
@@ -252,6 +298,7 @@ SDFR_API int sdfr_render_backward_l1(const float* loss_grad, float loss_weight, 
                             float* g_inv_scale, void* workspace, size_t workspace_bytes, int device,
                             void* stream);
 
+/* ==== 1. CORE (continued) ===================================================================== */
 /* ---- trilinear SDF sampler of the point-cloud loss --------------------------------------- */
 
 /* Replaces losses.pc_loss (sdfest/estimation/losses.py:32-135), for all views of a step at once.
@@ -325,11 +372,22 @@ SDFR_API int sdfr_decoder_forward(const sdfr_decoder* decoder, const float* z, i
                          float* out, float* tape, void* workspace, size_t workspace_bytes,
                          void* stream);
 
-/* TEST HOOK: how batched forwards treat an up-sampling resize in front of a 3x3x3 layer: 1 (default) inside that
- * layer's patch load where that is faster (fine sizes up to 16), 2 wherever the folded form exists (fine sizes 16, 32,
- * 64), 0 always as its own launch.  Same results bit for bit: tests compare 2 against 0.  Process-wide; returns the old
- * value. */
-SDFR_API int sdfr_debug_set_decoder_fused_resize(int on);
+/* Which of two equivalent kernel forms the calls on ONE decoder handle take.  The defaults are the measured-faster forms;
+ * the results are the same bit for bit either way (the tests compare the forms through this call).  Per handle: nothing
+ * is process-wide.  Returns the option's old value (>= 0) or SDFR_E_INVALID / SDFR_E_NULL.
+ *   SDFR_DECODER_OPT_FUSED_RESIZE  how batched forwards treat an up-sampling resize in front of a 3x3x3 layer: 1 (default)
+ *                                  inside that layer's patch load where that is faster (fine sizes up to 16), 2 wherever
+ *                                  the folded form exists (fine sizes 16, 32, 64), 0 always as its own launch
+ *   SDFR_DECODER_OPT_TILED_VJP     1 (default): the transposed resizes of the VJP in one launch each (an LDS-staged block
+ *                                  per workgroup); 0: the three single-axis launches it replaces
+ *   SDFR_DECODER_OPT_FC_ONE_WAVE   1 (default): the backward of a NARROW Linear stack (every layer input <= 64 wide, e.g.
+ *                                  the mug decoder's 8 -> 20 -> 50) runs as one wave out of LDS -- in
+ *                                  sdfr_decoder_backward_latent and inside sdfr_loop_tail[_records]; 0: the one-workgroup
+ *                                  form wider stacks take */
+#define SDFR_DECODER_OPT_FUSED_RESIZE 0
+#define SDFR_DECODER_OPT_TILED_VJP 1
+#define SDFR_DECODER_OPT_FC_ONE_WAVE 2
+SDFR_API int sdfr_decoder_set_option(sdfr_decoder* decoder, int option, int value);
 /* Vector-Jacobian product of the decoder w.r.t. the latent, weights held constant: what
  * loss.backward() propagates to latent_shape in SDFPipeline.__call__
  * (sdfest/estimation/simple_setup.py:413-414, :456) through SDFDecoder.forward
@@ -346,16 +404,8 @@ SDFR_API int sdfr_decoder_backward_latent_deferred(const sdfr_decoder* decoder, 
                                           const float* grad_out, void* workspace, size_t workspace_bytes,
                                           void* stream, const float** t_mid);
 
-/* TEST HOOK: batches take the transposed resizes of the VJP in one launch each (an LDS-staged block per workgroup,
- * bit-identical to the three single-axis launches it replaces); 0 switches back to the three launches so that a
- * test can compare the two bit for bit.  Process-wide; returns the old value. */
-SDFR_API int sdfr_debug_set_decoder_tiled_vjp(int on);
-/* TEST HOOK: the backward of a NARROW Linear stack (every layer input <= 64 wide, e.g. the mug decoder's 8 -> 20 -> 50)
- * runs as one wave out of LDS -- in sdfr_decoder_backward_latent and inside sdfr_loop_tail[_records] --, bit-identical
- * to the one-workgroup form wider stacks take; 0 switches to that form so that a test can compare the two bit for
- * bit.  Process-wide; returns the old value. */
-SDFR_API int sdfr_debug_set_decoder_fc_one_wave(int on);
 
+/* ==== 3. LOOP ================================================================================= */
 /* ---- glue of one render-and-compare iteration (SDFPipeline.__call__, simple_setup.py:408-470) --- */
 /* Small kernels that replace the reference's per-iteration torch-op soup so that a whole
  * iteration is a fixed launch sequence (graph-capturable).  All pointers are device pointers. */
@@ -509,9 +559,11 @@ SDFR_API int sdfr_depth_to_points_ordered(const float* depth, int V, int W, int 
  * pointset -= mean(pointset), position -= mean; optionally + a noise vector).  Both passes over the images do that
  * on the way: sdfr_depth_count_centroid = sdfr_depth_count_ordered that also leaves centroid[v] = mean of view v's
  * back-projected points (fixed-order sums; 0 for an empty view) and, with `offsets` [V] (nullable), the exclusive
- * prefix of the counts that sdfr_depth_to_points_* takes -- the caller reads the counts (to size `points`), forms
- * shift[v] = centroid[v] - noise[v] on the device -- and sdfr_depth_to_points_shifted writes points - shift[v]
- * (shift NULL: the plain points).  No pass over the packed points, no per-point owner index, no atomics.
+ * prefix of the counts that sdfr_depth_to_points_* takes -- the caller reads the counts (to size `points`) -- and
+ * sdfr_depth_to_points_shifted writes (points - shift[v]) + noise[v]: two roundings, in the reference's order
+ * (`pointset -= centroid`, then `pointset += noise`).  shift / noise [V][3], either may be NULL (that term is
+ * skipped: shift = noise = NULL gives the plain points).  No pass over the packed points, no per-point owner index,
+ * no atomics.
  * Workspace: sdfr_depth_centroid_workspace_bytes, 16-byte aligned, the same for both calls. */
 SDFR_API size_t sdfr_depth_centroid_workspace_bytes(int V, int W, int H);
 SDFR_API int sdfr_depth_count_centroid(const float* depth, int V, int W, int H, int order, float rfx, float rfy,
@@ -519,7 +571,7 @@ SDFR_API int sdfr_depth_count_centroid(const float* depth, int V, int W, int H, 
                               size_t workspace_bytes, int device, void* stream);
 SDFR_API int sdfr_depth_to_points_shifted(const float* depth, int V, int W, int H, int order, float rfx, float rfy,
                                  float cx0, float cy0, const int* offsets, const void* workspace, const float* shift,
-                                 float* points, int device, void* stream);
+                                 const float* noise, float* points, int device, void* stream);
 
 /* The same pair of passes WITHOUT the host in between, for a caller that re-uses its buffers from observation to
  * observation (the captured render-and-compare loop, rebound to new depth images): `points` has room for every pixel
@@ -581,6 +633,7 @@ SDFR_API int sdfr_nn_loss_backward(const float* grad_dist, const float* points_f
 SDFR_API int sdfr_affine_mask(const float* depth, int B, int W, int H, const float* matrices,
                      unsigned char* mask, int device, void* stream);
 
+/* ==== 4. GENERATOR / INITIALISATION (sdfr_affine_mask above; the network below) =============== */
 /* ---- initialisation network forward: sdfest/initialization/pointnet.py:7-96,
  * sdf_pose_network.py:9-115, estimation/simple_setup.py:795-812 ------------------------------------ */
 

@@ -25,17 +25,17 @@ SIGNATURES = {
     "sdfr_last_error": (ctypes.c_char_p, []),
     "sdfr_render_forward_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
     "sdfr_render_sync_offset": (c_sz, [c_int]),
-    "sdfr_debug_set_prologue_polls": (c_int, [c_int]),
-    "sdfr_debug_set_decoder_tiled_vjp": (c_int, [c_int]),
-    "sdfr_debug_set_decoder_fc_one_wave": (c_int, [c_int]),
-    "sdfr_debug_set_decoder_fused_resize": (c_int, [c_int]),
+    "sdfr_decoder_set_option": (c_int, [c_fp, c_int, c_int]),
     "sdfr_render_partials_offset": (c_sz, [c_int, c_int, c_int, c_int, c_int]),
     "sdfr_render_step_forward_l1": (c_int, [c_fp, c_int, c_ll, c_fp, c_fp, c_fp, c_int, c_int, c_int,
                                             c_f, c_f, c_f, c_f, c_f, c_fp, c_fp, c_fp, c_fp, c_fp, c_ll, c_fp, c_sz,
-                                            c_int, c_fp]),
+                                            c_fp, c_int, c_fp]),
     "sdfr_render_step_backward_l1_pc": (c_int, [c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_int, c_ll, c_fp, c_fp, c_fp,
                                                 c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_int, c_fp, c_ll, c_fp, c_sz,
-                                                c_f, c_fp, c_fp, c_int, c_fp, c_fp, c_sz, c_int, c_fp]),
+                                                c_f, c_fp, c_fp, c_int, c_fp, c_fp, c_sz, c_fp, c_fp, c_int, c_fp]),
+    "sdfr_render_step_backward_l1": (c_int, [c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_int, c_ll, c_int, c_int, c_int,
+                                             c_f, c_f, c_f, c_f, c_int, c_fp, c_ll, c_fp, c_fp, c_fp, c_fp, c_sz,
+                                             c_fp, c_fp, c_int, c_fp]),
     "sdfr_loop_tail": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_f, c_f, c_f, c_f, c_int, c_fp, c_fp, c_int,
                                c_fp, c_sz, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                c_f, c_fp, c_fp, c_fp, c_int, c_fp]),
@@ -110,7 +110,7 @@ SIGNATURES = {
     "sdfr_depth_count_centroid": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_fp, c_fp, c_fp, c_fp,
                                           c_sz, c_int, c_fp]),
     "sdfr_depth_to_points_shifted": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_fp, c_fp, c_fp,
-                                             c_fp, c_int, c_fp]),
+                                             c_fp, c_fp, c_int, c_fp]),
     "sdfr_depth_to_points_resident": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_fp, c_fp, c_fp,
                                               c_sz, c_fp, c_int, c_fp]),
     "sdfr_preprocess_depth": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_f, c_int, c_fp, c_int, c_fp]),

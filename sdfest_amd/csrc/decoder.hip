@@ -66,6 +66,9 @@ struct sdfr_decoder {
   size_t tape_fc_off = 0;                  // per-sample float offsets
   std::vector<size_t> tape_conv_off;
   size_t tape_floats = 0;                  // per sample
+  // which of two equivalent kernel forms a call takes (sdfr_decoder_set_option; the defaults are the measured-faster
+  // ones, results are the same bit for bit): per HANDLE, so that nothing one caller selects reaches another's decoder
+  mutable std::atomic<int> opt_fused_resize{1}, opt_tiled_vjp{1}, opt_fc_one_wave{1};
 };
 
 namespace sdfr {
@@ -1787,13 +1790,12 @@ bool launch_direct(const sdfr_decoder* d, size_t w_off, const float* src, const 
 #undef SDFR_DIRECT
   return true;
 }
-std::atomic<int> g_fused_resize{1};   // tests switch the resize-in-the-patch-load form off: sdfr_debug_set_decoder_fused_resize
 
 // resize ni -> n (up-sampling) folded into the direct convolution that follows it (conv3d_direct_up_kernel): true if
 // launched.  Same tiling as launch_direct; the chunk is also bounded by the coarse columns a thread prefetches.
 bool launch_direct_up(const sdfr_decoder* d, size_t w_off, const float* src, int ni, const float* bias, float* dst,
                       int cin, int cout, int n, int m, int relu, int N, hipStream_t st) {
-  const int mode = g_fused_resize.load(std::memory_order_relaxed);
+  const int mode = d->opt_fused_resize.load(std::memory_order_relaxed);
   if (!mode) return false;
   if (n < 16 || n > 64 || (n & (n - 1)) != 0 || ni > n || ni < 2) return false;
   // Measured on 256 mug latents (profiles/r04_decoder_fused_resize.txt): 6 -> 16 in front of the 16 -> 8 layer,
@@ -1845,8 +1847,18 @@ bool launch_direct_up(const sdfr_decoder* d, size_t w_off, const float* src, int
 }
 }  // namespace
 
-extern "C" int sdfr_debug_set_decoder_fused_resize(int on) {
-  return g_fused_resize.exchange(on < 0 ? 0 : (on > 2 ? 2 : on), std::memory_order_relaxed);
+extern "C" int sdfr_decoder_set_option(sdfr_decoder* d, int option, int value) {
+  if (!d) return fail(SDFR_E_NULL, "sdfr_decoder_set_option: decoder is NULL");
+  switch (option) {
+    case SDFR_DECODER_OPT_FUSED_RESIZE:
+      return d->opt_fused_resize.exchange(value < 0 ? 0 : (value > 2 ? 2 : value), std::memory_order_relaxed);
+    case SDFR_DECODER_OPT_TILED_VJP:
+      return d->opt_tiled_vjp.exchange(value ? 1 : 0, std::memory_order_relaxed);
+    case SDFR_DECODER_OPT_FC_ONE_WAVE:
+      return d->opt_fc_one_wave.exchange(value ? 1 : 0, std::memory_order_relaxed);
+    default:
+      return fail(SDFR_E_INVALID, "sdfr_decoder_set_option: unknown option %d", option);
+  }
 }
 
 extern "C" int sdfr_decoder_create(const float* h_params, size_t n_params, int latent, int n_fc,
@@ -2168,7 +2180,7 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
     for (int l = 0; l + 1 < d->n_fc; ++l) hid = std::max(hid, d->fc_out[l]);
     constexpr int kFcSamples = 8;
     const size_t fc_lds = 2 * (size_t)hid * kFcSamples * sizeof(float);
-    if (N >= 4 * kFcSamples && fc_lds <= 32 * 1024 && decoder_fc_one_wave(fd))   // batches (small ones keep the form of a single decode)
+    if (N >= 4 * kFcSamples && fc_lds <= 32 * 1024 && decoder_fc_one_wave(d, fd))   // batches (small ones keep the form of a single decode)
       hipLaunchKernelGGL((fc_stack_batch_kernel<kFcSamples, true>),
                          dim3((last + kFcBlock - 1) / kFcBlock, (N + kFcSamples - 1) / kFcSamples), dim3(kFcBlock),
                          fc_lds, st, d->d_params, fd, z, N, hid, fc_dst);
@@ -2176,7 +2188,7 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
       hipLaunchKernelGGL((fc_stack_batch_kernel<kFcSamples, false>),
                          dim3((last + kFcBlock - 1) / kFcBlock, (N + kFcSamples - 1) / kFcSamples), dim3(kFcBlock),
                          fc_lds, st, d->d_params, fd, z, N, hid, fc_dst);
-    else if (decoder_fc_one_wave(fd))
+    else if (decoder_fc_one_wave(d, fd))
       hipLaunchKernelGGL(fc_stack_kernel<true>, dim3((last + kFcBlock - 1) / kFcBlock, N), dim3(kFcBlock), 0, st,
                          d->d_params, fd, z, fc_dst);
     else
@@ -2359,19 +2371,10 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
   return 0;
 }
 
-namespace sdfr { namespace {
-std::atomic<int> g_tiled_resize_vjp{1};   // tests switch the one-launch transposed resize off: sdfr_debug_set_decoder_tiled_vjp
-} }
-
-extern "C" int sdfr_debug_set_decoder_tiled_vjp(int on) {
-  return sdfr::g_tiled_resize_vjp.exchange(on ? 1 : 0, std::memory_order_relaxed);
-}
 namespace sdfr {
-namespace { std::atomic<int> g_fc_one_wave{1}; }   // tests switch the one-wave Linear-stack backward off
-bool decoder_fc_one_wave(const FcDesc& d) { return g_fc_one_wave.load() != 0 && fc_one_wave_ok(d); }
+bool decoder_fc_one_wave(const sdfr_decoder* dec, const FcDesc& d) {
+  return dec->opt_fc_one_wave.load(std::memory_order_relaxed) != 0 && fc_one_wave_ok(d);
 }
-extern "C" int sdfr_debug_set_decoder_fc_one_wave(int on) {
-  return sdfr::g_fc_one_wave.exchange(on ? 1 : 0);
 }
 
 extern "C" size_t sdfr_decoder_backward_workspace_bytes(const sdfr_decoder* d, int N) {
@@ -2439,7 +2442,7 @@ int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* ta
     }
     // (n_in <= n_out: the z pass writes a row's n_in results over the row's own n_out sources)
     // (single latents too: one launch of ~9 us instead of two of 6 + 5 in the captured loop, C5 0.144 -> 0.1375 ms)
-    if (g_tiled_resize_vjp.load(std::memory_order_relaxed) && (!mix_w || (C == 1 && pad >= 0)) && n_in <= 64 &&
+    if (d->opt_tiled_vjp.load(std::memory_order_relaxed) && (!mix_w || (C == 1 && pad >= 0)) && n_in <= 64 &&
         n_in <= n_out && n_out <= 1024 && nc < (1u << 24)) {
       // the three passes in one launch on an LDS-staged block (resize3_backward_tiled_kernel)
       const float ratio = (float)n_in / (float)n_out;
@@ -2706,7 +2709,7 @@ int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* ta
                          t_mid);
   }
   if (t_mid_out) *t_mid_out = t_mid;
-  else if (decoder_fc_one_wave(fd))
+  else if (decoder_fc_one_wave(d, fd))
     hipLaunchKernelGGL(fc_stack_backward_wave_kernel, dim3(N), dim3(64), 0, st, d->d_params, fd, z, t_mid, g_z);
   else hipLaunchKernelGGL(fc_stack_backward_kernel, dim3(N), dim3(kFcBlock), 0, st, d->d_params, fd, z, t_mid, g_z);
   SDFR_HIP_TRY(hipGetLastError());

@@ -20,9 +20,9 @@ struct FcDesc {
 
 // the decoder's Linear stack and its parameter block (device pointer); defined in decoder.hip
 void decoder_fc_desc(const sdfr_decoder* d, FcDesc* out, const float** d_params, size_t* tape_fc_off);
-// whether the backward of the stack's leading layers runs as one wave (fc_one_wave_ok, and not switched off by the
-// tests' sdfr_debug_set_decoder_fc_one_wave); defined in decoder.hip
-bool decoder_fc_one_wave(const FcDesc& d);
+// whether the backward of the stack's leading layers runs as one wave (fc_one_wave_ok, and not switched off for this
+// handle: sdfr_decoder_set_option, SDFR_DECODER_OPT_FC_ONE_WAVE); defined in decoder.hip
+bool decoder_fc_one_wave(const sdfr_decoder* dec, const FcDesc& d);
 
 // Backward of the small leading layers for ONE sample, by one workgroup of kFcBlock threads: t_in (gradient w.r.t.
 // the input of the last layer, not yet ReLU-masked) -> g_z.  Hidden activations are recomputed in LDS (80 KB static).

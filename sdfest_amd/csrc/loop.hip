@@ -994,6 +994,7 @@ __global__ __launch_bounds__(256) void depth_compact_kernel(const float* __restr
                                                             const int* __restrict__ offsets, float rfx,
                                                             float rfy, float cx0, float cy0,
                                                             const float* __restrict__ shift,
+                                                            const float* __restrict__ noise,
                                                             float* __restrict__ points) {
   __shared__ int wsum[4];
   __shared__ int base_s;
@@ -1030,14 +1031,23 @@ __global__ __launch_bounds__(256) void depth_compact_kernel(const float* __restr
   float* out = points + 3 * (size_t)(base_s + before);
   // (x - 0.0f == x bit for bit, so the plain form is this one with a zero shift)
   const V3 sh = shift ? mk(shift[3 * v], shift[3 * v + 1], shift[3 * v + 2]) : mk(0.0f, 0.0f, 0.0f);
+  // (noise: a SECOND rounding, as the reference's `pointset -= centroid; pointset += noise`, generated_dataset.py:314-326)
+  const V3 nz = noise ? mk(noise[3 * v], noise[3 * v + 1], noise[3 * v + 2]) : mk(0.0f, 0.0f, 0.0f);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
+    // (torch divides by a scalar as "* (1 / scalar)" on the GPU.  Every operation rounds on its own, as torch's
+    // separate kernels do -- no contraction into fused multiply-adds -- so the points, their centred and their
+    // noised forms are the reference's bit for bit)
+#pragma clang fp contract(off)
     if (z[k] == 0.0f) continue;
     const int p = p0 + k;
     const int row = po.tiled ? trow : p / W, col = po.tiled ? tcol + k : p - (p / W) * W;
-    out[0] = ((float)col - cx0) * z[k] * rfx - sh.x;   // torch divides by a scalar as "* (1 / scalar)" on the GPU
-    out[1] = -((float)row - cy0) * z[k] * rfy - sh.y;
-    out[2] = -z[k] - sh.z;
+    float x = (((float)col - cx0) * z[k]) * rfx;
+    float y = (-((float)row - cy0) * z[k]) * rfy;
+    float zz = -z[k];
+    x = x - sh.x; y = y - sh.y; zz = zz - sh.z;
+    if (noise) { x = x + nz.x; y = y + nz.y; zz = zz + nz.z; }
+    out[0] = x; out[1] = y; out[2] = zz;
     out += 3;
   }
 }
@@ -1158,7 +1168,7 @@ extern "C" int sdfr_loop_tail(float* params, float* grads, float* exp_avg, float
   a.con_source = con_source; a.con_target = con_target; a.con_weight = con_weight; a.con_loss = con_loss;
   if (decoder) {
     decoder_fc_desc(decoder, &a.fc, &a.dec_params, nullptr);
-    a.fc_one_wave = decoder_fc_one_wave(a.fc) ? 1 : 0;
+    a.fc_one_wave = decoder_fc_one_wave(decoder, a.fc) ? 1 : 0;
     if (a.fc.width[0] != n_params - 8)
       return fail(SDFR_E_INVALID, "%s: the decoder's latent has %d entries, the parameter vector %d", fn, a.fc.width[0],
                   n_params - 8);
@@ -1227,7 +1237,7 @@ extern "C" int sdfr_loop_tail_records(float* params, float* grads, float* exp_av
   a.con_source = con_source; a.con_target = con_target; a.con_weight = con_weight; a.con_loss = con_loss;
   if (decoder) {
     decoder_fc_desc(decoder, &a.fc, &a.dec_params, nullptr);
-    a.fc_one_wave = decoder_fc_one_wave(a.fc) ? 1 : 0;
+    a.fc_one_wave = decoder_fc_one_wave(decoder, a.fc) ? 1 : 0;
     if (a.fc.width[0] != n_params - 8)
       return fail(SDFR_E_INVALID, "%s: the decoder's latent has %d entries, the parameter vector %d", fn, a.fc.width[0],
                   n_params - 8);
@@ -1492,13 +1502,14 @@ extern "C" int sdfr_depth_count_centroid(const float* depth, int V, int W, int H
 extern "C" int sdfr_depth_to_points_ordered(const float* depth, int V, int W, int H, int order, float rfx, float rfy,
                                             float cx0, float cy0, const int* offsets, const void* workspace,
                                             float* points, int device, void* stream) {
-  return sdfr_depth_to_points_shifted(depth, V, W, H, order, rfx, rfy, cx0, cy0, offsets, workspace, nullptr, points,
-                                      device, stream);
+  return sdfr_depth_to_points_shifted(depth, V, W, H, order, rfx, rfy, cx0, cy0, offsets, workspace, nullptr, nullptr,
+                                      points, device, stream);
 }
 
 extern "C" int sdfr_depth_to_points_shifted(const float* depth, int V, int W, int H, int order, float rfx, float rfy,
                                             float cx0, float cy0, const int* offsets, const void* workspace,
-                                            const float* shift, float* points, int device, void* stream) {
+                                            const float* shift, const float* noise, float* points, int device,
+                                            void* stream) {
   if (order != SDFR_POINT_ORDER_ROW_MAJOR && order != SDFR_POINT_ORDER_TILED)
     return fail(SDFR_E_INVALID, "sdfr_depth_to_points: unknown point order %d", order);
   if (V < 0 || W < 0 || H < 0 || V > 65535 || (long long)(W + 63) * (H + 15) > 0x7fffffffLL)
@@ -1510,7 +1521,7 @@ extern "C" int sdfr_depth_to_points_shifted(const float* depth, int V, int W, in
   const PixelOrder po = pixel_order(W, H, order);
   const int nblk = (po.count() + kCompactPix - 1) / kCompactPix;
   hipLaunchKernelGGL(depth_compact_kernel, dim3(nblk, V), dim3(256), 0, (hipStream_t)stream, depth, po,
-                     nblk, (const int*)workspace, offsets, rfx, rfy, cx0, cy0, shift, points);
+                     nblk, (const int*)workspace, offsets, rfx, rfy, cx0, cy0, shift, noise, points);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1543,7 +1554,7 @@ extern "C" int sdfr_depth_to_points_resident(const float* depth, int V, int W, i
   hipLaunchKernelGGL(resident_offsets_kernel, dim3(1), dim3(256), 0, st, (const int*)workspace, nblk, V, counts,
                      offsets);
   hipLaunchKernelGGL(depth_compact_kernel, dim3(nblk, V), dim3(256), 0, st, depth, po, nblk, (const int*)workspace,
-                     offsets, rfx, rfy, cx0, cy0, (const float*)nullptr, points);
+                     offsets, rfx, rfy, cx0, cy0, (const float*)nullptr, (const float*)nullptr, points);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -479,12 +479,15 @@ __global__ __launch_bounds__(256) void pack_cells_kernel(const float* __restrict
 // A view that was set up that way is counted in the sync header's word 1 (sdfr_render_prologue_fallbacks): the
 // count stays 0 unless the launch was serialised (a profiler replaying block by block, a CU mask of one CU).
 constexpr int kPrologueMaxPolls = 1 << 16;
-std::atomic<int> g_prologue_max_polls{kPrologueMaxPolls};   // tests force the fallback: sdfr_debug_set_prologue_polls
+// The bound of the wait below, in polling rounds, is a property of the WORKSPACE: sync header words 6 / 7 =
+// {SDFR_SYNC_POLLS_MAGIC, rounds} override the default for the forwards on that workspace (0 rounds: every view set-up
+// takes the fall-back path -- how the tests reach it); any other word 6, e.g. of a workspace nobody initialised, means
+// the default.  Nothing process-wide.
 __global__ __launch_bounds__(256) void forward_prologue_kernel(
     const float* __restrict__ sdf, int R, float4* __restrict__ cells, int n_plane, int n_setup,
     unsigned* __restrict__ sync, const float* __restrict__ pos, const float* __restrict__ quat,
     const float* __restrict__ inv_scale, int B, int W, int H, float cx, float cy, float fx, float fy,
-    ViewSetup* __restrict__ out, float threshold, float* __restrict__ g_zero, size_t n_zero, int max_polls,
+    ViewSetup* __restrict__ out, float threshold, float* __restrict__ g_zero, size_t n_zero, int default_polls,
     unsigned* __restrict__ spans) {
   const unsigned tag = sync[0] + 1u;  // the epoch the last forward on this workspace left, + 1
   PlaneEntry* ent = reinterpret_cast<PlaneEntry*>(sync + kSyncHeaderWords);
@@ -502,6 +505,7 @@ __global__ __launch_bounds__(256) void forward_prologue_kernel(
     ViewSetup s;
     if (b < B) setup_pose(b, pos, quat, inv_scale, R, fx, fy, s);
     bool ready = false;
+    const int max_polls = sync[6] == SDFR_SYNC_POLLS_MAGIC ? (int)sync[7] : default_polls;   // (workgroup-uniform)
     for (int poll = 0; poll < max_polls; ++poll) {
       bool ok = true;
       for (int j = tid; j < n_ent; j += 256) {
@@ -844,6 +848,68 @@ __device__ __forceinline__ HitPoint hit_point(const ViewSetup& s, int row, int c
   return p;
 }
 
+// A loss-fused STEP whose forward left the reduction of its (sum, count) tile records to the backward (deferred:
+// sdfr_render_step_forward_l1 with loss = loss_stats = NULL): no launch between the two image kernels.  A backward
+// tile that has a hit pixel sums the view's counts itself -- integers held in floats below 2^24: the sum is exact in
+// any order, so k = weight / count is the very number the reduce launch would have handed it -- and workgroup (0, 0)
+// of every view (a corner of the image: nearly always a culled tile) runs the fixed-order reduction of
+// loss_reduce_kernel on the side: loss[b], stats[b] for whoever reads them after this launch.
+struct LossTiles {
+  const float* part;   // the forward's records, [view][nty][ntx][2]; nullptr: the forward reduced them itself
+  int ntx, nty, wl, hl;   // the FORWARD's tiling (not the backward's): tiles of 2^wl x 2^hl pixels
+  float* loss;         // [B]
+  float* stats;        // [B][2]
+};
+// every thread of the workgroup calls it; `scratch`: 4 floats of LDS nobody else uses until the next barrier
+__device__ __forceinline__ float view_overlap_count(const LossTiles& lt, const ViewSetup& s, int b, float* scratch) {
+  const int x0 = s.rect[0], y0 = s.rect[1], x1 = s.rect[2], y1 = s.rect[3];
+  float cnt = 0.0f;
+  if (x1 > x0 && y1 > y0) {
+    // (scalar divisions: the rectangle and the tiling are workgroup-uniform; the threads walk the records as an
+    // 8 x 32 block -- no per-thread division in a path every tile with a hit pixel takes)
+    const int tx0 = x0 >> lt.wl, tx1 = (x1 - 1) >> lt.wl, ty0 = y0 >> lt.hl, ty1 = (y1 - 1) >> lt.hl;   // (x0, y0 >= 0)
+    const float2* base = reinterpret_cast<const float2*>(lt.part) + (size_t)b * lt.ntx * lt.nty;
+    const int c = (int)threadIdx.x & 31, r = (int)threadIdx.x >> 5;
+    for (int ty = ty0 + r; ty <= ty1; ty += kBlock / 32)
+      for (int tx = tx0 + c; tx <= tx1; tx += 32) cnt += base[ty * lt.ntx + tx].y;
+  }
+  cnt = wave_sum(cnt);
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+}
+// one wave: the body of loss_reduce_kernel (same lane-strided order, same butterfly: the same bits)
+__device__ __forceinline__ void reduce_view_loss(const LossTiles& lt, const ViewSetup& s, int b, int lane) {
+  const int x0 = s.rect[0], y0 = s.rect[1], x1 = s.rect[2], y1 = s.rect[3];
+  float sum = 0.0f, cnt = 0.0f;
+  if (x1 > x0 && y1 > y0) {
+    const int tx0 = x0 >> lt.wl, tx1 = (x1 - 1) >> lt.wl, ty0 = y0 >> lt.hl, ty1 = (y1 - 1) >> lt.hl;
+    const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1);
+    const float2* base = reinterpret_cast<const float2*>(lt.part) + (size_t)b * lt.ntx * lt.nty;
+    for (int i = lane; i < n; i += 64) {
+      const float2 p = base[(size_t)(ty0 + i / nx) * lt.ntx + tx0 + i % nx];
+      sum += p.x;
+      cnt += p.y;
+    }
+  }
+  sum = wave_sum(sum);
+  cnt = wave_sum(cnt);
+  if (lane == 0) {
+    lt.loss[b] = sum / cnt;
+    lt.stats[2 * b] = sum;
+    lt.stats[2 * b + 1] = cnt;
+  }
+}
+
+// What a loss-fused tile needs to form its upstream gradient -- looked at only once the tile is known to hold a hit
+// pixel: a culled workgroup's life is its chain of dependent scalar loads, and three out of four workgroups are culled.
+struct LossArgs {
+  const float* loss_grad;    // [B] or nullptr
+  const float* loss_stats;   // [B][2] from the forward (nullptr with lt.part)
+  float loss_weight;
+  LossTiles lt;
+};
+
 // One tile of the backward.  Every return is workgroup-uniform.
 // LOSS: `grad_depth` is the OBSERVED depth image and the upstream gradient is formed on the fly,
 // go = +-k on the overlap mask (obs > 0) & (est > 0), k = weight * dL/dloss_b / count_b
@@ -854,7 +920,7 @@ __device__ __forceinline__ HitPoint hit_point(const ViewSetup& s, int row, int c
 constexpr int kDetQuantumBits = SDFR_FIXED_QUANTUM_BITS;
 template <int RT, int SX, int SY, typename Hash, bool LOSS, bool DET = false>
 __device__ __forceinline__ void backward_tile(
-    BackwardLds<Hash>& lds, int tile_x, int tile_y, size_t record, int b, float loss_k,
+    BackwardLds<Hash>& lds, int tile_x, int tile_y, size_t record, int b, const LossArgs& la,
     const float* __restrict__ grad_depth, const float* __restrict__ depth,
     const float* __restrict__ sdf, int R, long long sdf_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx, float rfy,
@@ -898,9 +964,9 @@ __device__ __forceinline__ void backward_tile(
     const int row = py0 + (sub / SX) * kSubH + PB::oy(wave) + PB::y(lane);
     const bool hit = zs[sub] != 0.0f;
     gos[sub] = hit ? gimg[(size_t)row * W + col] : 0.0f;
-    if (LOSS) {
+    if (LOSS) {   // the sign of (estimate - observation) on the overlap; times k below
       const float e = zs[sub], o = gos[sub];
-      gos[sub] = (e > 0.0f && o > 0.0f) ? ((e > o) ? loss_k : ((e < o) ? -loss_k : 0.0f)) : 0.0f;
+      gos[sub] = (e > 0.0f && o > 0.0f) ? ((e > o) ? 1.0f : ((e < o) ? -1.0f : 0.0f)) : 0.0f;
     }
     gmax = fmaxf(gmax, fabsf(gos[sub]));
     any_hit = any_hit || hit;
@@ -908,6 +974,16 @@ __device__ __forceinline__ void backward_tile(
   if (!__syncthreads_or(any_hit)) {
     if (tid < 8) part[tid] = 0.0f;
     return;
+  }
+  if (LOSS) {
+    // same expression as depth_l1_grad_kernel (loop.hip): k = weight / count, 0 if the overlap is empty
+    const float w = la.loss_grad ? la.loss_weight * la.loss_grad[b] : la.loss_weight;
+    const float cnt = la.lt.part ? view_overlap_count(la.lt, s, b, &lds.wave_part[0][0])   // (workgroup-uniform)
+                                 : la.loss_stats[2 * b + 1];
+    const float k = cnt > 0.0f ? w / cnt : 0.0f;
+#pragma unroll
+    for (int sub = 0; sub < kSubs; ++sub) gos[sub] = gos[sub] > 0.0f ? k : (gos[sub] < 0.0f ? -k : 0.0f);
+    gmax = gmax > 0.0f ? fabsf(k) : 0.0f;
   }
   const float h = 0.5f * (float)(Rr - 1);
   const float scale = s.scale, isc = s.isc;
@@ -1121,14 +1197,7 @@ __device__ __forceinline__ void backward_dispatch(
     const float* __restrict__ grad_depth, const float* __restrict__ depth, const float* __restrict__ sdf, int R,
     long long sdf_view_stride, const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx,
     float rfy, int sdf_grad_mode, float* __restrict__ g_sdf, long long g_sdf_view_stride,
-    float* __restrict__ partials, const float* __restrict__ loss_grad, const float* __restrict__ loss_stats,
-    float loss_weight) {
-  float loss_k = 0.0f;
-  if (LOSS) {  // same expression as depth_l1_grad_kernel (loop.hip): k = weight / count, 0 if empty
-    const float cnt = loss_stats[2 * b + 1];
-    const float w = loss_grad ? loss_weight * loss_grad[b] : loss_weight;
-    loss_k = cnt > 0.0f ? w / cnt : 0.0f;
-  }
+    float* __restrict__ partials, const LossArgs& la = LossArgs{}) {
   if (BATCH) {
     using Table = typename std::conditional<DET, BatchHash, BatchTable>::type;   // DET: 64-bit sums
     auto& lds = *reinterpret_cast<BackwardLds<Table>*>(raw);
@@ -1137,7 +1206,7 @@ __device__ __forceinline__ void backward_dispatch(
       const int tx = 2 * bx + (by & 1), ty = by >> 1;
       if (tx >= kBwdBigTile.nx(W) || ty >= kBwdBigTile.ny(H)) return;
       backward_tile<RT, kBwdBigTile.sx, kBwdBigTile.sy, Table, LOSS, DET>(
-          lds, tx, ty, record, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx,
+          lds, tx, ty, record, b, la, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx,
           rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
     } else if (PAIR) {
 #pragma unroll 1
@@ -1149,19 +1218,19 @@ __device__ __forceinline__ void backward_dispatch(
         const int ty = 2 * by + k;
         if (ty >= nty) break;
         backward_tile<RT, SDFR_MACRO_SX, SDFR_MACRO_SY, Table, LOSS, DET>(
-            lds, bx, ty, (size_t)b * stride + ty * ntx + bx, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride,
+            lds, bx, ty, (size_t)b * stride + ty * ntx + bx, b, la, grad_depth, depth, sdf, R, sdf_view_stride,
             setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
       }
     } else {
       if (by >= nty) return;
       backward_tile<RT, SDFR_MACRO_SX, SDFR_MACRO_SY, Table, LOSS, DET>(
-          lds, bx, by, record, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx,
+          lds, bx, by, record, b, la, grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx,
           rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
     }
   } else {
     auto& lds = *reinterpret_cast<BackwardLds<SmallHash>*>(raw);
     backward_tile<RT, 1, 1, SmallHash, LOSS, DET>(
-        lds, bx, by, ((size_t)b * nty + by) * ntx + bx, b, loss_k, grad_depth, depth, sdf, R, sdf_view_stride,
+        lds, bx, by, ((size_t)b * nty + by) * ntx + bx, b, la, grad_depth, depth, sdf, R, sdf_view_stride,
         setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf, g_sdf_view_stride, partials);
   }
 }
@@ -1182,15 +1251,18 @@ __global__ __launch_bounds__(kBlock) SDFR_BWD_OCC void render_backward_kernel(
     const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, int stride, float cx, float cy,
     float rfx, float rfy, int sdf_grad_mode, float* __restrict__ g_sdf,
     long long g_sdf_view_stride, float* __restrict__ partials, const float* __restrict__ loss_grad,
-    const float* __restrict__ loss_stats, float loss_weight) {
+    const float* __restrict__ loss_stats, float loss_weight, LossTiles lt) {
   constexpr size_t kBatchLds = sizeof(BackwardLds<BatchTable>) > sizeof(BackwardLds<BatchHash>)
                                    ? sizeof(BackwardLds<BatchTable>) : sizeof(BackwardLds<BatchHash>);
   __shared__ __attribute__((aligned(16))) unsigned char raw[BATCH ? (DET ? kBatchLds : sizeof(BackwardLds<BatchTable>))
                                                                   : sizeof(BackwardLds<SmallHash>)];
   backward_dispatch<RT, BATCH, LOSS, DET, PAIR>(raw, blockIdx.x, blockIdx.y, ntx, nty, stride, blockIdx.z,
                                      grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy,
-                                     sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, loss_grad, loss_stats,
-                                     loss_weight);
+                                     sdf_grad_mode, g_sdf, g_sdf_view_stride, partials,
+                                     LossArgs{loss_grad, loss_stats, loss_weight, lt});
+  // (after the tile, not in front of it: nothing of this is on a culled workgroup's way to its exit)
+  if (LOSS && lt.part && (blockIdx.x | blockIdx.y) == 0 && threadIdx.x < 64)
+    reduce_view_loss(lt, setup[blockIdx.z], (int)blockIdx.z, (int)threadIdx.x);
 }
 
 // The renderer's backward (depth-L1 form) and the sampler's backward (point-cloud L1 form) of one loop iteration in
@@ -1205,7 +1277,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_pc_kernel(
     const ViewSetup* __restrict__ setup, int W, int H, int ntx, int nty, int stride, float cx, float cy,
     float rfx, float rfy, int sdf_grad_mode, float* __restrict__ g_sdf,
     long long g_sdf_view_stride, float* __restrict__ partials, const float* __restrict__ loss_grad,
-    const float* __restrict__ loss_stats, float loss_weight, int pc_rows, PcBackwardArgs pa) {
+    const float* __restrict__ loss_stats, float loss_weight, int pc_rows, PcBackwardArgs pa, LossTiles lt) {
   constexpr size_t kBatchLds = (DET && sizeof(BackwardLds<BatchHash>) > sizeof(BackwardLds<BatchTable>))
                                    ? sizeof(BackwardLds<BatchHash>) : sizeof(BackwardLds<BatchTable>);
   constexpr size_t kTileLds = BATCH ? kBatchLds : sizeof(BackwardLds<SmallHash>);
@@ -1219,7 +1291,9 @@ __global__ __launch_bounds__(kBlock) void render_backward_pc_kernel(
   }
   backward_dispatch<RT, BATCH, true, DET>(raw, blockIdx.x, (int)blockIdx.y - pc_rows, ntx, nty, stride, b, target, depth,
                                      sdf, R, sdf_view_stride, setup, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_sdf,
-                                     g_sdf_view_stride, partials, loss_grad, loss_stats, loss_weight);
+                                     g_sdf_view_stride, partials, LossArgs{loss_grad, loss_stats, loss_weight, lt});
+  if (lt.part && blockIdx.x == 0 && (int)blockIdx.y == pc_rows && threadIdx.x < 64)
+    reduce_view_loss(lt, setup[b], b, (int)threadIdx.x);
 }
 
 // deterministic mode: the 64-bit fixed-point volume -> float (one rounding per voxel)
@@ -1375,12 +1449,6 @@ extern "C" int sdfr_fixed_to_float(const long long* fixed, size_t n, float* out,
   return 0;
 }
 
-extern "C" int sdfr_debug_set_prologue_polls(int max_polls) {
-  const int old = g_prologue_max_polls.load(std::memory_order_relaxed);
-  g_prologue_max_polls.store(max_polls < 0 ? kPrologueMaxPolls : max_polls, std::memory_order_relaxed);
-  return old;
-}
-
 extern "C" size_t sdfr_render_forward_l1_workspace_bytes(int R, int B, int W, int H) {
   size_t n = (sdfr_render_forward_workspace_bytes(R, B, W, H) + 127) & ~(size_t)127;
   // one (sum, count) record per tile of the finer geometry
@@ -1464,7 +1532,7 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
     const int n_pack = (R * R * R + 255) / 256, n_setup = (B + 3) / 4;
     hipLaunchKernelGGL(forward_prologue_kernel, dim3(3 * R + n_setup + n_pack), dim3(256), 0, st, sdf, R,
                        (float4*)cells, 3 * R, n_setup, lay.sync, pos, quat, inv_scale, B, W, H, cx, cy, fx, fy,
-                       setup, threshold, g_zero, n_zero, g_prologue_max_polls.load(std::memory_order_relaxed),
+                       setup, threshold, g_zero, n_zero, kPrologueMaxPolls,
                        lay.spans);
     epoch = lay.sync;
   } else if (g_zero && !packed && inline_setup) {
@@ -1527,7 +1595,7 @@ int forward_impl(const char* fn, const float* sdf, int R, long long sdf_view_str
 #undef SDFR_LAUNCH_FWD
 #undef SDFR_LAUNCH_FWD_G
 #undef SDFR_LAUNCH_FWD_L
-  if (with_loss)
+  if (with_loss && loss)   // (loss == NULL: a step whose backward reduces the records, LossTiles)
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(B), dim3(64), 0, st, loss_part, setup, ntx, nty, geom.w(),
                        geom.h(), loss, loss_stats);
   SDFR_HIP_TRY(hipGetLastError());
@@ -1571,10 +1639,16 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
                   int sdf_grad_mode, float* g_sdf, long long g_sdf_view_stride, float* g_pos,
                   float* g_quat, float* g_inv_scale, const float* loss_grad, const float* loss_stats,
                   float loss_weight, void* workspace, size_t workspace_bytes, int device,
-                  void* stream, const PcBackwardArgs* pc = nullptr, bool prepared = false) {
+                  void* stream, const PcBackwardArgs* pc = nullptr, bool prepared = false,
+                  float* loss_out = nullptr, float* stats_out = nullptr) {
+  // loss_out / stats_out (a prepared, loss-fused step only): the step's forward left its (sum, count) tile records
+  // unreduced (sdfr_render_step_forward_l1 with loss = loss_stats = NULL); this launch reduces them (LossTiles)
   // prepared: a step's backward (sdfr_render_step_backward) -- the views were set up and g_sdf zero-filled by
   // the step's forward, in the step layout of the workspace; pos / quat / inv_scale are not read
-  const bool with_loss = loss_stats != nullptr;
+  const bool loss_deferred = loss_out != nullptr;
+  const bool with_loss = loss_stats != nullptr || loss_deferred;
+  if (loss_deferred && (!prepared || !stats_out || loss_stats))
+    return fail(SDFR_E_INVALID, "%s: loss / loss_stats outputs go with a step whose forward deferred them", fn);
   if (int rc = check_common(R, B, W, H, fx, fy)) return rc;
   const long long vox = (long long)R * R * R;
   if (sdf_view_stride != 0 && sdf_view_stride < vox)
@@ -1647,11 +1721,20 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
   const bool batch = geom.sx * geom.sy > 1;
   const int ntx = geom.nx(W), nty = geom.ny(H);
   const int stride = batch ? backward_tile_stride(W, H) : 0;
-  const bool half = half_hint && batch && !det && !with_loss && !pc;   // (a hint: ignored where it does not apply)
+  const bool half = half_hint && batch && !det && !pc;   // (a hint: ignored where it does not apply)
   const int rows = batch ? (half ? backward_half_rows(H) : backward_batch_rows(H)) : nty;
   const int pc_rows = pc ? (pc->nblk + ntx - 1) / ntx : 0;
   const dim3 grid_tile((unsigned)ntx, (unsigned)(rows + pc_rows), (unsigned)B);
   const float rfx = (float)(1.0 / (double)fx), rfy = (float)(1.0 / (double)fy);
+  LossTiles lt_arg{};
+  if (loss_deferred) {   // the records of the step's forward, in ITS tiling (forward_impl)
+    const TileGeom fg = forward_geom(B, W, H);
+    auto log2i = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };   // tiles are 32 sx x 8 sy, sx, sy powers of two
+    if ((1 << log2i(fg.w())) != fg.w() || (1 << log2i(fg.h())) != fg.h())
+      return fail(SDFR_E_INVALID, "%s: forward tiles of %d x %d pixels are not powers of two", fn, fg.w(), fg.h());
+    lt_arg = LossTiles{(const float*)((char*)workspace + step_loss_offset(R, B, W, H)), fg.nx(W), fg.ny(H),
+                       log2i(fg.w()), log2i(fg.h()), loss_out, stats_out};
+  }
 #define SDFR_BWD_ARGS                                                                                \
   grad_depth, depth, sdf, R, sdf_view_stride, setup, W, H, ntx, nty, stride, cx, cy, rfx, rfy,       \
       sdf_grad_mode, g_sdf, g_sdf_view_stride, partials, loss_grad, loss_stats, loss_weight
@@ -1661,25 +1744,28 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
   do {                                                                                               \
     if (pc && det)                                                                                   \
       hipLaunchKernelGGL((render_backward_pc_kernel<RT, BATCH, true>), grid_tile, dim3(kBlock), 0, st, \
-                         SDFR_BWD_ARGS, pc_rows, *pc);                                               \
+                         SDFR_BWD_ARGS, pc_rows, *pc, lt_arg);                                       \
     else if (pc)                                                                                     \
       hipLaunchKernelGGL((render_backward_pc_kernel<RT, BATCH>), grid_tile, dim3(kBlock), 0, st,     \
-                         SDFR_BWD_ARGS, pc_rows, *pc);                                               \
+                         SDFR_BWD_ARGS, pc_rows, *pc, lt_arg);                                       \
     else if (with_loss && det)                                                                       \
       hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, true, true>), grid_tile, dim3(kBlock), 0, st, \
-                         SDFR_BWD_ARGS);                                                      \
+                         SDFR_BWD_ARGS, lt_arg);                                              \
+    else if (with_loss && half)                                                                      \
+      hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, true, false, BATCH>), grid_tile, dim3(kBlock), 0, st, \
+                         SDFR_BWD_ARGS, lt_arg);                                              \
     else if (with_loss)                                                                              \
       hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, true>), grid_tile, dim3(kBlock), 0, st,  \
-                         SDFR_BWD_ARGS);                                                      \
+                         SDFR_BWD_ARGS, lt_arg);                                              \
     else if (det)                                                                                    \
       hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false, true>), grid_tile, dim3(kBlock), 0, st, \
-                         SDFR_BWD_ARGS);                                                      \
+                         SDFR_BWD_ARGS, lt_arg);                                              \
     else if (half)                                                                                   \
       hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false, false, BATCH>), grid_tile, dim3(kBlock), 0, st, \
-                         SDFR_BWD_ARGS);                                                      \
+                         SDFR_BWD_ARGS, lt_arg);                                              \
     else                                                                                             \
       hipLaunchKernelGGL((render_backward_kernel<RT, BATCH, false>), grid_tile, dim3(kBlock), 0, st, \
-                         SDFR_BWD_ARGS);                                                      \
+                         SDFR_BWD_ARGS, lt_arg);                                              \
   } while (0)
   if (R == 64) { if (batch) SDFR_LAUNCH_BWD(64, true); else SDFR_LAUNCH_BWD(64, false); }
   else { if (batch) SDFR_LAUNCH_BWD(0, true); else SDFR_LAUNCH_BWD(0, false); }
@@ -1752,13 +1838,15 @@ extern "C" int sdfr_render_step_forward_l1(const float* sdf, int R, long long sd
                                            float cy, float fx, float fy, float threshold, const float* target,
                                            float* depth, float* loss, float* loss_stats, float* g_sdf,
                                            long long g_sdf_view_stride, void* workspace, size_t workspace_bytes,
-                                           int device, void* stream) {
+                                           unsigned long long* close_views_word, int device, void* stream) {
   const char* fn = "sdfr_render_step_forward_l1";
+  if ((uintptr_t)close_views_word % 8) return fail(SDFR_E_INVALID, "%s: close_views_word must be 8-byte aligned", fn);
   const long long vox = (long long)R * R * R;
   if (R >= 2 && R <= 1023 && g_sdf_view_stride != 0 && g_sdf_view_stride != vox)
     return fail(SDFR_E_INVALID, "g_sdf_view_stride must be 0 or R^3");
   if (B > 0 && !g_sdf) return fail(SDFR_E_NULL, "%s: g_sdf is NULL", fn);
-  if (B > 0 && W > 0 && H > 0 && (!target || !loss || !loss_stats)) return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
+  if (B > 0 && W > 0 && H > 0 && (!target || (!loss) != (!loss_stats)))
+    return fail(SDFR_E_NULL, "%s: NULL pointer argument (loss and loss_stats: both, or neither = deferred)", fn);
   ForwardLayout lay{};
   if (workspace && R >= 2 && R <= 1023 && B > 0) {
     char* w = (char*)workspace;
@@ -1771,7 +1859,8 @@ extern "C" int sdfr_render_step_forward_l1(const float* sdf, int R, long long sd
   const size_t g_words = (R >= 2 && R <= 1023) ? (size_t)vox * (g_sdf_view_stride ? (size_t)(B > 0 ? B : 1) : 1) : 0;
   return forward_impl(fn, sdf, R, sdf_view_stride, pos, quat, inv_scale, B, W, H, cx, cy, fx, fy, threshold, depth,
                       target, loss, loss_stats, workspace, workspace_bytes,
-                      sdfr_render_step_workspace_bytes(R, B, W, H), lay, g_sdf, g_words, device, stream);
+                      sdfr_render_step_workspace_bytes(R, B, W, H), lay, g_sdf, g_words, device, stream,
+                      close_views_word);
 }
 
 extern "C" int sdfr_render_step_backward(const float* grad_depth, const float* depth, const float* sdf, int R,
@@ -1813,6 +1902,30 @@ extern "C" int sdfr_render_backward_l1(const float* loss_grad, float loss_weight
                        workspace_bytes, device, stream);
 }
 
+extern "C" int sdfr_render_step_backward_l1(const float* loss_grad, float loss_weight, const float* loss_stats,
+                                            const float* target, const float* depth, const float* sdf, int R,
+                                            long long sdf_view_stride, int B, int W, int H, float cx, float cy,
+                                            float fx, float fy, int sdf_grad_mode, float* g_sdf,
+                                            long long g_sdf_view_stride, float* g_pos, float* g_quat,
+                                            float* g_inv_scale, void* workspace, size_t workspace_bytes, float* loss,
+                                            float* loss_stats_out, int device, void* stream) {
+  const char* fn = "sdfr_render_step_backward_l1";
+  if (B > 0 && !loss_stats && !loss) return fail(SDFR_E_NULL, "%s: loss_stats is NULL (and no deferred outputs)", fn);
+  if (B == 0 || W == 0 || H == 0) {   // nothing was rendered (as sdfr_render_step_backward)
+    if (int rc = check_common(R, B, W, H, fx, fy)) return rc;
+    if (B > 0 && g_pos && g_quat && g_inv_scale) {
+      SDFR_HIP_TRY(hipSetDevice(device));
+      zero_words_async(g_pos, (size_t)B * 3, (hipStream_t)stream);
+      zero_words_async(g_quat, (size_t)B * 4, (hipStream_t)stream);
+      zero_words_async(g_inv_scale, (size_t)B, (hipStream_t)stream);
+    }
+    return 0;
+  }
+  return backward_impl(fn, target, depth, sdf, R, sdf_view_stride, nullptr, nullptr, nullptr, B, W, H, cx, cy, fx, fy,
+                       sdf_grad_mode, g_sdf, g_sdf_view_stride, g_pos, g_quat, g_inv_scale, loss_grad, loss_stats,
+                       loss_weight, workspace, workspace_bytes, device, stream, nullptr, true, loss, loss_stats_out);
+}
+
 namespace {
 int backward_l1_pc_impl(const char* fn, bool prepared,
     const float* loss_grad, float loss_weight, const float* loss_stats, const float* target, const float* depth,
@@ -1820,12 +1933,13 @@ int backward_l1_pc_impl(const char* fn, bool prepared,
     int B, int W, int H, float cx, float cy, float fx, float fy, int sdf_grad_mode, float* g_sdf,
     long long g_sdf_view_stride, void* workspace, size_t workspace_bytes, float pc_weight, const float* points,
     const int* offsets, int max_view_points, const float* scale, void* pc_workspace, size_t pc_workspace_bytes,
-    int device, void* stream) {
+    int device, void* stream, float* loss_out = nullptr, float* stats_out = nullptr) {
   if (B <= 0 || W <= 0 || H <= 0 || max_view_points <= 0)
     return fail(SDFR_E_INVALID, "%s: needs B, W, H, max_view_points > 0 (B=%d W=%d H=%d points=%d)", fn, B, W, H,
                 max_view_points);
   if (R > 1023) return fail(SDFR_E_INVALID, "%s: R=%d out of range", fn, R);
-  if (!loss_stats || !points || !scale || !pc_workspace) return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
+  if ((!loss_stats && !loss_out) || !points || !scale || !pc_workspace)
+    return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
   if (!offsets && B > 1) return fail(SDFR_E_NULL, "offsets may be NULL only for a single view");
   if (pc_workspace_bytes < sdfr_pc_loss_backward_workspace_bytes(B, max_view_points))
     return fail(SDFR_E_WORKSPACE, "%s: sampler workspace %zu < %zu bytes", fn, pc_workspace_bytes,
@@ -1838,7 +1952,7 @@ int backward_l1_pc_impl(const char* fn, bool prepared,
   if (!pos || !quat || !inv_scale) return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
   return backward_impl(fn, target, depth, sdf, R, sdf_view_stride, pos, quat, inv_scale, B, W, H, cx, cy, fx, fy,
                        sdf_grad_mode, g_sdf, g_sdf_view_stride, nullptr, nullptr, nullptr, loss_grad, loss_stats,
-                       loss_weight, workspace, workspace_bytes, device, stream, &pa, prepared);
+                       loss_weight, workspace, workspace_bytes, device, stream, &pa, prepared, loss_out, stats_out);
 }
 }  // namespace
 
@@ -1861,9 +1975,9 @@ extern "C" int sdfr_render_step_backward_l1_pc(
     int B, int W, int H, float cx, float cy, float fx, float fy, int sdf_grad_mode, float* g_sdf,
     long long g_sdf_view_stride, void* workspace, size_t workspace_bytes, float pc_weight, const float* points,
     const int* offsets, int max_view_points, const float* scale, void* pc_workspace, size_t pc_workspace_bytes,
-    int device, void* stream) {
+    float* loss, float* loss_stats_out, int device, void* stream) {
   return backward_l1_pc_impl("sdfr_render_step_backward_l1_pc", true, loss_grad, loss_weight, loss_stats, target, depth,
                              sdf, R, sdf_view_stride, pos, quat, inv_scale, B, W, H, cx, cy, fx, fy, sdf_grad_mode, g_sdf,
                              g_sdf_view_stride, workspace, workspace_bytes, pc_weight, points, offsets, max_view_points,
-                             scale, pc_workspace, pc_workspace_bytes, device, stream);
+                             scale, pc_workspace, pc_workspace_bytes, device, stream, loss, loss_stats_out);
 }

@@ -681,24 +681,32 @@ class BatchRenderPlan:
         n = self.R ** 3 * 8
         return self.workspace[off:off + n].view(torch.int64).view(self.R, self.R, self.R)
 
-    def forward_l1(self, sdf, pos, quat, inv_scale, threshold: float, target, prepare_backward: bool = False):
+    def forward_l1(self, sdf, pos, quat, inv_scale, threshold: float, target, prepare_backward: bool = False,
+                   defer_loss: bool = False):
         """forward + masked depth-L1 against ``target`` (B,H,W): returns (depth, loss (B,)).
 
-        ``prepare_backward``: first half of a step whose second half is ``backward_l1_pc``
-        (``sdfr_render_step_forward_l1`` / ``sdfr_render_step_backward_l1_pc``): the gradient volume is zero-filled
-        and the view records are left for the backward, which then has no prologue launch."""
+        ``prepare_backward``: first half of a step whose second half is ``backward_l1`` or ``backward_l1_pc``
+        (``sdfr_render_step_forward_l1`` / ``sdfr_render_step_backward_l1[_pc]``): the gradient volume is zero-filled
+        and the view records are left for the backward, which then has no prologue launch.
+        ``defer_loss`` (with prepare_backward): the forward does not reduce its per-tile (sum, count) records -- one
+        dependent launch less between the two image kernels -- and ``self.loss`` / ``self.loss_stats`` are written
+        by the step's backward instead (same bits; include/sdfr.h, "DEFERRED LOSS").  The caller promises that the
+        step's backward follows, on the same tensors."""
         self._step = None   # the workspace is about to be re-used
         self._check(sdf, pos, quat, inv_scale, target=target)
+        if defer_loss and not prepare_backward:
+            raise ValueError("defer_loss goes with prepare_backward")
         if prepare_backward:
             nxt = self._g_sdf_ring[self._g_sdf_next]
             rc = self._L.sdfr_render_step_forward_l1(
                 sdf.data_ptr(), self.R, self.sdf_stride, pos.data_ptr(), quat.data_ptr(), inv_scale.data_ptr(),
                 self.B, self.W, self.H, self.cx, self.cy, self.fx, self.fy, threshold, target.data_ptr(),
-                self.depth.data_ptr(), self.loss.data_ptr(), self.loss_stats.data_ptr(), nxt.data_ptr(),
-                self.sdf_stride, self.workspace.data_ptr(), self.workspace.numel(), self.device.index,
-                _stream(self.device))
+                self.depth.data_ptr(), None if defer_loss else self.loss.data_ptr(),
+                None if defer_loss else self.loss_stats.data_ptr(), nxt.data_ptr(),
+                self.sdf_stride, self.workspace.data_ptr(), self.workspace.numel(),
+                self._close_word.data_ptr() if self._close_auto else None, self.device.index, _stream(self.device))
             _lib.check(rc, "sdfr_render_step_forward_l1")
-            self._step_l1 = (self._key(sdf, pos, quat, inv_scale), nxt)
+            self._step_l1 = (self._key(sdf, pos, quat, inv_scale), nxt, bool(defer_loss))
             return self.depth, self.loss
         self._step_l1 = None
         rc = self._L.sdfr_render_forward_l1(
@@ -715,12 +723,42 @@ class BatchRenderPlan:
         """gradients of sum_b weight * loss_grad[b] * loss[b] (after ``forward_l1``); ``defer_pose`` as in
         ``backward``."""
         self._step = None   # the workspace is about to be re-used
-        self._step_l1 = None
+        prepared, self._step_l1 = self._step_l1, None
         self._check(sdf, pos, quat, inv_scale, target=target)
         if loss_grad is not None:
             _check_input(loss_grad, "loss_grad")
             if tuple(loss_grad.shape) != (self.B,) or loss_grad.device != self.device:
                 raise RuntimeError(f"loss_grad must have shape ({self.B},) on {self.device}")
+        if prepared is not None:
+            # second half of a step begun by forward_l1(prepare_backward=True): into the volume that forward zero-filled;
+            # as the step's backward (no prologue, the forward's records) only for the very tensors the forward saw
+            key, g_sdf, deferred = prepared
+            self.g_sdf = g_sdf
+            self._g_sdf_index = self._g_sdf_next
+            self._g_sdf_next = (self._g_sdf_next + 1) % len(self._g_sdf_ring)
+            if key == self._key(sdf, pos, quat, inv_scale):
+                mode = self.sdf_grad_mode
+                if self._close_auto:      # the half-grid hint, as in ``backward``
+                    seen, close = self.close_views_seen()
+                    if seen and close >= 0.9 * self.B:
+                        mode |= BWD_HALF_GRID
+                self.half_grid_steps += 1 if mode & BWD_HALF_GRID else 0
+                rc = self._L.sdfr_render_step_backward_l1(
+                    loss_grad.data_ptr() if loss_grad is not None else None, weight,
+                    None if deferred else self.loss_stats.data_ptr(), target.data_ptr(), self.depth.data_ptr(),
+                    sdf.data_ptr(), self.R, self.sdf_stride, self.B, self.W, self.H, self.cx, self.cy, self.fx, self.fy,
+                    mode, self.g_sdf.data_ptr(), self.sdf_stride,
+                    None if defer_pose else self.g_pos.data_ptr(), None if defer_pose else self.g_quat.data_ptr(),
+                    None if defer_pose else self.g_inv_scale.data_ptr(), self.workspace.data_ptr(),
+                    self.workspace.numel(), self.loss.data_ptr() if deferred else None,
+                    self.loss_stats.data_ptr() if deferred else None, self.device.index, _stream(self.device))
+                _lib.check(rc, "sdfr_render_step_backward_l1")
+                self.partials_offset = self._L.sdfr_render_partials_offset(self.R, self.B, self.W, self.H, 1)
+                self._fixed_layout = 1
+                return self.g_sdf, self.g_pos, self.g_quat, self.g_inv_scale
+            if deferred:
+                raise RuntimeError("forward_l1(defer_loss=True) must be followed by the step's backward on the same "
+                                   "tensors: its loss statistics were left to that launch")
         rc = self._L.sdfr_render_backward_l1(
             loss_grad.data_ptr() if loss_grad is not None else None, weight,
             self.loss_stats.data_ptr(), target.data_ptr(), self.depth.data_ptr(), sdf.data_ptr(),
@@ -760,10 +798,13 @@ class BatchRenderPlan:
             # second half of a step begun by forward_l1(prepare_backward=True): its backward writes the volume that
             # forward zero-filled.  As a step's backward (no prologue, the forward's view records and rectangles)
             # only for the very tensors the forward saw, judged like ``backward`` does (address and version counter)
-            key, self.g_sdf = prepared
+            key, self.g_sdf, deferred = prepared
             self._g_sdf_index = self._g_sdf_next
             self._g_sdf_next = (self._g_sdf_next + 1) % len(self._g_sdf_ring)
             if key != self._key(sdf, pos, quat, inv_scale):
+                if deferred:
+                    raise RuntimeError("forward_l1(defer_loss=True) must be followed by the step's backward on the "
+                                       "same tensors: its loss statistics were left to that launch")
                 prepared = None
         if prepared is not None:
             self.partials_offset = self._L.sdfr_render_partials_offset(self.R, self.B, self.W, self.H, 1)
@@ -771,15 +812,19 @@ class BatchRenderPlan:
         else:
             self.partials_offset = self._L.sdfr_render_partials_offset(self.R, self.B, self.W, self.H, 0)
             self._fixed_layout = 0
-        fn = self._L.sdfr_render_step_backward_l1_pc if prepared is not None else self._L.sdfr_render_backward_l1_pc
-        rc = fn(
-            loss_grad.data_ptr() if loss_grad is not None else None, weight,
-            self.loss_stats.data_ptr(), target.data_ptr(), self.depth.data_ptr(), sdf.data_ptr(),
-            self.R, self.sdf_stride, pos.data_ptr(), quat.data_ptr(), inv_scale.data_ptr(), self.B,
-            self.W, self.H, self.cx, self.cy, self.fx, self.fy, self.sdf_grad_mode,
-            self.g_sdf.data_ptr(), self.sdf_stride, self.workspace.data_ptr(), self.workspace.numel(),
-            pc_weight, points.data_ptr(), offsets.data_ptr() if offsets is not None else None, max_view_points,
-            scale.data_ptr(), pc_workspace.data_ptr(), pc_workspace.numel(),
-            self.device.index, _stream(self.device))
+        deferred = prepared is not None and prepared[2]
+        args = (loss_grad.data_ptr() if loss_grad is not None else None, weight,
+                None if deferred else self.loss_stats.data_ptr(), target.data_ptr(), self.depth.data_ptr(),
+                sdf.data_ptr(), self.R, self.sdf_stride, pos.data_ptr(), quat.data_ptr(), inv_scale.data_ptr(), self.B,
+                self.W, self.H, self.cx, self.cy, self.fx, self.fy, self.sdf_grad_mode,
+                self.g_sdf.data_ptr(), self.sdf_stride, self.workspace.data_ptr(), self.workspace.numel(),
+                pc_weight, points.data_ptr(), offsets.data_ptr() if offsets is not None else None, max_view_points,
+                scale.data_ptr(), pc_workspace.data_ptr(), pc_workspace.numel())
+        if prepared is not None:
+            rc = self._L.sdfr_render_step_backward_l1_pc(
+                *args, self.loss.data_ptr() if deferred else None, self.loss_stats.data_ptr() if deferred else None,
+                self.device.index, _stream(self.device))
+        else:
+            rc = self._L.sdfr_render_backward_l1_pc(*args, self.device.index, _stream(self.device))
         _lib.check(rc, "sdfr_render_backward_l1_pc" if prepared is None else "sdfr_render_step_backward_l1_pc")
         return self.g_sdf

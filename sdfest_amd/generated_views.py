@@ -203,9 +203,11 @@ class PointSets:
 def depth_to_centred_pointsets(depth: torch.Tensor, camera: Camera, noise: Optional[torch.Tensor] = None,
                                while_waiting=None):
     """``depth_to_pointsets`` for the generator's normalised samples (generated_dataset.py:318-326): every view's
-    points minus their centroid (plus ``noise`` (B,3), if given), without a pass over the packed points -- the count
-    pass leaves the centroids (``sdfr_depth_count_centroid``), the compaction subtracts them
-    (``sdfr_depth_to_points_shifted``).  Returns (points (N,3), counts (B,) int64 on the device, counts on the host,
+    points minus their centroid (plus ``noise`` (B,3), if given: ``(points - centroid) + noise``, the reference's two
+    roundings), without a pass over the packed points -- the count pass leaves the centroids
+    (``sdfr_depth_count_centroid``), the compaction subtracts them (``sdfr_depth_to_points_shifted``).  The centroid
+    itself is a fixed-order float32 block-sum tree, not ``torch.mean``'s: equal to it within float32 rounding of the
+    mean (a few 1e-7 relative), which the tests state.  Returns (points (N,3), counts (B,) int64 on the device, counts on the host,
     centroid (B,3)); one synchronisation (the caller sizes the output).  ``while_waiting``: called on the host
     after the count pass has been issued and before its result is waited for (CPU work that hides behind the GPU's)."""
     from . import _lib
@@ -222,7 +224,7 @@ def depth_to_centred_pointsets(depth: torch.Tensor, camera: Camera, noise: Optio
     _lib.check(L.sdfr_depth_count_centroid(depth.data_ptr(), V, W, H, 0, 1.0 / fx, 1.0 / fy, cx, cy, counts.data_ptr(),
                                            offsets.data_ptr(), centroid.data_ptr(), ws.data_ptr(), ws.numel(),
                                            dev.index, st), "sdfr_depth_count_centroid")
-    shift = centroid if noise is None else centroid - noise.to(centroid)
+    noise_dev = None if noise is None else noise.to(centroid).contiguous()
     host = torch.empty(V, dtype=torch.int32).pin_memory()
     host.copy_(counts, non_blocking=True)
     done = torch.cuda.Event()
@@ -235,7 +237,8 @@ def depth_to_centred_pointsets(depth: torch.Tensor, camera: Camera, noise: Optio
     pts = torch.empty((int(counts_host.sum()), 3), dtype=torch.float32, device=dev)
     if pts.shape[0]:
         _lib.check(L.sdfr_depth_to_points_shifted(depth.data_ptr(), V, W, H, 0, 1.0 / fx, 1.0 / fy, cx, cy,
-                                                  offsets.data_ptr(), ws.data_ptr(), shift.contiguous().data_ptr(),
+                                                  offsets.data_ptr(), ws.data_ptr(), centroid.data_ptr(),
+                                                  noise_dev.data_ptr() if noise_dev is not None else None,
                                                   pts.data_ptr(), dev.index, st), "sdfr_depth_to_points_shifted")
     return pts, counts64, counts_host, centroid
 
@@ -260,9 +263,8 @@ class SDFVAEViewGenerator:
         self.prefetch_draws = bool(prefetch_draws)
         self.decode_ahead = bool(decode_ahead)
         self._ahead = None
-        self._side = None          # the second stream, the event after this stream's last decode, the batch decoded ahead
+        self._side = None          # the second stream and the batch decoded ahead on it
         self._decoded = None
-        self._decode_done = None
         cfg = dict(DEFAULT_CONFIG)
         cfg.update(config)
         for k in ("z_min", "z_max", "extent_mean", "extent_std"):
@@ -306,8 +308,6 @@ class SDFVAEViewGenerator:
         z0, p, q, s = self._ahead
         Lz = z0.shape[1]
         with torch.cuda.stream(self._side), torch.no_grad():
-            if self._decode_done is not None:       # this stream's last decode shares the decoder's workspace
-                self._side.wait_event(self._decode_done)
             packed = torch.cat((z0, p, q, s[:, None]), 1).to(dev, non_blocking=True)
             latent, position, quaternion, scale = (packed[:, :Lz], packed[:, Lz:Lz + 3].clone(),
                                                    packed[:, Lz + 3:Lz + 7], packed[:, Lz + 7].clone())
@@ -374,12 +374,8 @@ class SDFVAEViewGenerator:
                 depth = self.plan.forward(sdf_ahead, position.contiguous(), quaternion.contiguous(),
                                           (1.0 / scale).contiguous(), cfg["render_threshold"], out=depth_out)
         else:
-            if self._side is not None:   # (a decode still running ahead -- discarded or not -- uses the same workspace)
-                torch.cuda.current_stream(dev).wait_stream(self._side)
+            # (a decode still running ahead on the second stream has its own scratch: SDFDecoder keeps one per stream)
             depth = self.render(latent, position, quaternion, scale, out=depth_out)
-            if self.decode_ahead and dev.type == "cuda":   # (the decoder's workspace is free from here on)
-                self._decode_done = torch.cuda.Event()
-                self._decode_done.record(torch.cuda.current_stream(dev))
         final_mask = None
         if cfg["mask_noise"]:                                                          # :286-291
             if mask_affine is None:
@@ -457,6 +453,8 @@ class SDFVAEViewGenerator:
         return res
 
     def __iter__(self):
+        # (the consumer may use the same decoder on its own stream between two samples -- a validation decode, a VJP, a
+        # FusedRenderAndCompare: the decode running ahead on the second stream has a scratch buffer of its own)
         self.prefetch_draws = True
         self.decode_ahead = True
         while True:

@@ -573,8 +573,9 @@ class FusedRenderAndCompare:
         if self._tail_form():
             # [decoder] -> render pair as a step -> [decoder VJP] -> sdfr_loop_tail; the camera-frame poses of THIS
             # iteration were left by the previous tail (or by _poses_to_views before the first one)
+            # (the depth loss values are reduced inside the backward's launch: no launch between the image kernels)
             self.plan.forward_l1(sdf, self.pos_c, self.quat_c, self.inv_scale, self.cfg["threshold"], self.target,
-                                 prepare_backward=True)
+                                 prepare_backward=True, defer_loss=True)
             self.loss_depth = self.plan.loss
             g_sdf = self.plan.backward_l1_pc(self.target, sdf, self.pos_c, self.quat_c, self.inv_scale,
                                              self.scale_v, self.points, self.offsets, self.max_pts, self.ws_pc,
@@ -705,7 +706,7 @@ class FusedRenderAndCompare:
         # torch.mean over nothing, simple_setup.py:144, and they contribute no gradient -- as in the reference)
         have_pts = True
         self.plan.forward_l1(sdf, self.pos_c, self.quat_c, self.inv_scale, self.cfg["threshold"], self.target,
-                             prepare_backward=True)
+                             prepare_backward=True, defer_loss=True)
         g_sdf = self.plan.backward_l1_pc(self.target, sdf, self.pos_c, self.quat_c, self.inv_scale, self.scale_v,
                                          self.points, self.offsets, self.max_pts, self.ws_pc,
                                          weight=self.cfg["depth_weight"], pc_weight=self.cfg["pc_weight"])

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .differentiable_renderer import _stream
 
 
 def _flatten_state(state: Mapping, n_fc: int, n_conv: int, prefix: str) -> np.ndarray:
@@ -84,7 +85,7 @@ class SDFDecoder:
                                    self.device.index, ctypes.byref(handle))
         _lib.check(rc, "sdfr_decoder_create")
         self._L, self._h = L, handle
-        self._ws = None
+        self._ws = {}     # stream handle -> scratch buffer
 
     @classmethod
     def from_config(cls, config: Mapping, state_dict: Mapping, device="cuda", sdf_size: int = 64):
@@ -98,10 +99,28 @@ class SDFDecoder:
             self._L.sdfr_decoder_destroy(h)
             self._h = None
 
+    OPTIONS = {"fused_resize": 0, "tiled_vjp": 1, "fc_one_wave": 2}     # SDFR_DECODER_OPT_* (include/sdfr.h)
+
+    def set_option(self, name: str, value: int) -> int:
+        """Select one of two equivalent kernel forms for THIS decoder (``sdfr_decoder_set_option``: same results bit
+        for bit, the defaults are the faster forms); returns the old value."""
+        old = self._L.sdfr_decoder_set_option(self._h, self.OPTIONS[name], int(value))
+        if old < 0:
+            _lib.check(old, "sdfr_decoder_set_option")
+        return old
+
     def _scratch(self, need: int) -> torch.Tensor:
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
-        return self._ws
+        """Scratch of the calls on the CURRENT stream, grown on demand -- one buffer per stream, like the renderer's
+        (``differentiable_renderer._workspace``): two streams driving the same decoder (the view generator decodes
+        the next batch on a side stream while its consumer decodes or differentiates on its own) never share
+        intermediate tensors without an ordering between them.  A buffer that is outgrown goes back to the caching
+        allocator, which keeps it out of circulation until the work queued on ITS stream has finished."""
+        key = _stream(self.device)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
 
     def _forward_raw(self, zc: torch.Tensor, enforce_tsdf: bool, tape: Optional[torch.Tensor]):
         N, D = zc.shape[0], self._volume_size
@@ -110,7 +129,7 @@ class SDFDecoder:
         rc = self._L.sdfr_decoder_forward(self._h, zc.data_ptr(), N, int(bool(enforce_tsdf)),
                                           out.data_ptr(), None if tape is None else tape.data_ptr(),
                                           ws.data_ptr(), ws.numel(),
-                                          torch.cuda.current_stream(self.device).cuda_stream)
+                                          _stream(self.device))
         _lib.check(rc, "sdfr_decoder_forward")
         return out
 
@@ -121,7 +140,7 @@ class SDFDecoder:
         rc = self._L.sdfr_decoder_backward_latent(self._h, zc.data_ptr(), tape.data_ptr(),
                                                   grad_out.data_ptr(), N, g_z.data_ptr(),
                                                   ws.data_ptr(), ws.numel(),
-                                                  torch.cuda.current_stream(self.device).cuda_stream)
+                                                  _stream(self.device))
         _lib.check(rc, "sdfr_decoder_backward_latent")
         return g_z
 

@@ -26,9 +26,11 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     else:
         dist.init_process_group(backend, rank=rank, world_size=world)
-    sc = _loop_scenes.build(scene)
+    iterations = int(os.environ.get("SDFR_TEST_ITERATIONS", "0")) or None
+    sc = _loop_scenes.build(scene, iterations=iterations)
     mode = (SDF_GRAD_DETERMINISTIC | BWD_SMALL_TILES) if flavour == "det" else 0
-    hist = []
+    # "graph_nohist": no history -> the multi-iteration replay (head | all-reduce | tail + next head | all-reduce | ...)
+    hist = None if graph == "graph_nohist" else []
     if form in ("fused", "fused_pose_only"):
         # "fused_pose_only": shape optimisation off (the exchange is the view records alone) and a point constraint
         con = (torch.tensor([0.0, 1.0, 0.0]), torch.tensor([0.1, 0.9, -0.2]), 0.05) if form == "fused_pose_only" else None
@@ -36,7 +38,7 @@ def main():
                                      camera_orientations=sc["cam_quat"], shape_optimization=(form == "fused"),
                                      process_group="world", exchange=exchange, sdf_grad_mode=mode, track_inliers=True,
                                      point_constraint=con)
-        out = loop(*sc["init"], use_graph=(graph == "graph"), history=hist)
+        out = loop(*sc["init"], use_graph=graph.startswith("graph"), history=hist)
         inl = loop.inlier_history.cpu().numpy()
         shard = (loop.view_begin, loop.view_end)
     else:
@@ -47,8 +49,9 @@ def main():
         shard = (-1, -1)
     torch.cuda.synchronize()
     final = np.concatenate([o.detach().cpu().numpy().ravel() for o in out])
-    traj = _loop_scenes.history_array(hist)
-    loss = np.array([float(h["loss"]) for h in hist])
+    traj = _loop_scenes.history_array(hist) if hist else final[None]
+    loss = np.array([float(h["loss"]) for h in hist]) if hist else np.zeros(0)
+    steps_taken = int(loop.step.item()) if hasattr(loop, "step") else -1
     parts = [None] * world
     dist.all_gather_object(parts, (rank, final, traj, loss, inl, shard))
     if rank == 0:
@@ -57,7 +60,7 @@ def main():
                    and np.array_equal(p[3], parts[0][3], equal_nan=True) and np.array_equal(p[4], parts[0][4], equal_nan=True)
                    for p in parts)
         np.savez(out_path, final=final, traj=traj, loss=loss, inlier=inl, ranks_identical=same,
-                 shards=np.array([p[5] for p in parts]))
+                 shards=np.array([p[5] for p in parts]), steps_taken=steps_taken)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -34,6 +34,21 @@ def test_library_exports_every_declared_symbol(libpath):
         assert hasattr(h, s), f"{s} declared in include/sdfr.h but not exported"
 
 
+def test_shipped_library_exports_no_test_switches(libpath):
+    """The production ABI has no process-global test hooks: kernel-form selection is per decoder handle
+    (sdfr_decoder_set_option), the prologue's poll bound per workspace (sync header words 6 / 7), the timing stamps
+    exist only in -DSDFR_TAIL_STAMPS builds.  Every exported symbol is one the header declares."""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", libpath], text=True)
+    exported = sorted(line.split()[-1] for line in out.splitlines() if " T " in line)
+    ours = [s for s in exported if s.startswith("sdfr_")]
+    assert ours, "no sdfr_ symbols exported?"
+    assert not [s for s in exported if "debug" in s.lower()], "a debug switch is exported"
+    assert sorted(ours) == declared_symbols()
+    header = open(os.path.join(ROOT, "include", "sdfr.h")).read()
+    assert "TEST HOOK" not in header and "sdfr_debug" not in header
+
+
 def test_binding_table_matches_header(libpath):
     from sdfest_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_symbols()

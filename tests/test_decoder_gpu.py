@@ -143,9 +143,17 @@ def test_decoder_latent_gradient_matches_torch_autograd_golden(mug):
     out = dec.decode(z)
     (out[:, 0] * torch.tensor(G, device="cuda")).sum().backward()
     gz = z.grad.cpu().numpy()
-    ref = d["grad_z"]
+    # the north star's bound, 1e-4 of each latent's largest component, against the reference module in FLOAT64
+    # (tools/make_goldens.py::make_decoder, vae.double()) ...
+    ref = d["grad_z_f64"]
     scale = np.abs(ref).max(axis=1, keepdims=True)
-    assert np.max(np.abs(gz - ref) / scale) <= 2e-4, np.max(np.abs(gz - ref) / scale)
+    err = np.max(np.abs(gz - ref) / scale)
+    assert err <= 1e-4, f"latent gradient vs the float64 reference decoder: {err:.2e} of the row maximum"
+    # ... and 2e-4 only against the module's own float32 run: two fp32 implementations, each within its rounding of
+    # the float64 value (the torch one by 9e-7 here)
+    ref32 = d["grad_z"]
+    err32 = np.max(np.abs(gz - ref32) / np.abs(ref32).max(axis=1, keepdims=True))
+    assert err32 <= 2e-4, f"latent gradient vs the fp32 torch run (fp32 against fp32): {err32:.2e}"
     # forward with a tape gives the same output as the inference path
     with torch.no_grad():
         assert torch.equal(dec.decode(z.detach()), out.detach())
@@ -207,7 +215,7 @@ def test_decoder_latent_gradient_other_architecture_vs_torch():
     (ref[:, 0] * torch.tensor(G).double()).sum().backward()
     assert np.max(np.abs(out.detach().cpu().numpy() - ref.detach().numpy())) <= 1e-4 * ref.abs().max().item()
     g, gr = z.grad.cpu().numpy(), zt.grad.numpy()
-    assert np.max(np.abs(g - gr)) <= 2e-4 * np.abs(gr).max(), (g, gr)
+    assert np.max(np.abs(g - gr)) <= 1e-4 * np.abs(gr).max(), (g, gr)      # (gr: torch in float64)
 
 
 def test_decoder_latent_gradient_wide_hidden_layer_vs_torch():
@@ -245,7 +253,7 @@ def test_decoder_latent_gradient_wide_hidden_layer_vs_torch():
         (out[:, 0] * torch.tensor(G, device="cuda")).sum().backward()
         assert np.max(np.abs(out.detach().cpu().numpy() - ref.detach().numpy())) <= 1e-4 * ref.abs().max().item()
         g = z.grad.cpu().numpy()
-        assert np.max(np.abs(g - gr)) <= 2e-4 * np.abs(gr).max(), (g, gr)
+        assert np.max(np.abs(g - gr)) <= 1e-4 * np.abs(gr).max(), (g, gr)      # (gr: torch in float64)
 
 
 def test_batched_decoder_kernels_equal_single_decodes(mug):
@@ -271,7 +279,9 @@ def test_batched_decoder_kernels_equal_single_decodes(mug):
         a, b = out[i].detach(), oi[0].detach()
         assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-3), i
         ga, gb = z.grad[i], zi.grad[0]
-        assert (ga - gb).abs().max().item() <= 2e-4 * gb.abs().max().item(), (i, ga, gb)
+        assert (ga - gb).abs().max().item() <= 2e-4 * gb.abs().max().item(), (
+            "batched against single-latent kernels -- fp32 against fp32, hence 2e-4 and not the 1e-4 kept for float64 "
+            "comparands", i, ga, gb)
     # and the golden output of the reference decoder for the first latent (z = 0 is d["z"][0]?)
     with torch.no_grad():
         o = dec.decode(torch.zeros(N, 8, device="cuda"))
@@ -330,14 +340,14 @@ def test_tiled_transposed_resize_is_bitwise_the_three_launches(mug):
         G = torch.tensor(rng.normal(size=(N, 1, volume, volume, volume)).astype(np.float32), device="cuda")
         grads = []
         for on in (1, 0):
-            old = L.sdfr_debug_set_decoder_tiled_vjp(on)
+            old = dec.set_option("tiled_vjp", on)
             try:
                 z = torch.tensor(z_np, device="cuda", requires_grad=True)
                 dec.decode(z).backward(G)
                 torch.cuda.synchronize()
                 grads.append(z.grad.clone())
             finally:
-                L.sdfr_debug_set_decoder_tiled_vjp(old)
+                dec.set_option("tiled_vjp", old)
         assert torch.isfinite(grads[0]).all() and grads[0].abs().max() > 0, name
         assert torch.equal(grads[0], grads[1]), (name, N, (grads[0] - grads[1]).abs().max().item())
 
@@ -380,7 +390,7 @@ def test_resize_folded_into_the_patch_load_is_bitwise_the_two_launches(mug):
         G = torch.tensor(rng.normal(size=(N, 1, volume, volume, volume)).astype(np.float32), device="cuda")
         outs, grads = [], []
         for on in (2, 0):      # folded wherever the form exists / never (the default folds fine sizes up to 16)
-            old = L.sdfr_debug_set_decoder_fused_resize(on)
+            old = dec.set_option("fused_resize", on)
             try:
                 z = torch.tensor(z_np, device="cuda", requires_grad=True)
                 o = dec.decode(z)
@@ -389,7 +399,7 @@ def test_resize_folded_into_the_patch_load_is_bitwise_the_two_launches(mug):
                 outs.append(o.detach().clone())
                 grads.append(z.grad.clone())
             finally:
-                L.sdfr_debug_set_decoder_fused_resize(old)
+                dec.set_option("fused_resize", old)
         assert torch.isfinite(outs[0]).all() and outs[0].abs().max() > 0, name
         assert torch.equal(outs[0], outs[1]), (name, N, (outs[0] - outs[1]).abs().max().item())
         assert torch.equal(grads[0], grads[1]), (name, N)
@@ -423,7 +433,7 @@ def test_one_wave_linear_backward_is_bitwise_the_workgroup_form(mug):
         G = torch.tensor(rng.normal(size=(N, 1, volume, volume, volume)).astype(np.float32), device="cuda")
         grads, outs = [], []
         for on in (1, 0):
-            old = L.sdfr_debug_set_decoder_fc_one_wave(on)
+            old = dec.set_option("fc_one_wave", on)
             try:
                 z = torch.tensor(z_np, device="cuda", requires_grad=True)
                 o = dec.decode(z)
@@ -432,7 +442,7 @@ def test_one_wave_linear_backward_is_bitwise_the_workgroup_form(mug):
                 grads.append(z.grad.clone())
                 outs.append(o.detach().clone())
             finally:
-                L.sdfr_debug_set_decoder_fc_one_wave(old)
+                dec.set_option("fc_one_wave", old)
         assert torch.isfinite(grads[0]).all() and grads[0].abs().max() > 0, name
         assert torch.equal(outs[0], outs[1]), (name, N, (outs[0] - outs[1]).abs().max().item())   # (the forward's stack too)
         assert torch.equal(grads[0], grads[1]), (name, N, (grads[0] - grads[1]).abs().max().item())

@@ -151,6 +151,12 @@ def test_centred_point_sets_come_out_of_the_two_image_passes(mug_decoder):
                 assert torch.allclose(centroid[v].double(), c, rtol=2e-6, atol=1e-7), (W, H, v)
                 want = ref.double() - centroid[v].double() + (0 if noise is None else noise[v].double())
                 assert torch.allclose(part.double(), want, rtol=0, atol=3e-7 * float(ref.abs().max()))
+                # and bit for bit the reference's two float32 operations on the kernel's centroid: `pointset -=
+                # centroid`, then `pointset += noise` (generated_dataset.py:314-326)
+                want32 = ref - centroid[v]
+                if noise is not None:
+                    want32 = want32 + noise[v]
+                assert torch.equal(part, want32), (W, H, v, (part - want32).abs().max())
 
 
 def test_prefetched_draws_are_the_same_numbers(mug_decoder):

@@ -5,8 +5,8 @@ by tools/make_goldens.py::make_loop_g7 -> tests/golden/loop_g7.npz.  Run A: 2 vi
 extrinsics, shape optimisation on; run B: 1 view, point constraint, shape optimisation off; run C (round 4): the
 CLEAN scene -- 160x120, 2 views, shape optimisation on, the first seeded scene in which no sample of any ray of any
 iteration lies within 2e-7 of its hit test (fp32 against the twin's float64 moves that comparison by ~1e-8), so
-nothing has to be allowed for pixels that flip between hit and miss: loss terms to 5e-5, first gradients to 2e-4 of
-their group's scale, the trajectory to 0.5 % of an Adam step per iteration.  Runs A and B are FRAGILE (pixels down to
+nothing has to be allowed for pixels that flip between hit and miss: loss terms to 5e-5, first gradients to 1e-4 of
+their group's scale (against the float64 pass of the same loop), the trajectory to 0.5 % of an Adam step per iteration.  Runs A and B are FRAGILE (pixels down to
 6e-8 of their hit test; the golden carries the counts) and keep the looser bounds.
 Checked per iteration: parameters, first-iteration gradients, loss terms, the inlier ratio of the LAST
 view's loop variables (:463-470); plus nn_loss / point_constraint_loss on seeded inputs."""
@@ -134,11 +134,13 @@ def test_fused_loop_matches_g7(g7, mug, tag, use_graph):
     assert torch.equal(out[0], hist[-1]["position"])
 
 
-@pytest.mark.parametrize("tag,tol", [("a", 2e-3), ("c", 2e-4)])
+@pytest.mark.parametrize("tag,tol", [("a", 2e-3), ("c", 1e-4)])
 def test_first_gradient_matches_g7(g7, mug, tag, tol):
     """Iteration 1 before Adam: d loss / d (position, orientation, scale, latent) as autograd gave them to the
-    reference pieces (the chain through both cameras, the normalisation and the decoder).  The clean scene C at
-    2e-4 of each group's largest component; the fragile scene A keeps 2e-3 (a flipped pixel moves a masked mean)."""
+    reference pieces (the chain through both cameras, the normalisation and the decoder).  The clean scene C at the
+    north star's 1e-4 of each group's largest component against the FLOAT64 pass of the same assembled loop
+    (``c_grads_f64``: vae.double(), float64 parameters; the float32 pass ``c_grads`` is itself 1.8e-6 away from it);
+    the fragile scene A keeps 2e-3 against its float32 pass (a flipped pixel moves a masked mean)."""
     from sdfest_amd.pipeline import RenderAndCompare
     cam, cfg, a, _ = _setup(g7, tag)
     loop = RenderAndCompare(mug, cam, cfg)
@@ -148,7 +150,7 @@ def test_first_gradient_matches_g7(g7, mug, tag, tol):
     ld, lp, _ = loop.losses(a["depth"], points, offsets, lens, a["cam_pos"], a["cam_quat"], p, q, s, sdf)
     (1.0 * ld + 3.0 * lp).backward()
     got = np.concatenate([x.grad.cpu().numpy().ravel() for x in (p, q, s, z)])
-    ref = g7[f"{tag}_grads"][0]
+    ref = g7[f"{tag}_grads_f64"] if f"{tag}_grads_f64" in g7 else g7[f"{tag}_grads"][0]
     scale = np.array([np.abs(ref[0:3]).max()] * 3 + [np.abs(ref[3:7]).max()] * 4 + [abs(ref[7])]
                      + [np.abs(ref[8:]).max()] * (len(ref) - 8))
     assert np.all(np.abs(got - ref) < tol * scale), (np.abs(got - ref) / scale, _fragility(g7, tag))

@@ -82,6 +82,46 @@ def test_sharded_loop_matches_the_single_process_loop(tmp_path, scene, exchange)
     assert np.allclose(loss, r["loss"], rtol=1e-4) and np.max(np.abs(inl - r["inlier"])) < 2.5 / 300
 
 
+def test_records_form_multi_iteration_graph_replays(tmp_path, monkeypatch):
+    """The records form's replay paths that run only WITHOUT a history (the default for 8 or more views, and the only
+    form a process group can use): two ranks replaying `tail + next head` between the all-reduces
+    (``_run_records``' graph_many), and a single process replaying graphs of 3 and of 5 iterations with a remainder
+    (``_run_records_single``) -- the plan's ring_reset and volume bookkeeping inside a multi-iteration capture, the
+    head / tail interleaving around the collective.  Deterministic mode: final parameters, step count and inlier
+    history are BITWISE the eager run's."""
+    from sdfest_amd.differentiable_renderer import BWD_SMALL_TILES, SDF_GRAD_DETERMINISTIC
+    from sdfest_amd.pipeline import FusedRenderAndCompare
+    det = SDF_GRAD_DETERMINISTIC | BWD_SMALL_TILES
+    n_iter = 7
+    sc = _loop_scenes.build("seven", iterations=n_iter)
+
+    def single(use_graph, graph_iterations=5, history=False):
+        loop = FusedRenderAndCompare(sc["decoder"], sc["camera"], sc["config"], sc["depth"], camera_positions=sc["cam_pos"],
+                                     camera_orientations=sc["cam_quat"], shape_optimization=True, sdf_grad_mode=det,
+                                     track_inliers=True, graph_iterations=graph_iterations)
+        assert loop.records_form
+        res = []
+        for _ in range(2):        # the second call replays what the first captured
+            out = loop(*sc["init"], use_graph=use_graph, history=[] if history else None)
+            torch.cuda.synchronize()
+            res.append((np.concatenate([o.cpu().numpy().ravel() for o in out]), int(loop.step.item()),
+                        loop.inlier_history.cpu().numpy().copy(), loop.best_state.cpu().numpy().copy()))
+        assert loop.graph_many is not None or not use_graph or graph_iterations == 1
+        return res
+    ref = single(False, history=True)[0]
+    assert ref[1] == n_iter and np.abs(ref[0][8:]).max() > 1e-4 and ref[2][:n_iter].max() > 0
+    for gi in (5, 3, 1):
+        for got in single(True, gi):
+            assert np.array_equal(got[0], ref[0]), (gi, got[0], ref[0])
+            assert got[1] == ref[1] and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3]), gi
+    # two ranks, no history: graph_many = this iteration's tail and the next one's head between two all-reduces
+    monkeypatch.setenv("SDFR_TEST_ITERATIONS", str(n_iter))
+    r = _spawn(tmp_path, "seven", "det", "sdf", "graph_nohist")
+    assert int(r["steps_taken"]) == n_iter
+    assert np.array_equal(r["final"], ref[0]), (r["final"], ref[0])
+    assert np.array_equal(r["inlier"], ref[2])
+
+
 def test_deterministic_backward_with_the_latent_exchange(tmp_path):
     """SDF_GRAD_DETERMINISTIC with exchange="latent": every rank's d/d latent is a float contribution, so this bucket
     is summed as floats (summing its bits as integers would be no sum at all) -- the trajectory follows the

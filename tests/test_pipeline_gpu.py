@@ -358,7 +358,7 @@ def test_empty_overlap_view_gives_nan_loss_and_finite_steps(mug_decoder):
 def test_one_wave_linear_backward_in_the_tail_is_bitwise_the_workgroup_form(mug_decoder, views):
     """The tail's backward of the mug decoder's narrow Linear stack (8 -> 20 -> 50) as ONE wave out of LDS, the other
     waves reducing the views meanwhile (fc_stack_backward_one_wave), against the one-workgroup form of wider stacks
-    (sdfr_debug_set_decoder_fc_one_wave(0)): same fmaf chains in the same order.  Nine views (records form: the tail
+    (sdfr_decoder_set_option(SDFR_DECODER_OPT_FC_ONE_WAVE, 0)): same fmaf chains in the same order.  Nine views (records form: the tail
     works from the records) in the deterministic d/dSDF mode -- no float atomics anywhere on the way --: a
     shape-optimising run agrees bit for bit, every iteration, eager and replayed.  One view (the tail reduces the view
     itself, three waves beside the Linear stack's one): the float atomics of d/dSDF leave their ~1e-7 of noise, as
@@ -389,7 +389,7 @@ def test_one_wave_linear_backward_in_the_tail_is_bitwise_the_workgroup_form(mug_
     args = (p_true + 0.008, q0 / q0.norm(), t([0.058]), torch.zeros(1, 8, device=dev))
     runs = {}
     for on in (1, 0):
-        old = L.sdfr_debug_set_decoder_fc_one_wave(on)
+        old = dec.set_option("fc_one_wave", on)
         try:
             loop = FusedRenderAndCompare(dec, cam, cfg, obs.contiguous(), cam_pos, cam_quat,
                                          sdf_grad_mode=SDF_GRAD_DETERMINISTIC if views >= 8 else 0)
@@ -400,7 +400,7 @@ def test_one_wave_linear_backward_in_the_tail_is_bitwise_the_workgroup_form(mug_
                 torch.cuda.synchronize()
                 runs[(on, use_graph)] = h
         finally:
-            L.sdfr_debug_set_decoder_fc_one_wave(old)
+            dec.set_option("fc_one_wave", old)
     ref = runs[(0, False)]
     assert (ref[-1]["latent"]).abs().max().item() > 1e-3 and (ref[-1]["position"] - args[0]).abs().max().item() > 1e-3
     for key, h in runs.items():

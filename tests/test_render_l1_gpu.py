@@ -100,6 +100,79 @@ def test_fused_equals_unfused_and_oracle(R, B, W, H, f):
         assert np.all(np.abs(pose - ref) <= REL * l1), (b, pose, ref, l1)
 
 
+@pytest.mark.parametrize("B,W,H,f", [(1, 160, 120, 80.0), (3, 640, 480, 320.0), (6, 320, 240, 160.0),
+                                     (40, 640, 480, 320.0), (256, 640, 480, 320.0)])
+def test_loss_fused_step_equals_the_unfused_step_bit_for_bit(R, B, W, H, f):
+    """forward_l1(prepare_backward=True) -> backward_l1 as ONE step (sdfr_render_step_forward_l1 /
+    sdfr_render_step_backward_l1), with the loss statistics reduced by the forward's own launch or DEFERRED into the
+    backward's (no launch between the image kernels), against the unfused step on the same plan geometry: forward(
+    prepare_backward=True) -> sdfr_depth_l1_loss -> backward.  Same depth, same loss and statistics, same pose
+    gradients, bit for bit; d/dSDF up to the order of its float atomics.  B = 1: the inline set-up (no prologue
+    launch at all); 3: plain grid; 6: packed records; 40, 256: batch tiles, 256 = the benchmark's C3."""
+    from sdfest_amd import _lib
+    from sdfest_amd.differentiable_renderer import BatchRenderPlan, Camera
+    L = _lib.lib()
+    if B == 256:     # (the oracle render of 256 observed images would take minutes: the observation is a HIP render)
+        sdf = oracle.blobs_sdf(0)
+        pos, quat, isc = oracle.random_poses(B, seed=1, width=W, height=H, f=f)
+        cam = (W, H, W / 2, H / 2, f, f)
+        rng = np.random.default_rng(7)
+        pos_t = pos + rng.normal(0, 0.01, pos.shape).astype(np.float32)
+        tgt = R.forward_raw(dev(sdf), dev(pos_t), dev(quat), dev(isc), W, H, W / 2, H / 2, f, f, 0.005)
+        tgt = torch.where(torch.rand(tgt.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(3)) < 0.1,
+                          torch.zeros_like(tgt), tgt).cpu().numpy()
+    else:
+        sdf, pos, quat, isc, cam, tgt = scene(B, W, H, f)
+    camera = Camera(W, H, cam[4], cam[5], cam[2], cam[3], pixel_center=0.5)
+    a = [dev(sdf), dev(pos), dev(quat), dev(isc)]
+    t = dev(tgt)
+    w = 0.7
+    # the unfused step (close_views=False: the loss-fused forms ignore the half-grid hint)
+    plan_u = BatchRenderPlan(64, B, camera, close_views=False)
+    depth_u = plan_u.forward(*a, 0.005, prepare_backward=True)
+    loss_u = torch.empty(B, device="cuda")
+    grad = torch.empty_like(depth_u)
+    ws = torch.empty(max(L.sdfr_depth_l1_workspace_bytes(B, W, H), 256), dtype=torch.uint8, device="cuda")
+    _lib.check(L.sdfr_depth_l1_loss(depth_u.data_ptr(), t.data_ptr(), B, W, H, w, loss_u.data_ptr(), grad.data_ptr(),
+                                    ws.data_ptr(), ws.numel(), 0, torch.cuda.current_stream().cuda_stream), "l1")
+    g_u = [x.clone() for x in plan_u.backward(grad, *a)]
+    assert (grad != 0).sum() > 50 * B
+    runs = {}
+    for deferred in (False, True):
+        plan = BatchRenderPlan(64, B, camera, close_views=False)
+        for rep in range(2):      # twice on the same plan: the ring of volumes, stale statistics
+            plan.loss.fill_(-1.0); plan.loss_stats.fill_(-1.0)
+            depth, _ = plan.forward_l1(*a, 0.005, t, prepare_backward=True, defer_loss=deferred)
+            if deferred:          # nothing was reduced yet
+                assert torch.all(plan.loss == -1.0)
+            g = plan.backward_l1(t, *a, weight=w)
+            runs[(deferred, rep)] = (depth.clone(), plan.loss.clone(), plan.loss_stats.clone(), [x.clone() for x in g])
+        with pytest.raises(RuntimeError, match="same tensors") if deferred else _nullcontext():
+            plan.forward_l1(*a, 0.005, t, prepare_backward=True, defer_loss=deferred)
+            plan.backward_l1(t, a[0], a[1].clone(), a[2], a[3], weight=w)      # another tensor: not the step's backward
+    ref = runs[(False, 0)]
+    assert torch.equal(ref[0], depth_u)
+    mask = (t > 0) & (depth_u > 0)
+    assert torch.equal(ref[2][:, 1], mask.sum(dim=(1, 2)).float())
+    np.testing.assert_allclose(ref[1].cpu().numpy(), loss_u.cpu().numpy(), rtol=2e-6)
+    for k in (1, 2, 3):
+        assert torch.equal(ref[3][k], g_u[k]), k
+    assert rel_err(ref[3][0].cpu().numpy(), g_u[0].cpu().numpy()) <= 1e-5
+    for key, r in runs.items():
+        assert torch.equal(r[0], ref[0]) and torch.equal(r[1], ref[1]) and torch.equal(r[2], ref[2]), key
+        for k in (1, 2, 3):
+            assert torch.equal(r[3][k], ref[3][k]), (key, k)
+        assert rel_err(r[3][0].cpu().numpy(), ref[3][0].cpu().numpy()) <= 1e-5, key
+
+
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
 def test_per_view_weights_and_reproducibility(R):
     sdf, pos, quat, isc, cam, tgt = scene(5, 320, 240, 160.0, seed=3)
     lg = np.array([1.0, -2.0, 0.0, 0.5, 3.0], np.float32)

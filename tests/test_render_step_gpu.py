@@ -287,7 +287,7 @@ def test_plain_calls_sharing_one_workspace_with_a_changing_grid():
 
 def test_prologue_fallback_path_gives_the_same_depth_and_is_counted():
     """The set-up blocks of the one-launch prologue wait a bounded number of rounds for the plane minima and then
-    set their views up without them (whole cube as the may-hit box).  Forced here through the test hook: depth is
+    set their views up without them (whole cube as the may-hit box).  Forced here through the workspace's poll bound: depth is
     bit-identical at C3, and the workspace's counter reports one fall-back per view."""
     from sdfest_amd import BatchRenderPlan, Camera, _lib
     B, W, H, f = 256, 640, 480, 320.0
@@ -298,13 +298,16 @@ def test_prologue_fallback_path_gives_the_same_depth_and_is_counted():
     plan = BatchRenderPlan(64, B, cam)
     d0 = plan.forward(sdf, *pose, 0.005).clone()
     assert plan.prologue_fallbacks() == 0
-    L = _lib.lib()
-    old = L.sdfr_debug_set_prologue_polls(0)
+    # the workspace's own bound of the wait: sync header words 6 / 7 = {SDFR_SYNC_POLLS_MAGIC, rounds} (include/sdfr.h)
+    o = _lib.lib().sdfr_render_sync_offset(B)
+    words = plan.workspace[o + 24:o + 32].view(torch.int32)
+    assert words.tolist() == [0, 0]
+    words.copy_(torch.tensor([0x504F4C4C, 0], dtype=torch.int32))
     try:
         d1 = plan.forward(sdf, *pose, 0.005).clone()
         torch.cuda.synchronize()
     finally:
-        L.sdfr_debug_set_prologue_polls(old)
+        words.zero_()
     assert plan.prologue_fallbacks() == B
     assert torch.equal(d0, d1)
     d2 = plan.forward(sdf, *pose, 0.005, prepare_backward=True)      # back on the normal path, step layout

@@ -149,11 +149,31 @@ def main():
     def render_only():
         plan.forward(sdf64, pos, quat, isc, 0.005)
         plan.backward(grad, sdf64, pos, quat, isc)
+
+    # the same three as STEPS (forward prepares the backward: no prologue launch, the forward's rectangles)
+    def separate_step():
+        est = plan.forward(sdf64, pos, quat, isc, 0.005, prepare_backward=True)
+        _lib.check(L.sdfr_depth_l1_loss(est.data_ptr(), target.data_ptr(), B, 640, 480, 1.0, loss.data_ptr(),
+                                        grad.data_ptr(), ws.data_ptr(), ws.numel(), 0, st), "l1")
+        plan.backward(grad, sdf64, pos, quat, isc)
+
+    def folded_step(defer):
+        plan.forward_l1(sdf64, pos, quat, isc, 0.005, target, prepare_backward=True, defer_loss=defer)
+        plan.backward_l1(target, sdf64, pos, quat, isc)
+
+    def render_only_step():
+        plan.forward(sdf64, pos, quat, isc, 0.005, prepare_backward=True)
+        plan.backward(grad, sdf64, pos, quat, isc)
     t_sep, t_fold, t_r = timeit(separate, 20), timeit(folded, 20), timeit(render_only, 20)
+    ts_sep, ts_r = timeit(separate_step, 20), timeit(render_only_step, 20)
+    ts_fold, ts_fold_d = timeit(lambda: folded_step(False), 20), timeit(lambda: folded_step(True), 20)
     out[f"render-and-compare step (depth term), B={B} 640x480"] = {
         "separate_loss_kernel_us": round(t_sep, 1), "loss_folded_into_renderer_us": round(t_fold, 1),
         "render_fwd+bwd_only_us": round(t_r, 1), "views_per_s_folded": round(B / t_fold * 1e6, 1),
-        "views_per_s_separate": round(B / t_sep * 1e6, 1)}
+        "views_per_s_separate": round(B / t_sep * 1e6, 1),
+        "as_steps": {"separate_loss_kernel_us": round(ts_sep, 1), "loss_folded_us": round(ts_fold, 1),
+                     "loss_folded_deferred_reduce_us": round(ts_fold_d, 1), "render_fwd+bwd_only_us": round(ts_r, 1),
+                     "views_per_s_folded_deferred": round(B / ts_fold_d * 1e6, 1)}}
     print(json.dumps(out, indent=1))
 
 

@@ -241,6 +241,17 @@ def make_decoder(ref):
     out["sub16"] = np.array(subs)
     out["stats"] = np.array(stats)
     out["grad_z"] = np.array(gz)
+    # the same VJPs by the same module in float64 (vae.double()): what the fp32 figures are rounded versions of --
+    # the comparand for the 1e-4 bound of the decoder's latent gradient (the fp32 ones differ from it by ~2e-5 themselves)
+    import copy
+    vae64 = copy.deepcopy(vae).double()
+    gz64 = []
+    for i in range(len(zs)):
+        zt = torch.tensor(zs[i:i + 1], dtype=torch.float64, requires_grad=True)
+        o = vae64.decode(zt)[0, 0]
+        (o * torch.tensor(G, dtype=torch.float64)).sum().backward()
+        gz64.append(zt.grad.numpy()[0].copy())
+    out["grad_z_f64"] = np.array(gz64)
     out["G_sub16"] = G[::4, ::4, ::4]  # sanity check of the formula only
     np.savez_compressed(os.path.join(OUT, "decoder_mug.npz"), **out)
     print(f"  decoder z=0 range [{full0.min():.4f}, {full0.max():.4f}]")
@@ -348,8 +359,35 @@ def make_loop_g7(ref):
         rel = torch.abs(depth_in - depth_est) / depth_in
         return (torch.count_nonzero(rel < thr) / torch.count_nonzero(depth_in)).item()
 
+    def first_gradient_f64(depth_images, cam_p, cam_q, position, orientation, scale, latent):
+        """Iteration 1 of the same assembled loop with every piece in float64 (vae.double(), float64 parameters and
+        cameras; the observation -- the float32 depth images and their float32 back-projection -- is the input and
+        stays what it is): d loss / d (position, orientation, scale, latent).  The float32 pass's own gradients
+        (``*_grads``) differ from these by its rounding; this is the comparand for a 1e-4 bound."""
+        import copy
+        f64 = torch.float64
+        vae64 = copy.deepcopy(vae).double()
+        p, o, s, z = (t.detach().to(f64).clone().requires_grad_() for t in (position, orientation, scale, latent))
+        norm_o = o / torch.sqrt(torch.sum(o ** 2))
+        sdf = vae64.decode(z)
+        loss_depth = torch.tensor(0.0, dtype=f64, requires_grad=True)
+        loss_pc = torch.tensor(0.0, dtype=f64, requires_grad=True)
+        hits = []
+        for depth_image, cp, cq in zip(depth_images, cam_p.to(f64), cam_q.to(f64)):
+            q_w2c = qu.quaternion_invert(cq)
+            position_c = qu.quaternion_apply(q_w2c, p - cp)
+            orientation_c = qu.quaternion_multiply(q_w2c, norm_o)
+            est = TwinRender.apply(sdf[0, 0], position_c[0], orientation_c[0], 1 / s[0])
+            overlap = (depth_image > 0) & (est > 0)
+            hits.append((est > 0).numpy())
+            loss_depth = loss_depth + torch.mean(torch.abs(est - depth_image.to(f64))[overlap])
+            pts = depth_to_pointcloud(depth_image).to(f64)
+            loss_pc = loss_pc + torch.mean(torch.abs(losses.pc_loss(pts, position_c[0], orientation_c[0], s[0], sdf[0, 0])))
+        (1.0 * loss_depth + 3.0 * loss_pc).backward()
+        return np.concatenate([t.grad.numpy().ravel() for t in (p, o, s, z)]), hits
+
     def run(tag, z_true, p_true, q_true, s_true, cams, n_iter, shape_opt, point_constraint, out, size=(96, 72),
-            min_margin=None):
+            min_margin=None, f64_first_gradient=False):
         """min_margin: give up (return False) as soon as a pixel of any view of any iteration lies closer than this
         to one of its decisions -- the search for a scene whose comparison needs no allowance for flipped pixels."""
         res["W"], res["H"] = size
@@ -381,6 +419,8 @@ def make_loop_g7(ref):
         opt = torch.optim.Adam([{"params": position, "lr": 1e-3}, {"params": orientation, "lr": 1e-2},
                                 {"params": scale, "lr": 1e-3}, {"params": latent, "lr": 1e-2}])
         traj, terms, ratios, grads, margins = [], [], [], [], []
+        initial = tuple(t.detach().clone() for t in (position, orientation, scale, latent))
+        first_hits = []
         for it in range(n_iter):
             opt.zero_grad()
             norm_orientation = orientation / torch.sqrt(torch.sum(orientation ** 2))
@@ -398,6 +438,8 @@ def make_loop_g7(ref):
                     print(f"  {tag} it{it}: a pixel at margin {margins[-1].min():.2e} < {min_margin:.0e}: scene dropped")
                     return False
                 depth_estimate = TwinRender.apply(sdf[0, 0], position_c[0], orientation_c[0], 1 / scale[0]).float()
+                if it == 0:
+                    first_hits.append((depth_estimate > 0).numpy())
                 overlap = (depth_image > 0) & (depth_estimate > 0)
                 loss_depth = loss_depth + torch.mean(torch.abs(depth_estimate - depth_image)[overlap])
                 pts = depth_to_pointcloud(depth_image)
@@ -432,6 +474,14 @@ def make_loop_g7(ref):
         out[f"{tag}_fragile_1e-6"] = (mg < 1e-6).sum(axis=2)
         out[f"{tag}_fragile_1e-5"] = (mg < 1e-5).sum(axis=2)
         out[f"{tag}_size"] = np.array(size)
+        if f64_first_gradient:
+            g64, hits64 = first_gradient_f64(depth_images, cam_p, cam_q, *initial)
+            # (a clean scene: the float64 pass renders the very pixels the float32 pass rendered)
+            assert all(np.array_equal(a, b) for a, b in zip(first_hits, hits64)), "hit masks differ between the passes"
+            out[f"{tag}_grads_f64"] = g64
+            rel = np.abs(g64 - grads[0]) / np.array([np.abs(g64[0:3]).max()] * 3 + [np.abs(g64[3:7]).max()] * 4
+                                                     + [abs(g64[7])] + [np.abs(g64[8:]).max()] * (len(g64) - 8))
+            print(f"  {tag}: float32 pass vs float64 pass, first gradient, per group scale: max {rel.max():.2e}")
         return True
 
     rng = np.random.default_rng(17)
@@ -465,7 +515,7 @@ def make_loop_g7(ref):
         trial = {}
         print(f" run C: seed {seed}")
         if run("c", zc, pc, qc, float(rc.uniform(0.10, 0.13)), cams_c, 4, True, None, trial, size=(160, 120),
-               min_margin=2e-7):
+               min_margin=2e-7, f64_first_gradient=True):
             out.update(trial)
             out["c_seed"] = seed
             W, H, fx, fy, cx, cy = intrinsics()

@@ -15,7 +15,7 @@ for f in glob.glob("$OUT/pmc/**/*counter_collection.csv", recursive=True):
         n=r["Kernel_Name"]
         if "sdfr" not in n: continue
         import re
-        k=n.split("(")[0].replace("sdfr::(anonymous namespace)::","").replace("void ","")  # (template arguments kept)
+        k=n.replace("sdfr::(anonymous namespace)::","").replace("void ","").split("(")[0]  # (template arguments kept)
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in acc:
     print("$TAG", k, {c: round(sum(v)/len(v)) for c,v in acc[k].items()}, "launches", max(len(v) for v in acc[k].values()))
