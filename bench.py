@@ -53,9 +53,11 @@ def parse():
                          "volumes per M/2 steps, waited for when the ring wraps (independent steps); sync: every "
                          "step's volume is summed before the next forward starts (the dependency of "
                          "render-and-compare).  The other one is measured too and reported beside it.")
-    ap.add_argument("--watchdog-s", type=float, default=30.0,
+    ap.add_argument("--watchdog-s", type=float, default=0.0,
                     help="N > 1: a rank that has not come out of process-group start-up / its first collective after "
-                         "this many seconds reports its stage and exits non-zero (0: no watchdog)")
+                         "this many seconds reports its stage and exits non-zero (default 0 = 120 s + 15 s per rank: "
+                         "communicator creation is eager (device_id) and a cold 8-rank RCCL bring-up falls inside the "
+                         "first window; negative: no watchdog)")
     return ap.parse_args()
 
 
@@ -199,6 +201,115 @@ def load_traffic():
     return t, f"{t.get('source')}, kernel sources {here}"
 
 
+def gpus_without_the_runtime():
+    """GPUs of this node as the kernel driver lists them (/sys/class/kfd topology: nodes with SIMDs), for the launcher
+    parent, which must not touch the HIP runtime before it starts its ranks (spawn_ranks' precondition) --
+    torch.cuda.device_count() stays clear of it only while amdsmi discovery works and calls hipGetDeviceCount (hipInit)
+    otherwise.  0 when the topology cannot be read: the check is then left to the ranks themselves."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    n = 0
+    try:
+        for node in os.listdir(base):
+            try:
+                props = open(os.path.join(base, node, "properties")).read()
+            except OSError:
+                continue
+            for line in props.splitlines():
+                if line.startswith("simd_count ") and int(line.split()[1]) > 0:
+                    n += 1
+    except OSError:
+        return 0
+    return n
+
+
+def sharded_loop_section(N, rank, barrier):
+    """N > 1: the render-and-compare LOOP sharded over the ranks (sdfest_amd.pipeline, process_group="world"): what the
+    one all-reduce INSIDE an iteration costs over xGMI -- the headline's steps are independent and do not show it.
+    8 N and 64 N views of the C5 scene, 50 iterations, both exchanges, beside the same per-rank view count as a single
+    process.  Bounded by the job watchdog; an exception becomes {"error": ...}, never a lost headline."""
+    from sdfest_amd.pipeline import FusedRenderAndCompare
+    from tools._loop_scene import c5_scene
+    rows = []
+    for per_rank in (8, 64):
+        V = per_rank * N
+        s = c5_scene(views=V, max_iterations=50)
+
+        def time_loop(loop):
+            loop(*s["init"])             # warm-up iteration, captures, 50 iterations
+            torch.cuda.synchronize()
+            ts, res = [], None
+            for _ in range(3):
+                barrier()
+                t0 = time.perf_counter()
+                res = loop(*s["init"])
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) / 50 * 1e3)
+            return round(float(np.median(ts)), 4), res
+        row = {"views": V, "views_per_rank": per_rank}
+        for exchange in ("sdf", "latent"):
+            loop = FusedRenderAndCompare(s["decoder"], s["camera"], s["config"], s["targets"], process_group="world",
+                                         exchange=exchange)
+            row[f"ms_per_iteration_{exchange}"], res = time_loop(loop)
+            row[f"final_position_error_mm_{exchange}"] = round((res[0] - s["p_true"]).norm().item() * 1e3, 3)
+            del loop
+        single = FusedRenderAndCompare(s["decoder"], s["camera"], s["config"], s["targets"][:per_rank].contiguous())
+        row["single_rank_ms_same_views_per_rank"], _ = time_loop(single)
+        del single, s
+        torch.cuda.empty_cache()
+        rows.append(row)
+    return rows
+
+
+def collective_in_graph_section(N, rank, barrier, seconds, line):
+    """The sharded loop with its all-reduce captured INSIDE the hipGraphs (FusedRenderAndCompare(graph_collective=True):
+    measured at world size 1, 0.140 -> 0.125 ms per iteration) -- never run over more than one GPU before this line, so
+    it comes LAST and under a guard: if it has not finished after `seconds`, rank 0 prints the line it already has
+    (with the fact) and every rank leaves.  Returns the rows, or {"error": ...}."""
+    import threading
+    from sdfest_amd.pipeline import FusedRenderAndCompare
+    from tools._loop_scene import c5_scene
+
+    def give_up():
+        if rank == 0:
+            line["loop_sharded_collective_in_graph"] = {"error": f"not finished after {seconds:.0f} s: abandoned"}
+            print(json.dumps(line), flush=True)
+        os._exit(0 if rank == 0 else 0)
+    guard = threading.Timer(seconds, give_up)
+    guard.daemon = True
+    guard.start()
+    try:
+        rows = []
+        for per_rank in (8, 64):
+            s = c5_scene(views=per_rank * N, max_iterations=50)
+            row = {"views": per_rank * N, "views_per_rank": per_rank}
+            for exchange in ("sdf", "latent"):
+                loop = FusedRenderAndCompare(s["decoder"], s["camera"], s["config"], s["targets"], process_group="world",
+                                             exchange=exchange, graph_collective=True)
+                loop(*s["init"])
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(3):
+                    barrier()
+                    t0 = time.perf_counter()
+                    res = loop(*s["init"])
+                    torch.cuda.synchronize()
+                    ts.append((time.perf_counter() - t0) / 50 * 1e3)
+                row[f"ms_per_iteration_{exchange}"] = (round(float(np.median(ts)), 4)
+                                                       if loop.graph_whole_one is not None else None)
+                row[f"captured_{exchange}"] = (True if loop.graph_whole_one is not None
+                                               else f"refused: {loop.graph_collective_error}")
+                row[f"final_position_error_mm_{exchange}"] = round((res[0] - s["p_true"]).norm().item() * 1e3, 3)
+                del loop
+            del s
+            torch.cuda.empty_cache()
+            rows.append(row)
+        return rows
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        guard.cancel()
+
+
 def main():
     args = parse()
     N = args.gpus
@@ -208,8 +319,8 @@ def main():
     # rehearsal on a box with fewer GPUs than ranks (never a measurement): SDFR_BENCH_SHARE_GPU=1 puts every rank on
     # GPU 0 and SDFR_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device)
     share_gpu = os.environ.get("SDFR_BENCH_SHARE_GPU") == "1"
-    n_dev = torch.cuda.device_count()          # (counting devices does not initialise the GPU)
     if "RANK" not in os.environ and N > 1:
+        n_dev = gpus_without_the_runtime()
         # plain `python bench.py --gpus N`: this process has not touched the GPU; it starts the N
         # ranks as child processes (what torch.distributed.run would do), relays their output
         # (rank 0 prints the result line) and exits with their status.
@@ -224,6 +335,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False); "
                          "the product has no CPU path")
+    n_dev = torch.cuda.device_count()          # (a rank: it is about to initialise its GPU anyway)
     if share_gpu:
         local_rank = 0
     elif local_rank >= n_dev:
@@ -236,6 +348,10 @@ def main():
     # under torch.distributed.run (RANK set) the collective path is taken even at world size 1,
     # so a 1-GPU torchrun exercises exactly the code the multi-GPU runs execute
     use_dist = N > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if args.watchdog_s == 0.0:
+        args.watchdog_s = 120.0 + 15.0 * N
+    elif args.watchdog_s < 0.0:
+        args.watchdog_s = 0.0
     if use_dist:
         import faulthandler
         import torch.distributed as dist
@@ -460,6 +576,16 @@ def main():
         state["mode"] = main_mode
     time.sleep(0.005)
     tele.stop()
+    def plain_barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+    loop_sharded = None
+    if use_dist and (N > 1 or os.environ.get("SDFR_BENCH_LOOP_SHARDED") == "1"):
+        try:
+            loop_sharded = sharded_loop_section(N, rank, plain_barrier)
+        except Exception as e:      # (every rank takes the same path: the section's collectives are all inside)
+            loop_sharded = {"error": f"{type(e).__name__}: {e}"}
 
     fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
     bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
@@ -558,6 +684,8 @@ def main():
             "prologue_fallbacks_in_timed_region": fallbacks,
             "gpu_telemetry": tele.summary("t0", "t1"),
         }
+        if loop_sharded is not None:
+            line["loop_sharded"] = loop_sharded
         if collective:
             line["collective"] = collective
             v_other = views / elapsed_other
@@ -588,6 +716,12 @@ def main():
             del plan
             torch.cuda.empty_cache()
             line["configs"] = extra_configs(sdf_np, device, HBM_PEAK)
+    line = line if rank == 0 else {}
+    if use_dist and backend == "nccl" and (N > 1 or os.environ.get("SDFR_BENCH_LOOP_SHARDED") == "1"):
+        # (every rank enters; only rank 0's line matters)
+        line["loop_sharded_collective_in_graph"] = collective_in_graph_section(
+            N, rank, plain_barrier, float(os.environ.get("SDFR_BENCH_GRAPH_COLLECTIVE_S", "120")), line)
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()

@@ -294,7 +294,8 @@ class FusedRenderAndCompare:
                  shape_optimization: bool = True, device="cuda", fuse_depth_loss: bool = True,
                  point_constraint: Optional[Sequence] = None, track_inliers: Optional[bool] = None,
                  merge_launches: bool = True, graph_iterations: int = 5, process_group=None,
-                 exchange: str = "sdf", sdf_grad_mode: int = 0, form: str = "auto", views: Optional[int] = None):
+                 exchange: str = "sdf", sdf_grad_mode: int = 0, form: str = "auto", views: Optional[int] = None,
+                 graph_collective: bool = False):
         """depth_images (V,H,W): the first observation (``rebind`` takes the next ones: the reference calls its
         pipeline once per detected object with fresh images, simple_setup.py:213-225, and so re-uses nothing; this
         object keeps every buffer and every captured graph across observations of the same V, W, H).  None with
@@ -320,6 +321,11 @@ class FusedRenderAndCompare:
         sdf_grad_mode: flag bits for the renderer's backward (differentiable_renderer.SDF_GRAD_*, BWD_*).  With
         ``SDF_GRAD_DETERMINISTIC | BWD_SMALL_TILES`` and exchange="sdf" the bucket is summed as integers and the
         trajectory is bitwise the same however the views are spread over ranks (and as a single process).
+        graph_collective (process group over RCCL only): try to capture the all-reduce INSIDE the graphs -- whole
+        iterations (head | all-reduce | tail) x graph_iterations as ONE graph, instead of two graphs per iteration with
+        the collective issued between them.  c10d's NCCL backend is capturable; whether RCCL's kernels replay on this
+        platform is what ``self.graph_collective_error`` says afterwards (None: captured; a string: why not -- the loop
+        then runs the two-graph form).  An experiment, off by default.
         graph_iterations: iterations per replayed hipGraph (a graph launch costs ~5-8 us between iterations; the
         remainder of max_iterations and runs with ``history`` replay the one-iteration graph).
         merge_launches: the per-view reductions of both backward passes run inside the gradient chain's launch
@@ -333,6 +339,9 @@ class FusedRenderAndCompare:
         # False: every loss is a kernel of its own between a forward and a backward.  Same results.
         self.fuse_depth_loss = bool(fuse_depth_loss)
         self.graph_iterations = max(1, int(graph_iterations))
+        self.graph_collective = bool(graph_collective)
+        self.graph_collective_error = None
+        self.graph_whole = self.graph_whole_one = None
         self.L = _lib.lib()
         self.check = _lib.check
         self.dec = decoder
@@ -811,8 +820,24 @@ class FusedRenderAndCompare:
                 self._head()
             for t, c in zip(state, saved):
                 t.copy_(c)
+            if self.graph_collective:
+                self._capture_with_collective(mode)
+                for t, c in zip(state, saved):
+                    t.copy_(c)
             self._poses_to_views(self._stream())
             self._keep_graphs()
+        if use_graph and self.graph_whole_one is not None:
+            # the collective is a node of the graphs: whole iterations replay, nothing is issued in between
+            done = 0
+            if history is None and self.graph_whole is not None:
+                for _ in range(n_iter // self.graph_iterations):
+                    self.graph_whole.replay()
+                done = n_iter - n_iter % self.graph_iterations
+            for _ in range(n_iter - done):
+                self.graph_whole_one.replay()
+                if history is not None:
+                    self._record_history(history)
+            return
         fused = use_graph and history is None
         for it in range(n_iter):
             if not use_graph:
@@ -828,6 +853,31 @@ class FusedRenderAndCompare:
                 self.graph_tail.replay()
             if history is not None:
                 self._record_history(history)
+
+    def _capture_with_collective(self, mode):
+        """the experiment of ``graph_collective``: head | all-reduce | tail as ONE captured sequence"""
+        import torch.distributed as dist
+        try:
+            if dist.get_backend(self.group) != "nccl":
+                raise RuntimeError(f"backend {dist.get_backend(self.group)!r}: only RCCL's collectives are stream work")
+            one = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(one, **mode):
+                self._head()
+                self._exchange()
+                self._tail()
+            many = None
+            if self.graph_iterations > 1:
+                many = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(many, **mode):
+                    for _ in range(self.graph_iterations):
+                        self._head()
+                        self._exchange()
+                        self._tail()
+            self.graph_whole_one, self.graph_whole = one, many
+        except Exception as e:      # capture refused: the two-graph form stays
+            torch.cuda.synchronize(self.dev)
+            self.graph_whole_one = self.graph_whole = None
+            self.graph_collective_error = f"{type(e).__name__}: {e}"
 
     def _record_history(self, history):
         ld, lp = self.view_losses()

@@ -37,8 +37,13 @@ def main():
         loop = FusedRenderAndCompare(sc["decoder"], sc["camera"], sc["config"], sc["depth"], camera_positions=sc["cam_pos"],
                                      camera_orientations=sc["cam_quat"], shape_optimization=(form == "fused"),
                                      process_group="world", exchange=exchange, sdf_grad_mode=mode, track_inliers=True,
-                                     point_constraint=con)
+                                     point_constraint=con, graph_collective=(graph == "graph_one"))
         out = loop(*sc["init"], use_graph=graph.startswith("graph"), history=hist)
+        if graph == "graph_one":     # what became of the experiment: for the test to report
+            print(f"[graph_one] captured={loop.graph_whole_one is not None} error={loop.graph_collective_error}",
+                  file=sys.stderr, flush=True)
+            with open(out_path + ".graph_one.txt", "w") as f:
+                f.write(f"{loop.graph_whole_one is not None}\n{loop.graph_collective_error}\n")
         inl = loop.inlier_history.cpu().numpy()
         shard = (loop.view_begin, loop.view_end)
     else:

@@ -166,3 +166,10 @@ def test_bench_py_with_two_ranks_in_rehearsal_mode(tmp_path, exchange):
     assert sorted(r["rank"] for r in col["per_rank"]) == [0, 1]
     assert all(r["hit_pixels"] > 1000 and r["prologue_fallbacks"] == 0 for r in col["per_rank"])
     assert col["per_rank"][0]["hit_pixels"] != col["per_rank"][1]["hit_pixels"]      # different pose shards
+    # N > 1 also measures the render-and-compare LOOP sharded over the ranks (its one all-reduce inside an iteration)
+    rows = line["loop_sharded"]
+    assert [r["views"] for r in rows] == [16, 128] and [r["views_per_rank"] for r in rows] == [8, 64]
+    for r in rows:
+        assert r["ms_per_iteration_sdf"] > 0 and r["ms_per_iteration_latent"] > 0
+        assert r["single_rank_ms_same_views_per_rank"] > 0
+        assert r["final_position_error_mm_sdf"] < 5.0 and r["final_position_error_mm_latent"] < 5.0

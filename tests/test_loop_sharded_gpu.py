@@ -229,6 +229,20 @@ def test_sharded_loop_over_rccl_with_one_rank(tmp_path, graph):
     assert _steps(traj, r["traj"]).max() < 5e-3
 
 
+def test_collective_inside_the_graph_over_rccl_with_one_rank(tmp_path):
+    """graph_collective=True: head | all-reduce | tail captured as ONE graph (c10d's NCCL backend is capturable).
+    Whether or not this platform captures RCCL's launch, the trajectory must be the two-graph form's bit for bit:
+    captured -> the whole-iteration graphs replay; refused -> ``graph_collective_error`` says why and the loop runs
+    the two-graph form."""
+    from sdfest_amd.differentiable_renderer import BWD_SMALL_TILES, SDF_GRAD_DETERMINISTIC
+    r = _spawn(tmp_path, "g7a", "det", "sdf", "graph_one", world=1, backend="nccl")
+    note = open(str(tmp_path / "loop_g7a_det_sdf_graph_one_fused.npz") + ".graph_one.txt").read().split("\n")
+    print("collective captured inside the graph:", note[0], "| error:", note[1])
+    traj, _, inl = _single("g7a", SDF_GRAD_DETERMINISTIC | BWD_SMALL_TILES, True)
+    assert np.array_equal(traj, r["traj"]) and np.array_equal(inl, r["inlier"])
+    assert note[0] == "True" or note[1] != "None"
+
+
 def test_single_process_forms_agree_and_auto_picks_by_view_count():
     """form="tail" (one workgroup reduces every view) and form="records" (one wave per view; what a process group
     uses) are the same loop: trajectories agree to rounding, eager and captured; "auto" takes the records form from 8

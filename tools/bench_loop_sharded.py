@@ -53,6 +53,17 @@ def main():
         ms, res = time_loop(loop)
         out[f"ms_per_iteration_sharded_exchange_{exchange}"] = ms
         out[f"final_position_error_mm_{exchange}"] = round((res[0] - s["p_true"]).norm().item() * 1e3, 3)
+        if os.environ.get("SDFR_BENCH_GRAPH_COLLECTIVE", "1") == "1" and dist.get_backend() == "nccl":
+            # the experiment: the all-reduce captured INSIDE the graphs (whole iterations as one graph)
+            loop = FusedRenderAndCompare(s["decoder"], s["camera"], s["config"], s["targets"], process_group="world",
+                                         exchange=exchange, graph_collective=True)
+            ms, res = time_loop(loop)
+            out[f"ms_per_iteration_sharded_exchange_{exchange}_collective_in_graph"] = (
+                ms if loop.graph_whole_one is not None else None)
+            out[f"collective_in_graph_{exchange}"] = ("captured" if loop.graph_whole_one is not None
+                                                      else f"refused: {loop.graph_collective_error}")
+            out[f"final_position_error_mm_{exchange}_collective_in_graph"] = round(
+                (res[0] - s["p_true"]).norm().item() * 1e3, 3)
     # the single-process loop of the same views, in both of its forms (every rank runs them: time_loop has barriers)
     for form in ("tail", "records"):
         if form == "tail" and views > 64:
