@@ -105,6 +105,8 @@ inline TileGeom backward_geom(int B, int W, int H) {
 // deferred gradient chain in loop.hip reads those records)
 constexpr int kSamplerPts = 256;
 constexpr int kDeferredMaxViews = 64;  // sdfr_views_to_pose_grad_deferred: views per call
+constexpr int kSamplerGridTarget = SDFR_PC_GRID_TARGET;
+constexpr int kSamplerMinGroups = SDFR_PC_MIN_GROUPS;
 
 // The batch backward picks its tile shape PER VIEW.  What a tile costs is its flush -- one global float atomic per
 // voxel its hit pixels touched -- and what it saves is the pre-summation of the pixels that share those voxels, so

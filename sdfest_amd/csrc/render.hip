@@ -1286,7 +1286,8 @@ __global__ __launch_bounds__(kBlock) void render_backward_pc_kernel(
   const int b = blockIdx.z;
   if ((int)blockIdx.y < pc_rows) {
     const int bx = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
-    if (bx < pa.nblk) pc_backward_block<RT, true, DET>(*reinterpret_cast<PcBackwardLds*>(raw), pa, bx, b);
+    if (bx < (pa.groups > 0 ? pa.groups : pa.nblk))
+      pc_backward_block<RT, true, DET>(*reinterpret_cast<PcBackwardLds*>(raw), pa, bx, b);
     return;
   }
   backward_dispatch<RT, BATCH, true, DET>(raw, blockIdx.x, (int)blockIdx.y - pc_rows, ntx, nty, stride, b, target, depth,
@@ -1723,7 +1724,8 @@ int backward_impl(const char* fn, const float* grad_depth, const float* depth, c
   const int stride = batch ? backward_tile_stride(W, H) : 0;
   const bool half = half_hint && batch && !det && !pc;   // (a hint: ignored where it does not apply)
   const int rows = batch ? (half ? backward_half_rows(H) : backward_batch_rows(H)) : nty;
-  const int pc_rows = pc ? (pc->nblk + ntx - 1) / ntx : 0;
+  const int pc_groups = pc ? (pc->groups > 0 ? pc->groups : pc->nblk) : 0;   // workgroups of the sampler per view
+  const int pc_rows = pc ? (pc_groups + ntx - 1) / ntx : 0;
   const dim3 grid_tile((unsigned)ntx, (unsigned)(rows + pc_rows), (unsigned)B);
   const float rfx = (float)(1.0 / (double)fx), rfy = (float)(1.0 / (double)fy);
   LossTiles lt_arg{};
@@ -1947,8 +1949,12 @@ int backward_l1_pc_impl(const char* fn, bool prepared,
   if ((uintptr_t)pc_workspace % 16) return fail(SDFR_E_INVALID, "sampler workspace must be 16-byte aligned");
   const int nblk = (max_view_points + kSamplerPts - 1) / kSamplerPts;
   float* pc_part = (float*)pc_workspace;
+  // workgroups of the sampler per view (sampler_device.hpp, GROUPS): one per block while the launch is small, but
+  // never a grid that grows with the point buffers' capacity times the views -- ~8192 workgroups keep the chip busy
+  // (2 048 resident at 256 threads), and at least 64 per view: a mug's ~60 blocks still run side by side
+  const int groups = std::min(nblk, std::max(kSamplerMinGroups, (kSamplerGridTarget + B - 1) / B));
   const PcBackwardArgs pa{nullptr, points, offsets, max_view_points, pos, quat, scale, sdf, R, sdf_view_stride,
-                          g_sdf, g_sdf_view_stride, pc_part, nblk, pc_weight, pc_part + (size_t)B * nblk * 8};
+                          g_sdf, g_sdf_view_stride, pc_part, nblk, pc_weight, pc_part + (size_t)B * nblk * 8, groups};
   if (!pos || !quat || !inv_scale) return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
   return backward_impl(fn, target, depth, sdf, R, sdf_view_stride, pos, quat, inv_scale, B, W, H, cx, cy, fx, fy,
                        sdf_grad_mode, g_sdf, g_sdf_view_stride, nullptr, nullptr, nullptr, loss_grad, loss_stats,

@@ -47,6 +47,14 @@
 #ifndef SDFR_DENSE_CAP
 #define SDFR_DENSE_CAP 4608
 #endif
+// sampler side of sdfr_render_*backward_l1_pc: workgroups the launch aims at over all views, and the least a view gets
+// (sampler_device.hpp, GROUPS)
+#ifndef SDFR_PC_GRID_TARGET
+#define SDFR_PC_GRID_TARGET 8192
+#endif
+#ifndef SDFR_PC_MIN_GROUPS
+#define SDFR_PC_MIN_GROUPS 64
+#endif
 // waves per SIMD the backward kernel's register allocation is held to (0: the compiler's choice)
 #ifndef SDFR_BWD_WAVES_PER_EU
 #define SDFR_BWD_WAVES_PER_EU 8

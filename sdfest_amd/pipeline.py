@@ -295,7 +295,7 @@ class FusedRenderAndCompare:
                  point_constraint: Optional[Sequence] = None, track_inliers: Optional[bool] = None,
                  merge_launches: bool = True, graph_iterations: int = 5, process_group=None,
                  exchange: str = "sdf", sdf_grad_mode: int = 0, form: str = "auto", views: Optional[int] = None,
-                 graph_collective: bool = False):
+                 graph_collective: bool = False, defer_loss: Optional[bool] = None):
         """depth_images (V,H,W): the first observation (``rebind`` takes the next ones: the reference calls its
         pipeline once per detected object with fresh images, simple_setup.py:213-225, and so re-uses nothing; this
         object keeps every buffer and every captured graph across observations of the same V, W, H).  None with
@@ -321,6 +321,11 @@ class FusedRenderAndCompare:
         sdf_grad_mode: flag bits for the renderer's backward (differentiable_renderer.SDF_GRAD_*, BWD_*).  With
         ``SDF_GRAD_DETERMINISTIC | BWD_SMALL_TILES`` and exchange="sdf" the bucket is summed as integers and the
         trajectory is bitwise the same however the views are spread over ranks (and as a single process).
+        defer_loss: the step's forward leaves the reduction of its depth-loss tile records to the backward's launch
+        (include/sdfr.h, "DEFERRED LOSS": one dependent launch less per iteration, a count loop in every backward tile
+        that holds a hit pixel); default: for fewer than 32 views (ms per iteration on the C5 scene, own launch / deferred:
+        1 view 0.1223 / 0.1196, 8: 0.1531 / 0.1501, 16: 0.1784 / 0.1747, 64: 0.2115 / 0.2226 -- many views, many tiles
+        that each repeat the count; profiles/r05_pc_rounds.md).  Same numbers either way.
         graph_collective (process group over RCCL only): try to capture the all-reduce INSIDE the graphs -- whole
         iterations (head | all-reduce | tail) x graph_iterations as ONE graph, instead of two graphs per iteration with
         the collective issued between them.  c10d's NCCL backend is capturable; whether RCCL's kernels replay on this
@@ -340,6 +345,7 @@ class FusedRenderAndCompare:
         self.fuse_depth_loss = bool(fuse_depth_loss)
         self.graph_iterations = max(1, int(graph_iterations))
         self.graph_collective = bool(graph_collective)
+        self._defer_loss_arg = defer_loss
         self.graph_collective_error = None
         self.graph_whole = self.graph_whole_one = None
         self.L = _lib.lib()
@@ -391,6 +397,7 @@ class FusedRenderAndCompare:
         if depth_images is not None and tuple(depth_images.shape[1:]) != (H, W):
             raise ValueError(f"depth_images must be (V, {H}, {W}) for this camera, got {tuple(depth_images.shape)}")
         self.V, self.H, self.W = V, H, W
+        self.defer_loss = (V < 32) if self._defer_loss_arg is None else bool(self._defer_loss_arg)
         self.defer_pose = bool(merge_launches) and V <= 64
         # the iteration's tail -- gradient chain, point constraint, Adam and the next iteration's view poses -- in
         # one launch (sdfr_loop_tail), the render pair in its step form: 26 -> 22 launches per iteration
@@ -584,7 +591,7 @@ class FusedRenderAndCompare:
             # iteration were left by the previous tail (or by _poses_to_views before the first one)
             # (the depth loss values are reduced inside the backward's launch: no launch between the image kernels)
             self.plan.forward_l1(sdf, self.pos_c, self.quat_c, self.inv_scale, self.cfg["threshold"], self.target,
-                                 prepare_backward=True, defer_loss=True)
+                                 prepare_backward=True, defer_loss=self.defer_loss)
             self.loss_depth = self.plan.loss
             g_sdf = self.plan.backward_l1_pc(self.target, sdf, self.pos_c, self.quat_c, self.inv_scale,
                                              self.scale_v, self.points, self.offsets, self.max_pts, self.ws_pc,
@@ -715,7 +722,7 @@ class FusedRenderAndCompare:
         # torch.mean over nothing, simple_setup.py:144, and they contribute no gradient -- as in the reference)
         have_pts = True
         self.plan.forward_l1(sdf, self.pos_c, self.quat_c, self.inv_scale, self.cfg["threshold"], self.target,
-                             prepare_backward=True, defer_loss=True)
+                             prepare_backward=True, defer_loss=self.defer_loss)
         g_sdf = self.plan.backward_l1_pc(self.target, sdf, self.pos_c, self.quat_c, self.inv_scale, self.scale_v,
                                          self.points, self.offsets, self.max_pts, self.ws_pc,
                                          weight=self.cfg["depth_weight"], pc_weight=self.cfg["pc_weight"])
