@@ -105,6 +105,8 @@ inline TileGeom backward_geom(int B, int W, int H) {
 // deferred gradient chain in loop.hip reads those records)
 constexpr int kSamplerPts = 256;
 constexpr int kDeferredMaxViews = 64;  // sdfr_views_to_pose_grad_deferred: views per call
+// floats of a forward tile's loss record: a (sum, count) pair per wave, four waves (render.hip, forward_tile LOSS)
+constexpr int kLossRec = 8;
 constexpr int kSamplerGridTarget = SDFR_PC_GRID_TARGET;
 constexpr int kSamplerMinGroups = SDFR_PC_MIN_GROUPS;
 

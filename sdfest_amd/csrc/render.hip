@@ -640,7 +640,7 @@ __device__ __forceinline__ void forward_tile(
   if (!overlaps(rc, px0, py0, kTileW, kTileH)) {
     // nothing of the cube projects here: stream zeros.  (LOSS: the view's reduce sums the records of every tile of
     // the rectangle, also of those the band span leaves out)
-    if (LOSS && in_rect && tid < 2) loss_part[(((size_t)b * nty + tile_y) * ntx + tile_x) * 2 + tid] = 0.0f;
+    if (LOSS && in_rect && tid < kLossRec) loss_part[(((size_t)b * nty + tile_y) * ntx + tile_x) * kLossRec + tid] = 0.0f;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     if (vec_ok) {
@@ -714,16 +714,15 @@ __device__ __forceinline__ void forward_tile(
     if (inside) img[row * W + col] = result;
   }
   if (LOSS) {
-    // fixed-order tile sum: lanes (butterfly) -> waves -> one record per tile
-    __shared__ float wave_loss[4][2];
+    // The tile's record: one (sum, count) pair per WAVE (4 slots; a tile walked by fewer waves zero-fills the rest),
+    // each a fixed-order butterfly over the wave's lanes.  No LDS and no barrier: a wave that is done leaves, and
+    // whoever reads the record adds the four pairs as (w0 + w1) + (w2 + w3) -- the order in which the tile itself
+    // used to add them behind a barrier, so the sums are the same bit for bit.
     l_sum = wave_sum(l_sum);
     l_cnt = wave_sum(l_cnt);
-    if (lane == 0) { wave_loss[wave][0] = l_sum; wave_loss[wave][1] = l_cnt; }
-    if (tid < 8 && (tid >> 1) >= NW) wave_loss[tid >> 1][tid & 1] = 0.0f;
-    __syncthreads();
-    if (tid < 2)
-      loss_part[(((size_t)b * nty + tile_y) * ntx + tile_x) * 2 + tid] =
-          (wave_loss[0][tid] + wave_loss[1][tid]) + (wave_loss[2][tid] + wave_loss[3][tid]);
+    float* rec = loss_part + (((size_t)b * nty + tile_y) * ntx + tile_x) * kLossRec;
+    if (lane == 0) *reinterpret_cast<float2*>(rec + 2 * wave) = make_float2(l_sum, l_cnt);
+    if (NW < 4 && wave == 0 && lane >= 2 * NW && lane < kLossRec) rec[lane] = 0.0f;
   }
 }
 
@@ -848,6 +847,14 @@ __device__ __forceinline__ HitPoint hit_point(const ViewSetup& s, int row, int c
   return p;
 }
 
+// (sum, count) of one forward tile from its record of four per-wave pairs (forward_tile, LOSS): the one association
+// every reader uses
+__device__ __forceinline__ float2 loss_tile_record(const float* __restrict__ part, size_t tile) {
+  const float4* r = reinterpret_cast<const float4*>(part + tile * kLossRec);
+  const float4 a = r[0], c = r[1];   // (s0, n0, s1, n1), (s2, n2, s3, n3)
+  return make_float2((a.x + a.z) + (c.x + c.z), (a.y + a.w) + (c.y + c.w));
+}
+
 // A loss-fused STEP whose forward left the reduction of its (sum, count) tile records to the backward (deferred:
 // sdfr_render_step_forward_l1 with loss = loss_stats = NULL): no launch between the two image kernels.  A backward
 // tile that has a hit pixel sums the view's counts itself -- integers held in floats below 2^24: the sum is exact in
@@ -855,7 +862,7 @@ __device__ __forceinline__ HitPoint hit_point(const ViewSetup& s, int row, int c
 // of every view (a corner of the image: nearly always a culled tile) runs the fixed-order reduction of
 // loss_reduce_kernel on the side: loss[b], stats[b] for whoever reads them after this launch.
 struct LossTiles {
-  const float* part;   // the forward's records, [view][nty][ntx][2]; nullptr: the forward reduced them itself
+  const float* part;   // the forward's records, [view][nty][ntx][kLossRec]; nullptr: the forward reduced them itself
   int ntx, nty, wl, hl;   // the FORWARD's tiling (not the backward's): tiles of 2^wl x 2^hl pixels
   float* loss;         // [B]
   float* stats;        // [B][2]
@@ -868,10 +875,10 @@ __device__ __forceinline__ float view_overlap_count(const LossTiles& lt, const V
     // (scalar divisions: the rectangle and the tiling are workgroup-uniform; the threads walk the records as an
     // 8 x 32 block -- no per-thread division in a path every tile with a hit pixel takes)
     const int tx0 = x0 >> lt.wl, tx1 = (x1 - 1) >> lt.wl, ty0 = y0 >> lt.hl, ty1 = (y1 - 1) >> lt.hl;   // (x0, y0 >= 0)
-    const float2* base = reinterpret_cast<const float2*>(lt.part) + (size_t)b * lt.ntx * lt.nty;
+    const size_t base = (size_t)b * lt.ntx * lt.nty;
     const int c = (int)threadIdx.x & 31, r = (int)threadIdx.x >> 5;
     for (int ty = ty0 + r; ty <= ty1; ty += kBlock / 32)
-      for (int tx = tx0 + c; tx <= tx1; tx += 32) cnt += base[ty * lt.ntx + tx].y;
+      for (int tx = tx0 + c; tx <= tx1; tx += 32) cnt += loss_tile_record(lt.part, base + (size_t)ty * lt.ntx + tx).y;
   }
   cnt = wave_sum(cnt);
   if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = cnt;
@@ -885,9 +892,9 @@ __device__ __forceinline__ void reduce_view_loss(const LossTiles& lt, const View
   if (x1 > x0 && y1 > y0) {
     const int tx0 = x0 >> lt.wl, tx1 = (x1 - 1) >> lt.wl, ty0 = y0 >> lt.hl, ty1 = (y1 - 1) >> lt.hl;
     const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1);
-    const float2* base = reinterpret_cast<const float2*>(lt.part) + (size_t)b * lt.ntx * lt.nty;
+    const size_t base = (size_t)b * lt.ntx * lt.nty;
     for (int i = lane; i < n; i += 64) {
-      const float2 p = base[(size_t)(ty0 + i / nx) * lt.ntx + tx0 + i % nx];
+      const float2 p = loss_tile_record(lt.part, base + (size_t)(ty0 + i / nx) * lt.ntx + tx0 + i % nx);
       sum += p.x;
       cnt += p.y;
     }
@@ -1359,9 +1366,9 @@ __global__ __launch_bounds__(64) void loss_reduce_kernel(const float* __restrict
   if (x1 > x0 && y1 > y0) {
     const int tx0 = x0 / tile_w, tx1 = (x1 - 1) / tile_w, ty0 = y0 / tile_h, ty1 = (y1 - 1) / tile_h;
     const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1);
-    const float2* base = reinterpret_cast<const float2*>(loss_part) + (size_t)b * ntx * nty;
+    const size_t base = (size_t)b * ntx * nty;
     for (int i = lane; i < n; i += 64) {
-      const float2 p = base[(size_t)(ty0 + i / nx) * ntx + tx0 + i % nx];
+      const float2 p = loss_tile_record(loss_part, base + (size_t)(ty0 + i / nx) * ntx + tx0 + i % nx);
       sum += p.x;
       cnt += p.y;
     }
@@ -1452,8 +1459,8 @@ extern "C" int sdfr_fixed_to_float(const long long* fixed, size_t n, float* out,
 
 extern "C" size_t sdfr_render_forward_l1_workspace_bytes(int R, int B, int W, int H) {
   size_t n = (sdfr_render_forward_workspace_bytes(R, B, W, H) + 127) & ~(size_t)127;
-  // one (sum, count) record per tile of the finer geometry
-  if (B > 0 && W > 0 && H > 0) n += (size_t)B * kSmallTile.nx(W) * kSmallTile.ny(H) * 2 * sizeof(float);
+  // one record (four per-wave (sum, count) pairs) per tile of the finer geometry
+  if (B > 0 && W > 0 && H > 0) n += (size_t)B * kSmallTile.nx(W) * kSmallTile.ny(H) * kLossRec * sizeof(float);
   return n;
 }
 
@@ -1464,7 +1471,7 @@ size_t step_loss_offset(int R, int B, int W, int H) {
 extern "C" size_t sdfr_render_step_workspace_bytes(int R, int B, int W, int H) {
   if (R < 2 || B <= 0) return 256;
   size_t n = step_loss_offset(R, B, W, H);
-  if (W > 0 && H > 0) n += (size_t)B * kSmallTile.nx(W) * kSmallTile.ny(H) * 2 * sizeof(float);
+  if (W > 0 && H > 0) n += (size_t)B * kSmallTile.nx(W) * kSmallTile.ny(H) * kLossRec * sizeof(float);
   return n;
 }
 

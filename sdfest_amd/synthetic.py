@@ -81,3 +81,17 @@ def init_network_state(seed, backbone=MUG_INIT_BACKBONE, head=MUG_INIT_HEAD, sha
     n_out = shape_dimension + (8 if head.get("orientation_repr", "quaternion") == "quaternion" else 4 + num_cells)
     linear("_head._final_layer", hs[-1], n_out)
     return state
+
+
+def plausible_init_network_state(seed=7, scale=0.06, position_offset=(0.004, -0.003, 0.005)):
+    """``init_network_state`` with a final layer that answers like a trained network would -- latent ~ 0, position ~
+    the centroid of the observed points (+ a small offset), half-width ~ `scale`, and whatever orientation cell its
+    small logits favour: a usable starting point for the loop when the front door is driven end to end (tests,
+    bench.py's time to result) without the trained weights, which are not in the reference repository."""
+    st = {k: v.copy() for k, v in init_network_state(seed).items()}
+    st["_head._final_layer.weight"] *= 0.01
+    b = st["_head._final_layer.bias"]
+    b *= 0.01
+    b[8:11] += np.asarray(position_offset, dtype=np.float32)
+    b[11] = scale
+    return st

@@ -90,7 +90,7 @@ def test_argument_errors_without_gpu(libpath):
     # a step keeps face records, the backward's tile partials and the deterministic mode's int64 volume side by side
     # (+ the (sum, count) tile records of the loss-fused step)
     assert L.sdfr_render_step_workspace_bytes(64, 2, 640, 480) == (2 * 256 + sync + spans(2) + 64 ** 3 * 16
-                                                                    + 2 * 20 * 60 * 32 + 64 ** 3 * 8 + 2 * 20 * 60 * 8)
+                                                                    + 2 * 20 * 60 * 32 + 64 ** 3 * 8 + 2 * 20 * 60 * 32)
     assert L.sdfr_render_partials_offset(64, 2, 640, 480, 1) == 2 * 256 + sync + spans(2) + 64 ** 3 * 16
     assert L.sdfr_render_partials_offset(64, 2, 640, 480, 0) == 2 * 256 + sync + spans(2)
     assert L.sdfr_render_fixed_volume_offset(64, 2, 640, 480, 1) == (2 * 256 + sync + spans(2) + 64 ** 3 * 16

@@ -30,16 +30,8 @@ def mug_weights():
 
 
 def plausible_init_state(seed=7):
-    """the seeded random SDFPoseNet weights (the trained ones are not in the reference repository) with a final layer
-    that answers like a trained network would: latent ~ 0, position ~ the centroid of the observed points, half-width
-    ~ 0.06 -- and whatever orientation cell its small logits favour"""
-    st = {k: v.copy() for k, v in init_network_state(seed).items()}
-    st["_head._final_layer.weight"] *= 0.01
-    b = st["_head._final_layer.bias"]
-    b *= 0.01
-    b[8:11] += np.array([0.004, -0.003, 0.005], dtype=np.float32)
-    b[11] = 0.06
-    return st
+    from sdfest_amd.synthetic import plausible_init_network_state
+    return plausible_init_network_state(seed)
 
 
 def make_config(W, H, fx, fy, cx, cy, thr, n_iter, **extra):

@@ -387,6 +387,59 @@ def c5_scene(views=1, max_iterations=50):
             "q_true": q_true, "s_true": s_true}
 
 
+def front_door_times(sc, others):
+    """`sdfest_amd.SDFPipeline(config)(depth_images, masks, color_images)` end to end -- the reference's call
+    (simple_setup.py:213-226): mask + far-field clip, initialisation network, 50 iterations, result -- on the C5 images
+    with a background wall the mask removes; seeded initialisation-network weights with a plausible final layer (the
+    trained ones are not in the reference repository)."""
+    try:
+        from sdfest_amd import SDFPipeline
+        from sdfest_amd.synthetic import MUG_INIT_BACKBONE, MUG_INIT_HEAD, plausible_init_network_state
+        gdir = os.path.join(ROOT, "tests", "golden")
+        d = np.load(os.path.join(gdir, "decoder_mug.npz"))
+        w = np.load(os.path.join(gdir, "mug_decoder_weights.npz"))
+        vae = {"latent_size": int(d["latent_size"]), "tsdf": False, "decoder": {
+            "fc_layers": [{"out": int(o)} for o in d["fc_out"]],
+            "conv_layers": [{"in_size": int(a), "in_channels": int(b), "out_channels": int(c), "kernel_size": int(k),
+                             "relu": bool(r)} for a, b, c, k, r in zip(d["conv_in_size"], d["conv_cin"], d["conv_cout"],
+                                                                      d["conv_k"], d["conv_relu"])]}}
+        cfg = dict(sc["config"], device="cuda", nn_weight=0.0, mean_shape=False, init_view="first", far_field=2.0,
+                   camera={"width": 640, "height": 480, "fx": 320.0, "fy": 320.0, "cx": 320.0, "cy": 240.0,
+                           "pixel_center": 0.5}, vae=vae,
+                   init={"backbone_type": "VanillaPointNet", "backbone": dict(MUG_INIT_BACKBONE),
+                         "head_type": "SDFPoseHead", "head": dict(MUG_INIT_HEAD), "normalize_pose": True})
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pipe = SDFPipeline(cfg, vae_state_dict={k: w[k] for k in w.files},
+                           init_state_dict=plausible_init_network_state(7, scale=0.06))
+        t_ctor = (time.perf_counter() - t0) * 1e3
+        images = [sc["targets"][0], others[0][0], others[1][0]]
+        scenes = []
+        for img in images:
+            mask = img > 0
+            wall = torch.where(mask, img, torch.full_like(img, 1.2))     # a background the mask must remove
+            scenes.append((wall, mask))
+        color = torch.zeros((480, 640, 3), device=images[0].device)
+        totals = []
+        out = None
+        for k in range(8):
+            depth, mask = scenes[k % 3]
+            arg = depth.clone()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = pipe(arg, mask, color)
+            torch.cuda.synchronize()
+            totals.append((time.perf_counter() - t0) * 1e3)
+        return {"what": "SDFPipeline.__call__(depth (480,640), mask, color): preprocess + init network + 50 iterations + "
+                        "synchronize, wall clock; first call = loop buffers and graph captures included",
+                "ms_constructor": round(t_ctor, 2), "ms_first_call": round(totals[0], 2),
+                "ms_per_call_after": round(float(np.median(totals[1:])), 3),
+                "ms_per_call_all": [round(t, 3) for t in totals],
+                "final_scale": round(float(out[2]), 5)}
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def c5_config(hbm_peak):
     """C5: the whole render-and-compare loop (simple_setup.py:408-470) as one hipGraph per iteration, 50 Adam
     iterations, mug decoder; ms per iteration, the final pose error, and TIME TO RESULT the way the reference is used
@@ -434,6 +487,7 @@ def c5_config(hbm_peak):
         totals.append((time.perf_counter() - t0) * 1e3)
         rebinds.append((t1 - t0) * 1e3)
     assert fused.graph is graph     # nothing was captured again
+    front_door = front_door_times(sc, others)
     q = out[1] / out[1].norm()
     dot = float(torch.abs((q * sc["q_true"]).sum()).clamp(max=1.0))
     # algorithmic bytes of one iteration: render fwd+bwd of one view + decoder weights + volume
@@ -445,6 +499,7 @@ def c5_config(hbm_peak):
             "ms_new_observation_total": round(float(np.median(totals)), 3),
             "ms_new_observation_all": [round(t, 3) for t in totals],
             "ms_rebind_host": round(float(np.median(rebinds)), 3),
+            "front_door": front_door,
             "time_to_result": "ms_first_call_total = constructor (buffers at capacity) + warm-up iteration + graph "
                               "captures + 50 iterations, first use of these kernels in the process; "
                               "ms_new_observation_total = rebind(new 640x480 image already in HBM) + 50 iterations "
