@@ -59,7 +59,8 @@
  *        sharded over ranks: sdfr_loop_view_records, sdfr_loop_tail_records, sdfr_inlier_counts_record,
  *        sdfr_inlier_update_record
  *   4. GENERATOR / INITIALISATION (the forward-only callers around the loop)
- *        sdfr_affine_mask; sdfr_pointnet_layer, sdfr_linear_vec, sdfr_orientation_posterior
+ *        sdfr_affine_mask; sdfr_pointnet_layer[_counted], sdfr_linear_vec, sdfr_orientation_posterior,
+ *        sdfr_init_estimate
  * (Within the file the groups follow the order in which the reference's code runs; every declaration carries the
  * reference file:line it replaces.)
  */
@@ -648,6 +649,14 @@ SDFR_API int sdfr_pointnet_layer(const float* x, int M, int cin, int ldx, const 
                         const float* resid, float* y, int ldy, int cout, float* colmax, int device,
                         void* stream);
 
+/* The same with the number of points ON THE DEVICE (row_count[0], clamped to M_capacity = the rows x, y and resid have
+ * room for): for a caller that never reads the count of a depth image's points back -- the initialisation network
+ * inside a captured launch sequence (sdfest_amd.init_network.ResidentInit).  The grid strides over the real rows. */
+SDFR_API int sdfr_pointnet_layer_counted(const float* x, const int* row_count, int M_capacity, int cin, int ldx,
+                                const float* w, int ldw, const float* cvec, const float* bn_scale,
+                                const float* bn_shift, const float* resid, float* y, int ldy, int cout,
+                                float* colmax, int device, void* stream);
+
 /* y[cout] = act((W[:, koff:koff+k] . x + bias) * bn_scale + bn_shift): the head's layers on the set feature
  * and the bias vectors of dense links.  bias, bn_scale / bn_shift may be NULL; relu = 0 / 1. */
 SDFR_API int sdfr_linear_vec(const float* w, int ldw, int koff, const float* x, int k, const float* bias,
@@ -659,6 +668,20 @@ SDFR_API int sdfr_linear_vec(const float* w, int ldw, int koff, const float* x, 
  * probability. */
 SDFR_API int sdfr_orientation_posterior(const float* logits, int C, const float* prior, const float* train_prior,
                                float* posterior, int* out_index, float* out_max, int device, void* stream);
+
+/* simple_setup.py:790-838 for one view, on the device: the head's output row -> the estimate in the WORLD frame, written
+ * into params [position 3 | orientation 4 | scale 1 | latent] (the loop's parameter vector: sdfr_loop_tail).
+ *   head          [latent + 4 + C] (discretised orientation: latent, position, scale, C logits) or [latent + 8]
+ *   grid_quats    [C][4] with index = the argmax of sdfr_orientation_posterior (SO3Grid.index_to_quat of every cell,
+ *                 uploaded once), or NULL: the head's quaternion, normalised (sdf_pose_network.py:97-101)
+ *   centroid [3]  nullable: `position += centroid` (:793-794);  cam_pos [3], cam_quat [4]: camera -> world (:819-825)
+ *   mean_shape    zero latent (:790-791)
+ *   take_if_better 0: "first" -- always written; 1: "best" -- written only where posterior_max[0] > best[0], which
+ *                 then takes its value (:829-838; the caller zeroes best[0] in front of the first view). */
+SDFR_API int sdfr_init_estimate(const float* head, int latent, const float* grid_quats, const int* index,
+                       const float* centroid, const float* cam_pos, const float* cam_quat, int mean_shape,
+                       int take_if_better, const float* posterior_max, float* best, float* params, int device,
+                       void* stream);
 
 #ifdef __cplusplus
 }

@@ -121,6 +121,10 @@ SIGNATURES = {
                                   c_fp, c_int, c_fp]),
     "sdfr_pointnet_layer": (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int,
                                     c_fp, c_int, c_fp]),
+    "sdfr_pointnet_layer_counted": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp,
+                                            c_int, c_int, c_fp, c_int, c_fp]),
+    "sdfr_init_estimate": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_int,
+                                   c_fp]),
     "sdfr_linear_vec": (c_int, [c_fp, c_int, c_int, c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_fp, c_int, c_int, c_fp]),
     "sdfr_orientation_posterior": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp]),
     "sdfr_affine_mask": (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_fp, c_int, c_fp]),

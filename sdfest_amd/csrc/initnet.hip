@@ -15,6 +15,8 @@
 //   * the last backbone layer (M x 1024) is never written: only its column maximum leaves the kernel.
 #include "common.hpp"
 
+#include <algorithm>
+
 namespace sdfr {
 namespace {
 
@@ -31,7 +33,8 @@ constexpr int kPtsPerBlock = 64, kColsPerBlock = 64, kChunk = 124;
 __global__ __launch_bounds__(256) void pointnet_layer_kernel(
     const float* __restrict__ x, int M, int cin, int ldx, const float* __restrict__ w, int ldw,
     const float* __restrict__ cvec, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
-    const float* __restrict__ resid, float* __restrict__ y, int ldy, int cout, int* __restrict__ colmax) {
+    const float* __restrict__ resid, float* __restrict__ y, int ldy, int cout, int* __restrict__ colmax,
+    const int* __restrict__ row_count) {
   // K runs in chunks of kChunk columns staged in LDS (X tile and W tile, rows padded by one float: a row
   // stride of a multiple of 32 floats would put the 16 rows a wave-instruction reads into one bank)
   __shared__ float xs[kPtsPerBlock * (kChunk + 1)];
@@ -39,8 +42,13 @@ __global__ __launch_bounds__(256) void pointnet_layer_kernel(
   __shared__ int wave_max[4][kColsPerBlock];
   constexpr int ld = kChunk + 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int p0 = blockIdx.x * kPtsPerBlock, c0 = blockIdx.y * kColsPerBlock;
+  // row_count (sdfr_pointnet_layer_counted): the number of points lives on the device and M is the buffers' capacity;
+  // the grid's row blocks stride over the real rows (workgroup-uniform loop)
+  if (row_count) M = min(max(row_count[0], 0), M);
+  const int c0 = blockIdx.y * kColsPerBlock;
   const int row = lane & 15, kq = lane >> 4;
+  for (int p0 = blockIdx.x * kPtsPerBlock; p0 < M; p0 += gridDim.x * kPtsPerBlock) {
+  if (p0 != (int)blockIdx.x * kPtsPerBlock) __syncthreads();   // (the previous block's LDS reads are done)
   f32x4 acc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -86,6 +94,55 @@ __global__ __launch_bounds__(256) void pointnet_layer_kernel(
   __syncthreads();
   if (tid < kColsPerBlock && c0 + tid < cout)
     atomicMax(&colmax[c0 + tid], max(max(wave_max[0][tid], wave_max[1][tid]), max(wave_max[2][tid], wave_max[3][tid])));
+  }
+}
+
+// simple_setup.py:790-838 for ONE view, on the device: the head's output row -> the estimate in the world frame,
+// written straight into the loop's parameter vector [position 3 | orientation 4 | scale 1 | latent L].
+//   head [L + 4 + C] (discretised: latent, position, scale, C orientation logits) or [L + 8] (quaternion)
+//   grid_quats [C][4] + index (the argmax of sdfr_orientation_posterior): the orientation of the chosen cell
+//   centroid (nullable): added to the position (`position += centroid`, :793-794)
+//   cam_pos [3], cam_quat [4]: camera in the world (:819-825): p_w = q_c (p, 0) q_c* + t_c, q_w = q_c q
+//   take_if_better: 0 = "first" (always written); 1 = "best": written only if post_max[0] > best[0], which it then
+//   becomes (:835-838; best[0] starts at 0)
+__global__ void init_estimate_kernel(const float* __restrict__ head, int L, const float* __restrict__ grid_quats,
+                                     const int* __restrict__ index, const float* __restrict__ centroid,
+                                     const float* __restrict__ cam_pos, const float* __restrict__ cam_quat,
+                                     int mean_shape, int take_if_better, const float* __restrict__ post_max,
+                                     float* __restrict__ best, float* __restrict__ params) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  if (take_if_better) {
+    if (!(post_max[0] > best[0])) return;
+    best[0] = post_max[0];
+  }
+  float p[3] = {head[L], head[L + 1], head[L + 2]};
+  if (centroid) { p[0] += centroid[0]; p[1] += centroid[1]; p[2] += centroid[2]; }
+  float q[4];
+  if (grid_quats) {
+    const int i = index[0];
+    for (int k = 0; k < 4; ++k) q[k] = grid_quats[4 * i + k];
+  } else {   // sdf_pose_network.py:97-101: the head normalises its quaternion
+    const float* o = head + L + 4;
+    const float n = sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+    for (int k = 0; k < 4; ++k) q[k] = o[k] / n;
+  }
+  const float c[4] = {cam_quat[0], cam_quat[1], cam_quat[2], cam_quat[3]};
+  // quaternion_multiply (quaternion_utils.py:12-33), scalar last
+  auto mul = [](const float* a, const float* b, float* o) {
+    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    o[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+    o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+  };
+  const float pq[4] = {p[0], p[1], p[2], 0.0f}, ci[4] = {-c[0], -c[1], -c[2], c[3]};
+  float t[4], r[4], qw[4];
+  mul(c, pq, t);      // quaternion_apply (:36-54): q (p, 0) q^-1
+  mul(t, ci, r);
+  mul(c, q, qw);
+  params[0] = r[0] + cam_pos[0]; params[1] = r[1] + cam_pos[1]; params[2] = r[2] + cam_pos[2];
+  for (int k = 0; k < 4; ++k) params[3 + k] = qw[k];
+  params[7] = head[L + 3];
+  for (int k = 0; k < L; ++k) params[8 + k] = mean_shape ? 0.0f : head[k];
 }
 
 // y[col] = act((W[col][koff .. koff + k) . x + bias[col]) * s[col] + t[col]); one wave per column.
@@ -177,22 +234,55 @@ __global__ __launch_bounds__(256) void orientation_posterior_kernel(const float*
 
 using namespace sdfr;
 
+namespace {
+int pointnet_layer_impl(const char* fn, const float* x, const int* row_count, int M, int cin, int ldx, const float* w,
+                        int ldw, const float* cvec, const float* bn_scale, const float* bn_shift, const float* resid,
+                        float* y, int ldy, int cout, float* colmax, int device, void* stream) {
+  if (M < 1 || cin < 1 || cout < 1 || ldx < cin || ldw < cin || (y && ldy < cout))
+    return fail(SDFR_E_INVALID, "%s: bad sizes M=%d cin=%d cout=%d", fn, M, cin, cout);
+  if (!x || !w || !cvec || !bn_scale || !bn_shift || !colmax) return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
+  if (resid && !y) return fail(SDFR_E_NULL, "%s: a residual needs an output", fn);
+  SDFR_HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  zero_words_async(colmax, (size_t)cout, st);
+  // (a counted call does not know its rows: enough row blocks to fill the chip, striding over the real ones)
+  const int row_blocks = (M + kPtsPerBlock - 1) / kPtsPerBlock;
+  const int col_blocks = (cout + kColsPerBlock - 1) / kColsPerBlock;
+  const int gx = row_count ? std::min(row_blocks, std::max(1, 4096 / col_blocks)) : row_blocks;
+  hipLaunchKernelGGL(pointnet_layer_kernel, dim3((unsigned)gx, (unsigned)col_blocks), dim3(256), 0, st, x, M, cin, ldx, w,
+                     ldw, cvec, bn_scale, bn_shift, resid, y, ldy, cout, reinterpret_cast<int*>(colmax), row_count);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
 extern "C" int sdfr_pointnet_layer(const float* x, int M, int cin, int ldx, const float* w, int ldw,
                                    const float* cvec, const float* bn_scale, const float* bn_shift,
                                    const float* resid, float* y, int ldy, int cout, float* colmax, int device,
                                    void* stream) {
-  if (M < 1 || cin < 1 || cout < 1 || ldx < cin || ldw < cin || (y && ldy < cout))
-    return fail(SDFR_E_INVALID, "sdfr_pointnet_layer: bad sizes M=%d cin=%d cout=%d", M, cin, cout);
-  if (!x || !w || !cvec || !bn_scale || !bn_shift || !colmax)
-    return fail(SDFR_E_NULL, "sdfr_pointnet_layer: NULL pointer argument");
-  if (resid && !y) return fail(SDFR_E_NULL, "sdfr_pointnet_layer: a residual needs an output");
+  return pointnet_layer_impl("sdfr_pointnet_layer", x, nullptr, M, cin, ldx, w, ldw, cvec, bn_scale, bn_shift, resid, y,
+                             ldy, cout, colmax, device, stream);
+}
+
+extern "C" int sdfr_pointnet_layer_counted(const float* x, const int* row_count, int M_capacity, int cin, int ldx,
+                                           const float* w, int ldw, const float* cvec, const float* bn_scale,
+                                           const float* bn_shift, const float* resid, float* y, int ldy, int cout,
+                                           float* colmax, int device, void* stream) {
+  if (!row_count) return fail(SDFR_E_NULL, "sdfr_pointnet_layer_counted: row_count is NULL");
+  return pointnet_layer_impl("sdfr_pointnet_layer_counted", x, row_count, M_capacity, cin, ldx, w, ldw, cvec, bn_scale,
+                             bn_shift, resid, y, ldy, cout, colmax, device, stream);
+}
+
+extern "C" int sdfr_init_estimate(const float* head, int latent, const float* grid_quats, const int* index,
+                                  const float* centroid, const float* cam_pos, const float* cam_quat, int mean_shape,
+                                  int take_if_better, const float* posterior_max, float* best, float* params, int device,
+                                  void* stream) {
+  if (latent < 0 || latent > 1024) return fail(SDFR_E_INVALID, "sdfr_init_estimate: latent=%d", latent);
+  if (!head || !cam_pos || !cam_quat || !params || (grid_quats && !index) || (take_if_better && (!posterior_max || !best)))
+    return fail(SDFR_E_NULL, "sdfr_init_estimate: NULL pointer argument");
   SDFR_HIP_TRY(hipSetDevice(device));
-  hipStream_t st = (hipStream_t)stream;
-  zero_words_async(colmax, (size_t)cout, st);
-  hipLaunchKernelGGL(pointnet_layer_kernel, dim3((unsigned)((M + kPtsPerBlock - 1) / kPtsPerBlock),
-                                                 (unsigned)((cout + kColsPerBlock - 1) / kColsPerBlock)),
-                     dim3(256), 0, st, x, M, cin, ldx, w, ldw, cvec, bn_scale, bn_shift, resid, y, ldy, cout,
-                     reinterpret_cast<int*>(colmax));
+  hipLaunchKernelGGL(init_estimate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, head, latent, grid_quats, index,
+                     centroid, cam_pos, cam_quat, mean_shape, take_if_better, posterior_max, best, params);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -229,3 +229,206 @@ def nn_init(network: SDFPoseNet, camera: Camera, depth_images: torch.Tensor, cam
         else:
             raise NotImplementedError('Only "first" and "best" strategies are currently supported')
     return best_result
+
+
+class ResidentInit:
+    """``SDFPipeline._nn_init`` (simple_setup.py:718-844) as a FIXED launch sequence with nothing read back: the number
+    of observed points stays on the device (``sdfr_depth_count_centroid`` leaves count and centroid, the per-point
+    layers are ``sdfr_pointnet_layer_counted``), the orientation cell's quaternion comes from a table uploaded once
+    (``SO3Grid.index_to_quat`` of every cell), the camera -> world transform and the "first" / "best" choice are one
+    small kernel (``sdfr_init_estimate``) that writes the estimate where the loop reads its parameters.  Every buffer
+    is allocated at construction (points and activations at capacity, W * H rows), so the sequence can be captured
+    into a hipGraph (``use_graph``) and the front door's call has no host synchronisation between the observation
+    and the result.
+
+    ``nn_init`` above stays the host-driven form (one call of ~25 launches, two host reads): same layers, same
+    arithmetic per point; the centroid here is the count pass's fixed-order block-sum tree instead of ``torch.mean``
+    (a few 1e-7 relative apart), so the two agree to rounding, not to the bit (tests/test_init_network_gpu.py).
+    The empty-cloud check of :780-781 cannot raise before the launches it would prevent: ``empty_views()`` reads the
+    counts afterwards (one small copy; the caller raises ``NoDepthError``)."""
+
+    def __init__(self, network: SDFPoseNet, camera: Camera, views: int, config: Dict, normalize_pose: bool = True):
+        net = self.net = network
+        self.cam, self.V = camera, int(views)
+        self.dev, self.L = net.dev, net.L            # (L: the loaded library, as in SDFPoseNet)
+        self.normalize_pose = bool(normalize_pose)
+        self.mean_shape = bool(config.get("mean_shape", False))
+        self.strategy = config.get("init_view", "first")
+        if self.strategy not in ("first", "best"):
+            raise NotImplementedError('Only "first" and "best" strategies are currently supported')
+        if self.strategy == "best" and net.orientation_repr != "discretized":
+            raise NotImplementedError('"best" init strategy only supported with discretized orientation representation')
+        if net.in_size != 3:
+            raise NotImplementedError("the resident form feeds back-projected points (in_size = 3)")
+        H, W = camera.height, camera.width
+        self.H, self.W, M = H, W, H * W
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        # the plan of the backbone: what `features` decides per call, decided once
+        self.plan = []
+        F_width, G_width, prev_width, n = net.in_size, 0, net.in_size, len(net.pn)
+        for i, layer in enumerate(net.pn):
+            last = i == n - 1
+            if layer.cin_total != F_width + G_width:
+                raise RuntimeError("state dict does not match the backbone configuration")
+            out_width = layer.cout * (2 if (net.dense and not last) else 1)
+            use_res = net.residual and prev_width == out_width
+            if use_res and F_width != layer.cout:
+                raise NotImplementedError("a residual link over a concatenated dense input: use nn_init")
+            if last and use_res:
+                raise NotImplementedError("a residual link into the last backbone layer: use nn_init")
+            self.plan.append(dict(layer=layer, F_width=F_width, G_width=G_width, use_res=use_res, last=last,
+                                  store=not last))
+            G_width = layer.cout if (net.dense and not last) else 0
+            F_width, prev_width = layer.cout, out_width
+        width = max([p["layer"].cout for p in self.plan if p["store"]] + [4])
+        self.points = torch.zeros((M, 3), **f32)
+        self.act = [torch.zeros((M, width), **f32) for _ in range(2)]       # ping-pong per-point activations
+        self.colmax = [torch.zeros(p["layer"].cout, **f32) for p in self.plan]
+        self.cvec = [torch.zeros(p["layer"].cout, **f32) for p in self.plan]
+        self.G = [torch.zeros(p["layer"].cout, **f32) for p in self.plan]
+        self.head_vec = [torch.zeros(l.cout, **f32) for l in net.head] + [torch.zeros(net.final.cout, **f32)]
+        i32 = dict(dtype=torch.int32, device=self.dev)
+        self.count = torch.zeros(1, **i32)
+        self.offset1 = torch.zeros(1, **i32)
+        self.counts_all = torch.zeros(self.V, **i32)
+        self.centroid = torch.zeros(3, **f32)
+        self.ws = torch.zeros(max(self.L.sdfr_depth_centroid_workspace_bytes(1, W, H), 256) + 16, dtype=torch.uint8,
+                              device=self.dev)
+        self.discretized = net.orientation_repr == "discretized"
+        if self.discretized:
+            C = net.grid.num_cells()
+            self.C = C
+            self.grid_quats = torch.tensor(np.stack([np.asarray(net.grid.index_to_quat(i), dtype=np.float64)
+                                                     for i in range(C)]), **f32).contiguous()
+            self.posterior = torch.zeros(C, **f32)
+            self.prior = torch.zeros((self.V, C), **f32)
+            self.train_prior = torch.zeros(C, **f32)
+        self.index = torch.zeros(1, **i32)
+        self.post_max = torch.zeros(1, **f32)
+        self.best = torch.zeros(1, **f32)
+        self.params = torch.zeros(8 + net.shape_dimension, **f32)
+        self._graphs = {}
+        self._host_counts = torch.zeros(self.V, dtype=torch.int32).pin_memory()
+        self._counts_event = None
+
+    def _vec(self, layer, koff, x, k, bn, relu, out):
+        rc = self.L.sdfr_linear_vec(layer.w.data_ptr(), layer.cin_total, koff, x.data_ptr() if x is not None else None, k,
+                                    layer.b.data_ptr(), layer.scale.data_ptr() if bn else None,
+                                    layer.shift.data_ptr() if bn else None, int(relu), out.data_ptr(), layer.cout,
+                                    self.dev.index, self._st)
+        _lib.check(rc, "sdfr_linear_vec")
+
+    def _sequence(self, depth: torch.Tensor, cam_pos: torch.Tensor, cam_quat: torch.Tensor, has_prior: bool,
+                  has_train: bool):
+        """the launches, on the current stream; depth (V,H,W) float32 contiguous on the device"""
+        L, net, d = self.L, self.net, self.dev.index
+        self._st = st = torch.cuda.current_stream(self.dev).cuda_stream
+        fx, fy, cx0, cy0, _ = self.cam.get_pinhole_camera_parameters(0.0)
+        W, H, M = self.W, self.H, self.W * self.H
+        ws = self.ws[(-self.ws.data_ptr()) % 16:]
+        views = range(self.V) if self.strategy == "best" else range(1)
+        if self.strategy == "best":
+            self.best.zero_()
+        for v in views:
+            img = depth[v]
+            _lib.check(L.sdfr_depth_count_centroid(img.data_ptr(), 1, W, H, 0, 1.0 / fx, 1.0 / fy, cx0, cy0,
+                                                   self.count.data_ptr(), self.offset1.data_ptr(), self.centroid.data_ptr(),
+                                                   ws.data_ptr(), ws.numel(), d, st), "sdfr_depth_count_centroid")
+            _lib.check(L.sdfr_depth_to_points_shifted(img.data_ptr(), 1, W, H, 0, 1.0 / fx, 1.0 / fy, cx0, cy0,
+                                                      self.offset1.data_ptr(), ws.data_ptr(),
+                                                      self.centroid.data_ptr() if self.normalize_pose else None, None,
+                                                      self.points.data_ptr(), d, st), "sdfr_depth_to_points_shifted")
+            self.counts_all[v:v + 1].copy_(self.count)
+            F, ldF = self.points, 3
+            G = None
+            for i, p in enumerate(self.plan):
+                layer = p["layer"]
+                if G is not None:     # bias + what the concatenated set maximum contributes to every point
+                    self._vec(layer, p["F_width"], G, p["G_width"], False, False, self.cvec[i])
+                    cvec = self.cvec[i]
+                else:
+                    cvec = layer.b
+                Y = self.act[i % 2] if p["store"] else None
+                ldy = Y.shape[1] if Y is not None else layer.cout
+                rc = L.sdfr_pointnet_layer_counted(
+                    F.data_ptr(), self.count.data_ptr(), M, p["F_width"], ldF, layer.w.data_ptr(), layer.cin_total,
+                    cvec.data_ptr(), layer.scale.data_ptr(), layer.shift.data_ptr(),
+                    F.data_ptr() if p["use_res"] else None, Y.data_ptr() if Y is not None else None, ldy, layer.cout,
+                    self.colmax[i].data_ptr(), d, st)
+                _lib.check(rc, "sdfr_pointnet_layer_counted")
+                if net.dense and not p["last"]:
+                    if p["use_res"] and G is not None:
+                        torch.add(self.colmax[i], G, out=self.G[i])
+                        G = self.G[i]
+                    else:
+                        G = self.colmax[i]
+                else:
+                    G = None
+                if not p["last"]:
+                    F, ldF = Y, ldy
+            out = self.colmax[-1]
+            for j, layer in enumerate(net.head):
+                self._vec(layer, 0, out, layer.cin_total, True, True, self.head_vec[j])
+                out = self.head_vec[j]
+            self._vec(net.final, 0, out, net.final.cin_total, False, False, self.head_vec[-1])
+            head = self.head_vec[-1]
+            sd = net.shape_dimension
+            if self.discretized:
+                _lib.check(L.sdfr_orientation_posterior(
+                    head.data_ptr() + 4 * (sd + 4), self.C, self.prior[v].data_ptr() if has_prior else None,
+                    self.train_prior.data_ptr() if (has_prior and has_train) else None, self.posterior.data_ptr(),
+                    self.index.data_ptr(), self.post_max.data_ptr(), d, st), "sdfr_orientation_posterior")
+            _lib.check(L.sdfr_init_estimate(
+                head.data_ptr(), sd, self.grid_quats.data_ptr() if self.discretized else None,
+                self.index.data_ptr() if self.discretized else None,
+                self.centroid.data_ptr() if self.normalize_pose else None, cam_pos[v].data_ptr(), cam_quat[v].data_ptr(),
+                int(self.mean_shape), int(self.strategy == "best"), self.post_max.data_ptr(), self.best.data_ptr(),
+                self.params.data_ptr(), d, st), "sdfr_init_estimate")
+
+    def __call__(self, depth: torch.Tensor, cam_pos: torch.Tensor, cam_quat: torch.Tensor,
+                 prior_orientation_distribution: Optional[torch.Tensor] = None,
+                 training_orientation_distribution: Optional[torch.Tensor] = None, use_graph: bool = True):
+        """depth (V,H,W), cam_pos (V,3), cam_quat (V,4): float32, contiguous, on the device, and THE SAME TENSORS on
+        every call when ``use_graph`` (their addresses are part of the captured sequence: the loop's target and camera
+        buffers are such tensors).  Returns (latent (1,L), position (1,3), scale (1,), orientation (1,4)) as views of
+        ``self.params``."""
+        if prior_orientation_distribution is not None and not self.discretized:
+            raise ValueError("prior_orientation_distribution only supported for discretized orientation representation.")
+        has_prior = prior_orientation_distribution is not None
+        has_train = has_prior and training_orientation_distribution is not None
+        if has_prior:
+            self.prior.copy_(prior_orientation_distribution.reshape(self.V, self.C))
+        if has_train:
+            self.train_prior.copy_(training_orientation_distribution.reshape(self.C))
+        if use_graph:
+            key = (depth.data_ptr(), cam_pos.data_ptr(), cam_quat.data_ptr(), has_prior, has_train)
+            g = self._graphs.get(key)
+            if g is None:
+                side = torch.cuda.Stream(self.dev)        # warm-up on a side stream (lazy module loads), then capture
+                side.wait_stream(torch.cuda.current_stream(self.dev))
+                with torch.cuda.stream(side):
+                    self._sequence(depth, cam_pos, cam_quat, has_prior, has_train)
+                torch.cuda.current_stream(self.dev).wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._sequence(depth, cam_pos, cam_quat, has_prior, has_train)
+                self._graphs[key] = g
+            g.replay()
+        else:
+            self._sequence(depth, cam_pos, cam_quat, has_prior, has_train)
+        # the counts for the empty-cloud check, without waiting for them here
+        self._host_counts.copy_(self.counts_all, non_blocking=True)
+        self._counts_event = torch.cuda.Event()
+        self._counts_event.record(torch.cuda.current_stream(self.dev))
+        sd = self.net.shape_dimension
+        p = self.params
+        return p[8:8 + sd][None], p[0:3][None], p[7:8], p[3:7][None]
+
+    def empty_views(self):
+        """the views (of those the strategy looked at) without a single observed point -- waits for the counts of the
+        last call only (they were copied behind its launches), not for whatever was enqueued after them"""
+        if self._counts_event is None:
+            return []
+        self._counts_event.synchronize()
+        n = self.V if self.strategy == "best" else 1
+        return [v for v in range(n) if int(self._host_counts[v]) == 0]

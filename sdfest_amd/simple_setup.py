@@ -24,7 +24,7 @@ from typing import Dict, Mapping, Optional, Tuple
 import torch
 
 from .differentiable_renderer import Camera, render_depth_gpu
-from .init_network import NoDepthError, SDFPoseNet, adjust_categorical_posterior, nn_init
+from .init_network import NoDepthError, ResidentInit, SDFPoseNet, adjust_categorical_posterior, nn_init
 from .pipeline import FusedRenderAndCompare, _selection_strategy, preprocess_depth
 from .vae import SDFDecoder
 
@@ -60,7 +60,7 @@ class SDFPipeline:
     """
 
     def __init__(self, config: Dict, vae_state_dict: Optional[Mapping] = None,
-                 init_state_dict: Optional[Mapping] = None, init_network=None) -> None:
+                 init_state_dict: Optional[Mapping] = None, init_network=None, resident_init: bool = True) -> None:
         self._parse_config(config)
         dev = torch.device(self.device)
         if dev.type != "cuda":
@@ -95,6 +95,10 @@ class SDFPipeline:
         self.config = config
         self.log_data = []
         self._loops = {}     # (views, shape_optimization) -> the captured loop, re-bound per call
+        # resident_init: the initialisation network as a captured launch sequence with nothing read back
+        # (init_network.ResidentInit) where its architecture allows; False: the host-driven nn_init (two host reads)
+        self._resident_wanted = bool(resident_init)
+        self._residents = {}
         self._ignored_warned = False
 
     def _parse_config(self, config: Dict) -> None:
@@ -127,6 +131,18 @@ class SDFPipeline:
                        normalize_pose=bool(self.init_config.get("normalize_pose", False)),
                        prior_orientation_distribution=prior_orientation_distribution,
                        training_orientation_distribution=training_orientation_distribution)
+
+    def _resident_init(self, views: int):
+        """the captured form of ``_nn_init`` for `views` images, or None where only the host-driven form applies"""
+        if not self._resident_wanted or self._nn_init_override is not None or not isinstance(self.init_network, SDFPoseNet):
+            return None
+        if views not in self._residents:
+            try:
+                self._residents[views] = ResidentInit(self.init_network, self.cam, views, self.config,
+                                                      normalize_pose=bool(self.init_config.get("normalize_pose", False)))
+            except NotImplementedError:
+                self._residents[views] = None
+        return self._residents[views]
 
     def generate_depth(self, position, orientation, scale, latent) -> torch.Tensor:
         """simple_setup.py:609-619"""
@@ -179,19 +195,56 @@ class SDFPipeline:
         loop = self._loop(n_imgs, shape_optimization)
         with torch.no_grad():
             # :333-334, and the observation into the loop's buffers in the same pass
-            loop.rebind(depth_images, camera_positions, camera_orientations, point_constraint, masks=masks,
-                        far_field=self._far_field)
+            if (depth_images.is_cuda and depth_images.dtype is torch.float32 and depth_images.is_contiguous()
+                    and depth_images.device == dev):
+                loop.rebind(depth_images, camera_positions, camera_orientations, point_constraint, masks=masks,
+                            far_field=self._far_field)
+            else:
+                # any other tensor the reference would take (another dtype or device, a strided view): its own two
+                # in-place assignments, then the copy into the loop's buffers
+                depth_images[~masks.to(device=depth_images.device, dtype=torch.bool)] = 0
+                if self._far_field is not None:
+                    depth_images[depth_images > self._far_field] = 0
+                loop.rebind(depth_images, camera_positions, camera_orientations, point_constraint)
+                depth_images = loop.target if loop.group is None else depth_images.to(dev, torch.float32)
             # :352-359
-            latent_shape, position, scale, orientation = self._nn_init(
-                depth_images, camera_positions, camera_orientations, prior_orientation_distribution,
-                training_orientation_distribution)
+            resident = self._resident_init(n_imgs)
+            if resident is not None:
+                # on the loop's own (address-stable) buffers: the preprocessed images and the cameras rebind left there
+                latent_shape, position, scale, orientation = resident(
+                    loop.target, loop.cam_pos_all, loop.cam_quat_all, prior_orientation_distribution,
+                    training_orientation_distribution)
+            else:
+                latent_shape, position, scale, orientation = self._nn_init(
+                    depth_images, camera_positions, camera_orientations, prior_orientation_distribution,
+                    training_orientation_distribution)
             # :381-470
             position, orientation, scale, latent_shape = loop(position, orientation, scale, latent_shape)
+            if resident is not None and resident.empty_views():
+                # (:780-781 -- known only now: the counts were never waited for in front of the launches)
+                raise NoDepthError
         self._last_loop = loop
         # :583-596 -- "best_inlier_ratio" returns the tensors the reference stored, which its optimiser went on
         # updating in place: the last iterate as well (pipeline._BestEstimate); the snapshot at the best ratio is
         # self.best_estimate()
         return position, orientation, scale, latent_shape
+
+    def prepare(self, views: int = 1, shape_optimization: bool = True) -> "SDFPipeline":
+        """Optional: build the loop for `views` images and capture its graphs NOW (on an empty observation) instead of
+        inside the first call -- a service that must answer its first request in the steady-state time calls this
+        after construction.  The reference has no counterpart (it re-uses nothing between calls)."""
+        loop = self._loop(views, shape_optimization)
+        with torch.no_grad():
+            H, W = self.cam.height, self.cam.width
+            loop.rebind(torch.zeros((views, H, W), device=self._dev))
+            z = torch.zeros((1, self.vae.latent_size), device=self._dev)
+            loop(torch.tensor([[0.0, 0.0, -1.0]], device=self._dev), torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=self._dev),
+                 torch.tensor([0.1], device=self._dev), z)
+            resident = self._resident_init(views)
+            if resident is not None:
+                resident(loop.target, loop.cam_pos_all, loop.cam_quat_all)
+            torch.cuda.synchronize(self._dev)
+        return self
 
     def best_estimate(self):
         """(ratio, 1-based iteration, (position, orientation, scale, latent)) at the best inlier ratio of the last call

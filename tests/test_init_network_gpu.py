@@ -111,6 +111,58 @@ def test_nn_init_frames_and_strategies(gold, mug_net):
         nn_init(mug_net, cam, depth, cam_pos, cq, {"init_view": "median"})
 
 
+def test_resident_init_matches_the_host_driven_form(gold, mug_net):
+    """ResidentInit = _nn_init (simple_setup.py:718-844) as a fixed launch sequence with the point count on the device
+    (sdfr_pointnet_layer_counted), the cell's quaternion from an uploaded table and camera -> world + "first" / "best"
+    in sdfr_init_estimate: against nn_init (same layers; the centroid is a block-sum tree instead of torch.mean, hence
+    rounding, not bits), eager == captured bit for bit, priors, mean_shape, and the empty-cloud report."""
+    from sdfest_amd import Camera
+    from sdfest_amd.init_network import ResidentInit, nn_init
+    W, H = 96, 72
+    cam = Camera(W, H, 48.0, 48.0, 48.0, 36.0, pixel_center=0.5)
+    g = torch.Generator().manual_seed(4)
+    depth = torch.zeros((3, H, W))
+    depth[0, 20:50, 30:70] = 0.4 + 0.05 * torch.rand((30, 40), generator=g)
+    depth[1, 10:40, 20:50] = 0.5 + 0.05 * torch.rand((30, 30), generator=g)
+    depth[2, 5:66, 3:90] = 0.3 + 0.1 * torch.rand((61, 87), generator=g)       # > 4096 points: several row blocks
+    depth = depth.cuda().contiguous()
+    cam_pos = torch.tensor([[0.0, 0.0, 0.0], [0.2, -0.1, 0.05], [-0.1, 0.1, 0.0]], device="cuda")
+    cq = torch.tensor([[0.0, 0.0, 0.0, 1.0], [0.1, 0.3, -0.2, 0.9], [-0.2, 0.1, 0.1, 0.95]], device="cuda")
+    cq = (cq / cq.norm(dim=1, keepdim=True)).contiguous()
+    C = mug_net.grid.num_cells()
+    prior = torch.rand((3, C), generator=g).cuda()
+    train = (0.5 + torch.rand(C, generator=g)).cuda()
+    for cfg, kw in (({"init_view": "first"}, {}), ({"init_view": "best"}, {}), ({"init_view": "best", "mean_shape": True}, {}),
+                    ({"init_view": "best"}, dict(prior_orientation_distribution=prior)),
+                    ({"init_view": "first"}, dict(prior_orientation_distribution=prior,
+                                                  training_orientation_distribution=train))):
+        for normalize in (True, False):
+            ri = ResidentInit(mug_net, cam, 3, cfg, normalize_pose=normalize)
+            ref = nn_init(mug_net, cam, depth, cam_pos, cq, cfg, normalize_pose=normalize, **kw)
+            eager = [t.clone() for t in ri(depth, cam_pos, cq, kw.get("prior_orientation_distribution"),
+                                           kw.get("training_orientation_distribution"), use_graph=False)]
+            assert ri.empty_views() == []
+            for rep in range(2):          # captured, then replayed
+                got = [t.clone() for t in ri(depth, cam_pos, cq, kw.get("prior_orientation_distribution"),
+                                             kw.get("training_orientation_distribution"), use_graph=True)]
+                for a, b in zip(got, eager):
+                    assert torch.equal(a, b), (cfg, normalize, rep)
+            assert len(ri._graphs) == 1
+            for name, a, b in zip(("latent", "position", "scale", "orientation"), eager, ref):
+                assert a.shape == b.shape, (name, a.shape, b.shape)
+                tol = 1e-4 * max(1.0, float(b.abs().max()))
+                assert (a - b).abs().max().item() <= tol, (cfg, normalize, name, a, b)
+            assert torch.equal(eager[3], ref[3])                      # the same orientation cell, the same product
+    # an image without a point: reported after the launches (the front door raises NoDepthError, :780-781)
+    ri = ResidentInit(mug_net, cam, 3, {"init_view": "best"})
+    empty = depth.clone(); empty[1] = 0
+    ri(empty, cam_pos, cq, use_graph=False)
+    assert ri.empty_views() == [1]
+    ri = ResidentInit(mug_net, cam, 3, {"init_view": "first"})
+    ri(empty, cam_pos, cq)
+    assert ri.empty_views() == []                                      # "first" never looks at view 1
+
+
 def test_nan_points_reach_the_outputs(gold, mug_net):
     """torch's relu and max propagate NaN (pointnet.py:64-96): a NaN coordinate (or weight) must come out as NaN, not
     as a plausible pose computed from `fmaxf(NaN, 0) = 0` (round-2 advisor finding)."""

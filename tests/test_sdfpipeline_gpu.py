@@ -132,7 +132,12 @@ def test_front_door_semantics_with_the_real_initialisation_network():
     assert torch.equal(arg, expect)                                                    # preprocessed in place
     # what the call did, step by step
     cam_pos, cam_quat = torch.zeros(1, 3, device="cuda"), T([[0, 0, 0, 1.0]])
-    z0, p0, s0, q0 = nn_init(pipe.init_network, pipe.cam, expect[None], cam_pos, cam_quat, cfg, normalize_pose=True)
+    # (the front door runs the initialisation network in its resident, captured form: the same launches here, eagerly)
+    from sdfest_amd.init_network import ResidentInit
+    ri = ResidentInit(pipe.init_network, pipe.cam, 1, cfg, normalize_pose=True)
+    z0, p0, s0, q0 = (t.clone() for t in ri(expect[None].contiguous(), cam_pos, cam_quat, use_graph=False))
+    zh, ph, sh, qh = nn_init(pipe.init_network, pipe.cam, expect[None], cam_pos, cam_quat, cfg, normalize_pose=True)
+    assert torch.equal(q0, qh) and (p0 - ph).abs().max() < 1e-6 and (z0 - zh).abs().max() < 1e-6   # the host-driven form
     assert abs(float(q0.norm()) - 1.0) < 1e-5 and z0.shape == (1, 8)
     assert 0.04 < float(s0) < 0.08 and (p0 - T([[0.02, -0.01, -0.5]])).abs().max() < 0.06     # a usable starting point
     loop = FusedRenderAndCompare(pipe.vae, pipe.cam, cfg, expect[None].contiguous(), shape_optimization=False)
@@ -152,6 +157,64 @@ def test_front_door_semantics_with_the_real_initialisation_network():
     bad = copy.deepcopy(cfg); bad["result_selection_strategy"] = "median"
     with pytest.raises(ValueError):
         SDFPipeline(bad, vae_state_dict=mug_weights(), init_state_dict=plausible_init_state())
+
+
+def test_two_views_best_init_view_priors_and_any_depth_tensor():
+    """N views with camera extrinsics: `init_view="best"` picks the view whose posterior peaks highest (:829-838), an
+    orientation prior reaches the initialisation network (:799-804); a float64 / host / strided depth tensor takes the
+    reference's own two assignments and gives the same result; `prepare()` moves construction and capture out of the
+    first call."""
+    from sdfest_amd import SDFPipeline, render_depth_gpu
+    from sdfest_amd.init_network import nn_init
+    from sdfest_amd.pipeline import FusedRenderAndCompare, quaternion_apply, quaternion_invert, quaternion_multiply
+    W, H = 160, 120
+    cfg = make_config(W, H, 150.0, 150.0, 80.0, 60.0, 0.005, 5, init_view="best", far_field=2.0)
+    pipe = SDFPipeline(cfg, vae_state_dict=mug_weights(), init_state_dict=plausible_init_state()).prepare(views=2)
+    loop0 = pipe._loops[(2, True)]
+    graph0 = loop0.graph
+    assert graph0 is not None
+    d = np.load(os.path.join(GOLDEN, "decoder_mug.npz"))
+    z_true = T(d["z"][10:11]) * 0.4
+    p_true, s_true = T([[0.01, -0.02, -0.45]]), T([0.06])
+    q_true = T([[0.3, 0.5, -0.1, 0.8]]); q_true = q_true / q_true.norm()
+    cam_pos = T([[0.0, 0.0, 0.0], [0.2, 0.05, 0.02]])
+    cq = T([[0, 0, 0, 1.0], [0.02, 0.25, 0.01, 1.0]]); cq = cq / cq.norm(dim=1, keepdim=True)
+    with torch.no_grad():
+        sdf = pipe.vae.decode(z_true)[0, 0]
+        imgs = []
+        for v in range(2):
+            qi = quaternion_invert(cq[v])
+            imgs.append(render_depth_gpu(sdf, quaternion_apply(qi, p_true[0] - cam_pos[v]),
+                                         quaternion_multiply(qi, q_true[0]), 1 / s_true[0], None, None, None, 0.005,
+                                         pipe.cam))
+    depth = torch.stack(imgs).contiguous()
+    assert (depth > 0).sum(dim=(1, 2)).min() > 300
+    masks = depth > 0
+    color = torch.zeros((2, H, W, 3), device="cuda")
+    C = pipe.init_network.grid.num_cells()
+    prior = torch.full((2, C), 1.0 / C, device="cuda")
+    prior[:, 7] = 0.5                                   # a prior that prefers one cell strongly
+    out = pipe(depth.clone(), masks, color, camera_positions=cam_pos, camera_orientations=cq,
+               prior_orientation_distribution=prior)
+    assert pipe._loops[(2, True)] is loop0 and loop0.graph is graph0          # nothing built or captured in the call
+    from sdfest_amd.init_network import ResidentInit
+    ri = ResidentInit(pipe.init_network, pipe.cam, 2, cfg, normalize_pose=True)
+    z0, p0, s0, q0 = (t.clone() for t in ri(depth, cam_pos, cq, prior, use_graph=False))
+    zh, ph, sh, qh = nn_init(pipe.init_network, pipe.cam, depth, cam_pos, cq, cfg, normalize_pose=True,
+                             prior_orientation_distribution=prior)
+    assert torch.equal(q0, qh) and (p0 - ph).abs().max() < 1e-6              # resident and host-driven forms agree
+    z1, p1, s1, q1 = nn_init(pipe.init_network, pipe.cam, depth, cam_pos, cq, cfg, normalize_pose=True)
+    assert not torch.equal(q0, q1)                                            # the prior changed the initial cell
+    ref = FusedRenderAndCompare(pipe.vae, pipe.cam, cfg, depth, cam_pos, cq)(p0, q0, s0, z0)
+    for a, b, tol in zip(out, ref, (2e-6, 2e-5, 2e-6, 5e-5)):                 # (shape optimisation: float atomics)
+        assert (a - b).abs().max().item() <= tol
+    # the same observation as float64 on the host, and as a strided device view
+    for variant in (depth.double().cpu(), torch.stack([depth, depth], dim=1)[:, 0]):
+        arg = variant.clone() if variant.is_contiguous() else variant
+        m = masks.to(arg.device)
+        got = pipe(arg, m, color, camera_positions=cam_pos, camera_orientations=cq, prior_orientation_distribution=prior)
+        for a, b, tol in zip(got, out, (2e-6, 2e-5, 2e-6, 5e-5)):
+            assert (a - b).abs().max().item() <= tol
 
 
 def test_adjust_categorical_posterior_known_answers_of_the_reference_suite():
