@@ -54,7 +54,7 @@
  *        sdfr_preprocess_depth, sdfr_depth_to_points_resident, sdfr_depth_count[_ordered|_centroid],
  *        sdfr_depth_to_points[_ordered|_shifted], sdfr_depth_points_workspace_bytes, sdfr_depth_centroid_workspace_bytes
  *        sdfr_pose_to_views, sdfr_views_to_pose_grad[_deferred], sdfr_decoder_backward_latent_deferred,
- *        sdfr_loop_tail, sdfr_adam_step, sdfr_point_constraint, sdfr_add_inplace
+ *        sdfr_loop_tail, sdfr_loop_tail_objects, sdfr_adam_step, sdfr_point_constraint, sdfr_add_inplace
  *        sdfr_depth_l1_loss[_workspace_bytes], sdfr_pc_l1_loss, sdfr_inlier_ratio, sdfr_nn_loss_forward / _backward
  *        sharded over ranks: sdfr_loop_view_records, sdfr_loop_tail_records, sdfr_inlier_counts_record,
  *        sdfr_inlier_update_record
@@ -456,6 +456,23 @@ SDFR_API int sdfr_loop_tail(float* params, float* grads, float* exp_avg, float* 
                    int max_view_points, float* pos_c, float* quat_c, float* inv_scale, float* scale_v, float* pc_loss,
                    const float* con_source, const float* con_target, float con_weight, float* con_loss,
                    const sdfr_decoder* decoder, const float* decoder_t_mid, int device, void* stream);
+
+/* sdfr_loop_tail for SEVERAL estimates at once -- the K detected objects of one frame, each with its own pose, scale,
+ * latent and Adam state, optimised side by side in one launch sequence (the reference runs its pipeline once per object,
+ * one after the other: simple_setup.py:213-225; a single estimate's iteration is a chain of dependent launches that
+ * leaves most of the chip idle).  Workgroup k is object k:
+ *   params / grads / exp_avg / exp_avg_sq  [K][n_params];  step [K]  (one counter per object)
+ *   the launch's views are object-major: object k owns views k V .. k V + V - 1 of the render / sampler launches
+ *   (set-up records, tile partials, point blocks, quat_c, pc_loss, and the pos_c / quat_c / inv_scale / scale_v written
+ *   for the next iteration: all [K V ...]); cam_pos [V][3], cam_quat [V][4] are ONE camera list, the same for every object
+ *   grads[k][8..] must hold d loss / d latent of object k (sdfr_decoder_backward_latent with N = K); no point constraint,
+ *   no deferred decoder stage.  Same arithmetic per object, in the same order, as sdfr_loop_tail. */
+SDFR_API int sdfr_loop_tail_objects(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int* step, int n_params,
+                           int n_objects, float lr_position, float lr_orientation, float lr_scale, float lr_latent,
+                           int update_latent, const float* cam_pos, const float* cam_quat, int V,
+                           const void* render_workspace, size_t render_partials_offset, int W, int H,
+                           const void* pc_workspace, const int* offsets, int max_view_points, float* pos_c,
+                           float* quat_c, float* inv_scale, float* scale_v, float* pc_loss, int device, void* stream);
 
 /* ---- the loop sharded over ranks (one process per GPU) ------------------------------------------------
  * The reference's multi-view iteration is one Python loop over the views with ONE shared pose and ONE shared SDF

@@ -320,15 +320,18 @@ __device__ __forceinline__ void deferred_chain(
     int nty_all, int tile_w_all, int tile_h_all, int stride, const float* __restrict__ pc_part,
     const float* __restrict__ pc_loss_part,
     const int* __restrict__ offsets, int n_single, int nblk, const float* __restrict__ quat_c,
-    float* __restrict__ pc_loss, float* g_position, float* g_orientation, float* g_scale) {
+    float* __restrict__ pc_loss, float* g_position, float* g_orientation, float* g_scale, int view_base = 0) {
+  // view_base (sdfr_loop_tail_objects): the V views of THIS object are the launch's views view_base .. view_base + V - 1
+  // (their set-up records, tile partials, point blocks, quaternions, losses); the cameras are the object's own list
   __shared__ float view_g[kDeferredMaxViews][16];  // [0..7] renderer: pos, quat, inv_scale; [8..15] sampler
   __shared__ float view_cq[kDeferredMaxViews][4];  // the views' camera orientations (the chain's thread reads them here)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // view v is wave (v + 1) % 4's: wave 0, which may arrive late, takes the fourth, eighth, ... view only
   for (int v = (wave + 3) & 3; v < V; v += 4) {
     const float cq = lane < 4 ? cam_quat[4 * v + lane] : 0.0f;
-    reduce_view_wave(v, lane, setup, tile_part, W, H, ntx_all, nty_all, tile_w_all, tile_h_all, stride, pc_part,
-                     pc_loss_part, offsets, n_single, nblk, quat_c, pc_loss ? pc_loss + v : nullptr, view_g[v]);
+    reduce_view_wave(view_base + v, lane, setup, tile_part, W, H, ntx_all, nty_all, tile_w_all, tile_h_all, stride,
+                     pc_part, pc_loss_part, offsets, n_single, nblk, quat_c,
+                     pc_loss ? pc_loss + view_base + v : nullptr, view_g[v]);
     if (lane < 4) view_cq[v][lane] = cq;
   }
   __syncthreads();
@@ -699,6 +702,9 @@ struct LoopTailArgs {
   // rank's partials; cam_pos / cam_quat / V above are then this rank's shard (the next iteration's view poses)
   const float* records; int V_all; const float* cam_quat_all;
   int fc_one_wave;   // the Linear stack is narrow enough for fc_stack_backward_one_wave (decoder_fc_one_wave)
+  // sdfr_loop_tail_objects: workgroup k is object k -- its own parameters, moments, step counter and V views (the
+  // launch's views k V .. k V + V - 1), the same cameras for every object; 0 / 1: the single estimate of sdfr_loop_tail
+  int n_obj;
 };
 static_assert(kFcBlock == 256, "the tail's workgroup runs the decoder's Linear-stack backward");
 #ifdef SDFR_TAIL_STAMPS   // timing experiment (tools/microbench): where the tail's time goes, in 10 ns ticks
@@ -714,11 +720,18 @@ __device__ unsigned long long g_tail_stamps[8];
 // constraint's points); (b) a narrow Linear stack is one wave's work out of LDS (fc_stack_backward_one_wave), and the
 // other three waves reduce the views meanwhile; (c) gradients and the updated parameters pass between the stages in
 // LDS (g_l, p_new) instead of through global memory.  Same arithmetic, same order: the numbers do not change.
-__global__ __launch_bounds__(256) void loop_tail_kernel(LoopTailArgs a) {
+__global__ __launch_bounds__(256) void loop_tail_kernel(LoopTailArgs a_in) {
   __shared__ float g_l[256];      // the gradients, laid out as a.grads (copied there at the end)
   __shared__ float p_cur[256];    // the parameters of this iteration ...
   __shared__ float p_new[256];    // ... and after the Adam step
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  LoopTailArgs a = a_in;
+  const int view_base = (int)blockIdx.x * a.V;     // (0 for the single estimate)
+  if (a.n_obj > 1) {
+    const size_t o = (size_t)blockIdx.x * a.n;
+    a.params += o; a.grads += o; a.m += o; a.v += o; a.step += blockIdx.x;
+    a.pos_c += 3 * view_base; a.quat_c += 4 * view_base; a.inv_scale += view_base; a.scale_v += view_base;
+  }
   SDFR_STAMP(0);
   const bool mine = tid < a.n;
   const float p_old = mine ? a.params[tid] : 0.0f, m_old = mine ? a.m[tid] : 0.0f, v_old = mine ? a.v[tid] : 0.0f;
@@ -749,9 +762,10 @@ __global__ __launch_bounds__(256) void loop_tail_kernel(LoopTailArgs a) {
     pose_chain_block(a.params + 3, a.params + 7, a.cam_quat_all, a.V_all, a.records, kViewRecord, g_l, g_l + 3,
                      g_l + 7);
   } else {
+    // (a.quat_c has been advanced to this object's views; the chain indexes the launch's views: undo it there)
     deferred_chain(p_cur + 3, p_cur + 7, a.cam_quat, a.V, a.setup, a.tile_part, a.W, a.H, a.ntx, a.nty,
-                   a.tile_w, a.tile_h, a.stride, a.pc_part, a.pc_loss_part, a.offsets, a.n_single, a.nblk, a.quat_c,
-                   a.pc_loss, g_l, g_l + 3, g_l + 7);
+                   a.tile_w, a.tile_h, a.stride, a.pc_part, a.pc_loss_part, a.offsets, a.n_single, a.nblk,
+                   a_in.quat_c, a.pc_loss, g_l, g_l + 3, g_l + 7, a.n_obj > 1 ? view_base : 0);
   }
   SDFR_STAMP(2);
   if (tid == 0 && a.con_source)   // (p_cur: thread 0 has passed a barrier of the chain above since it was written)
@@ -1174,7 +1188,54 @@ extern "C" int sdfr_loop_tail(float* params, float* grads, float* exp_avg, float
                   n_params - 8);
     a.t_mid = decoder_t_mid;
   }
+  a.n_obj = 1;
   hipLaunchKernelGGL(loop_tail_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfr_loop_tail_objects(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int* step,
+                                      int n_params, int n_objects, float lr_position, float lr_orientation,
+                                      float lr_scale, float lr_latent, int update_latent, const float* cam_pos,
+                                      const float* cam_quat, int V, const void* render_workspace,
+                                      size_t render_partials_offset, int W, int H, const void* pc_workspace,
+                                      const int* offsets, int max_view_points, float* pos_c, float* quat_c,
+                                      float* inv_scale, float* scale_v, float* pc_loss, int device, void* stream) {
+  const char* fn = "sdfr_loop_tail_objects";
+  if (n_objects < 1 || n_objects > 65535) return fail(SDFR_E_INVALID, "%s: n_objects=%d", fn, n_objects);
+  if (V < 1 || V > kDeferredMaxViews) return fail(SDFR_E_INVALID, "%s: V=%d out of range [1,%d]", fn, V, kDeferredMaxViews);
+  if ((long long)n_objects * V > 65535) return fail(SDFR_E_INVALID, "%s: %d objects x %d views exceed a launch", fn, n_objects, V);
+  if (n_params < 8 || n_params > 256) return fail(SDFR_E_INVALID, "%s: n_params=%d out of range [8,256]", fn, n_params);
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !step || !cam_pos || !cam_quat || !pos_c || !quat_c ||
+      !inv_scale || !scale_v)
+    return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
+  if (render_workspace && (W <= 0 || H <= 0)) return fail(SDFR_E_INVALID, "%s: W=%d H=%d", fn, W, H);
+  const int B = n_objects * V;
+  if (pc_workspace && (max_view_points <= 0 || (!offsets && B > 1)))
+    return fail(SDFR_E_INVALID, "%s: bad sampler arguments", fn);
+  if (render_workspace && ((uintptr_t)render_workspace % alignof(ViewSetup) || render_partials_offset % 16))
+    return fail(SDFR_E_INVALID, "%s: render_workspace / partials offset misaligned", fn);
+  SDFR_HIP_TRY(hipSetDevice(device));
+  const TileGeom geom = render_workspace ? backward_geom(B, W, H) : kSmallTile;   // the tiling of the launch of ALL views
+  const int nblk = pc_workspace ? (max_view_points + kSamplerPts - 1) / kSamplerPts : 0;
+  const float* pc_part = (const float*)pc_workspace;
+  LoopTailArgs a{};
+  a.params = params; a.grads = grads; a.m = exp_avg; a.v = exp_avg_sq; a.step = step; a.n = n_params;
+  a.lr_pos = lr_position; a.lr_quat = lr_orientation; a.lr_scale = lr_scale; a.lr_latent = lr_latent;
+  a.update_latent = update_latent;
+  a.cam_pos = cam_pos; a.cam_quat = cam_quat; a.V = V;
+  a.setup = (const ViewSetup*)render_workspace;
+  a.tile_part = render_workspace ? (const float*)((const char*)render_workspace + render_partials_offset) : nullptr;
+  a.W = W; a.H = H;
+  a.ntx = render_workspace ? geom.nx(W) : 0; a.nty = render_workspace ? geom.ny(H) : 0;
+  a.tile_w = geom.w(); a.tile_h = geom.h();
+  a.stride = (render_workspace && geom.sx * geom.sy > 1) ? backward_tile_stride(W, H) : 0;
+  a.pc_part = pc_part;
+  a.pc_loss_part = (pc_workspace && pc_loss) ? pc_part + (size_t)B * nblk * 8 : nullptr;
+  a.offsets = offsets; a.n_single = max_view_points; a.nblk = nblk;
+  a.pos_c = pos_c; a.quat_c = quat_c; a.inv_scale = inv_scale; a.scale_v = scale_v; a.pc_loss = pc_loss;
+  a.n_obj = n_objects;
+  hipLaunchKernelGGL(loop_tail_kernel, dim3((unsigned)n_objects), dim3(256), 0, (hipStream_t)stream, a);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -247,9 +247,14 @@ class ResidentInit:
     The empty-cloud check of :780-781 cannot raise before the launches it would prevent: ``empty_views()`` reads the
     counts afterwards (one small copy; the caller raises ``NoDepthError``)."""
 
-    def __init__(self, network: SDFPoseNet, camera: Camera, views: int, config: Dict, normalize_pose: bool = True):
+    def __init__(self, network: SDFPoseNet, camera: Camera, views: int, config: Dict, normalize_pose: bool = True,
+                 objects: bool = False):
+        """objects: the `views` images are `views` different OBJECTS seen from one camera (cam_pos / cam_quat hold one
+        row): every image gets its own estimate, ``self.params`` is (views, 8 + L) -- the initialisation of
+        ``pipeline.MultiObjectRenderAndCompare``; the "first" / "best" choice among views does not apply."""
         net = self.net = network
         self.cam, self.V = camera, int(views)
+        self.objects = bool(objects)
         self.dev, self.L = net.dev, net.L            # (L: the loaded library, as in SDFPoseNet)
         self.normalize_pose = bool(normalize_pose)
         self.mean_shape = bool(config.get("mean_shape", False))
@@ -306,7 +311,7 @@ class ResidentInit:
         self.index = torch.zeros(1, **i32)
         self.post_max = torch.zeros(1, **f32)
         self.best = torch.zeros(1, **f32)
-        self.params = torch.zeros(8 + net.shape_dimension, **f32)
+        self.params = torch.zeros((self.V, 8 + net.shape_dimension) if self.objects else (8 + net.shape_dimension,), **f32)
         self._graphs = {}
         self._host_counts = torch.zeros(self.V, dtype=torch.int32).pin_memory()
         self._counts_event = None
@@ -326,8 +331,9 @@ class ResidentInit:
         fx, fy, cx0, cy0, _ = self.cam.get_pinhole_camera_parameters(0.0)
         W, H, M = self.W, self.H, self.W * self.H
         ws = self.ws[(-self.ws.data_ptr()) % 16:]
-        views = range(self.V) if self.strategy == "best" else range(1)
-        if self.strategy == "best":
+        views = range(self.V) if (self.strategy == "best" or self.objects) else range(1)
+        best = self.strategy == "best" and not self.objects
+        if best:
             self.best.zero_()
         for v in views:
             img = depth[v]
@@ -381,9 +387,10 @@ class ResidentInit:
             _lib.check(L.sdfr_init_estimate(
                 head.data_ptr(), sd, self.grid_quats.data_ptr() if self.discretized else None,
                 self.index.data_ptr() if self.discretized else None,
-                self.centroid.data_ptr() if self.normalize_pose else None, cam_pos[v].data_ptr(), cam_quat[v].data_ptr(),
-                int(self.mean_shape), int(self.strategy == "best"), self.post_max.data_ptr(), self.best.data_ptr(),
-                self.params.data_ptr(), d, st), "sdfr_init_estimate")
+                self.centroid.data_ptr() if self.normalize_pose else None,
+                cam_pos[0 if self.objects else v].data_ptr(), cam_quat[0 if self.objects else v].data_ptr(),
+                int(self.mean_shape), int(best), self.post_max.data_ptr(), self.best.data_ptr(),
+                (self.params[v] if self.objects else self.params).data_ptr(), d, st), "sdfr_init_estimate")
 
     def __call__(self, depth: torch.Tensor, cam_pos: torch.Tensor, cam_quat: torch.Tensor,
                  prior_orientation_distribution: Optional[torch.Tensor] = None,
@@ -422,6 +429,8 @@ class ResidentInit:
         self._counts_event.record(torch.cuda.current_stream(self.dev))
         sd = self.net.shape_dimension
         p = self.params
+        if self.objects:
+            return p[:, 8:8 + sd], p[:, 0:3], p[:, 7], p[:, 3:7]
         return p[8:8 + sd][None], p[0:3][None], p[7:8], p[3:7][None]
 
     def empty_views(self):
@@ -430,5 +439,5 @@ class ResidentInit:
         if self._counts_event is None:
             return []
         self._counts_event.synchronize()
-        n = self.V if self.strategy == "best" else 1
+        n = self.V if (self.strategy == "best" or self.objects) else 1
         return [v for v in range(n) if int(self._host_counts[v]) == 0]

@@ -1034,3 +1034,196 @@ class FusedRenderAndCompare:
             return None
         bp = self.best_params
         return ratio, int(it), (bp[0:3].clone()[None], bp[3:7].clone()[None], bp[7:8].clone(), bp[8:].clone()[None])
+
+
+class MultiObjectRenderAndCompare:
+    """K estimates optimised SIDE BY SIDE: the K detected objects of one frame -- each with its own depth image (the
+    frame masked by the object's instance mask), pose, scale, latent and Adam state -- go through ONE launch sequence
+    per iteration.  The reference calls its pipeline once per object, one after the other (simple_setup.py:213-225), and
+    a single estimate's iteration is a chain of ~17 dependent launches that leaves most of an MI355X idle (C5: 0.12 ms
+    per iteration whatever the object); here the decoder runs on K latents at once, the renderer and the sampler on K
+    views with one SDF each (``sdf_view_stride = R^3``), the decoder's VJP on the K gradient volumes, and the tail is K
+    workgroups (``sdfr_loop_tail_objects``).  Same arithmetic per object as :class:`FusedRenderAndCompare` (one view per
+    object, no point constraint, no inlier bookkeeping, "last_iteration" results); the objects share the camera.
+
+    Everything is allocated here; ``rebind`` takes the next frame's K images (point clouds at capacity, counts on the
+    device); ``__call__`` replays captured graphs."""
+
+    def __init__(self, decoder, camera: Camera, config: Dict, objects: int, shape_optimization: bool = True,
+                 device="cuda", graph_iterations: int = 5):
+        from . import _lib
+        from .differentiable_renderer import BatchRenderPlan
+        self.L, self.check = _lib.lib(), _lib.check
+        self.dec, self.cam, self.cfg = decoder, camera, config
+        self.dev = torch.device(device)
+        if self.dev.index is None:
+            self.dev = torch.device("cuda", torch.cuda.current_device())
+        K = self.K = int(objects)
+        if K < 1:
+            raise ValueError("objects must be >= 1")
+        self.shape_opt = bool(shape_optimization)
+        self.graph_iterations = max(1, int(graph_iterations))
+        H, W = int(camera.height), int(camera.width)
+        self.H, self.W = H, W
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        i32 = dict(dtype=torch.int32, device=self.dev)
+        u8 = dict(dtype=torch.uint8, device=self.dev)
+        R = self.R = decoder._volume_size
+        self.Lz = decoder.latent_size
+        n = self.n = 8 + self.Lz
+        if n > 256:
+            raise ValueError("the tail handles parameter vectors of up to 256 entries")
+        self.params = torch.zeros((K, n), **f32)
+        self._zeroed = torch.zeros((3, K, n), **f32)          # Adam's moments and the gradients: one fill resets a run
+        self.m, self.v, self.grads = self._zeroed[0], self._zeroed[1], self._zeroed[2]
+        self.step = torch.zeros(K, **i32)
+        self.z = torch.zeros((K, self.Lz), **f32)             # the latents, packed for the decoder
+        self.g_z = torch.zeros((K, self.Lz), **f32)
+        self.cam_pos = torch.zeros((1, 3), **f32)
+        self.cam_quat = torch.tensor([[0.0, 0.0, 0.0, 1.0]], **f32)
+        self.target = torch.zeros((K, H, W), **f32)
+        self.max_pts = W * H
+        self.points = torch.zeros((K * W * H, 3), **f32)
+        self.offsets = torch.zeros(K + 1, **i32)
+        self.counts = torch.zeros(K, **i32)
+        self.ws_points = torch.empty(max(self.L.sdfr_depth_points_workspace_bytes(K, W, H), 256), **u8)
+        self.plan = BatchRenderPlan(R, K, camera, device=self.dev, per_view_sdf=True, close_views=False)
+        self.pos_c = torch.empty((K, 3), **f32)
+        self.quat_c = torch.empty((K, 4), **f32)
+        self.inv_scale = torch.empty((K,), **f32)
+        self.scale_v = torch.empty((K,), **f32)
+        self.loss_pc = torch.zeros((K,), **f32)
+        self.sdf = torch.empty((K, 1, R, R, R), **f32)
+        self.tape = torch.empty(max(self.L.sdfr_decoder_tape_bytes(decoder._h, K), 256), **u8)
+        self.ws_dec = torch.empty(max(self.L.sdfr_decoder_workspace_bytes(decoder._h, K),
+                                      self.L.sdfr_decoder_backward_workspace_bytes(decoder._h, K), 256), **u8)
+        self.ws_pc = torch.empty(max(self.L.sdfr_pc_loss_backward_workspace_bytes(K, self.max_pts), 256), **u8)
+        self.defer_loss = K < 32
+        self.graph = self.graph_many = None
+        self.bound = False
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def rebind(self, depth_images: torch.Tensor, camera_position: Optional[torch.Tensor] = None,
+               camera_orientation: Optional[torch.Tensor] = None, masks: Optional[torch.Tensor] = None,
+               far_field: Optional[float] = None) -> "MultiObjectRenderAndCompare":
+        """depth_images (K,H,W): one image per object (``masks`` / ``far_field``: preprocessed in place on the way,
+        simple_setup.py:671-693).  camera_position (3,) / camera_orientation (4,): the one camera all objects are seen
+        from (default: the origin)."""
+        if tuple(depth_images.shape) != (self.K, self.H, self.W):
+            raise ValueError(f"depth_images must have shape {(self.K, self.H, self.W)}, got {tuple(depth_images.shape)}")
+        with torch.no_grad():
+            if masks is not None or far_field is not None:
+                preprocess_depth(depth_images, masks, far_field, copy_to=(self.target, 0, self.K))
+            else:
+                self.target.copy_(depth_images)
+            if camera_position is None:
+                self.cam_pos.zero_()
+            else:
+                self.cam_pos.copy_(camera_position.reshape(1, 3))
+            if camera_orientation is None:
+                self.cam_quat.copy_(torch.tensor([[0.0, 0.0, 0.0, 1.0]]))
+            else:
+                self.cam_quat.copy_(camera_orientation.reshape(1, 4))
+            fx, fy, cx0, cy0, _ = self.cam.get_pinhole_camera_parameters(0.0)
+            self.check(self.L.sdfr_depth_to_points_resident(
+                self.target.data_ptr(), self.K, self.W, self.H, 1, 1.0 / fx, 1.0 / fy, cx0, cy0, self.counts.data_ptr(),
+                self.offsets.data_ptr(), self.ws_points.data_ptr(), self.ws_points.numel(), self.points.data_ptr(),
+                self.dev.index, self._stream()), "sdfr_depth_to_points_resident")
+        self.bound = True
+        return self
+
+    def _decode(self, st, with_tape):
+        self.z.copy_(self.params[:, 8:])
+        self.check(self.L.sdfr_decoder_forward(self.dec._h, self.z.data_ptr(), self.K, 0, self.sdf.data_ptr(),
+                                               self.tape.data_ptr() if with_tape else None, self.ws_dec.data_ptr(),
+                                               self.ws_dec.numel(), st), "sdfr_decoder_forward")
+
+    def _poses_to_views(self, st):
+        """every object's pose in the camera's frame (simple_setup.py:411, :424-430): one call per object would be K
+        launches, the tail does it for the NEXT iteration; here, once per run, the single-estimate kernel per object"""
+        for k in range(self.K):
+            p = self.params[k].data_ptr()
+            self.check(self.L.sdfr_pose_to_views(p, p + 12, p + 28, self.cam_pos.data_ptr(), self.cam_quat.data_ptr(), 1,
+                                                 self.pos_c[k].data_ptr(), self.quat_c[k].data_ptr(),
+                                                 self.inv_scale[k:].data_ptr(), self.scale_v[k:].data_ptr(),
+                                                 self.dev.index, st), "sdfr_pose_to_views")
+
+    def iteration(self):
+        L, d, st = self.L, self.dev.index, self._stream()
+        if self.shape_opt:
+            self._decode(st, True)
+        sdf = self.sdf[:, 0]
+        self.plan.forward_l1(sdf, self.pos_c, self.quat_c, self.inv_scale, self.cfg["threshold"], self.target,
+                             prepare_backward=True, defer_loss=self.defer_loss)
+        g_sdf = self.plan.backward_l1_pc(self.target, sdf, self.pos_c, self.quat_c, self.inv_scale, self.scale_v,
+                                         self.points, self.offsets, self.max_pts, self.ws_pc,
+                                         weight=self.cfg["depth_weight"], pc_weight=self.cfg["pc_weight"])
+        if self.shape_opt:
+            self.check(L.sdfr_decoder_backward_latent(self.dec._h, self.z.data_ptr(), self.tape.data_ptr(),
+                                                      g_sdf.data_ptr(), self.K, self.g_z.data_ptr(), self.ws_dec.data_ptr(),
+                                                      self.ws_dec.numel(), st), "sdfr_decoder_backward_latent")
+            self.grads[:, 8:].copy_(self.g_z)
+        self.check(L.sdfr_loop_tail_objects(
+            self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.step.data_ptr(),
+            self.n, self.K, 1e-3, 1e-2, 1e-3, 1e-2, int(self.shape_opt), self.cam_pos.data_ptr(), self.cam_quat.data_ptr(),
+            1, self.plan.workspace.data_ptr(), self.plan.partials_offset, self.W, self.H, self.ws_pc.data_ptr(),
+            self.offsets.data_ptr(), self.max_pts, self.pos_c.data_ptr(), self.quat_c.data_ptr(),
+            self.inv_scale.data_ptr(), self.scale_v.data_ptr(), self.loss_pc.data_ptr(), d, st), "sdfr_loop_tail_objects")
+
+    def view_losses(self):
+        """(depth loss, point-cloud loss) of every object in the last iteration, (K,) each"""
+        return self.plan.loss, self.loss_pc
+
+    def __call__(self, position, orientation, scale, latent, use_graph: bool = True, history: Optional[List] = None):
+        """position (K,3), orientation (K,4), scale (K,), latent (K,L): the initial estimates (or ``params=`` rows from
+        ResidentInit).  Returns the optimised (position (K,3), orientation (K,4), scale (K,), latent (K,L))."""
+        if not self.bound:
+            raise RuntimeError("no observation bound: call rebind(depth_images, ...) first")
+        K = self.K
+        with torch.no_grad():
+            self.params[:, 0:3] = position.reshape(K, 3)
+            self.params[:, 3:7] = orientation.reshape(K, 4)
+            self.params[:, 7] = scale.reshape(K)
+            self.params[:, 8:] = latent.reshape(K, self.Lz)
+            self._zeroed.zero_()
+            self.step.zero_()
+        st = self._stream()
+        if not self.shape_opt:
+            self._decode(st, False)
+        self._poses_to_views(st)
+        n_iter = self.cfg["max_iterations"]
+        if use_graph and self.graph is None:
+            saved = [t.clone() for t in (self.params, self._zeroed, self.step)]
+            side = torch.cuda.Stream(self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                self.iteration()
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.iteration()
+            if self.graph_iterations > 1:
+                self.graph_many = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_many):
+                    for _ in range(self.graph_iterations):
+                        self.iteration()
+            for t, c in zip((self.params, self._zeroed, self.step), saved):
+                t.copy_(c)
+            self._poses_to_views(self._stream())     # (the warm-up's tail left the poses of ITS updated parameters)
+        done = 0
+        if use_graph and history is None and self.graph_many is not None:
+            for _ in range(n_iter // self.graph_iterations):
+                self.graph_many.replay()
+            done = n_iter - n_iter % self.graph_iterations
+        for _ in range(n_iter - done):
+            if use_graph:
+                self.graph.replay()
+            else:
+                self.iteration()
+            if history is not None:
+                ld, lp = self.view_losses()
+                history.append({"loss_depth": ld.clone(), "loss_pc": lp.clone(), "params": self.params.clone()})
+        p = self.params
+        return p[:, 0:3].clone(), p[:, 3:7].clone(), p[:, 7].clone(), p[:, 8:].clone()

@@ -25,7 +25,7 @@ import torch
 
 from .differentiable_renderer import Camera, render_depth_gpu
 from .init_network import NoDepthError, ResidentInit, SDFPoseNet, adjust_categorical_posterior, nn_init
-from .pipeline import FusedRenderAndCompare, _selection_strategy, preprocess_depth
+from .pipeline import FusedRenderAndCompare, MultiObjectRenderAndCompare, _selection_strategy, preprocess_depth
 from .vae import SDFDecoder
 
 __all__ = ["SDFPipeline", "NoDepthError"]
@@ -99,6 +99,7 @@ class SDFPipeline:
         # (init_network.ResidentInit) where its architecture allows; False: the host-driven nn_init (two host reads)
         self._resident_wanted = bool(resident_init)
         self._residents = {}
+        self._multi_loops, self._resident_objects = {}, {}     # estimate_objects: per (K, shape_optimization) / per K
         self._ignored_warned = False
 
     def _parse_config(self, config: Dict) -> None:
@@ -228,6 +229,61 @@ class SDFPipeline:
         # updating in place: the last iterate as well (pipeline._BestEstimate); the snapshot at the best ratio is
         # self.best_estimate()
         return position, orientation, scale, latent_shape
+
+    def estimate_objects(self, depth_image: torch.Tensor, masks: torch.Tensor,
+                         camera_position: Optional[torch.Tensor] = None,
+                         camera_orientation: Optional[torch.Tensor] = None, shape_optimization: bool = True,
+                         prior_orientation_distribution: Optional[torch.Tensor] = None,
+                         training_orientation_distribution: Optional[torch.Tensor] = None) -> tuple:
+        """The K detected objects of ONE frame at once: what a caller of the reference does with a loop of K
+        ``pipeline(depth, mask_k, color)`` calls (one per instance mask), as one call whose K estimates are optimised side
+        by side (``pipeline.MultiObjectRenderAndCompare``: one launch sequence per iteration for all of them).
+
+        depth_image (H,W): the frame (NOT modified: every object gets its own masked copy); masks (K,H,W) bool: the
+        instance masks; camera_position (3,) / camera_orientation (4,): the camera in the world (default: the origin);
+        prior_orientation_distribution (K,C) / training_orientation_distribution (C,): as in ``__call__``, one row per
+        object.  Returns position (K,3), orientation (K,4), scale (K,), latent (K,L) -- row k is what
+        ``pipeline(depth, masks[k], color)`` estimates for object k (same arithmetic; `result_selection_strategy`
+        "last_iteration")."""
+        dev = self._dev
+        if depth_image.dim() != 2 or masks.dim() != 3 or tuple(masks.shape[1:]) != tuple(depth_image.shape):
+            raise ValueError("depth_image (H,W) and masks (K,H,W) are expected")
+        K = int(masks.shape[0])
+        key = (K, bool(shape_optimization))
+        loop = self._multi_loops.get(key)
+        if loop is None:
+            loop = self._multi_loops[key] = MultiObjectRenderAndCompare(self.vae, self.cam, self.config, K,
+                                                                        shape_optimization=shape_optimization, device=dev)
+        with torch.no_grad():
+            frames = depth_image.to(device=dev, dtype=torch.float32)[None].expand(K, -1, -1).contiguous()
+            loop.rebind(frames, camera_position, camera_orientation, masks=masks, far_field=self._far_field)
+            resident = None
+            if self._resident_wanted and self._nn_init_override is None and isinstance(self.init_network, SDFPoseNet):
+                if K not in self._resident_objects:
+                    try:
+                        self._resident_objects[K] = ResidentInit(
+                            self.init_network, self.cam, K, dict(self.config, init_view="first"),
+                            normalize_pose=bool(self.init_config.get("normalize_pose", False)), objects=True)
+                    except NotImplementedError:
+                        self._resident_objects[K] = None
+                resident = self._resident_objects[K]
+            if resident is not None:
+                latent, position, scale, orientation = resident(loop.target, loop.cam_pos, loop.cam_quat,
+                                                                prior_orientation_distribution,
+                                                                training_orientation_distribution)
+            else:     # the host-driven form, object by object
+                rows = []
+                for k in range(K):
+                    prior = prior_orientation_distribution[k:k + 1] if prior_orientation_distribution is not None else None
+                    rows.append(self._nn_init(loop.target[k:k + 1], loop.cam_pos, loop.cam_quat, prior,
+                                              training_orientation_distribution))
+                latent, position, scale, orientation = (torch.cat([r[i].reshape(1, -1) for r in rows]) for i in range(4))
+                scale = scale.reshape(K)
+            out = loop(position, orientation, scale, latent)
+            if resident is not None and resident.empty_views():
+                raise NoDepthError
+        self._last_multi_loop = loop
+        return out
 
     def prepare(self, views: int = 1, shape_optimization: bool = True) -> "SDFPipeline":
         """Optional: build the loop for `views` images and capture its graphs NOW (on an empty observation) instead of

@@ -440,6 +440,40 @@ def front_door_times(sc, others):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+def objects_side_by_side(sc):
+    """K objects of one frame optimised in ONE launch sequence per iteration (MultiObjectRenderAndCompare) against the
+    reference's one pipeline call per object: frames per second and objects per second, 50 iterations each, the C5
+    image as every object's observation."""
+    try:
+        from sdfest_amd.pipeline import MultiObjectRenderAndCompare
+        p0, q0, s0, z0 = sc["init"]
+        rows = []
+        for K in (4, 8, 32):
+            multi = MultiObjectRenderAndCompare(sc["decoder"], sc["camera"], sc["config"], K)
+            frames = sc["targets"].expand(K, -1, -1).contiguous()
+            args = (p0.expand(K, 3).contiguous(), q0.expand(K, 4).contiguous(), s0.expand(K).contiguous(),
+                    z0.expand(K, z0.shape[-1]).contiguous())
+            multi.rebind(frames)
+            multi(*args)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                multi.rebind(frames)
+                out = multi(*args)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            t = float(np.median(ts))
+            rows.append({"objects": K, "ms_per_frame": round(t * 1e3, 3), "ms_per_object": round(t / K * 1e3, 3),
+                         "objects_per_s": round(K / t, 1), "ms_per_iteration": round(t / sc["config"]["max_iterations"] * 1e3, 4),
+                         "worst_final_position_error_mm": round(float((out[0] - sc["p_true"]).norm(dim=1).max()) * 1e3, 3)})
+            del multi
+            torch.cuda.empty_cache()
+        return rows
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def c5_config(hbm_peak):
     """C5: the whole render-and-compare loop (simple_setup.py:408-470) as one hipGraph per iteration, 50 Adam
     iterations, mug decoder; ms per iteration, the final pose error, and TIME TO RESULT the way the reference is used
@@ -488,6 +522,7 @@ def c5_config(hbm_peak):
         rebinds.append((t1 - t0) * 1e3)
     assert fused.graph is graph     # nothing was captured again
     front_door = front_door_times(sc, others)
+    side_by_side = objects_side_by_side(sc)
     q = out[1] / out[1].norm()
     dot = float(torch.abs((q * sc["q_true"]).sum()).clamp(max=1.0))
     # algorithmic bytes of one iteration: render fwd+bwd of one view + decoder weights + volume
@@ -500,6 +535,7 @@ def c5_config(hbm_peak):
             "ms_new_observation_all": [round(t, 3) for t in totals],
             "ms_rebind_host": round(float(np.median(rebinds)), 3),
             "front_door": front_door,
+            "objects_side_by_side": side_by_side,
             "time_to_result": "ms_first_call_total = constructor (buffers at capacity) + warm-up iteration + graph "
                               "captures + 50 iterations, first use of these kernels in the process; "
                               "ms_new_observation_total = rebind(new 640x480 image already in HBM) + 50 iterations "
