@@ -53,7 +53,7 @@
  *   3. LOOP: one render-and-compare iteration (SDFPipeline.__call__) as a fixed launch sequence
  *        sdfr_preprocess_depth, sdfr_depth_to_points_resident, sdfr_depth_count[_ordered|_centroid],
  *        sdfr_depth_to_points[_ordered|_shifted], sdfr_depth_points_workspace_bytes, sdfr_depth_centroid_workspace_bytes
- *        sdfr_pose_to_views, sdfr_views_to_pose_grad[_deferred], sdfr_decoder_backward_latent_deferred,
+ *        sdfr_pose_to_views[_objects], sdfr_views_to_pose_grad[_deferred], sdfr_decoder_backward_latent_deferred,
  *        sdfr_loop_tail, sdfr_loop_tail_objects, sdfr_adam_step, sdfr_point_constraint, sdfr_add_inplace
  *        sdfr_depth_l1_loss[_workspace_bytes], sdfr_pc_l1_loss, sdfr_inlier_ratio, sdfr_nn_loss_forward / _backward
  *        sharded over ranks: sdfr_loop_view_records, sdfr_loop_tail_records, sdfr_inlier_counts_record,
@@ -467,6 +467,11 @@ SDFR_API int sdfr_loop_tail(float* params, float* grads, float* exp_avg, float* 
  *   for the next iteration: all [K V ...]); cam_pos [V][3], cam_quat [V][4] are ONE camera list, the same for every object
  *   grads[k][8..] must hold d loss / d latent of object k (sdfr_decoder_backward_latent with N = K); no point constraint,
  *   no deferred decoder stage.  Same arithmetic per object, in the same order, as sdfr_loop_tail. */
+/* sdfr_pose_to_views for the K rows of `params` ([K][n_params]: position 3 | orientation 4 | scale 1 | ...) and one camera
+ * list: view k V + v of the outputs is object k seen from camera v. */
+SDFR_API int sdfr_pose_to_views_objects(const float* params, int n_params, int n_objects, const float* cam_pos,
+                               const float* cam_quat, int V, float* pos_c, float* quat_c, float* inv_scale,
+                               float* scale_v, int device, void* stream);
 SDFR_API int sdfr_loop_tail_objects(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int* step, int n_params,
                            int n_objects, float lr_position, float lr_orientation, float lr_scale, float lr_latent,
                            int update_latent, const float* cam_pos, const float* cam_quat, int V,

@@ -39,6 +39,7 @@ SIGNATURES = {
     "sdfr_loop_tail": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_f, c_f, c_f, c_f, c_int, c_fp, c_fp, c_int,
                                c_fp, c_sz, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                c_f, c_fp, c_fp, c_fp, c_int, c_fp]),
+    "sdfr_pose_to_views_objects": (c_int, [c_fp, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp]),
     "sdfr_loop_tail_objects": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_f, c_f, c_f, c_f, c_int, c_fp, c_fp,
                                        c_int, c_fp, c_sz, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp,
                                        c_int, c_fp]),

@@ -76,6 +76,21 @@ __global__ void pose_to_views_kernel(const float* __restrict__ position,
   if (v < V) pose_to_view(v, position, orientation, scale, cam_pos, cam_quat, pos_c, quat_c, inv_scale, scale_v);
 }
 
+// the same for K estimates (rows of `params`, `n` floats each: position 3 | orientation 4 | scale 1 | ...) seen from
+// ONE camera list: the launch's view k V + v is object k from camera v (sdfr_loop_tail_objects' layout)
+__global__ void pose_to_views_objects_kernel(const float* __restrict__ params, int n, int K,
+                                             const float* __restrict__ cam_pos, const float* __restrict__ cam_quat,
+                                             int V, float* __restrict__ pos_c, float* __restrict__ quat_c,
+                                             float* __restrict__ inv_scale, float* __restrict__ scale_v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * V) return;
+  const int k = i / V, v = i - k * V;
+  const float* p = params + (size_t)k * n;
+  const float cp[3] = {cam_pos[3 * v], cam_pos[3 * v + 1], cam_pos[3 * v + 2]};
+  const float cq[4] = {cam_quat[4 * v], cam_quat[4 * v + 1], cam_quat[4 * v + 2], cam_quat[4 * v + 3]};
+  pose_to_view_core(i, p, p + 3, p + 7, cp, cq, pos_c, quat_c, inv_scale, scale_v);
+}
+
 // one thread: sum the per-view gradients back to the world-frame parameters
 __global__ void views_to_pose_grad_kernel(const float* __restrict__ orientation,
                                           const float* __restrict__ scale,
@@ -725,18 +740,24 @@ __global__ __launch_bounds__(256) void loop_tail_kernel(LoopTailArgs a_in) {
   __shared__ float p_cur[256];    // the parameters of this iteration ...
   __shared__ float p_new[256];    // ... and after the Adam step
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  LoopTailArgs a = a_in;
-  const int view_base = (int)blockIdx.x * a.V;     // (0 for the single estimate)
-  if (a.n_obj > 1) {
-    const size_t o = (size_t)blockIdx.x * a.n;
-    a.params += o; a.grads += o; a.m += o; a.v += o; a.step += blockIdx.x;
-    a.pos_c += 3 * view_base; a.quat_c += 4 * view_base; a.inv_scale += view_base; a.scale_v += view_base;
-  }
+  const LoopTailArgs& a = a_in;
+  // (the object's own slices as plain locals: a modified copy of the argument block would live in scratch memory)
+  const int view_base = a.n_obj > 1 ? (int)blockIdx.x * a.V : 0;
+  const size_t obj_o = a.n_obj > 1 ? (size_t)blockIdx.x * a.n : 0;
+  float* const params = a.params + obj_o;
+  float* const grads = a.grads + obj_o;
+  float* const mom1 = a.m + obj_o;
+  float* const mom2 = a.v + obj_o;
+  int* const step = a.step + (a.n_obj > 1 ? blockIdx.x : 0);
+  float* const pos_c = a.pos_c + 3 * view_base;
+  float* const quat_c = a.quat_c + 4 * view_base;
+  float* const inv_scale = a.inv_scale + view_base;
+  float* const scale_v = a.scale_v + view_base;
   SDFR_STAMP(0);
   const bool mine = tid < a.n;
-  const float p_old = mine ? a.params[tid] : 0.0f, m_old = mine ? a.m[tid] : 0.0f, v_old = mine ? a.v[tid] : 0.0f;
-  const int step_old = a.step[0];
-  const float g_given = (mine && tid >= 8 && !a.t_mid) ? a.grads[tid] : 0.0f;   // the latent's gradient is the caller's
+  const float p_old = mine ? params[tid] : 0.0f, m_old = mine ? mom1[tid] : 0.0f, v_old = mine ? mom2[tid] : 0.0f;
+  const int step_old = step[0];
+  const float g_given = (mine && tid >= 8 && !a.t_mid) ? grads[tid] : 0.0f;   // the latent's gradient is the caller's
   float cp[3] = {0, 0, 0}, cq[4] = {0, 0, 0, 1};
   if (tid < a.V) {
     cp[0] = a.cam_pos[3 * tid]; cp[1] = a.cam_pos[3 * tid + 1]; cp[2] = a.cam_pos[3 * tid + 2];
@@ -749,23 +770,23 @@ __global__ __launch_bounds__(256) void loop_tail_kernel(LoopTailArgs a_in) {
   }
   const bool fc_wave = a.t_mid && a.fc_one_wave;
   if (a.t_mid && !fc_wave) {   // d loss / d latent (g[8 ...]) from the gradient w.r.t. the wide Linear layer's input
-    fc_stack_backward_sample(a.dec_params, a.fc, a.params + 8, a.t_mid, g_l + 8);
+    fc_stack_backward_sample(a.dec_params, a.fc, params + 8, a.t_mid, g_l + 8);
     __syncthreads();
   }
-  if (fc_wave && wave == 0) fc_stack_backward_one_wave(a.dec_params, a.fc, a.params + 8, a.t_mid, g_l + 8, lane);
+  if (fc_wave && wave == 0) fc_stack_backward_one_wave(a.dec_params, a.fc, params + 8, a.t_mid, g_l + 8, lane);
   // (only now: an LDS store of a loaded value waits for the load, and the Linear stack's loads should not queue
   // behind that wait)
   if (mine) p_cur[tid] = p_old;
   if (mine && tid >= 8 && !a.t_mid) g_l[tid] = g_given;
   SDFR_STAMP(1);
   if (a.records) {
-    pose_chain_block(a.params + 3, a.params + 7, a.cam_quat_all, a.V_all, a.records, kViewRecord, g_l, g_l + 3,
+    pose_chain_block(params + 3, params + 7, a.cam_quat_all, a.V_all, a.records, kViewRecord, g_l, g_l + 3,
                      g_l + 7);
   } else {
-    // (a.quat_c has been advanced to this object's views; the chain indexes the launch's views: undo it there)
+    // (the chain indexes the LAUNCH's views: the un-advanced quat_c / pc_loss and the object's first view)
     deferred_chain(p_cur + 3, p_cur + 7, a.cam_quat, a.V, a.setup, a.tile_part, a.W, a.H, a.ntx, a.nty,
                    a.tile_w, a.tile_h, a.stride, a.pc_part, a.pc_loss_part, a.offsets, a.n_single, a.nblk,
-                   a_in.quat_c, a.pc_loss, g_l, g_l + 3, g_l + 7, a.n_obj > 1 ? view_base : 0);
+                   a.quat_c, a.pc_loss, g_l, g_l + 3, g_l + 7, view_base);
   }
   SDFR_STAMP(2);
   if (tid == 0 && a.con_source)   // (p_cur: thread 0 has passed a barrier of the chain above since it was written)
@@ -778,17 +799,17 @@ __global__ __launch_bounds__(256) void loop_tail_kernel(LoopTailArgs a_in) {
   __syncthreads();   // the updated parameters are visible to the pose chain
   SDFR_STAMP(4);
   if (tid < a.V)
-    pose_to_view_core(tid, p_new, p_new + 3, p_new + 7, cp, cq, a.pos_c, a.quat_c, a.inv_scale, a.scale_v);
+    pose_to_view_core(tid, p_new, p_new + 3, p_new + 7, cp, cq, pos_c, quat_c, inv_scale, scale_v);
   for (int v = tid + 256; v < a.V; v += 256)
-    pose_to_view(v, p_new, p_new + 3, p_new + 7, a.cam_pos, a.cam_quat, a.pos_c, a.quat_c, a.inv_scale, a.scale_v);
+    pose_to_view(v, p_new, p_new + 3, p_new + 7, a.cam_pos, a.cam_quat, pos_c, quat_c, inv_scale, scale_v);
   // the stores nothing in this launch waits for
   if (mine) {
-    a.grads[tid] = g_l[tid];
-    a.params[tid] = p_i;
-    a.m[tid] = m_i;
-    a.v[tid] = v_i;
+    grads[tid] = g_l[tid];
+    params[tid] = p_i;
+    mom1[tid] = m_i;
+    mom2[tid] = v_i;
   }
-  if (tid == 0) a.step[0] = step_old + 1;
+  if (tid == 0) step[0] = step_old + 1;
   SDFR_STAMP(5);
 }
 
@@ -1082,6 +1103,22 @@ extern "C" int sdfr_pose_to_views(const float* position, const float* orientatio
   SDFR_HIP_TRY(hipSetDevice(device));
   hipLaunchKernelGGL(pose_to_views_kernel, dim3((V + 63) / 64), dim3(64), 0, (hipStream_t)stream, position,
                      orientation, scale, cam_pos, cam_quat, V, pos_c, quat_c, inv_scale, scale_v);
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfr_pose_to_views_objects(const float* params, int n_params, int n_objects, const float* cam_pos,
+                                          const float* cam_quat, int V, float* pos_c, float* quat_c, float* inv_scale,
+                                          float* scale_v, int device, void* stream) {
+  if (V < 0 || n_objects < 0 || n_params < 8 || (long long)V * n_objects > 0x7fffffffLL)
+    return fail(SDFR_E_INVALID, "sdfr_pose_to_views_objects: bad sizes V=%d objects=%d n_params=%d", V, n_objects, n_params);
+  if (V == 0 || n_objects == 0) return 0;
+  if (!params || !cam_pos || !cam_quat || !pos_c || !quat_c || !inv_scale || !scale_v)
+    return fail(SDFR_E_NULL, "sdfr_pose_to_views_objects: NULL pointer argument");
+  SDFR_HIP_TRY(hipSetDevice(device));
+  const int total = V * n_objects;
+  hipLaunchKernelGGL(pose_to_views_objects_kernel, dim3((total + 63) / 64), dim3(64), 0, (hipStream_t)stream, params,
+                     n_params, n_objects, cam_pos, cam_quat, V, pos_c, quat_c, inv_scale, scale_v);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -1141,14 +1141,12 @@ class MultiObjectRenderAndCompare:
                                                self.ws_dec.numel(), st), "sdfr_decoder_forward")
 
     def _poses_to_views(self, st):
-        """every object's pose in the camera's frame (simple_setup.py:411, :424-430): one call per object would be K
-        launches, the tail does it for the NEXT iteration; here, once per run, the single-estimate kernel per object"""
-        for k in range(self.K):
-            p = self.params[k].data_ptr()
-            self.check(self.L.sdfr_pose_to_views(p, p + 12, p + 28, self.cam_pos.data_ptr(), self.cam_quat.data_ptr(), 1,
-                                                 self.pos_c[k].data_ptr(), self.quat_c[k].data_ptr(),
-                                                 self.inv_scale[k:].data_ptr(), self.scale_v[k:].data_ptr(),
-                                                 self.dev.index, st), "sdfr_pose_to_views")
+        """every object's pose in the camera's frame (simple_setup.py:411, :424-430), once per run: the tail leaves the
+        NEXT iteration's"""
+        self.check(self.L.sdfr_pose_to_views_objects(
+            self.params.data_ptr(), self.n, self.K, self.cam_pos.data_ptr(), self.cam_quat.data_ptr(), 1,
+            self.pos_c.data_ptr(), self.quat_c.data_ptr(), self.inv_scale.data_ptr(), self.scale_v.data_ptr(),
+            self.dev.index, st), "sdfr_pose_to_views_objects")
 
     def iteration(self):
         L, d, st = self.L, self.dev.index, self._stream()
