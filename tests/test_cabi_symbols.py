@@ -137,3 +137,59 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
                 assert "sdfr_oracle" not in src, f
+
+
+def test_round5_entry_points_validate_their_arguments_without_gpu(libpath):
+    """the entry points added in round 5 (the re-bindable loop, the front door, the loss-fused step, K objects side by
+    side, per-handle options): argument errors are reported before any HIP call"""
+    from sdfest_amd import _lib
+    L = _lib.lib()
+    buf = (ctypes.c_float * 64)()
+    q = ctypes.cast(buf, ctypes.c_void_p)   # a non-NULL pointer that is never dereferenced
+    err = lambda: L.sdfr_last_error()
+    # SDFPipeline._preprocess_depth
+    assert L.sdfr_preprocess_depth(q, q, -1, 8, 8, 1.0, 1, None, 0, None) == -1 and b"negative" in err()
+    assert L.sdfr_preprocess_depth(q, None, 1, 8, 8, 1.0, 1, None, 0, None) == -2
+    assert L.sdfr_preprocess_depth(None, None, 0, 8, 8, 1.0, 1, None, 0, None) == 0        # nothing to do
+    # depth -> points without a host round trip
+    assert L.sdfr_depth_to_points_resident(q, 1, 8, 8, 7, 1.0, 1.0, 4.0, 4.0, q, q, q, 1 << 20, q, 0, None) == -1
+    assert b"point order" in err()
+    assert L.sdfr_depth_to_points_resident(q, 70000, 8, 8, 0, 1.0, 1.0, 4.0, 4.0, q, q, q, 1 << 20, q, 0, None) == -1
+    assert L.sdfr_depth_to_points_resident(q, 1, 8, 8, 0, 1.0, 1.0, 4.0, 4.0, None, q, q, 1 << 20, q, 0, None) == -2
+    assert L.sdfr_depth_to_points_resident(None, 0, 8, 8, 0, 1.0, 1.0, 4.0, 4.0, None, None, None, 0, None, 0, None) == 0
+    # the loss-fused step
+    rc = L.sdfr_render_step_backward_l1(None, 1.0, None, q, q, q, 64, 0, 2, 8, 8, 4.0, 4.0, 4.0, 4.0, 0, q, 0, q, q, q,
+                                        q, 1 << 30, None, None, 0, None)
+    assert rc == -2 and b"loss_stats" in err()
+    rc = L.sdfr_render_step_forward_l1(q, 64, 0, q, q, q, 1, 8, 8, 4.0, 4.0, 8.0, 8.0, 0.0, q, q, q, None, q, 0, q,
+                                       1 << 30, None, 0, None)
+    assert rc == -2 and b"both, or neither" in err()                                        # loss without loss_stats
+    rc = L.sdfr_render_step_forward_l1(q, 64, 0, q, q, q, 1, 8, 8, 4.0, 4.0, 8.0, 8.0, 0.0, q, q, None, None, q, 0, q,
+                                       1 << 30, ctypes.c_void_p(4), 0, None)
+    assert rc == -1 and b"8-byte aligned" in err()
+    # per-handle kernel forms
+    assert L.sdfr_decoder_set_option(None, 0, 1) == -2
+    # K estimates side by side
+    rc = L.sdfr_loop_tail_objects(q, q, q, q, q, 16, 0, 1e-3, 1e-2, 1e-3, 1e-2, 1, q, q, 1, None, 0, 0, 0, None, None, 0,
+                                  q, q, q, q, None, 0, None)
+    assert rc == -1 and b"n_objects" in err()
+    rc = L.sdfr_loop_tail_objects(q, q, q, q, q, 16, 4, 1e-3, 1e-2, 1e-3, 1e-2, 1, q, q, 65, None, 0, 0, 0, None, None, 0,
+                                  q, q, q, q, None, 0, None)
+    assert rc == -1 and b"V=65" in err()
+    rc = L.sdfr_loop_tail_objects(q, q, q, q, q, 300, 4, 1e-3, 1e-2, 1e-3, 1e-2, 1, q, q, 1, None, 0, 0, 0, None, None, 0,
+                                  q, q, q, q, None, 0, None)
+    assert rc == -1 and b"n_params" in err()
+    rc = L.sdfr_loop_tail_objects(q, q, q, q, None, 16, 4, 1e-3, 1e-2, 1e-3, 1e-2, 1, q, q, 1, None, 0, 0, 0, None, None,
+                                  0, q, q, q, q, None, 0, None)
+    assert rc == -2
+    assert L.sdfr_pose_to_views_objects(q, 4, 2, q, q, 1, q, q, q, q, 0, None) == -1        # n_params < 8
+    assert L.sdfr_pose_to_views_objects(None, 16, 2, q, q, 1, q, q, q, q, 0, None) == -2
+    assert L.sdfr_pose_to_views_objects(None, 16, 0, q, q, 1, q, q, q, q, 0, None) == 0
+    # the initialisation network with the point count on the device
+    assert L.sdfr_pointnet_layer_counted(q, None, 64, 3, 3, q, 3, q, q, q, None, q, 8, 8, q, 0, None) == -2
+    assert b"row_count" in err()
+    assert L.sdfr_pointnet_layer_counted(q, q, 0, 3, 3, q, 3, q, q, q, None, q, 8, 8, q, 0, None) == -1
+    assert L.sdfr_init_estimate(None, 8, None, None, None, q, q, 0, 0, None, None, q, 0, None) == -2
+    assert L.sdfr_init_estimate(q, 8, q, None, None, q, q, 0, 0, None, None, q, 0, None) == -2     # a table needs an index
+    assert L.sdfr_init_estimate(q, 8, None, None, None, q, q, 0, 1, None, None, q, 0, None) == -2  # "best" needs its state
+    assert L.sdfr_init_estimate(q, 5000, None, None, None, q, q, 0, 0, None, None, q, 0, None) == -1

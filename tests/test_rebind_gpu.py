@@ -195,3 +195,35 @@ def test_preprocess_depth_is_the_torch_expression_bit_for_bit():
         preprocess_depth(depth.cpu(), None, 1.0)
     with pytest.raises(RuntimeError):
         preprocess_depth(depth, torch.ones((4, 24, 31), dtype=torch.bool, device="cuda"))
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_resident_point_sets_equal_the_two_call_form(order):
+    """sdfr_depth_to_points_resident (counts and offsets on the device, points at capacity) against sdfr_depth_count_ordered
+    + host prefix + sdfr_depth_to_points_ordered: the same points in the same order, bit for bit -- ragged image sizes,
+    an empty view, a full view, both point orders"""
+    from sdfest_amd import Camera, _lib
+    from sdfest_amd.generated_views import depth_to_pointsets
+    L = _lib.lib()
+    rng = np.random.default_rng(31 + order)
+    for W, H, V in ((37, 29, 4), (640, 480, 3), (1030, 3, 2), (64, 16, 70)):
+        cam = Camera(W, H, 0.9 * W + 3.3, 1.1 * W + 1.7, 0.47 * W, 0.55 * H, pixel_center=0.5)
+        dd = rng.uniform(0.3, 2.0, (V, H, W)).astype(np.float32)
+        dd[rng.uniform(size=dd.shape) < 0.7] = 0
+        dd[1] = 0
+        if V > 2:
+            dd[2] = 1.0
+        depth = torch.tensor(dd, device="cuda")
+        ref_pts, ref_counts = depth_to_pointsets(depth, cam, tiled=bool(order))
+        fx, fy, cx0, cy0, _ = cam.get_pinhole_camera_parameters(0.0)
+        counts = torch.full((V,), -1, dtype=torch.int32, device="cuda")
+        offsets = torch.full((V + 1,), -1, dtype=torch.int32, device="cuda")
+        ws = torch.empty(max(L.sdfr_depth_points_workspace_bytes(V, W, H), 256), dtype=torch.uint8, device="cuda")
+        pts = torch.full((V * W * H, 3), float("nan"), device="cuda")
+        _lib.check(L.sdfr_depth_to_points_resident(depth.data_ptr(), V, W, H, order, 1.0 / fx, 1.0 / fy, cx0, cy0,
+                                                   counts.data_ptr(), offsets.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                   pts.data_ptr(), 0, torch.cuda.current_stream().cuda_stream), "resident")
+        assert counts.tolist() == ref_counts.tolist() == [(dd[v] != 0).sum() for v in range(V)]
+        assert offsets.tolist() == [0] + np.cumsum(ref_counts.cpu().numpy()).tolist()
+        n = int(offsets[-1])
+        assert torch.equal(pts[:n], ref_pts) and torch.isnan(pts[n:]).all()       # nothing written beyond the count
