@@ -419,6 +419,8 @@ class ResidentInit:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._sequence(depth, cam_pos, cam_quat, has_prior, has_train)
+                if len(self._graphs) >= 4:      # (a caller that hands other tensors every call: re-capture, no hoard)
+                    self._graphs.pop(next(iter(self._graphs)))
                 self._graphs[key] = g
             g.replay()
         else:

@@ -545,6 +545,10 @@ class FusedRenderAndCompare:
         return self
 
     def _keep_graphs(self):
+        # (at most 4 sets: a caller whose constraint weight changes from call to call re-captures instead of
+        # collecting graphs without bound)
+        if self._graph_key not in self._graphs and len(self._graphs) >= 4:
+            self._graphs.pop(next(iter(self._graphs)))
         self._graphs[self._graph_key] = (self.graph, self.graph_many, self.graph_tail)
 
     def view_point_counts(self) -> torch.Tensor:
