@@ -1758,7 +1758,12 @@ bool direct_ok(size_t w_off, int n, int m, int N, int* tx = nullptr, int* ty = n
     if (best < 0 || cost < best) { best = cost; TX = a; TY = b; }
   }
   const int tiles = ((m + TX - 1) / TX) * ((m + TY - 1) / TY);
-  if ((long long)tiles * N < 512) return false;
+  // enough workgroups to fill the chip -- or, for the handful of latents of a multi-object frame (8 ... 31: K objects
+  // side by side), a layer of at least 15 tiles from 240 workgroups on: decoder N = 16 forward 162 -> 97 us, the 8- and
+  // 16-object loops +8 % / +24 % objects per second; single latents, small layers and big batches keep their forms
+  // (measured with the plain 240 threshold: N = 1 VJP 123 -> 160 us, N = 256 403 -> 453 us)
+  const long long wgs = (long long)tiles * N;
+  if (wgs < SDFR_DIRECT_MIN_TILES && !(N >= 8 && tiles >= 15 && wgs >= SDFR_DIRECT_MIN_TILES_FEW)) return false;
   if (tx) *tx = TX;
   if (ty) *ty = TY;
   if (zc) *zc = zc_pow;

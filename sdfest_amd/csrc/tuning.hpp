@@ -55,6 +55,14 @@
 #ifndef SDFR_PC_MIN_GROUPS
 #define SDFR_PC_MIN_GROUPS 64
 #endif
+// batched decoder: the direct (VALU) convolution from this many workgroups (tiles x latents) on, the MFMA form below
+#ifndef SDFR_DIRECT_MIN_TILES
+#define SDFR_DIRECT_MIN_TILES 512
+#endif
+// ... and for 8 or more latents on layers of at least 15 tiles
+#ifndef SDFR_DIRECT_MIN_TILES_FEW
+#define SDFR_DIRECT_MIN_TILES_FEW 240
+#endif
 // waves per SIMD the backward kernel's register allocation is held to (0: the compiler's choice)
 #ifndef SDFR_BWD_WAVES_PER_EU
 #define SDFR_BWD_WAVES_PER_EU 8
