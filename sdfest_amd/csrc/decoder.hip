@@ -1763,7 +1763,7 @@ bool direct_ok(size_t w_off, int n, int m, int N, int* tx = nullptr, int* ty = n
   // 16-object loops +8 % / +24 % objects per second; single latents, small layers and big batches keep their forms
   // (measured with the plain 240 threshold: N = 1 VJP 123 -> 160 us, N = 256 403 -> 453 us)
   const long long wgs = (long long)tiles * N;
-  if (wgs < SDFR_DIRECT_MIN_TILES && !(N >= 8 && tiles >= 15 && wgs >= SDFR_DIRECT_MIN_TILES_FEW)) return false;
+  if (wgs < SDFR_DIRECT_MIN_TILES && !(N >= SDFR_DIRECT_MIN_LATENTS_FEW && tiles >= 15 && wgs >= SDFR_DIRECT_MIN_TILES_FEW)) return false;
   if (tx) *tx = TX;
   if (ty) *ty = TY;
   if (zc) *zc = zc_pow;

@@ -59,9 +59,12 @@
 #ifndef SDFR_DIRECT_MIN_TILES
 #define SDFR_DIRECT_MIN_TILES 512
 #endif
-// ... and for 8 or more latents on layers of at least 15 tiles
+// ... and for SDFR_DIRECT_MIN_LATENTS_FEW or more latents on layers of at least 15 tiles
 #ifndef SDFR_DIRECT_MIN_TILES_FEW
 #define SDFR_DIRECT_MIN_TILES_FEW 240
+#endif
+#ifndef SDFR_DIRECT_MIN_LATENTS_FEW
+#define SDFR_DIRECT_MIN_LATENTS_FEW 8
 #endif
 // waves per SIMD the backward kernel's register allocation is held to (0: the compiler's choice)
 #ifndef SDFR_BWD_WAVES_PER_EU
