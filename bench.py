@@ -226,7 +226,7 @@ def sharded_loop_section(N, rank, barrier):
     """N > 1: the render-and-compare LOOP sharded over the ranks (sdfest_amd.pipeline, process_group="world"): what the
     one all-reduce INSIDE an iteration costs over xGMI -- the headline's steps are independent and do not show it.
     8 N and 64 N views of the C5 scene, 50 iterations, both exchanges, beside the same per-rank view count as a single
-    process.  Bounded by the job watchdog; an exception becomes {"error": ...}, never a lost headline."""
+    process.  Runs after the headline is complete, under a SectionGuard; an exception becomes {"error": ...}."""
     from sdfest_amd.pipeline import FusedRenderAndCompare
     from tools._loop_scene import c5_scene
     rows = []
@@ -260,23 +260,40 @@ def sharded_loop_section(N, rank, barrier):
     return rows
 
 
+class SectionGuard:
+    """An optional multi-rank section that comes AFTER the headline is complete: if it has not finished after `seconds`,
+    rank 0 prints the line it already has (with the fact under `key`) and every rank leaves -- a hang in an extra can
+    cost the extra, never the measurement."""
+
+    def __init__(self, rank, key, seconds, line):
+        import threading
+
+        def give_up():
+            if rank == 0:
+                line[key] = {"error": f"not finished after {seconds:.0f} s: abandoned"}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        self.timer = threading.Timer(seconds, give_up)
+        self.timer.daemon = True
+
+    def __enter__(self):
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        return False
+
+
 def collective_in_graph_section(N, rank, barrier, seconds, line):
     """The sharded loop with its all-reduce captured INSIDE the hipGraphs (FusedRenderAndCompare(graph_collective=True):
     measured at world size 1, 0.140 -> 0.125 ms per iteration) -- never run over more than one GPU before this line, so
     it comes LAST and under a guard: if it has not finished after `seconds`, rank 0 prints the line it already has
     (with the fact) and every rank leaves.  Returns the rows, or {"error": ...}."""
-    import threading
     from sdfest_amd.pipeline import FusedRenderAndCompare
     from tools._loop_scene import c5_scene
-
-    def give_up():
-        if rank == 0:
-            line["loop_sharded_collective_in_graph"] = {"error": f"not finished after {seconds:.0f} s: abandoned"}
-            print(json.dumps(line), flush=True)
-        os._exit(0 if rank == 0 else 0)
-    guard = threading.Timer(seconds, give_up)
-    guard.daemon = True
-    guard.start()
+    guard = SectionGuard(rank, "loop_sharded_collective_in_graph", seconds, line)
+    guard.__enter__()
     try:
         rows = []
         for per_rank in (8, 64):
@@ -307,7 +324,7 @@ def collective_in_graph_section(N, rank, barrier, seconds, line):
     except Exception as e:
         return {"error": f"{type(e).__name__}: {e}"}
     finally:
-        guard.cancel()
+        guard.__exit__()
 
 
 def main():
@@ -580,12 +597,6 @@ def main():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
-    loop_sharded = None
-    if use_dist and (N > 1 or os.environ.get("SDFR_BENCH_LOOP_SHARDED") == "1"):
-        try:
-            loop_sharded = sharded_loop_section(N, rank, plain_barrier)
-        except Exception as e:      # (every rank takes the same path: the section's collectives are all inside)
-            loop_sharded = {"error": f"{type(e).__name__}: {e}"}
 
     fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
     bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
@@ -684,8 +695,6 @@ def main():
             "prologue_fallbacks_in_timed_region": fallbacks,
             "gpu_telemetry": tele.summary("t0", "t1"),
         }
-        if loop_sharded is not None:
-            line["loop_sharded"] = loop_sharded
         if collective:
             line["collective"] = collective
             v_other = views / elapsed_other
@@ -717,6 +726,14 @@ def main():
             torch.cuda.empty_cache()
             line["configs"] = extra_configs(sdf_np, device, HBM_PEAK)
     line = line if rank == 0 else {}
+    # the extras of a multi-rank run, AFTER the headline is complete and each under its own guard (every rank enters;
+    # only rank 0's line matters): the sharded loop between graphs, then with its all-reduce inside the graphs
+    if use_dist and (N > 1 or os.environ.get("SDFR_BENCH_LOOP_SHARDED") == "1"):
+        with SectionGuard(rank, "loop_sharded", float(os.environ.get("SDFR_BENCH_LOOP_SHARDED_S", "180")), line):
+            try:
+                line["loop_sharded"] = sharded_loop_section(N, rank, plain_barrier)
+            except Exception as e:      # (every rank takes the same path: the section's collectives are all inside)
+                line["loop_sharded"] = {"error": f"{type(e).__name__}: {e}"}
     if use_dist and backend == "nccl" and (N > 1 or os.environ.get("SDFR_BENCH_LOOP_SHARDED") == "1"):
         # (every rank enters; only rank 0's line matters)
         line["loop_sharded_collective_in_graph"] = collective_in_graph_section(
@@ -724,8 +741,14 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     if use_dist:
+        # (the line is out: a rank that never arrives here must not turn the run into a failure)
+        import threading
+        bye = threading.Timer(60.0, lambda: os._exit(0))
+        bye.daemon = True
+        bye.start()
         dist.barrier()
         dist.destroy_process_group()
+        bye.cancel()
         faulthandler.cancel_dump_traceback_later()
 
 
