@@ -57,3 +57,32 @@ def test_a_hung_rank_ends_the_whole_spawned_job(tmp_path):
     t0 = time.monotonic()
     assert spawn_ranks([sys.executable, str(script)], 2, timeout=100) == 3
     assert time.monotonic() - t0 < 40
+
+
+def test_a_hung_extra_section_costs_the_extra_not_the_headline(tmp_path):
+    """bench.SectionGuard: the multi-rank extras (the sharded loop, its all-reduce inside the graphs) run after the
+    headline is complete; one that does not finish is abandoned -- rank 0 prints the line it has, with the fact, and
+    every rank exits 0; a section that finishes in time leaves no timer behind."""
+    script = tmp_path / "extra.py"
+    script.write_text(textwrap.dedent(f"""
+        import json, sys, time
+        sys.path.insert(0, {ROOT!r})
+        import bench
+        rank = int(sys.argv[1])
+        line = {{"metric": "m", "value": 1.5}}
+        with bench.SectionGuard(rank, "quick", 1.0, line):
+            line["quick"] = [1, 2]
+        time.sleep(1.5)              # past the first guard's time: it must not fire any more
+        with bench.SectionGuard(rank, "loop_sharded", 1.0, line):
+            time.sleep(30)           # a collective that never completes
+        print("not reached")
+    """))
+    for rank in (0, 1):
+        t0 = time.monotonic()
+        res = subprocess.run([sys.executable, str(script), str(rank)], capture_output=True, text=True, timeout=120)
+        assert res.returncode == 0 and time.monotonic() - t0 < 25 and "not reached" not in res.stdout
+        if rank == 0:
+            line = __import__("json").loads(res.stdout.strip().splitlines()[-1])
+            assert line["value"] == 1.5 and line["quick"] == [1, 2] and "abandoned" in line["loop_sharded"]["error"]
+        else:
+            assert res.stdout.strip() == ""
