@@ -53,7 +53,7 @@
  *   3. LOOP: one render-and-compare iteration (SDFPipeline.__call__) as a fixed launch sequence
  *        sdfr_preprocess_depth, sdfr_depth_to_points_resident, sdfr_depth_count[_ordered|_centroid],
  *        sdfr_depth_to_points[_ordered|_shifted], sdfr_depth_points_workspace_bytes, sdfr_depth_centroid_workspace_bytes
- *        sdfr_pose_to_views[_objects], sdfr_views_to_pose_grad[_deferred], sdfr_decoder_backward_latent_deferred,
+ *        sdfr_pose_to_views[_objects], sdfr_views_to_pose_grad[_deferred], sdfr_decoder_backward_latent_deferred[_batch],
  *        sdfr_loop_tail, sdfr_loop_tail_objects, sdfr_adam_step, sdfr_point_constraint, sdfr_add_inplace
  *        sdfr_depth_l1_loss[_workspace_bytes], sdfr_pc_l1_loss, sdfr_inlier_ratio, sdfr_nn_loss_forward / _backward
  *        sharded over ranks: sdfr_loop_view_records, sdfr_loop_tail_records, sdfr_inlier_counts_record,
@@ -404,6 +404,11 @@ SDFR_API int sdfr_decoder_backward_latent(const sdfr_decoder* decoder, const flo
 SDFR_API int sdfr_decoder_backward_latent_deferred(const sdfr_decoder* decoder, const float* z, const float* tape,
                                           const float* grad_out, void* workspace, size_t workspace_bytes,
                                           void* stream, const float** t_mid);
+/* ... and for N latents (the K objects of a frame): *t_mid is [N][width of the wide layer's input]; sdfr_loop_tail_objects
+ * finishes object k's product rule from row k. */
+SDFR_API int sdfr_decoder_backward_latent_deferred_batch(const sdfr_decoder* decoder, const float* z, const float* tape,
+                                                const float* grad_out, int N, void* workspace, size_t workspace_bytes,
+                                                void* stream, const float** t_mid);
 
 
 /* ==== 3. LOOP ================================================================================= */
@@ -465,19 +470,26 @@ SDFR_API int sdfr_loop_tail(float* params, float* grads, float* exp_avg, float* 
  *   the launch's views are object-major: object k owns views k V .. k V + V - 1 of the render / sampler launches
  *   (set-up records, tile partials, point blocks, quat_c, pc_loss, and the pos_c / quat_c / inv_scale / scale_v written
  *   for the next iteration: all [K V ...]); cam_pos [V][3], cam_quat [V][4] are ONE camera list, the same for every object
- *   grads[k][8..] must hold d loss / d latent of object k (sdfr_decoder_backward_latent with N = K); no point constraint,
- *   no deferred decoder stage.  Same arithmetic per object, in the same order, as sdfr_loop_tail. */
+ *   decoder == NULL: grads[k][8..] must hold d loss / d latent of object k (sdfr_decoder_backward_latent with N = K);
+ *   decoder + decoder_t_mid (sdfr_decoder_backward_latent_deferred_batch with N = K, row k = object k): workgroup k runs
+ *   the last stage of object k's VJP itself, as sdfr_loop_tail does for the single estimate (one launch less, and no
+ *   copy of the latent gradients into `grads`)
+ *   latents (may be NULL): [K][n_params - 8], receives the UPDATED latents packed for the next iteration's batched
+ *   decode (sdfr_decoder_forward with N = K reads z [N][latent]; `params` holds them with stride n_params)
+ *   No point constraint.  Same arithmetic per object, in the same order, as sdfr_loop_tail. */
 /* sdfr_pose_to_views for the K rows of `params` ([K][n_params]: position 3 | orientation 4 | scale 1 | ...) and one camera
- * list: view k V + v of the outputs is object k seen from camera v. */
+ * list: view k V + v of the outputs is object k seen from camera v; latents (may be NULL): as above, the CURRENT ones. */
 SDFR_API int sdfr_pose_to_views_objects(const float* params, int n_params, int n_objects, const float* cam_pos,
                                const float* cam_quat, int V, float* pos_c, float* quat_c, float* inv_scale,
-                               float* scale_v, int device, void* stream);
+                               float* scale_v, float* latents, int device, void* stream);
 SDFR_API int sdfr_loop_tail_objects(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int* step, int n_params,
                            int n_objects, float lr_position, float lr_orientation, float lr_scale, float lr_latent,
                            int update_latent, const float* cam_pos, const float* cam_quat, int V,
                            const void* render_workspace, size_t render_partials_offset, int W, int H,
                            const void* pc_workspace, const int* offsets, int max_view_points, float* pos_c,
-                           float* quat_c, float* inv_scale, float* scale_v, float* pc_loss, int device, void* stream);
+                           float* quat_c, float* inv_scale, float* scale_v, float* pc_loss,
+                           const sdfr_decoder* decoder, const float* decoder_t_mid, float* latents, int device,
+                           void* stream);
 
 /* ---- the loop sharded over ranks (one process per GPU) ------------------------------------------------
  * The reference's multi-view iteration is one Python loop over the views with ONE shared pose and ONE shared SDF

@@ -39,10 +39,11 @@ SIGNATURES = {
     "sdfr_loop_tail": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_f, c_f, c_f, c_f, c_int, c_fp, c_fp, c_int,
                                c_fp, c_sz, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                c_f, c_fp, c_fp, c_fp, c_int, c_fp]),
-    "sdfr_pose_to_views_objects": (c_int, [c_fp, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp]),
+    "sdfr_pose_to_views_objects": (c_int, [c_fp, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int,
+                                           c_fp]),
     "sdfr_loop_tail_objects": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_f, c_f, c_f, c_f, c_int, c_fp, c_fp,
                                        c_int, c_fp, c_sz, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp,
-                                       c_int, c_fp]),
+                                       c_fp, c_fp, c_fp, c_int, c_fp]),
     "sdfr_loop_view_records": (c_int, [c_fp, c_sz, c_int, c_int, c_int, c_fp, c_int, c_fp, c_int, c_fp, c_fp, c_int,
                                        c_int, c_int, c_fp, c_int, c_fp]),
     "sdfr_loop_tail_records": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_f, c_f, c_f, c_f, c_int, c_fp, c_fp,
@@ -92,6 +93,7 @@ SIGNATURES = {
     "sdfr_decoder_backward_workspace_bytes": (c_sz, [c_fp, c_int]),
     "sdfr_decoder_backward_latent": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_sz, c_fp]),
     "sdfr_decoder_backward_latent_deferred": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_fp, c_fp]),
+    "sdfr_decoder_backward_latent_deferred_batch": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_sz, c_fp, c_fp]),
     "sdfr_pose_to_views": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp]),
     "sdfr_views_to_pose_grad": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                         c_fp, c_fp, c_fp, c_int, c_fp]),

@@ -295,6 +295,8 @@ __device__ __forceinline__ int div_by(int x, unsigned m) { return m ? (int)__umu
 constexpr int kResizeTile = 8;
 // tensors up to this many elements take the launch-count-saving fused forms (single decodes, up to 8 latents)
 constexpr size_t kFewElements = (size_t)1 << 21;
+// ... and the forward's resize with the 1x1x1 mix inside (resize3_mix_kernel, eight gathers per output) up to this many
+constexpr size_t kFewElementsMix = (size_t)1 << SDFR_FEW_MIX_LOG2;
 // A workgroup takes its tile of `ipw` consecutive (sample, channel) volumes one after the other (round 4): the tables,
 // where each thread's staged elements come from and its x / y / z terms are formed ONCE -- they were two thirds of the
 // 36 VALU instructions per output of a kernel that is VALU-bound (0.98 busy, profiles/r04_decoder_batched_pmc.md) --
@@ -2226,12 +2228,12 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
     const bool pow2 = no >= 16 && no <= 128 && (no & (no - 1)) == 0;
     // (a single decode has too few tiles to fill the chip: the gather kernel is faster there)
     const long long tile_items = (long long)tiles * tiles * C * N;
-    if (pow2 && ni <= no && lds <= 48 * 1024 && (long long)C * N < (1ll << 30) && tile_items >= 2048) {
+    if (pow2 && ni <= no && lds <= 48 * 1024 && (long long)C * N < (1ll << 30) && tile_items >= SDFR_RESIZE_TILED_MIN_ITEMS) {
       // volumes per workgroup: as many as still leave ~8 workgroups per CU
       const int items = C * N;
       // (256 mug latents, us: 14 -> 32 x 8 channels 68.6 / 52.9 / 55.4 / 53.3 at 1 / 2 / 4 / 8 volumes per workgroup,
       // 30 -> 64 x 1 channel 68.5 / 60.3 / 55.8 / 63.6 -- profiles/r04_decoder_resize_ipw.txt; before this form 70.8 / 66.7)
-      const int ipw = std::max((int)std::min<long long>(4, tile_items / 2048), (items + 65534) / 65535);
+      const int ipw = std::max((int)std::max<long long>(1, std::min<long long>(4, tile_items / 2048)), (items + 65534) / 65535);
       const dim3 grid(tiles * tiles, (items + ipw - 1) / ipw, 1);
       const bool vec = ((uintptr_t)dst & 15) == 0;
 #define SDFR_RESIZE_T(LOG)                                                                                              \
@@ -2281,7 +2283,7 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
     const float* wm = d->d_params + d->conv_w_off[l];
     const float* bs = d->d_params + d->conv_b_off[l];
     if (swap && k == 1 && co_n <= 4 && m_out != n &&
-        (size_t)N * co_n * m_out * m_out * m_out <= kFewElements) {
+        (size_t)N * co_n * m_out * m_out * m_out <= kFewElementsMix) {
       // single latents: the 1x1 mix inside the resize (one launch)
       float* dst = layer_dst ? layer_dst : buf[cur ^ 1];
       const size_t vo = (size_t)m_out * m_out * m_out;
@@ -2311,7 +2313,7 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
     if (!swap && !fused_up && k == 3 && l + 1 < d->n_conv && d->conv_swap[l + 1] && d->conv_k[l + 1] == 1 &&
         d->conv_cout[l + 1] <= 4 && d->fwd_direct_off[l] != 0) {
       const int mo = d->conv_in_size[l + 1], co2 = d->conv_cout[l + 1];
-      const bool few_next = mo != m && (size_t)N * co2 * mo * mo * mo <= kFewElements;   // (takes resize3_mix_kernel)
+      const bool few_next = mo != m && (size_t)N * co2 * mo * mo * mo <= kFewElementsMix;   // (takes resize3_mix_kernel)
       float* act_dst = tape ? tape + (size_t)N * d->tape_conv_off[l] : nullptr;
       mix_next = !few_next && launch_direct(d, d->fwd_direct_off[l], act_in, bs, act_dst, c, co_n, n, n, m, conv_relu,
                                             N, st, d->d_params + d->conv_w_off[l + 1], d->d_params + d->conv_b_off[l + 1],
@@ -2734,4 +2736,11 @@ extern "C" int sdfr_decoder_backward_latent_deferred(const sdfr_decoder* d, cons
                                                      void* stream, const float** t_mid) {
   if (!t_mid) return fail(SDFR_E_NULL, "sdfr_decoder_backward_latent_deferred: NULL pointer argument");
   return decoder_backward_impl(d, z, tape, grad_out, 1, nullptr, workspace, workspace_bytes, stream, t_mid);
+}
+
+extern "C" int sdfr_decoder_backward_latent_deferred_batch(const sdfr_decoder* d, const float* z, const float* tape,
+                                                           const float* grad_out, int N, void* workspace,
+                                                           size_t workspace_bytes, void* stream, const float** t_mid) {
+  if (!t_mid) return fail(SDFR_E_NULL, "sdfr_decoder_backward_latent_deferred_batch: NULL pointer argument");
+  return decoder_backward_impl(d, z, tape, grad_out, N, nullptr, workspace, workspace_bytes, stream, t_mid);
 }

@@ -81,11 +81,14 @@ __global__ void pose_to_views_kernel(const float* __restrict__ position,
 __global__ void pose_to_views_objects_kernel(const float* __restrict__ params, int n, int K,
                                              const float* __restrict__ cam_pos, const float* __restrict__ cam_quat,
                                              int V, float* __restrict__ pos_c, float* __restrict__ quat_c,
-                                             float* __restrict__ inv_scale, float* __restrict__ scale_v) {
+                                             float* __restrict__ inv_scale, float* __restrict__ scale_v,
+                                             float* __restrict__ latents) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= K * V) return;
   const int k = i / V, v = i - k * V;
   const float* p = params + (size_t)k * n;
+  if (latents && v == 0)   // the object's latent, packed [K][n - 8]: what a batched decode reads
+    for (int j = 8; j < n; ++j) latents[(size_t)k * (n - 8) + j - 8] = p[j];
   const float cp[3] = {cam_pos[3 * v], cam_pos[3 * v + 1], cam_pos[3 * v + 2]};
   const float cq[4] = {cam_quat[4 * v], cam_quat[4 * v + 1], cam_quat[4 * v + 2], cam_quat[4 * v + 3]};
   pose_to_view_core(i, p, p + 3, p + 7, cp, cq, pos_c, quat_c, inv_scale, scale_v);
@@ -720,6 +723,7 @@ struct LoopTailArgs {
   // sdfr_loop_tail_objects: workgroup k is object k -- its own parameters, moments, step counter and V views (the
   // launch's views k V .. k V + V - 1), the same cameras for every object; 0 / 1: the single estimate of sdfr_loop_tail
   int n_obj;
+  float* latents;   // objects: the updated latents, packed [n_obj][n - 8] (the next iteration's batched decode), or NULL
 };
 static_assert(kFcBlock == 256, "the tail's workgroup runs the decoder's Linear-stack backward");
 #ifdef SDFR_TAIL_STAMPS   // timing experiment (tools/microbench): where the tail's time goes, in 10 ns ticks
@@ -769,11 +773,13 @@ __global__ __launch_bounds__(256) void loop_tail_kernel(LoopTailArgs a_in) {
     for (int k = 0; k < 3; ++k) { con[k] = a.con_source[k]; con[3 + k] = a.con_target[k]; }
   }
   const bool fc_wave = a.t_mid && a.fc_one_wave;
+  // (objects: the batched VJP left one row per object)
+  const float* const t_mid = a.t_mid ? a.t_mid + (a.n_obj > 1 ? (size_t)blockIdx.x * a.fc.width[a.fc.n_fc - 1] : 0) : nullptr;
   if (a.t_mid && !fc_wave) {   // d loss / d latent (g[8 ...]) from the gradient w.r.t. the wide Linear layer's input
-    fc_stack_backward_sample(a.dec_params, a.fc, params + 8, a.t_mid, g_l + 8);
+    fc_stack_backward_sample(a.dec_params, a.fc, params + 8, t_mid, g_l + 8);
     __syncthreads();
   }
-  if (fc_wave && wave == 0) fc_stack_backward_one_wave(a.dec_params, a.fc, params + 8, a.t_mid, g_l + 8, lane);
+  if (fc_wave && wave == 0) fc_stack_backward_one_wave(a.dec_params, a.fc, params + 8, t_mid, g_l + 8, lane);
   // (only now: an LDS store of a loaded value waits for the load, and the Linear stack's loads should not queue
   // behind that wait)
   if (mine) p_cur[tid] = p_old;
@@ -808,6 +814,7 @@ __global__ __launch_bounds__(256) void loop_tail_kernel(LoopTailArgs a_in) {
     params[tid] = p_i;
     mom1[tid] = m_i;
     mom2[tid] = v_i;
+    if (a.latents && tid >= 8) a.latents[(size_t)blockIdx.x * (a.n - 8) + tid - 8] = p_i;
   }
   if (tid == 0) step[0] = step_old + 1;
   SDFR_STAMP(5);
@@ -1109,7 +1116,7 @@ extern "C" int sdfr_pose_to_views(const float* position, const float* orientatio
 
 extern "C" int sdfr_pose_to_views_objects(const float* params, int n_params, int n_objects, const float* cam_pos,
                                           const float* cam_quat, int V, float* pos_c, float* quat_c, float* inv_scale,
-                                          float* scale_v, int device, void* stream) {
+                                          float* scale_v, float* latents, int device, void* stream) {
   if (V < 0 || n_objects < 0 || n_params < 8 || (long long)V * n_objects > 0x7fffffffLL)
     return fail(SDFR_E_INVALID, "sdfr_pose_to_views_objects: bad sizes V=%d objects=%d n_params=%d", V, n_objects, n_params);
   if (V == 0 || n_objects == 0) return 0;
@@ -1118,7 +1125,7 @@ extern "C" int sdfr_pose_to_views_objects(const float* params, int n_params, int
   SDFR_HIP_TRY(hipSetDevice(device));
   const int total = V * n_objects;
   hipLaunchKernelGGL(pose_to_views_objects_kernel, dim3((total + 63) / 64), dim3(64), 0, (hipStream_t)stream, params,
-                     n_params, n_objects, cam_pos, cam_quat, V, pos_c, quat_c, inv_scale, scale_v);
+                     n_params, n_objects, cam_pos, cam_quat, V, pos_c, quat_c, inv_scale, scale_v, latents);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1237,8 +1244,11 @@ extern "C" int sdfr_loop_tail_objects(float* params, float* grads, float* exp_av
                                       const float* cam_quat, int V, const void* render_workspace,
                                       size_t render_partials_offset, int W, int H, const void* pc_workspace,
                                       const int* offsets, int max_view_points, float* pos_c, float* quat_c,
-                                      float* inv_scale, float* scale_v, float* pc_loss, int device, void* stream) {
+                                      float* inv_scale, float* scale_v, float* pc_loss, const sdfr_decoder* decoder,
+                                      const float* decoder_t_mid, float* latents, int device, void* stream) {
   const char* fn = "sdfr_loop_tail_objects";
+  if ((decoder != nullptr) != (decoder_t_mid != nullptr))
+    return fail(SDFR_E_NULL, "%s: decoder and decoder_t_mid go together", fn);
   if (n_objects < 1 || n_objects > 65535) return fail(SDFR_E_INVALID, "%s: n_objects=%d", fn, n_objects);
   if (V < 1 || V > kDeferredMaxViews) return fail(SDFR_E_INVALID, "%s: V=%d out of range [1,%d]", fn, V, kDeferredMaxViews);
   if ((long long)n_objects * V > 65535) return fail(SDFR_E_INVALID, "%s: %d objects x %d views exceed a launch", fn, n_objects, V);
@@ -1272,6 +1282,14 @@ extern "C" int sdfr_loop_tail_objects(float* params, float* grads, float* exp_av
   a.offsets = offsets; a.n_single = max_view_points; a.nblk = nblk;
   a.pos_c = pos_c; a.quat_c = quat_c; a.inv_scale = inv_scale; a.scale_v = scale_v; a.pc_loss = pc_loss;
   a.n_obj = n_objects;
+  a.latents = latents;
+  if (decoder) {   // the batched VJP's last stage (sdfr_decoder_backward_latent_deferred_batch), one row per object
+    decoder_fc_desc(decoder, &a.fc, &a.dec_params, nullptr);
+    if (a.fc.width[0] != n_params - 8)
+      return fail(SDFR_E_INVALID, "%s: n_params=%d does not hold the decoder's latent (%d)", fn, n_params, a.fc.width[0]);
+    a.fc_one_wave = decoder_fc_one_wave(decoder, a.fc) ? 1 : 0;
+    a.t_mid = decoder_t_mid;
+  }
   hipLaunchKernelGGL(loop_tail_kernel, dim3((unsigned)n_objects), dim3(256), 0, (hipStream_t)stream, a);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;

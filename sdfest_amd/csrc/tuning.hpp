@@ -66,6 +66,19 @@
 #ifndef SDFR_DIRECT_MIN_LATENTS_FEW
 #define SDFR_DIRECT_MIN_LATENTS_FEW 8
 #endif
+// decoder forward: the last resize with the 1x1x1 layer inside it (one gather kernel, eight gathers per output) up to
+// 2^this output elements -- one or two mug latents -- conv1x1 + the tiled resize above (bit-identical; at 2^21 the
+// 4- and 8-object loops ran 431 / 680 objects/s, at 2^19 446 / 744)
+#ifndef SDFR_FEW_MIX_LOG2
+#define SDFR_FEW_MIX_LOG2 19
+#endif
+// decoder forward: an up-sampling resize takes the LDS-tiled kernel from this many (tile, volume) items on, the gather
+// kernel below (a single decode -- 128 and 64 items at the mug decoder's two up-sampling resizes -- has too few tiles to
+// fill the chip; from two latents on the tiled kernel wins: at 2048 the 4- / 8- / 16-object loops ran 474 / 778 / 1263
+// objects/s, at 256 489 / 840 / 1360)
+#ifndef SDFR_RESIZE_TILED_MIN_ITEMS
+#define SDFR_RESIZE_TILED_MIN_ITEMS 256
+#endif
 // waves per SIMD the backward kernel's register allocation is held to (0: the compiler's choice)
 #ifndef SDFR_BWD_WAVES_PER_EU
 #define SDFR_BWD_WAVES_PER_EU 8

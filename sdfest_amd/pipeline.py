@@ -1139,7 +1139,7 @@ class MultiObjectRenderAndCompare:
         return self
 
     def _decode(self, st, with_tape):
-        self.z.copy_(self.params[:, 8:])
+        # (self.z holds the current latents, packed: sdfr_pose_to_views_objects at the start of a run, the tail after)
         self.check(self.L.sdfr_decoder_forward(self.dec._h, self.z.data_ptr(), self.K, 0, self.sdf.data_ptr(),
                                                self.tape.data_ptr() if with_tape else None, self.ws_dec.data_ptr(),
                                                self.ws_dec.numel(), st), "sdfr_decoder_forward")
@@ -1150,7 +1150,7 @@ class MultiObjectRenderAndCompare:
         self.check(self.L.sdfr_pose_to_views_objects(
             self.params.data_ptr(), self.n, self.K, self.cam_pos.data_ptr(), self.cam_quat.data_ptr(), 1,
             self.pos_c.data_ptr(), self.quat_c.data_ptr(), self.inv_scale.data_ptr(), self.scale_v.data_ptr(),
-            self.dev.index, st), "sdfr_pose_to_views_objects")
+            self.z.data_ptr(), self.dev.index, st), "sdfr_pose_to_views_objects")
 
     def iteration(self):
         L, d, st = self.L, self.dev.index, self._stream()
@@ -1162,17 +1162,20 @@ class MultiObjectRenderAndCompare:
         g_sdf = self.plan.backward_l1_pc(self.target, sdf, self.pos_c, self.quat_c, self.inv_scale, self.scale_v,
                                          self.points, self.offsets, self.max_pts, self.ws_pc,
                                          weight=self.cfg["depth_weight"], pc_weight=self.cfg["pc_weight"])
+        t_mid = ctypes.c_void_p()
         if self.shape_opt:
-            self.check(L.sdfr_decoder_backward_latent(self.dec._h, self.z.data_ptr(), self.tape.data_ptr(),
-                                                      g_sdf.data_ptr(), self.K, self.g_z.data_ptr(), self.ws_dec.data_ptr(),
-                                                      self.ws_dec.numel(), st), "sdfr_decoder_backward_latent")
-            self.grads[:, 8:].copy_(self.g_z)
+            # the VJP without its last stage: workgroup k of the tail finishes object k's (one launch and a copy less)
+            self.check(L.sdfr_decoder_backward_latent_deferred_batch(
+                self.dec._h, self.z.data_ptr(), self.tape.data_ptr(), g_sdf.data_ptr(), self.K, self.ws_dec.data_ptr(),
+                self.ws_dec.numel(), st, ctypes.byref(t_mid)), "sdfr_decoder_backward_latent_deferred_batch")
         self.check(L.sdfr_loop_tail_objects(
             self.params.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.step.data_ptr(),
             self.n, self.K, 1e-3, 1e-2, 1e-3, 1e-2, int(self.shape_opt), self.cam_pos.data_ptr(), self.cam_quat.data_ptr(),
             1, self.plan.workspace.data_ptr(), self.plan.partials_offset, self.W, self.H, self.ws_pc.data_ptr(),
             self.offsets.data_ptr(), self.max_pts, self.pos_c.data_ptr(), self.quat_c.data_ptr(),
-            self.inv_scale.data_ptr(), self.scale_v.data_ptr(), self.loss_pc.data_ptr(), d, st), "sdfr_loop_tail_objects")
+            self.inv_scale.data_ptr(), self.scale_v.data_ptr(), self.loss_pc.data_ptr(),
+            self.dec._h if self.shape_opt else None, t_mid if self.shape_opt else None, self.z.data_ptr(), d, st),
+            "sdfr_loop_tail_objects")
 
     def view_losses(self):
         """(depth loss, point-cloud loss) of every object in the last iteration, (K,) each"""
@@ -1192,9 +1195,9 @@ class MultiObjectRenderAndCompare:
             self._zeroed.zero_()
             self.step.zero_()
         st = self._stream()
+        self._poses_to_views(st)        # (also packs the latents for the decoder)
         if not self.shape_opt:
             self._decode(st, False)
-        self._poses_to_views(st)
         n_iter = self.cfg["max_iterations"]
         if use_graph and self.graph is None:
             saved = [t.clone() for t in (self.params, self._zeroed, self.step)]

@@ -171,20 +171,25 @@ def test_round5_entry_points_validate_their_arguments_without_gpu(libpath):
     assert L.sdfr_decoder_set_option(None, 0, 1) == -2
     # K estimates side by side
     rc = L.sdfr_loop_tail_objects(q, q, q, q, q, 16, 0, 1e-3, 1e-2, 1e-3, 1e-2, 1, q, q, 1, None, 0, 0, 0, None, None, 0,
-                                  q, q, q, q, None, 0, None)
+                                  q, q, q, q, None, None, None, None, 0, None)
     assert rc == -1 and b"n_objects" in err()
     rc = L.sdfr_loop_tail_objects(q, q, q, q, q, 16, 4, 1e-3, 1e-2, 1e-3, 1e-2, 1, q, q, 65, None, 0, 0, 0, None, None, 0,
-                                  q, q, q, q, None, 0, None)
+                                  q, q, q, q, None, None, None, None, 0, None)
     assert rc == -1 and b"V=65" in err()
     rc = L.sdfr_loop_tail_objects(q, q, q, q, q, 300, 4, 1e-3, 1e-2, 1e-3, 1e-2, 1, q, q, 1, None, 0, 0, 0, None, None, 0,
-                                  q, q, q, q, None, 0, None)
+                                  q, q, q, q, None, None, None, None, 0, None)
     assert rc == -1 and b"n_params" in err()
     rc = L.sdfr_loop_tail_objects(q, q, q, q, None, 16, 4, 1e-3, 1e-2, 1e-3, 1e-2, 1, q, q, 1, None, 0, 0, 0, None, None,
-                                  0, q, q, q, q, None, 0, None)
+                                  0, q, q, q, q, None, None, None, None, 0, None)
     assert rc == -2
-    assert L.sdfr_pose_to_views_objects(q, 4, 2, q, q, 1, q, q, q, q, 0, None) == -1        # n_params < 8
-    assert L.sdfr_pose_to_views_objects(None, 16, 2, q, q, 1, q, q, q, q, 0, None) == -2
-    assert L.sdfr_pose_to_views_objects(None, 16, 0, q, q, 1, q, q, q, q, 0, None) == 0
+    # (a decoder stage needs both the handle and the pointer the batched VJP left)
+    rc = L.sdfr_loop_tail_objects(q, q, q, q, q, 16, 4, 1e-3, 1e-2, 1e-3, 1e-2, 1, q, q, 1, None, 0, 0, 0, None, None, 0,
+                                  q, q, q, q, None, None, q, None, 0, None)
+    assert rc == -2 and b"go together" in err()
+    assert L.sdfr_decoder_backward_latent_deferred_batch(None, q, q, q, 4, q, 1 << 20, None, None) == -2
+    assert L.sdfr_pose_to_views_objects(q, 4, 2, q, q, 1, q, q, q, q, None, 0, None) == -1        # n_params < 8
+    assert L.sdfr_pose_to_views_objects(None, 16, 2, q, q, 1, q, q, q, q, None, 0, None) == -2
+    assert L.sdfr_pose_to_views_objects(None, 16, 0, q, q, 1, q, q, q, q, None, 0, None) == 0
     # the initialisation network with the point count on the device
     assert L.sdfr_pointnet_layer_counted(q, None, 64, 3, 3, q, 3, q, q, q, None, q, 8, 8, q, 0, None) == -2
     assert b"row_count" in err()

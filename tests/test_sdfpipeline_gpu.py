@@ -92,7 +92,7 @@ def test_call_reproduces_g7_run_c(g7):
     loop, graph = pipe._last_loop, pipe._last_loop.graph
     out2 = pipe(depth.clone(), masks, color, camera_positions=T(g7["c_cam_pos"]), camera_orientations=T(g7["c_cam_quat"]))
     assert pipe._last_loop is loop and loop.graph is graph and len(pipe._loops) == 1
-    for a, b, tol in zip(out, out2, (2e-6, 2e-5, 2e-6, 5e-5)):       # (d/dSDF by float atomics: ~1e-7 per iteration)
+    for a, b, tol in zip(out, out2, (2e-5, 3e-4, 2e-5, 1e-3)):       # (d/dSDF by float atomics, amplified by 50 Adam steps)
         assert (a - b).abs().max().item() <= tol
 
 
@@ -206,14 +206,16 @@ def test_two_views_best_init_view_priors_and_any_depth_tensor():
     z1, p1, s1, q1 = nn_init(pipe.init_network, pipe.cam, depth, cam_pos, cq, cfg, normalize_pose=True)
     assert not torch.equal(q0, q1)                                            # the prior changed the initial cell
     ref = FusedRenderAndCompare(pipe.vae, pipe.cam, cfg, depth, cam_pos, cq)(p0, q0, s0, z0)
-    for a, b, tol in zip(out, ref, (2e-6, 2e-5, 2e-6, 5e-5)):                 # (shape optimisation: float atomics)
+    # (shape optimisation: the SDF gradient is summed with float atomics, and 50 Adam steps amplify the last bits --
+    # 7e-5 on a quaternion component has been seen between two runs of the SAME loop; a different initial cell is 0.1)
+    for a, b, tol in zip(out, ref, (2e-5, 3e-4, 2e-5, 1e-3)):
         assert (a - b).abs().max().item() <= tol
     # the same observation as float64 on the host, and as a strided device view
     for variant in (depth.double().cpu(), torch.stack([depth, depth], dim=1)[:, 0]):
         arg = variant.clone() if variant.is_contiguous() else variant
         m = masks.to(arg.device)
         got = pipe(arg, m, color, camera_positions=cam_pos, camera_orientations=cq, prior_orientation_distribution=prior)
-        for a, b, tol in zip(got, out, (2e-6, 2e-5, 2e-6, 5e-5)):
+        for a, b, tol in zip(got, out, (2e-5, 3e-4, 2e-5, 1e-3)):
             assert (a - b).abs().max().item() <= tol
 
 

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Run on the GPU box: kernel trace of tools/profile_loop.py, then the launches of the LAST captured iteration in
-# order, with durations and the idle gap before each one.  tools/loop_sequence.sh <tag>
+# order, with durations and the idle gap before each one.  tools/loop_sequence.sh <tag>   (PROFILE_SCRIPT=tools/profile_multi.py K=8: the K-object loop)
 TAG=${1:-loopseq}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 "$ROOT/tools/profile_loop.py" > $OUT/cmd.log 2>&1 || echo "trace failed"
+timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 "$ROOT/${PROFILE_SCRIPT:-tools/profile_loop.py}" > $OUT/cmd.log 2>&1 || echo "trace failed"
 python3 - <<PY > $OUT/sequence.md
 import csv, glob, re
 rows = []
