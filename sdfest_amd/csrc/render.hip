@@ -42,7 +42,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kFwdWaves = SDFR_FWD_WAVES;  // waves per workgroup of the batch forward (macro tiles)
-constexpr int kInlineSetupMaxViews = 8;    // a step's forward without a prologue launch (render_forward_kernel, INLINE)
+constexpr int kInlineSetupMaxViews = SDFR_INLINE_MAX_VIEWS;    // a step's forward without a prologue launch (render_forward_kernel, INLINE)
 
 
 // ---------------------------------------------------------------------------------------------
