@@ -22,7 +22,7 @@ for _ in range(5):
 t1 = float(np.median(ts))
 print(f"one object at a time: {t1 * 1e3:.3f} ms per object, {1 / t1:.1f} objects/s", flush=True)
 p0, q0, s0, z0 = s["init"]
-for K in (1, 2, 4, 8, 16, 32, 64):
+for K in [int(k) for k in os.environ.get("KS", "1,2,4,8,16,32,64").split(",")]:
     multi = MultiObjectRenderAndCompare(s["decoder"], s["camera"], s["config"], K)
     frames = s["targets"].expand(K, -1, -1).contiguous()
     args = (p0.expand(K, 3).contiguous(), q0.expand(K, 4).contiguous(), s0.expand(K).contiguous(), z0.expand(K, 8).contiguous())
