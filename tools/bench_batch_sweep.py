@@ -14,7 +14,7 @@ def timeit(fn, n=30):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for B in (1, 2, 3, 4, 8, 16, 32, 48, 54, 56, 64, 96, 128, 256, 512):
+for B in [int(b) for b in os.environ.get("BS", "1,2,3,4,8,16,32,48,54,56,64,96,128,256,512").split(",")]:
     p, q, i = (torch.tensor(a, device=dev) for a in oracle.random_poses(B, seed=1))
     plan = BatchRenderPlan(64, B, cam, device=dev)
     g = torch.rand(B, 480, 640, device=dev) * 2 - 1
