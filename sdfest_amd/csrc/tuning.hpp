@@ -36,7 +36,7 @@
 #define SDFR_BWD_BIG_MIN_RATIO 2.0f
 #endif
 // face records are packed for a grid shared by at least this many views (below, a step's forward sets its views up
-// itself -- SDFR_INLINE_MAX_VIEWS -- and saves the prologue launch: the 4-view loop 0.141 -> 0.131 ms per iteration;
+// itself or takes the plain grid behind the set-up launch: the 4-view loop 0.141 -> 0.129 ms per iteration;
 // stand-alone forwards of 4 ... 6 views 24.0 / 26.1 / 25.0 -> 21.9 / 25.9 / 23.7 us)
 #ifndef SDFR_PACKED_MIN_VIEWS
 #define SDFR_PACKED_MIN_VIEWS 7
@@ -81,11 +81,12 @@
 #ifndef SDFR_RESIZE_TILED_MIN_ITEMS
 #define SDFR_RESIZE_TILED_MIN_ITEMS 256
 #endif
-// a step's forward over at most this many views of the plain grid sets its views up itself (no prologue launch; at 8
-// views the one-object loop is indifferent -- 0.150 ms per iteration either way -- and 8 objects with their own grids
-// run 839 objects/s inline, 864 with the prologue)
+// a step's forward over at most this many views of the plain grid sets its views up itself (no prologue launch): the
+// inline form's threads also zero-fill the step's gradient volume(s), which grows with the views -- ms per iteration of
+// the V-view loop at 6 / 4 / 3 / 2: V = 4 0.1305 / 0.1315 / 0.1288 / 0.1283, V = 6 0.1384 / 0.1344 / - / -; K objects
+// with their own grids, objects/s: K = 4 488 / 485 / 495 / 495, K = 6 641 / 655 / - / -, K = 8 (at 8) 839 -> 864
 #ifndef SDFR_INLINE_MAX_VIEWS
-#define SDFR_INLINE_MAX_VIEWS 6
+#define SDFR_INLINE_MAX_VIEWS 3
 #endif
 // waves per SIMD the backward kernel's register allocation is held to (0: the compiler's choice)
 #ifndef SDFR_BWD_WAVES_PER_EU

@@ -108,7 +108,7 @@ def test_loss_fused_step_equals_the_unfused_step_bit_for_bit(R, B, W, H, f):
     backward's (no launch between the image kernels), against the unfused step on the same plan geometry: forward(
     prepare_backward=True) -> sdfr_depth_l1_loss -> backward.  Same depth, same loss and statistics, same pose
     gradients, bit for bit; d/dSDF up to the order of its float atomics.  B = 1: the inline set-up (no prologue
-    launch at all); 3, 6: plain grid (6: the largest inline set-up); 7: packed records; 40, 256: batch tiles, 256 = the
+    launch at all); 3: the largest inline set-up; 6: plain grid behind the set-up launch; 7: packed records; 40, 256: batch tiles, 256 = the
     benchmark's C3."""
     from sdfest_amd import _lib
     from sdfest_amd.differentiable_renderer import BatchRenderPlan, Camera

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from _loop_scene import c5_scene  # noqa: E402
 from sdfest_amd.pipeline import FusedRenderAndCompare  # noqa: E402
 
-for views in (1, 2, 4, 8, 16, 64):
+for views in [int(v) for v in os.environ.get("VS", "1,2,4,8,16,64").split(",")]:
     s = c5_scene(views=views, max_iterations=50)
     row = {}
     for defer in (False, True):
