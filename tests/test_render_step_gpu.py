@@ -53,7 +53,9 @@ def assert_same(step, ref, name=""):
 
 
 @pytest.mark.parametrize("B,W,H,f", [(256, 200, 136, 300.0),     # batch tiles, packed records, one-launch prologue
-                                     (8, 640, 480, 320.0),       # small tiles, packed records
+                                     (18, 320, 240, 160.0),      # small tiles, packed records (>= 17 views), a last
+                                                                 # set-up block with two views
+                                     (8, 640, 480, 320.0),       # small tiles, plain grid behind the set-up launch
                                      (5, 320, 240, 160.0),       # a last set-up block with one view
                                      (2, 160, 120, 80.0),        # plain grid (no records, no plane minima):
                                      (1, 640, 480, 320.0)])      # ... zero fill + set-up are ONE prologue launch
