@@ -1712,9 +1712,6 @@ namespace {
 #ifndef SDFR_SPLITK_MAX_TILES
 #define SDFR_SPLITK_MAX_TILES 2048
 #endif
-#ifndef SDFR_SPLITK_MAX_LATENTS
-#define SDFR_SPLITK_MAX_LATENTS 16
-#endif
 int use_split_k(bool zgrp, int n_tiles, int co_tiles, int N, int kpad) {
   // (the choice does not depend on N up to 16 samples: small batches decode bit-identically to single latents)
   return (!zgrp && (long long)n_tiles * co_tiles <= SDFR_SPLITK_MAX_TILES && N <= SDFR_SPLITK_MAX_LATENTS && kpad >= 128) ? 1 : 0;

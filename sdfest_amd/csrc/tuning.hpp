@@ -92,6 +92,12 @@
 #ifndef SDFR_INLINE_MAX_VIEWS
 #define SDFR_INLINE_MAX_VIEWS 3
 #endif
+// decoder: the split-K form of the MFMA convolution (four waves share a tile) up to this many latents -- small
+// batches then equal single decodes bit for bit (64 measured: the 32- and 64-object loops 1 915 -> 1 863, 2 433 -> 2 227
+// objects/s)
+#ifndef SDFR_SPLITK_MAX_LATENTS
+#define SDFR_SPLITK_MAX_LATENTS 16
+#endif
 // waves per SIMD the backward kernel's register allocation is held to (0: the compiler's choice)
 #ifndef SDFR_BWD_WAVES_PER_EU
 #define SDFR_BWD_WAVES_PER_EU 8
