@@ -47,12 +47,20 @@ def main():
             ts.append((time.perf_counter() - t0) / 50 * 1e3)
         return round(float(np.median(ts)), 4), res
 
+    # the single-process loop of the same views first, in both of its forms (every rank runs them: time_loop has barriers)
+    for form in ("tail", "records"):
+        if form == "tail" and views > 64:
+            continue
+        single = FusedRenderAndCompare(s["decoder"], s["camera"], s["config"], s["targets"], form=form)
+        out[f"ms_per_iteration_single_process_{form}_form"], _ = time_loop(single)
+        del single
     for exchange in ("sdf", "latent"):
         loop = FusedRenderAndCompare(s["decoder"], s["camera"], s["config"], s["targets"], process_group="world",
                                      exchange=exchange)
         ms, res = time_loop(loop)
         out[f"ms_per_iteration_sharded_exchange_{exchange}"] = ms
         out[f"final_position_error_mm_{exchange}"] = round((res[0] - s["p_true"]).norm().item() * 1e3, 3)
+        del loop
         if os.environ.get("SDFR_BENCH_GRAPH_COLLECTIVE", "1") == "1" and dist.get_backend() == "nccl":
             # the experiment: the all-reduce captured INSIDE the graphs (whole iterations as one graph)
             loop = FusedRenderAndCompare(s["decoder"], s["camera"], s["config"], s["targets"], process_group="world",
@@ -64,12 +72,7 @@ def main():
                                                       else f"refused: {loop.graph_collective_error}")
             out[f"final_position_error_mm_{exchange}_collective_in_graph"] = round(
                 (res[0] - s["p_true"]).norm().item() * 1e3, 3)
-    # the single-process loop of the same views, in both of its forms (every rank runs them: time_loop has barriers)
-    for form in ("tail", "records"):
-        if form == "tail" and views > 64:
-            continue
-        single = FusedRenderAndCompare(s["decoder"], s["camera"], s["config"], s["targets"], form=form)
-        out[f"ms_per_iteration_single_process_{form}_form"], _ = time_loop(single)
+            del loop
     if rank == 0:
         print(json.dumps(out), flush=True)
     dist.barrier()
