@@ -474,6 +474,34 @@ def objects_side_by_side(sc):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+def views_of_one_object():
+    """The same loop seeing ONE object from V cameras (the C5 image V times; simple_setup.py:408-434 loops over the
+    views in Python): ms per iteration of 50, new observation included, and the final position error."""
+    try:
+        from sdfest_amd.pipeline import FusedRenderAndCompare
+        rows = []
+        for V in (4, 8, 16):
+            s = c5_scene(views=V, max_iterations=50)
+            loop = FusedRenderAndCompare(s["decoder"], s["camera"], s["config"], s["targets"])
+            loop(*s["init"])
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                loop.rebind(s["targets"])
+                out = loop(*s["init"])
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            t = float(np.median(ts))
+            rows.append({"views": V, "ms_new_observation_total": round(t * 1e3, 3), "ms_per_iteration": round(t / 50 * 1e3, 4),
+                         "final_position_error_mm": round(float((out[0] - s["p_true"]).norm()) * 1e3, 3)})
+            del loop, s
+            torch.cuda.empty_cache()
+        return rows
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def c5_config(hbm_peak):
     """C5: the whole render-and-compare loop (simple_setup.py:408-470) as one hipGraph per iteration, 50 Adam
     iterations, mug decoder; ms per iteration, the final pose error, and TIME TO RESULT the way the reference is used
@@ -523,6 +551,7 @@ def c5_config(hbm_peak):
     assert fused.graph is graph     # nothing was captured again
     front_door = front_door_times(sc, others)
     side_by_side = objects_side_by_side(sc)
+    several_views = views_of_one_object()
     q = out[1] / out[1].norm()
     dot = float(torch.abs((q * sc["q_true"]).sum()).clamp(max=1.0))
     # algorithmic bytes of one iteration: render fwd+bwd of one view + decoder weights + volume
@@ -536,6 +565,7 @@ def c5_config(hbm_peak):
             "ms_rebind_host": round(float(np.median(rebinds)), 3),
             "front_door": front_door,
             "objects_side_by_side": side_by_side,
+            "views_of_one_object": several_views,
             "time_to_result": "ms_first_call_total = constructor (buffers at capacity) + warm-up iteration + graph "
                               "captures + 50 iterations, first use of these kernels in the process; "
                               "ms_new_observation_total = rebind(new 640x480 image already in HBM) + 50 iterations "
