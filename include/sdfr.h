@@ -384,10 +384,16 @@ SDFR_API int sdfr_decoder_forward(const sdfr_decoder* decoder, const float* z, i
  *   SDFR_DECODER_OPT_FC_ONE_WAVE   1 (default): the backward of a NARROW Linear stack (every layer input <= 64 wide, e.g.
  *                                  the mug decoder's 8 -> 20 -> 50) runs as one wave out of LDS -- in
  *                                  sdfr_decoder_backward_latent and inside sdfr_loop_tail[_records]; 0: the one-workgroup
- *                                  form wider stacks take */
+ *                                  form wider stacks take
+ *   SDFR_DECODER_OPT_FUSED_SINGLE  few latents (the render-and-compare loop decodes ONE): layer pairs as one launch each,
+ *                                  the producer recomputed under the consumer's tile.  Bits (default 7, all):
+ *                                  1 an up-sampling resize + the 3x3x3 convolution behind it (sdf_vae.py:235-246),
+ *                                  2 the Linear stack + the first convolution (:223-238), 4 in the VJP a transposed
+ *                                  resize (+ ReLU mask, swapped 1x1x1 layer, padding) + the transposed convolution */
 #define SDFR_DECODER_OPT_FUSED_RESIZE 0
 #define SDFR_DECODER_OPT_TILED_VJP 1
 #define SDFR_DECODER_OPT_FC_ONE_WAVE 2
+#define SDFR_DECODER_OPT_FUSED_SINGLE 3
 SDFR_API int sdfr_decoder_set_option(sdfr_decoder* decoder, int option, int value);
 /* Vector-Jacobian product of the decoder w.r.t. the latent, weights held constant: what
  * loss.backward() propagates to latent_shape in SDFPipeline.__call__

@@ -69,6 +69,9 @@ struct sdfr_decoder {
   // which of two equivalent kernel forms a call takes (sdfr_decoder_set_option; the defaults are the measured-faster
   // ones, results are the same bit for bit): per HANDLE, so that nothing one caller selects reaches another's decoder
   mutable std::atomic<int> opt_fused_resize{1}, opt_tiled_vjp{1}, opt_fc_one_wave{1};
+  // bits: 1 resize + convolution (conv3d_mfma_up_kernel), 2 Linear stack + first convolution (fc_conv_kernel),
+  // 4 transposed resize + transposed convolution of the VJP (conv3d_mfma_tresize_kernel) -- few latents only
+  mutable std::atomic<int> opt_fused_single{0};   // (0 until the fused forms are the faster ones)
 };
 
 namespace sdfr {
@@ -1702,6 +1705,8 @@ __global__ __launch_bounds__(64) void fc_stack_backward_wave_kernel(const float*
                              g_z + (size_t)n * d.width[0], threadIdx.x);
 }
 
+#include "decoder_fused.hpp"   // the single decode's layer pairs as one launch each (round 6)
+
 }  // namespace
 }  // namespace sdfr
 
@@ -1852,6 +1857,184 @@ bool launch_direct_up(const sdfr_decoder* d, size_t w_off, const float* src, int
 #undef SDFR_DIRECT_UP
   return true;
 }
+
+// ---- few latents: layer pairs as one launch each (decoder_fused.hpp) --------------------------------------------------
+constexpr size_t kFusedLdsMax = 150 * 1024;
+
+// the kernel's dynamic-LDS limit raised once (above 64 KiB it must be; `bytes` + the kernel's static LDS <= 160 KiB);
+// false: the runtime refused, take the unfused form
+bool fused_lds_limit(const void* fn, size_t bytes = kFusedLdsMax) {
+  static std::map<const void*, bool> done;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = done.find(fn);
+  if (it == done.end()) {
+    const bool ok = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+    if (!ok) (void)hipGetLastError();   // (not an error of the call that asked: it takes the other form)
+    it = done.emplace(fn, ok).first;
+  }
+  return it->second;
+}
+
+// resize_axis on the host (the kernels' float arithmetic)
+void host_resize_axis(int dd, float ratio, int ni, int& i0, int& i1, float& l1) {
+  float sp = fmaf(ratio, (float)dd + 0.5f, -0.5f);
+  sp = sp < 0.0f ? 0.0f : sp;
+  i0 = std::min((int)sp, ni - 1);
+  i1 = i0 + (i0 < ni - 1 ? 1 : 0);
+  l1 = sp - (float)i0;
+}
+
+// resize ni -> n + the 3x3x3 convolution n -> m behind it in one launch (conv3d_mfma_up_kernel): true if launched.
+// Only where the unfused convolution takes its split-K form (the arithmetic this kernel reproduces).
+bool launch_mfma_up(const sdfr_decoder* d, const float* src, int ni, const float* w, const float* bias, float* dst, int cin,
+                    int cout, int n, int m, int kpad, int relu, int N, hipStream_t st) {
+  if (!(d->opt_fused_single.load(std::memory_order_relaxed) & 1)) return false;
+  if (ni > n || ni < 1 || m != n - 2 || m < 1) return false;
+  const int co_tiles = (cout + 15) / 16, ZT = (m + 15) / 16;
+  if (ZT > 4 || !use_split_k(false, (m * m * m + 15) / 16, co_tiles, N, kpad)) return false;
+  const float ratio = (float)ni / (float)n;
+  int CX = 1;
+  for (int x = 0; x < m; ++x) {
+    int lo, hi, t;
+    float f;
+    host_resize_axis(x, ratio, ni, lo, t, f);
+    host_resize_axis(x + 2, ratio, ni, t, hi, f);
+    CX = std::max(CX, hi - lo + 1);
+  }
+  const int PZ = 16 * ZT + 2, patch_n = cin * 9 * PZ;
+  const size_t coarse_n = (size_t)cin * CX * CX * ni;
+  if (coarse_n >= 65536 || patch_n >= 65536) return false;   // (the kernel's reciprocal divisions)
+  const size_t lds = ((size_t)kpad * 16 + 1024 * ZT + ((patch_n + patch_slack(ZT) + 3) & ~3) + coarse_n) * sizeof(float);
+  const void* fn = reinterpret_cast<const void*>(&conv3d_mfma_up_kernel);
+  if (lds > kFusedLdsMax || !fused_lds_limit(fn)) return false;
+  hipLaunchKernelGGL(conv3d_mfma_up_kernel, dim3(m * m, co_tiles, N), dim3(256 * ZT), lds, st, src, ni, w, bias, dst, cin,
+                     cout, n, m, kpad, relu, CX, ZT);
+  return true;
+}
+
+// the Linear stack + the first convolution in one launch (fc_conv_kernel): true if launched
+bool launch_fc_conv(const sdfr_decoder* d, const FcDesc& fd, const float* z, float* fc_out, const float* w,
+                    const float* bias, float* dst, int cin, int cout, int n, int kpad, int relu, int N, hipStream_t st) {
+  if (!(d->opt_fused_single.load(std::memory_order_relaxed) & 2)) return false;
+  const int m = n - 2;
+  if (m < 1 || !decoder_fc_one_wave(d, fd)) return false;
+  const int co_tiles = (cout + 15) / 16, ZT = (m + 15) / 16;
+  if (ZT > 4 || !use_split_k(false, (m * m * m + 15) / 16, co_tiles, N, kpad)) return false;
+  const int PZ = 16 * ZT + 2, patch_n = cin * 9 * PZ;
+  if (patch_n >= 65536) return false;
+  const size_t lds = ((size_t)kpad * 16 + 1024 * ZT + ((patch_n + patch_slack(ZT) + 3) & ~3)) * sizeof(float);
+  const int wout = fd.width[fd.n_fc];
+  const float* wt = d->d_params + fd.w_off[fd.n_fc - 1];
+  const float* bl = d->d_params + fd.b_off[fd.n_fc - 1];
+  const bool vec4 = (n & 3) == 0 && (wout & 3) == 0 &&
+                    (((uintptr_t)wt | (uintptr_t)bl | (uintptr_t)fc_out) & 15) == 0;
+  // rows of the wide layer per thread: one (vector) item each where the workgroup size allows
+  const int items = cin * 9 * (vec4 ? n / 4 : n);
+  int threads = 256 * ZT;
+  while (threads < 1024 && threads < items) threads *= 2;
+  const void* fn = vec4 ? reinterpret_cast<const void*>(&fc_conv_kernel<true>) : reinterpret_cast<const void*>(&fc_conv_kernel<false>);
+  if (lds > 100 * 1024 || !fused_lds_limit(fn, 100 * 1024)) return false;   // (+ 25 KB static)
+  if (vec4) hipLaunchKernelGGL(fc_conv_kernel<true>, dim3(m * m, co_tiles, N), dim3(threads), lds, st, d->d_params, fd, z,
+                               fc_out, w, bias, dst, cin, cout, n, m, kpad, relu, ZT);
+  else hipLaunchKernelGGL(fc_conv_kernel<false>, dim3(m * m, co_tiles, N), dim3(threads), lds, st, d->d_params, fd, z,
+                          fc_out, w, bias, dst, cin, cout, n, m, kpad, relu, ZT);
+  return true;
+}
+
+// The VJP's transposed resize n_out -> n_in of C channels (+ ReLU mask `act`, + the swapped 1x1x1 layer C = 1 -> mix_cout
+// channels, + zero padding) and the transposed convolution of layer lc that reads it, in one launch
+// (conv3d_mfma_tresize_kernel): the plan, or ok == false where the pair keeps its two launches.
+struct TresizePlan {
+  bool ok = false;
+  int taps = 0, split = 0, CK = 0, FX = 0, ZT = 0, threads = 0;
+  size_t lds = 0;
+};
+TresizePlan tresize_conv_plan(const sdfr_decoder* d, int lc, int C, int n_in, int n_out, int mix_cout, int N,
+                              const float* g) {
+  TresizePlan p;
+  if (!(d->opt_fused_single.load(std::memory_order_relaxed) & 4)) return p;
+  const int k = d->conv_k[lc], ci_n = d->conv_cin[lc], co_n = d->conv_cout[lc];
+  const int CP = mix_cout > 0 ? mix_cout : C;
+  if (k != 3 || d->conv_swap[lc] || CP != co_n || (mix_cout > 0 && (C != 1 || mix_cout > 4))) return p;
+  if (n_in != d->conv_in_size[lc] - k + 1 || n_in > n_out || n_in > 64 || (n_out & 3) || ((uintptr_t)g & 15)) return p;
+  const int pad = k - 1, np = n_in + 2 * pad, nc = np - 2, kpad = d->bwd_kpad[lc], ci_tiles = (ci_n + 15) / 16;
+  // the form the unfused transposed convolution takes: plain or split-K only (not the direct, not the z-grouped one)
+  if (direct_ok(d->bwd_direct_off[lc], np, nc, N)) return p;
+  p.split = use_split_k(false, (nc * nc * nc + 15) / 16, ci_tiles, N, kpad);
+  const sdfr_decoder::ZPlan& zp = d->bwd_z[lc];
+  if (!p.split && zp.zg > 1 && (long long)nc * nc * (nc / zp.zg) * N >= kZGroupMinRows) return p;
+  if (!p.split && (nc * nc * nc + 15) / 16 >= 32768) return p;   // (tiles_per_wave 4: never for few latents)
+  if (N > SDFR_SPLITK_MAX_LATENTS) return p;
+  p.ZT = (nc + 15) / 16;
+  if (p.ZT > 4) return p;
+  // source ranges (resize_sources / resize_weight on the host)
+  const float ratio = (float)n_in / (float)n_out, inv = (float)n_out / (float)n_in;
+  auto weight = [&](int dd, int i) {
+    int i0, i1;
+    float l1;
+    host_resize_axis(dd, ratio, n_in, i0, i1, l1);
+    return (i0 == i ? 1.0f - l1 : 0.0f) + (i1 == i ? l1 : 0.0f);
+  };
+  std::vector<int> lo(n_in), hi(n_in);
+  int max_taps = 1, max_span = 1;
+  for (int i = 0; i < n_in; ++i) {
+    int d0 = std::max((int)floorf(((float)i - 0.5f) * inv - 0.5f) - 1, 0);
+    int d1 = std::min((int)ceilf(((float)i + 1.5f) * inv - 0.5f) + 1, n_out - 1);
+    max_span = std::max(max_span, d1 - d0 + 1);
+    while (d0 <= d1 && weight(d0, i) == 0.0f) ++d0;
+    while (d1 >= d0 && weight(d1, i) == 0.0f) --d1;
+    if (d0 > d1) return p;
+    lo[i] = d0; hi[i] = d1;
+    max_taps = std::max(max_taps, d1 - d0 + 1);
+  }
+  if (max_span > 16 || max_taps > kBtTaps) return p;
+  p.taps = max_taps <= 6 ? 6 : 12;
+  for (int x = 0; x < nc; ++x) p.FX = std::max(p.FX, hi[std::min(x, n_in - 1)] - lo[std::max(x - pad, 0)] + 1);
+  // channels per round and workgroup size: the whole tensor in one round where the LDS allows
+  const int PZ = 16 * p.ZT + 2, patch_n = CP * 9 * PZ;
+  const int min_thr = p.split ? 256 * p.ZT : 256;
+  const size_t fixed = (size_t)kpad * 16 + (p.split ? 1024 * p.ZT : 0) + ((patch_n + patch_slack(p.ZT) + 3) & ~3);
+  for (int CK = C; CK >= 1; --CK) {
+    const size_t yf = (((size_t)CK * p.FX * 3 * n_in + 3) & ~(size_t)3) + (size_t)CK * p.FX * p.FX * n_out;
+    const size_t total4 = (size_t)CK * p.FX * p.FX * (n_out >> 2);
+    if ((fixed + yf) * sizeof(float) > kFusedLdsMax || total4 >= 65536 || (size_t)CK * 9 * n_in >= 65536) continue;
+    p.CK = CK;
+    p.lds = (fixed + yf) * sizeof(float);
+    p.threads = min_thr;
+    while (p.threads < (p.split ? 1024 : 512) && (size_t)p.threads * 8 < total4) p.threads *= 2;
+    break;
+  }
+  if (!p.CK || patch_n >= 65536) return p;
+  p.ok = true;
+  return p;
+}
+
+bool launch_tresize_conv(const sdfr_decoder* d, const TresizePlan& p, int lc, const float* g, int C, int n_in, int n_out,
+                         const float* act, const float* mix_w, int mix_cout, float* dst, int N, hipStream_t st) {
+  const int ci_n = d->conv_cin[lc], ci_tiles = (ci_n + 15) / 16, pad = d->conv_k[lc] - 1, nc = n_in + 2 * pad - 2;
+  const float* wb = d->d_params + d->bwd_w_off[lc];
+  const float* zb = d->d_params + d->zero_bias_off;
+  const dim3 grid(nc * nc, ci_tiles, N), block(p.threads);
+#define SDFR_TR(CO, TAPS, SPLIT)                                                                                       \
+  do {                                                                                                                 \
+    const void* fn = reinterpret_cast<const void*>(&conv3d_mfma_tresize_kernel<CO, TAPS, SPLIT>);                      \
+    if (!fused_lds_limit(fn)) return false;                                                                            \
+    hipLaunchKernelGGL((conv3d_mfma_tresize_kernel<CO, TAPS, SPLIT>), grid, block, p.lds, st, g, C, n_in, n_out, act, \
+                       pad, mix_w, zb, wb, zb, dst, ci_n, d->bwd_kpad[lc], p.CK, p.FX, p.ZT);                           \
+  } while (0)
+#define SDFR_TR_S(CO, TAPS) { if (p.split) SDFR_TR(CO, TAPS, true); else SDFR_TR(CO, TAPS, false); }
+#define SDFR_TR_T(CO) { if (p.taps == 6) SDFR_TR_S(CO, 6) else SDFR_TR_S(CO, 12) }
+  if (mix_cout == 0) SDFR_TR_T(0)
+  else if (mix_cout == 1) SDFR_TR_T(1)
+  else if (mix_cout == 2) SDFR_TR_T(2)
+  else if (mix_cout == 3) SDFR_TR_T(3)
+  else SDFR_TR_T(4)
+#undef SDFR_TR_T
+#undef SDFR_TR_S
+#undef SDFR_TR
+  return true;
+}
 }  // namespace
 
 extern "C" int sdfr_decoder_set_option(sdfr_decoder* d, int option, int value) {
@@ -1863,6 +2046,8 @@ extern "C" int sdfr_decoder_set_option(sdfr_decoder* d, int option, int value) {
       return d->opt_tiled_vjp.exchange(value ? 1 : 0, std::memory_order_relaxed);
     case SDFR_DECODER_OPT_FC_ONE_WAVE:
       return d->opt_fc_one_wave.exchange(value ? 1 : 0, std::memory_order_relaxed);
+    case SDFR_DECODER_OPT_FUSED_SINGLE:
+      return d->opt_fused_single.exchange(value & 7, std::memory_order_relaxed);
     default:
       return fail(SDFR_E_INVALID, "sdfr_decoder_set_option: unknown option %d", option);
   }
@@ -2181,7 +2366,21 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
   const int last = d->fc_out[d->n_fc - 1];
   // with a tape, every ReLU'd layer output goes to its own slot (and is read from there)
   const float* act_in;
-  {
+  int l_first = 0;   // the first conv layer the loop below still has to run
+  // few latents: the Linear stack and the first convolution as one launch (fc_conv_kernel) -- a 3x3x3 layer that is not
+  // the last, with a layer behind it that is not a 1x1x1 one swapped with its resize
+  if (d->n_conv >= 2 && !d->conv_swap[0] && d->conv_k[0] == 3 && !(d->conv_swap[1] && d->conv_k[1] == 1) &&
+      N < 32 && d->conv_in_size[0] - 2 != d->volume) {
+    float* fc_dst = tape ? tape + (size_t)N * d->tape_fc_off : nullptr;
+    float* dst0 = tape ? tape + (size_t)N * d->tape_conv_off[0] : buf[cur ^ 1];
+    if (launch_fc_conv(d, fd, z, fc_dst, d->d_params + d->conv_w_off[0], d->d_params + d->conv_b_off[0], dst0,
+                       d->conv_cin[0], d->conv_cout[0], d->conv_in_size[0], d->conv_kpad[0], d->conv_relu[0], N, st)) {
+      if (dst0 == buf[cur ^ 1]) cur ^= 1;
+      act_in = dst0;
+      l_first = 1;
+    }
+  }
+  if (l_first == 0) {
     float* fc_dst = tape ? tape + (size_t)N * d->tape_fc_off : buf[cur];
     int hid = d->latent;   // widest input of a layer
     for (int l = 0; l + 1 < d->n_fc; ++l) hid = std::max(hid, d->fc_out[l]);
@@ -2206,6 +2405,7 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
 
   const float clampv = (enforce_tsdf && d->tsdf > 0.0f) ? d->tsdf : 0.0f;
   int c = d->conv_cin[0], n = d->conv_in_size[0];
+  if (l_first == 1) { c = d->conv_cout[0]; n = d->conv_in_size[0] - d->conv_k[0] + 1; }
   const size_t vox = (size_t)d->volume * d->volume * d->volume;
   auto resize = [&](const float* src, int C, int ni, int no, int relu, float clamp, float* dst) {
     // input columns under an 8 x 8 output patch, worst tile (same float arithmetic as the kernel)
@@ -2252,7 +2452,7 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
                        ni, no, relu, clamp, dst);
   };
   bool premixed = false;   // the previous layer's epilogue has applied this (1x1x1) layer already: act_in is its output
-  for (int l = 0; l < d->n_conv; ++l) {
+  for (int l = l_first; l < d->n_conv; ++l) {
     const bool swap = d->conv_swap[l] != 0, is_last = (l == d->n_conv - 1);
     const int k = d->conv_k[l], co_n = d->conv_cout[l], kpad = d->conv_kpad[l];
     // (batches: an up-sampling resize in front of a 3x3x3 layer is folded into that layer's patch load --
@@ -2266,6 +2466,16 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
       fused_up = launch_direct_up(d, d->fwd_direct_off[l], act_in, n, d->d_params + d->conv_b_off[l], cdst, c, co_n,
                                   nf, mf, d->conv_relu[l], N, st);
       if (fused_up) n = nf;   // (act_in stays the coarse tensor: the launch has consumed it)
+    }
+    // few latents: the resize inside the split-K MFMA convolution's operand fetch (conv3d_mfma_up_kernel)
+    if (!fused_up && !swap && n != d->conv_in_size[l] && k == 3) {
+      const int nf = d->conv_in_size[l], mf = nf - k + 1;
+      const bool to_out_f = is_last && mf == d->volume && clampv == 0.0f;
+      float* ldst = to_out_f ? out : (tape ? tape + (size_t)N * d->tape_conv_off[l] : nullptr);
+      float* cdst = ldst ? ldst : buf[cur ^ 1];
+      fused_up = launch_mfma_up(d, act_in, n, d->d_params + d->conv_w_off[l], d->d_params + d->conv_b_off[l], cdst, c,
+                                co_n, nf, mf, kpad, d->conv_relu[l], N, st);
+      if (fused_up) n = nf;
     }
     if (!swap && n != d->conv_in_size[l]) {
       resize(act_in, c, n, d->conv_in_size[l], 0, 0.0f, buf[cur ^ 1]);
@@ -2604,6 +2814,14 @@ int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* ta
     return direct ? (np + 3) & ~3 : np;
   };
   bool padded = false;  // g already is layer l's padded, masked output gradient (written by the resize above)
+  // few latents: a transposed resize whose output only the transposed convolution of the layer below reads is not
+  // launched -- it is left pending and runs inside that convolution's launch (conv3d_mfma_tresize_kernel)
+  struct {
+    bool on = false;
+    TresizePlan plan;
+    const float *g = nullptr, *act = nullptr, *mix_w = nullptr;
+    int C = 0, n_in = 0, n_out = 0, mix_cout = 0;
+  } pend;
   int n = d->volume;
   if (out_n[d->n_conv - 1] != d->volume) {  // final resize
     const int ni = out_n[d->n_conv - 1];
@@ -2620,7 +2838,17 @@ int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* ta
     const int pz = swap ? np : pitch_of(l);         // ... and the floats between its z-rows
     // 1. ReLU' and zero padding of the output gradient
     const float* act = d->conv_relu[l] ? tape + (size_t)N * d->tape_conv_off[l] : nullptr;
-    if (padded) {
+    bool conv_done = false;
+    if (pend.on) {   // steps 1 and 2 in one launch with the transposed resize above them
+      pend.on = false;
+      if (!launch_tresize_conv(d, pend.plan, l, pend.g, pend.C, pend.n_in, pend.n_out, pend.act, pend.mix_w,
+                               pend.mix_cout, buf[cur], N, st))
+        return fail(SDFR_E_INVALID, "sdfr_decoder_backward_latent: the fused transposed resize could not be launched");
+      g = buf[cur];
+      cur ^= 1;
+      n = nconv;
+      conv_done = true;
+    } else if (padded) {
       padded = false;
     } else if (!swap || act) {
       const size_t cntp = (size_t)co_n * (swap ? m : np) * (swap ? m : np) * (swap ? m : pz);
@@ -2636,6 +2864,15 @@ int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* ta
                      d->conv_cout[l - 1] == ci_n && prev != nin &&
                      ((size_t)N * co_n * nin * nin * nin <= kFewElements || co_n == 1);
     if (mix) {
+      const float* act_below = d->conv_relu[l - 1] ? tape + (size_t)N * d->tape_conv_off[l - 1] : nullptr;
+      pend.plan = tresize_conv_plan(d, l - 1, co_n, prev, nin, ci_n, N, g);
+      if (pend.plan.ok) {
+        pend.on = true;
+        pend.g = g; pend.act = act_below; pend.mix_w = d->d_params + d->bwd_w_off[l];
+        pend.C = co_n; pend.n_in = prev; pend.n_out = nin; pend.mix_cout = ci_n;
+        n = prev;
+        continue;
+      }
       resize_backward(co_n, prev, nin, d->conv_k[l - 1] - 1,
                       d->conv_relu[l - 1] ? tape + (size_t)N * d->tape_conv_off[l - 1] : nullptr,
                       d->d_params + d->bwd_w_off[l], ci_n, pitch_of(l - 1));
@@ -2646,7 +2883,9 @@ int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* ta
     if (swap) resize_backward(co_n, prev, nin);
     // 2. data gradient = valid conv (kernel k) of the padded tensor with the flipped weights
     const int kpad = d->bwd_kpad[l];
-    if (k == 1 && ci_n <= 4) {
+    if (conv_done) {
+      // (launched above)
+    } else if (k == 1 && ci_n <= 4) {
       // transposed 1x1 layer: element-wise, like its forward (the MFMA form: 207 us per 256 latents, this: ~35)
       const int voxn = np * np * np;
       const dim3 g1((voxn + 255) / 256, N);
@@ -2672,15 +2911,23 @@ int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* ta
                   d->d_params + d->zero_bias_off, buf[cur], co_n, ci_n, np, nconv, kp, 0, nt,
                   zgrp ? 1 : (ci_n + 15) / 16, zgrp ? zp.zg : 1, split, N, st);
     }
-    g = buf[cur];
-    cur ^= 1;
+    if (!conv_done) {
+      g = buf[cur];
+      cur ^= 1;
+    }
     n = nconv;
     // 3. the resize in front of this layer, if any
     if (!swap && prev != nin) {
       // the layer below (l - 1) produced this tensor: if its transposed convolution is of the padded kind,
       // the last resize pass writes its input directly
       const bool fuse = l > 0 && !d->conv_swap[l - 1] && out_n[l - 1] == prev && d->conv_cout[l - 1] == ci_n;
-      if (fuse) {
+      if (fuse) pend.plan = tresize_conv_plan(d, l - 1, ci_n, prev, nin, 0, N, g);
+      if (fuse && pend.plan.ok) {
+        pend.on = true;
+        pend.g = g; pend.act = d->conv_relu[l - 1] ? tape + (size_t)N * d->tape_conv_off[l - 1] : nullptr;
+        pend.mix_w = nullptr;
+        pend.C = ci_n; pend.n_in = prev; pend.n_out = nin; pend.mix_cout = 0;
+      } else if (fuse) {
         resize_backward(ci_n, prev, nin, d->conv_k[l - 1] - 1,
                         d->conv_relu[l - 1] ? tape + (size_t)N * d->tape_conv_off[l - 1] : nullptr, nullptr, 0,
                         pitch_of(l - 1));

@@ -46,6 +46,22 @@ SDF_GRAD_DETERMINISTIC = 0x100    # flag bit: integer accumulation of d/dSDF, bi
 FIXED_QUANTUM_BITS = 40
 BWD_HALF_GRID = 0x200             # flag bit: performance hint "every view is close" (views_are_close)
 BWD_SMALL_TILES = 0x400           # flag bit: 32 x 8 backward tiles whatever the batch (pose sums independent of it)
+
+
+def parse_sdf_grad_mode(value) -> int:
+    """``config["sdf_grad_mode"]`` of the pipelines -> SDF_GRAD_EXACT / SDF_GRAD_CUDA_COMPAT: "exact" (default; the
+    numpy twin's weights, simple_renderer.py:399-408) or "cuda_compat" (the weights the reference's GPU extension adds,
+    sdf_renderer_cuda.cu:373-388 -- what produced the published system's latent trajectories); 0 / 1 are accepted too."""
+    if value is None:
+        return SDF_GRAD_EXACT
+    if isinstance(value, str):
+        names = {"exact": SDF_GRAD_EXACT, "cuda_compat": SDF_GRAD_CUDA_COMPAT}
+        if value not in names:
+            raise ValueError(f"sdf_grad_mode {value!r}: expected 'exact' or 'cuda_compat'")
+        return names[value]
+    if int(value) not in (SDF_GRAD_EXACT, SDF_GRAD_CUDA_COMPAT):
+        raise ValueError(f"sdf_grad_mode {value!r}: expected 0 (exact) or 1 (cuda_compat)")
+    return int(value)
 VIEW_RECORD_FLOATS = 20           # SDFR_VIEW_RECORD_FLOATS: the sharded loop's exchange record of one view
 
 
@@ -289,8 +305,10 @@ class SDFRendererFunctionGPU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sdf: torch.Tensor, position: torch.Tensor, orientation: torch.Tensor,
                 inv_scale: torch.Tensor, threshold: Optional[float] = 0.0,
-                camera: Optional[Camera] = None) -> torch.Tensor:
+                camera: Optional[Camera] = None, sdf_grad_mode: Optional[int] = None) -> torch.Tensor:
+        # sdf_grad_mode (not in the reference's signature): None = the module-wide render_depth_gpu.sdf_grad_mode
         _check_inputs((sdf, "sdf"), (position, "position"), (orientation, "orientation"), (inv_scale, "inv_scale"))
+        ctx.sdf_grad_mode = sdf_grad_mode
         fx, fy, cx, cy, _ = camera.get_pinhole_camera_parameters(0.5)
         # the pair forward / backward of one view is one step (sdfr_render_step_*: 4 launches instead of 5)
         ctx.step = None
@@ -313,28 +331,32 @@ class SDFRendererFunctionGPU(torch.autograd.Function):
         g_sdf, g_p, g_q, g_is = step_backward_raw(
             step, grad_depth_image.contiguous().reshape(1, h, w), image.reshape(1, h, w), sdf,
             position.reshape(1, 3), orientation.reshape(1, 4), inv_scale.reshape(1), w, h, cx, cy,
-            fx, fy, render_depth_gpu.sdf_grad_mode)
+            fx, fy, render_depth_gpu.sdf_grad_mode if ctx.sdf_grad_mode is None else ctx.sdf_grad_mode)
         # gradients come back in the shape of the inputs ((4,) or (1,4); () or (1,))
         return (g_sdf, g_p.reshape(position.shape), g_q.reshape(orientation.shape),
-                g_is.reshape(inv_scale.shape), None, None)
+                g_is.reshape(inv_scale.shape), None, None, None)
 
 
 def render_depth_gpu(sdf: torch.Tensor, position: torch.Tensor, orientation: torch.Tensor,
                      inv_scale: torch.Tensor, width: Optional[int] = None,
                      height: Optional[int] = None, fov_deg: Optional[float] = None,
-                     threshold: Optional[float] = 0.0, camera: Optional[Camera] = None):
+                     threshold: Optional[float] = 0.0, camera: Optional[Camera] = None,
+                     sdf_grad_mode: Optional[int] = None):
     """Render a depth image of a 7-DOF discrete SDF (drop-in for sdf_renderer.py:360-424).
 
     The SDF pose is given in the camera frame under the OpenGL convention; the first image
     row is up.  Give either ``camera`` or ``width``+``height``+``fov_deg`` (horizontal fov,
     square pixels).  Differentiable w.r.t. sdf, position, orientation and inv_scale.
+    sdf_grad_mode (beyond the reference's signature): which d depth / d sdf weights the backward uses for THIS call
+    -- ``SDF_GRAD_EXACT`` (the numpy twin's, simple_renderer.py:399-408) or ``SDF_GRAD_CUDA_COMPAT`` (what the
+    reference's GPU extension really adds, sdf_renderer_cuda.cu:373-388); None: ``render_depth_gpu.sdf_grad_mode``.
     """
     if None not in [width, height, fov_deg] and camera is not None:
         raise ValueError("Either width+height+fov_dev or camera must be provided.")
     if camera is None:
         f = width / math.tan(fov_deg * math.pi / 180.0 / 2.0) / 2
         camera = Camera(width, height, f, f, width / 2, height / 2, pixel_center=0.5)
-    return SDFRendererFunctionGPU.apply(sdf, position, orientation, inv_scale, threshold, camera)
+    return SDFRendererFunctionGPU.apply(sdf, position, orientation, inv_scale, threshold, camera, sdf_grad_mode)
 
 
 # d depth / d sdf weights: 0 = exact (numpy twin), 1 = the CUDA kernel's permutation (SURVEY F4)

@@ -1054,7 +1054,7 @@ class MultiObjectRenderAndCompare:
     device); ``__call__`` replays captured graphs."""
 
     def __init__(self, decoder, camera: Camera, config: Dict, objects: int, shape_optimization: bool = True,
-                 device="cuda", graph_iterations: int = 5):
+                 device="cuda", graph_iterations: int = 5, sdf_grad_mode: int = 0):
         from . import _lib
         from .differentiable_renderer import BatchRenderPlan
         self.L, self.check = _lib.lib(), _lib.check
@@ -1091,7 +1091,9 @@ class MultiObjectRenderAndCompare:
         self.offsets = torch.zeros(K + 1, **i32)
         self.counts = torch.zeros(K, **i32)
         self.ws_points = torch.empty(max(self.L.sdfr_depth_points_workspace_bytes(K, W, H), 256), **u8)
-        self.plan = BatchRenderPlan(R, K, camera, device=self.dev, per_view_sdf=True, close_views=False)
+        self.sdf_grad_mode = int(sdf_grad_mode)     # SDF_GRAD_EXACT / SDF_GRAD_CUDA_COMPAT
+        self.plan = BatchRenderPlan(R, K, camera, device=self.dev, per_view_sdf=True, close_views=False,
+                                    sdf_grad_mode=self.sdf_grad_mode)
         self.pos_c = torch.empty((K, 3), **f32)
         self.quat_c = torch.empty((K, 4), **f32)
         self.inv_scale = torch.empty((K,), **f32)

@@ -23,7 +23,7 @@ from typing import Dict, Mapping, Optional, Tuple
 
 import torch
 
-from .differentiable_renderer import Camera, render_depth_gpu
+from .differentiable_renderer import Camera, parse_sdf_grad_mode, render_depth_gpu
 from .init_network import NoDepthError, ResidentInit, SDFPoseNet, adjust_categorical_posterior, nn_init
 from .pipeline import FusedRenderAndCompare, MultiObjectRenderAndCompare, _selection_strategy, preprocess_depth
 from .vae import SDFDecoder
@@ -91,7 +91,7 @@ class SDFPipeline:
         self.cam = Camera(**self.camera_config)
         # a plain attribute, as in the reference (:84-86; real_data.py:230-243 replaces it at run time)
         self.render = lambda sdf, pos, quat, i_s: render_depth_gpu(
-            sdf, pos, quat, i_s, None, None, None, config["threshold"], self.cam)
+            sdf, pos, quat, i_s, None, None, None, config["threshold"], self.cam, self.sdf_grad_mode)
         self.config = config
         self.log_data = []
         self._loops = {}     # (views, shape_optimization) -> the captured loop, re-bound per call
@@ -113,6 +113,7 @@ class SDFPipeline:
         # (the reference sets _far_field only when the key exists and then reads it unconditionally, :106-107, :692:
         # without the key its _preprocess_depth raises AttributeError; None here = no far-field clipping)
         self._far_field = config.get("far_field")
+        self.sdf_grad_mode = parse_sdf_grad_mode(config.get("sdf_grad_mode"))
         self.config = config
 
     # ---- the reference's helpers, same names ------------------------------------------------------------------
@@ -155,7 +156,8 @@ class SDFPipeline:
         loop = self._loops.get(key)
         if loop is None:
             loop = FusedRenderAndCompare(self.vae, self.cam, self.config, views=views,
-                                         shape_optimization=shape_optimization, device=self._dev)
+                                         shape_optimization=shape_optimization, device=self._dev,
+                                         sdf_grad_mode=self.sdf_grad_mode)
             self._loops[key] = loop
         return loop
 
@@ -252,8 +254,9 @@ class SDFPipeline:
         key = (K, bool(shape_optimization))
         loop = self._multi_loops.get(key)
         if loop is None:
-            loop = self._multi_loops[key] = MultiObjectRenderAndCompare(self.vae, self.cam, self.config, K,
-                                                                        shape_optimization=shape_optimization, device=dev)
+            loop = self._multi_loops[key] = MultiObjectRenderAndCompare(
+                self.vae, self.cam, self.config, K, shape_optimization=shape_optimization, device=dev,
+                sdf_grad_mode=self.sdf_grad_mode)
         with torch.no_grad():
             frames = depth_image.to(device=dev, dtype=torch.float32)[None].expand(K, -1, -1).contiguous()
             loop.rebind(frames, camera_position, camera_orientation, masks=masks, far_field=self._far_field)

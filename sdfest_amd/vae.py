@@ -99,7 +99,7 @@ class SDFDecoder:
             self._L.sdfr_decoder_destroy(h)
             self._h = None
 
-    OPTIONS = {"fused_resize": 0, "tiled_vjp": 1, "fc_one_wave": 2}     # SDFR_DECODER_OPT_* (include/sdfr.h)
+    OPTIONS = {"fused_resize": 0, "tiled_vjp": 1, "fc_one_wave": 2, "fused_single": 3}     # SDFR_DECODER_OPT_* (include/sdfr.h)
 
     def set_option(self, name: str, value: int) -> int:
         """Select one of two equivalent kernel forms for THIS decoder (``sdfr_decoder_set_option``: same results bit

@@ -449,3 +449,75 @@ def test_one_wave_linear_backward_is_bitwise_the_workgroup_form(mug):
         assert torch.isfinite(grads[0]).all() and grads[0].abs().max() > 0, name
         assert torch.equal(outs[0], outs[1]), (name, N, (outs[0] - outs[1]).abs().max().item())   # (the forward's stack too)
         assert torch.equal(grads[0], grads[1]), (name, N, (grads[0] - grads[1]).abs().max().item())
+
+
+def _fused_single_cases(d, wts, rng):
+    cases = [("mug", mug_config(d), wts, 64, 8, n) for n in (1, 3, 16)]
+    extra = [
+        # odd channel counts (padding taps), sizes that are no multiples of 4 (scalar rows of the wide layer), a 1x1x1
+        # layer that is not swapped, a final resize behind the last layer
+        dict(name="7 -> 5 | 12 -> 10 | 24 -> 22 | 1x1 | -> 32", volume=32, latent=4, batch=1, fc=[{"out": 3 * 7 ** 3}],
+             conv=[dict(in_size=7, in_channels=3, out_channels=5, kernel_size=3, relu=True),
+                   dict(in_size=12, in_channels=5, out_channels=3, kernel_size=3, relu=True),
+                   dict(in_size=24, in_channels=3, out_channels=2, kernel_size=3, relu=True),
+                   dict(in_size=22, in_channels=2, out_channels=1, kernel_size=1, relu=False)]),
+        # a 5x resize (11 taps), three z tiles per column (46 and 48 rows), a swapped last layer with 4 mixed channels
+        dict(name="6 -> 4 | 20 -> 18 | 48 -> 46 | swapped 1x1 -> 64", volume=64, latent=5, batch=2, fc=[{"out": 20}, {"out": 2 * 6 ** 3}],
+             conv=[dict(in_size=6, in_channels=2, out_channels=4, kernel_size=3, relu=True),
+                   dict(in_size=20, in_channels=4, out_channels=3, kernel_size=3, relu=True),
+                   dict(in_size=48, in_channels=3, out_channels=4, kernel_size=3, relu=True),
+                   dict(in_size=64, in_channels=4, out_channels=1, kernel_size=1, relu=False)]),
+        # two column tiles of output channels (20), a layer without ReLU, two mixed channels
+        dict(name="6 -> 4 (20 ch) | 12 -> 10 | swapped 1x1 -> 16", volume=16, latent=3, batch=2, fc=[{"out": 7}, {"out": 3 * 6 ** 3}],
+             conv=[dict(in_size=6, in_channels=3, out_channels=20, kernel_size=3, relu=True),
+                   dict(in_size=12, in_channels=20, out_channels=2, kernel_size=3, relu=False),
+                   dict(in_size=16, in_channels=2, out_channels=1, kernel_size=1, relu=True)]),
+        # an 8-wide first layer (16-byte rows of the wide layer) into a resize by 1 (none) and by 2
+        dict(name="8 -> 6 | 6 -> 4 | 8 -> 6 | 1x1 -> 16", volume=16, latent=6, batch=5, fc=[{"out": 4 * 8 ** 3}],
+             conv=[dict(in_size=8, in_channels=4, out_channels=6, kernel_size=3, relu=True),
+                   dict(in_size=6, in_channels=6, out_channels=6, kernel_size=3, relu=True),
+                   dict(in_size=8, in_channels=6, out_channels=3, kernel_size=3, relu=True),
+                   dict(in_size=16, in_channels=3, out_channels=1, kernel_size=1, relu=False)]),
+    ]
+    for case in extra:
+        cfg = {"latent_size": case["latent"], "tsdf": False, "sdf_size": case["volume"],
+               "decoder": {"fc_layers": case["fc"], "conv_layers": case["conv"]}}
+        cases.append((case["name"], cfg, _random_state(rng, case), case["volume"], case["latent"], case["batch"]))
+    return cases
+
+
+def test_single_latent_fused_pairs_are_bitwise_the_unfused_launches(mug):
+    """Few latents (the render-and-compare loop decodes one): the layer PAIRS as one launch each -- the up-sampling
+    resize inside the split-K MFMA convolution behind it (conv3d_mfma_up_kernel, sdf_vae.py:235-246), the Linear stack
+    with the first convolution (fc_conv_kernel, :223-238), and in the VJP the transposed resize (+ mask, swapped 1x1x1
+    layer, padding) inside the transposed convolution (conv3d_mfma_tresize_kernel) -- against the launches they replace,
+    every pair alone (option bits 1, 2, 4) and all together (7): outputs, the taped activations the VJP reads, and the
+    latent gradients bit for bit."""
+    from sdfest_amd import SDFDecoder
+    d, wts = mug
+    rng = np.random.default_rng(23)
+    for name, cfg, state, volume, latent, N in _fused_single_cases(d, wts, rng):
+        dec = SDFDecoder.from_config(cfg, state, sdf_size=volume) if name == "mug" else SDFDecoder.from_config(cfg, state, sdf_size=volume)
+        z_np = rng.normal(size=(N, latent)).astype(np.float32)
+        G = torch.tensor(rng.normal(size=(N, 1, volume, volume, volume)).astype(np.float32), device="cuda")
+        res = {}
+        for bits in (0, 1, 2, 4, 7):
+            old = dec.set_option("fused_single", bits)
+            try:
+                z = torch.tensor(z_np, device="cuda", requires_grad=True)
+                o = dec.decode(z)
+                o.backward(G)
+                torch.cuda.synchronize()
+                with torch.no_grad():
+                    plain = dec.decode(torch.tensor(z_np, device="cuda"))   # (the forward without a tape)
+                res[bits] = (o.detach().clone(), z.grad.clone(), plain.clone())
+            finally:
+                dec.set_option("fused_single", old)
+        ref = res[0]
+        assert torch.isfinite(ref[0]).all() and ref[0].abs().max() > 0 and ref[1].abs().max() > 0, name
+        assert torch.equal(ref[0], ref[2]), name
+        for bits in (1, 2, 4, 7):
+            o, g, plain = res[bits]
+            assert torch.equal(o, ref[0]), (name, N, bits, "output", (o - ref[0]).abs().max().item())
+            assert torch.equal(plain, ref[0]), (name, N, bits, "output without a tape", (plain - ref[0]).abs().max().item())
+            assert torch.equal(g, ref[1]), (name, N, bits, "latent gradient", (g - ref[1]).abs().max().item())

@@ -12,6 +12,8 @@ from _loop_scene import c5_scene  # noqa: E402
 def main():
     from sdfest_amd.pipeline import FusedRenderAndCompare
     s = c5_scene(views=int(os.environ.get("VIEWS", "1")), max_iterations=10)
+    if "FUSED_SINGLE" in os.environ:     # the decoder's fused layer pairs (SDFR_DECODER_OPT_FUSED_SINGLE bits)
+        s["decoder"].set_option("fused_single", int(os.environ["FUSED_SINGLE"]))
     loop = FusedRenderAndCompare(s["decoder"], s["camera"], s["config"], s["targets"],
                                  form=os.environ.get("FORM", "auto"))
     for _ in range(3):
