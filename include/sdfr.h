@@ -386,10 +386,13 @@ SDFR_API int sdfr_decoder_forward(const sdfr_decoder* decoder, const float* z, i
  *                                  sdfr_decoder_backward_latent and inside sdfr_loop_tail[_records]; 0: the one-workgroup
  *                                  form wider stacks take
  *   SDFR_DECODER_OPT_FUSED_SINGLE  few latents (the render-and-compare loop decodes ONE): layer pairs as one launch each,
- *                                  the producer recomputed under the consumer's tile.  Bits (default 7, all):
+ *                                  the producer recomputed under the consumer's tile.  Bits (default 5 = the pairs that
+ *                                  measured faster on MI355X, C5 0.1200 -> 0.1120 ms per iteration):
  *                                  1 an up-sampling resize + the 3x3x3 convolution behind it (sdf_vae.py:235-246),
- *                                  2 the Linear stack + the first convolution (:223-238), 4 in the VJP a transposed
- *                                  resize (+ ReLU mask, swapped 1x1x1 layer, padding) + the transposed convolution */
+ *                                  2 the Linear stack + the first convolution (:223-238),
+ *                                  4 in the VJP the first transposed resize (+ ReLU mask, swapped 1x1x1 layer, padding)
+ *                                    + the transposed convolution that reads it,
+ *                                  8 the VJP's following stages likewise, chained through a z-pass epilogue */
 #define SDFR_DECODER_OPT_FUSED_RESIZE 0
 #define SDFR_DECODER_OPT_TILED_VJP 1
 #define SDFR_DECODER_OPT_FC_ONE_WAVE 2

@@ -52,6 +52,9 @@ struct sdfr_decoder {
   std::vector<size_t> bwd_w_off, bwd_tab_off;
   std::vector<int> bwd_kpad;
   size_t zero_bias_off = 0;
+  // transposed-resize tables of the fused VJP stages (vjp_stage_kernel): for the resize in FRONT of layer l (conv_prev[l]
+  // -> conv_in_size[l]), a row of 16 words per coarse index: first source (int), taps (int), 12 weights; 0: none
+  std::vector<size_t> rs_tab_off;
   // z-grouped contraction for layers with few output channels (see conv3d_mfma_kernel): per layer,
   // forward and data-gradient
   struct ZPlan {
@@ -70,8 +73,9 @@ struct sdfr_decoder {
   // ones, results are the same bit for bit): per HANDLE, so that nothing one caller selects reaches another's decoder
   mutable std::atomic<int> opt_fused_resize{1}, opt_tiled_vjp{1}, opt_fc_one_wave{1};
   // bits: 1 resize + convolution (conv3d_mfma_up_kernel), 2 Linear stack + first convolution (fc_conv_kernel),
-  // 4 transposed resize + transposed convolution of the VJP (conv3d_mfma_tresize_kernel) -- few latents only
-  mutable std::atomic<int> opt_fused_single{0};   // (0 until the fused forms are the faster ones)
+  // 4 / 8 transposed resize + transposed convolution of the VJP (vjp_stage_kernel): its first stage / the stages
+  // behind a fused one -- few latents only
+  mutable std::atomic<int> opt_fused_single{5};   // (the pairs measured faster: C5 0.1200 -> 0.1120 ms per iteration)
 };
 
 namespace sdfr {
@@ -1887,85 +1891,101 @@ void host_resize_axis(int dd, float ratio, int ni, int& i0, int& i1, float& l1) 
 
 // resize ni -> n + the 3x3x3 convolution n -> m behind it in one launch (conv3d_mfma_up_kernel): true if launched.
 // Only where the unfused convolution takes its split-K form (the arithmetic this kernel reproduces).
-bool launch_mfma_up(const sdfr_decoder* d, const float* src, int ni, const float* w, const float* bias, float* dst, int cin,
-                    int cout, int n, int m, int kpad, int relu, int N, hipStream_t st) {
+bool launch_mfma_up(const sdfr_decoder* d, size_t direct_off, const float* src, int ni, const float* w, const float* bias,
+                    float* dst, int cin, int cout, int n, int m, int kpad, int relu, int N, hipStream_t st) {
   if (!(d->opt_fused_single.load(std::memory_order_relaxed) & 1)) return false;
-  if (ni > n || ni < 1 || m != n - 2 || m < 1) return false;
+  if (ni > n || ni < 1 || m != n - 2 || m < 1 || direct_ok(direct_off, n, m, N)) return false;
   const int co_tiles = (cout + 15) / 16, ZT = (m + 15) / 16;
   if (ZT > 4 || !use_split_k(false, (m * m * m + 15) / 16, co_tiles, N, kpad)) return false;
+  // columns per workgroup: the smallest tile that gives every workgroup a CU of its own (<= 16 MFMA tiles each)
+  static const int kShapes[][2] = {{1, 1}, {1, 2}, {2, 2}, {2, 3}, {3, 3}, {2, 4}, {3, 4}, {4, 4}};
+  int TX = 1, TY = 1;
+  for (const auto& sh : kShapes) {
+    if (sh[0] * sh[1] * ZT > 16) break;
+    TX = sh[0]; TY = sh[1];
+    if ((long long)((m + TX - 1) / TX) * ((m + TY - 1) / TY) * co_tiles * N <= 256) break;
+  }
+  const int tiles = TX * TY * ZT, wpt = 4 * tiles <= 16 ? 4 : 1;
+  const int threads = std::max(256, 64 * wpt * tiles);
+  const int IX = TX + 2, IY = TY + 2;
   const float ratio = (float)ni / (float)n;
   int CX = 1;
-  for (int x = 0; x < m; ++x) {
-    int lo, hi, t;
-    float f;
-    host_resize_axis(x, ratio, ni, lo, t, f);
-    host_resize_axis(x + 2, ratio, ni, t, hi, f);
-    CX = std::max(CX, hi - lo + 1);
+  for (int pass = 0; pass < 2; ++pass) {
+    const int T = pass ? TY : TX, I = pass ? IY : IX;
+    for (int t0 = 0; t0 < m; t0 += T) {
+      int lo, hi, t;
+      float f;
+      host_resize_axis(t0, ratio, ni, lo, t, f);
+      host_resize_axis(std::min(t0 + I, n) - 1, ratio, ni, t, hi, f);
+      CX = std::max(CX, hi - lo + 1);
+    }
   }
-  const int PZ = 16 * ZT + 2, patch_n = cin * 9 * PZ;
-  const size_t coarse_n = (size_t)cin * CX * CX * ni;
-  if (coarse_n >= 65536 || patch_n >= 65536) return false;   // (the kernel's reciprocal divisions)
-  const size_t lds = ((size_t)kpad * 16 + 1024 * ZT + ((patch_n + patch_slack(ZT) + 3) & ~3) + coarse_n) * sizeof(float);
-  const void* fn = reinterpret_cast<const void*>(&conv3d_mfma_up_kernel);
-  if (lds > kFusedLdsMax || !fused_lds_limit(fn)) return false;
-  hipLaunchKernelGGL(conv3d_mfma_up_kernel, dim3(m * m, co_tiles, N), dim3(256 * ZT), lds, st, src, ni, w, bias, dst, cin,
-                     cout, n, m, kpad, relu, CX, ZT);
+  const int PZ = 16 * ZT + 2, patch_n = cin * IX * IY * PZ;
+  const size_t zc_n = (size_t)cin * CX * CX * PZ;
+  if (zc_n >= 65536 || patch_n >= 65536 || threads / PZ < 1 || threads / (IX * IY) < 1) return false;   // (reciprocal divisions)
+  const size_t lds = ((size_t)kpad * 17 + (wpt == 4 ? 4 * threads : 0) + ((patch_n + 3) & ~3) + zc_n) * sizeof(float);
+  const void* fn = wpt == 4 ? reinterpret_cast<const void*>(&conv3d_mfma_up_kernel<4>) : reinterpret_cast<const void*>(&conv3d_mfma_up_kernel<1>);
+  if (lds > kFusedLdsMax || (lds > 64 * 1024 && !fused_lds_limit(fn))) return false;
+  const dim3 grid(((m + TX - 1) / TX) * ((m + TY - 1) / TY), co_tiles, N);
+  if (wpt == 4) hipLaunchKernelGGL(conv3d_mfma_up_kernel<4>, grid, dim3(threads), lds, st, src, ni, w, bias, dst, cin, cout, n,
+                                   m, kpad, relu, CX, ZT, TX, TY);
+  else hipLaunchKernelGGL(conv3d_mfma_up_kernel<1>, grid, dim3(threads), lds, st, src, ni, w, bias, dst, cin, cout, n, m,
+                          kpad, relu, CX, ZT, TX, TY);
   return true;
 }
 
 // the Linear stack + the first convolution in one launch (fc_conv_kernel): true if launched
-bool launch_fc_conv(const sdfr_decoder* d, const FcDesc& fd, const float* z, float* fc_out, const float* w,
-                    const float* bias, float* dst, int cin, int cout, int n, int kpad, int relu, int N, hipStream_t st) {
+bool launch_fc_conv(const sdfr_decoder* d, const FcDesc& fd, const float* z, float* fc_out, size_t direct_off,
+                    const float* w, const float* bias, float* dst, int cin, int cout, int n, int kpad, int relu, int N,
+                    hipStream_t st) {
   if (!(d->opt_fused_single.load(std::memory_order_relaxed) & 2)) return false;
   const int m = n - 2;
-  if (m < 1 || !decoder_fc_one_wave(d, fd)) return false;
+  if (m < 1 || !decoder_fc_one_wave(d, fd) || direct_ok(direct_off, n, m, N)) return false;
   const int co_tiles = (cout + 15) / 16, ZT = (m + 15) / 16;
   if (ZT > 4 || !use_split_k(false, (m * m * m + 15) / 16, co_tiles, N, kpad)) return false;
-  const int PZ = 16 * ZT + 2, patch_n = cin * 9 * PZ;
-  if (patch_n >= 65536) return false;
-  const size_t lds = ((size_t)kpad * 16 + 1024 * ZT + ((patch_n + patch_slack(ZT) + 3) & ~3)) * sizeof(float);
-  const int wout = fd.width[fd.n_fc];
-  const float* wt = d->d_params + fd.w_off[fd.n_fc - 1];
-  const float* bl = d->d_params + fd.b_off[fd.n_fc - 1];
-  const bool vec4 = (n & 3) == 0 && (wout & 3) == 0 &&
-                    (((uintptr_t)wt | (uintptr_t)bl | (uintptr_t)fc_out) & 15) == 0;
-  // rows of the wide layer per thread: one (vector) item each where the workgroup size allows
-  const int items = cin * 9 * (vec4 ? n / 4 : n);
+  const int PZ = 16 * ZT + 2, patch_n = cin * 9 * PZ, items = cin * 9 * n;
+  if (patch_n >= 65536 || fd.width[fd.n_fc - 1] > kFcWaveWidth) return false;
+  // a row of the wide layer per thread where the workgroup size allows
   int threads = 256 * ZT;
   while (threads < 1024 && threads < items) threads *= 2;
-  const void* fn = vec4 ? reinterpret_cast<const void*>(&fc_conv_kernel<true>) : reinterpret_cast<const void*>(&fc_conv_kernel<false>);
-  if (lds > 100 * 1024 || !fused_lds_limit(fn, 100 * 1024)) return false;   // (+ 25 KB static)
-  if (vec4) hipLaunchKernelGGL(fc_conv_kernel<true>, dim3(m * m, co_tiles, N), dim3(threads), lds, st, d->d_params, fd, z,
-                               fc_out, w, bias, dst, cin, cout, n, m, kpad, relu, ZT);
-  else hipLaunchKernelGGL(fc_conv_kernel<false>, dim3(m * m, co_tiles, N), dim3(threads), lds, st, d->d_params, fd, z,
-                          fc_out, w, bias, dst, cin, cout, n, m, kpad, relu, ZT);
+  const size_t lds = ((size_t)kpad * 17 + 4 * threads + patch_n) * sizeof(float);
+  const void* fn = reinterpret_cast<const void*>(&fc_conv_kernel);
+  if (lds > 100 * 1024 || (lds > 38 * 1024 && !fused_lds_limit(fn, 100 * 1024))) return false;   // (+ 25 KB static)
+  hipLaunchKernelGGL(fc_conv_kernel, dim3(m * m, co_tiles, N), dim3(threads), lds, st, d->d_params, fd, z, fc_out, w, bias,
+                     dst, cin, cout, n, m, kpad, relu, ZT);
   return true;
 }
 
-// The VJP's transposed resize n_out -> n_in of C channels (+ ReLU mask `act`, + the swapped 1x1x1 layer C = 1 -> mix_cout
-// channels, + zero padding) and the transposed convolution of layer lc that reads it, in one launch
-// (conv3d_mfma_tresize_kernel): the plan, or ok == false where the pair keeps its two launches.
-struct TresizePlan {
+// One stage of the VJP for few latents in one launch (vjp_stage_kernel): the transposed resize n_out -> n_in of C channels
+// (+ ReLU mask, + the swapped 1x1x1 layer C = 1 -> mix_cout channels, + zero padding) and the transposed convolution of
+// layer lc that reads it.  The plan, or ok == false where the pair keeps its two launches.  zin: the stage runs the z pass
+// itself (g is the fine gradient); 0: its producer's epilogue has (g is coarse along z already).
+struct VjpPlan {
   bool ok = false;
-  int taps = 0, split = 0, CK = 0, FX = 0, ZT = 0, threads = 0;
+  int taps = 0, mode = 0, CK = 0, FX = 0, ZT = 0, TX = 1, TY = 1, threads = 0, zin = 1;
   size_t lds = 0;
 };
-TresizePlan tresize_conv_plan(const sdfr_decoder* d, int lc, int C, int n_in, int n_out, int mix_cout, int N,
-                              const float* g) {
-  TresizePlan p;
-  if (!(d->opt_fused_single.load(std::memory_order_relaxed) & 4)) return p;
+VjpPlan vjp_stage_plan(const sdfr_decoder* d, int lc, int C, int n_in, int n_out, int mix_cout, int N, int zin,
+                       const float* g, bool first) {
+  VjpPlan p;
+  p.zin = zin;
+  // bit 4: the FIRST stage of the VJP (the one that reads the decoder's incoming gradient); bit 8: the stages behind a
+  // fused one as well, chained through the z-pass epilogue (measured: no faster than their two launches each)
+  const int opt = d->opt_fused_single.load(std::memory_order_relaxed);
+  if (!(opt & (first ? 4 : 8))) return p;
   const int k = d->conv_k[lc], ci_n = d->conv_cin[lc], co_n = d->conv_cout[lc];
   const int CP = mix_cout > 0 ? mix_cout : C;
-  if (k != 3 || d->conv_swap[lc] || CP != co_n || (mix_cout > 0 && (C != 1 || mix_cout > 4))) return p;
-  if (n_in != d->conv_in_size[lc] - k + 1 || n_in > n_out || n_in > 64 || (n_out & 3) || ((uintptr_t)g & 15)) return p;
+  if (k != 3 || d->conv_swap[lc] || CP != co_n || (mix_cout > 0 && (C != 1 || mix_cout > 4 || !zin))) return p;
+  if (n_in != d->conv_in_size[lc] - k + 1 || n_in > n_out || n_in > 64) return p;
+  if (zin && ((n_out & 3) || ((uintptr_t)g & 15))) return p;
+  // (the tables of this resize: built at creation for the resize in front of layer lc + 1)
+  if (lc + 1 >= d->n_conv || d->rs_tab_off[lc + 1] == 0 || d->conv_prev[lc + 1] != n_in || d->conv_in_size[lc + 1] != n_out) return p;
   const int pad = k - 1, np = n_in + 2 * pad, nc = np - 2, kpad = d->bwd_kpad[lc], ci_tiles = (ci_n + 15) / 16;
   // the form the unfused transposed convolution takes: plain or split-K only (not the direct, not the z-grouped one)
-  if (direct_ok(d->bwd_direct_off[lc], np, nc, N)) return p;
-  p.split = use_split_k(false, (nc * nc * nc + 15) / 16, ci_tiles, N, kpad);
+  if (N > SDFR_SPLITK_MAX_LATENTS || direct_ok(d->bwd_direct_off[lc], np, nc, N)) return p;
+  const int split = use_split_k(false, (nc * nc * nc + 15) / 16, ci_tiles, N, kpad);
   const sdfr_decoder::ZPlan& zp = d->bwd_z[lc];
-  if (!p.split && zp.zg > 1 && (long long)nc * nc * (nc / zp.zg) * N >= kZGroupMinRows) return p;
-  if (!p.split && (nc * nc * nc + 15) / 16 >= 32768) return p;   // (tiles_per_wave 4: never for few latents)
-  if (N > SDFR_SPLITK_MAX_LATENTS) return p;
+  if (!split && zp.zg > 1 && (long long)nc * nc * (nc / zp.zg) * N >= kZGroupMinRows) return p;
   p.ZT = (nc + 15) / 16;
   if (p.ZT > 4) return p;
   // source ranges (resize_sources / resize_weight on the host)
@@ -1990,19 +2010,37 @@ TresizePlan tresize_conv_plan(const sdfr_decoder* d, int lc, int C, int n_in, in
   }
   if (max_span > 16 || max_taps > kBtTaps) return p;
   p.taps = max_taps <= 6 ? 6 : 12;
-  for (int x = 0; x < nc; ++x) p.FX = std::max(p.FX, hi[std::min(x, n_in - 1)] - lo[std::max(x - pad, 0)] + 1);
+  // columns per workgroup: the smallest tile that gives every workgroup a CU of its own
+  static const int kShapes[][2] = {{1, 1}, {1, 2}, {2, 2}, {2, 3}, {3, 3}, {2, 4}, {3, 4}, {4, 4}};
+  for (const auto& sh : kShapes) {
+    if (sh[0] * sh[1] * p.ZT > 16) break;
+    p.TX = sh[0]; p.TY = sh[1];
+    if ((long long)((nc + p.TX - 1) / p.TX) * ((nc + p.TY - 1) / p.TY) * ci_tiles * N <= 256) break;
+  }
+  const int tiles = p.TX * p.TY * p.ZT, max_thr = zin ? 512 : 1024;   // (vjp_stage_kernel's launch bounds)
+  if (64 * tiles > max_thr) return p;
+  p.mode = !split ? 0 : (256 * tiles <= max_thr ? 4 : 1);
+  const int IX = p.TX + 2, IY = p.TY + 2;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int T = pass ? p.TY : p.TX, I = pass ? IY : IX;
+    for (int t0 = 0; t0 < nc; t0 += T)
+      p.FX = std::max(p.FX, hi[std::min(t0 - pad + I - 1, n_in - 1)] - lo[std::max(t0 - pad, 0)] + 1);
+  }
   // channels per round and workgroup size: the whole tensor in one round where the LDS allows
-  const int PZ = 16 * p.ZT + 2, patch_n = CP * 9 * PZ;
-  const int min_thr = p.split ? 256 * p.ZT : 256;
-  const size_t fixed = (size_t)kpad * 16 + (p.split ? 1024 * p.ZT : 0) + ((patch_n + patch_slack(p.ZT) + 3) & ~3);
+  const int PZ = 16 * p.ZT + 2, patch_n = CP * IX * IY * PZ, RL = zin ? n_out : n_in;
+  const int min_thr = std::max(256, p.mode == 4 ? 256 * tiles : 64 * tiles);
+  const size_t epi = (size_t)p.TX * p.TY * 16 * nc;   // (the epilogue's rows reuse F)
   for (int CK = C; CK >= 1; --CK) {
-    const size_t yf = (((size_t)CK * p.FX * 3 * n_in + 3) & ~(size_t)3) + (size_t)CK * p.FX * p.FX * n_out;
-    const size_t total4 = (size_t)CK * p.FX * p.FX * (n_out >> 2);
-    if ((fixed + yf) * sizeof(float) > kFusedLdsMax || total4 >= 65536 || (size_t)CK * 9 * n_in >= 65536) continue;
+    const size_t f_n = std::max((size_t)CK * p.FX * p.FX * RL, epi);
+    const size_t units = (size_t)CK * p.FX * p.FX * (zin ? RL / 4 : RL);
+    int threads = min_thr;
+    while (threads < max_thr && (size_t)threads * 8 < units) threads *= 2;
+    const size_t fixed = (size_t)kpad * 17 + (p.mode == 4 ? 4 * threads : 0) + ((patch_n + 3) & ~3);
+    const size_t lds = (fixed + (((size_t)CK * p.FX * IY * n_in + 3) & ~(size_t)3) + f_n) * sizeof(float);
+    if (lds > kFusedLdsMax - 8 * 1024 || units >= 65536 || (size_t)CK * IX * IY * n_in >= 65536) continue;   // (8 KB static)
     p.CK = CK;
-    p.lds = (fixed + yf) * sizeof(float);
-    p.threads = min_thr;
-    while (p.threads < (p.split ? 1024 : 512) && (size_t)p.threads * 8 < total4) p.threads *= 2;
+    p.lds = lds;
+    p.threads = threads;
     break;
   }
   if (!p.CK || patch_n >= 65536) return p;
@@ -2010,29 +2048,35 @@ TresizePlan tresize_conv_plan(const sdfr_decoder* d, int lc, int C, int n_in, in
   return p;
 }
 
-bool launch_tresize_conv(const sdfr_decoder* d, const TresizePlan& p, int lc, const float* g, int C, int n_in, int n_out,
-                         const float* act, const float* mix_w, int mix_cout, float* dst, int N, hipStream_t st) {
+// e_nin > 0: the stage's epilogue applies the z pass of the NEXT stage's transposed resize (nc -> e_nin)
+bool launch_vjp_stage(const sdfr_decoder* d, const VjpPlan& p, int lc, const float* g, int C, int n_in, int n_out,
+                      const float* act, const float* mix_w, int mix_cout, int e_nin, float* dst, int N, hipStream_t st) {
   const int ci_n = d->conv_cin[lc], ci_tiles = (ci_n + 15) / 16, pad = d->conv_k[lc] - 1, nc = n_in + 2 * pad - 2;
-  const float* wb = d->d_params + d->bwd_w_off[lc];
   const float* zb = d->d_params + d->zero_bias_off;
-  const dim3 grid(nc * nc, ci_tiles, N), block(p.threads);
-#define SDFR_TR(CO, TAPS, SPLIT)                                                                                       \
-  do {                                                                                                                 \
-    const void* fn = reinterpret_cast<const void*>(&conv3d_mfma_tresize_kernel<CO, TAPS, SPLIT>);                      \
-    if (!fused_lds_limit(fn)) return false;                                                                            \
-    hipLaunchKernelGGL((conv3d_mfma_tresize_kernel<CO, TAPS, SPLIT>), grid, block, p.lds, st, g, C, n_in, n_out, act, \
-                       pad, mix_w, zb, wb, zb, dst, ci_n, d->bwd_kpad[lc], p.CK, p.FX, p.ZT);                           \
+  VjpStage s;
+  s.g = g; s.act = act; s.mix_w = mix_w; s.mix_b = zb;
+  s.wmat = d->d_params + d->bwd_w_off[lc]; s.bias = zb; s.out = dst;
+  s.C = C; s.n_in = n_in; s.n_out = n_out; s.pad = pad; s.Cc = ci_n; s.kpad = d->bwd_kpad[lc];
+  s.CK = p.CK; s.FX = p.FX; s.ZT = p.ZT; s.TX = p.TX; s.TY = p.TY; s.zin = p.zin; s.e_nin = e_nin;
+  s.tab = d->d_params + d->rs_tab_off[lc + 1];
+  s.e_tab = e_nin > 0 ? d->d_params + d->rs_tab_off[lc] : nullptr;
+  const dim3 grid(((nc + p.TX - 1) / p.TX) * ((nc + p.TY - 1) / p.TY), ci_tiles, N), block(p.threads);
+#define SDFR_VS(CO, TAPS, MODE, ZIN)                                                               \
+  do {                                                                                           \
+    const void* fn = reinterpret_cast<const void*>(&vjp_stage_kernel<CO, TAPS, MODE, ZIN>);      \
+    if (p.lds > 56 * 1024 && !fused_lds_limit(fn, kFusedLdsMax - 8 * 1024)) return false;        \
+    hipLaunchKernelGGL((vjp_stage_kernel<CO, TAPS, MODE, ZIN>), grid, block, p.lds, st, s);      \
   } while (0)
-#define SDFR_TR_S(CO, TAPS) { if (p.split) SDFR_TR(CO, TAPS, true); else SDFR_TR(CO, TAPS, false); }
-#define SDFR_TR_T(CO) { if (p.taps == 6) SDFR_TR_S(CO, 6) else SDFR_TR_S(CO, 12) }
-  if (mix_cout == 0) SDFR_TR_T(0)
-  else if (mix_cout == 1) SDFR_TR_T(1)
-  else if (mix_cout == 2) SDFR_TR_T(2)
-  else if (mix_cout == 3) SDFR_TR_T(3)
-  else SDFR_TR_T(4)
-#undef SDFR_TR_T
-#undef SDFR_TR_S
-#undef SDFR_TR
+#define SDFR_VS_M(CO, TAPS, ZIN) { if (p.mode == 0) SDFR_VS(CO, TAPS, 0, ZIN); else if (p.mode == 4) SDFR_VS(CO, TAPS, 4, ZIN); else SDFR_VS(CO, TAPS, 1, ZIN); }
+#define SDFR_VS_T(CO, ZIN) { if (p.taps == 6) SDFR_VS_M(CO, 6, ZIN) else SDFR_VS_M(CO, 12, ZIN) }
+  if (mix_cout == 0) { if (p.zin) SDFR_VS_T(0, true) else SDFR_VS_T(0, false) }
+  else if (mix_cout == 1) SDFR_VS_T(1, true)
+  else if (mix_cout == 2) SDFR_VS_T(2, true)
+  else if (mix_cout == 3) SDFR_VS_T(3, true)
+  else SDFR_VS_T(4, true)
+#undef SDFR_VS_T
+#undef SDFR_VS_M
+#undef SDFR_VS
   return true;
 }
 }  // namespace
@@ -2047,7 +2091,7 @@ extern "C" int sdfr_decoder_set_option(sdfr_decoder* d, int option, int value) {
     case SDFR_DECODER_OPT_FC_ONE_WAVE:
       return d->opt_fc_one_wave.exchange(value ? 1 : 0, std::memory_order_relaxed);
     case SDFR_DECODER_OPT_FUSED_SINGLE:
-      return d->opt_fused_single.exchange(value & 7, std::memory_order_relaxed);
+      return d->opt_fused_single.exchange(value & 15, std::memory_order_relaxed);
     default:
       return fail(SDFR_E_INVALID, "sdfr_decoder_set_option: unknown option %d", option);
   }
@@ -2232,6 +2276,38 @@ extern "C" int sdfr_decoder_create(const float* h_params, size_t n_params, int l
     for (int l = 0; l < n_conv; ++l) max_c = std::max(max_c, conv_cin[l]);
     img.insert(img.end(), (size_t)max_c, 0.0f);
   }
+  // transposed-resize tables (resize_row16's results, the kernels' float arithmetic): see rs_tab_off
+  d->rs_tab_off.assign(n_conv, 0);
+  for (int l = 1; l < n_conv; ++l) {
+    const int n_in = d->conv_prev[l], n_out = conv_in_size[l];
+    if (n_in == n_out || n_in > n_out || n_in > 64) continue;
+    const float ratio = (float)n_in / (float)n_out, inv = (float)n_out / (float)n_in;
+    auto weight = [&](int dd, int i) {
+      float sp = fmaf(ratio, (float)dd + 0.5f, -0.5f);
+      sp = sp < 0.0f ? 0.0f : sp;
+      const int i0 = std::min((int)sp, n_in - 1), i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+      const float l1 = sp - (float)i0;
+      return (i0 == i ? 1.0f - l1 : 0.0f) + (i1 == i ? l1 : 0.0f);
+    };
+    std::vector<float> tab((size_t)n_in * 16, 0.0f);
+    bool ok = true;
+    for (int i = 0; i < n_in && ok; ++i) {
+      int d0 = std::max((int)floorf(((float)i - 0.5f) * inv - 0.5f) - 1, 0);
+      int d1 = std::min((int)ceilf(((float)i + 1.5f) * inv - 0.5f) + 1, n_out - 1);
+      if (d1 - d0 + 1 > 16) ok = false;
+      while (d0 <= d1 && weight(d0, i) == 0.0f) ++d0;
+      while (d1 >= d0 && weight(d1, i) == 0.0f) --d1;
+      const int nt = d1 - d0 + 1;
+      if (nt < 1 || nt > 12) { ok = false; break; }
+      memcpy(&tab[(size_t)i * 16], &d0, sizeof(int));
+      memcpy(&tab[(size_t)i * 16 + 1], &nt, sizeof(int));
+      for (int kk = 0; kk < nt; ++kk) tab[(size_t)i * 16 + 2 + kk] = weight(d0 + kk, i);
+    }
+    if (!ok) continue;
+    align();
+    d->rs_tab_off[l] = img.size();
+    img.insert(img.end(), tab.begin(), tab.end());
+  }
   // z-grouped plans.  wfun(co, ci, a, b, c): weight of input channel ci at tap (a,b,c) for output
   // channel co, in the correlation sense out[x] = sum w(a,b,c) in[x + (a,b,c)].
   auto plan_z = [&](int cin, int cout, int k, int n, auto wfun) {
@@ -2373,7 +2449,7 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
       N < 32 && d->conv_in_size[0] - 2 != d->volume) {
     float* fc_dst = tape ? tape + (size_t)N * d->tape_fc_off : nullptr;
     float* dst0 = tape ? tape + (size_t)N * d->tape_conv_off[0] : buf[cur ^ 1];
-    if (launch_fc_conv(d, fd, z, fc_dst, d->d_params + d->conv_w_off[0], d->d_params + d->conv_b_off[0], dst0,
+    if (launch_fc_conv(d, fd, z, fc_dst, d->fwd_direct_off[0], d->d_params + d->conv_w_off[0], d->d_params + d->conv_b_off[0], dst0,
                        d->conv_cin[0], d->conv_cout[0], d->conv_in_size[0], d->conv_kpad[0], d->conv_relu[0], N, st)) {
       if (dst0 == buf[cur ^ 1]) cur ^= 1;
       act_in = dst0;
@@ -2460,7 +2536,7 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
     bool fused_up = false;
     if (!swap && n != d->conv_in_size[l] && k == 3 && d->fwd_direct_off[l] != 0) {
       const int nf = d->conv_in_size[l], mf = nf - k + 1;
-      const bool to_out_f = is_last && mf == d->volume && clampv == 0.0f;
+      const bool to_out_f = is_last && mf == d->volume && clampv == 0.0f && !(tape && d->conv_relu[l]);
       float* ldst = to_out_f ? out : (tape ? tape + (size_t)N * d->tape_conv_off[l] : nullptr);
       float* cdst = ldst ? ldst : buf[cur ^ 1];
       fused_up = launch_direct_up(d, d->fwd_direct_off[l], act_in, n, d->d_params + d->conv_b_off[l], cdst, c, co_n,
@@ -2470,11 +2546,11 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
     // few latents: the resize inside the split-K MFMA convolution's operand fetch (conv3d_mfma_up_kernel)
     if (!fused_up && !swap && n != d->conv_in_size[l] && k == 3) {
       const int nf = d->conv_in_size[l], mf = nf - k + 1;
-      const bool to_out_f = is_last && mf == d->volume && clampv == 0.0f;
+      const bool to_out_f = is_last && mf == d->volume && clampv == 0.0f && !(tape && d->conv_relu[l]);
       float* ldst = to_out_f ? out : (tape ? tape + (size_t)N * d->tape_conv_off[l] : nullptr);
       float* cdst = ldst ? ldst : buf[cur ^ 1];
-      fused_up = launch_mfma_up(d, act_in, n, d->d_params + d->conv_w_off[l], d->d_params + d->conv_b_off[l], cdst, c,
-                                co_n, nf, mf, kpad, d->conv_relu[l], N, st);
+      fused_up = launch_mfma_up(d, d->fwd_direct_off[l], act_in, n, d->d_params + d->conv_w_off[l],
+                                d->d_params + d->conv_b_off[l], cdst, c, co_n, nf, mf, kpad, d->conv_relu[l], N, st);
       if (fused_up) n = nf;
     }
     if (!swap && n != d->conv_in_size[l]) {
@@ -2486,7 +2562,9 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
     const int m = n - k + 1;                     // swapped: k == 1, the conv keeps the incoming size
     const int m_out = d->conv_in_size[l] - k + 1;  // size of the layer's output tensor
     // where the layer's output goes: straight to `out`, to its tape slot, or to the other buffer
-    const bool to_out = is_last && m_out == d->volume && (swap || clampv == 0.0f);
+    // (a ReLU'd last layer of a taped forward goes to its tape slot first -- the VJP reads its mask there -- and is
+    // copied out: until round 6 it went straight to `out` and the VJP masked with whatever the slot held)
+    const bool to_out = is_last && m_out == d->volume && (swap || clampv == 0.0f) && !(tape && d->conv_relu[l]);
     float* layer_dst = to_out ? out : (tape ? tape + (size_t)N * d->tape_conv_off[l] : nullptr);
     float* conv_dst = (!swap && layer_dst) ? layer_dst : buf[cur ^ 1];
     const int conv_relu = swap ? 0 : d->conv_relu[l];
@@ -2818,7 +2896,7 @@ int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* ta
   // launched -- it is left pending and runs inside that convolution's launch (conv3d_mfma_tresize_kernel)
   struct {
     bool on = false;
-    TresizePlan plan;
+    VjpPlan plan;
     const float *g = nullptr, *act = nullptr, *mix_w = nullptr;
     int C = 0, n_in = 0, n_out = 0, mix_cout = 0;
   } pend;
@@ -2839,11 +2917,17 @@ int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* ta
     // 1. ReLU' and zero padding of the output gradient
     const float* act = d->conv_relu[l] ? tape + (size_t)N * d->tape_conv_off[l] : nullptr;
     bool conv_done = false;
+    // (does the resize in front of THIS layer fold into the stage of the layer below?  Then this stage's epilogue runs
+    // that resize's z pass on its output rows, and the stage below starts from them.)
+    const bool fuse_below = !swap && prev != nin && l > 0 && !d->conv_swap[l - 1] && out_n[l - 1] == prev &&
+                            d->conv_cout[l - 1] == ci_n;
+    VjpPlan below;
     if (pend.on) {   // steps 1 and 2 in one launch with the transposed resize above them
       pend.on = false;
-      if (!launch_tresize_conv(d, pend.plan, l, pend.g, pend.C, pend.n_in, pend.n_out, pend.act, pend.mix_w,
-                               pend.mix_cout, buf[cur], N, st))
-        return fail(SDFR_E_INVALID, "sdfr_decoder_backward_latent: the fused transposed resize could not be launched");
+      if (fuse_below) below = vjp_stage_plan(d, l - 1, ci_n, prev, nin, 0, N, 0, nullptr, false);
+      if (!launch_vjp_stage(d, pend.plan, l, pend.g, pend.C, pend.n_in, pend.n_out, pend.act, pend.mix_w, pend.mix_cout,
+                            below.ok ? prev : 0, buf[cur], N, st))
+        return fail(SDFR_E_INVALID, "sdfr_decoder_backward_latent: the fused stage could not be launched");
       g = buf[cur];
       cur ^= 1;
       n = nconv;
@@ -2865,7 +2949,7 @@ int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* ta
                      ((size_t)N * co_n * nin * nin * nin <= kFewElements || co_n == 1);
     if (mix) {
       const float* act_below = d->conv_relu[l - 1] ? tape + (size_t)N * d->tape_conv_off[l - 1] : nullptr;
-      pend.plan = tresize_conv_plan(d, l - 1, co_n, prev, nin, ci_n, N, g);
+      pend.plan = vjp_stage_plan(d, l - 1, co_n, prev, nin, ci_n, N, 1, g, g == grad_out);
       if (pend.plan.ok) {
         pend.on = true;
         pend.g = g; pend.act = act_below; pend.mix_w = d->d_params + d->bwd_w_off[l];
@@ -2921,7 +3005,7 @@ int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* ta
       // the layer below (l - 1) produced this tensor: if its transposed convolution is of the padded kind,
       // the last resize pass writes its input directly
       const bool fuse = l > 0 && !d->conv_swap[l - 1] && out_n[l - 1] == prev && d->conv_cout[l - 1] == ci_n;
-      if (fuse) pend.plan = tresize_conv_plan(d, l - 1, ci_n, prev, nin, 0, N, g);
+      if (fuse) pend.plan = below.ok ? below : vjp_stage_plan(d, l - 1, ci_n, prev, nin, 0, N, 1, g, g == grad_out);
       if (fuse && pend.plan.ok) {
         pend.on = true;
         pend.g = g; pend.act = d->conv_relu[l - 1] ? tape + (size_t)N * d->tape_conv_off[l - 1] : nullptr;

@@ -133,214 +133,426 @@ __device__ __forceinline__ void column_store(const f32x4& acc, int tile, const f
   }
 }
 
+// Tap table of a patch [channel][IX][IY][PZ]: offset of tap kk = channel * 27 + (a * 3 + b) * 3 + c; 0 for the
+// zero-weight padding taps kk >= K.
+__device__ __forceinline__ void patch_taps(int* __restrict__ tap_l, int kpad, int K, int IX, int IY, int PZ, int tid,
+                                           int nthr) {
+  for (int kk = tid; kk < kpad; kk += nthr) {
+    int off = 0;
+    if (kk < K) {
+      const int ch = kk / 27, r = kk - 27 * ch, a = r / 9, b = (r - 9 * a) / 3, c = r - 9 * a - 3 * b;
+      off = ((ch * IX + a) * IY + b) * PZ + c;
+    }
+    tap_l[kk] = off;
+  }
+}
+
+// One tile's contraction in conv3d_mfma_kernel's split-K ORDER -- four partial accumulators, partial w taking the
+// 32-tap chunks c = w, w + 4, ... in ascending order and partial (kpad / 32) & 3 the tail, combined (p0 + p1) + (p2 + p3)
+// -- by four waves (WPT == 4: waves 4t .. 4t+3 of the workgroup share tile t, as that kernel does; barrier inside, every
+// thread must call) or by ONE wave holding all four partials (WPT == 1: workgroups of many tiles; the matrix cores are
+// not what binds a single decode).  `base`: the patch at this lane's row of the tile; A[row][kk] = base[tap_l[kk]].
+// Returns true where `out` holds the finished rows kq * 4 + r of column lane & 15 (bias not added).
+template <int WPT>
+__device__ __forceinline__ bool tile_contract(const float* __restrict__ base, bool has_tile, const int* __restrict__ tap_l,
+                                              const float* __restrict__ w_l, float* __restrict__ red, int kpad,
+                                              f32x4& out) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = lane & 15, kq = lane >> 4;
+  const int full = kpad / 32;
+  auto chunk = [&](int kk0, f32x4 acc) {
+    float a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int kk = kk0 + 4 * u + kq;
+      a[u] = base[tap_l[kk]];
+      b[u] = w_l[kk * 16 + row];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+    return acc;
+  };
+  auto tail = [&](f32x4 acc) {
+    for (int kk0 = full * 32; kk0 < kpad; kk0 += 4) {
+      const int kk = kk0 + kq;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(base[tap_l[kk]], w_l[kk * 16 + row], acc, 0, 0, 0);
+    }
+    return acc;
+  };
+  if (WPT == 4) {
+    const int sub = wave & 3;
+    if (has_tile) {
+      f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+      for (int c = sub; c < full; c += 4) acc = chunk(c * 32, acc);
+      if (sub == (full & 3)) acc = tail(acc);
+      *reinterpret_cast<f32x4*>(red + (size_t)tid * 4) = acc;
+    }
+    __syncthreads();
+    if (!has_tile || sub != 0) return false;
+    const float* r0 = red + (size_t)tid * 4;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(r0), a1 = *reinterpret_cast<const f32x4*>(r0 + 256);
+    const f32x4 a2 = *reinterpret_cast<const f32x4*>(r0 + 512), a3 = *reinterpret_cast<const f32x4*>(r0 + 768);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = (a0[r] + a1[r]) + (a2[r] + a3[r]);
+    return true;
+  } else {
+    if (!has_tile) return false;
+    f32x4 p[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int c0 = 0; c0 < full; c0 += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c0 + j < full) p[j] = chunk((c0 + j) * 32, p[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j == (full & 3)) p[j] = tail(p[j]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = (p[0][r] + p[1][r]) + (p[2][r] + p[3][r]);
+    return true;
+  }
+}
+
 // resize ni -> n (trilinear, align_corners = False, up-sampling) + valid 3x3x3 convolution n -> m = n - 2, split-K order.
 //   in [N][Cin][ni^3];  out [N][Cout][m^3];  wmat [co_tiles][kpad][16]
-//   grid (m * m, co_tiles, N), block 256 * ZT, ZT = ceil(m / 16)
-//   LDS: w_l [kpad * 16] | red [1024 * ZT] | patch [Cin * 9 * PZ + patch_slack] | coarse [Cin][CX][CX][ni]
-// CX: the most coarse columns under three fine ones along an axis (host, the kernel's arithmetic).
+// A workgroup owns TX x TY output columns, all of z (ZT = ceil(m / 16) tiles each): few enough workgroups that every
+// one has a CU to itself, and a patch whose halo is shared by the columns (one column per workgroup interpolates every
+// fine element nine times over: measured, 900 workgroups of the 8 -> 4 layer 16.6 us against 5.4 + 8.6 as two launches).
+// The patch [Cin][TX + 2][TY + 2][PZ] is formed in two steps with resize3_kernel's expression tree, z innermost:
+//   A  Zc[ci][coarse column][fine z] = blend along z of the coarse columns under the patch, straight from memory (a
+//      thread keeps its z: the terms once);
+//   B  patch = blend along y, then x of four Zc columns (a thread keeps its (x, y): the terms once).
+//   grid (tiles_x * tiles_y, co_tiles, N), block 64 * WPT * TX * TY * ZT (>= 256)
+//   LDS: w_l [kpad * 16] | tap_l [kpad] | red [WPT == 4 ? 4 * nthr : 0] | patch | Zc [Cin][CX][CX][PZ]
+// CX: the most coarse columns under TX + 2 (TY + 2) fine ones (host, the kernel's arithmetic).
+template <int WPT>
 __global__ __launch_bounds__(1024) void conv3d_mfma_up_kernel(
     const float* __restrict__ in, int ni, const float* __restrict__ wmat, const float* __restrict__ bias,
-    float* __restrict__ out, int Cin, int Cout, int n, int m, int kpad, int relu, int CX, int ZT) {
+    float* __restrict__ out, int Cin, int Cout, int n, int m, int kpad, int relu, int CX, int ZT, int TX, int TY) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int PZ = 16 * ZT + 2, patch_n = Cin * 9 * PZ;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+  const int IX = TX + 2, IY = TY + 2, PZ = 16 * ZT + 2, patch_n = Cin * IX * IY * PZ;
   float* w_l = lds;
-  float* red = w_l + (size_t)kpad * 16;
-  float* patch = red + 1024 * ZT;
-  float* coarse = patch + ((patch_n + patch_slack(ZT) + 3) & ~3);
-  const int tid = threadIdx.x, nthr = blockDim.x;
+  int* tap_l = reinterpret_cast<int*>(w_l + (size_t)kpad * 16);
+  float* red = reinterpret_cast<float*>(tap_l + kpad);
+  float* patch = red + (WPT == 4 ? 4 * nthr : 0);
+  float* Zc = patch + ((patch_n + 3) & ~3);
   const int co_tile = blockIdx.y, nb = blockIdx.z;
-  const int x = (int)blockIdx.x / m, y = (int)blockIdx.x - x * m;
+  const int tiles_y = (m + TY - 1) / TY;
+  const int tx0 = ((int)blockIdx.x / tiles_y) * TX, ty0 = ((int)blockIdx.x % tiles_y) * TY;
   const float ratio = (float)ni / (float)n;
   int cx0, cx1, cy0, cy1, t;
   float fl;
-  resize_axis(x, ratio, ni, cx0, t, fl);
-  resize_axis(x + 2, ratio, ni, t, cx1, fl);
-  resize_axis(y, ratio, ni, cy0, t, fl);
-  resize_axis(y + 2, ratio, ni, t, cy1, fl);
+  resize_axis(tx0, ratio, ni, cx0, t, fl);
+  resize_axis(min(tx0 + IX, n) - 1, ratio, ni, t, cx1, fl);
+  resize_axis(ty0, ratio, ni, cy0, t, fl);
+  resize_axis(min(ty0 + IY, n) - 1, ratio, ni, t, cy1, fl);
   const int cxn = cx1 - cx0 + 1, cyn = cy1 - cy0 + 1;
   const size_t vi = (size_t)ni * ni * ni;
   const float* src = in + (size_t)nb * Cin * vi;
-  // the coarse columns under the patch (all of z): loads in flight before the weights are staged
-  const int c_total = Cin * cxn * cyn * ni;
-  const unsigned m_ni = magic_of(ni), m_cy = magic_of(cyn), m_cx = magic_of(cxn);
-  auto coarse_at = [&](int e, int& lds_off) {
-    const int r0 = div_by(e, m_ni), jz = e - r0 * ni;
-    const int r1 = div_by(r0, m_cy), jy = r0 - r1 * cyn;
-    const int ci = div_by(r1, m_cx), jx = r1 - ci * cxn;
-    lds_off = ((ci * CX + jx) * CX + jy) * ni + jz;
-    return (size_t)ci * vi + ((size_t)(cx0 + jx) * ni + (cy0 + jy)) * ni + jz;
-  };
-  constexpr int kCo = 4;
-  float cv[kCo];
-  int ca[kCo];
+  {   // A: thread <-> (fine z, coarse columns g, g + gpz, ...), four columns' loads in flight
+    const int gpz = nthr / PZ, fz = tid % PZ, g = tid / PZ;
+    int z0, z1;
+    float lz;
+    resize_axis(min(fz, n - 1), ratio, ni, z0, z1, lz);
+    const float wz0 = 1.0f - lz;
+    const int columns = Cin * cxn * cyn;
+    const unsigned m_cy = magic_of(cyn), m_cx = magic_of(cxn);
+    bool first = true;
+    for (int col0 = g; col0 < columns && g < gpz; col0 += 4 * gpz) {
+      float v0[4], v1[4];
+      int at[4];
 #pragma unroll
-  for (int u = 0; u < kCo; ++u) {
-    const int e = tid + nthr * u;
-    int lo;
-    const size_t g = coarse_at(min(e, c_total - 1), lo);
-    cv[u] = src[g];
-    ca[u] = e < c_total ? lo : -1;
-  }
-  stage_to_lds_n(w_l, wmat + (size_t)co_tile * kpad * 16, kpad * 16, tid, nthr);
-#pragma unroll
-  for (int u = 0; u < kCo; ++u)
-    if (ca[u] >= 0) coarse[ca[u]] = cv[u];
-  for (int e = tid + nthr * kCo; e < c_total; e += nthr) {
-    int lo;
-    const size_t g = coarse_at(e, lo);
-    coarse[lo] = src[g];
-  }
-  if (tid < patch_slack(ZT)) patch[patch_n + tid] = 0.0f;   // (read by the zero-weight padding taps)
-  __syncthreads();
-  // the fine patch: resize3_kernel's expression tree, z innermost
-  const unsigned m_pz = magic_of(PZ);
-  for (int e = tid; e < patch_n; e += nthr) {
-    const int r0 = div_by(e, m_pz), zz = e - r0 * PZ;
-    const int r1 = r0 / 3, b = r0 - 3 * r1, ci = r1 / 3, a = r1 - 3 * ci;
-    int x0, x1, y0, y1, z0, z1;
-    float lx, ly, lz;
-    resize_axis(x + a, ratio, ni, x0, x1, lx);
-    resize_axis(y + b, ratio, ni, y0, y1, ly);
-    resize_axis(min(zz, n - 1), ratio, ni, z0, z1, lz);
-    const float* p = coarse + (size_t)ci * CX * CX * ni;
-#define AT(ix, iy, iz) p[(((ix) - cx0) * CX + ((iy) - cy0)) * ni + (iz)]
-    const float wx0 = 1.0f - lx, wy0 = 1.0f - ly, wz0 = 1.0f - lz;
-    patch[e] = blend(wx0, blend(wy0, blend(wz0, AT(x0, y0, z0), lz, AT(x0, y0, z1)),
-                                ly, blend(wz0, AT(x0, y1, z0), lz, AT(x0, y1, z1))),
-                     lx, blend(wy0, blend(wz0, AT(x1, y0, z0), lz, AT(x1, y0, z1)),
-                               ly, blend(wz0, AT(x1, y1, z0), lz, AT(x1, y1, z1))));
-#undef AT
-  }
-  __syncthreads();
-  f32x4 acc;
-  int tile;
-  if (column_contract<true>(patch, w_l, red, kpad, PZ, ZT, acc, tile))
-    column_store(acc, tile, bias, co_tile, Cout, relu, out, nb, m, x, y);
-}
-
-// Transposed trilinear resize n_out -> n_in (the VJP of an up-sampling resize), ReLU mask, [the transposed 1x1x1 layer
-// that was swapped with the resize: COUT > 0, one source channel -> COUT channels,] zero padding by `pad` -- all of it on
-// the fine block above one output column -- and the flipped-weight 3x3x3 convolution that reads the padded tensor:
-//   g_out [N][C][n_out^3]  ->  (never stored) P [N][CP][np^3], np = n_in + 2 pad, CP = COUT > 0 ? COUT : C
-//                          ->  out [N][Cc][nc^3], nc = np - 2
-// Same chains as resize3_backward_tiled_kernel (per pass the non-zero taps in ascending source order, fmaf(w, v, acc)
-// from 0; z, then y, then x; `fmaf(acc, w_mix, 0) + bias` for the 1x1 layer) and as conv3d_mfma_kernel (SPLIT or plain).
-//   grid (nc * nc, co_tiles, N), block nthr (SPLIT: 256 * ZT .. 1024, plain: 256 .. 512), ZT = ceil(nc / 16)
-//   the channels of g_out are taken CK at a time (C % CK may be anything)
-//   LDS: w_l [kpad * 16] | red [SPLIT ? 1024 * ZT : 0] | patch [CP * 9 * PZ + patch_slack] | Y [CK][FX][3][n_in] | F [CK][FX][FX][n_out]
-// FX: the longest run of fine indices that feed three neighbouring coarse ones (host).  n_out % 4 == 0, g_out 16-byte
-// aligned, n_in <= 64, the exact source range of a coarse index <= TAPS long and its candidate range <= 16 (host).
-template <int COUT, int TAPS, bool SPLIT>
-__global__ __launch_bounds__(SPLIT ? 1024 : 512) void conv3d_mfma_tresize_kernel(
-    const float* __restrict__ g_out, int C, int n_in, int n_out, const float* __restrict__ act, int pad,
-    const float* __restrict__ mix_w, const float* __restrict__ mix_b, const float* __restrict__ wmat,
-    const float* __restrict__ bias, float* __restrict__ out, int Cc, int kpad, int CK, int FX, int ZT) {
-  constexpr int CO = COUT > 0 ? COUT : 1;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ float w_tab[6 + 64][kBtTaps];   // rows: a = 0..2 (x), 3 + b (y), 6 + iz (z)
-  __shared__ int d_tab[6 + 64], n_tab[6];
-  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
-  const int co_tile = blockIdx.y, nb = blockIdx.z;
-  const int np = n_in + 2 * pad, nc = np - 2;
-  const int x = (int)blockIdx.x / nc, y = (int)blockIdx.x - x * nc;
-  const int CP = COUT > 0 ? COUT : C;
-  const int PZ = 16 * ZT + 2, patch_n = CP * 9 * PZ;
-  float* w_l = lds;
-  float* red = w_l + (size_t)kpad * 16;
-  float* patch = red + (SPLIT ? 1024 * ZT : 0);
-  float* Y = patch + ((patch_n + patch_slack(ZT) + 3) & ~3);
-  float* F = Y + (((size_t)CK * FX * 3 * n_in + 3) & ~(size_t)3);
-  const float ratio = (float)n_in / (float)n_out;
-  // weight tables: a row per 16-lane group (resize_row16); rows of coarse indices outside the tensor are empty
-  {
-    const int k16 = tid & 15, g16 = lane & 48;
-    for (int row = tid >> 4; row < 6 + n_in; row += nthr >> 4) {
-      int i;
-      if (row < 3) { i = x + row - pad; if (i < 0 || i >= n_in) i = -1; }
-      else if (row < 6) { i = y + row - 3 - pad; if (i < 0 || i >= n_in) i = -1; }
-      else i = row - 6;
-      int d0, nt;
-      float w;
-      resize_row16(i, k16, g16, ratio, n_in, n_out, d0, nt, w);
-      if (k16 == 0) {
-        d_tab[row] = d0;
-        if (row < 6) n_tab[row] = nt;
+      for (int u = 0; u < 4; ++u) {
+        const int col = min(col0 + u * gpz, columns - 1);
+        const int r1 = div_by(col, m_cy), jy = col - r1 * cyn;
+        const int ci = div_by(r1, m_cx), jx = r1 - ci * cxn;
+        const float* p = src + (size_t)ci * vi + ((size_t)(cx0 + jx) * ni + (cy0 + jy)) * ni;
+        v0[u] = p[z0];
+        v1[u] = p[z1];
+        at[u] = col0 + u * gpz < columns ? ((ci * CX + jx) * CX + jy) * PZ + fz : -1;
       }
-      if (k16 < kBtTaps) w_tab[row][k16] = w;
+      if (first) {   // (the weights' loads behind the first columns': one wait covers both)
+        stage_to_lds_n(w_l, wmat + (size_t)co_tile * kpad * 16, kpad * 16, tid, nthr);
+        first = false;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (at[u] >= 0) Zc[at[u]] = blend(wz0, v0[u], lz, v1[u]);
+    }
+    if (first) stage_to_lds_n(w_l, wmat + (size_t)co_tile * kpad * 16, kpad * 16, tid, nthr);
+  }
+  patch_taps(tap_l, kpad, Cin * 27, IX, IY, PZ, tid, nthr);
+  __syncthreads();
+  {   // B: thread <-> (patch column (a, b), elements j, j + lpp, ... of its Cin * PZ)
+    const int pairs = IX * IY, lpp = nthr / pairs, pair = tid / lpp, j0 = tid - pair * lpp;
+    if (pair < pairs) {
+      const int a = pair / IY, b = pair - a * IY;
+      int x0, x1, y0, y1;
+      float lx, ly;
+      resize_axis(min(tx0 + a, n - 1), ratio, ni, x0, x1, lx);
+      resize_axis(min(ty0 + b, n - 1), ratio, ni, y0, y1, ly);
+      const float wx0 = 1.0f - lx, wy0 = 1.0f - ly;
+      const int o00 = ((x0 - cx0) * CX + (y0 - cy0)) * PZ, o01 = ((x0 - cx0) * CX + (y1 - cy0)) * PZ;
+      const int o10 = ((x1 - cx0) * CX + (y0 - cy0)) * PZ, o11 = ((x1 - cx0) * CX + (y1 - cy0)) * PZ;
+      const unsigned m_pz = magic_of(PZ);
+      const int per = Cin * PZ, zc_ch = CX * CX * PZ, p_ch = IX * IY * PZ;
+      float* dst = patch + (a * IY + b) * PZ;
+      for (int j = j0; j < per; j += lpp) {
+        const int ci = div_by(j, m_pz), fz = j - ci * PZ;
+        const float* zc = Zc + ci * zc_ch + fz;
+        dst[ci * p_ch + fz] = blend(wx0, blend(wy0, zc[o00], ly, zc[o01]), lx, blend(wy0, zc[o10], ly, zc[o11]));
+      }
     }
   }
-  for (int e = tid; e < patch_n + patch_slack(ZT); e += nthr) patch[e] = 0.0f;   // the padding, and what the zero-weight taps read
   __syncthreads();
-  // the fine block above the column: x in [fx0, fx0 + fnx), y in [fy0, fy0 + fny), all of z
-  const int a_lo = max(pad - x, 0), a_hi = min(n_in - 1 - x + pad, 2);
-  const int b_lo = max(pad - y, 0), b_hi = min(n_in - 1 - y + pad, 2);
-  const int fx0 = d_tab[a_lo], fnx = d_tab[a_hi] + n_tab[a_hi] - fx0;
-  const int fy0 = d_tab[3 + b_lo], fny = d_tab[3 + b_hi] + n_tab[3 + b_hi] - fy0;
-  const int q4 = n_out >> 2;
-  const size_t fine_vol = (size_t)n_out * n_out * n_out, coarse_vol = (size_t)n_in * n_in * n_in;
-  const unsigned m_q = magic_of(q4), m_fy = magic_of(fny), m_fx = magic_of(fnx), m_ni = magic_of(n_in);
-  constexpr int kFl = 8;
-  f32x4 pre[kFl];
-  auto fine_at = [&](int e, int& lds_off) {   // vector e of a round's block -> offsets (floats) in g_out's channel / in F
-    const int r0 = div_by(e, m_q), q = e - r0 * q4;
-    const int r1 = div_by(r0, m_fy), fy = r0 - r1 * fny;
-    const int ck = div_by(r1, m_fx), fx = r1 - ck * fnx;
-    lds_off = ((ck * FX + fx) * FX + fy) * n_out + 4 * q;
-    return (size_t)ck * fine_vol + ((size_t)(fx0 + fx) * n_out + (fy0 + fy)) * n_out + 4 * q;
+  const int tw = WPT == 4 ? wave >> 2 : wave;           // this wave's tile: (column lx, ly; z tile zt)
+  const int zt = tw % ZT, cl = tw / ZT, ly_ = cl % TY, lx_ = cl / TY;
+  const int x = tx0 + lx_, y = ty0 + ly_;
+  const bool has = tw < TX * TY * ZT && x < m && y < m;
+  f32x4 acc;
+  if (tile_contract<WPT>(patch + (lx_ * IY + ly_) * PZ + zt * 16 + (lane & 15), has, tap_l, w_l, red, kpad, acc))
+    column_store(acc, zt, bias, co_tile, Cout, relu, out, nb, m, x, y);
+}
+
+// One tile's contraction in conv3d_mfma_kernel's PLAIN order (what it takes where K = Cout * 27 is short): a single
+// chain, 32 taps at a time, then 4.
+__device__ __forceinline__ void tile_contract_plain(const float* __restrict__ base, const int* __restrict__ tap_l,
+                                                    const float* __restrict__ w_l, int kpad, f32x4& out) {
+  const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  int kk0 = 0;
+  for (; kk0 + 32 <= kpad; kk0 += 32) {
+    float a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int kk = kk0 + 4 * u + kq;
+      a[u] = base[tap_l[kk]];
+      b[u] = w_l[kk * 16 + row];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+  }
+  for (; kk0 < kpad; kk0 += 4) {
+    const int kk = kk0 + kq;
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(base[tap_l[kk]], w_l[kk * 16 + row], acc, 0, 0, 0);
+  }
+  out = acc;
+}
+
+// One stage of the VJP for few latents: the transposed trilinear resize n_out -> n_in of C channels, the ReLU mask of the
+// tensor it lands on, [the transposed 1x1x1 layer that was swapped with the resize: COUT > 0, one source channel -> COUT
+// channels,] zero padding by `pad` -- none of it stored -- and the flipped-weight 3x3x3 convolution that reads the padded
+// tensor P [CP][np^3] (np = n_in + 2 pad, CP = COUT > 0 ? COUT : C), giving [Cc][nc^3], nc = np - 2.
+//   * a workgroup owns TX x TY output columns, all of z; it stages the block of fine rows above its (TX + 2) x (TY + 2)
+//     columns of P and runs resize3_backward_tiled_kernel's passes on it -- z (in place), y, x; per pass the non-zero taps
+//     in ascending source order, fmaf(w, v, acc) from 0 -- then mask, mix (`fmaf(acc, w_mix, 0) + bias`), into the LDS
+//     patch; conv3d_mfma_kernel's contraction from there (MODE 0: its plain order, 4 / 1: its split-K order by four waves
+//     / by one wave with four partial accumulators);
+//   * the z pass is the heavy one (every fine row above the columns' halo), and a convolution's workgroup holds whole
+//     z-rows of its OUTPUT: with e_nin > 0 it applies the z pass of the NEXT stage's transposed resize (nc -> e_nin) to
+//     them before they are stored -- out [Cc][nc][nc][e_nin] -- and that stage (zin == 0) starts from rows that are
+//     coarse along z already: it stages 2 - 3 x fewer floats and runs the two light passes only.  Same chains in the same
+//     order either way: bit for bit the unfused launches.
+//   g: zin ? [N][C][n_out^3] (n_out % 4 == 0, 16-byte aligned) : [N][C][n_out][n_out][n_in]
+//   grid (tiles_x * tiles_y, co_tiles, N), block: MODE 4: 256 * tiles, else >= 64 * tiles (tiles = TX * TY * ZT <= 16)
+//   LDS: w_l [kpad * 16] | tap_l [kpad] | red [MODE == 4 ? 4 * nthr : 0] | patch [CP][IX][IY][PZ] | Y [CK][FX][IY][n_in] |
+//        F [CK][FX][FX][RL] (RL = zin ? n_out : n_in; reused as R [TX * TY][16][nc] by the epilogue)
+// FX: the longest run of fine indices under TX + 2 (TY + 2) neighbouring coarse ones (host).  n_in, e_nin <= 64; exact
+// source ranges <= TAPS (epilogue: kBtTaps), candidate ranges <= 16 (host).
+struct VjpStage {
+  const float* g;
+  const float* act;
+  const float* mix_w;
+  const float* mix_b;
+  const float* wmat;
+  const float* bias;
+  float* out;
+  const float* tab;     // this stage's transposed resize: [n_in][16] = first source, taps, 12 weights (sdfr_decoder_create)
+  const float* e_tab;   // the epilogue's ([e_nin][16]), or NULL
+  int C, n_in, n_out, pad, Cc, kpad, CK, FX, ZT, TX, TY, zin, e_nin;
+};
+constexpr int kVjpXY = 6;   // TX + 2, TY + 2 <= 6
+#ifdef SDFR_VS_STAMPS   // timing experiment: the stages of the first workgroup, 10 ns ticks (device printf)
+#define VSS() do { if (vsk < 10) vss[vsk++] = wall_clock64(); } while (0)
+#else
+#define VSS() do { } while (0)
+#endif
+// ZIN: the stage runs the z pass itself (its registers: the next round's block and the z taps -- workgroups of <= 512
+// threads); else its producer's epilogue has (s.zin == ZIN: host).
+template <int COUT, int TAPS, int MODE, bool ZIN>
+__global__ __launch_bounds__(ZIN ? 512 : 1024) void vjp_stage_kernel(VjpStage s) {
+  constexpr int CO = COUT > 0 ? COUT : 1;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float w_tab[2 * kVjpXY + 64][kBtTaps];   // rows: a (x), kVjpXY + b (y), 2 kVjpXY + iz (z)
+  __shared__ int d_tab[2 * kVjpXY + 64], n_tab[2 * kVjpXY];
+  __shared__ float e_w[64][kBtTaps];                  // the epilogue's z pass
+  __shared__ int e_d[64], e_n[64];
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+  const int co_tile = blockIdx.y, nb = blockIdx.z;
+#ifdef SDFR_VS_STAMPS
+  unsigned long long vss[10]; int vsk = 0;
+#endif
+  VSS();
+  const int C = s.C, n_in = s.n_in, n_out = s.n_out, pad = s.pad, TX = s.TX, TY = s.TY, ZT = s.ZT, FX = s.FX, CK = s.CK;
+  const int np = n_in + 2 * pad, nc = np - 2;
+  const int tiles_y = (nc + TY - 1) / TY;
+  const int tx0 = ((int)blockIdx.x / tiles_y) * TX, ty0 = ((int)blockIdx.x % tiles_y) * TY;
+  const int CP = COUT > 0 ? COUT : C;
+  const int IX = TX + 2, IY = TY + 2, PZ = 16 * ZT + 2, patch_n = CP * IX * IY * PZ, ab_n = IX * IY;
+  const int RL = ZIN ? n_out : n_in;
+  float* w_l = lds;
+  int* tap_l = reinterpret_cast<int*>(w_l + (size_t)s.kpad * 16);
+  float* red = reinterpret_cast<float*>(tap_l + s.kpad);
+  float* patch = red + (MODE == 4 ? 4 * nthr : 0);
+  float* Y = patch + ((patch_n + 3) & ~3);
+  float* F = Y + (((size_t)CK * FX * IY * n_in + 3) & ~(size_t)3);
+  const size_t coarse_vol = (size_t)n_in * n_in * n_in;
+  const unsigned m_ni = magic_of(n_in), m_ab = magic_of(ab_n), m_iy = magic_of(IY);
+  // an item of the x pass: e -> (ck, a, b, jz); its place in the coarse tensor (-1: outside, a zero of the padding)
+  auto x_item = [&](int e, int& ck, int& ab, int& a, int& b, int& jz) {
+    const int r0 = div_by(e, m_ni);
+    jz = e - r0 * n_in;
+    ck = div_by(r0, m_ab);
+    ab = r0 - ck * ab_n;
+    a = div_by(ab, m_iy);
+    b = ab - a * IY;
+    const int ix = tx0 + a - pad, iy = ty0 + b - pad;
+    return (ix < 0 || ix >= n_in || iy < 0 || iy >= n_in) ? -1 : (ix * n_in + iy) * n_in + jz;
   };
+  // the ReLU mask of this thread's first item of the first round: on its way before anything else
+  float mask0[CO];
+  if (s.act) {
+    int ck, ab, a, b, jz;
+    const int at = tid < min(CK, C) * ab_n * n_in ? x_item(tid, ck, ab, a, b, jz) : -1;
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+      mask0[co] = at >= 0 ? s.act[((size_t)nb * CP + (COUT > 0 ? co : ck)) * coarse_vol + at] : 0.0f;
+  }
+  // the block of fine rows above the workgroup's columns of P: x in [fx0, fx0 + fnx), y in [fy0, fy0 + fny), whole rows
+  // (first source and taps of the first / last coarse index inside the tensor: four rows of the table, scalar loads)
+  const int a_lo = max(pad - tx0, 0), a_hi = min(n_in - 1 - tx0 + pad, IX - 1);
+  const int b_lo = max(pad - ty0, 0), b_hi = min(n_in - 1 - ty0 + pad, IY - 1);
+  const int* itab = reinterpret_cast<const int*>(s.tab);
+  const int fx0 = itab[(tx0 + a_lo - pad) * 16], fx1 = itab[(tx0 + a_hi - pad) * 16] + itab[(tx0 + a_hi - pad) * 16 + 1];
+  const int fy0 = itab[(ty0 + b_lo - pad) * 16], fy1 = itab[(ty0 + b_hi - pad) * 16] + itab[(ty0 + b_hi - pad) * 16 + 1];
+  const int fnx = fx1 - fx0, fny = fy1 - fy0;
+  const size_t src_vol = (size_t)n_out * n_out * RL;
+  const int slab = fny * RL, slab_u = ZIN ? slab >> 2 : slab;   // units: 16-byte vectors (ZIN: RL % 4 == 0) / floats
+  const unsigned m_fy = magic_of(fny), m_fx = magic_of(fnx), m_su = magic_of(slab_u);
+  auto unit_at = [&](int e, int& lds_off) {   // unit e of a round's block -> float offsets in g's channels / in F
+    const int sl = div_by(e, m_su), off = (e - sl * slab_u) * (ZIN ? 4 : 1);
+    const int ck = div_by(sl, m_fx), fx = sl - ck * fnx;
+    lds_off = (ck * FX + fx) * FX * RL + off;
+    return (size_t)ck * src_vol + ((size_t)(fx0 + fx) * n_out + fy0) * RL + off;
+  };
+  constexpr int kFl = ZIN ? 8 : 1;
+  f32x4 pre[kFl];
   auto prefetch = [&](int c0) {
-    const int total4 = min(CK, C - c0) * fnx * fny * q4;
-    const float* src = g_out + ((size_t)nb * C + c0) * fine_vol;
+    const int total = min(CK, C - c0) * fnx * slab_u;
+    const float* src = s.g + ((size_t)nb * C + c0) * src_vol;
 #pragma unroll
     for (int j = 0; j < kFl; ++j) {
       int lo;
-      const size_t g = fine_at(min(tid + nthr * j, total4 - 1), lo);
+      const size_t g = unit_at(min(tid + nthr * j, total - 1), lo);
       pre[j] = *reinterpret_cast<const f32x4*>(src + g);
     }
   };
-  prefetch(0);   // (in flight while the weights are staged: their wait covers both)
-  stage_to_lds_n(w_l, wmat + (size_t)co_tile * kpad * 16, kpad * 16, tid, nthr);
+  // the tables of this column block -- rows a (x), kVjpXY + b (y), 2 kVjpXY + iz (z, ZIN), then the epilogue's --: loaded
+  // first, stored behind everything else that is issued (the block's loads do not wait for them)
+  constexpr int kTv = 4;
+  float tv[kTv];
+  const int t_rows = 2 * kVjpXY + (ZIN ? n_in : 0), t_total = (t_rows + s.e_nin) * 16;
+  auto table_row = [&](int row, bool& epi) {
+    epi = row >= t_rows;
+    int i;
+    if (epi) i = row - t_rows;
+    else if (row < kVjpXY) { i = tx0 + row - pad; if (row >= IX || i < 0 || i >= n_in) i = -1; }
+    else if (row < 2 * kVjpXY) { i = ty0 + row - kVjpXY - pad; if (row - kVjpXY >= IY || i < 0 || i >= n_in) i = -1; }
+    else i = row - 2 * kVjpXY;
+    return i;
+  };
+#pragma unroll
+  for (int u = 0; u < kTv; ++u) {
+    const int e = tid + nthr * u;
+    bool epi;
+    const int i = e < t_total ? table_row(e >> 4, epi) : -1;
+    tv[u] = i >= 0 ? (epi ? s.e_tab : s.tab)[i * 16 + (e & 15)] : 0.0f;
+  }
+  if (ZIN) prefetch(0);   // (in flight while the tables and the weights are staged)
+  auto table_store = [&](int e, float v) {
+    const int row = e >> 4, k = e & 15;
+    bool epi;
+    const int i = table_row(row, epi);
+    const int vi = __builtin_bit_cast(int, v);
+    if (epi) {
+      if (k == 0) e_d[i] = vi; else if (k == 1) e_n[i] = vi; else if (k - 2 < kBtTaps) e_w[i][k - 2] = v;
+    } else {
+      if (k == 0) d_tab[row] = vi; else if (k == 1) { if (row < 2 * kVjpXY) n_tab[row] = vi; } else if (k - 2 < kBtTaps) w_tab[row][k - 2] = v;
+    }
+  };
+  for (int e = tid; e < patch_n; e += nthr) patch[e] = 0.0f;   // the padding
+  patch_taps(tap_l, s.kpad, CP * 27, IX, IY, PZ, tid, nthr);
+  VSS();   // 1: set-up issued
+  auto tables_to_lds = [&]() {
+#pragma unroll
+    for (int u = 0; u < kTv; ++u)
+      if (tid + nthr * u < t_total) table_store(tid + nthr * u, tv[u]);
+    for (int e = tid + nthr * kTv; e < t_total; e += nthr) {   // (more rows than the registers hold: rare)
+      bool epi;
+      const int i = table_row(e >> 4, epi);
+      table_store(e, i >= 0 ? (epi ? s.e_tab : s.tab)[i * 16 + (e & 15)] : 0.0f);
+    }
+  };
   // lane -> (slot, iz): 64 / nl rows per wave step, nl = the power of two that holds a coarse row
   const int nl = n_in <= 8 ? 8 : (n_in <= 16 ? 16 : (n_in <= 32 ? 32 : 64));
   const int spw = 64 / nl, slot = lane / nl, iz = lane - slot * nl;
   const bool zok = iz < n_in;
-  const int dz = zok ? d_tab[6 + iz] : 0;
-  float wz[TAPS];
-  int oz[TAPS];
-#pragma unroll
-  for (int k = 0; k < TAPS; ++k) {
-    wz[k] = zok ? w_tab[6 + iz][k] : 0.0f;
-    oz[k] = min(dz + k, n_out - 1);
-  }
   for (int c0 = 0; c0 < C; c0 += CK) {
     const int ck_n = min(CK, C - c0);
-    const int total4 = ck_n * fnx * fny * q4;
+    const int total = ck_n * fnx * slab_u;
     if (c0 > 0) __syncthreads();   // the previous round's passes have left F and Y
+    if (ZIN) {
+      if (c0 == 0) {
+        tables_to_lds();
+        stage_to_lds_n(w_l, s.wmat + (size_t)co_tile * s.kpad * 16, s.kpad * 16, tid, nthr);
+      }
 #pragma unroll
-    for (int j = 0; j < kFl; ++j) {
-      const int e = tid + nthr * j;
-      if (e < total4) {
-        int lo;
-        (void)fine_at(e, lo);
-        *reinterpret_cast<f32x4*>(F + lo) = pre[j];
+      for (int j = 0; j < kFl; ++j) {
+        const int e = tid + nthr * j;
+        if (e < total) {
+          int lo;
+          (void)unit_at(e, lo);
+          *reinterpret_cast<f32x4*>(F + lo) = pre[j];
+        }
       }
-    }
-    if (total4 > kFl * nthr) {   // (blocks larger than the prefetch: the rest straight from memory)
-      const float* src = g_out + ((size_t)nb * C + c0) * fine_vol;
-      for (int e = tid + nthr * kFl; e < total4; e += nthr) {
-        int lo;
-        const size_t g = fine_at(e, lo);
-        *reinterpret_cast<f32x4*>(F + lo) = *reinterpret_cast<const f32x4*>(src + g);
+      if (total > kFl * nthr) {   // (blocks larger than the prefetch: the rest straight from memory)
+        const float* src = s.g + ((size_t)nb * C + c0) * src_vol;
+        for (int e = tid + nthr * kFl; e < total; e += nthr) {
+          int lo;
+          const size_t g = unit_at(e, lo);
+          *reinterpret_cast<f32x4*>(F + lo) = *reinterpret_cast<const f32x4*>(src + g);
+        }
       }
-    }
-    __syncthreads();
-    if (c0 + CK < C) prefetch(c0 + CK);
-    {   // z pass, in place: row (ck, fx, fy) -> its head [0, n_in)
+      __syncthreads();
+      if (c0 + CK < C) prefetch(c0 + CK);
+      // z pass, in place: row (ck, fx, fy) -> its head [0, n_in)
+      float wz[TAPS];
+      int oz[TAPS];
+      {
+        const int dz = zok ? d_tab[2 * kVjpXY + iz] : 0;
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) {
+          wz[k] = zok ? w_tab[2 * kVjpXY + iz][k] : 0.0f;
+          oz[k] = min(dz + k, n_out - 1);
+        }
+      }
       const int rows = ck_n * fnx * fny;
       for (int r = wave * spw + slot; r < rows; r += nw * spw) {
         const int r1 = div_by(r, m_fy), fy = r - r1 * fny;
         const int ck = div_by(r1, m_fx), fx = r1 - ck * fnx;
-        float* f = F + (size_t)((ck * FX + fx) * FX + fy) * n_out;
+        float* f = F + (size_t)((ck * FX + fx) * FX + fy) * RL;
         float v[TAPS];
 #pragma unroll
         for (int k = 0; k < TAPS; ++k) v[k] = f[oz[k]];
@@ -349,81 +561,161 @@ __global__ __launch_bounds__(SPLIT ? 1024 : 512) void conv3d_mfma_tresize_kernel
         for (int k = 0; k < TAPS; ++k) acc = (wz[k] != 0.0f) ? fmaf(wz[k], v[k], acc) : acc;
         if (zok) f[iz] = acc;
       }
+    } else {
+      // rows that the producer's epilogue left coarse along z: eight loads in flight per thread
+      const float* src = s.g + ((size_t)nb * C + c0) * src_vol;
+      constexpr int kB = 8;
+      bool staged = c0 > 0;
+      for (int e0 = tid; e0 < total; e0 += kB * nthr) {
+        float v[kB];
+        int lo[kB];
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+          const size_t g = unit_at(min(e0 + u * nthr, total - 1), lo[u]);
+          v[u] = src[g];
+        }
+        if (!staged) {
+          tables_to_lds();
+          stage_to_lds_n(w_l, s.wmat + (size_t)co_tile * s.kpad * 16, s.kpad * 16, tid, nthr);
+          staged = true;
+        }
+#pragma unroll
+        for (int u = 0; u < kB; ++u)
+          if (e0 + u * nthr < total) F[lo[u]] = v[u];
+      }
+      if (!staged) {
+        tables_to_lds();
+        stage_to_lds_n(w_l, s.wmat + (size_t)co_tile * s.kpad * 16, s.kpad * 16, tid, nthr);
+      }
     }
     __syncthreads();
+    VSS();   // 2: block staged (+ z pass)
     {   // y pass: (ck, fx, b) -> Y[ck][fx][b][iz]
-      const int trip = ck_n * fnx * 3;
+      const int trip = ck_n * fnx * IY;
       for (int r = wave * spw + slot; r < trip; r += nw * spw) {
-        const int r1 = r / 3, b = r - 3 * r1;
+        const int r1 = div_by(r, m_iy), b = r - r1 * IY;
         const int ck = div_by(r1, m_fx), fx = r1 - ck * fnx;
-        const int d0 = d_tab[3 + b] - fy0;
-        const float* zc = F + (size_t)((ck * FX + fx) * FX) * n_out + (zok ? iz : 0);
+        const int d0 = d_tab[kVjpXY + b] - fy0;
+        const float* zc = F + (size_t)((ck * FX + fx) * FX) * RL + (zok ? iz : 0);
         float w[TAPS], v[TAPS];
 #pragma unroll
         for (int k = 0; k < TAPS; ++k) {
-          w[k] = w_tab[3 + b][k];
-          v[k] = zc[min(max(d0 + k, 0), fny - 1) * n_out];
+          w[k] = w_tab[kVjpXY + b][k];
+          v[k] = zc[min(max(d0 + k, 0), fny - 1) * RL];
         }
         float acc = 0.0f;
 #pragma unroll
         for (int k = 0; k < TAPS; ++k) acc = (w[k] != 0.0f) ? fmaf(w[k], v[k], acc) : acc;
-        if (zok) Y[((ck * FX + fx) * 3 + b) * n_in + iz] = acc;
+        if (zok) Y[((ck * FX + fx) * IY + b) * n_in + iz] = acc;
       }
     }
     __syncthreads();
+    VSS();   // 3: y pass
     {   // x pass, mask, (mix,) into the patch: items (ck, a, b, iz), inside the tensor only
-      const int items = ck_n * 9 * n_in;
+      const int items = ck_n * ab_n * n_in;
       for (int e = tid; e < items; e += nthr) {
-        const int r0 = div_by(e, m_ni), jz = e - r0 * n_in;
-        const int ck = r0 / 9, ab = r0 - 9 * ck, a = ab / 3, b = ab - 3 * a;
-        const int ix = x + a - pad, iy = y + b - pad;
-        if (ix < 0 || ix >= n_in || iy < 0 || iy >= n_in) continue;
-        const size_t at = ((size_t)ix * n_in + iy) * n_in + jz;
+        int ck, ab, a, b, jz;
+        const int at = x_item(e, ck, ab, a, b, jz);
+        if (at < 0) continue;
         float mask[CO];
-        if (act) {
+        if (s.act) {
 #pragma unroll
           for (int co = 0; co < CO; ++co)
-            mask[co] = act[((size_t)nb * CP + (COUT > 0 ? co : c0 + ck)) * coarse_vol + at];
+            mask[co] = (e == tid && c0 == 0) ? mask0[co]
+                                             : s.act[((size_t)nb * CP + (COUT > 0 ? co : c0 + ck)) * coarse_vol + at];
         }
         const int d0 = d_tab[a] - fx0;
-        const float* yc = Y + (size_t)((ck * FX) * 3 + b) * n_in + jz;
+        const float* yc = Y + (size_t)((ck * FX) * IY + b) * n_in + jz;
         float w[TAPS], v[TAPS];
 #pragma unroll
         for (int k = 0; k < TAPS; ++k) {
           w[k] = w_tab[a][k];
-          v[k] = yc[min(max(d0 + k, 0), fnx - 1) * 3 * n_in];
+          v[k] = yc[min(max(d0 + k, 0), fnx - 1) * IY * n_in];
         }
         float acc = 0.0f;
 #pragma unroll
         for (int k = 0; k < TAPS; ++k) acc = (w[k] != 0.0f) ? fmaf(w[k], v[k], acc) : acc;
         if (COUT == 0) {
-          if (act && !(mask[0] > 0.0f)) acc = 0.0f;
-          patch[((c0 + ck) * 9 + ab) * PZ + jz + pad] = acc;
+          if (s.act && !(mask[0] > 0.0f)) acc = 0.0f;
+          patch[((c0 + ck) * ab_n + ab) * PZ + jz + pad] = acc;
         } else {
 #pragma unroll
           for (int co = 0; co < CO; ++co) {
-            const float v1 = fmaf(acc, mix_w[co], 0.0f) + mix_b[co];
-            patch[(co * 9 + ab) * PZ + jz + pad] = (!act || mask[co] > 0.0f) ? v1 : 0.0f;
+            const float v1 = fmaf(acc, s.mix_w[co], 0.0f) + s.mix_b[co];
+            patch[(co * ab_n + ab) * PZ + jz + pad] = (!s.act || mask[co] > 0.0f) ? v1 : 0.0f;
           }
         }
       }
     }
   }
   __syncthreads();
+  VSS();   // 4: x pass
+  // contraction: this wave's tile (column lx, ly; z tile zt)
+  const int tw = MODE == 4 ? wave >> 2 : wave;
+  const int zt = tw % ZT, cl = tw / ZT, ly_ = cl % TY, lx_ = cl / TY;
+  const int x = tx0 + lx_, y = ty0 + ly_;
+  const bool has = tw < TX * TY * ZT && x < nc && y < nc;
+  const float* base = patch + (lx_ * IY + ly_) * PZ + zt * 16 + (lane & 15);
   f32x4 acc;
-  int tile;
-  if (column_contract<SPLIT>(patch, w_l, red, kpad, PZ, ZT, acc, tile))
-    column_store(acc, tile, bias, co_tile, Cc, 0, out, nb, nc, x, y);
+  bool done;
+  if (MODE == 0) {
+    done = has;
+    if (has) tile_contract_plain(base, tap_l, w_l, s.kpad, acc);
+  } else {
+    done = tile_contract<MODE == 4 ? 4 : 1>(base, has, tap_l, w_l, red, s.kpad, acc);
+  }
+  VSS();   // 5: contraction
+#ifdef SDFR_VS_STAMPS
+  if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+    printf("vjp stage n_in %d n_out %d zin %d threads %d: tables %.2f stage%s %.2f y %.2f x %.2f contract %.2f us (first round)\n", n_in,
+           n_out, (int)ZIN, nthr, (double)(vss[1] - vss[0]) * 0.01, ZIN ? "+z" : "", (double)(vss[2] - vss[1]) * 0.01,
+           (double)(vss[3] - vss[2]) * 0.01, (double)(vss[4] - vss[3]) * 0.01, (double)(vss[5] - vss[4]) * 0.01);
+#endif
+  if (s.e_nin == 0) {
+    if (done) column_store(acc, zt, s.bias, co_tile, s.Cc, 0, s.out, nb, nc, x, y);
+    return;
+  }
+  // epilogue: the z pass of the next stage's transposed resize (nc -> e_nin) on the finished z-rows
+  float* R = F;   // [TX * TY][16][nc]  (every pass has left F: the barrier in front of the contraction)
+  if (done) {
+    const int row = lane & 15, kq = lane >> 4, co = co_tile * 16 + row;
+    const float bv = co < s.Cc ? s.bias[co] : 0.0f;
+    float* rr = R + (size_t)((lx_ * TY + ly_) * 16 + row) * nc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int zz = zt * 16 + kq * 4 + r;
+      if (zz < nc) rr[zz] = acc[r] + bv;
+    }
+  }
+  __syncthreads();
+  {
+    const int e_nin = s.e_nin, items = TX * TY * 16 * e_nin;
+    const unsigned m_e = magic_of(e_nin);
+    for (int e = tid; e < items; e += nthr) {
+      const int r0 = div_by(e, m_e), jz = e - r0 * e_nin;
+      const int col = r0 >> 4, row = r0 & 15, co = co_tile * 16 + row;
+      const int lx = col / TY, ly = col - lx * TY, xx = tx0 + lx, yy = ty0 + ly;
+      if (co >= s.Cc || xx >= nc || yy >= nc) continue;
+      const float* rr = R + (size_t)r0 * nc + e_d[jz];
+      const int nt = e_n[jz];
+      float a2 = 0.0f;
+      for (int k = 0; k < nt; ++k) {
+        const float w = e_w[jz][k];
+        a2 = (w != 0.0f) ? fmaf(w, rr[k], a2) : a2;
+      }
+      s.out[((((size_t)nb * s.Cc + co) * nc + xx) * nc + yy) * e_nin + jz] = a2;
+    }
+  }
 }
 
 // The Linear stack (narrow leading layers: fc_one_wave_ok) and the FIRST convolution (3x3x3, no resize in front of it:
 // sdf_vae.py:223-238) in one launch: every workgroup runs the narrow layers as fc_stack_kernel<true> does, forms the
 // rows of the wide layer under its column -- bias first, inputs in ascending order, ReLU: fc_stack_kernel's chain --
-// straight into the operand patch, and contracts it (split-K order).  The wide layer's output is needed again by the VJP
-// (its ReLU mask): with fc_out != NULL the column that owns a fine (x, y) -- (min(x, m - 1), min(y, m - 1)) -- stores it.
-//   grid (m * m, co_tiles, N), block >= 256 * ZT;  LDS (dynamic): w_l [kpad * 16] | red [1024 * ZT] | patch [Cin * 9 * PZ + slack]
-// VEC4: a thread forms four consecutive z of a row with 16-byte weight loads (n % 4 == 0, wide weights 16-byte aligned).
-template <bool VEC4>
+// straight into the operand patch, and contracts it (split-K order).  A row's weights (one per input of the wide layer,
+// <= kFcWaveWidth) are ALL in flight before the narrow layers start: one memory round trip for the whole stack.
+// The wide layer's output is needed again by the VJP (its ReLU mask): with fc_out != NULL the column that owns a fine
+// (x, y) -- (min(x, m - 1), min(y, m - 1)) -- stores it.
+//   grid (m * m, co_tiles, N), block >= 256 * ZT;  LDS (dynamic): w_l [kpad * 16] | tap_l [kpad] | red [4 * nthr] | patch [Cin * 9 * PZ]
 __global__ __launch_bounds__(1024) void fc_conv_kernel(const float* __restrict__ params, FcDesc d,
                                                        const float* __restrict__ z, float* __restrict__ fc_out,
                                                        const float* __restrict__ wmat, const float* __restrict__ bias,
@@ -432,103 +724,107 @@ __global__ __launch_bounds__(1024) void fc_conv_kernel(const float* __restrict__
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float act[2][kFcWaveWidth];
   __shared__ float p_lds[kFcWaveSpan];
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
   const int PZ = 16 * ZT + 2, patch_n = Cin * 9 * PZ;
   float* w_l = lds;
-  float* red = w_l + (size_t)kpad * 16;
-  float* patch = red + 1024 * ZT;
-  const int tid = threadIdx.x, nthr = blockDim.x;
+  int* tap_l = reinterpret_cast<int*>(w_l + (size_t)kpad * 16);
+  float* red = reinterpret_cast<float*>(tap_l + kpad);
+  float* patch = red + 4 * nthr;
   const int co_tile = blockIdx.y, nb = blockIdx.z;
   const int x = (int)blockIdx.x / m, y = (int)blockIdx.x - x * m;
+  const int lw = d.n_fc - 1, win = d.width[lw], wout = d.width[lw + 1];
+  const float* wt = params + d.w_off[lw];   // transposed: [in][out]
+  const float* bl = params + d.b_off[lw];
+  const int n3 = n * n * n, items = Cin * 9 * n;
+  const unsigned m_n = magic_of(n);
+  // row e of the patch: (channel, a, b, z) -> its output index o of the wide layer, its place in the patch
+  auto row_of = [&](int e, int& o, int& at, bool& own) {
+    const int r0 = div_by(e, m_n), zz = e - r0 * n;
+    const int ci = r0 / 9, ab = r0 - 9 * ci, a = ab / 3, b = ab - 3 * a;
+    o = ci * n3 + ((x + a) * n + (y + b)) * n + zz;
+    at = r0 * PZ + zz;
+    own = min(x + a, m - 1) == x && min(y + b, m - 1) == y;
+  };
+  // this thread's first row: its weights on their way before anything else
+  float wr[kFcWaveWidth];
+  float b0 = 0.0f;
+  int o0 = 0, at0 = 0;
+  bool own0 = false;
+  if (tid < items) {
+    row_of(tid, o0, at0, own0);
+    b0 = bl[o0];
+#pragma unroll
+    for (int i = 0; i < kFcWaveWidth; ++i) wr[i] = i < win ? wt[(size_t)i * wout + o0] : 0.0f;
+  }
   // the narrow layers (fc_stack_kernel<true>): their parameters to LDS with all loads in flight, then wave 0
   int cur = 0;
   {
     const long long base = d.w_off[0];
     const int span = (int)fc_wave_span(d);
     const float z_t = tid < d.width[0] ? z[(size_t)nb * d.width[0] + tid] : 0.0f;
-    constexpr int U = kFcWaveSpan / kFcBlock;   // (enough for 256 threads; larger workgroups leave the tail idle)
-    float r[U];
+    constexpr int U = 6;
+    for (int e0 = 0; e0 < span; e0 += U * nthr) {
+      float r[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e = u * nthr + tid;
-      r[u] = e < span ? params[base + e] : 0.0f;
-    }
-    stage_to_lds_n(w_l, wmat + (size_t)co_tile * kpad * 16, kpad * 16, tid, nthr);
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * nthr + tid;
+        r[u] = e < span ? params[base + e] : 0.0f;
+      }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e = u * nthr + tid;
-      if (e < span) p_lds[e] = r[u];
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * nthr + tid;
+        if (e < span) p_lds[e] = r[u];
+      }
     }
-    for (int e = tid; e < patch_n + patch_slack(ZT); e += nthr) patch[e] = 0.0f;
     if (tid < d.width[0]) act[0][tid] = z_t;
     __syncthreads();
     if (tid < 64) {
       for (int l = 0; l < d.n_fc - 1; ++l) {
-        const int win = d.width[l], wout = d.width[l + 1];
-        if (tid < wout) {
+        const int wi = d.width[l], wo = d.width[l + 1];
+        if (tid < wo) {
           float acc = p_lds[d.b_off[l] - base + tid];
-          const float* w = p_lds + (d.w_off[l] - base) + tid * win;
+          const float* w = p_lds + (d.w_off[l] - base) + tid * wi;
 #pragma unroll 8
-          for (int i = 0; i < win; ++i) acc = fmaf(w[i], act[cur][i], acc);
+          for (int i = 0; i < wi; ++i) acc = fmaf(w[i], act[cur][i], acc);
           act[cur ^ 1][tid] = fmaxf(acc, 0.0f);
         }
         __builtin_amdgcn_wave_barrier();
         cur ^= 1;
       }
     } else {
+      // (meanwhile: the convolution's weights, the tap table, the rows of the patch no output reads)
       cur = (d.n_fc - 1) & 1;
     }
+    stage_to_lds_n(w_l, wmat + (size_t)co_tile * kpad * 16, kpad * 16, tid, nthr);
+    patch_taps(tap_l, kpad, Cin * 27, 3, 3, PZ, tid, nthr);
+    for (int e = tid; e < patch_n; e += nthr) patch[e] = 0.0f;
     __syncthreads();
   }
   // the wide layer's rows under the column
-  {
-    const int l = d.n_fc - 1;
-    const int win = d.width[l], wout = d.width[l + 1];
-    const float* wt = params + d.w_off[l];   // transposed: [in][out]
-    const float* bl = params + d.b_off[l];
-    const int n3 = n * n * n;
-    const int own_x = min(x, m - 1), own_y = min(y, m - 1);   // (this column's own coordinates: x < m, y < m)
-    float* fo = (fc_out && co_tile == 0) ? fc_out + (size_t)nb * wout : nullptr;
-    if (VEC4) {
-      const int q4 = n >> 2, items = Cin * 9 * q4;
-      const unsigned m_q = magic_of(q4);
-      for (int e = tid; e < items; e += nthr) {
-        const int r0 = div_by(e, m_q), zz = (e - r0 * q4) << 2;
-        const int ci = r0 / 9, ab = r0 - 9 * ci, a = ab / 3, b = ab - 3 * a;
-        const int o = ci * n3 + ((x + a) * n + (y + b)) * n + zz;
-        f32x4 acc = *reinterpret_cast<const f32x4*>(bl + o);
+  float* fo = (fc_out && co_tile == 0) ? fc_out + (size_t)nb * wout : nullptr;
+  if (tid < items) {
+    float acc = b0;
+#pragma unroll
+    for (int i = 0; i < kFcWaveWidth; ++i)
+      if (i < win) acc = fmaf(wr[i], act[cur][i], acc);
+    acc = fmaxf(acc, 0.0f);
+    patch[at0] = acc;
+    if (fo && own0) fo[o0] = acc;
+  }
+  for (int e = tid + nthr; e < items; e += nthr) {
+    int o, at;
+    bool own;
+    row_of(e, o, at, own);
+    float acc = bl[o];
 #pragma unroll 16
-        for (int i = 0; i < win; ++i) {
-          const f32x4 w = *reinterpret_cast<const f32x4*>(wt + (size_t)i * wout + o);
-          const float h = act[cur][i];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] = fmaf(w[j], h, acc[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = fmaxf(acc[j], 0.0f);
-        float* pr = patch + r0 * PZ + zz;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pr[j] = acc[j];
-        if (fo && min(x + a, m - 1) == own_x && min(y + b, m - 1) == own_y) *reinterpret_cast<f32x4*>(fo + o) = acc;
-      }
-    } else {
-      const int items = Cin * 9 * n;
-      const unsigned m_n = magic_of(n);
-      for (int e = tid; e < items; e += nthr) {
-        const int r0 = div_by(e, m_n), zz = e - r0 * n;
-        const int ci = r0 / 9, ab = r0 - 9 * ci, a = ab / 3, b = ab - 3 * a;
-        const int o = ci * n3 + ((x + a) * n + (y + b)) * n + zz;
-        float acc = bl[o];
-#pragma unroll 16
-        for (int i = 0; i < win; ++i) acc = fmaf(wt[(size_t)i * wout + o], act[cur][i], acc);
-        acc = fmaxf(acc, 0.0f);
-        patch[r0 * PZ + zz] = acc;
-        if (fo && min(x + a, m - 1) == own_x && min(y + b, m - 1) == own_y) fo[o] = acc;
-      }
-    }
+    for (int i = 0; i < win; ++i) acc = fmaf(wt[(size_t)i * wout + o], act[cur][i], acc);
+    acc = fmaxf(acc, 0.0f);
+    patch[at] = acc;
+    if (fo && own) fo[o] = acc;
   }
   __syncthreads();
+  const int tw = wave >> 2;
   f32x4 acc;
-  int tile;
-  if (column_contract<true>(patch, w_l, red, kpad, PZ, ZT, acc, tile))
-    column_store(acc, tile, bias, co_tile, Cout, relu, out, nb, m, x, y);
+  if (tile_contract<4>(patch + tw * 16 + (lane & 15), tw < ZT, tap_l, w_l, red, kpad, acc))
+    column_store(acc, tw, bias, co_tile, Cout, relu, out, nb, m, x, y);
 }

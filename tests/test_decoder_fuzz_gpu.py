@@ -44,6 +44,11 @@ def draw(seed):
                      "relu": bool(i < n_conv - 1 and rng.uniform() < 0.8)})
         cur = in_size - k + 1
     fc.append({"out": chans[0] * conv[0]["in_size"] ** 3})
+    # a ReLU on the LAST layer too, now and then (sdf_vae.py:194-202 allows it; a taped forward then has to keep that
+    # layer's output for the VJP's mask -- round 6 found it going straight to the result instead); its own generator, so
+    # that the other draws of a seed stay what they were
+    if np.random.default_rng(10_000 + seed).uniform() < 0.3:
+        conv[-1]["relu"] = True
     volume = int(np.clip(cur + rng.integers(-2, 12), 2, 40))
     tsdf = [False, False, 0.1, True][int(rng.integers(0, 4))]
     N = int(rng.choice([1, 1, 2, 5, 20, 48]))   # 48: the batch forms of the small launches (Linear stack, 1x1, resident MFMA)

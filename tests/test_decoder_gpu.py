@@ -478,6 +478,16 @@ def _fused_single_cases(d, wts, rng):
                    dict(in_size=6, in_channels=6, out_channels=6, kernel_size=3, relu=True),
                    dict(in_size=8, in_channels=6, out_channels=3, kernel_size=3, relu=True),
                    dict(in_size=16, in_channels=3, out_channels=1, kernel_size=1, relu=False)]),
+        # five channels into the first layer (135 taps: its split-K form, so the Linear stack folds into it), three mixed
+        dict(name="7 (5 ch) -> 5 | 12 -> 10 | swapped 1x1 -> 16", volume=16, latent=4, batch=3, fc=[{"out": 12}, {"out": 5 * 7 ** 3}],
+             conv=[dict(in_size=7, in_channels=5, out_channels=6, kernel_size=3, relu=True),
+                   dict(in_size=12, in_channels=6, out_channels=3, kernel_size=3, relu=True),
+                   dict(in_size=16, in_channels=3, out_channels=1, kernel_size=1, relu=False)]),
+        # 18 output channels of the first layer (two column tiles) from 6 x 8^3, a 2.5x resize
+        dict(name="8 (6 ch) -> 6 (18 ch) | 20 -> 18 | 1x1", volume=18, latent=7, batch=1, fc=[{"out": 33}, {"out": 6 * 8 ** 3}],
+             conv=[dict(in_size=8, in_channels=6, out_channels=18, kernel_size=3, relu=True),
+                   dict(in_size=20, in_channels=18, out_channels=2, kernel_size=3, relu=True),
+                   dict(in_size=18, in_channels=2, out_channels=1, kernel_size=1, relu=False)]),
     ]
     for case in extra:
         cfg = {"latent_size": case["latent"], "tsdf": False, "sdf_size": case["volume"],
@@ -490,9 +500,9 @@ def test_single_latent_fused_pairs_are_bitwise_the_unfused_launches(mug):
     """Few latents (the render-and-compare loop decodes one): the layer PAIRS as one launch each -- the up-sampling
     resize inside the split-K MFMA convolution behind it (conv3d_mfma_up_kernel, sdf_vae.py:235-246), the Linear stack
     with the first convolution (fc_conv_kernel, :223-238), and in the VJP the transposed resize (+ mask, swapped 1x1x1
-    layer, padding) inside the transposed convolution (conv3d_mfma_tresize_kernel) -- against the launches they replace,
-    every pair alone (option bits 1, 2, 4) and all together (7): outputs, the taped activations the VJP reads, and the
-    latent gradients bit for bit."""
+    layer, padding) inside the transposed convolution (vjp_stage_kernel: its first stage alone, bit 4, and the following
+    stages chained to it through the z-pass epilogue, bits 4 + 8) -- against the launches they replace, every pair alone
+    and all together (15): outputs, the taped activations the VJP reads, and the latent gradients bit for bit."""
     from sdfest_amd import SDFDecoder
     d, wts = mug
     rng = np.random.default_rng(23)
@@ -501,7 +511,7 @@ def test_single_latent_fused_pairs_are_bitwise_the_unfused_launches(mug):
         z_np = rng.normal(size=(N, latent)).astype(np.float32)
         G = torch.tensor(rng.normal(size=(N, 1, volume, volume, volume)).astype(np.float32), device="cuda")
         res = {}
-        for bits in (0, 1, 2, 4, 7):
+        for bits in (0, 1, 2, 4, 12, 15):
             old = dec.set_option("fused_single", bits)
             try:
                 z = torch.tensor(z_np, device="cuda", requires_grad=True)
@@ -516,7 +526,7 @@ def test_single_latent_fused_pairs_are_bitwise_the_unfused_launches(mug):
         ref = res[0]
         assert torch.isfinite(ref[0]).all() and ref[0].abs().max() > 0 and ref[1].abs().max() > 0, name
         assert torch.equal(ref[0], ref[2]), name
-        for bits in (1, 2, 4, 7):
+        for bits in (1, 2, 4, 12, 15):
             o, g, plain = res[bits]
             assert torch.equal(o, ref[0]), (name, N, bits, "output", (o - ref[0]).abs().max().item())
             assert torch.equal(plain, ref[0]), (name, N, bits, "output without a tape", (plain - ref[0]).abs().max().item())

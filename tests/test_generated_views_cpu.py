@@ -93,3 +93,12 @@ def test_mask_affine_parameters_and_matrices():
     fwd = torch.tensor([[0.5 * c, -0.5 * s_, 1.0], [0.5 * s_, 0.5 * c, 4.0], [0, 0, 1]]).double()
     inv = torch.cat([m[2].reshape(2, 3), torch.tensor([[0.0, 0, 1]]).double()])
     assert torch.allclose(inv @ fwd, torch.eye(3).double(), atol=1e-6)
+    # two parameter tuples of the dataset's range worked out by hand from torchvision's documented formula
+    # (functional._get_inverse_affine_matrix, center (0, 0), no shear: M^-1 = [[cos, sin], [-sin, cos]] / scale, then
+    # M^-1 (-t) in the last column):  (0.5 deg, t = (0, 3), s = 1.0005)  and  (0.75 deg, t = (0, -5), s = 0.9992)
+    k = gv.inverse_affine_matrices(torch.tensor([0.5, 0.75]), torch.tensor([[0.0, 3.0], [0.0, -5.0]]),
+                                   torch.tensor([1.0005, 0.9992])).double()
+    assert torch.allclose(k[0], torch.tensor([0.999462192, 0.0087221744, -0.0261665232, -0.0087221744, 0.999462192,
+                                              -2.9983865759]).double(), atol=2e-7)
+    assert torch.allclose(k[1], torch.tensor([1.0007148995, 0.0131000756, 0.0655003782, -0.0131000756, 1.0007148995,
+                                              5.0035744975]).double(), atol=2e-7)

@@ -85,3 +85,48 @@ def test_healpix_equal_area():
     # and a point stays in its pixel under a small displacement away from the pixel's border
     t, p = pix2ang_nest(8, np.arange(768))
     assert np.array_equal(ang2pix_nest(8, t + 1e-3, p + 1e-3), np.arange(768))
+
+
+# healpy.nest2ring(2, np.arange(48)) as printed in healpy's documentation / HEALPix primer figure 4 (N_side = 2): the RING
+# index of every NESTED pixel.  Published data, typed in -- not produced by this repository's code.
+_NEST2RING_NSIDE2 = [13, 5, 4, 0, 15, 7, 6, 1, 17, 9, 8, 2, 19, 11, 10, 3, 28, 20, 27, 12, 30, 22, 21, 14, 32, 24, 23, 16,
+                     34, 26, 25, 18, 44, 37, 36, 29, 45, 39, 38, 31, 46, 41, 40, 33, 47, 43, 42, 35]
+
+
+def test_healpix_nside2_nested_pixel_centres_known_answers():
+    """The 48 pixel centres of N_side = 2 in NESTED order -- the S2 part of the mug grid's 576 cells (resol 1) --
+    from the closed-form RING-scheme centres of Gorski et al. 2005 (ApJ 622:759), equations (2)-(9):
+        north cap   ring i < N:        z = 1 - i^2 / (3 N^2),    phi = pi / (2 i) (j - 1/2),      j = 1 .. 4 i
+        belt        N <= i <= 3 N:     z = 4/3 - 2 i / (3 N),    phi = pi / (2 N) (j - s / 2),    s = (i - N + 1) mod 2
+        south cap   by the mirror z -> -z
+    (pixels of a ring in ascending phi from [0, 2 pi)) and the published NESTED -> RING table above.  A pixel order that
+    is self-consistent but wrong (which every round-trip test would pass, rotating every initial orientation) fails
+    here.  so3grid.py:163-175 (hp.pix2ang) and :43 (hp.ang2pix)."""
+    N = 2
+    ring = []
+    for i in range(1, 4 * N):
+        if i < N:
+            z, phis = 1 - i * i / (3 * N * N), [np.pi / (2 * i) * (j - 0.5) for j in range(1, 4 * i + 1)]
+        elif i <= 3 * N:
+            s = (i - N + 1) % 2
+            z, phis = 4 / 3 - 2 * i / (3 * N), sorted((np.pi / (2 * N) * (j - s / 2)) % (2 * np.pi) for j in range(1, 4 * N + 1))
+        else:
+            k = 4 * N - i
+            z, phis = -(1 - k * k / (3 * N * N)), [np.pi / (2 * k) * (j - 0.5) for j in range(1, 4 * k + 1)]
+        ring += [(np.arccos(z), p) for p in phis]
+    assert len(ring) == 48
+    expect = np.array(ring)[_NEST2RING_NSIDE2]
+    # a few of them spelled out: pixel 3 is the north corner of base pixel 0, pixel 0 its south corner (both at phi = pi/4);
+    # base pixel 4 (centred on z = 0, phi = 0) has its children 16 .. 19 to the south, east, west and north of its centre;
+    # pixel 44 is the south corner of base pixel 11, pixel 47 its north corner
+    assert np.allclose(expect[3], [np.arccos(11 / 12), np.pi / 4]) and np.allclose(expect[0], [np.arccos(1 / 3), np.pi / 4])
+    assert np.allclose(expect[16:20], [[np.arccos(-1 / 3), 0], [np.pi / 2, np.pi / 8], [np.pi / 2, 15 * np.pi / 8], [np.arccos(1 / 3), 0]])
+    assert np.allclose(expect[44], [np.arccos(-11 / 12), 7 * np.pi / 4]) and np.allclose(expect[47], [np.arccos(-1 / 3), 7 * np.pi / 4])
+    theta, phi = pix2ang_nest(2, np.arange(48))
+    assert np.allclose(theta, expect[:, 0], atol=1e-14) and np.allclose(phi, expect[:, 1], atol=1e-14)
+    assert np.array_equal(ang2pix_nest(2, expect[:, 0], expect[:, 1]), np.arange(48))
+    # ... and through the grid object: cell s1 * 48 + p has these angles
+    grid = SO3Grid(1)
+    assert grid.num_cells() == 576
+    psi, th, ph = grid.index_to_hopf(np.arange(576))
+    assert np.allclose(th, np.tile(expect[:, 0], 12)) and np.allclose(ph, np.tile(expect[:, 1], 12))

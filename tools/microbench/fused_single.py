@@ -40,8 +40,8 @@ def main():
         z_np = rng.normal(size=(N, latent)).astype(np.float32)
         G = torch.tensor(rng.normal(size=(N, 1, volume, volume, volume)).astype(np.float32), device="cuda")
         res = {}
-        for bits in (0, 1, 2, 4, 7, 8):     # (8: bits 0 again -- is the unfused form itself reproducible?)
-            dec.set_option("fused_single", bits & 7)
+        for bits in (0, 1, 2, 4, 12, 15, 16):     # (16: bits 0 again -- is the unfused form itself reproducible?)
+            dec.set_option("fused_single", bits & 15)
             z = torch.tensor(z_np, device="cuda", requires_grad=True)
             try:
                 o = dec.decode(z)
@@ -50,7 +50,7 @@ def main():
                 res[bits] = (o.detach().clone(), z.grad.clone())
             except RuntimeError as e:
                 print(f"{name} N={N} bits={bits}: {e}", flush=True)
-        for bits in (1, 2, 4, 7, 8):
+        for bits in (1, 2, 4, 12, 15, 16):
             if bits not in res or 0 not in res:
                 continue
             o, g = res[bits]
@@ -58,7 +58,7 @@ def main():
             dg = (g - res[0][1]).abs().max().item()
             bad_o = int((o != res[0][0]).sum().item())
             print(f"{name:55s} N={N:2d} bits={bits}: out {'==' if torch.equal(o, res[0][0]) else f'DIFF {do:.3e} ({bad_o} values of {o.numel()})':30s} "
-                  f"grad {'==' if torch.equal(g, res[0][1]) else f'DIFF {dg:.3e} rel {dg / res[0][1].abs().max().item():.2e}'}", flush=True)
+                  f"grad {'==' if torch.equal(g, res[0][1]) else f'DIFF {dg:.3e} of max {res[0][1].abs().max().item():.3e}'}  (out max {res[0][0].abs().max().item():.3e})", flush=True)
     if os.environ.get("NO_TIMES"):
         return
     # times: the mug decoder, one latent
@@ -66,7 +66,7 @@ def main():
     dec = SDFDecoder.from_config(cfg, wts)
     z0 = torch.zeros(1, 8, device="cuda")
     G = torch.ones(1, 1, 64, 64, 64, device="cuda")
-    for bits in (0, 1, 2, 3, 4, 7, 0, 7):
+    for bits in (0, 1, 5, 13, 15, 0, 5):
         dec.set_option("fused_single", bits)
 
         def fwd():
@@ -81,7 +81,7 @@ def main():
         torch.cuda.synchronize()
         print(f"bits {bits}: decode {event_us(fwd, 200):7.2f} us (host-driven), decode + VJP {event_us(both, 100):7.2f} us", flush=True)
     s = c5_scene(views=1, max_iterations=50)
-    for bits in (0, 7, 1, 2, 4, 3, 5, 6, 0, 7):
+    for bits in (0, 5, 1, 4, 13, 7, 15, 0, 5):
         s["decoder"].set_option("fused_single", bits)
         loop = FusedRenderAndCompare(s["decoder"], s["camera"], s["config"], s["targets"], graph_iterations=5)
         out = loop(*s["init"])
