@@ -22,6 +22,36 @@
 static int g_margin_hit_tests_only = 0;
 void sdfo_set_margin_mode(int hit_tests_only) { g_margin_hit_tests_only = hit_tests_only != 0; }
 
+/* Per-thread d/dSDF slabs of the renderer's backward ("per-thread grad_sdf slabs + tree reduce"; until round 6
+ * every contribution was an `omp atomic` on one shared volume, and the port stopped scaling at 64 threads).  A slab is a
+ * thread's own R^3 doubles, kept between calls and left all-zero by the reduction; each thread notes the range of
+ * voxels it touched, so a single view (C1 / C2) reduces over thousands of words, not over threads x R^3. */
+#ifdef _OPENMP
+#include <omp.h>
+#else
+static int omp_get_max_threads(void) { return 1; }
+static int omp_get_thread_num(void) { return 0; }
+#endif
+typedef struct { double* v; size_t cap, lo, hi; } sdfo_slab;
+static sdfo_slab* g_slabs = NULL;
+static int g_nslabs = 0;
+static sdfo_slab* sdfo_slabs(int threads) {   /* (called outside parallel regions) */
+  if (threads > g_nslabs) {
+    g_slabs = (sdfo_slab*)realloc(g_slabs, (size_t)threads * sizeof(sdfo_slab));
+    for (int t = g_nslabs; t < threads; ++t) { g_slabs[t].v = NULL; g_slabs[t].cap = 0; }
+    g_nslabs = threads;
+  }
+  return g_slabs;
+}
+static double* sdfo_slab_of(sdfo_slab* s, size_t nvox) {   /* (by the owning thread: first touch places the pages) */
+  if (s->cap < nvox) {
+    free(s->v);
+    s->v = (double*)calloc(nvox, sizeof(double));
+    s->cap = nvox;
+  }
+  return s->v;
+}
+
 #define REAL float
 #define SUFFIX _f32
 #define SQRT sqrtf
@@ -49,7 +79,6 @@ void sdfo_set_margin_mode(int hit_tests_only) { g_margin_hit_tests_only = hit_te
 int sdfo_version(void) { return 1; }
 
 #ifdef _OPENMP
-#include <omp.h>
 void sdfo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 int sdfo_max_threads(void) { return omp_get_max_threads(); }
 #else

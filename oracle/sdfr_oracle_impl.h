@@ -283,7 +283,8 @@ static inline void FN(pixel_derivs)(const REAL* sdf, int R, REAL z, FN(v3) d, FN
 /* Depth render, backward.  sdf_renderer_cuda.cu:300-468 (+ host launcher
  * :512-556 for the zero-fill) == simple_renderer.py:317-458 reduced as in
  * sdf_renderer.py:242-261.  Sums are carried in double in both builds so that
- * the oracle is the summation-order-free reference value.
+ * the oracle is the summation-order-free reference value (the _f32 build: every
+ * per-pixel term in float, summed exactly -- the floor a float kernel can reach).
  * g_sdf R^3 is the sum over all B views; g_pos B*3, g_quat B*4, g_inv_scale B. */
 void FN(sdfo_render_backward)(const REAL* grad_depth, const REAL* depth, const REAL* sdf, int R,
                               const REAL* pos, const REAL* quat, const REAL* inv_scale, int B,
@@ -292,43 +293,74 @@ void FN(sdfo_render_backward)(const REAL* grad_depth, const REAL* depth, const R
                               REAL* g_inv_scale) {
   const size_t nvox = (size_t)R * R * R;
   const size_t RR = (size_t)R * R;
-  double* acc_sdf = (double*)calloc(nvox, sizeof(double));
-  /* views in parallel; pose sums are per view and sequential in pixel order, voxel sums use
-   * atomics on doubles (order-dependent only at the 1e-16 level) */
-#pragma omp parallel for schedule(dynamic, 1)
-  for (int b = 0; b < B; ++b) {
-    REAL rot[3][3];
-    FN(quat_matrix)(quat + 4 * b, rot);
-    const FN(v3) p = FN(v3_make)(pos[3 * b], pos[3 * b + 1], pos[3 * b + 2]);
-    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int row = 0; row < H; ++row) {
-      for (int col = 0; col < W; ++col) {
-        const size_t pix = ((size_t)b * H + row) * W + col;
-        const REAL z = depth[pix];
-        if (z == 0) continue;
-        const REAL go = grad_depth[pix];
-        FN(v3) d = FN(pixel_ray)(row, col, cx, cy, fx, fy);
-        FN(cell) c;
-        REAL dz[8], f, wgt[8];
-        FN(pixel_derivs)(sdf, R, z, d, p, quat + 4 * b, rot, inv_scale[b], &c, dz, &f);
-        for (int k = 0; k < 8; ++k) acc[k] += (double)(dz[k] * go);
-        FN(corner_weights)(c.off, sdf_grad_mode, wgt);
-        double* a = acc_sdf + c.base[0] * RR + (size_t)c.base[1] * R + c.base[2];
-        const size_t offs[8] = {0, 1, (size_t)R, (size_t)R + 1, RR, RR + 1, RR + R, RR + R + 1};
-        for (int k = 0; k < 8; ++k) {
-          const double contrib = (double)(go * wgt[k] * f);
-#pragma omp atomic
-          a[offs[k]] += contrib;
+  /* (view, row) pairs in parallel; every thread adds into its OWN double volume and its own per-view pose sums,
+   * both reduced over the threads afterwards in thread order (doubles: order-dependent at the 1e-16 level only) */
+  const int T = omp_get_max_threads();
+  sdfo_slab* slabs = sdfo_slabs(T);
+  double* pose_acc = (double*)calloc((size_t)T * B * 8, sizeof(double));
+  for (int t = 0; t < T; ++t) { slabs[t].lo = nvox; slabs[t].hi = 0; }
+#pragma omp parallel
+  {
+    const int t = omp_get_thread_num();
+    sdfo_slab* mine = slabs + t;
+    double* acc_sdf = NULL;
+    double* accs = pose_acc + (size_t)t * B * 8;
+    size_t lo = nvox, hi = 0;
+#pragma omp for collapse(2) schedule(dynamic, 8)
+    for (int b = 0; b < B; ++b) {
+      for (int row = 0; row < H; ++row) {
+        REAL rot[3][3];
+        FN(quat_matrix)(quat + 4 * b, rot);
+        const FN(v3) p = FN(v3_make)(pos[3 * b], pos[3 * b + 1], pos[3 * b + 2]);
+        double* acc = accs + (size_t)b * 8;
+        for (int col = 0; col < W; ++col) {
+          const size_t pix = ((size_t)b * H + row) * W + col;
+          const REAL z = depth[pix];
+          if (z == 0) continue;
+          if (!acc_sdf) acc_sdf = sdfo_slab_of(mine, nvox);
+          const REAL go = grad_depth[pix];
+          FN(v3) d = FN(pixel_ray)(row, col, cx, cy, fx, fy);
+          FN(cell) c;
+          REAL dz[8], f, wgt[8];
+          FN(pixel_derivs)(sdf, R, z, d, p, quat + 4 * b, rot, inv_scale[b], &c, dz, &f);
+          for (int k = 0; k < 8; ++k) acc[k] += (double)(dz[k] * go);
+          FN(corner_weights)(c.off, sdf_grad_mode, wgt);
+          const size_t first = c.base[0] * RR + (size_t)c.base[1] * R + c.base[2];
+          double* a = acc_sdf + first;
+          const size_t offs[8] = {0, 1, (size_t)R, (size_t)R + 1, RR, RR + 1, RR + R, RR + R + 1};
+          for (int k = 0; k < 8; ++k) a[offs[k]] += (double)(go * wgt[k] * f);
+          if (first < lo) lo = first;
+          if (first + RR + R + 2 > hi) hi = first + RR + R + 2;
         }
       }
     }
+    mine->lo = lo;
+    mine->hi = hi;
+  }
+  size_t LO = nvox, HI = 0;
+  for (int t = 0; t < T; ++t) {
+    if (slabs[t].lo < LO) LO = slabs[t].lo;
+    if (slabs[t].hi > HI) HI = slabs[t].hi;
+  }
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < nvox; ++i) {
+    double sum = 0;
+    if (i >= LO && i < HI)
+      for (int t = 0; t < T; ++t)
+        if (i >= slabs[t].lo && i < slabs[t].hi) { sum += slabs[t].v[i]; slabs[t].v[i] = 0; }
+    g_sdf[i] = (REAL)sum;
+  }
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < B; ++b) {
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = 0; t < T; ++t)
+      for (int k = 0; k < 8; ++k) acc[k] += pose_acc[((size_t)t * B + b) * 8 + k];
     g_pos[3 * b] = (REAL)acc[0]; g_pos[3 * b + 1] = (REAL)acc[1]; g_pos[3 * b + 2] = (REAL)acc[2];
     g_quat[4 * b] = (REAL)acc[3]; g_quat[4 * b + 1] = (REAL)acc[4];
     g_quat[4 * b + 2] = (REAL)acc[5]; g_quat[4 * b + 3] = (REAL)acc[6];
     g_inv_scale[b] = (REAL)acc[7];
   }
-  for (size_t i = 0; i < nvox; ++i) g_sdf[i] = (REAL)acc_sdf[i];
-  free(acc_sdf);
+  free(pose_acc);
 }
 
 /* Per-pixel derivative images, dimg[B][H][W][8] in the order of pixel_derivs;

@@ -1246,8 +1246,12 @@ __device__ __forceinline__ void backward_dispatch(
 // 8 waves per SIMD for the backward: the register allocator is held to 64 VGPRs (it takes 67 on its own: 7 waves
 // per SIMD; the price is 8 bytes of scratch): stand-alone backward 134.6 -> 129.3 us, a step's 117.8 -> 116.6 us at the
 // benchmark, mug-sized objects unchanged.  0: the compiler's own choice (timing experiments).
+// (The single-view tiling's workgroups hold 21 KB of LDS each: seven of them, 7 waves per SIMD, is what a CU takes
+// whatever the registers -- there the target is 7, which the compiler's own 67 VGPRs meet without a spill; asking for
+// 8 only earned "failed to meet occupancy target" from every such instantiation of a clean build.)
 #if SDFR_BWD_WAVES_PER_EU
-#define SDFR_BWD_OCC __attribute__((amdgpu_waves_per_eu(SDFR_BWD_WAVES_PER_EU, SDFR_BWD_WAVES_PER_EU)))
+#define SDFR_BWD_OCC __attribute__((amdgpu_waves_per_eu(BATCH ? SDFR_BWD_WAVES_PER_EU : (SDFR_BWD_WAVES_PER_EU > 7 ? 7 : SDFR_BWD_WAVES_PER_EU), \
+                                                        BATCH ? SDFR_BWD_WAVES_PER_EU : (SDFR_BWD_WAVES_PER_EU > 7 ? 7 : SDFR_BWD_WAVES_PER_EU))))
 #else
 #define SDFR_BWD_OCC
 #endif

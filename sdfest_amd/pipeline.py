@@ -135,11 +135,14 @@ class RenderAndCompare:
         decoder's VJP on the rank's own d/dSDF, and the VJP is linear) are summed by ONE all-reduce before the
         replicated Adam step.  No broadcast: every rank ends with the same estimate."""
         from .parallel import resolve_group
+        from .differentiable_renderer import parse_sdf_grad_mode
         self.decoder = decoder
         self.cam = camera
         self.config = config
         self.device = torch.device(device)
         self.group, self.rank, self.world = resolve_group(process_group)
+        # config["sdf_grad_mode"]: "exact" (default) | "cuda_compat" -- see SDFPipeline
+        self.sdf_grad_mode = parse_sdf_grad_mode(config.get("sdf_grad_mode"))
 
     def prepare_views(self, depth_images: torch.Tensor, tiled: bool = False):
         """Observed point clouds of all views, concatenated, with their segment offsets.  Done once
@@ -162,7 +165,7 @@ class RenderAndCompare:
         quat_c = quaternion_multiply(q_w2c, norm_q)                           # (V,4)
         inv_scale = (1.0 / scale).expand(V)
         est = render_depth_batch(sdf, pos_c.contiguous(), quat_c.contiguous(), inv_scale.contiguous(),
-                                 self.config["threshold"], self.cam)          # (V,H,W)
+                                 self.config["threshold"], self.cam, self.sdf_grad_mode)          # (V,H,W)
         overlap = (depth_images > 0) & (est > 0)
         err = torch.abs(est - depth_images) * overlap
         count = overlap.sum(dim=(1, 2))

@@ -134,6 +134,46 @@ def test_fused_loop_matches_g7(g7, mug, tag, use_graph):
     assert torch.equal(out[0], hist[-1]["position"])
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_fused_loop_with_the_reference_extensions_sdf_gradient_matches_run_d(mug, use_graph):
+    """SDF_GRAD_CUDA_COMPAT in the captured loop (FusedRenderAndCompare(sdf_grad_mode=1)): run D of
+    tests/golden/loop_g7_compat.npz -- scene C with the d depth / d SDF weights of sdf_renderer_cuda.cu:373-388 (taken
+    from the oracle's mode 1, pinned by reading those lines; every other piece imported from the reference) -- iteration
+    by iteration, and the FIRST latent gradient against the golden's."""
+    from sdfest_amd.pipeline import FusedRenderAndCompare
+    from sdfest_amd.differentiable_renderer import SDF_GRAD_CUDA_COMPAT
+    g = dict(np.load(os.path.join(GOLDEN, "loop_g7_compat.npz")))
+    cam, cfg, a, _ = _setup(g, "d")
+    loop = FusedRenderAndCompare(mug, cam, cfg, a["depth"], camera_positions=a["cam_pos"],
+                                 camera_orientations=a["cam_quat"], sdf_grad_mode=SDF_GRAD_CUDA_COMPAT)
+    hist = []
+    loop(a["p0"], a["q0"], a["s0"], a["z0"], use_graph=use_graph, history=hist)
+    torch.cuda.synchronize()
+    _check_trajectory(g, "d", hist)      # (not a "clean" tag: the fragile scenes' bounds)
+    # and the exact weights walk elsewhere: by the last iteration the latents differ by far more than the bound
+    exact = FusedRenderAndCompare(mug, cam, cfg, a["depth"], camera_positions=a["cam_pos"], camera_orientations=a["cam_quat"])
+    h0 = []
+    exact(a["p0"], a["q0"], a["s0"], a["z0"], use_graph=use_graph, history=h0)
+    dz = (h0[-1]["latent"] - hist[-1]["latent"]).abs().max().item()
+    assert dz > 3e-4, dz      # (Adam's first steps are +-lr whatever the gradient's size: the runs part slowly)
+    # iteration 1 before Adam, through autograd (RenderAndCompare, config["sdf_grad_mode"]): the latent gradient is where
+    # the two weightings differ -- by 0.7 % of its largest entry in this scene -- the pose gradients are the same
+    from sdfest_amd.pipeline import RenderAndCompare
+    ref = g["d_grads"][0]
+    scale = np.array([np.abs(ref[0:3]).max()] * 3 + [np.abs(ref[3:7]).max()] * 4 + [abs(ref[7])]
+                     + [np.abs(ref[8:]).max()] * (len(ref) - 8))
+    got = {}
+    for mode in ("cuda_compat", "exact"):
+        rc = RenderAndCompare(mug, cam, dict(cfg, sdf_grad_mode=mode))
+        p, q, s, z = (x.clone().requires_grad_() for x in (a["p0"], a["q0"], a["s0"], a["z0"]))
+        points, offsets, lens = rc.prepare_views(a["depth"])
+        ld, lp, _ = rc.losses(a["depth"], points, offsets, lens, a["cam_pos"], a["cam_quat"], p, q, s, mug.decode(z)[0, 0])
+        (1.0 * ld + 3.0 * lp).backward()
+        got[mode] = np.abs(np.concatenate([x.grad.cpu().numpy().ravel() for x in (p, q, s, z)]) - ref) / scale
+    assert got["cuda_compat"].max() < 1e-3, (got["cuda_compat"], _fragility(g, "d"))
+    assert got["exact"][8:].max() > 4e-3 and got["exact"][:8].max() < 1e-3, got["exact"]
+
+
 @pytest.mark.parametrize("tag,tol", [("a", 2e-3), ("c", 1e-4)])
 def test_first_gradient_matches_g7(g7, mug, tag, tol):
     """Iteration 1 before Adam: d loss / d (position, orientation, scale, latent) as autograd gave them to the

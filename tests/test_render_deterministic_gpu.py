@@ -65,20 +65,28 @@ def test_bitwise_reproducible_and_independent_of_path_and_split(B, W, H, f):
         assert torch.equal(total, runs[0][1])
 
 
-def test_deterministic_mode_against_the_oracle_and_its_limits():
+@pytest.mark.parametrize("mode", [0, 1])
+def test_deterministic_mode_against_the_oracle_and_its_limits(mode):
+    """mode: the d/dSDF weights underneath the flag -- exact (0) or the reference extension's (1,
+    sdf_renderer_cuda.cu:373-388)"""
     from sdfest_amd import BatchRenderPlan, _lib
     B, W, H, f = 6, 160, 120, 80.0
     cam, (pos, quat, isc), g = setup(B, W, H, f, seed=22)
     sdf_np = oracle.blobs_sdf(0)
     sdf = dev(sdf_np)
     pose = (dev(pos), dev(quat), dev(isc))
-    plan = BatchRenderPlan(64, B, cam, sdf_grad_mode=DET)
+    plan = BatchRenderPlan(64, B, cam, sdf_grad_mode=DET | mode)
     d = plan.forward(sdf, *pose, 0.005)
     gs = plan.backward(dev(g), sdf, *pose)[0].cpu().numpy()
-    ref = oracle.render_backward(g, d.cpu().numpy(), sdf_np, pos, quat, isc, W / 2, H / 2, f, f, dtype=np.float64)[0]
+    ref = oracle.render_backward(g, d.cpu().numpy(), sdf_np, pos, quat, isc, W / 2, H / 2, f, f, dtype=np.float64,
+                                 sdf_grad_mode=mode)[0]
     assert np.max(np.abs(gs - ref)) <= 1e-4 * np.max(np.abs(ref))      # fp32 evaluation of the contributions
+    # (bitwise repeatable in this mode as well, on the step path too)
+    plan.forward(sdf, *pose, 0.005, prepare_backward=True)
+    again = plan.backward(dev(g), sdf, *pose)[0].cpu().numpy()
+    assert np.array_equal(gs, again)
     # per-view gradient volumes are not supported in this mode
-    per_view = BatchRenderPlan(64, B, cam, per_view_sdf=True, sdf_grad_mode=DET)
+    per_view = BatchRenderPlan(64, B, cam, per_view_sdf=True, sdf_grad_mode=DET | mode)
     sdfs = dev(np.stack([sdf_np] * B))
     per_view.forward(sdfs, *pose, 0.005)
     with pytest.raises(RuntimeError, match="DETERMINISTIC"):

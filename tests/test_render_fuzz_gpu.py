@@ -55,7 +55,10 @@ def test_random_configuration(seed):
     c = draw(seed)
     B, W, H, R = c["B"], c["W"], c["H"], c["R"]
     cam = (W, H, c["cx"], c["cy"], c["fx"], c["fy"])
-    name = f"seed {seed}: B={B} {W}x{H} R={R} thr={c['thr']} per_view={c['per_view']}"
+    # every other seed with the d/dSDF weights of the reference's GPU extension (SDF_GRAD_CUDA_COMPAT,
+    # sdf_renderer_cuda.cu:373-388; the oracle's mode 1 is pinned by reading those lines)
+    mode = seed % 2
+    name = f"seed {seed}: B={B} {W}x{H} R={R} thr={c['thr']} per_view={c['per_view']} sdf_grad_mode={mode}"
     sdf_t, pos_t, quat_t, isc_t = (T.dev(c[k]) for k in ("sdf", "pos", "quat", "isc"))
 
     # 1. forward against the oracle (per-view grids: the oracle takes one grid at a time)
@@ -89,7 +92,7 @@ def test_random_configuration(seed):
     # a hit point within fp32 rounding of a face (~1e-4 cells for small objects) falls on either side: such pixels
     # are found by moving the grid by 3e-4 cells along each of its axes in the oracle, and their jump is allowed for.
     g = np.random.default_rng(seed).uniform(-1, 1, d.shape).astype(np.float32)
-    hb = [o.cpu().numpy() for o in Rm.backward_raw(T.dev(g), T.dev(d), sdf_t, pos_t, quat_t, isc_t, *cam)]
+    hb = [o.cpu().numpy() for o in Rm.backward_raw(T.dev(g), T.dev(d), sdf_t, pos_t, quat_t, isc_t, *cam, mode)]
     x, y, z, w = (c["quat"][:, k].astype(np.float64) for k in range(4))
     rot = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], -1),
                     np.stack([2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)], -1),
@@ -99,7 +102,7 @@ def test_random_configuration(seed):
     def oracle_backward(b0, b1, grid):
         sl = slice(b0, b1)
         pose64 = (c["pos"][sl].astype(np.float64), c["quat"][sl], c["isc"][sl])
-        ob = oracle.render_backward(g[sl], d[sl], grid, *pose64, *cam[2:], dtype=np.float64)
+        ob = oracle.render_backward(g[sl], d[sl], grid, *pose64, *cam[2:], dtype=np.float64, sdf_grad_mode=mode)
         di = oracle.render_derivative_images(d[sl], grid, *pose64, *cam[2:], dtype=np.float64)
         jump = np.zeros_like(di)
         for axis in range(3):
@@ -134,7 +137,7 @@ def test_random_configuration(seed):
     # 3. the step API against the stand-alone calls: depth bit for bit, gradients to summation order
     camera = Camera(W, H, c["fx"], c["fy"], c["cx"] - 0.5, c["cy"] - 0.5, pixel_center=0.0)
     assert np.allclose(camera.get_pinhole_camera_parameters(0.5)[:4], (c["fx"], c["fy"], c["cx"], c["cy"]))
-    plan = BatchRenderPlan(R, B, camera, per_view_sdf=c["per_view"])
+    plan = BatchRenderPlan(R, B, camera, per_view_sdf=c["per_view"], sdf_grad_mode=mode)
     for _ in range(2):                                   # twice on one workspace: epochs, alternating volumes
         ds = plan.forward(sdf_t, pos_t, quat_t, isc_t, c["thr"], prepare_backward=True)
         assert plan._step is not None
@@ -154,8 +157,9 @@ def test_random_configuration(seed):
     tgt[:, ::7, ::5] = 1.0                                    # observed depth where nothing is rendered, too
     l1cam = (W, H, c["cx"], c["cy"], c["fx"], c["fy"])
     d_f, loss_f, stats, g_f = L1.fused(Rm, c["sdf"], c["pos"], c["quat"], c["isc"], l1cam, tgt, thr=c["thr"],
-                                       weight=0.7, per_view=c["per_view"])
-    d_u, loss_u, g_u = L1.unfused(Rm, c["sdf"], c["pos"], c["quat"], c["isc"], l1cam, tgt, thr=c["thr"], weight=0.7)
+                                       weight=0.7, per_view=c["per_view"], mode=mode)
+    d_u, loss_u, g_u = L1.unfused(Rm, c["sdf"], c["pos"], c["quat"], c["isc"], l1cam, tgt, thr=c["thr"], weight=0.7,
+                                  mode=mode)
     assert np.array_equal(d_f, d) and np.array_equal(d_u, d), name
     mask = (tgt > 0) & (d > 0)
     assert np.array_equal(stats[:, 1], mask.sum(axis=(1, 2)).astype(np.float32)), name

@@ -145,9 +145,12 @@ def test_c1_c2_single_view_full_size(R):
         assert rel_err(hb[0], ob[0]) <= REL
 
 
-def test_batch_random_poses_equals_per_view(R):
+@pytest.mark.parametrize("mode", [0, 1])
+def test_batch_random_poses_equals_per_view(R, mode):
     """configs[2] shape (random poses of one SDF) at B=8: a batched launch equals B single
-    launches bit for bit (forward, pose grads) and the oracle within tolerance."""
+    launches bit for bit (forward, pose grads) and the oracle within tolerance -- with the exact d/dSDF weights
+    (mode 0, simple_renderer.py:399-408) and with the ones the reference's GPU extension adds (mode 1,
+    sdf_renderer_cuda.cu:373-388: the oracle's mode 1 is pinned by reading those lines)."""
     sdf = oracle.blobs_sdf(0)
     B, s = 8, c2_scene()
     pos, quat, isc = oracle.random_poses(B, seed=1)
@@ -157,20 +160,23 @@ def test_batch_random_poses_equals_per_view(R):
                                             with_aux=True)
     rng = np.random.default_rng(2)
     g = rng.uniform(-1, 1, d_b.shape).astype(np.float32)
-    hb = hip_backward(R, g, d_b, sdf, pos, quat, isc, *cam)
+    hb = hip_backward(R, g, d_b, sdf, pos, quat, isc, *cam, mode=mode)
     acc = np.zeros_like(hb[0], dtype=np.float64)
     for b in range(B):
         d1 = hip_forward(R, sdf, pos[b], quat[b], isc[b:b + 1], *cam, s["thr"])[0]
         assert np.array_equal(d1, d_b[b])
         check_depth(d_b[b], d_or[b], margin[b], f"view{b}")
         assert (d_b[b] > 0).sum() > 1000
-        h1 = hip_backward(R, g[b], d_b[b], sdf, pos[b], quat[b], isc[b:b + 1], *cam)
+        h1 = hip_backward(R, g[b], d_b[b], sdf, pos[b], quat[b], isc[b:b + 1], *cam, mode=mode)
         assert np.array_equal(h1[1][0], hb[1][b]) and np.array_equal(h1[2][0], hb[2][b])
         assert h1[3][0] == hb[3][b]
         acc += h1[0]
     assert rel_err(hb[0], acc) <= 1e-5          # float-atomic order only
-    ob = oracle.render_backward(g, d_b, sdf, pos, quat, isc, *cam[2:], dtype=np.float32)
+    ob = oracle.render_backward(g, d_b, sdf, pos, quat, isc, *cam[2:], dtype=np.float32, sdf_grad_mode=mode)
     assert rel_err(hb[0], ob[0]) <= REL
+    if mode == 1:     # (and the two weightings are not the same thing)
+        o0 = oracle.render_backward(g, d_b, sdf, pos, quat, isc, *cam[2:], dtype=np.float32, sdf_grad_mode=0)
+        assert rel_err(hb[0], o0[0]) > 0.05
     for b in range(B):
         dimg = oracle.render_derivative_images(d_b[b], sdf, pos[b], quat[b], isc[b:b + 1], *cam[2:],
                                                dtype=np.float64)[0]

@@ -36,11 +36,11 @@ def scene(B, W, H, f, seed=1, target_seed=7):
     return sdf, pos, quat, isc, cam, tgt
 
 
-def fused(R, sdf, pos, quat, isc, cam, tgt, thr=0.005, weight=1.0, loss_grad=None, per_view=False):
+def fused(R, sdf, pos, quat, isc, cam, tgt, thr=0.005, weight=1.0, loss_grad=None, per_view=False, mode=0):
     from sdfest_amd.differentiable_renderer import BatchRenderPlan, Camera
     W, H, cx, cy, fx, fy = cam
     camera = Camera(W, H, fx, fy, cx, cy, pixel_center=0.5)
-    plan = BatchRenderPlan(sdf.shape[-1], len(pos), camera, per_view_sdf=per_view)
+    plan = BatchRenderPlan(sdf.shape[-1], len(pos), camera, per_view_sdf=per_view, sdf_grad_mode=mode)
     a = [dev(sdf), dev(pos), dev(quat), dev(isc)]
     t = dev(tgt)
     depth, loss = plan.forward_l1(*a, thr, t)
@@ -49,7 +49,7 @@ def fused(R, sdf, pos, quat, isc, cam, tgt, thr=0.005, weight=1.0, loss_grad=Non
     return depth, loss, stats, [x.cpu().numpy().copy() for x in g]
 
 
-def unfused(R, sdf, pos, quat, isc, cam, tgt, thr=0.005, weight=1.0):
+def unfused(R, sdf, pos, quat, isc, cam, tgt, thr=0.005, weight=1.0, mode=0):
     """sdfr_render_forward -> sdfr_depth_l1_loss -> sdfr_render_backward."""
     from sdfest_amd import _lib
     L = _lib.lib()
@@ -64,18 +64,20 @@ def unfused(R, sdf, pos, quat, isc, cam, tgt, thr=0.005, weight=1.0):
     st = torch.cuda.current_stream().cuda_stream
     _lib.check(L.sdfr_depth_l1_loss(depth.data_ptr(), t.data_ptr(), B, W, H, weight, loss.data_ptr(),
                                     grad.data_ptr(), ws.data_ptr(), ws.numel(), 0, st), "l1")
-    g = R.backward_raw(grad, depth, *a, W, H, cx, cy, fx, fy)
+    g = R.backward_raw(grad, depth, *a, W, H, cx, cy, fx, fy, mode)
     return depth.cpu().numpy(), loss.cpu().numpy(), [x.cpu().numpy() for x in g]
 
 
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("B,W,H,f", [(1, 160, 120, 80.0), (3, 640, 480, 320.0), (17, 320, 240, 160.0),
                                      (40, 640, 480, 320.0)])
-def test_fused_equals_unfused_and_oracle(R, B, W, H, f):
-    """B=1,3: plain-grid small tiles; B=17: packed records; B=40 at 640x480: batch (macro) tiles."""
+def test_fused_equals_unfused_and_oracle(R, B, W, H, f, mode):
+    """B=1,3: plain-grid small tiles; B=17: packed records; B=40 at 640x480: batch (macro) tiles.  mode 1: the d/dSDF
+    weights of the reference's GPU extension (SDF_GRAD_CUDA_COMPAT, sdf_renderer_cuda.cu:373-388)."""
     sdf, pos, quat, isc, cam, tgt = scene(B, W, H, f)
     w = 0.7
-    d_f, loss_f, stats, g_f = fused(R, sdf, pos, quat, isc, cam, tgt, weight=w)
-    d_u, loss_u, g_u = unfused(R, sdf, pos, quat, isc, cam, tgt, weight=w)
+    d_f, loss_f, stats, g_f = fused(R, sdf, pos, quat, isc, cam, tgt, weight=w, mode=mode)
+    d_u, loss_u, g_u = unfused(R, sdf, pos, quat, isc, cam, tgt, weight=w, mode=mode)
     assert np.array_equal(d_f, d_u)                       # same march
     l_ref, grad_ref = oracle.depth_l1(d_f, tgt, weight=w)  # float64 on the HIP depth
     mask = (tgt > 0) & (d_f > 0)
@@ -89,7 +91,8 @@ def test_fused_equals_unfused_and_oracle(R, B, W, H, f):
         assert np.array_equal(g_f[k], g_u[k]), k
     assert rel_err(g_f[0], g_u[0]) <= 1e-5                # float-atomic order only
     # and the oracle's backward on the float64 gradient image
-    ob = oracle.render_backward(grad_ref.astype(np.float32), d_f, sdf, pos, quat, isc, *cam[2:], dtype=np.float32)
+    ob = oracle.render_backward(grad_ref.astype(np.float32), d_f, sdf, pos, quat, isc, *cam[2:], dtype=np.float32,
+                                sdf_grad_mode=mode)
     assert rel_err(g_f[0], ob[0]) <= REL
     for b in range(B):
         dimg = oracle.render_derivative_images(d_f[b], sdf, pos[b], quat[b], isc[b:b + 1], *cam[2:],

@@ -17,12 +17,12 @@ def dev(a):
     return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device="cuda")
 
 
-def make(B, W, H, f, seed, per_view_sdf=False):
+def make(B, W, H, f, seed, per_view_sdf=False, sdf_grad_mode=0):
     from sdfest_amd import BatchRenderPlan, Camera
     cam = Camera(W, H, f, f, W / 2.0, H / 2.0, pixel_center=0.5)
     pos, quat, isc = oracle.random_poses(B, seed=seed, width=W, height=H, f=f)
     g = np.random.default_rng(seed + 100).uniform(-1, 1, (B, H, W)).astype(np.float32)
-    plans = [BatchRenderPlan(64, B, cam, per_view_sdf=per_view_sdf) for _ in range(2)]
+    plans = [BatchRenderPlan(64, B, cam, per_view_sdf=per_view_sdf, sdf_grad_mode=sdf_grad_mode) for _ in range(2)]
     return plans, (dev(pos), dev(quat), dev(isc)), dev(g), (pos, quat, isc)
 
 
@@ -189,17 +189,20 @@ def test_backward_after_changed_inputs_is_the_standalone_call():
     assert rel_err(out[1].cpu().numpy(), ref[1][1].cpu().numpy()) <= 2e-5 and rel_err(out[0].cpu().numpy(), ref[1][0].cpu().numpy()) <= 1e-5
 
 
-def test_step_at_the_bench_configuration_against_the_oracle():
+@pytest.mark.parametrize("mode", [0, 1])
+def test_step_at_the_bench_configuration_against_the_oracle(mode):
     """C3 as bench.py runs it (step path): depth hit count, d/dSDF and the pose gradients of a sample of views
-    against the oracle."""
+    against the oracle -- with the exact d/dSDF weights and with the reference extension's (SDF_GRAD_CUDA_COMPAT,
+    sdf_renderer_cuda.cu:373-388)."""
     import os
-    (p_step, _), pose, g, (pos, quat, isc) = make(256, 640, 480, 320.0, seed=1)
+    (p_step, _), pose, g, (pos, quat, isc) = make(256, 640, 480, 320.0, seed=1, sdf_grad_mode=mode)
     sdf_np = oracle.blobs_sdf(0)
     d, (gs, gp, gq, gi) = run_step(p_step, dev(sdf_np), pose, g)
     assert int((d > 0).sum().item()) in range(4207800, 4207900)
     oracle.set_threads(min(64, os.cpu_count() or 1))
     dn, gn = d.cpu().numpy(), g.cpu().numpy()
-    ob = oracle.render_backward(gn, dn, sdf_np, pos, quat, isc, 320.0, 240.0, 320.0, 320.0, dtype=np.float32)
+    ob = oracle.render_backward(gn, dn, sdf_np, pos, quat, isc, 320.0, 240.0, 320.0, 320.0, dtype=np.float32,
+                                sdf_grad_mode=mode)
     assert rel_err(gs.cpu().numpy(), ob[0]) <= 1e-4
     pose_hip = np.concatenate([gp.cpu().numpy(), gq.cpu().numpy(), gi.cpu().numpy()[:, None]], axis=1)
     ref = np.concatenate([ob[1], ob[2], ob[3][:, None]], axis=1)

@@ -214,6 +214,30 @@ def parity_report(plan, g, sdf, pose, sdf_np, poses_np, W, H, thr, n_l1=8):
         scale = np.max(np.abs(ref1_pose[:, s_]), axis=1, keepdims=True)
         rel_group = max(rel_group, float(np.max(np.abs(hip1[:, s_] - ref1_pose[:, s_]) / np.maximum(scale, 1e-300))))
     gs1_err = float(np.max(np.abs(gs1 - ref1[0])))
+    # The floor: the SAME formulas with every per-pixel term evaluated in float and summed exactly (the oracle's float
+    # build carries its sums in double), against the float64 oracle, by the same three yardsticks.  A float kernel
+    # cannot be closer to the float64 value than its terms are; what it adds on top is its summation.
+    def group_max_err(p_, r_):
+        out = 0.0
+        for s_ in (slice(0, 3), slice(3, 7), slice(7, 8)):
+            scale = np.max(np.abs(r_[:, s_]), axis=1, keepdims=True)
+            out = max(out, float(np.max(np.abs(p_[:, s_] - r_[:, s_]) / np.maximum(scale, 1e-300))))
+        return out
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    o32 = oracle.render_backward(g_np, d_hip, sdf_np, f32(pos), f32(quat), f32(isc), W / 2, H / 2, f, f, dtype=np.float32)
+    o32_1 = oracle.render_backward(np.ones_like(g_np), d_hip, sdf_np, f32(pos), f32(quat), f32(isc), W / 2, H / 2, f, f,
+                                   dtype=np.float32)
+    p32 = np.concatenate([o32[1], o32[2], o32[3][:, None]], axis=1).astype(np.float64)
+    p32_1 = np.concatenate([o32_1[1], o32_1[2], o32_1[3][:, None]], axis=1).astype(np.float64)
+    rel32 = np.abs(p32_1[:n] - ref1_pose[:n])[well] / np.abs(ref1_pose[:n][well])
+    floor = {
+        "what": "the oracle's float build (per-pixel terms in float, exact sums) against its float64 build, same inputs",
+        "grad_pose_benchmark_upstream_max_err_over_sum_of_term_magnitudes":
+            float(np.max(np.abs(p32[:n] - ref_pose[:n]) / np.maximum(l1, 1e-300))),
+        "grad_pose_benchmark_upstream_max_abs_err": float(np.max(np.abs(p32 - ref_pose))),
+        "ones_upstream_grad_pose_max_rel_err_well_conditioned": float(rel32.max()) if rel32.size else None,
+        "ones_upstream_grad_pose_max_err_over_group_max_all_views": group_max_err(p32_1, ref1_pose),
+        "grad_sdf_max_err_over_max": float(np.max(np.abs(o32[0].astype(np.float64) - ref[0])) / gs_max)}
     return {
         "reference": "oracle (CPU restatement pinned by the reference's goldens): float64 gradients on the HIP "
                      "depth images, float32 depth",
@@ -230,6 +254,7 @@ def parity_report(plan, g, sdf, pose, sdf_np, poses_np, W, H, thr, n_l1=8):
             "grad_pose_well_conditioned_components": int(well.sum()), "of": int(well.size),
             "grad_pose_max_rel_err_well_conditioned": float(rel_plain.max()) if rel_plain.size else None,
             "grad_pose_max_err_over_group_max_all_views": rel_group},
+        "fp32_floor": floor,
     }
 
 
@@ -280,7 +305,20 @@ def single_view_config(name, W, H, native_lib, sdf_np, dev, hbm_peak, cpu_budget
     for _ in range(10):
         gr.replay()
     torch.cuda.synchronize()
-    graph_us = _event_us(gr.replay, 300)
+    graph1_us = _event_us(gr.replay, 300)
+    # A graph LAUNCH costs ~4.5 us of its own on this runtime whatever it holds (tools/microbench/graph_env.py,
+    # profiles/r06_graph_env.txt: a one-pair graph 26.2 us, the same pair eager 22.2, ten pairs per graph 21.6 each --
+    # the nodes themselves replay faster than eager launches, 2.0 against 4.3 us for an empty kernel).  So a single pair
+    # is issued eagerly (what render_depth_gpu and BatchRenderPlan do), and a caller who captures captures several:
+    # `hip_us_graph` is the pair's cost inside a ten-pair graph, `hip_us_graph_single_replay` the one-pair replay.
+    gr10 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr10):
+        for _ in range(10):
+            step()
+    for _ in range(5):
+        gr10.replay()
+    torch.cuda.synchronize()
+    graph_us = _event_us(gr10.replay, 60) / 10
     # parity (float64 gradients on the HIP depth)
     d = plan.depth.cpu().numpy()
     p_, q_, i_ = [0, 0, -1.5], [0, 0, 0, 1], [2.0]
@@ -307,6 +345,9 @@ def single_view_config(name, W, H, native_lib, sdf_np, dev, hbm_peak, cpu_budget
     bytes_per_view = 12 * W * H + 12 * 64 ** 3 + 32
     res = {"workload": f"{name}: one {W}x{H} view of blobs(0), identity pose, forward+backward (step pair)",
            "hip_us_eager": round(eager_us, 2), "hip_us_graph": round(graph_us, 2),
+           "hip_us_graph_single_replay": round(graph1_us, 2),
+           "graph_note": "a graph launch costs ~4.5 us whatever it holds: hip_us_graph = per pair in a ten-pair graph; "
+                         "single pairs are issued eagerly (the product's default)",
            "renders_per_s": round(1e6 / best_us, 1), "hit_pixels": int((d > 0).sum()),
            "roofline": {"bound": "hbm (nominal: the pair is launch- and latency-bound)", "bytes_per_view": bytes_per_view,
                         "achieved": round(bytes_per_view / (best_us * 1e-6) / 1e9, 2), "unit": "GB/s",

@@ -273,8 +273,10 @@ def make_quaternion(ref):
         inv=qu.quaternion_invert(t(q1)).numpy())
 
 
-def make_loop_g7(ref):
-    """G7: a few iterations of the render-and-compare loop of
+def make_loop_g7(ref, compat_only=False):
+    """compat_only: write tests/golden/loop_g7_compat.npz instead (run D, see the end of this function).
+
+    G7: a few iterations of the render-and-compare loop of
     estimation/simple_setup.py:381-470 assembled from IMPORTED reference pieces --
     the numpy twin (simple_renderer.render_depth, value "d") with the reduction of
     sdf_renderer.py:242-261, losses.pc_loss, losses.point_constraint_loss, quaternion_utils,
@@ -331,6 +333,7 @@ def make_loop_g7(ref):
                                              position.detach().numpy(), orientation.detach().numpy(),
                                              inv_scale.detach().numpy())
             ctx.der = der
+            ctx.image_np = np.asarray(image)
             return torch.from_numpy(image)
 
         @staticmethod
@@ -346,6 +349,29 @@ def make_loop_g7(ref):
             g_is = torch.tensor(s("s_inv"), dtype=inv_s.dtype)
             for k, v in der.get("sdf", {}).items():
                 g_sdf[k] = float(np.sum(v * g))
+            if res.get("compat"):
+                # run D: d depth / d sdf with the weights the reference's GPU extension really adds
+                # (sdf_renderer_cuda.cu:373-388) -- that extension cannot run here, so this one tensor comes
+                # from the oracle's mode 1 (pinned by reading those lines), evaluated in float64 on the twin's own depth
+                # image; every other number of the run is still the imported reference pieces'
+                W, H, fx, fy, cx, cy = intrinsics()
+                image, _ = ctx.image_np, None
+                o = margin_oracle.render_backward(g.astype(np.float64)[None], image.astype(np.float64)[None],
+                                                  sdf.detach().numpy().astype(np.float64),
+                                                  pos.detach().numpy().astype(np.float64)[None],
+                                                  quat.detach().numpy().astype(np.float64)[None],
+                                                  [float(inv_s)], cx, cy, fx, fy, dtype=np.float64, sdf_grad_mode=1)
+                exact = margin_oracle.render_backward(g.astype(np.float64)[None], image.astype(np.float64)[None],
+                                                      sdf.detach().numpy().astype(np.float64),
+                                                      pos.detach().numpy().astype(np.float64)[None],
+                                                      quat.detach().numpy().astype(np.float64)[None],
+                                                      [float(inv_s)], cx, cy, fx, fy, dtype=np.float64, sdf_grad_mode=0)
+                # (the oracle's EXACT weights reproduce the twin's d/dsdf: what licenses taking its mode 1 here)
+                twin = g_sdf.numpy().astype(np.float64)
+                dev_ = np.max(np.abs(exact[0] - twin)) / max(np.max(np.abs(twin)), 1e-30)
+                print(f"    (oracle exact mode vs twin d/dsdf: {dev_:.2e} of its maximum; depth dtype {image.dtype}, sdf {sdf.dtype})")
+                assert dev_ <= 1e-5, "oracle != twin (exact mode)"
+                g_sdf = torch.from_numpy(o[0].astype(np.float64)).to(sdf.dtype)
             return g_sdf, g_p, g_q, g_is
 
     def depth_to_pointcloud(depth):  # pointset_utils.py:57-77, "opengl", no mask
@@ -484,6 +510,27 @@ def make_loop_g7(ref):
             print(f"  {tag}: float32 pass vs float64 pass, first gradient, per group scale: max {rel.max():.2e}")
         return True
 
+    if compat_only:
+        # Run D: scene C (its seed is in loop_g7.npz) with the reference GPU extension's d/dSDF weights, the gradient
+        # the published system's latent trajectories came from -- 160x120, 2 views, shape optimisation on.
+        seed = int(np.load(os.path.join(OUT, "loop_g7.npz"))["c_seed"])
+        rc = np.random.default_rng(seed)
+        qc = rc.normal(size=4); qc /= np.linalg.norm(qc)
+        zc = (0.5 * rc.normal(size=cfg["latent_size"])).astype(np.float32)
+        pc = (float(rc.uniform(-0.03, 0.03)), float(rc.uniform(-0.03, 0.03)), float(rc.uniform(-0.45, -0.36)))
+        cams_c = [((0.0, 0.0, 0.0), (0.0, 0.0, 0.0, 1.0)),
+                  ((float(rc.uniform(0.15, 0.3)), float(rc.uniform(-0.06, 0.06)), float(rc.uniform(-0.1, 0.0))),
+                   (float(rc.uniform(-0.05, 0.05)), float(rc.uniform(0.2, 0.4)), float(rc.uniform(-0.05, 0.05)), 0.94))]
+        trial = {}
+        res["compat"] = True
+        ok = run("d", zc, pc, qc, float(rc.uniform(0.10, 0.13)), cams_c, 4, True, None, trial, size=(160, 120))
+        res["compat"] = False
+        assert ok
+        W, H, fx, fy, cx, cy = intrinsics()
+        trial.update(d_W=W, d_H=H, d_fx=fx, d_fy=fy, d_cx=cx, d_cy=cy, thr=THR, d_seed=seed,
+                     note="d/dsdf: oracle mode 1 (sdf_renderer_cuda.cu:373-388 by reading); everything else imported reference pieces")
+        np.savez_compressed(os.path.join(OUT, "loop_g7_compat.npz"), **trial)
+        return
     rng = np.random.default_rng(17)
     W, H, fx, fy, cx, cy = intrinsics()
     out = {"W": W, "H": H, "fov": FOV, "thr": THR, "fx": fx, "fy": fy, "cx": cx, "cy": cy}
@@ -617,7 +664,8 @@ def main():
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     jobs = {"render": make_render, "pc_loss": make_pc_loss, "decoder": make_decoder,
-            "quaternion": make_quaternion, "loop_g7": make_loop_g7, "init_network": make_init_network}
+            "quaternion": make_quaternion, "loop_g7": make_loop_g7,
+            "loop_g7_compat": lambda ref: make_loop_g7(ref, compat_only=True), "init_network": make_init_network}
     for name, fn in jobs.items():
         if args.only and args.only != name:
             continue
