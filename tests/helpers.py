@@ -49,3 +49,28 @@ def decoder_probe_G(n=64):
     a = np.arange(n, dtype=np.float64)
     X, Y, Z = np.meshgrid(a, a, a, indexing="ij")
     return (np.sin(0.37 * X + 0.11) * np.cos(0.23 * Y - 0.4) + 0.5 * np.sin(0.05 * Z * X * 0.1 + 0.3 * Y)).astype(np.float32)
+
+
+def check_sdf_grad(hip, ref, mode, n_hits, rel=1e-4, name=""):
+    """d/dSDF of the HIP backward against the oracle's.  mode 0 (the exact trilinear weights): within `rel` of the
+    largest entry, everywhere -- the weights are continuous across cell faces, so a hit point within rounding of a face
+    gives the same contributions whichever cell it is filed under.  mode 1 (the weights the reference's GPU extension
+    adds, sdf_renderer_cuda.cu:373-388) is NOT continuous there: corner (0,0,0) of the cell gets (1-x)(1-y) z, not
+    (1-x)(1-y)(1-z), so a hit point that float and double arithmetic file under neighbouring cells (a float hit point is
+    good to ~3e-5 cells: a few pixels in ten thousand) puts one pixel's weight on other voxels -- up to 12 of them, the
+    two cells' corners.  Those voxels are allowed for by COUNT; every other voxel is held to `rel`."""
+    hip = np.asarray(hip, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    top = float(np.max(np.abs(ref))) if ref.size else 0.0
+    if top == 0.0:
+        assert not hip.any(), name
+        return 0
+    bad = np.abs(hip - ref) > rel * top
+    if mode == 0:
+        assert not bad.any(), f"{name}: d/dSDF off by {np.max(np.abs(hip - ref)) / top:.2e} of its maximum"
+        return 0
+    allowed = 12 * max(2, int(1e-3 * n_hits))
+    assert bad.sum() <= allowed, f"{name}: {int(bad.sum())} voxels off (mode 1 allows for {allowed}: pixels on cell faces)"
+    # ... and those differ by single pixels' weights, not by a share of the whole volume
+    assert np.abs(hip - ref)[bad].sum() <= 0.02 * np.abs(ref).sum() + 1e-30, name
+    return int(bad.sum())

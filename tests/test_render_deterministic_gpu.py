@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import oracle
-from helpers import rel_err
+from helpers import check_sdf_grad, rel_err
 
 pytestmark = pytest.mark.gpu
 DET = 0x100
@@ -80,7 +80,7 @@ def test_deterministic_mode_against_the_oracle_and_its_limits(mode):
     gs = plan.backward(dev(g), sdf, *pose)[0].cpu().numpy()
     ref = oracle.render_backward(g, d.cpu().numpy(), sdf_np, pos, quat, isc, W / 2, H / 2, f, f, dtype=np.float64,
                                  sdf_grad_mode=mode)[0]
-    assert np.max(np.abs(gs - ref)) <= 1e-4 * np.max(np.abs(ref))      # fp32 evaluation of the contributions
+    check_sdf_grad(gs, ref, mode, int((d > 0).sum().item()), 1e-4)      # fp32 evaluation of the contributions
     # (bitwise repeatable in this mode as well, on the step path too)
     plan.forward(sdf, *pose, 0.005, prepare_backward=True)
     again = plan.backward(dev(g), sdf, *pose)[0].cpu().numpy()

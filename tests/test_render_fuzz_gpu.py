@@ -16,7 +16,7 @@ import torch
 import oracle
 import test_render_gpu as T
 import test_render_l1_gpu as L1
-from helpers import rel_err
+from helpers import check_sdf_grad, rel_err
 
 pytestmark = pytest.mark.gpu
 REL = 1e-4
@@ -126,10 +126,7 @@ def test_random_configuration(seed):
         g_sdf_ref = ob[0]
         pose_ref = np.concatenate([ob[1], ob[2], ob[3][:, None]], axis=1)
     assert n_fragile <= 2 + 0.01 * (d > 0).sum(), f"{name}: {n_fragile} pixels on cell faces"    # not vacuous
-    if np.abs(g_sdf_ref).max() > 0:
-        assert rel_err(hb[0], g_sdf_ref) <= REL, name
-    else:
-        assert not hb[0].any(), name
+    check_sdf_grad(hb[0], g_sdf_ref, mode, int((d > 0).sum()), REL, name)
     pose = np.concatenate([hb[1], hb[2], hb[3][:, None]], axis=1)
     excess = np.abs(pose - pose_ref) - (REL * l1 + allowance + 1e-30)
     assert np.all(excess <= 0), f"{name}: view/entry {np.argwhere(excess > 0)[:5].tolist()}, over by {excess.max():.3g}"
