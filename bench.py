@@ -269,8 +269,14 @@ class SectionGuard:
         import threading
 
         def give_up():
+            # (the headline is on stdout already -- main() prints it before the first extra --; this is the line again
+            # with the fact.  Exit status 0 on purpose: the MEASUREMENT is complete and a launcher that fails the job on
+            # any rank's status would throw it away; the hang is in the line (`abandoned_sections`) and on stderr.)
+            sys.stderr.write(f"bench.py rank {rank}: extra section '{key}' not finished after {seconds:.0f} s: abandoned\n")
+            sys.stderr.flush()
             if rank == 0:
                 line[key] = {"error": f"not finished after {seconds:.0f} s: abandoned"}
+                line.setdefault("abandoned_sections", []).append(key)
                 print(json.dumps(line), flush=True)
             os._exit(0)
         self.timer = threading.Timer(seconds, give_up)
@@ -372,12 +378,15 @@ def main():
     if use_dist:
         import faulthandler
         import torch.distributed as dist
-        # backstop for the whole multi-rank run: a rank still here after 15 minutes dumps every thread's stack and
+        # backstop for the whole multi-rank run: a rank still here after 9 minutes dumps every thread's stack and
         # exits 1 (C-level timer, needs no interpreter lock), so a hang past start-up also says where it is
-        job_s = float(os.environ.get("SDFR_BENCH_JOB_WATCHDOG_S", "900"))
+        # (540 s: below the 600 s the driver gives a bench run, so that it can fire under the driver)
+        job_s = float(os.environ.get("SDFR_BENCH_JOB_WATCHDOG_S", "540"))
         Watchdog.job_deadline = time.monotonic() + job_s
         faulthandler.dump_traceback_later(job_s, exit=True)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # (this pool's host driver supports only dmabuf IPC: without this RCCL's set-up fails with "hipIpcGetMemHandle:
+        # invalid argument" -- the environment's own statement; a value the node exports wins)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # RCCL prints a version banner on STDOUT when its communicator comes up; stdout is for the one result
         # line, so file descriptor 1 points at stderr until the first collective has run
@@ -621,6 +630,18 @@ def main():
                       "allreduce_us": ({"median": round(float(np.median(ar_us)), 1), "min": round(min(ar_us), 1),
                                         "max": round(max(ar_us), 1), "n": len(ar_us)} if ar_us else None),
                       "per_rank": per_rank}
+        # the sync exchange read against its own parts: a step that waits for its sum costs the
+        # rank's compute (forward + backward calls, events) + the all-reduce span; the ring exchange hides the
+        # collective, so its per-GPU rate should stay the single-GPU rate (weak scaling ~N).  The xGMI figure is
+        # SURVEY section 5's model of a 1 MiB ring all-reduce: 2 (N - 1) hops of (1 MiB / N) / 153 GB/s + ~2 us each.
+        hop_us = (64 ** 3 * 4 / max(N, 1)) / 153e9 * 1e6 + 2.0
+        collective["sync_exchange_model"] = {
+            "compute_ms_per_step_events": round(fwd_ms + bwd_ms, 4),
+            "allreduce_us_measured_median": (round(float(np.median(ar_us)), 1) if ar_us else None),
+            "sum_ms_per_step": (round(fwd_ms + bwd_ms + float(np.median(ar_us)) * 1e-3, 4) if ar_us else None),
+            "allreduce_us_predicted_xgmi_ring": round(2 * (N - 1) * hop_us, 1) if N > 1 else None,
+            "note": "ms_per_step_sync_exchange (measured) against sum_ms_per_step; value_ring_exchange / n_gpus against "
+                    "the single-GPU value"}
 
     if rank == 0:
         views = B * N * args.steps
@@ -727,14 +748,21 @@ def main():
             line["configs"] = extra_configs(sdf_np, device, HBM_PEAK)
     line = line if rank == 0 else {}
     # the extras of a multi-rank run, AFTER the headline is complete and each under its own guard (every rank enters;
-    # only rank 0's line matters): the sharded loop between graphs, then with its all-reduce inside the graphs
-    if use_dist and (N > 1 or os.environ.get("SDFR_BENCH_LOOP_SHARDED") == "1"):
+    # only rank 0's line matters): the sharded loop between graphs, then (opt-in) with its all-reduce inside the graphs
+    extras = use_dist and (N > 1 or os.environ.get("SDFR_BENCH_LOOP_SHARDED") == "1")
+    if extras and rank == 0:
+        # The finished measurement goes out NOW: a native abort inside an extra -- a fault in a collective, the
+        # process group's watchdog, the job watchdog -- kills the process without a word, and the guards above only
+        # cover hangs and Python exceptions.  The line is printed again, augmented, at the end: readers take the last.
+        print(json.dumps(line), flush=True)
+    if extras:
         with SectionGuard(rank, "loop_sharded", float(os.environ.get("SDFR_BENCH_LOOP_SHARDED_S", "180")), line):
             try:
                 line["loop_sharded"] = sharded_loop_section(N, rank, plain_barrier)
             except Exception as e:      # (every rank takes the same path: the section's collectives are all inside)
                 line["loop_sharded"] = {"error": f"{type(e).__name__}: {e}"}
-    if use_dist and backend == "nccl" and (N > 1 or os.environ.get("SDFR_BENCH_LOOP_SHARDED") == "1"):
+    if extras and backend == "nccl" and os.environ.get("SDFR_BENCH_GRAPH_COLLECTIVE") == "1":
+        # opt-in until it has run once over several GPUs (it has only ever captured RCCL's all-reduce with ONE rank)
         # (every rank enters; only rank 0's line matters)
         line["loop_sharded_collective_in_graph"] = collective_in_graph_section(
             N, rank, plain_barrier, float(os.environ.get("SDFR_BENCH_GRAPH_COLLECTIVE_S", "120")), line)

@@ -542,7 +542,10 @@ class FusedRenderAndCompare:
             else:
                 self.pc_source, self.pc_weight = None, 0.0
         key = None if self.pc_source is None else self.pc_weight
-        self.graph, self.graph_many, self.graph_tail = self._graphs.get(key, (None, None, None))
+        # (the whole-iteration graphs of `graph_collective` carry the constraint's launch arguments too: they belong
+        # to the key like the others -- until round 6 a rebind to another constraint kept replaying the old ones)
+        (self.graph, self.graph_many, self.graph_tail, self.graph_whole_one,
+         self.graph_whole) = self._graphs.get(key, (None, None, None, None, None))
         self._graph_key = key
         self.bound = True
         return self
@@ -552,7 +555,8 @@ class FusedRenderAndCompare:
         # collecting graphs without bound)
         if self._graph_key not in self._graphs and len(self._graphs) >= 4:
             self._graphs.pop(next(iter(self._graphs)))
-        self._graphs[self._graph_key] = (self.graph, self.graph_many, self.graph_tail)
+        self._graphs[self._graph_key] = (self.graph, self.graph_many, self.graph_tail, self.graph_whole_one,
+                                         self.graph_whole)
 
     def view_point_counts(self) -> torch.Tensor:
         """observed points per view of this rank's shard, (V,) int32 on the device (reading it synchronises)"""

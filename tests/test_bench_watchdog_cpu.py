@@ -84,5 +84,7 @@ def test_a_hung_extra_section_costs_the_extra_not_the_headline(tmp_path):
         if rank == 0:
             line = __import__("json").loads(res.stdout.strip().splitlines()[-1])
             assert line["value"] == 1.5 and line["quick"] == [1, 2] and "abandoned" in line["loop_sharded"]["error"]
+            assert line["abandoned_sections"] == ["loop_sharded"]
         else:
             assert res.stdout.strip() == ""
+        assert "extra section 'loop_sharded'" in res.stderr
