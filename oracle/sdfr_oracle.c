@@ -32,6 +32,15 @@ void sdfo_set_margin_mode(int hit_tests_only) { g_margin_hit_tests_only = hit_te
 static int omp_get_max_threads(void) { return 1; }
 static int omp_get_thread_num(void) { return 0; }
 #endif
+#include <stdio.h>
+#include <time.h>
+static int g_sdfo_timing = 0;   /* sdfo_set_timing(1): the backward prints its phases on stderr (bench experiments) */
+void sdfo_set_timing(int on) { g_sdfo_timing = on; }
+static double sdfo_now(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 typedef struct { double* v; size_t cap, lo, hi; } sdfo_slab;
 static sdfo_slab* g_slabs = NULL;
 static int g_nslabs = 0;

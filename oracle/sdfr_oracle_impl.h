@@ -299,6 +299,7 @@ void FN(sdfo_render_backward)(const REAL* grad_depth, const REAL* depth, const R
   sdfo_slab* slabs = sdfo_slabs(T);
   double* pose_acc = (double*)calloc((size_t)T * B * 8, sizeof(double));
   for (int t = 0; t < T; ++t) { slabs[t].lo = nvox; slabs[t].hi = 0; }
+  const double tm0 = sdfo_now();
 #pragma omp parallel
   {
     const int t = omp_get_thread_num();
@@ -337,6 +338,7 @@ void FN(sdfo_render_backward)(const REAL* grad_depth, const REAL* depth, const R
     mine->lo = lo;
     mine->hi = hi;
   }
+  const double tm1 = sdfo_now();
   size_t LO = nvox, HI = 0;
   for (int t = 0; t < T; ++t) {
     if (slabs[t].lo < LO) LO = slabs[t].lo;
@@ -361,6 +363,9 @@ void FN(sdfo_render_backward)(const REAL* grad_depth, const REAL* depth, const R
     g_inv_scale[b] = (REAL)acc[7];
   }
   free(pose_acc);
+  if (g_sdfo_timing)
+    fprintf(stderr, "sdfo backward: %d threads, %d views: pixels %.2f ms, reduce %.2f ms\n", T, B, (tm1 - tm0) * 1e3,
+            (sdfo_now() - tm1) * 1e3);
 }
 
 /* Per-pixel derivative images, dimg[B][H][W][8] in the order of pixel_derivs;

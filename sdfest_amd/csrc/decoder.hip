@@ -1892,7 +1892,8 @@ void host_resize_axis(int dd, float ratio, int ni, int& i0, int& i1, float& l1) 
 // resize ni -> n + the 3x3x3 convolution n -> m behind it in one launch (conv3d_mfma_up_kernel): true if launched.
 // Only where the unfused convolution takes its split-K form (the arithmetic this kernel reproduces).
 bool launch_mfma_up(const sdfr_decoder* d, size_t direct_off, const float* src, int ni, const float* w, const float* bias,
-                    float* dst, int cin, int cout, int n, int m, int kpad, int relu, int N, hipStream_t st) {
+                    float* dst, int cin, int cout, int n, int m, int kpad, int relu, int N, hipStream_t st,
+                    const float* mix_w = nullptr, const float* mix_b = nullptr, int mix_co = 0, float* mix_out = nullptr) {
   if (!(d->opt_fused_single.load(std::memory_order_relaxed) & 1)) return false;
   if (ni > n || ni < 1 || m != n - 2 || m < 1 || direct_ok(direct_off, n, m, N)) return false;
   const int co_tiles = (cout + 15) / 16, ZT = (m + 15) / 16;
@@ -1927,10 +1928,11 @@ bool launch_mfma_up(const sdfr_decoder* d, size_t direct_off, const float* src, 
   const void* fn = wpt == 4 ? reinterpret_cast<const void*>(&conv3d_mfma_up_kernel<4>) : reinterpret_cast<const void*>(&conv3d_mfma_up_kernel<1>);
   if (lds > kFusedLdsMax || (lds > 64 * 1024 && !fused_lds_limit(fn))) return false;
   const dim3 grid(((m + TX - 1) / TX) * ((m + TY - 1) / TY), co_tiles, N);
+  if (mix_out && co_tiles != 1) return false;
   if (wpt == 4) hipLaunchKernelGGL(conv3d_mfma_up_kernel<4>, grid, dim3(threads), lds, st, src, ni, w, bias, dst, cin, cout, n,
-                                   m, kpad, relu, CX, ZT, TX, TY);
+                                   m, kpad, relu, CX, ZT, TX, TY, mix_w, mix_b, mix_co, mix_out);
   else hipLaunchKernelGGL(conv3d_mfma_up_kernel<1>, grid, dim3(threads), lds, st, src, ni, w, bias, dst, cin, cout, n, m,
-                          kpad, relu, CX, ZT, TX, TY);
+                          kpad, relu, CX, ZT, TX, TY, mix_w, mix_b, mix_co, mix_out);
   return true;
 }
 
@@ -2533,7 +2535,7 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
     const int k = d->conv_k[l], co_n = d->conv_cout[l], kpad = d->conv_kpad[l];
     // (batches: an up-sampling resize in front of a 3x3x3 layer is folded into that layer's patch load --
     // conv3d_direct_up_kernel -- and the up-sampled tensor is never written)
-    bool fused_up = false;
+    bool fused_up = false, fused_mixed = false;
     if (!swap && n != d->conv_in_size[l] && k == 3 && d->fwd_direct_off[l] != 0) {
       const int nf = d->conv_in_size[l], mf = nf - k + 1;
       const bool to_out_f = is_last && mf == d->volume && clampv == 0.0f && !(tape && d->conv_relu[l]);
@@ -2549,9 +2551,21 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
       const bool to_out_f = is_last && mf == d->volume && clampv == 0.0f && !(tape && d->conv_relu[l]);
       float* ldst = to_out_f ? out : (tape ? tape + (size_t)N * d->tape_conv_off[l] : nullptr);
       float* cdst = ldst ? ldst : buf[cur ^ 1];
+      // ... and where a swapped 1x1x1 layer follows (the mug decoder's last: 4 -> 1 channels behind the resize to the
+      // volume), its channel mix in this launch's epilogue: the resize behind it gathers one channel, not four
+      // (resize3_kernel instead of resize3_mix_kernel: bit for bit the same corner values)
+      const bool mix2 = (d->opt_fused_single.load(std::memory_order_relaxed) & 1) && l + 1 < d->n_conv && !to_out_f &&
+                        d->conv_swap[l + 1] && d->conv_k[l + 1] == 1 && d->conv_cout[l + 1] <= 4 && co_n <= 16 &&
+                        d->conv_in_size[l + 1] != mf;
       fused_up = launch_mfma_up(d, d->fwd_direct_off[l], act_in, n, d->d_params + d->conv_w_off[l],
-                                d->d_params + d->conv_b_off[l], cdst, c, co_n, nf, mf, kpad, d->conv_relu[l], N, st);
-      if (fused_up) n = nf;
+                                d->d_params + d->conv_b_off[l], mix2 ? ldst : cdst, c, co_n, nf, mf, kpad, d->conv_relu[l],
+                                N, st, mix2 ? d->d_params + d->conv_w_off[l + 1] : nullptr,
+                                mix2 ? d->d_params + d->conv_b_off[l + 1] : nullptr, mix2 ? d->conv_cout[l + 1] : 0,
+                                mix2 ? buf[cur ^ 1] : nullptr);
+      if (fused_up) {
+        n = nf;
+        fused_mixed = mix2;
+      }
     }
     if (!swap && n != d->conv_in_size[l]) {
       resize(act_in, c, n, d->conv_in_size[l], 0, 0.0f, buf[cur ^ 1]);
@@ -2570,7 +2584,7 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
     const int conv_relu = swap ? 0 : d->conv_relu[l];
     const float* wm = d->d_params + d->conv_w_off[l];
     const float* bs = d->d_params + d->conv_b_off[l];
-    if (swap && k == 1 && co_n <= 4 && m_out != n &&
+    if (!premixed && swap && k == 1 && co_n <= 4 && m_out != n &&
         (size_t)N * co_n * m_out * m_out * m_out <= kFewElementsMix) {
       // single latents: the 1x1 mix inside the resize (one launch)
       float* dst = layer_dst ? layer_dst : buf[cur ^ 1];
@@ -2615,6 +2629,10 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
       premixed = true;
     } else if (fused_up) {
       // (launched above)
+      if (fused_mixed) {
+        premixed = true;
+        conv_dst = buf[cur ^ 1];
+      }
     } else if (k == 1 && co_n <= 4) {
       const int voxn = n * n * n;
       const dim3 g1((voxn + 255) / 256, N);

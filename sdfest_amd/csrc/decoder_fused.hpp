@@ -20,6 +20,14 @@
 // Included by decoder.hip inside namespace sdfr { namespace {  (uses resize_axis, blend, resize_row16, stage_to_lds).
 #pragma once
 
+#ifdef SDFR_VS_STAMPS   // timing experiment: the stages of the first workgroup, 10 ns ticks (device printf)
+#define VSS_DECL() unsigned long long vss[10]; int vsk = 0
+#define VSS() do { if (vsk < 10) vss[vsk++] = wall_clock64(); } while (0)
+#else
+#define VSS_DECL() do { } while (0)
+#define VSS() do { } while (0)
+#endif
+
 // stage_to_lds for a workgroup of nthr threads (n % 4 == 0, both 16-byte aligned; four loads in flight per thread)
 __device__ __forceinline__ void stage_to_lds_n(float* __restrict__ dst, const float* __restrict__ src, int n, int tid,
                                                int nthr) {
@@ -226,12 +234,19 @@ __device__ __forceinline__ bool tile_contract(const float* __restrict__ base, bo
 //   grid (tiles_x * tiles_y, co_tiles, N), block 64 * WPT * TX * TY * ZT (>= 256)
 //   LDS: w_l [kpad * 16] | tap_l [kpad] | red [WPT == 4 ? 4 * nthr : 0] | patch | Zc [Cin][CX][CX][PZ]
 // CX: the most coarse columns under TX + 2 (TY + 2) fine ones (host, the kernel's arithmetic).
+// mix_out != NULL: the 1x1x1 layer that FOLLOWS (mix_co <= 4 output channels, its [Kpad][16] matrix and bias; a layer
+// swapped with its resize, so no ReLU here) is applied to the finished rows -- conv1x1_kernel's chain over the channels
+// in ascending order, "+ bias" last, exactly what resize3_mix_kernel forms at each corner -- and written to mix_out
+// [N][mix_co][m^3]: the resize behind it then gathers ONE channel instead of Cout (`out` may be NULL without a tape).
 template <int WPT>
 __global__ __launch_bounds__(1024) void conv3d_mfma_up_kernel(
     const float* __restrict__ in, int ni, const float* __restrict__ wmat, const float* __restrict__ bias,
-    float* __restrict__ out, int Cin, int Cout, int n, int m, int kpad, int relu, int CX, int ZT, int TX, int TY) {
+    float* __restrict__ out, int Cin, int Cout, int n, int m, int kpad, int relu, int CX, int ZT, int TX, int TY,
+    const float* __restrict__ mix_w, const float* __restrict__ mix_b, int mix_co, float* __restrict__ mix_out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+  VSS_DECL();
+  VSS();
   const int IX = TX + 2, IY = TY + 2, PZ = 16 * ZT + 2, patch_n = Cin * IX * IY * PZ;
   float* w_l = lds;
   int* tap_l = reinterpret_cast<int*>(w_l + (size_t)kpad * 16);
@@ -285,6 +300,7 @@ __global__ __launch_bounds__(1024) void conv3d_mfma_up_kernel(
   }
   patch_taps(tap_l, kpad, Cin * 27, IX, IY, PZ, tid, nthr);
   __syncthreads();
+  VSS();   // 1: A (+ weights)
   {   // B: thread <-> (patch column (a, b), elements j, j + lpp, ... of its Cin * PZ)
     const int pairs = IX * IY, lpp = nthr / pairs, pair = tid / lpp, j0 = tid - pair * lpp;
     if (pair < pairs) {
@@ -299,6 +315,7 @@ __global__ __launch_bounds__(1024) void conv3d_mfma_up_kernel(
       const unsigned m_pz = magic_of(PZ);
       const int per = Cin * PZ, zc_ch = CX * CX * PZ, p_ch = IX * IY * PZ;
       float* dst = patch + (a * IY + b) * PZ;
+      // (four elements' reads in flight at a time was measured: no faster, 1.48 -> 1.60 us)
       for (int j = j0; j < per; j += lpp) {
         const int ci = div_by(j, m_pz), fz = j - ci * PZ;
         const float* zc = Zc + ci * zc_ch + fz;
@@ -307,13 +324,48 @@ __global__ __launch_bounds__(1024) void conv3d_mfma_up_kernel(
     }
   }
   __syncthreads();
+  VSS();   // 2: B
   const int tw = WPT == 4 ? wave >> 2 : wave;           // this wave's tile: (column lx, ly; z tile zt)
   const int zt = tw % ZT, cl = tw / ZT, ly_ = cl % TY, lx_ = cl / TY;
   const int x = tx0 + lx_, y = ty0 + ly_;
   const bool has = tw < TX * TY * ZT && x < m && y < m;
   f32x4 acc;
-  if (tile_contract<WPT>(patch + (lx_ * IY + ly_) * PZ + zt * 16 + (lane & 15), has, tap_l, w_l, red, kpad, acc))
-    column_store(acc, zt, bias, co_tile, Cout, relu, out, nb, m, x, y);
+  const bool fin = tile_contract<WPT>(patch + (lx_ * IY + ly_) * PZ + zt * 16 + (lane & 15), has, tap_l, w_l, red, kpad, acc);
+  VSS();   // 3: contraction
+#ifdef SDFR_VS_STAMPS
+  if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+    printf("up-conv n %d m %d threads %d: A %.2f B %.2f contract %.2f us\n", n, m, nthr, (double)(vss[1] - vss[0]) * 0.01,
+           (double)(vss[2] - vss[1]) * 0.01, (double)(vss[3] - vss[2]) * 0.01);
+#endif
+  if (fin) {
+    if (out) column_store(acc, zt, bias, co_tile, Cout, relu, out, nb, m, x, y);
+    if (mix_out) {   // (one column tile of channels: host)
+      const int row = lane & 15, kq = lane >> 4;
+      const float bv = row < Cout ? bias[row] : 0.0f;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[r] + bv;
+        if (relu) v[r] = fmaxf(v[r], 0.0f);
+      }
+      float a2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      const int c2 = row < mix_co ? row : 0;
+      for (int co = 0; co < Cout; ++co) {
+        const float w = mix_w[co * 16 + c2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a2[r] = fmaf(__shfl(v[r], kq * 16 + co, 64), w, a2[r]);
+      }
+      if (row < mix_co) {
+        const float b2 = mix_b[row];
+        float* dst = mix_out + ((((size_t)nb * mix_co + row) * m + x) * m + y) * m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int z = zt * 16 + kq * 4 + r;
+          if (z < m) dst[z] = a2[r] + b2;
+        }
+      }
+    }
+  }
 }
 
 // One tile's contraction in conv3d_mfma_kernel's PLAIN order (what it takes where K = Cout * 27 is short): a single
@@ -374,11 +426,6 @@ struct VjpStage {
   int C, n_in, n_out, pad, Cc, kpad, CK, FX, ZT, TX, TY, zin, e_nin;
 };
 constexpr int kVjpXY = 6;   // TX + 2, TY + 2 <= 6
-#ifdef SDFR_VS_STAMPS   // timing experiment: the stages of the first workgroup, 10 ns ticks (device printf)
-#define VSS() do { if (vsk < 10) vss[vsk++] = wall_clock64(); } while (0)
-#else
-#define VSS() do { } while (0)
-#endif
 // ZIN: the stage runs the z pass itself (its registers: the next round's block and the z taps -- workgroups of <= 512
 // threads); else its producer's epilogue has (s.zin == ZIN: host).
 template <int COUT, int TAPS, int MODE, bool ZIN>
@@ -391,9 +438,7 @@ __global__ __launch_bounds__(ZIN ? 512 : 1024) void vjp_stage_kernel(VjpStage s)
   __shared__ int e_d[64], e_n[64];
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
   const int co_tile = blockIdx.y, nb = blockIdx.z;
-#ifdef SDFR_VS_STAMPS
-  unsigned long long vss[10]; int vsk = 0;
-#endif
+  VSS_DECL();
   VSS();
   const int C = s.C, n_in = s.n_in, n_out = s.n_out, pad = s.pad, TX = s.TX, TY = s.TY, ZT = s.ZT, FX = s.FX, CK = s.CK;
   const int np = n_in + 2 * pad, nc = np - 2;
@@ -725,6 +770,8 @@ __global__ __launch_bounds__(1024) void fc_conv_kernel(const float* __restrict__
   __shared__ float act[2][kFcWaveWidth];
   __shared__ float p_lds[kFcWaveSpan];
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+  VSS_DECL();
+  VSS();
   const int PZ = 16 * ZT + 2, patch_n = Cin * 9 * PZ;
   float* w_l = lds;
   int* tap_l = reinterpret_cast<int*>(w_l + (size_t)kpad * 16);
@@ -778,6 +825,7 @@ __global__ __launch_bounds__(1024) void fc_conv_kernel(const float* __restrict__
     }
     if (tid < d.width[0]) act[0][tid] = z_t;
     __syncthreads();
+    VSS();   // 1: parameters staged
     if (tid < 64) {
       for (int l = 0; l < d.n_fc - 1; ++l) {
         const int wi = d.width[l], wo = d.width[l + 1];
@@ -799,6 +847,7 @@ __global__ __launch_bounds__(1024) void fc_conv_kernel(const float* __restrict__
     patch_taps(tap_l, kpad, Cin * 27, 3, 3, PZ, tid, nthr);
     for (int e = tid; e < patch_n; e += nthr) patch[e] = 0.0f;
     __syncthreads();
+    VSS();   // 2: narrow layers (+ conv weights)
   }
   // the wide layer's rows under the column
   float* fo = (fc_out && co_tile == 0) ? fc_out + (size_t)nb * wout : nullptr;
@@ -823,8 +872,15 @@ __global__ __launch_bounds__(1024) void fc_conv_kernel(const float* __restrict__
     if (fo && own) fo[o] = acc;
   }
   __syncthreads();
+  VSS();   // 3: wide rows
   const int tw = wave >> 2;
   f32x4 acc;
-  if (tile_contract<4>(patch + tw * 16 + (lane & 15), tw < ZT, tap_l, w_l, red, kpad, acc))
-    column_store(acc, tw, bias, co_tile, Cout, relu, out, nb, m, x, y);
+  const bool fin = tile_contract<4>(patch + tw * 16 + (lane & 15), tw < ZT, tap_l, w_l, red, kpad, acc);
+  VSS();   // 4: contraction
+#ifdef SDFR_VS_STAMPS
+  if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+    printf("fc+conv threads %d: params %.2f narrow %.2f wide %.2f contract %.2f us\n", nthr, (double)(vss[1] - vss[0]) * 0.01,
+           (double)(vss[2] - vss[1]) * 0.01, (double)(vss[3] - vss[2]) * 0.01, (double)(vss[4] - vss[3]) * 0.01);
+#endif
+  if (fin) column_store(acc, tw, bias, co_tile, Cout, relu, out, nb, m, x, y);
 }

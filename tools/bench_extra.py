@@ -655,10 +655,32 @@ def c3_l1_config(sdf_np, dev, hbm_peak, B=256, W=640, H=480, steps=40):
     overlap = int(((target > 0) & (plan.depth > 0)).sum())
     bytes_view = 8 * W * H + 12 * 64 ** 3 / B + 32
     med = float(np.median(us))
+    # What the fused pair replaces: the SAME render-and-compare step as three calls -- plain step forward,
+    # sdfr_depth_l1_loss (reads depth and observation, writes the gradient image), plain step backward.  (The headline's
+    # plain step is NOT the comparand: it is handed a gradient image and computes no loss.)
+    from sdfest_amd import _lib
+    L = _lib.lib()
+    plan_u = BatchRenderPlan(64, B, cam, device=dev, close_views=False)
+    loss_u = torch.empty(B, device=dev)
+    grad_u = torch.empty((B, H, W), device=dev)
+    ws = torch.empty(max(L.sdfr_depth_l1_workspace_bytes(B, W, H), 256), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(torch.device(dev)).cuda_stream
+
+    def step_unfused():
+        d = plan_u.forward(sdf, pos, quat, isc, 0.005, prepare_backward=True)
+        _lib.check(L.sdfr_depth_l1_loss(d.data_ptr(), target.data_ptr(), B, W, H, 1.0, loss_u.data_ptr(), grad_u.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), torch.device(dev).index or 0, st), "sdfr_depth_l1_loss")
+        plan_u.backward(grad_u, sdf, pos, quat, isc)
+    for _ in range(20):
+        step_unfused()
+    torch.cuda.synchronize()
+    unfused_us = _event_us(step_unfused, steps)
     return {"workload": f"C3_l1: C3's {B} poses with the masked depth-L1 folded into both render kernels "
                         "(sdfr_render_step_forward_l1 / sdfr_render_step_backward_l1), observed images = renders of "
                         "poses perturbed by 1 cm",
             "us_per_step": {"median": round(med, 1), "min": round(float(us.min()), 1), "wall": round(wall_us, 1)},
+            "us_per_step_unfused_sequence": round(unfused_us, 1),
+            "unfused_sequence": "plain step forward -> sdfr_depth_l1_loss -> plain step backward: the same losses and gradients",
             "renders_per_s": round(B / med * 1e6, 1), "overlap_pixels": overlap,
             "loss_mean": round(float(plan.loss[torch.isfinite(plan.loss)].mean()), 6),
             "roofline": {"bound": "hbm", "bytes_per_view": bytes_view,
