@@ -1051,7 +1051,7 @@ class MultiObjectRenderAndCompare:
     """K estimates optimised SIDE BY SIDE: the K detected objects of one frame -- each with its own depth image (the
     frame masked by the object's instance mask), pose, scale, latent and Adam state -- go through ONE launch sequence
     per iteration.  The reference calls its pipeline once per object, one after the other (simple_setup.py:213-225), and
-    a single estimate's iteration is a chain of ~17 dependent launches that leaves most of an MI355X idle (C5: 0.12 ms
+    a single estimate's iteration is a chain of ~14 dependent launches that leaves most of an MI355X idle (C5: 0.11 ms
     per iteration whatever the object); here the decoder runs on K latents at once, the renderer and the sampler on K
     views with one SDF each (``sdf_view_stride = R^3``), the decoder's VJP on the K gradient volumes, and the tail is K
     workgroups (``sdfr_loop_tail_objects``).  Same arithmetic per object as :class:`FusedRenderAndCompare` (one view per
