@@ -37,6 +37,11 @@
  *   B views share one SDF (sdf_view_stride = 0) or have one each
  *   (sdf_view_stride = R*R*R elements).
  *
+ * STABILITY -- group 1 below is the boundary: its signatures and semantics are what a binding relies on and do not change
+ * without SDFR_VERSION's major number changing.  Groups 2 - 4 are UNSTABLE: they exist for this repository's own host
+ * code (sdfest_amd/*.py), follow its needs from round to round (arguments were added in every round so far), and are
+ * exported only because that host code is Python over ctypes; bind to them at your own risk, pinned to one SDFR_VERSION.
+ *
  * CONTENTS -- four groups; a binding from another language needs group 1 only
  *   1. CORE: the reference boundary (what sdf_renderer_cpp, losses.pc_loss and SDFDecoder.forward are replaced by)
  *        sdfr_version, sdfr_last_error
@@ -44,13 +49,13 @@
  *        sdfr_pc_loss_forward, sdfr_pc_loss_backward[_workspace_bytes]
  *        sdfr_decoder_create / _destroy / _forward / _workspace_bytes / _tape_bytes,
  *        sdfr_decoder_backward_latent[_workspace_bytes], sdfr_decoder_set_option
- *   2. BATCHED / STEP forms of the same arithmetic (fewer launches, fewer bytes; same results)
+ *   2. [unstable] BATCHED / STEP forms of the same arithmetic (fewer launches, fewer bytes; same results)
  *        sdfr_render_step_forward[_counted] / _step_backward / _step_workspace_bytes, sdfr_render_sync_offset,
  *        sdfr_render_partials_offset, sdfr_render_fixed_volume_offset, sdfr_fixed_to_float
  *        sdfr_render_forward_l1[_workspace_bytes], sdfr_render_backward_l1, sdfr_render_step_forward_l1,
  *        sdfr_render_step_backward_l1, sdfr_render_backward_l1_pc, sdfr_render_step_backward_l1_pc
  *        sdfr_pc_l1_backward[_accumulate]
- *   3. LOOP: one render-and-compare iteration (SDFPipeline.__call__) as a fixed launch sequence
+ *   3. [unstable] LOOP: one render-and-compare iteration (SDFPipeline.__call__) as a fixed launch sequence
  *        sdfr_preprocess_depth, sdfr_depth_to_points_resident, sdfr_depth_count[_ordered|_centroid],
  *        sdfr_depth_to_points[_ordered|_shifted], sdfr_depth_points_workspace_bytes, sdfr_depth_centroid_workspace_bytes
  *        sdfr_pose_to_views[_objects], sdfr_views_to_pose_grad[_deferred], sdfr_decoder_backward_latent_deferred[_batch],
@@ -58,7 +63,7 @@
  *        sdfr_depth_l1_loss[_workspace_bytes], sdfr_pc_l1_loss, sdfr_inlier_ratio, sdfr_nn_loss_forward / _backward
  *        sharded over ranks: sdfr_loop_view_records, sdfr_loop_tail_records, sdfr_inlier_counts_record,
  *        sdfr_inlier_update_record
- *   4. GENERATOR / INITIALISATION (the forward-only callers around the loop)
+ *   4. [unstable] GENERATOR / INITIALISATION (the forward-only callers around the loop)
  *        sdfr_affine_mask; sdfr_pointnet_layer[_counted], sdfr_linear_vec, sdfr_orientation_posterior,
  *        sdfr_init_estimate
  * (Within the file the groups follow the order in which the reference's code runs; every declaration carries the

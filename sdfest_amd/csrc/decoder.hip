@@ -2019,6 +2019,10 @@ VjpPlan vjp_stage_plan(const sdfr_decoder* d, int lc, int C, int n_in, int n_out
     p.TX = sh[0]; p.TY = sh[1];
     if ((long long)((nc + p.TX - 1) / p.TX) * ((nc + p.TY - 1) / p.TY) * ci_tiles * N <= 256) break;
   }
+#ifdef SDFR_VJP_TUNE   // timing experiments: tile shape and workgroup size from the environment
+  if (const char* e = getenv("SDFR_VJP_TX")) p.TX = atoi(e);
+  if (const char* e = getenv("SDFR_VJP_TY")) p.TY = atoi(e);
+#endif
   const int tiles = p.TX * p.TY * p.ZT, max_thr = zin ? 512 : 1024;   // (vjp_stage_kernel's launch bounds)
   if (64 * tiles > max_thr) return p;
   p.mode = !split ? 0 : (256 * tiles <= max_thr ? 4 : 1);
@@ -2037,6 +2041,9 @@ VjpPlan vjp_stage_plan(const sdfr_decoder* d, int lc, int C, int n_in, int n_out
     const size_t units = (size_t)CK * p.FX * p.FX * (zin ? RL / 4 : RL);
     int threads = min_thr;
     while (threads < max_thr && (size_t)threads * 8 < units) threads *= 2;
+#ifdef SDFR_VJP_TUNE
+    if (const char* e = getenv("SDFR_VJP_THREADS")) threads = std::max(min_thr, std::min(max_thr, atoi(e)));
+#endif
     const size_t fixed = (size_t)kpad * 17 + (p.mode == 4 ? 4 * threads : 0) + ((patch_n + 3) & ~3);
     const size_t lds = (fixed + (((size_t)CK * p.FX * IY * n_in + 3) & ~(size_t)3) + f_n) * sizeof(float);
     if (lds > kFusedLdsMax - 8 * 1024 || units >= 65536 || (size_t)CK * IX * IY * n_in >= 65536) continue;   // (8 KB static)

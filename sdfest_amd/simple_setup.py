@@ -139,6 +139,7 @@ class SDFPipeline:
         if not self._resident_wanted or self._nn_init_override is not None or not isinstance(self.init_network, SDFPoseNet):
             return None
         if views not in self._residents:
+            self._bounded(self._residents, self.MAX_CACHED_LOOPS)
             try:
                 self._residents[views] = ResidentInit(self.init_network, self.cam, views, self.config,
                                                       normalize_pose=bool(self.init_config.get("normalize_pose", False)))
@@ -151,10 +152,20 @@ class SDFPipeline:
         sdf = self.vae.decode(latent)
         return self.render(sdf[0, 0], position, orientation, 1 / scale)
 
+    MAX_CACHED_LOOPS = 4     # per kind: a loop holds its point clouds at capacity (3.7 MB per 640x480 view) and its graphs
+
+    @staticmethod
+    def _bounded(cache: dict, limit: int) -> None:
+        """drop the least recently built entry before a new one goes in (a caller whose number of views or objects
+        varies from call to call re-builds instead of collecting buffers without bound)"""
+        while len(cache) >= limit:
+            cache.pop(next(iter(cache)))
+
     def _loop(self, views: int, shape_optimization: bool) -> FusedRenderAndCompare:
         key = (int(views), bool(shape_optimization))
         loop = self._loops.get(key)
         if loop is None:
+            self._bounded(self._loops, self.MAX_CACHED_LOOPS)
             loop = FusedRenderAndCompare(self.vae, self.cam, self.config, views=views,
                                          shape_optimization=shape_optimization, device=self._dev,
                                          sdf_grad_mode=self.sdf_grad_mode)
@@ -244,9 +255,13 @@ class SDFPipeline:
         depth_image (H,W): the frame (NOT modified: every object gets its own masked copy); masks (K,H,W) bool: the
         instance masks; camera_position (3,) / camera_orientation (4,): the camera in the world (default: the origin);
         prior_orientation_distribution (K,C) / training_orientation_distribution (C,): as in ``__call__``, one row per
-        object.  Returns position (K,3), orientation (K,4), scale (K,), latent (K,L) -- row k is what
-        ``pipeline(depth, masks[k], color)`` estimates for object k (same arithmetic; `result_selection_strategy`
-        "last_iteration")."""
+        object.  Returns position (K,3), orientation (K,4), scale (K,), latent (K,L) -- row k follows what
+        ``pipeline(depth, masks[k], color)`` estimates for object k (`result_selection_strategy` "last_iteration"): BIT FOR
+        BIT when only the pose is optimised (``shape_optimization=False``; tests/test_multi_object_gpu.py), to rounding
+        with shape optimisation -- a batch of latents takes other, equivalent decoder kernels than a single one (the direct
+        convolution from 8 latents on, the tiled resize from 2, no split-K above 16), tested to 1 % of an Adam step per
+        iteration.  ``NoDepthError`` for an object without a valid depth pixel is raised AFTER the call's work was
+        enqueued (the counts are read behind the launches), where the reference raises before optimising (:780-781)."""
         dev = self._dev
         if depth_image.dim() != 2 or masks.dim() != 3 or tuple(masks.shape[1:]) != tuple(depth_image.shape):
             raise ValueError("depth_image (H,W) and masks (K,H,W) are expected")
@@ -254,6 +269,7 @@ class SDFPipeline:
         key = (K, bool(shape_optimization))
         loop = self._multi_loops.get(key)
         if loop is None:
+            self._bounded(self._multi_loops, self.MAX_CACHED_LOOPS)
             loop = self._multi_loops[key] = MultiObjectRenderAndCompare(
                 self.vae, self.cam, self.config, K, shape_optimization=shape_optimization, device=dev,
                 sdf_grad_mode=self.sdf_grad_mode)
@@ -263,6 +279,7 @@ class SDFPipeline:
             resident = None
             if self._resident_wanted and self._nn_init_override is None and isinstance(self.init_network, SDFPoseNet):
                 if K not in self._resident_objects:
+                    self._bounded(self._resident_objects, self.MAX_CACHED_LOOPS)
                     try:
                         self._resident_objects[K] = ResidentInit(
                             self.init_network, self.cam, K, dict(self.config, init_view="first"),
