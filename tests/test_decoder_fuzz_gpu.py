@@ -76,13 +76,22 @@ def test_random_architecture(seed):
             f"conv={[(l['in_size'], l['in_channels'], l['out_channels'], l['kernel_size'], l['relu']) for l in c['conv']]}"
             f" volume={c['volume']} tsdf={c['tsdf']}")
     dec = SDFDecoder(c["volume"], c["latent"], c["fc"], c["conv"], tsdf=c["tsdf"], state_dict=c["state"])
+    if "SDFR_FUZZ_FUSED_SINGLE" in os.environ:     # a one-off hunt with other fused layer pairs than the default's
+        dec.set_option("fused_single", int(os.environ["SDFR_FUZZ_FUSED_SINGLE"]))
     z = torch.tensor(c["z"], device="cuda", requires_grad=True)
     out = dec(z)
     assert out.shape == (c["N"], 1, c["volume"], c["volume"], c["volume"]), name
     z64 = torch.tensor(c["z"], dtype=torch.float64, requires_grad=True)
     ref = D.torch_decoder(c["state"], c["fc"], c["conv"], c["volume"], z64)
     r = ref.detach().numpy()
-    assert rel_err(out.detach().cpu().numpy(), r) <= 2e-4, name
+    floor = None
+    if c["conv"][-1]["relu"]:
+        # a ReLU'd last layer leaves an output that is mostly zeros and whose largest entry may be tiny against the
+        # values the ReLU saw: the yardstick is the size of THOSE (the same decoder without the last ReLU)
+        pre = D.torch_decoder(c["state"], c["fc"], c["conv"][:-1] + [dict(c["conv"][-1], relu=False)], c["volume"],
+                              z64.detach())
+        floor = float(pre.abs().max())
+    assert rel_err(out.detach().cpu().numpy(), r, floor) <= 2e-4, name
     if c["tsdf"] is not False:                           # SDFDecoder.forward's clamp (sdf_vae.py:254-257), forward only
         t = 1.0 if c["tsdf"] is True else float(c["tsdf"])
         clamped = dec(z.detach(), enforce_tsdf=True).cpu().numpy()
