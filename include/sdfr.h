@@ -39,7 +39,7 @@
  *
  * STABILITY -- group 1 below is the boundary: its signatures and semantics are what a binding relies on and do not change
  * without SDFR_VERSION's major number changing.  Groups 2 - 4 are UNSTABLE: they exist for this repository's own host
- * code (sdfest_amd/*.py), follow its needs from round to round (arguments were added in every round so far), and are
+ * code (the Python modules under sdfest_amd/), follow its needs from round to round (arguments were added in every round so far), and are
  * exported only because that host code is Python over ctypes; bind to them at your own risk, pinned to one SDFR_VERSION.
  *
  * CONTENTS -- four groups; a binding from another language needs group 1 only

@@ -568,19 +568,22 @@ __global__ void clamp_kernel(float* __restrict__ x, size_t count, float clamp) {
 
 
 // Copy n floats (n % 4 == 0, both 16-byte aligned) global -> LDS with a whole workgroup: 16-byte
-// pieces, four loads in flight per thread before the first LDS store (a plain `lds[i] = g[i]`
+// pieces, eight loads in flight per thread before the first LDS store (a plain `lds[i] = g[i]`
 // loop waits for every load before it issues the next).
+// (eight in flight since round 6: a 432-tap layer's 27 KB are 6.75 vectors per thread, and a second pass of the loop is
+// a second memory round trip in front of everything else the workgroup does -- ~1 us of a 5.6 us launch)
 __device__ __forceinline__ void stage_to_lds(float* __restrict__ dst, const float* __restrict__ src, int n,
                                              int tid) {
   const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
   f32x4* d4 = reinterpret_cast<f32x4*>(dst);
   const int n4 = n >> 2;
-  for (int i = tid; i < n4; i += 4 * 256) {
-    f32x4 v[4];
+  constexpr int kIn = 8;
+  for (int i = tid; i < n4; i += kIn * 256) {
+    f32x4 v[kIn];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = s4[min(i + u * 256, n4 - 1)];
+    for (int u = 0; u < kIn; ++u) v[u] = s4[min(i + u * 256, n4 - 1)];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < kIn; ++u)
       if (i + u * 256 < n4) d4[i + u * 256] = v[u];
   }
 }
