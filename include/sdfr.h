@@ -53,13 +53,14 @@
  *        sdfr_render_step_forward[_counted] / _step_backward / _step_workspace_bytes, sdfr_render_sync_offset,
  *        sdfr_render_partials_offset, sdfr_render_fixed_volume_offset, sdfr_fixed_to_float
  *        sdfr_render_forward_l1[_workspace_bytes], sdfr_render_backward_l1, sdfr_render_step_forward_l1,
- *        sdfr_render_step_backward_l1, sdfr_render_backward_l1_pc, sdfr_render_step_backward_l1_pc
+ *        sdfr_render_step_backward_l1, sdfr_render_backward_l1_pc, sdfr_render_step_backward_l1_pc,
+ *        sdfr_render_step_fused_l1_pc, sdfr_render_fused_view_count_offset, sdfr_render_fused_tile_loss_offset
  *        sdfr_pc_l1_backward[_accumulate]
  *   3. [unstable] LOOP: one render-and-compare iteration (SDFPipeline.__call__) as a fixed launch sequence
  *        sdfr_preprocess_depth, sdfr_depth_to_points_resident, sdfr_depth_count[_ordered|_centroid],
  *        sdfr_depth_to_points[_ordered|_shifted], sdfr_depth_points_workspace_bytes, sdfr_depth_centroid_workspace_bytes
- *        sdfr_pose_to_views[_objects], sdfr_views_to_pose_grad[_deferred], sdfr_decoder_backward_latent_deferred[_batch],
- *        sdfr_loop_tail, sdfr_loop_tail_objects, sdfr_adam_step, sdfr_point_constraint, sdfr_add_inplace
+ *        sdfr_pose_to_views[_objects], sdfr_views_to_pose_grad[_deferred], sdfr_decoder_backward_latent_deferred[_batch|_scaled],
+ *        sdfr_loop_tail, sdfr_loop_tail_fused, sdfr_loop_tail_objects, sdfr_adam_step, sdfr_point_constraint, sdfr_add_inplace
  *        sdfr_depth_l1_loss[_workspace_bytes], sdfr_pc_l1_loss, sdfr_inlier_ratio, sdfr_nn_loss_forward / _backward
  *        sharded over ranks: sdfr_loop_view_records, sdfr_loop_tail_records, sdfr_inlier_counts_record,
  *        sdfr_inlier_update_record
@@ -249,6 +250,33 @@ SDFR_API int sdfr_render_step_backward_l1_pc(
     long long g_sdf_view_stride, void* workspace, size_t workspace_bytes, float pc_weight, const float* points,
     const int* offsets, int max_view_points, const float* scale, void* pc_workspace, size_t pc_workspace_bytes,
     float* loss, float* loss_stats_out, int device, void* stream);
+/* ONE LAUNCH for the whole loss-fused step of 1 .. 3 views of the plain grid (sdfr_render_step_forward_l1 with the
+ * loss deferred + sdfr_render_step_backward_l1_pc): every image tile marches its rays and, while the depths are still
+ * in registers, runs the backward of its hit pixels; the sampler's blocks run beside the tiles as before.  The depth
+ * loss is a mean over a count that no tile knows before the launch ends, so the depth term is left UNSCALED, with
+ * the bare sign of (estimate - observation) as its upstream gradient:
+ *   workspace (sdfr_render_step_workspace_bytes; offsets by the functions named)
+ *     sdfr_render_fixed_volume_offset(R, B, W, H, 1)   float [R^3]   d/dSDF of the depth term, unscaled, ADDED to
+ *     sdfr_render_partials_offset(R, B, W, H, 1)       the tiles' pose sums, unscaled (32 x 8-pixel tiles)
+ *     sdfr_render_fused_view_count_offset(B, H)        float [B]     the views' overlap counts, ADDED to (integers
+ *                                                      below 2^24 held in floats: exact in any order)
+ *     behind the 64-bit volume: (sum |est - obs|, count) per tile, 8 floats apart
+ *   g_sdf (nullable: nobody wants d/dSDF -- the tiles then skip it)  float [R^3]: the point-cloud term, ADDED to;
+ *     with g_sdf, B = 1 (every view's depth term has its own k: one unscaled volume serves one view).
+ * Nothing is zero-filled by this call: whoever consumes a sum clears it (sdfr_decoder_backward_latent_deferred_scaled
+ * forms  k * depth volume + g_sdf,  k = weight / count, and clears both; sdfr_loop_tail_fused multiplies the pose
+ * sums and resets the count) -- the volumes and the counts must be zero before the FIRST call.
+ * depth equals sdfr_render_step_forward_l1's bit for bit; the gradients equal the two launches' up to rounding (k
+ * multiplies sums instead of terms).  sdf_grad_mode: SDFR_SDF_GRAD_EXACT or _CUDA_COMPAT, no flags.  R <= 128.
+ * pos / quat / inv_scale / scale: the views' poses (scale = 1 / inv_scale, what the sampler takes). */
+SDFR_API size_t sdfr_render_fused_view_count_offset(int B, int H);
+SDFR_API size_t sdfr_render_fused_tile_loss_offset(int R, int B, int W, int H);   /* the (sum, count) tile records */
+SDFR_API int sdfr_render_step_fused_l1_pc(
+    const float* sdf, int R, long long sdf_view_stride, const float* pos, const float* quat, const float* inv_scale,
+    const float* scale, int B, int W, int H, float cx, float cy, float fx, float fy, float threshold,
+    const float* target, float* depth, int sdf_grad_mode, float* g_sdf, void* workspace, size_t workspace_bytes,
+    float pc_weight, const float* points, const int* offsets, int max_view_points, void* pc_workspace,
+    size_t pc_workspace_bytes, int device, void* stream);
 /* sdfr_render_step_backward_l1 = sdfr_render_backward_l1 as the second half of a step begun by
  * sdfr_render_step_forward_l1 (no prologue launch, the forward's view records and rectangles; pos / quat / inv_scale
  * are not passed again) -- the loss-fused form of sdfr_render_step_backward.
@@ -418,6 +446,16 @@ SDFR_API int sdfr_decoder_backward_latent(const sdfr_decoder* decoder, const flo
 SDFR_API int sdfr_decoder_backward_latent_deferred(const sdfr_decoder* decoder, const float* z, const float* tape,
                                           const float* grad_out, void* workspace, size_t workspace_bytes,
                                           void* stream, const float** t_mid);
+/* sdfr_decoder_backward_latent_deferred for an incoming gradient in TWO volumes, one of them not yet normalised:
+ *     grad = grad_out + k * grad_scaled,   k = count[0] > 0 ? weight / count[0] : 0     (count: a device float)
+ * -- what sdfr_render_step_fused_l1_pc leaves: the point-cloud term, and the depth term before its division by the
+ * view's overlap count.  The first launch of the VJP forms the sum as it loads (decoders whose first launch cannot,
+ * get it from one small launch in front), and BOTH volumes are zero-filled once they have been read -- their
+ * producer adds into them.  volume^3 a multiple of 4, both volumes 16-byte aligned. */
+SDFR_API int sdfr_decoder_backward_latent_deferred_scaled(const sdfr_decoder* decoder, const float* z, const float* tape,
+                                                 float* grad_out, float* grad_scaled, const float* count, float weight,
+                                                 void* workspace, size_t workspace_bytes, void* stream,
+                                                 const float** t_mid);
 /* ... and for N latents (the K objects of a frame): *t_mid is [N][width of the wide layer's input]; sdfr_loop_tail_objects
  * finishes object k's product rule from row k. */
 SDFR_API int sdfr_decoder_backward_latent_deferred_batch(const sdfr_decoder* decoder, const float* z, const float* tape,
@@ -475,6 +513,21 @@ SDFR_API int sdfr_loop_tail(float* params, float* grads, float* exp_avg, float* 
                    int max_view_points, float* pos_c, float* quat_c, float* inv_scale, float* scale_v, float* pc_loss,
                    const float* con_source, const float* con_target, float con_weight, float* con_loss,
                    const sdfr_decoder* decoder, const float* decoder_t_mid, int device, void* stream);
+
+/* sdfr_loop_tail behind sdfr_render_step_fused_l1_pc (the render pair as ONE launch): the tiles' pose sums of the
+ * depth term come unscaled, beside the views' overlap counts -- the per-view reduction multiplies them by
+ * k = depth_weight / count (the expression of the two-launch form's tiles), writes depth_loss [V] (nullable) =
+ * sum |est - obs| / count from the tiles' records, and RESETS the counts for the next step.  view_count_offset /
+ * tile_loss_offset: sdfr_render_fused_view_count_offset / _tile_loss_offset.  Everything else as sdfr_loop_tail. */
+SDFR_API int sdfr_loop_tail_fused(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int* step, int n_params,
+                         float lr_position, float lr_orientation, float lr_scale, float lr_latent, int update_latent,
+                         const float* cam_pos, const float* cam_quat, int V, void* render_workspace,
+                         size_t render_partials_offset, size_t view_count_offset, size_t tile_loss_offset,
+                         float depth_weight, float* depth_loss, int W, int H, const void* pc_workspace,
+                         const int* offsets, int max_view_points, float* pos_c, float* quat_c, float* inv_scale,
+                         float* scale_v, float* pc_loss, const float* con_source, const float* con_target,
+                         float con_weight, float* con_loss, const sdfr_decoder* decoder, const float* decoder_t_mid,
+                         int device, void* stream);
 
 /* sdfr_loop_tail for SEVERAL estimates at once -- the K detected objects of one frame, each with its own pose, scale,
  * latent and Adam state, optimised side by side in one launch sequence (the reference runs its pipeline once per object,

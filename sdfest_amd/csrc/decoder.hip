@@ -1580,6 +1580,16 @@ __global__ __launch_bounds__(kBtMaxThreads) void resize3_backward_tiled_kernel(
   }
 }
 
+// g += k g2,  k = weight / cnt[0] (0 for a zero count): the scaled form's incoming gradients as one volume, for the
+// decoders whose first VJP launch is not the fused stage (which adds them on load)
+__global__ __launch_bounds__(256) void scaled_combine_kernel(float* __restrict__ g, const float* __restrict__ g2,
+                                                             const float* __restrict__ cnt, float weight, size_t n) {
+  const float c = cnt[0];
+  const float k = c > 0.0f ? weight / c : 0.0f;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) g[i] = fmaf(k, g2[i], g[i]);
+}
+
 // Backward of the last (wide) Linear layer: t[n][i] = sum_o Wt[i][o] * g_last[n][o], one workgroup
 // per (i, sample) -- a 50 x 8192 GEMV spread over 50 workgroups instead of one.
 // `act`: the layer's forward output; its ReLU' is applied to g_last on the fly (no mask launch).
@@ -1587,9 +1597,21 @@ __global__ __launch_bounds__(kFcBlock) void fc_last_backward_kernel(const float*
                                                                     FcDesc d,
                                                                     const float* __restrict__ g_last,
                                                                     const float* __restrict__ act,
-                                                                    float* __restrict__ t_out) {
+                                                                    float* __restrict__ t_out,
+                                                                    float* __restrict__ clear_a,
+                                                                    float* __restrict__ clear_b, int clear_vec) {
   __shared__ float red[kFcBlock / 64];
   const int i = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  // sdfr_decoder_backward_latent_deferred_scaled: the VJP's incoming gradient volumes were consumed by its first
+  // launch -- this one, its last with a grid, zero-fills them for their producer (clear_vec 16-byte vectors each)
+  if (clear_a) {
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int nthreads = (int)(gridDim.x * gridDim.y) * kFcBlock, me = ((int)blockIdx.y * (int)gridDim.x + i) * kFcBlock + tid;
+    for (int e = me; e < clear_vec; e += nthreads) {
+      reinterpret_cast<f32x4*>(clear_a)[e] = zero4;
+      if (clear_b) reinterpret_cast<f32x4*>(clear_b)[e] = zero4;
+    }
+  }
   const int l = d.n_fc - 1, win = d.width[l], wout = d.width[l + 1];
   const float* wt = params + d.w_off[l] + (size_t)i * wout;
   const float* g = g_last + (size_t)n * wout;
@@ -2061,8 +2083,14 @@ VjpPlan vjp_stage_plan(const sdfr_decoder* d, int lc, int C, int n_in, int n_out
 }
 
 // e_nin > 0: the stage's epilogue applies the z pass of the NEXT stage's transposed resize (nc -> e_nin)
+struct ScaledGrad {   // sdfr_decoder_backward_latent_deferred_scaled
+  float* g2;
+  const float* cnt;
+  float weight;
+};
 bool launch_vjp_stage(const sdfr_decoder* d, const VjpPlan& p, int lc, const float* g, int C, int n_in, int n_out,
-                      const float* act, const float* mix_w, int mix_cout, int e_nin, float* dst, int N, hipStream_t st) {
+                      const float* act, const float* mix_w, int mix_cout, int e_nin, float* dst, int N, hipStream_t st,
+                      const ScaledGrad* sg = nullptr) {
   const int ci_n = d->conv_cin[lc], ci_tiles = (ci_n + 15) / 16, pad = d->conv_k[lc] - 1, nc = n_in + 2 * pad - 2;
   const float* zb = d->d_params + d->zero_bias_off;
   VjpStage s;
@@ -2072,6 +2100,10 @@ bool launch_vjp_stage(const sdfr_decoder* d, const VjpPlan& p, int lc, const flo
   s.CK = p.CK; s.FX = p.FX; s.ZT = p.ZT; s.TX = p.TX; s.TY = p.TY; s.zin = p.zin; s.e_nin = e_nin;
   s.tab = d->d_params + d->rs_tab_off[lc + 1];
   s.e_tab = e_nin > 0 ? d->d_params + d->rs_tab_off[lc] : nullptr;
+  if (sg) {
+    if (!p.zin || ((uintptr_t)sg->g2 & 15)) return false;
+    s.g2 = sg->g2; s.cnt = sg->cnt; s.weight = sg->weight;
+  }
   const dim3 grid(((nc + p.TX - 1) / p.TX) * ((nc + p.TY - 1) / p.TY), ci_tiles, N), block(p.threads);
 #define SDFR_VS(CO, TAPS, MODE, ZIN)                                                               \
   do {                                                                                           \
@@ -2722,9 +2754,11 @@ void decoder_fc_desc(const sdfr_decoder* d, FcDesc* out, const float** d_params,
 namespace {
 // t_mid_out != nullptr: the last launch (the small leading layers, fc_stack_backward_kernel) is left to the caller --
 // *t_mid_out is where the gradient w.r.t. the input of the wide layer lies ([N][width], inside the workspace).
+// sg != nullptr (N = 1): the incoming gradient is  grad_out + k sg->g2  (ScaledGrad), and both volumes are zero-filled
+// once they have been read.
 int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* tape, const float* grad_out, int N,
                           float* g_z, void* workspace, size_t workspace_bytes, void* stream,
-                          const float** t_mid_out) {
+                          const float** t_mid_out, const ScaledGrad* sg = nullptr) {
   if (!d) return fail(SDFR_E_NULL, "sdfr_decoder_backward_latent: NULL decoder");
   if (N < 0 || N > 65535) return fail(SDFR_E_INVALID, "N=%d out of range", N);
   if (N == 0) return 0;
@@ -2739,6 +2773,10 @@ int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* ta
   float* buf[2] = {(float*)wsp, (float*)wsp + (size_t)N * d->max_bwd};
   int cur = 0;
   const float* g = grad_out;  // gradient w.r.t. the current tensor, [N][c][n^3]
+  const size_t vox_in = (size_t)d->volume * d->volume * d->volume;
+  if (sg && (N != 1 || (vox_in & 3) || ((uintptr_t)grad_out & 15) || ((uintptr_t)sg->g2 & 15) || !sg->g2 || !sg->cnt))
+    return fail(SDFR_E_INVALID, "sdfr_decoder_backward_latent_deferred_scaled: one latent, 16-byte aligned volumes of a "
+                "multiple of 4 voxels");
 
   // sizes of the tensor each conv layer produces
   std::vector<int> out_n(d->n_conv);
@@ -2928,6 +2966,21 @@ int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* ta
     const float *g = nullptr, *act = nullptr, *mix_w = nullptr;
     int C = 0, n_in = 0, n_out = 0, mix_cout = 0;
   } pend;
+  // the scaled form: the fused first stage adds the two volumes on load (it is the launch that reads grad_out when the
+  // last layer is a swapped, ReLU-free 1x1x1 one: the `mix` step of the loop below); any other decoder gets them summed
+  // by a launch of its own first
+  bool sg_in_stage = false;
+  if (sg) {
+    const int l = d->n_conv - 1;
+    if (l > 0 && out_n[l] == d->volume && d->conv_swap[l] && !d->conv_relu[l] && d->conv_k[l] == 1 && d->conv_cin[l] <= 4 &&
+        !d->conv_swap[l - 1] && out_n[l - 1] == d->conv_prev[l] && d->conv_cout[l - 1] == d->conv_cin[l] &&
+        d->conv_prev[l] != d->conv_in_size[l] && ((uintptr_t)sg->g2 & 15) == 0)
+      sg_in_stage = vjp_stage_plan(d, l - 1, d->conv_cout[l], d->conv_prev[l], d->conv_in_size[l], d->conv_cin[l], N, 1,
+                                   grad_out, true).ok;
+    if (!sg_in_stage)
+      hipLaunchKernelGGL(scaled_combine_kernel, dim3((unsigned)((vox_in + 255) / 256)), dim3(256), 0, st,
+                         const_cast<float*>(grad_out), sg->g2, sg->cnt, sg->weight, vox_in);
+  }
   int n = d->volume;
   if (out_n[d->n_conv - 1] != d->volume) {  // final resize
     const int ni = out_n[d->n_conv - 1];
@@ -2954,7 +3007,7 @@ int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* ta
       pend.on = false;
       if (fuse_below) below = vjp_stage_plan(d, l - 1, ci_n, prev, nin, 0, N, 0, nullptr, false);
       if (!launch_vjp_stage(d, pend.plan, l, pend.g, pend.C, pend.n_in, pend.n_out, pend.act, pend.mix_w, pend.mix_cout,
-                            below.ok ? prev : 0, buf[cur], N, st))
+                            below.ok ? prev : 0, buf[cur], N, st, (sg_in_stage && pend.g == grad_out) ? sg : nullptr))
         return fail(SDFR_E_INVALID, "sdfr_decoder_backward_latent: the fused stage could not be launched");
       g = buf[cur];
       cur ^= 1;
@@ -2978,6 +3031,8 @@ int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* ta
     if (mix) {
       const float* act_below = d->conv_relu[l - 1] ? tape + (size_t)N * d->tape_conv_off[l - 1] : nullptr;
       pend.plan = vjp_stage_plan(d, l - 1, co_n, prev, nin, ci_n, N, 1, g, g == grad_out);
+      if (sg && g == grad_out && pend.plan.ok != sg_in_stage)
+        return fail(SDFR_E_INVALID, "sdfr_decoder_backward_latent: the scaled form's first stage changed its mind (internal)");
       if (pend.plan.ok) {
         pend.on = true;
         pend.g = g; pend.act = act_below; pend.mix_w = d->d_params + d->bwd_w_off[l];
@@ -3072,7 +3127,8 @@ int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* ta
                          dim3(kFcBlock), 0, st, d->d_params, fd, g, act_fc, N, t_mid);
     else
       hipLaunchKernelGGL(fc_last_backward_kernel, dim3(win, N), dim3(kFcBlock), 0, st, d->d_params, fd, g, act_fc,
-                         t_mid);
+                         t_mid, sg ? const_cast<float*>(grad_out) : (float*)nullptr, sg ? sg->g2 : (float*)nullptr,
+                         (int)(vox_in / 4));
   }
   if (t_mid_out) *t_mid_out = t_mid;
   else if (decoder_fc_one_wave(d, fd))
@@ -3102,4 +3158,14 @@ extern "C" int sdfr_decoder_backward_latent_deferred_batch(const sdfr_decoder* d
                                                            size_t workspace_bytes, void* stream, const float** t_mid) {
   if (!t_mid) return fail(SDFR_E_NULL, "sdfr_decoder_backward_latent_deferred_batch: NULL pointer argument");
   return decoder_backward_impl(d, z, tape, grad_out, N, nullptr, workspace, workspace_bytes, stream, t_mid);
+}
+
+extern "C" int sdfr_decoder_backward_latent_deferred_scaled(const sdfr_decoder* d, const float* z, const float* tape,
+                                                            float* grad_out, float* grad_scaled, const float* count,
+                                                            float weight, void* workspace, size_t workspace_bytes,
+                                                            void* stream, const float** t_mid) {
+  if (!t_mid || !grad_scaled || !count)
+    return fail(SDFR_E_NULL, "sdfr_decoder_backward_latent_deferred_scaled: NULL pointer argument");
+  const ScaledGrad sg{grad_scaled, count, weight};
+  return decoder_backward_impl(d, z, tape, grad_out, 1, nullptr, workspace, workspace_bytes, stream, t_mid, &sg);
 }

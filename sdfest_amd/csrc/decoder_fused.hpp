@@ -427,6 +427,12 @@ struct VjpStage {
   const float* tab;     // this stage's transposed resize: [n_in][16] = first source, taps, 12 weights (sdfr_decoder_create)
   const float* e_tab;   // the epilogue's ([e_nin][16]), or NULL
   int C, n_in, n_out, pad, Cc, kpad, CK, FX, ZT, TX, TY, zin, e_nin;
+  // sdfr_decoder_backward_latent_deferred_scaled (ZIN only): the stage reads  g + k g2,  k = weight / cnt[0] (0 if the
+  // count is 0) -- a second upstream volume whose normalisation its producer could not know (render.hip,
+  // render_fused_l1_pc_kernel)
+  const float* g2 = nullptr;
+  const float* cnt = nullptr;
+  float weight = 0.0f;
 };
 constexpr int kVjpXY = 6;   // TX + 2, TY + 2 <= 6
 // ZIN: the stage runs the z pass itself (its registers: the next round's block and the z taps -- workgroups of <= 512
@@ -497,9 +503,28 @@ __global__ __launch_bounds__(ZIN ? 512 : 1024) void vjp_stage_kernel(VjpStage s)
   };
   constexpr int kFl = ZIN ? 8 : 1;
   f32x4 pre[kFl];
+  // (with a second volume the registers hold half as many units, each from both volumes: pre[j], pre[j + kFl / 2])
+  const bool two = ZIN && s.g2 != nullptr;
+  const int kfl = two ? kFl / 2 : kFl;
+  float k2 = 0.0f;
+  if (two) {
+    const float cnt = s.cnt[0];
+    k2 = cnt > 0.0f ? s.weight / cnt : 0.0f;
+  }
   auto prefetch = [&](int c0) {
     const int total = min(CK, C - c0) * fnx * slab_u;
     const float* src = s.g + ((size_t)nb * C + c0) * src_vol;
+    if (two) {
+      const float* src2 = s.g2 + ((size_t)nb * C + c0) * src_vol;
+#pragma unroll
+      for (int j = 0; j < kFl / 2; ++j) {
+        int lo;
+        const size_t g = unit_at(min(tid + nthr * j, total - 1), lo);
+        pre[j] = *reinterpret_cast<const f32x4*>(src + g);
+        pre[(j + kFl / 2) % kFl] = *reinterpret_cast<const f32x4*>(src2 + g);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < kFl; ++j) {
       int lo;
@@ -569,18 +594,29 @@ __global__ __launch_bounds__(ZIN ? 512 : 1024) void vjp_stage_kernel(VjpStage s)
 #pragma unroll
       for (int j = 0; j < kFl; ++j) {
         const int e = tid + nthr * j;
-        if (e < total) {
+        if (j < kfl && e < total) {
           int lo;
           (void)unit_at(e, lo);
-          *reinterpret_cast<f32x4*>(F + lo) = pre[j];
+          f32x4 v = pre[j];
+          if (two) {
+            const f32x4 v2 = pre[(j + kFl / 2) % kFl];
+            v = f32x4{fmaf(k2, v2.x, v.x), fmaf(k2, v2.y, v.y), fmaf(k2, v2.z, v.z), fmaf(k2, v2.w, v.w)};
+          }
+          *reinterpret_cast<f32x4*>(F + lo) = v;
         }
       }
-      if (total > kFl * nthr) {   // (blocks larger than the prefetch: the rest straight from memory)
+      if (total > kfl * nthr) {   // (blocks larger than the prefetch: the rest straight from memory)
         const float* src = s.g + ((size_t)nb * C + c0) * src_vol;
-        for (int e = tid + nthr * kFl; e < total; e += nthr) {
+        const float* src2 = two ? s.g2 + ((size_t)nb * C + c0) * src_vol : nullptr;
+        for (int e = tid + nthr * kfl; e < total; e += nthr) {
           int lo;
           const size_t g = unit_at(e, lo);
-          *reinterpret_cast<f32x4*>(F + lo) = *reinterpret_cast<const f32x4*>(src + g);
+          f32x4 v = *reinterpret_cast<const f32x4*>(src + g);
+          if (two) {
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(src2 + g);
+            v = f32x4{fmaf(k2, v2.x, v.x), fmaf(k2, v2.y, v.y), fmaf(k2, v2.z, v.z), fmaf(k2, v2.w, v.w)};
+          }
+          *reinterpret_cast<f32x4*>(F + lo) = v;
         }
       }
       __syncthreads();

@@ -149,11 +149,22 @@ __global__ void views_to_pose_grad_kernel(const float* __restrict__ orientation,
 // Every load whose address does not depend on another load is issued first (the rectangle, the length of the point
 // set, the quaternion), and the sampler's first 64 blocks are in flight together with the renderer's first 64 tiles:
 // three dependent round trips instead of six -- the sums, and the order of their additions, are the same.
+// the depth term of sdfr_render_step_fused_l1_pc (render.hip): unscaled tile sums beside the view's overlap count
+struct FusedDepth {
+  float* view_cnt = nullptr;          // [views], read and reset here
+  const float* tile_loss = nullptr;   // [views][tiles][kLossRec]: (sum |est - obs|, count, ...)
+  float weight = 0.0f;
+  float* depth_loss = nullptr;        // [views] out (nullable)
+};
 __device__ __forceinline__ void reduce_view_wave(
     int v, int lane, const ViewSetup* __restrict__ setup, const float* __restrict__ tile_part, int W, int H,
     int ntx_all, int nty_all, int tile_w_all, int tile_h_all, int stride, const float* __restrict__ pc_part,
     const float* __restrict__ pc_loss_part, const int* __restrict__ offsets, int n_single, int nblk,
-    const float* __restrict__ quat_c, float* __restrict__ pc_loss_out, float* __restrict__ dst) {
+    const float* __restrict__ quat_c, float* __restrict__ pc_loss_out, float* __restrict__ dst,
+    const FusedDepth& fd = FusedDepth{}) {
+  // (the one-launch render step: the view's count -- on its way while the tiles are summed; reset below, once it has
+  // arrived: the render launch that added to it is complete, the next one comes after this launch)
+  const float cnt_l = fd.view_cnt ? fd.view_cnt[v] : 0.0f;
   int x0 = 0, y0 = 0, x1 = 0, y1 = 0, big_flag = 0;
   if (tile_part) {
     const ViewSetup& s = setup[v];
@@ -176,6 +187,7 @@ __device__ __forceinline__ void reduce_view_wave(
     if (pc_loss_part) sl0 = pc_loss_part[(size_t)v * nblk + lane];
   }
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float l_sum = 0.0f;
   if (tile_part) {
     // the view's tiling, as pose_reduce_kernel (render.hip): a batch backward picks it per view
     int ntx = ntx_all, nty = nty_all, tile_w = tile_w_all, tile_h = tile_h_all;
@@ -195,10 +207,22 @@ __device__ __forceinline__ void reduce_view_wave(
         const float4 a = p[0], c = p[1];
         acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
         acc[4] += c.x; acc[5] += c.y; acc[6] += c.z; acc[7] += c.w;
+        if (fd.tile_loss) l_sum += fd.tile_loss[(first + rec) * kLossRec];
       }
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = wave_sum(acc[k]);
+    if (fd.view_cnt) {
+      // the tiles' sums were formed with the bare sign of (est - obs) as their upstream gradient: times
+      // k = weight / count, the expression of the two-launch form's backward tiles (render.hip, backward_tile)
+      const float cnt = cnt_l;
+      const float kk = cnt > 0.0f ? fd.weight / cnt : 0.0f;
+      if (lane == 0) fd.view_cnt[v] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] *= kk;
+      l_sum = wave_sum(l_sum);
+      if (lane == 0 && fd.depth_loss) fd.depth_loss[v] = l_sum / cnt;   // (no overlap: 0 / 0, as loss_reduce_kernel)
+    }
   }
   if (lane < 8) {
     float r = acc[0];
@@ -338,7 +362,8 @@ __device__ __forceinline__ void deferred_chain(
     int nty_all, int tile_w_all, int tile_h_all, int stride, const float* __restrict__ pc_part,
     const float* __restrict__ pc_loss_part,
     const int* __restrict__ offsets, int n_single, int nblk, const float* __restrict__ quat_c,
-    float* __restrict__ pc_loss, float* g_position, float* g_orientation, float* g_scale, int view_base = 0) {
+    float* __restrict__ pc_loss, float* g_position, float* g_orientation, float* g_scale, int view_base = 0,
+    const FusedDepth& fd = FusedDepth{}) {
   // view_base (sdfr_loop_tail_objects): the V views of THIS object are the launch's views view_base .. view_base + V - 1
   // (their set-up records, tile partials, point blocks, quaternions, losses); the cameras are the object's own list
   __shared__ float view_g[kDeferredMaxViews][16];  // [0..7] renderer: pos, quat, inv_scale; [8..15] sampler
@@ -349,7 +374,7 @@ __device__ __forceinline__ void deferred_chain(
     const float cq = lane < 4 ? cam_quat[4 * v + lane] : 0.0f;
     reduce_view_wave(view_base + v, lane, setup, tile_part, W, H, ntx_all, nty_all, tile_w_all, tile_h_all, stride,
                      pc_part, pc_loss_part, offsets, n_single, nblk, quat_c,
-                     pc_loss ? pc_loss + view_base + v : nullptr, view_g[v]);
+                     pc_loss ? pc_loss + view_base + v : nullptr, view_g[v], fd);
     if (lane < 4) view_cq[v][lane] = cq;
   }
   __syncthreads();
@@ -724,6 +749,7 @@ struct LoopTailArgs {
   // launch's views k V .. k V + V - 1), the same cameras for every object; 0 / 1: the single estimate of sdfr_loop_tail
   int n_obj;
   float* latents;   // objects: the updated latents, packed [n_obj][n - 8] (the next iteration's batched decode), or NULL
+  FusedDepth fd;    // sdfr_loop_tail_fused: the render step was ONE launch (its depth term comes unscaled)
 };
 static_assert(kFcBlock == 256, "the tail's workgroup runs the decoder's Linear-stack backward");
 #ifdef SDFR_TAIL_STAMPS   // timing experiment (tools/microbench): where the tail's time goes, in 10 ns ticks
@@ -792,7 +818,7 @@ __global__ __launch_bounds__(256) void loop_tail_kernel(LoopTailArgs a_in) {
     // (the chain indexes the LAUNCH's views: the un-advanced quat_c / pc_loss and the object's first view)
     deferred_chain(p_cur + 3, p_cur + 7, a.cam_quat, a.V, a.setup, a.tile_part, a.W, a.H, a.ntx, a.nty,
                    a.tile_w, a.tile_h, a.stride, a.pc_part, a.pc_loss_part, a.offsets, a.n_single, a.nblk,
-                   a.quat_c, a.pc_loss, g_l, g_l + 3, g_l + 7, view_base);
+                   a.quat_c, a.pc_loss, g_l, g_l + 3, g_l + 7, view_base, a.fd);
   }
   SDFR_STAMP(2);
   if (tid == 0 && a.con_source)   // (p_cur: thread 0 has passed a barrier of the chain above since it was written)
@@ -1182,15 +1208,16 @@ extern "C" int sdfr_views_to_pose_grad_deferred(const float* orientation, const 
   return 0;
 }
 
-extern "C" int sdfr_loop_tail(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int* step, int n_params,
-                              float lr_position, float lr_orientation, float lr_scale, float lr_latent,
-                              int update_latent, const float* cam_pos, const float* cam_quat, int V,
-                              const void* render_workspace, size_t render_partials_offset, int W, int H,
-                              const void* pc_workspace, const int* offsets, int max_view_points, float* pos_c,
-                              float* quat_c, float* inv_scale, float* scale_v, float* pc_loss,
-                              const float* con_source, const float* con_target, float con_weight, float* con_loss,
-                              const sdfr_decoder* decoder, const float* decoder_t_mid, int device, void* stream) {
-  const char* fn = "sdfr_loop_tail";
+namespace {
+int loop_tail_impl(const char* fn, float* params, float* grads, float* exp_avg, float* exp_avg_sq, int* step, int n_params,
+                   float lr_position, float lr_orientation, float lr_scale, float lr_latent,
+                   int update_latent, const float* cam_pos, const float* cam_quat, int V,
+                   const void* render_workspace, size_t render_partials_offset, int W, int H,
+                   const void* pc_workspace, const int* offsets, int max_view_points, float* pos_c,
+                   float* quat_c, float* inv_scale, float* scale_v, float* pc_loss,
+                   const float* con_source, const float* con_target, float con_weight, float* con_loss,
+                   const sdfr_decoder* decoder, const float* decoder_t_mid, int device, void* stream,
+                   const FusedDepth& fd) {
   if ((decoder != nullptr) != (decoder_t_mid != nullptr))
     return fail(SDFR_E_NULL, "%s: decoder and decoder_t_mid go together", fn);
   if (V < 1 || V > kDeferredMaxViews) return fail(SDFR_E_INVALID, "%s: V=%d out of range [1,%d]", fn, V, kDeferredMaxViews);
@@ -1205,10 +1232,12 @@ extern "C" int sdfr_loop_tail(float* params, float* grads, float* exp_avg, float
   if (render_workspace && ((uintptr_t)render_workspace % alignof(ViewSetup) || render_partials_offset % 16))
     return fail(SDFR_E_INVALID, "%s: render_workspace / partials offset misaligned", fn);
   SDFR_HIP_TRY(hipSetDevice(device));
-  const TileGeom geom = render_workspace ? backward_geom(V, W, H) : kSmallTile;
+  // (the one-launch render step always works in 32 x 8 tiles)
+  const TileGeom geom = (render_workspace && !fd.view_cnt) ? backward_geom(V, W, H) : kSmallTile;
   const int nblk = pc_workspace ? (max_view_points + kSamplerPts - 1) / kSamplerPts : 0;
   const float* pc_part = (const float*)pc_workspace;
   LoopTailArgs a{};
+  a.fd = fd;
   a.params = params; a.grads = grads; a.m = exp_avg; a.v = exp_avg_sq; a.step = step; a.n = n_params;
   a.lr_pos = lr_position; a.lr_quat = lr_orientation; a.lr_scale = lr_scale; a.lr_latent = lr_latent;
   a.update_latent = update_latent;
@@ -1236,6 +1265,47 @@ extern "C" int sdfr_loop_tail(float* params, float* grads, float* exp_avg, float
   hipLaunchKernelGGL(loop_tail_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
+}
+}  // namespace
+
+extern "C" int sdfr_loop_tail(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int* step, int n_params,
+                              float lr_position, float lr_orientation, float lr_scale, float lr_latent,
+                              int update_latent, const float* cam_pos, const float* cam_quat, int V,
+                              const void* render_workspace, size_t render_partials_offset, int W, int H,
+                              const void* pc_workspace, const int* offsets, int max_view_points, float* pos_c,
+                              float* quat_c, float* inv_scale, float* scale_v, float* pc_loss,
+                              const float* con_source, const float* con_target, float con_weight, float* con_loss,
+                              const sdfr_decoder* decoder, const float* decoder_t_mid, int device, void* stream) {
+  return loop_tail_impl("sdfr_loop_tail", params, grads, exp_avg, exp_avg_sq, step, n_params, lr_position,
+                        lr_orientation, lr_scale, lr_latent, update_latent, cam_pos, cam_quat, V, render_workspace,
+                        render_partials_offset, W, H, pc_workspace, offsets, max_view_points, pos_c, quat_c, inv_scale,
+                        scale_v, pc_loss, con_source, con_target, con_weight, con_loss, decoder, decoder_t_mid, device,
+                        stream, FusedDepth{});
+}
+
+extern "C" int sdfr_loop_tail_fused(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int* step,
+                                    int n_params, float lr_position, float lr_orientation, float lr_scale,
+                                    float lr_latent, int update_latent, const float* cam_pos, const float* cam_quat,
+                                    int V, void* render_workspace, size_t render_partials_offset,
+                                    size_t view_count_offset, size_t tile_loss_offset, float depth_weight,
+                                    float* depth_loss, int W, int H, const void* pc_workspace, const int* offsets,
+                                    int max_view_points, float* pos_c, float* quat_c, float* inv_scale, float* scale_v,
+                                    float* pc_loss, const float* con_source, const float* con_target, float con_weight,
+                                    float* con_loss, const sdfr_decoder* decoder, const float* decoder_t_mid,
+                                    int device, void* stream) {
+  const char* fn = "sdfr_loop_tail_fused";
+  if (!render_workspace) return fail(SDFR_E_NULL, "%s: render_workspace is NULL", fn);
+  if (view_count_offset % 4 || tile_loss_offset % 16)
+    return fail(SDFR_E_INVALID, "%s: view count / tile loss offsets misaligned", fn);
+  FusedDepth fd;
+  fd.view_cnt = (float*)((char*)render_workspace + view_count_offset);
+  fd.tile_loss = (const float*)((const char*)render_workspace + tile_loss_offset);
+  fd.weight = depth_weight;
+  fd.depth_loss = depth_loss;
+  return loop_tail_impl(fn, params, grads, exp_avg, exp_avg_sq, step, n_params, lr_position, lr_orientation, lr_scale,
+                        lr_latent, update_latent, cam_pos, cam_quat, V, render_workspace, render_partials_offset, W, H,
+                        pc_workspace, offsets, max_view_points, pos_c, quat_c, inv_scale, scale_v, pc_loss, con_source,
+                        con_target, con_weight, con_loss, decoder, decoder_t_mid, device, stream, fd);
 }
 
 extern "C" int sdfr_loop_tail_objects(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int* step,

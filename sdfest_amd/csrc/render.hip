@@ -813,6 +813,7 @@ struct BackwardLds {
   float wave_part[4][8];
   int tile_max_bits;
   int box[6];   // cells of the tile's hit pixels: min x, y, z, max x, y, z (index of the cell's corner 000)
+  float loss_pair[4][2];   // REG: the waves' (sum |est - obs|, count)
 };
 
 // fractional bits of a tile's fixed-point sums in 32-bit words: a voxel receives at most one contribution per pixel,
@@ -925,14 +926,34 @@ struct LossArgs {
 // contribution is rounded ONCE, per pixel, to the fixed quantum 2^-kDetQuantumBits -- a function of the pixel alone,
 // not of its tile -- and everything after that is integer addition (64-bit LDS run table, 64-bit global atomics).
 constexpr int kDetQuantumBits = SDFR_FIXED_QUANTUM_BITS;
-template <int RT, int SX, int SY, typename Hash, bool LOSS, bool DET = false>
+// REG (render_fused_l1_pc_kernel: forward and backward of a tile in one launch): the thread's pixel comes in registers
+// -- its depth as the march has just left it, the SIGN of (estimate - observation) on the overlap as its upstream
+// gradient (the view's k = weight / count is not known before the launch ends: whoever consumes the sums multiplies by
+// it) -- and the tile also leaves its (sum |est - obs|, count) pair and adds its count to the view's.  `setup` points at
+// the workgroup's own record.  SDFG = false: pose sums only (a loop that does not optimise the shape).
+struct RegPixel {
+  float z = 0.0f, sign = 0.0f, l_sum = 0.0f, l_cnt = 0.0f;
+  int row = 0, col = 0;
+  float* tile_loss = nullptr;   // this tile's (sum, count)
+  float* view_cnt = nullptr;    // the view's overlap count (atomic: integers below 2^24, exact in any order)
+};
+template <int RT, int SX, int SY, typename Hash, bool LOSS, bool DET = false, bool REG = false, bool SDFG = true>
 __device__ __forceinline__ void backward_tile(
     BackwardLds<Hash>& lds, int tile_x, int tile_y, size_t record, int b, const LossArgs& la,
     const float* __restrict__ grad_depth, const float* __restrict__ depth,
     const float* __restrict__ sdf, int R, long long sdf_view_stride,
     const ViewSetup* __restrict__ setup, int W, int H, float cx, float cy, float rfx, float rfy,
     int sdf_grad_mode, float* __restrict__ g_sdf, long long g_sdf_view_stride,
-    float* __restrict__ partials) {
+    float* __restrict__ partials, const RegPixel& rp = RegPixel{}) {
+  static_assert(!REG || (SX * SY == 1 && LOSS && !DET), "the register form: one pixel per thread, loss-fused");
+  // d/dSDF pre-summed in the tile's LDS table -- or, REG, straight to the volume's float atomics: a launch over one or
+  // a few views is a few hundred tiles with hit pixels, and what it takes is the depth of a tile's chain of phases
+  // (bounds pass, clear, adds, flush: three barriers and a table walk), not the number of atomics it sends: the loop's
+  // iteration 0.1042 -> 0.0970 ms without the table (tools/microbench/fused_render.py)
+#ifndef SDFR_SMALL_DIRECT
+#define SDFR_SMALL_DIRECT 0
+#endif
+  constexpr bool TABLE = SDFG && !REG && !(SDFR_SMALL_DIRECT && std::is_same<Hash, SmallHash>::value && !DET);
   Hash& hash = lds.hash;
   float (*wave_part)[8] = lds.wave_part;
 
@@ -940,14 +961,20 @@ __device__ __forceinline__ void backward_tile(
   using PB = Patch<kPatchWBwd>;
   const int Rr = RT > 0 ? RT : R;
   const int px0 = tile_x * kTileW, py0 = tile_y * kTileH;
-  const ViewSetup& s = setup[b];
+  const ViewSetup& s = REG ? *setup : setup[b];
   const Rect rc{s.rect[0], s.rect[1], s.rect[2], s.rect[3]};
-  if (!overlaps(rc, px0, py0, kTileW, kTileH)) return;  // depth is 0 there by construction
+  if (!REG && !overlaps(rc, px0, py0, kTileW, kTileH)) return;  // depth is 0 there by construction
   float* part = partials + record * 8;  // this tile's pose sums
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const float* zimg = depth + (size_t)b * H * W;
-  const float* gimg = grad_depth + (size_t)b * H * W;
+  const float* zimg = REG ? nullptr : depth + (size_t)b * H * W;
+  const float* gimg = REG ? nullptr : grad_depth + (size_t)b * H * W;
+  // the thread's pixel of sub-tile `sub`
+  auto pixel = [&](int sub, int& row, int& col) {
+    if (REG) { row = rp.row; col = rp.col; return; }
+    col = px0 + (sub % SX) * kSubW + PB::ox(wave) + PB::x(lane);
+    row = py0 + (sub / SX) * kSubH + PB::oy(wave) + PB::y(lane);
+  };
 
   // all depth reads of the macro-tile up front (independent loads), then the upstream
   // gradient of the hit pixels only
@@ -955,9 +982,9 @@ __device__ __forceinline__ void backward_tile(
   bool any_hit = false;
 #pragma unroll
   for (int sub = 0; sub < kSubs; ++sub) {
-    const int col = px0 + (sub % SX) * kSubW + PB::ox(wave) + PB::x(lane);
-    const int row = py0 + (sub / SX) * kSubH + PB::oy(wave) + PB::y(lane);
-    zs[sub] = (col < W && row < H) ? zimg[(size_t)row * W + col] : 0.0f;  // (nt loads: +4 %, measured)
+    int row, col;
+    pixel(sub, row, col);
+    zs[sub] = REG ? rp.z : ((col < W && row < H) ? zimg[(size_t)row * W + col] : 0.0f);  // (nt loads: +4 %, measured)
   }
   if (tid == 0) {   // (ordered before the atomics below by the barrier of __syncthreads_or)
     lds.tile_max_bits = 0;
@@ -967,11 +994,11 @@ __device__ __forceinline__ void backward_tile(
   float gmax = 0.0f;
 #pragma unroll
   for (int sub = 0; sub < kSubs; ++sub) {
-    const int col = px0 + (sub % SX) * kSubW + PB::ox(wave) + PB::x(lane);
-    const int row = py0 + (sub / SX) * kSubH + PB::oy(wave) + PB::y(lane);
+    int row, col;
+    pixel(sub, row, col);
     const bool hit = zs[sub] != 0.0f;
-    gos[sub] = hit ? gimg[(size_t)row * W + col] : 0.0f;
-    if (LOSS) {   // the sign of (estimate - observation) on the overlap; times k below
+    gos[sub] = REG ? rp.sign : (hit ? gimg[(size_t)row * W + col] : 0.0f);
+    if (LOSS && !REG) {   // the sign of (estimate - observation) on the overlap; times k below
       const float e = zs[sub], o = gos[sub];
       gos[sub] = (e > 0.0f && o > 0.0f) ? ((e > o) ? 1.0f : ((e < o) ? -1.0f : 0.0f)) : 0.0f;
     }
@@ -980,9 +1007,10 @@ __device__ __forceinline__ void backward_tile(
   }
   if (!__syncthreads_or(any_hit)) {
     if (tid < 8) part[tid] = 0.0f;
+    if (REG && tid == 0) *reinterpret_cast<float2*>(rp.tile_loss) = make_float2(0.0f, 0.0f);
     return;
   }
-  if (LOSS) {
+  if (LOSS && !REG) {
     // same expression as depth_l1_grad_kernel (loop.hip): k = weight / count, 0 if the overlap is empty
     const float w = la.loss_grad ? la.loss_weight * la.loss_grad[b] : la.loss_weight;
     const float cnt = la.lt.part ? view_overlap_count(la.lt, s, b, &lds.wave_part[0][0])   // (workgroup-uniform)
@@ -997,13 +1025,13 @@ __device__ __forceinline__ void backward_tile(
   const float top = (float)(Rr - 2);
   // bounds pass: the box of cells under this tile's hit pixels (clamped like the cell choice itself, cu:196-207, so
   // the bounds are in [0, R - 2] whatever the depth image holds)
-  if (__ballot(any_hit) != 0ull) {
+  if (TABLE && __ballot(any_hit) != 0ull) {
     int lo0 = 0x7fffffff, lo1 = 0x7fffffff, lo2 = 0x7fffffff, hi0 = -1, hi1 = -1, hi2 = -1;
 #pragma unroll
     for (int sub = 0; sub < kSubs; ++sub) {
       if (zs[sub] == 0.0f) continue;
-      const int col = px0 + (sub % SX) * kSubW + PB::ox(wave) + PB::x(lane);
-      const int row = py0 + (sub / SX) * kSubH + PB::oy(wave) + PB::y(lane);
+      int row, col;
+      pixel(sub, row, col);
       const HitPoint hp = hit_point(s, row, col, zs[sub], cx, cy, rfx, rfy, isc, h);
       const int ix = (int)fminf(fmaxf(floorf(hp.gx), 0.0f), top);
       const int iy = (int)fminf(fmaxf(floorf(hp.gy), 0.0f), top);
@@ -1020,7 +1048,7 @@ __device__ __forceinline__ void backward_tile(
       atomicMax(&lds.tile_max_bits, gbits);
     }
   }
-  __syncthreads();
+  if (TABLE) __syncthreads();
   // the box in voxels: corners reach one past the last cell.  Workgroup-uniform -> scalar registers.
   const int bx0 = __builtin_amdgcn_readfirstlane(lds.box[0]), by0 = __builtin_amdgcn_readfirstlane(lds.box[1]),
             bz0 = __builtin_amdgcn_readfirstlane(lds.box[2]);
@@ -1028,17 +1056,17 @@ __device__ __forceinline__ void backward_tile(
             nz = __builtin_amdgcn_readfirstlane(lds.box[5]) - bz0 + 2;
   const int nvox = (__builtin_amdgcn_readfirstlane(lds.box[3]) - bx0 + 2) * ny * nz;
   const int tile_max_bits = __builtin_amdgcn_readfirstlane(lds.tile_max_bits);
-  const bool dense = !DET && nvox <= kDenseCap;
+  const bool dense = TABLE && !DET && nvox <= kDenseCap;
   constexpr int kDenseBits = tile_fixed_bits(kSubs * kBlock, 22);
   constexpr int kHashBits = HashIs32<Hash>::value ? tile_fixed_bits(kSubs * kBlock, Hash::kBits) : Hash::kBits;
   if (dense) {
     typedef int i32x4v __attribute__((ext_vector_type(4)));
     i32x4v* d4 = reinterpret_cast<i32x4v*>(lds.dense);
     for (int i = tid; i < (nvox + 3) >> 2; i += kBlock) d4[i] = i32x4v{0, 0, 0, 0};
-  } else {
+  } else if (TABLE) {
     hash.clear(tid, kBlock);
   }
-  __syncthreads();
+  if (TABLE) __syncthreads();
 
   const float* vol = sdf + (size_t)b * sdf_view_stride;
   float* gvol = g_sdf + (size_t)b * g_sdf_view_stride;
@@ -1047,7 +1075,7 @@ __device__ __forceinline__ void backward_tile(
   int e2;
   (void)frexpf(bound, &e2);  // bound = m * 2^e2, m in [0.5, 1)  ->  2^e2 > bound
   static_assert(!DET || !HashIs32<Hash>::value, "the deterministic mode needs 64-bit table sums");
-  const bool fixed_ok = DET || ((bound > 0.0f) && (bound < 1e30f) && (e2 > -80));
+  const bool fixed_ok = TABLE && (DET || ((bound > 0.0f) && (bound < 1e30f) && (e2 > -80)));
   const int bits = dense ? kDenseBits : kHashBits;
   const float to_fixed = DET ? (float)(1ll << kDetQuantumBits) : (fixed_ok ? ldexpf(1.0f, bits - e2) : 0.0f);
   const float from_fixed = (fixed_ok && !DET) ? ldexpf(1.0f, e2 - bits) : 0.0f;
@@ -1066,8 +1094,8 @@ __device__ __forceinline__ void backward_tile(
     float z = zs[sub];
     if (z == 0.0f) continue;
     asm volatile("" : "+v"(z));   // recompute below what the bounds pass computed, do not keep it in registers
-    const int col = px0 + (sub % SX) * kSubW + PB::ox(wave) + PB::x(lane);
-    const int row = py0 + (sub / SX) * kSubH + PB::oy(wave) + PB::y(lane);
+    int row, col;
+    pixel(sub, row, col);
     const float go = gos[sub];
     const HitPoint hp = hit_point(s, row, col, z, cx, cy, rfx, rfy, isc, h);
     const V3 d = hp.d, o = hp.o;
@@ -1126,7 +1154,8 @@ __device__ __forceinline__ void backward_tile(
     // false): NaN reaches g_sdf as it does through the reference's atomicAdd.
     const float wmax = fmaxf(fmaxf(fmaxf(fabsf(w0), fabsf(w1)), fmaxf(fabsf(w2), fabsf(w3))),
                              fmaxf(fmaxf(fabsf(w4), fabsf(w5)), fmaxf(fabsf(w6), fabsf(w7))));
-    if (fixed_ok && wmax * to_fixed < weight_limit) {
+    if (!SDFG || (REG && go == 0.0f)) {   // (REG: the sign is 0 off the overlap -- nothing to add)
+    } else if (fixed_ok && wmax * to_fixed < weight_limit) {
       const float wk[8] = {w0, w1, w2, w3, w4, w5, w6, w7};
       if (dense) {
         // word of corner 000 (the clamp cannot act -- the bounds pass saw this very cell -- and keeps every
@@ -1171,9 +1200,20 @@ __device__ __forceinline__ void backward_tile(
   } else if (lane < 8) {
     wave_part[wave][lane] = 0.0f;
   }
+  if (REG) {   // the tile's share of the view's depth loss: four waves' pairs, added as the records' readers add them
+    const float ls = wave_sum(rp.l_sum), lc = wave_sum(rp.l_cnt);
+    if (lane == 0) { lds.loss_pair[wave][0] = ls; lds.loss_pair[wave][1] = lc; }
+  }
   __syncthreads();
   if (tid < 8) part[tid] = (wave_part[0][tid] + wave_part[1][tid]) + (wave_part[2][tid] + wave_part[3][tid]);
+  if (REG && tid == 8) {
+    const float ls = (lds.loss_pair[0][0] + lds.loss_pair[1][0]) + (lds.loss_pair[2][0] + lds.loss_pair[3][0]);
+    const float lc = (lds.loss_pair[0][1] + lds.loss_pair[1][1]) + (lds.loss_pair[2][1] + lds.loss_pair[3][1]);
+    *reinterpret_cast<float2*>(rp.tile_loss) = make_float2(ls, lc);
+    if (lc > 0.0f) atomicAdd(rp.view_cnt, lc);
+  }
 
+  if (!TABLE) return;
   if (dense) {
     // consecutive lanes take consecutive words = consecutive z of a box row: contiguous global float atomics
     const unsigned m_nz = 0xffffffffu / (unsigned)nz + 1u, m_ny = 0xffffffffu / (unsigned)ny + 1u;   // exact for < 2^16
@@ -1298,7 +1338,7 @@ __global__ __launch_bounds__(kBlock) void render_backward_pc_kernel(
   if ((int)blockIdx.y < pc_rows) {
     const int bx = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
     if (bx < (pa.groups > 0 ? pa.groups : pa.nblk))
-      pc_backward_block<RT, true, DET>(*reinterpret_cast<PcBackwardLds*>(raw), pa, bx, b);
+      pc_backward_block<RT, true, DET, (SDFR_SMALL_DIRECT && !BATCH && !DET)>(*reinterpret_cast<PcBackwardLds*>(raw), pa, bx, b);
     return;
   }
   backward_dispatch<RT, BATCH, true, DET>(raw, blockIdx.x, (int)blockIdx.y - pc_rows, ntx, nty, stride, b, target, depth,
@@ -1306,6 +1346,109 @@ __global__ __launch_bounds__(kBlock) void render_backward_pc_kernel(
                                      g_sdf_view_stride, partials, LossArgs{loss_grad, loss_stats, loss_weight, lt});
   if (lt.part && blockIdx.x == 0 && (int)blockIdx.y == pc_rows && threadIdx.x < 64)
     reduce_view_loss(lt, setup[b], b, (int)threadIdx.x);
+}
+
+// ONE launch for the render pair of a loop iteration over a few views (and the sampler's blocks beside it, as in
+// render_backward_pc_kernel): a tile marches its rays (forward_tile's arithmetic, INLINE set-up, 32 x 8 pixels, one
+// 8 x 8 patch per wave) and, while the depths are still in registers, runs the backward of its hit pixels
+// (backward_tile, REG).  What a tile cannot know is the view's overlap count -- the depth loss is a MEAN over pixels
+// every tile contributes to -- so the upstream gradient is the bare sign of (est - obs):
+//   * d/dSDF of the depth term goes UNSCALED into its own volume `g_depth` (the sampler's blocks add the point-cloud
+//     term, whose scale is known, into pa.g_sdf): the consumer forms  k g_depth + g_sdf,  k = weight / count
+//     (sdfr_decoder_backward_latent_deferred_scaled);
+//   * the tile's pose sums are unscaled too, its (sum |est - obs|, count) pair lies in `tile_loss`, and the view's count
+//     is summed atomically in `view_cnt` (integers below 2^24 held in floats: exact whatever the order) -- the loop's
+//     tail multiplies and resets (sdfr_loop_tail_fused).
+// Neither the tiles nor the sampler's blocks pre-sum in LDS (backward_tile REG, pc_backward_block DIRECT).
+// Nothing in this launch zero-fills: both volumes are cleared by their consumer (the decoder VJP's last launch).
+// The depth image is the forward's, bit for bit; the gradients differ from the two launches' in rounding only
+// (k is applied to sums instead of to terms).     grid (tiles x, pc_rows + tiles y, views)
+template <int RT, bool SDFG>
+__global__ __launch_bounds__(kBlock) void render_fused_l1_pc_kernel(
+    const float* __restrict__ sdf, int R, long long sdf_view_stride, int W, int H, int ntx, int nty, float cx, float cy,
+    float rfx, float rfy, float threshold, int vec_ok, float* __restrict__ depth, const float* __restrict__ target,
+    InlineSetup in, int sdf_grad_mode, float* __restrict__ g_depth, float* __restrict__ partials,
+    float* __restrict__ tile_loss, float* __restrict__ view_cnt, int pc_rows, PcBackwardArgs pa) {
+  constexpr size_t kTileLds = sizeof(BackwardLds<SmallHash>);
+  constexpr size_t kLdsBytes = kTileLds > sizeof(PcBackwardLds) ? kTileLds : sizeof(PcBackwardLds);
+  __shared__ __attribute__((aligned(16))) unsigned char raw[kLdsBytes];
+  const int b = blockIdx.z;
+  if ((int)blockIdx.y < pc_rows) {
+    const int bx = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+    if (bx < (pa.groups > 0 ? pa.groups : pa.nblk))
+      pc_backward_block<RT, true, false, true, SDFG>(*reinterpret_cast<PcBackwardLds*>(raw), pa, bx, b);
+    return;
+  }
+  const int tile_x = blockIdx.x, tile_y = (int)blockIdx.y - pc_rows;
+  ViewSetup s;
+  setup_pose(b, in.pos, in.quat, in.inv_scale, R, in.fx, in.fy, s);
+  setup_box<false>(s, R, W, H, cx, cy, in.fx, in.fy, nullptr, threshold);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if ((tile_x | tile_y) == 0 && tid == 0) in.out[b] = s;   // (the tail's reductions walk the view's rectangle)
+  using PF = Patch<kPatchWFwd>;
+  const int px0 = tile_x * kSubW, py0 = tile_y * kSubH;
+  const Rect rc{s.rect[0], s.rect[1], s.rect[2], s.rect[3]};
+  float* img = depth + (size_t)b * H * W;
+  const size_t tile = ((size_t)b * nty + tile_y) * ntx + tile_x;
+  if (!overlaps(rc, px0, py0, kSubW, kSubH)) {   // nothing of the cube projects here: zeros, and no record anyone reads
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (vec_ok) {
+      if (tid < kSubW * kSubH / 4) {
+        const int row = py0 + tid / (kSubW / 4), col = px0 + (tid % (kSubW / 4)) * 4;
+        if (row < H && col < W) __builtin_nontemporal_store(zero4, reinterpret_cast<f32x4*>(img + (size_t)row * W + col));
+      }
+    } else {
+      const int row = py0 + tid / kSubW, col = px0 + tid % kSubW;
+      if (row < H && col < W) img[(size_t)row * W + col] = 0.0f;
+    }
+    return;
+  }
+  const int Rr = RT > 0 ? RT : R;
+  const float* vol = sdf + (size_t)b * sdf_view_stride;
+  const __amdgpu_buffer_rsrc_t vsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vol), 0, (int)((unsigned)Rr * Rr * Rr * 4u), 0x00020000);
+  RegPixel rp;
+  rp.col = px0 + PF::ox(wave) + PF::x(lane);
+  rp.row = py0 + PF::oy(wave) + PF::y(lane);
+  rp.tile_loss = tile_loss + tile * kLossRec;
+  rp.view_cnt = view_cnt + b;
+  const bool inside = (rp.col < W) && (rp.row < H);
+  // the march: forward_tile's (plain grid, full cube), one pixel per lane
+  if (overlaps(rc, px0 + PF::ox(wave), py0 + PF::oy(wave), PF::W, PF::H)) {
+    const Ray r = ray_setup<false>(s, rp.row, rp.col, inside, cx, cy, rfx, rfy);
+    if (r.go) {
+      const f32x2 dgxy = {r.dg[0], r.dg[1]}, ogxy = {s.og[0], s.og[1]};
+      float t = r.t;
+      bool hit;
+      int n = 0;
+      for (;;) {
+        ++n;
+        const f32x2 t2 = {t, t};
+        const float value = march_sample<RT, false>(vsrc, R, __builtin_elementwise_fma(t2, dgxy, ogxy),
+                                                    fmaf(t, r.dg[2], s.og[2]));
+        const float dist = value * s.scale;
+        hit = dist < threshold * t;
+        if (hit) break;
+        const float tn = t + dist;
+        if (!(tn < r.tf) || n >= SDFR_MAX_MARCH_STEPS) break;
+        t = tn;
+      }
+      rp.z = hit ? t * r.inv_len : 0.0f;
+      if (rp.z > 0.0f) {
+        const float o = target[(size_t)b * H * W + rp.row * W + rp.col];
+        if (o > 0.0f) {
+          rp.l_sum = fabsf(rp.z - o);
+          rp.l_cnt = 1.0f;
+          rp.sign = (rp.z > o) ? 1.0f : ((rp.z < o) ? -1.0f : 0.0f);
+        }
+      }
+    }
+  }
+  if (inside) img[rp.row * W + rp.col] = rp.z;
+  backward_tile<RT, 1, 1, SmallHash, true, false, true, SDFG>(
+      *reinterpret_cast<BackwardLds<SmallHash>*>(raw), tile_x, tile_y, tile, b, LossArgs{}, nullptr, nullptr, sdf, R,
+      sdf_view_stride, &s, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_depth, 0, partials, rp);
 }
 
 // deterministic mode: the 64-bit fixed-point volume -> float (one rounding per voxel)
@@ -1997,4 +2140,72 @@ extern "C" int sdfr_render_step_backward_l1_pc(
                              sdf, R, sdf_view_stride, pos, quat, inv_scale, B, W, H, cx, cy, fx, fy, sdf_grad_mode, g_sdf,
                              g_sdf_view_stride, workspace, workspace_bytes, pc_weight, points, offsets, max_view_points,
                              scale, pc_workspace, pc_workspace_bytes, device, stream, loss, loss_stats_out);
+}
+
+extern "C" size_t sdfr_render_fused_view_count_offset(int B, int H) { return scratch_offset(B, H); }
+extern "C" size_t sdfr_render_fused_tile_loss_offset(int R, int B, int W, int H) {
+  return (R < 2 || B <= 0) ? 0 : step_loss_offset(R, B, W, H);
+}
+
+extern "C" int sdfr_render_step_fused_l1_pc(
+    const float* sdf, int R, long long sdf_view_stride, const float* pos, const float* quat, const float* inv_scale,
+    const float* scale, int B, int W, int H, float cx, float cy, float fx, float fy, float threshold,
+    const float* target, float* depth, int sdf_grad_mode, float* g_sdf, void* workspace, size_t workspace_bytes,
+    float pc_weight, const float* points, const int* offsets, int max_view_points, void* pc_workspace,
+    size_t pc_workspace_bytes, int device, void* stream) {
+  const char* fn = "sdfr_render_step_fused_l1_pc";
+  if (int rc = check_common(R, B, W, H, fx, fy)) return rc;
+  if (B <= 0 || B > kInlineSetupMaxViews || W <= 0 || H <= 0 || max_view_points <= 0)
+    return fail(SDFR_E_INVALID, "%s: 1 .. %d views of a non-empty image with observed points (B=%d W=%d H=%d points=%d)",
+                fn, kInlineSetupMaxViews, B, W, H, max_view_points);
+  if (g_sdf && B != 1)   // (one unscaled volume, one count: a second view's k would need a volume of its own)
+    return fail(SDFR_E_INVALID, "%s: d/dSDF (g_sdf) goes with ONE view, got %d", fn, B);
+  if (fixed_bytes(R) == 0 || cells_bytes(R) == 0)   // (the workspace regions the unscaled volume and the counts live in)
+    return fail(SDFR_E_INVALID, "%s: grids up to R = %d", fn, std::min(kDetMaxR, kPackedMaxR));
+  if (sdf_grad_mode != SDFR_SDF_GRAD_EXACT && sdf_grad_mode != SDFR_SDF_GRAD_CUDA_COMPAT)
+    return fail(SDFR_E_INVALID, "%s: sdf_grad_mode %d (the weights only: no flags in the one-launch form)", fn,
+                sdf_grad_mode);
+  if (sdf_view_stride != 0 && sdf_view_stride < (long long)R * R * R)
+    return fail(SDFR_E_INVALID, "sdf_view_stride must be 0 or >= R^3");
+  if (!sdf || !pos || !quat || !inv_scale || !scale || !target || !depth || !workspace || !points || !pc_workspace)
+    return fail(SDFR_E_NULL, "%s: NULL pointer argument", fn);
+  if (!offsets && B > 1) return fail(SDFR_E_NULL, "offsets may be NULL only for a single view");
+  if (workspace_bytes < sdfr_render_step_workspace_bytes(R, B, W, H))
+    return fail(SDFR_E_WORKSPACE, "%s: workspace %zu < %zu bytes", fn, workspace_bytes,
+                sdfr_render_step_workspace_bytes(R, B, W, H));
+  if ((uintptr_t)workspace % alignof(ViewSetup))
+    return fail(SDFR_E_INVALID, "workspace must be %zu-byte aligned", alignof(ViewSetup));
+  if (pc_workspace_bytes < sdfr_pc_loss_backward_workspace_bytes(B, max_view_points))
+    return fail(SDFR_E_WORKSPACE, "%s: sampler workspace %zu < %zu bytes", fn, pc_workspace_bytes,
+                sdfr_pc_loss_backward_workspace_bytes(B, max_view_points));
+  if ((uintptr_t)pc_workspace % 16) return fail(SDFR_E_INVALID, "sampler workspace must be 16-byte aligned");
+  SDFR_HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  char* w = (char*)workspace;
+  ViewSetup* setup = (ViewSetup*)w;
+  float* partials = (float*)(w + step_partials_offset(R, B, H));
+  float* g_depth = (float*)((char*)partials + partials_bytes(B, W, H));   // (the deterministic mode's volume: not in use here)
+  float* tile_loss = (float*)(w + step_loss_offset(R, B, W, H));
+  float* view_cnt = (float*)(w + scratch_offset(B, H));                   // (the face records' place: the plain grid is marched)
+  const int nblk = (max_view_points + kSamplerPts - 1) / kSamplerPts;
+  float* pc_part = (float*)pc_workspace;
+  const int groups = std::min(nblk, std::max(kSamplerMinGroups, (kSamplerGridTarget + B - 1) / B));
+  // (pose only: the sampler's blocks still need a volume to add into -- the depth term's, which nobody reads then)
+  const PcBackwardArgs pa{nullptr, points, offsets, max_view_points, pos, quat, scale, sdf, R, sdf_view_stride,
+                          g_sdf ? g_sdf : g_depth, 0, pc_part, nblk, pc_weight, pc_part + (size_t)B * nblk * 8, groups};
+  const int ntx = kSmallTile.nx(W), nty = kSmallTile.ny(H);
+  const int pc_rows = (groups + ntx - 1) / ntx;
+  const dim3 grid((unsigned)ntx, (unsigned)(nty + pc_rows), (unsigned)B);
+  const float rfx = (float)(1.0 / (double)fx), rfy = (float)(1.0 / (double)fy);
+  const int vec_ok = (W % 4 == 0) && ((uintptr_t)depth % 16 == 0);
+  const InlineSetup in{pos, quat, inv_scale, fx, fy, setup, nullptr, 0};
+#define SDFR_LAUNCH_FUSED(RT, SDFG)                                                                              \
+  hipLaunchKernelGGL((render_fused_l1_pc_kernel<RT, SDFG>), grid, dim3(kBlock), 0, st, sdf, R, sdf_view_stride, W, H,  \
+                     ntx, nty, cx, cy, rfx, rfy, threshold, vec_ok, depth, target, in, sdf_grad_mode, g_depth,  \
+                     partials, tile_loss, view_cnt, pc_rows, pa)
+  if (R == 64) { if (g_sdf) SDFR_LAUNCH_FUSED(64, true); else SDFR_LAUNCH_FUSED(64, false); }
+  else { if (g_sdf) SDFR_LAUNCH_FUSED(0, true); else SDFR_LAUNCH_FUSED(0, false); }
+#undef SDFR_LAUNCH_FUSED
+  SDFR_HIP_TRY(hipGetLastError());
+  return 0;
 }

@@ -98,7 +98,11 @@ struct PcBackwardLds {
 // with the CAPACITY of the point buffers (sdfr_depth_to_points_resident: room for every pixel, 1 200 blocks per
 // 640x480 view, of which a mug fills ~60).  (Several blocks through ONE table, flushed once, was measured and
 // dropped: the block is a dependent chain and every block added to it costs its full length, profiles/r05_pc_rounds.md.)
-template <int RT, bool L1, bool DET = false>
+// DIRECT: every point's eight contributions go straight to the volume's float atomics -- no table, no block maximum,
+// two barriers less per block: for launches of a few dozen blocks (one view of the captured loop), where what a block
+// costs is the depth of its dependent chain and not the number of atomics it sends.
+// SDFG = false: nobody wants d/dSDF (a loop that does not optimise the shape) -- pose sums and the loss only.
+template <int RT, bool L1, bool DET = false, bool DIRECT = false, bool SDFG = true>
 __device__ __forceinline__ void pc_backward_block(PcBackwardLds& lds, const PcBackwardArgs& a, int bx, int v) {
   SamplerHash& hash = lds.hash;
   float (&wave_part)[kPts / 64][8] = lds.wave_part;
@@ -131,8 +135,8 @@ __device__ __forceinline__ void pc_backward_block(PcBackwardLds& lds, const PcBa
 #pragma unroll 1
   for (int blk = bx; blk * kPts < end - begin; blk += groups) {   // (workgroup-uniform)
     const int i = begin + blk * kPts + tid;
-    if (!DET) hash.clear(tid, kPts);   // (after the previous block's flush: its reads end at the barrier below)
-    if (tid == 0) blk_max_bits = 0;
+    if (!DET && !DIRECT) hash.clear(tid, kPts);   // (after the previous block's flush: its reads end at the barrier below)
+    if (!DIRECT && tid == 0) blk_max_bits = 0;
 
     bool live = false;
     float go = 0.0f, l1_abs = 0.0f;
@@ -153,16 +157,18 @@ __device__ __forceinline__ void pc_backward_block(PcBackwardLds& lds, const PcBa
         go = live ? grad_out[i] : 0.0f;
       }
     }
-    __syncthreads();   // (table cleared, blk_max_bits reset; the previous block's wave_part reads are done)
-    const float gmax = wave_max(fabsf(go));
-    if (lane == 0) atomicMax(&blk_max_bits, __float_as_int(gmax));
-    __syncthreads();
+    if (!DIRECT) {
+      __syncthreads();   // (table cleared, blk_max_bits reset; the previous block's wave_part reads are done)
+      const float gmax = wave_max(fabsf(go));
+      if (lane == 0) atomicMax(&blk_max_bits, __float_as_int(gmax));
+      __syncthreads();
+    }
 
     // the fixed-point scale: from the block's largest |go|
-    const float bound = 2.0f * __int_as_float(blk_max_bits) * fabsf(f.scale);
+    const float bound = DIRECT ? 0.0f : 2.0f * __int_as_float(blk_max_bits) * fabsf(f.scale);
     int e2;
     (void)frexpf(bound, &e2);
-    const bool fixed_ok = (bound > 0.0f) && (bound < 1e30f) && (e2 > -80);
+    const bool fixed_ok = !DIRECT && (bound > 0.0f) && (bound < 1e30f) && (e2 > -80);
     const float to_fixed = fixed_ok ? ldexpf(1.0f, SamplerHash::kBits - e2) : 0.0f;
     const float from_fixed = ldexpf(1.0f, e2 - SamplerHash::kBits);
     const float weight_limit = SamplerHash::kWeightLimit;
@@ -205,7 +211,8 @@ __device__ __forceinline__ void pc_backward_block(PcBackwardLds& lds, const PcBa
       const float w4 = x1w * ay * az, w5 = x1w * ay * c.oz, w6 = x1w * c.oy * az, w7 = x1w * c.oy * c.oz;
       // (a NaN upstream gradient can be dropped by the block's fmaxf-based maximum: such a lane, like
       // any lane beyond the fixed-point range, adds in float, so NaN/Inf reach g_sdf as in autograd)
-      if (DET) {
+      if (!SDFG) {
+      } else if (DET) {
         // (not finite: the conversion saturates, NaN counts as 0 -- include/sdfr.h)
         if (go != 0.0f) {
           unsigned long long* g0 = reinterpret_cast<unsigned long long*>(gvol) + c.lin;
@@ -249,8 +256,8 @@ __device__ __forceinline__ void pc_backward_block(PcBackwardLds& lds, const PcBa
       loss_part[(size_t)v * nblk + blk] = t;
     }
     // (the barrier above orders every table add before the flush's reads)
-    if (!DET) hash.flush(gvol, Rr * Rr * Rr, from_fixed, tid, kPts);
-    __syncthreads();   // the flush's reads before the next block's clear
+    if (!DET && !DIRECT) hash.flush(gvol, Rr * Rr * Rr, from_fixed, tid, kPts);
+    __syncthreads();   // the flush's reads before the next block's clear (DIRECT: wave_part's before its next writes)
   }
 }
 

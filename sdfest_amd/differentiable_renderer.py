@@ -793,6 +793,41 @@ class BatchRenderPlan:
         _lib.check(rc, "sdfr_render_backward_l1")
         return self.g_sdf, self.g_pos, self.g_quat, self.g_inv_scale
 
+    def step_fused_l1_pc(self, sdf, pos, quat, inv_scale, scale, threshold: float, target, points, offsets,
+                         max_view_points: int, pc_workspace, pc_weight: float = 1.0, g_sdf=None):
+        """``forward_l1(prepare_backward=True, defer_loss=True)`` and ``backward_l1_pc`` of at most 3 views as ONE launch
+        (``sdfr_render_step_fused_l1_pc``): a tile runs the backward of its hit pixels while their depths are still
+        in registers.  The view's overlap count is not known inside the launch, so the depth term is left UNSCALED --
+        d/dSDF in a volume of the workspace (``g_depth``), the pose sums in the tile partials -- beside the count
+        (``view_count``); ``g_sdf`` (None: a loop that does not optimise the shape) receives the point-cloud term.
+        Nothing is zero-filled here: the consumer clears what it has read (``sdfr_decoder_backward_latent_deferred_scaled``,
+        ``sdfr_loop_tail_fused``).  Returns the depth images."""
+        self._step = None
+        self._step_l1 = None
+        self._check(sdf, pos, quat, inv_scale, target=target)
+        rc = self._L.sdfr_render_step_fused_l1_pc(
+            sdf.data_ptr(), self.R, self.sdf_stride, pos.data_ptr(), quat.data_ptr(), inv_scale.data_ptr(),
+            scale.data_ptr(), self.B, self.W, self.H, self.cx, self.cy, self.fx, self.fy, threshold, target.data_ptr(),
+            self.depth.data_ptr(), self.sdf_grad_mode, g_sdf.data_ptr() if g_sdf is not None else None,
+            self.workspace.data_ptr(), self.workspace.numel(), pc_weight, points.data_ptr(),
+            offsets.data_ptr() if offsets is not None else None, max_view_points, pc_workspace.data_ptr(),
+            pc_workspace.numel(), self.device.index, _stream(self.device))
+        _lib.check(rc, "sdfr_render_step_fused_l1_pc")
+        self.partials_offset = self._L.sdfr_render_partials_offset(self.R, self.B, self.W, self.H, 1)
+        return self.depth
+
+    @property
+    def g_depth(self) -> torch.Tensor:
+        """the unscaled d/dSDF of the depth term that ``step_fused_l1_pc`` accumulates, (R,R,R) float32 in the workspace"""
+        off = self._L.sdfr_render_fixed_volume_offset(self.R, self.B, self.W, self.H, 1)
+        return self.workspace[off:off + self.R ** 3 * 4].view(torch.float32).view(self.R, self.R, self.R)
+
+    @property
+    def view_count(self) -> torch.Tensor:
+        """the views' overlap counts that ``step_fused_l1_pc`` adds up, (B,) float32 in the workspace"""
+        off = self._L.sdfr_render_fused_view_count_offset(self.B, self.H)
+        return self.workspace[off:off + 4 * self.B].view(torch.float32)
+
     def backward_l1_pc(self, target, sdf, pos, quat, inv_scale, scale, points, offsets, max_view_points: int,
                        pc_workspace, weight: float = 1.0, pc_weight: float = 1.0, loss_grad=None):
         """``backward_l1`` and the sampler's L1 backward (``sdfr_pc_l1_backward_accumulate``) in one launch

@@ -298,7 +298,8 @@ class FusedRenderAndCompare:
                  point_constraint: Optional[Sequence] = None, track_inliers: Optional[bool] = None,
                  merge_launches: bool = True, graph_iterations: int = 5, process_group=None,
                  exchange: str = "sdf", sdf_grad_mode: int = 0, form: str = "auto", views: Optional[int] = None,
-                 graph_collective: bool = False, defer_loss: Optional[bool] = None):
+                 graph_collective: bool = False, defer_loss: Optional[bool] = None,
+                 fused_render: Optional[bool] = None):
         """depth_images (V,H,W): the first observation (``rebind`` takes the next ones: the reference calls its
         pipeline once per detected object with fresh images, simple_setup.py:213-225, and so re-uses nothing; this
         object keeps every buffer and every captured graph across observations of the same V, W, H).  None with
@@ -334,6 +335,12 @@ class FusedRenderAndCompare:
         the collective issued between them.  c10d's NCCL backend is capturable; whether RCCL's kernels replay on this
         platform is what ``self.graph_collective_error`` says afterwards (None: captured; a string: why not -- the loop
         then runs the two-graph form).  An experiment, off by default.
+        fused_render: the render pair of an iteration as ONE launch (``sdfr_render_step_fused_l1_pc``: a tile runs the
+        backward of its hit pixels right behind their march; include/sdfr.h) -- for the tail form over ONE view (the
+        reference's own use: one call per detected object; up to 3 views when the shape is not optimised -- every view's
+        depth term has its own weight / count, and one unscaled d/dSDF volume serves one) of a grid up to 128^3, loss-fused,
+        with plain ``sdf_grad_mode`` weights; default: wherever that holds (C5: 0.110 -> 0.097 ms per iteration).  Depth images bit for bit the two launches'; gradients equal up to rounding (the view's
+        weight / count multiplies sums instead of terms), so the trajectory is the two-launch form's to ~1e-6.
         graph_iterations: iterations per replayed hipGraph (a graph launch costs ~5-8 us between iterations; the
         remainder of max_iterations and runs with ``history`` replay the one-iteration graph).
         merge_launches: the per-view reductions of both backward passes run inside the gradient chain's launch
@@ -482,6 +489,16 @@ class FusedRenderAndCompare:
                                       self.L.sdfr_decoder_backward_workspace_bytes(decoder._h, 1), 256), **u8)
         self.ws_loss = torch.empty(max(self.L.sdfr_depth_l1_workspace_bytes(V, W, H), 256), **u8)
         self.ws_pc = torch.empty(max(self.L.sdfr_pc_loss_backward_workspace_bytes(V, self.max_pts), 256), **u8)
+        can_fuse = (self.merge_tail and not self.records_form and self.fuse_depth_loss and R <= 128
+                    and V <= (1 if self.shape_opt else 3)
+                    and self.max_pts > 0 and self.sdf_grad_mode in (0, 1) and 8 + self.Lz <= 256)
+        if fused_render and not can_fuse:
+            raise ValueError("fused_render needs the tail form over ONE view (up to 3 without shape optimisation) of a "
+                             "grid up to 128^3, the loss-fused kernels and sdf_grad_mode 0 / 1")
+        self.fused_render = can_fuse if fused_render is None else bool(fused_render)
+        if self.fused_render:
+            # what the one-launch step ADDS into must start from zero (its consumers clear what they have read)
+            self.plan._g_sdf_ring[0].zero_()
         self.strategy = _selection_strategy(config)
         self.track_inliers = (self.strategy == "best_inlier_ratio") if track_inliers is None else bool(track_inliers)
         self.rel_thr = float(config.get("relative_inlier_threshold", 0.03))
@@ -601,6 +618,8 @@ class FusedRenderAndCompare:
             # [decoder] -> render pair as a step -> [decoder VJP] -> sdfr_loop_tail; the camera-frame poses of THIS
             # iteration were left by the previous tail (or by _poses_to_views before the first one)
             # (the depth loss values are reduced inside the backward's launch: no launch between the image kernels)
+            if self.fused_render:
+                return self._iteration_one_launch(L, d, st, p, g, sdf)
             self.plan.forward_l1(sdf, self.pos_c, self.quat_c, self.inv_scale, self.cfg["threshold"], self.target,
                                  prepare_backward=True, defer_loss=self.defer_loss)
             self.loss_depth = self.plan.loss
@@ -716,6 +735,39 @@ class FusedRenderAndCompare:
         self.check(L.sdfr_adam_step(p, g, self.m.data_ptr(), self.v.data_ptr(), self.step.data_ptr(),
                                     8 + self.Lz, 1e-3, 1e-2, 1e-3, 1e-2, int(self.shape_opt), d, st),
                    "sdfr_adam_step")
+        self._inliers(L, p, d, st)
+
+    def _iteration_one_launch(self, L, d, st, p, g, sdf):
+        """The tail form with the render pair as ONE launch (``fused_render``): [decoder] -> render forward + backward +
+        the sampler's blocks (``sdfr_render_step_fused_l1_pc``; the depth term's sums come out unscaled, beside the view's
+        overlap count) -> [decoder VJP on  point-cloud volume + k depth volume, which it clears afterwards] -> the tail
+        (multiplies the pose sums by k, writes the depth loss, resets the count)."""
+        plan = self.plan
+        g_pc = plan._g_sdf_ring[0] if self.shape_opt else None
+        plan.step_fused_l1_pc(sdf, self.pos_c, self.quat_c, self.inv_scale, self.scale_v, self.cfg["threshold"],
+                              self.target, self.points, self.offsets, self.max_pts, self.ws_pc,
+                              pc_weight=self.cfg["pc_weight"], g_sdf=g_pc)
+        self.loss_depth = plan.loss
+        ws = plan.workspace.data_ptr()
+        cnt_off = L.sdfr_render_fused_view_count_offset(self.V, self.H)
+        t_mid = None
+        if self.shape_opt:
+            t_mid = ctypes.c_void_p()
+            self.check(L.sdfr_decoder_backward_latent_deferred_scaled(
+                self.dec._h, self.latent.data_ptr(), self.tape.data_ptr(), g_pc.data_ptr(), plan.g_depth.data_ptr(),
+                ws + cnt_off, self.cfg["depth_weight"], self.ws_dec.data_ptr(), self.ws_dec.numel(), st,
+                ctypes.byref(t_mid)), "sdfr_decoder_backward_latent_deferred_scaled")
+        con = self.pc_source is not None
+        self.check(L.sdfr_loop_tail_fused(
+            p, g, self.m.data_ptr(), self.v.data_ptr(), self.step.data_ptr(), 8 + self.Lz, 1e-3, 1e-2, 1e-3, 1e-2,
+            int(self.shape_opt), self.cam_pos.data_ptr(), self.cam_quat.data_ptr(), self.V, ws, plan.partials_offset,
+            cnt_off, L.sdfr_render_fused_tile_loss_offset(self.R, self.V, self.W, self.H), self.cfg["depth_weight"],
+            plan.loss.data_ptr(), self.W, self.H, self.ws_pc.data_ptr(), self.offsets.data_ptr(), self.max_pts,
+            self.pos_c.data_ptr(), self.quat_c.data_ptr(), self.inv_scale.data_ptr(), self.scale_v.data_ptr(),
+            self.loss_pc.data_ptr(), self.pc_source.data_ptr() if con else None,
+            self.pc_target.data_ptr() if con else None, self.pc_weight if con else 0.0,
+            self.loss_con.data_ptr() if con else None, self.dec._h if t_mid is not None else None, t_mid, d, st),
+            "sdfr_loop_tail_fused")
         self._inliers(L, p, d, st)
 
     # ---- the records form: head | exchange | tail (the loop sharded over ranks) -----------------------------------

@@ -1,0 +1,189 @@
+"""GPU: the render pair of a loop iteration as ONE launch (sdfr_render_step_fused_l1_pc -> sdfr_decoder_backward_latent_
+deferred_scaled -> sdfr_loop_tail_fused; FusedRenderAndCompare(fused_render=True), the default for one view -- up to 3
+when the shape is not optimised: every view's depth term has its own weight / count --) against
+the two launches it replaces (sdfr_render_step_forward_l1 + sdfr_render_step_backward_l1_pc), which the G7 goldens and
+the oracle pin (tests/test_loop_g7_gpu.py, tests/test_render_l1_gpu.py).
+
+What differs between the forms is WHERE the depth loss's  weight / count  is applied -- to every pixel's term before the
+sums (two launches), to the sums (one launch: no tile knows the count before the launch ends) -- so:
+  * depth images, overlap counts, loss values' inputs: bit for bit;
+  * d loss / d (pose, scale, latent) before Adam: equal up to float rounding of the sums (1e-5 of each group's largest
+    component is asserted; 1e-6 is typical);
+  * trajectories: the same to a small multiple of that per iteration.
+The reference's arithmetic for this path: simple_setup.py:408-462 (iteration), :129-135 (masked depth L1), :144 (point
+L1), sdf_renderer_cuda.cu:300-468 (backward)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import _loop_scenes as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(V, iterations, W=None):
+    s = S.build("seven", iterations=iterations)
+    return dict(s, depth=s["depth"][:V].contiguous(), cam_pos=s["cam_pos"][:V].contiguous(),
+                cam_quat=s["cam_quat"][:V].contiguous())
+
+
+def _loop(s, fused, **kw):
+    from sdfest_amd.pipeline import FusedRenderAndCompare
+    return FusedRenderAndCompare(s["decoder"], s["camera"], s["config"], s["depth"], s["cam_pos"], s["cam_quat"],
+                                 fused_render=fused, form="tail", **kw)
+
+
+def _group_scale(g):
+    return np.array([np.abs(g[0:3]).max()] * 3 + [np.abs(g[3:7]).max()] * 4 + [abs(g[7])]
+                    + ([np.abs(g[8:]).max()] * (len(g) - 8) if len(g) > 8 else []))
+
+
+@pytest.mark.parametrize("views,shape", [(1, True), (1, False), (2, False), (3, False)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_first_gradient_equals_the_two_launch_form(views, shape, mode):
+    """one eager iteration: the gradient vector Adam is given, the depth images, both loss values"""
+    s = _scene(views, 1)
+    got = {}
+    for fused in (False, True):
+        loop = _loop(s, fused, sdf_grad_mode=mode, shape_optimization=shape)
+        assert loop.fused_render == fused
+        loop(*s["init"], use_graph=False)
+        torch.cuda.synchronize()
+        ld, lp = loop.view_losses()
+        got[fused] = (loop.grads.cpu().numpy().astype(np.float64), loop.plan.depth.clone(), ld.cpu().numpy(),
+                      lp.cpu().numpy())
+        if fused:
+            # the consumers cleared what they read: the next step adds into zeros
+            assert float(loop.plan.view_count.abs().max()) == 0.0
+            assert float(loop.plan.g_depth.abs().max()) == 0.0
+            assert float(loop.plan._g_sdf_ring[0].abs().max()) == 0.0
+    assert torch.equal(got[True][1], got[False][1]), "depth images differ"
+    g0, g1 = got[False][0], got[True][0]
+    assert np.all(np.isfinite(g1)) and (np.abs(g0[8:]).max() > 0) == shape
+    if not shape:
+        g0, g1 = g0[:8], g1[:8]
+    err = np.abs(g1 - g0) / _group_scale(g0)
+    assert err.max() < 1e-5, err
+    np.testing.assert_allclose(got[True][2], got[False][2], rtol=2e-6)    # depth loss: another order of the tile sums
+    np.testing.assert_array_equal(got[True][3], got[False][3])           # point loss: the same blocks, the same order
+
+
+@pytest.mark.parametrize("views,shape", [(1, True), (1, False), (2, False), (3, False)])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_trajectory_follows_the_two_launch_form(views, shape, use_graph):
+    s = _scene(views, 12)
+    hist = {}
+    for fused in (False, True):
+        loop = _loop(s, fused, shape_optimization=shape, graph_iterations=5)
+        h = []
+        loop(*s["init"], use_graph=use_graph, history=h)
+        torch.cuda.synchronize()
+        hist[fused] = S.history_array(h)
+        # ... and a second run on the same object starts from clean sums
+        h2 = []
+        loop(*s["init"], use_graph=use_graph, history=h2)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(S.history_array(h2), hist[fused], atol=2e-5 if shape else 0.0, rtol=0)
+    d = np.abs(hist[True] - hist[False])
+    # Adam's steps are +-lr at first whatever the gradient's size: a rounding-level difference of a gradient stays one
+    assert d[:, :8].max() < 5e-6 and d[:, 8:].max() < 2e-4, (d[:, :8].max(), d[:, 8:].max())
+    assert np.abs(hist[True][-1] - hist[True][0]).max() > 1e-3      # (something was optimised)
+
+
+def test_pose_only_run_is_reproducible_bit_for_bit():
+    """no float atomic on the way to the pose: tile sums in a fixed order, the count a sum of integers"""
+    s = _scene(2, 8)
+    runs = []
+    for _ in range(2):
+        loop = _loop(s, True, shape_optimization=False)
+        h = []
+        loop(*s["init"], use_graph=True, history=h)
+        torch.cuda.synchronize()
+        runs.append(S.history_array(h))
+    assert np.array_equal(runs[0], runs[1])
+
+
+def test_decoder_whose_first_vjp_launch_is_not_the_fused_stage():
+    """the scaled VJP on a decoder handle with the fused stages switched off: the two volumes are summed by a launch of
+    their own (scaled_combine_kernel) -- same numbers as the stage that adds them on load, to rounding"""
+    s = _scene(1, 1)
+    got = {}
+    for bits in (5, 0):
+        s["decoder"].set_option("fused_single", bits)
+        try:
+            loop = _loop(s, True)
+            loop(*s["init"], use_graph=False)
+            torch.cuda.synchronize()
+            got[bits] = loop.grads.cpu().numpy().astype(np.float64)
+            assert float(loop.plan.g_depth.abs().max()) == 0.0 and float(loop.plan._g_sdf_ring[0].abs().max()) == 0.0
+        finally:
+            s["decoder"].set_option("fused_single", 5)
+    err = np.abs(got[0] - got[5]) / _group_scale(got[5])
+    assert err.max() < 1e-5, err
+
+
+def test_an_object_out_of_sight_contributes_nothing():
+    """no pixel overlaps: count 0 -> k = 0, the depth loss the reference's mean over nothing (NaN), no depth gradient"""
+    s = _scene(1, 1)
+    p0, q0, s0, z0 = s["init"]
+    away = p0.clone()
+    away[0, 0] += 5.0
+    out = {}
+    for fused in (False, True):
+        loop = _loop(s, fused)
+        loop(away, q0, s0, z0, use_graph=False)
+        torch.cuda.synchronize()
+        out[fused] = (loop.grads.cpu().numpy(), loop.view_losses()[0].cpu().numpy())
+    assert np.isnan(out[True][1]).all() and np.isnan(out[False][1]).all()
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-5, atol=1e-9)
+
+
+def test_which_loops_take_the_one_launch_form():
+    from sdfest_amd.differentiable_renderer import BWD_SMALL_TILES, SDF_GRAD_DETERMINISTIC
+    s4 = _scene(4, 1)
+    assert _loop(_scene(1, 1), None).fused_render and not _loop(_scene(2, 1), None).fused_render
+    assert _loop(_scene(3, 1), None, shape_optimization=False).fused_render
+    assert not _loop(s4, None, shape_optimization=False).fused_render
+    with pytest.raises(ValueError, match="fused_render"):
+        _loop(s4, True, shape_optimization=False)
+    with pytest.raises(ValueError, match="fused_render"):
+        _loop(_scene(2, 1), True)
+    s = _scene(2, 1)
+    from sdfest_amd.pipeline import FusedRenderAndCompare
+    det = FusedRenderAndCompare(s["decoder"], s["camera"], s["config"], s["depth"], s["cam_pos"], s["cam_quat"],
+                                shape_optimization=False, sdf_grad_mode=SDF_GRAD_DETERMINISTIC | BWD_SMALL_TILES)
+    assert not det.fused_render          # (the records form)
+    with pytest.raises(ValueError, match="fused_render"):
+        FusedRenderAndCompare(s["decoder"], s["camera"], s["config"], s["depth"], s["cam_pos"], s["cam_quat"],
+                              shape_optimization=False, fuse_depth_loss=False, fused_render=True)
+
+
+def test_c_abi_argument_errors():
+    from sdfest_amd import _lib
+    L = _lib.lib()
+    s = _scene(1, 1)
+    loop = _loop(s, True)
+    plan = loop.plan
+    sdf = loop.sdf[0, 0]
+
+    def call(B=1, mode=0, R=64, pts=loop.max_pts, ws_bytes=None):
+        return L.sdfr_render_step_fused_l1_pc(
+            sdf.data_ptr(), R, 0, loop.pos_c.data_ptr(), loop.quat_c.data_ptr(), loop.inv_scale.data_ptr(),
+            loop.scale_v.data_ptr(), B, plan.W, plan.H, plan.cx, plan.cy, plan.fx, plan.fy, 0.005, loop.target.data_ptr(),
+            plan.depth.data_ptr(), mode, None, plan.workspace.data_ptr(),
+            plan.workspace.numel() if ws_bytes is None else ws_bytes, 3.0, loop.points.data_ptr(),
+            loop.offsets.data_ptr(), pts, loop.ws_pc.data_ptr(), loop.ws_pc.numel(), 0, None)
+
+    inv, wsp = -1, -3      # SDFR_E_INVALID, SDFR_E_WORKSPACE (include/sdfr.h)
+    assert call(B=4) == inv and b"views" in L.sdfr_last_error()
+    assert call(mode=0x100) == inv and b"sdf_grad_mode" in L.sdfr_last_error()
+    assert call(R=256) == inv
+    assert call(pts=0) == inv
+    assert call(ws_bytes=1024) == wsp
+    t_mid = ctypes.c_void_p()
+    rc = L.sdfr_decoder_backward_latent_deferred_scaled(
+        s["decoder"]._h, loop.latent.data_ptr(), loop.tape.data_ptr(), plan._g_sdf_ring[0].data_ptr(), None,
+        plan.view_count.data_ptr(), 1.0, loop.ws_dec.data_ptr(), loop.ws_dec.numel(), None, ctypes.byref(t_mid))
+    assert rc != 0 and b"NULL" in L.sdfr_last_error()
