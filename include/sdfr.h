@@ -59,7 +59,7 @@
  *   3. [unstable] LOOP: one render-and-compare iteration (SDFPipeline.__call__) as a fixed launch sequence
  *        sdfr_preprocess_depth, sdfr_depth_to_points_resident, sdfr_depth_count[_ordered|_centroid],
  *        sdfr_depth_to_points[_ordered|_shifted], sdfr_depth_points_workspace_bytes, sdfr_depth_centroid_workspace_bytes
- *        sdfr_pose_to_views[_objects], sdfr_views_to_pose_grad[_deferred], sdfr_decoder_backward_latent_deferred[_batch|_scaled],
+ *        sdfr_pose_to_views[_objects], sdfr_views_to_pose_grad[_deferred], sdfr_decoder_backward_latent_deferred[_batch|_scaled], sdfr_decoder_forward_stage,
  *        sdfr_loop_tail, sdfr_loop_tail_fused, sdfr_loop_tail_objects, sdfr_adam_step, sdfr_point_constraint, sdfr_add_inplace
  *        sdfr_depth_l1_loss[_workspace_bytes], sdfr_pc_l1_loss, sdfr_inlier_ratio, sdfr_nn_loss_forward / _backward
  *        sharded over ranks: sdfr_loop_view_records, sdfr_loop_tail_records, sdfr_inlier_counts_record,
@@ -446,6 +446,14 @@ SDFR_API int sdfr_decoder_backward_latent(const sdfr_decoder* decoder, const flo
 SDFR_API int sdfr_decoder_backward_latent_deferred(const sdfr_decoder* decoder, const float* z, const float* tape,
                                           const float* grad_out, void* workspace, size_t workspace_bytes,
                                           void* stream, const float** t_mid);
+/* sdfr_decoder_forward in two halves that meet in the tape (tape != NULL): stages = 1 the Linear stack only (z -> the
+ * wide layer's output, in the tape's slot; out may be NULL), 2 the convolutional part from that slot (z is not read),
+ * 3 both = sdfr_decoder_forward.  For the captured loop, whose tail launch leaves the NEXT iteration's Linear-stack
+ * output in the tape (sdfr_loop_tail_fused, decoder_tape): its decode is then stage 2 alone, stage 1 runs once in
+ * front of the first iteration.  Same kernels, same numbers. */
+SDFR_API int sdfr_decoder_forward_stage(const sdfr_decoder* decoder, const float* z, int N, int enforce_tsdf,
+                               float* out, float* tape, void* workspace, size_t workspace_bytes,
+                               void* stream, int stages);
 /* sdfr_decoder_backward_latent_deferred for an incoming gradient in TWO volumes, one of them not yet normalised:
  *     grad = grad_out + k * grad_scaled,   k = count[0] > 0 ? weight / count[0] : 0     (count: a device float)
  * -- what sdfr_render_step_fused_l1_pc leaves: the point-cloud term, and the depth term before its division by the
@@ -527,7 +535,15 @@ SDFR_API int sdfr_loop_tail_fused(float* params, float* grads, float* exp_avg, f
                          const int* offsets, int max_view_points, float* pos_c, float* quat_c, float* inv_scale,
                          float* scale_v, float* pc_loss, const float* con_source, const float* con_target,
                          float con_weight, float* con_loss, const sdfr_decoder* decoder, const float* decoder_t_mid,
-                         int device, void* stream);
+                         float* decoder_tape, unsigned* arrivals, int device, void* stream);
+/* decoder_tape / arrivals (both or neither; with decoder, update_latent and a Linear stack whose leading layers are
+ * at most 64 wide): the launch ALSO runs the decoder's Linear stack for the parameters it has just updated and leaves
+ * the wide layer's output in the tape's slot -- the next iteration's decode is sdfr_decoder_forward_stage(stages = 2),
+ * one launch less per iteration.  The launch then has one workgroup per 256 outputs of the wide layer: every one
+ * repeats the latent's share of the tail (its gradient, its Adam step -- same inputs, same arithmetic, same numbers;
+ * nothing is handed from workgroup to workgroup) and forms its slice; workgroup 0 is the tail proper and stores the
+ * state.  arrivals: one device word, zero before a run's first iteration -- the other workgroups count themselves in
+ * once they have read the state, workgroup 0 stores the new state only when all have (a bounded wait). */
 
 /* sdfr_loop_tail for SEVERAL estimates at once -- the K detected objects of one frame, each with its own pose, scale,
  * latent and Adam state, optimised side by side in one launch sequence (the reference runs its pipeline once per object,

@@ -40,7 +40,7 @@ SIGNATURES = {
     "sdfr_render_fused_tile_loss_offset": (c_sz, [c_int, c_int, c_int, c_int]),
     "sdfr_loop_tail_fused": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_f, c_f, c_f, c_f, c_int, c_fp, c_fp, c_int,
                                      c_fp, c_sz, c_sz, c_sz, c_f, c_fp, c_int, c_int, c_fp, c_fp, c_int, c_fp, c_fp, c_fp,
-                                     c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_int, c_fp]),
+                                     c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp]),
     "sdfr_render_step_backward_l1": (c_int, [c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_int, c_ll, c_int, c_int, c_int,
                                              c_f, c_f, c_f, c_f, c_int, c_fp, c_ll, c_fp, c_fp, c_fp, c_fp, c_sz,
                                              c_fp, c_fp, c_int, c_fp]),
@@ -98,6 +98,7 @@ SIGNATURES = {
     "sdfr_decoder_workspace_bytes": (c_sz, [c_fp, c_int]),
     "sdfr_decoder_tape_bytes": (c_sz, [c_fp, c_int]),
     "sdfr_decoder_forward": (c_int, [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_sz, c_fp]),
+    "sdfr_decoder_forward_stage": (c_int, [c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_sz, c_fp, c_int]),
     "sdfr_decoder_backward_workspace_bytes": (c_sz, [c_fp, c_int]),
     "sdfr_decoder_backward_latent": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_sz, c_fp]),
     "sdfr_decoder_backward_latent_deferred": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_fp, c_fp]),

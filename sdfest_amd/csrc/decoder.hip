@@ -1729,8 +1729,9 @@ __global__ __launch_bounds__(64) void fc_stack_backward_wave_kernel(const float*
                                                                     const float* __restrict__ z,
                                                                     const float* __restrict__ t_in,
                                                                     float* __restrict__ g_z) {
+  __shared__ FcWaveLds fc_lds;
   const int n = blockIdx.x, l = d.n_fc - 1;
-  fc_stack_backward_one_wave(params, d, z + (size_t)n * d.width[0], t_in + (size_t)n * d.width[l],
+  fc_stack_backward_one_wave(fc_lds, params, d, z + (size_t)n * d.width[0], t_in + (size_t)n * d.width[l],
                              g_z + (size_t)n * d.width[0], threadIdx.x);
 }
 
@@ -2459,13 +2460,18 @@ extern "C" size_t sdfr_decoder_tape_bytes(const sdfr_decoder* d, int N) {
   return (size_t)N * d->tape_floats * sizeof(float);
 }
 
-extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N, int enforce_tsdf,
-                                    float* out, float* tape, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
+namespace {
+// stages: 1 the Linear stack only (its output into the tape's slot), 2 the convolutional part from that slot, 3 both
+int decoder_forward_impl(const sdfr_decoder* d, const float* z, int N, int enforce_tsdf,
+                         float* out, float* tape, void* workspace,
+                         size_t workspace_bytes, void* stream, int stages) {
   if (!d) return fail(SDFR_E_NULL, "sdfr_decoder_forward: NULL decoder");
   if (N < 0 || N > 65535) return fail(SDFR_E_INVALID, "N=%d out of range", N);
+  if (stages < 1 || stages > 3) return fail(SDFR_E_INVALID, "sdfr_decoder_forward_stage: stages=%d", stages);
   if (N == 0) return 0;
-  if (!z || !out || !workspace) return fail(SDFR_E_NULL, "sdfr_decoder_forward: NULL pointer argument");
+  if (stages != 3 && !tape) return fail(SDFR_E_NULL, "sdfr_decoder_forward_stage: the stages meet in the tape");
+  if (((stages & 1) && !z) || ((stages & 2) && !out) || !workspace)
+    return fail(SDFR_E_NULL, "sdfr_decoder_forward: NULL pointer argument");
   if (workspace_bytes < sdfr_decoder_workspace_bytes(d, N))
     return fail(SDFR_E_WORKSPACE, "sdfr_decoder_forward: workspace %zu < %zu bytes", workspace_bytes,
                 sdfr_decoder_workspace_bytes(d, N));
@@ -2489,7 +2495,11 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
   int l_first = 0;   // the first conv layer the loop below still has to run
   // few latents: the Linear stack and the first convolution as one launch (fc_conv_kernel) -- a 3x3x3 layer that is not
   // the last, with a layer behind it that is not a 1x1x1 one swapped with its resize
-  if (d->n_conv >= 2 && !d->conv_swap[0] && d->conv_k[0] == 3 && !(d->conv_swap[1] && d->conv_k[1] == 1) &&
+  if (stages == 2) {
+    act_in = tape + (size_t)N * d->tape_fc_off;   // (left there by stage 1 -- or by the loop's tail, sdfr_loop_tail_fused)
+    l_first = -1;
+  }
+  if (stages == 3 && d->n_conv >= 2 && !d->conv_swap[0] && d->conv_k[0] == 3 && !(d->conv_swap[1] && d->conv_k[1] == 1) &&
       N < 32 && d->conv_in_size[0] - 2 != d->volume) {
     float* fc_dst = tape ? tape + (size_t)N * d->tape_fc_off : nullptr;
     float* dst0 = tape ? tape + (size_t)N * d->tape_conv_off[0] : buf[cur ^ 1];
@@ -2521,6 +2531,11 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
       hipLaunchKernelGGL(fc_stack_kernel<false>, dim3((last + kFcBlock - 1) / kFcBlock, N), dim3(kFcBlock), 0, st,
                          d->d_params, fd, z, fc_dst);
     act_in = fc_dst;
+  }
+  if (l_first < 0) l_first = 0;
+  if (stages == 1) {
+    SDFR_HIP_TRY(hipGetLastError());
+    return 0;
   }
 
   const float clampv = (enforce_tsdf && d->tsdf > 0.0f) ? d->tsdf : 0.0f;
@@ -2724,6 +2739,19 @@ extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N
   }
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
+}
+}  // namespace
+
+extern "C" int sdfr_decoder_forward(const sdfr_decoder* d, const float* z, int N, int enforce_tsdf,
+                                    float* out, float* tape, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  return decoder_forward_impl(d, z, N, enforce_tsdf, out, tape, workspace, workspace_bytes, stream, 3);
+}
+
+extern "C" int sdfr_decoder_forward_stage(const sdfr_decoder* d, const float* z, int N, int enforce_tsdf,
+                                          float* out, float* tape, void* workspace,
+                                          size_t workspace_bytes, void* stream, int stages) {
+  return decoder_forward_impl(d, z, N, enforce_tsdf, out, tape, workspace, workspace_bytes, stream, stages);
 }
 
 namespace sdfr {

@@ -119,13 +119,49 @@ __device__ __forceinline__ void wave_stage(float* dst, const float* __restrict__
   }
 }
 
+// The one-wave forms' LDS: the span of the parameter block at its own offsets, the layers' inputs, the gradients.
+struct FcWaveLds {
+  float p[kFcWaveSpan];
+  float a[8][kFcWaveWidth];   // a[l] = input of layer l (a[0] = the latent)
+  float g[2][kFcWaveWidth];
+};
+// The leading layers' forward by one wave out of LDS: a[0] (the latent) -> a[1] .. a[last]; L.p staged (wave_stage).
+// The fmaf chains of fc_stack_kernel / fc_stack_backward_sample: bias first, inputs in ascending order.
+__device__ __forceinline__ void fc_narrow_forward_one_wave(FcWaveLds& L, const FcDesc& d, int lane) {
+  const int last = d.n_fc - 1;
+  const long long base = d.w_off[0];
+  for (int l = 0; l < last; ++l) {
+    const int win = d.width[l], wout = d.width[l + 1];
+    if (lane < wout) {
+      float acc = L.p[d.b_off[l] - base + lane];
+      const float* w = L.p + (d.w_off[l] - base) + lane * win;
+#pragma unroll 8
+      for (int i = 0; i < win; ++i) acc = fmaf(w[i], L.a[l][i], acc);
+      L.a[l + 1][lane] = fmaxf(acc, 0.0f);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+// 256 outputs of the LAST (wide) layer by a workgroup of kFcBlock threads, from its input a_last in LDS (every thread
+// calls it behind a barrier): fc_stack_kernel's expression
+__device__ __forceinline__ void fc_wide_slice(const float* __restrict__ params, const FcDesc& d, const float* a_last,
+                                              int slice, float* __restrict__ out) {
+  const int l = d.n_fc - 1;
+  const int win = d.width[l], wout = d.width[l + 1];
+  const int o = slice * kFcBlock + (int)threadIdx.x;
+  if (o < wout) {
+    const float* wt = params + d.w_off[l];  // transposed: [in][out]
+    float acc = params[d.b_off[l] + o];
+#pragma unroll 16
+    for (int i = 0; i < win; ++i) acc = fmaf(wt[(size_t)i * wout + o], a_last[i], acc);
+    out[o] = fmaxf(acc, 0.0f);
+  }
+}
+
 // Called by the 64 lanes of one wave (lane = 0 .. 63); requires fc_one_wave_ok(d).  Results stored, nothing after.
-__device__ __forceinline__ void fc_stack_backward_one_wave(const float* __restrict__ params, const FcDesc& d,
-                                                           const float* __restrict__ z, const float* __restrict__ t_in,
-                                                           float* g_z, int lane) {
-  __shared__ float p_lds[kFcWaveSpan];       // the span of the parameter block, at its own offsets
-  __shared__ float a_lds[8][kFcWaveWidth];   // a_lds[l] = input of layer l
-  __shared__ float g_lds[2][kFcWaveWidth];
+__device__ __forceinline__ void fc_stack_backward_one_wave(FcWaveLds& L, const float* __restrict__ params,
+                                                           const FcDesc& d, const float* __restrict__ z,
+                                                           const float* __restrict__ t_in, float* g_z, int lane) {
   const int last = d.n_fc - 1;
   const long long base = d.w_off[0];
 #ifdef SDFR_TAIL_STAMPS
@@ -134,42 +170,32 @@ __device__ __forceinline__ void fc_stack_backward_one_wave(const float* __restri
 #endif
   const float t_last = lane < d.width[last] ? t_in[lane] : 0.0f;
   const float z_lane = lane < d.width[0] ? z[lane] : 0.0f;
-  wave_stage(p_lds, params + base, (int)fc_wave_span(d), lane);
-  if (lane < d.width[0]) a_lds[0][lane] = z_lane;
+  wave_stage(L.p, params + base, (int)fc_wave_span(d), lane);
+  if (lane < d.width[0]) L.a[0][lane] = z_lane;
   __builtin_amdgcn_wave_barrier();
 #ifdef SDFR_TAIL_STAMPS
   fcs[1] = wall_clock64();
 #endif
-  for (int l = 0; l < last; ++l) {
-    const int win = d.width[l], wout = d.width[l + 1];
-    if (lane < wout) {
-      float acc = p_lds[d.b_off[l] - base + lane];
-      const float* w = p_lds + (d.w_off[l] - base) + lane * win;
-#pragma unroll 8
-      for (int i = 0; i < win; ++i) acc = fmaf(w[i], a_lds[l][i], acc);
-      a_lds[l + 1][lane] = fmaxf(acc, 0.0f);
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
+  fc_narrow_forward_one_wave(L, d, lane);
   int cur = 0;
 #ifdef SDFR_TAIL_STAMPS
   fcs[2] = wall_clock64();
 #endif
-  if (lane < d.width[last]) g_lds[cur][lane] = (last == 0 || a_lds[last][lane] > 0.0f) ? t_last : 0.0f;
+  if (lane < d.width[last]) L.g[cur][lane] = (last == 0 || L.a[last][lane] > 0.0f) ? t_last : 0.0f;
   __builtin_amdgcn_wave_barrier();
   for (int l = last - 1; l >= 0; --l) {
     const int win = d.width[l], wout = d.width[l + 1];
     if (lane < win) {
-      const float* w = p_lds + (d.w_off[l] - base) + lane;
+      const float* w = L.p + (d.w_off[l] - base) + lane;
       float t = 0.0f;
 #pragma unroll 8
-      for (int o = 0; o < wout; ++o) t = fmaf(w[o * win], g_lds[cur][o], t);
-      g_lds[cur ^ 1][lane] = (l == 0 || a_lds[l][lane] > 0.0f) ? t : 0.0f;
+      for (int o = 0; o < wout; ++o) t = fmaf(w[o * win], L.g[cur][o], t);
+      L.g[cur ^ 1][lane] = (l == 0 || L.a[l][lane] > 0.0f) ? t : 0.0f;
     }
     __builtin_amdgcn_wave_barrier();
     cur ^= 1;
   }
-  if (lane < d.width[0]) g_z[lane] = g_lds[cur][lane];
+  if (lane < d.width[0]) g_z[lane] = L.g[cur][lane];
 #ifdef SDFR_TAIL_STAMPS
   fcs[3] = wall_clock64();
   if (lane == 0) printf("fc one wave: stage %.2f  forward %.2f  backward %.2f us\n", (double)(fcs[1] - fcs[0]) * 0.01,

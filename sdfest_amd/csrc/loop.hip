@@ -750,7 +750,12 @@ struct LoopTailArgs {
   int n_obj;
   float* latents;   // objects: the updated latents, packed [n_obj][n - 8] (the next iteration's batched decode), or NULL
   FusedDepth fd;    // sdfr_loop_tail_fused: the render step was ONE launch (its depth term comes unscaled)
+  // sdfr_loop_tail_fused(decoder_tape): gridDim.x workgroups, each leaves 256 outputs of the decoder's wide Linear layer
+  // for the NEXT iteration's latent in fc_next; `arrivals` counts the workgroups that have read the state
+  float* fc_next;
+  unsigned* arrivals;
 };
+constexpr int kTailArrivalPolls = 1 << 16;   // bound of workgroup 0's wait (~50 ms: a schedule that never comes)
 static_assert(kFcBlock == 256, "the tail's workgroup runs the decoder's Linear-stack backward");
 #ifdef SDFR_TAIL_STAMPS   // timing experiment (tools/microbench): where the tail's time goes, in 10 ns ticks
 __device__ unsigned long long g_tail_stamps[8];
@@ -769,8 +774,14 @@ __global__ __launch_bounds__(256) void loop_tail_kernel(LoopTailArgs a_in) {
   __shared__ float g_l[256];      // the gradients, laid out as a.grads (copied there at the end)
   __shared__ float p_cur[256];    // the parameters of this iteration ...
   __shared__ float p_new[256];    // ... and after the Adam step
+  __shared__ FcWaveLds fc_lds;    // the decoder's leading Linear layers (one-wave forms)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const LoopTailArgs& a = a_in;
+  // the next iteration's Linear stack in this launch (fc_next): workgroup 0 is the tail proper, the others repeat the
+  // latent's share of it -- gradient, Adam step: same inputs, same arithmetic -- and every workgroup forms its 256
+  // outputs of the wide layer from the updated latent.  Nothing passes between workgroups; the one thing to keep apart
+  // is workgroup 0's stores of the new state and the others' loads of the old one (arrivals).
+  const bool helper = a.fc_next != nullptr && blockIdx.x != 0;
   // (the object's own slices as plain locals: a modified copy of the argument block would live in scratch memory)
   const int view_base = a.n_obj > 1 ? (int)blockIdx.x * a.V : 0;
   const size_t obj_o = a.n_obj > 1 ? (size_t)blockIdx.x * a.n : 0;
@@ -805,13 +816,18 @@ __global__ __launch_bounds__(256) void loop_tail_kernel(LoopTailArgs a_in) {
     fc_stack_backward_sample(a.dec_params, a.fc, params + 8, t_mid, g_l + 8);
     __syncthreads();
   }
-  if (fc_wave && wave == 0) fc_stack_backward_one_wave(a.dec_params, a.fc, params + 8, t_mid, g_l + 8, lane);
+  if (fc_wave && wave == 0) fc_stack_backward_one_wave(fc_lds, a.dec_params, a.fc, params + 8, t_mid, g_l + 8, lane);
   // (only now: an LDS store of a loaded value waits for the load, and the Linear stack's loads should not queue
   // behind that wait)
   if (mine) p_cur[tid] = p_old;
   if (mine && tid >= 8 && !a.t_mid) g_l[tid] = g_given;
   SDFR_STAMP(1);
-  if (a.records) {
+  if (helper) {
+    if (tid < 8) g_l[tid] = 0.0f;   // (the pose's share of the step is workgroup 0's)
+    __builtin_amdgcn_s_waitcnt(0);  // this thread's loads of the state have landed (moments, step count: registers only)
+    __syncthreads();                // ... and every other thread's
+    if (tid == 0) atomicAdd(a.arrivals, 1u);
+  } else if (a.records) {
     pose_chain_block(params + 3, params + 7, a.cam_quat_all, a.V_all, a.records, kViewRecord, g_l, g_l + 3,
                      g_l + 7);
   } else {
@@ -821,7 +837,7 @@ __global__ __launch_bounds__(256) void loop_tail_kernel(LoopTailArgs a_in) {
                    a.quat_c, a.pc_loss, g_l, g_l + 3, g_l + 7, view_base, a.fd);
   }
   SDFR_STAMP(2);
-  if (tid == 0 && a.con_source)   // (p_cur: thread 0 has passed a barrier of the chain above since it was written)
+  if (!helper && tid == 0 && a.con_source)   // (p_cur: thread 0 has passed a barrier of the chain above since it was written)
     point_constraint_one(p_cur + 3, con, con + 3, a.con_weight, a.con_loss, g_l + 3);
   __syncthreads();   // the gradients (thread 0's, wave 0's) are visible to the Adam threads
   SDFR_STAMP(3);
@@ -830,6 +846,27 @@ __global__ __launch_bounds__(256) void loop_tail_kernel(LoopTailArgs a_in) {
                  step_old, p_new, p_i, m_i, v_i);
   __syncthreads();   // the updated parameters are visible to the pose chain
   SDFR_STAMP(4);
+  if (a.fc_next) {
+    // the updated latent through the leading layers (wave 0, out of the LDS copy the backward staged), then this
+    // workgroup's slice of the wide layer: fc_stack_kernel's arithmetic
+    unsigned seen = 0;
+    const unsigned want = (unsigned)(step_old + 1) * (gridDim.x - 1);   // (the word counts up over a run's iterations)
+    if (!helper && tid == 0) seen = __hip_atomic_load(a.arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == 0) {
+      if (lane < a.fc.width[0]) fc_lds.a[0][lane] = p_new[8 + lane];
+      __builtin_amdgcn_wave_barrier();
+      fc_narrow_forward_one_wave(fc_lds, a.fc, lane);
+    }
+    __syncthreads();
+    fc_wide_slice(a.dec_params, a.fc, fc_lds.a[a.fc.n_fc - 1], (int)blockIdx.x, a.fc_next);
+    if (helper) return;
+    // workgroup 0 stores the new state below: not before every other workgroup has read the old one
+    if (tid == 0) {
+      for (int polls = 0; seen < want && polls < kTailArrivalPolls; ++polls)
+        seen = __hip_atomic_load(a.arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+  }
   if (tid < a.V)
     pose_to_view_core(tid, p_new, p_new + 3, p_new + 7, cp, cq, pos_c, quat_c, inv_scale, scale_v);
   for (int v = tid + 256; v < a.V; v += 256)
@@ -1217,7 +1254,7 @@ int loop_tail_impl(const char* fn, float* params, float* grads, float* exp_avg, 
                    float* quat_c, float* inv_scale, float* scale_v, float* pc_loss,
                    const float* con_source, const float* con_target, float con_weight, float* con_loss,
                    const sdfr_decoder* decoder, const float* decoder_t_mid, int device, void* stream,
-                   const FusedDepth& fd) {
+                   const FusedDepth& fd, float* decoder_tape = nullptr, unsigned* arrivals = nullptr) {
   if ((decoder != nullptr) != (decoder_t_mid != nullptr))
     return fail(SDFR_E_NULL, "%s: decoder and decoder_t_mid go together", fn);
   if (V < 1 || V > kDeferredMaxViews) return fail(SDFR_E_INVALID, "%s: V=%d out of range [1,%d]", fn, V, kDeferredMaxViews);
@@ -1262,7 +1299,19 @@ int loop_tail_impl(const char* fn, float* params, float* grads, float* exp_avg, 
     a.t_mid = decoder_t_mid;
   }
   a.n_obj = 1;
-  hipLaunchKernelGGL(loop_tail_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+  unsigned nwg = 1;
+  if (decoder_tape || arrivals) {
+    if (!decoder_tape || !arrivals) return fail(SDFR_E_NULL, "%s: decoder_tape and arrivals go together", fn);
+    if (!decoder || !update_latent || !a.fc_one_wave)
+      return fail(SDFR_E_INVALID, "%s: the next Linear stack in this launch needs a decoder whose leading layers are "
+                  "at most %d wide (and its one-wave form switched on), and update_latent", fn, kFcWaveWidth);
+    size_t tape_fc_off = 0;
+    decoder_fc_desc(decoder, &a.fc, &a.dec_params, &tape_fc_off);
+    a.fc_next = decoder_tape + tape_fc_off;
+    a.arrivals = arrivals;
+    nwg = (unsigned)((a.fc.width[a.fc.n_fc] + kFcBlock - 1) / kFcBlock);
+  }
+  hipLaunchKernelGGL(loop_tail_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, a);
   SDFR_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1292,7 +1341,7 @@ extern "C" int sdfr_loop_tail_fused(float* params, float* grads, float* exp_avg,
                                     int max_view_points, float* pos_c, float* quat_c, float* inv_scale, float* scale_v,
                                     float* pc_loss, const float* con_source, const float* con_target, float con_weight,
                                     float* con_loss, const sdfr_decoder* decoder, const float* decoder_t_mid,
-                                    int device, void* stream) {
+                                    float* decoder_tape, unsigned* arrivals, int device, void* stream) {
   const char* fn = "sdfr_loop_tail_fused";
   if (!render_workspace) return fail(SDFR_E_NULL, "%s: render_workspace is NULL", fn);
   if (view_count_offset % 4 || tile_loss_offset % 16)
@@ -1305,7 +1354,8 @@ extern "C" int sdfr_loop_tail_fused(float* params, float* grads, float* exp_avg,
   return loop_tail_impl(fn, params, grads, exp_avg, exp_avg_sq, step, n_params, lr_position, lr_orientation, lr_scale,
                         lr_latent, update_latent, cam_pos, cam_quat, V, render_workspace, render_partials_offset, W, H,
                         pc_workspace, offsets, max_view_points, pos_c, quat_c, inv_scale, scale_v, pc_loss, con_source,
-                        con_target, con_weight, con_loss, decoder, decoder_t_mid, device, stream, fd);
+                        con_target, con_weight, con_loss, decoder, decoder_t_mid, device, stream, fd, decoder_tape,
+                        arrivals);
 }
 
 extern "C" int sdfr_loop_tail_objects(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int* step,

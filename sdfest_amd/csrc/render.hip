@@ -950,9 +950,6 @@ __device__ __forceinline__ void backward_tile(
   // a few views is a few hundred tiles with hit pixels, and what it takes is the depth of a tile's chain of phases
   // (bounds pass, clear, adds, flush: three barriers and a table walk), not the number of atomics it sends: the loop's
   // iteration 0.1042 -> 0.0970 ms without the table (tools/microbench/fused_render.py)
-#ifndef SDFR_SMALL_DIRECT
-#define SDFR_SMALL_DIRECT 0
-#endif
   constexpr bool TABLE = SDFG && !REG && !(SDFR_SMALL_DIRECT && std::is_same<Hash, SmallHash>::value && !DET);
   Hash& hash = lds.hash;
   float (*wave_part)[8] = lds.wave_part;

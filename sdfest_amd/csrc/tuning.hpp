@@ -53,6 +53,14 @@
 #ifndef SDFR_DENSE_CAP
 #define SDFR_DENSE_CAP 4608
 #endif
+// 1: the two-launch form's small-tile backward and its sampler blocks send d/dSDF straight to the volume's float
+// atomics, as the one-launch step always does (render_fused_l1_pc_kernel), instead of pre-summing in LDS.  Measured on
+// the C5 scene seen from V cameras, ms per iteration (tools/microbench/loop_forms.py): 2 views 0.1125 -> 0.1089, 4 views
+// 0.1207 -> 0.1233, 8: 0.1330 -> 0.1499, 16: 0.1624 -> 0.1979; K objects side by side unchanged -- beyond a view or two
+// the atomics on a shared volume collide, so: 0
+#ifndef SDFR_SMALL_DIRECT
+#define SDFR_SMALL_DIRECT 0
+#endif
 // sampler side of sdfr_render_*backward_l1_pc: workgroups the launch aims at over all views, and the least a view gets
 // (sampler_device.hpp, GROUPS)
 #ifndef SDFR_PC_GRID_TARGET

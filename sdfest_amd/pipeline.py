@@ -299,7 +299,7 @@ class FusedRenderAndCompare:
                  merge_launches: bool = True, graph_iterations: int = 5, process_group=None,
                  exchange: str = "sdf", sdf_grad_mode: int = 0, form: str = "auto", views: Optional[int] = None,
                  graph_collective: bool = False, defer_loss: Optional[bool] = None,
-                 fused_render: Optional[bool] = None):
+                 fused_render: Optional[bool] = None, fc_in_tail: Optional[bool] = None):
         """depth_images (V,H,W): the first observation (``rebind`` takes the next ones: the reference calls its
         pipeline once per detected object with fresh images, simple_setup.py:213-225, and so re-uses nothing; this
         object keeps every buffer and every captured graph across observations of the same V, W, H).  None with
@@ -339,8 +339,14 @@ class FusedRenderAndCompare:
         backward of its hit pixels right behind their march; include/sdfr.h) -- for the tail form over ONE view (the
         reference's own use: one call per detected object; up to 3 views when the shape is not optimised -- every view's
         depth term has its own weight / count, and one unscaled d/dSDF volume serves one) of a grid up to 128^3, loss-fused,
-        with plain ``sdf_grad_mode`` weights; default: wherever that holds (C5: 0.110 -> 0.097 ms per iteration).  Depth images bit for bit the two launches'; gradients equal up to rounding (the view's
-        weight / count multiplies sums instead of terms), so the trajectory is the two-launch form's to ~1e-6.
+        with plain ``sdf_grad_mode`` weights; default: wherever that holds (C5: 0.110 -> 0.100 ms per iteration).  Depth
+        images bit for bit the two launches'; gradients equal up to rounding (the view's weight / count multiplies sums
+        instead of terms), so the trajectory is the two-launch form's to ~1e-6.
+        fc_in_tail (with fused_render and shape optimisation, for decoders whose Linear stack has narrow leading layers:
+        ``SDFDecoder.narrow_linear_stack``): the tail's launch also runs the decoder's Linear stack for the latent it has
+        just updated (``sdfr_loop_tail_fused(decoder_tape=)``: one workgroup per 256 outputs of the wide layer, each
+        repeating the latent's share of the tail), and an iteration's decode starts behind it
+        (``sdfr_decoder_forward_stage``) -- one launch less per iteration, the same numbers; default: wherever it applies.
         graph_iterations: iterations per replayed hipGraph (a graph launch costs ~5-8 us between iterations; the
         remainder of max_iterations and runs with ``history`` replay the one-iteration graph).
         merge_launches: the per-view reductions of both backward passes run inside the gradient chain's launch
@@ -443,6 +449,7 @@ class FusedRenderAndCompare:
         ints = self._state[o + 4:o + 8].view(torch.int32)
         self.step = ints[0:1]
         self.inlier_counts = ints[1:3]
+        self.arrivals = ints[3:4]                     # sdfr_loop_tail_fused(decoder_tape=): zero at a run's start
         self._state_zero = self._state[n4:]           # (everything but the parameters)
         self.grads = torch.zeros(n, **f32)
         R = decoder._volume_size
@@ -496,9 +503,14 @@ class FusedRenderAndCompare:
             raise ValueError("fused_render needs the tail form over ONE view (up to 3 without shape optimisation) of a "
                              "grid up to 128^3, the loss-fused kernels and sdf_grad_mode 0 / 1")
         self.fused_render = can_fuse if fused_render is None else bool(fused_render)
+        can_fc = bool(self.fused_render and self.shape_opt and getattr(decoder, "narrow_linear_stack", lambda: False)())
+        if fc_in_tail and not can_fc:
+            raise ValueError("fc_in_tail needs fused_render, shape optimisation and a decoder with a narrow Linear stack")
+        self.fc_in_tail = can_fc if fc_in_tail is None else bool(fc_in_tail)
+        self._sums_open = False
         if self.fused_render:
             # what the one-launch step ADDS into must start from zero (its consumers clear what they have read)
-            self.plan._g_sdf_ring[0].zero_()
+            self._zero_fused_sums()
         self.strategy = _selection_strategy(config)
         self.track_inliers = (self.strategy == "best_inlier_ratio") if track_inliers is None else bool(track_inliers)
         self.rel_thr = float(config.get("relative_inlier_threshold", 0.03))
@@ -567,6 +579,13 @@ class FusedRenderAndCompare:
         self.bound = True
         return self
 
+    def _zero_fused_sums(self):
+        """the volumes and counts ``sdfr_render_step_fused_l1_pc`` adds into (normally left at zero by their consumers)"""
+        self.plan._g_sdf_ring[0].zero_()
+        self.plan.g_depth.zero_()
+        self.plan.view_count.zero_()
+        self._sums_open = False
+
     def _keep_graphs(self):
         # (at most 4 sets: a caller whose constraint weight changes from call to call re-captures instead of
         # collecting graphs without bound)
@@ -599,11 +618,27 @@ class FusedRenderAndCompare:
     def _stream(self):
         return torch.cuda.current_stream(self.dev).cuda_stream
 
-    def _decode(self, st, with_tape):
-        rc = self.L.sdfr_decoder_forward(self.dec._h, self.latent.data_ptr(), 1, 0, self.sdf.data_ptr(),
-                                         self.tape.data_ptr() if with_tape else None, self.ws_dec.data_ptr(),
-                                         self.ws_dec.numel(), st)
+    def _decode(self, st, with_tape, stages=3):
+        """stages (``sdfr_decoder_forward_stage``): 3 the whole decode; with ``fc_in_tail`` an iteration's decode is stage 2
+        (the Linear stack's output is in the tape: the previous tail's launch left it there), and stage 1 runs once in
+        front of the first iteration (``_prime``)"""
+        if stages == 3:
+            rc = self.L.sdfr_decoder_forward(self.dec._h, self.latent.data_ptr(), 1, 0, self.sdf.data_ptr(),
+                                             self.tape.data_ptr() if with_tape else None, self.ws_dec.data_ptr(),
+                                             self.ws_dec.numel(), st)
+        else:
+            rc = self.L.sdfr_decoder_forward_stage(self.dec._h, self.latent.data_ptr(), 1, 0, self.sdf.data_ptr(),
+                                                   self.tape.data_ptr(), self.ws_dec.data_ptr(), self.ws_dec.numel(), st,
+                                                   stages)
         self.check(rc, "sdfr_decoder_forward")
+
+    def _prime(self):
+        """what the FIRST iteration of a run finds where every later one finds the previous tail's results: the views'
+        poses of the initial estimate and -- ``fc_in_tail`` -- its Linear-stack output"""
+        st = self._stream()
+        self._poses_to_views(st)
+        if self.fc_in_tail:
+            self._decode(st, True, stages=1)
 
     def iteration(self):
         """One iteration of simple_setup.py:408-462 as a launch sequence on the current stream."""
@@ -612,7 +647,7 @@ class FusedRenderAndCompare:
         pos, quat, scale = p, p + 12, p + 28
         g = self.grads.data_ptr()
         if self.shape_opt:
-            self._decode(st, True)
+            self._decode(st, True, stages=2 if self.fc_in_tail else 3)
         sdf = self.sdf[0, 0]
         if self._tail_form():
             # [decoder] -> render pair as a step -> [decoder VJP] -> sdfr_loop_tail; the camera-frame poses of THIS
@@ -744,6 +779,7 @@ class FusedRenderAndCompare:
         (multiplies the pose sums by k, writes the depth loss, resets the count)."""
         plan = self.plan
         g_pc = plan._g_sdf_ring[0] if self.shape_opt else None
+        self._sums_open = True     # (until the tail has been enqueued: __call__ re-zeroes after an interrupted iteration)
         plan.step_fused_l1_pc(sdf, self.pos_c, self.quat_c, self.inv_scale, self.scale_v, self.cfg["threshold"],
                               self.target, self.points, self.offsets, self.max_pts, self.ws_pc,
                               pc_weight=self.cfg["pc_weight"], g_sdf=g_pc)
@@ -766,8 +802,10 @@ class FusedRenderAndCompare:
             self.pos_c.data_ptr(), self.quat_c.data_ptr(), self.inv_scale.data_ptr(), self.scale_v.data_ptr(),
             self.loss_pc.data_ptr(), self.pc_source.data_ptr() if con else None,
             self.pc_target.data_ptr() if con else None, self.pc_weight if con else 0.0,
-            self.loss_con.data_ptr() if con else None, self.dec._h if t_mid is not None else None, t_mid, d, st),
-            "sdfr_loop_tail_fused")
+            self.loss_con.data_ptr() if con else None, self.dec._h if t_mid is not None else None, t_mid,
+            self.tape.data_ptr() if self.fc_in_tail else None, self.arrivals.data_ptr() if self.fc_in_tail else None,
+            d, st), "sdfr_loop_tail_fused")
+        self._sums_open = False
         self._inliers(L, p, d, st)
 
     # ---- the records form: head | exchange | tail (the loop sharded over ranks) -----------------------------------
@@ -1033,6 +1071,8 @@ class FusedRenderAndCompare:
             self.params[8:] = latent.reshape(-1)
             self._state_zero.zero_()     # Adam's moments and step count, inlier history, counts and best-so-far state
             self.grads.zero_()
+            if self.fused_render and self._sums_open:   # an iteration was abandoned between its render and its tail
+                self._zero_fused_sums()
         if not self.shape_opt:
             self._decode(self._stream(), False)
         n_iter = self.cfg["max_iterations"]
@@ -1042,7 +1082,7 @@ class FusedRenderAndCompare:
             return (self.position.clone()[None], self.orientation.clone()[None], self.scale.clone(),
                     self.latent.clone()[None])
         if self._tail_form():
-            self._poses_to_views(self._stream())   # every later iteration gets its view poses from the tail before it
+            self._prime()   # every later iteration gets its view poses from the tail before it
         if use_graph and self.graph is None:
             # warm up on a side stream (lazy module loads), restore the state, then capture
             state = (self._state,)
@@ -1065,7 +1105,7 @@ class FusedRenderAndCompare:
             for t, c in zip(state, saved):
                 t.copy_(c)   # the capture itself does not execute, but keep the state explicit
             if self._tail_form():
-                self._poses_to_views(self._stream())   # the warm-up's tail left the poses of ITS updated parameters
+                self._prime()   # the warm-up's tail left the poses of ITS updated parameters
             self._keep_graphs()
         done = 0
         if use_graph and history is None and self.graph_many is not None:
@@ -1103,7 +1143,7 @@ class MultiObjectRenderAndCompare:
     """K estimates optimised SIDE BY SIDE: the K detected objects of one frame -- each with its own depth image (the
     frame masked by the object's instance mask), pose, scale, latent and Adam state -- go through ONE launch sequence
     per iteration.  The reference calls its pipeline once per object, one after the other (simple_setup.py:213-225), and
-    a single estimate's iteration is a chain of ~14 dependent launches that leaves most of an MI355X idle (C5: 0.11 ms
+    a single estimate's iteration is a chain of ~13 dependent launches that leaves most of an MI355X idle (C5: 0.11 ms
     per iteration whatever the object); here the decoder runs on K latents at once, the renderer and the sampler on K
     views with one SDF each (``sdf_view_stride = R^3``), the decoder's VJP on the K gradient volumes, and the tail is K
     workgroups (``sdfr_loop_tail_objects``).  Same arithmetic per object as :class:`FusedRenderAndCompare` (one view per

@@ -256,11 +256,12 @@ class SDFPipeline:
         instance masks; camera_position (3,) / camera_orientation (4,): the camera in the world (default: the origin);
         prior_orientation_distribution (K,C) / training_orientation_distribution (C,): as in ``__call__``, one row per
         object.  Returns position (K,3), orientation (K,4), scale (K,), latent (K,L) -- row k follows what
-        ``pipeline(depth, masks[k], color)`` estimates for object k (`result_selection_strategy` "last_iteration"): BIT FOR
-        BIT when only the pose is optimised (``shape_optimization=False``; tests/test_multi_object_gpu.py), to rounding
-        with shape optimisation -- a batch of latents takes other, equivalent decoder kernels than a single one (the direct
-        convolution from 8 latents on, the tiled resize from 2, no split-K above 16), tested to 1 % of an Adam step per
-        iteration.  ``NoDepthError`` for an object without a valid depth pixel is raised AFTER the call's work was
+        ``pipeline(depth, masks[k], color)`` estimates for object k (`result_selection_strategy` "last_iteration") TO
+        ROUNDING, tested to 1 % of an Adam step per iteration: the single call runs its render pair as one launch
+        (``FusedRenderAndCompare(fused_render=)``: the depth loss's weight / count multiplies sums instead of terms), and with
+        shape optimisation a batch of latents takes other, equivalent decoder kernels than a single one (the direct
+        convolution from 8 latents on, the tiled resize from 2, no split-K above 16).  Against the single loop in its
+        two-launch form the pose-only rows are BIT FOR BIT the same (tests/test_multi_object_gpu.py).  ``NoDepthError`` for an object without a valid depth pixel is raised AFTER the call's work was
         enqueued (the counts are read behind the launches), where the reference raises before optimising (:780-781)."""
         dev = self._dev
         if depth_image.dim() != 2 or masks.dim() != 3 or tuple(masks.shape[1:]) != tuple(depth_image.shape):

@@ -86,6 +86,21 @@ class SDFDecoder:
         _lib.check(rc, "sdfr_decoder_create")
         self._L, self._h = L, handle
         self._ws = {}     # stream handle -> scratch buffer
+        self._fc_widths = [int(latent_size)] + [int(o) for o in fc_out]
+
+    def narrow_linear_stack(self) -> bool:
+        """Whether the Linear stack's leading layers run as ONE wave out of LDS (csrc/decoder_fc.hpp, fc_one_wave_ok: every
+        layer input at most 64 wide, at most 8 layers, their parameters within 6144 floats -- the mug decoder's
+        8 -> 20 -> 50 -> 8192 does) and that form is switched on for this handle: what lets the captured loop's tail
+        launch run the next iteration's Linear stack (``FusedRenderAndCompare(fc_in_tail=)``)."""
+        w = self._fc_widths
+        span = sum(w[l] * w[l + 1] + w[l + 1] for l in range(len(w) - 2))
+        if len(w) - 1 > 8 or max(w[:-1]) > 64 or span > 6144:
+            return False
+        on = self.set_option("fc_one_wave", 1)
+        if on != 1:
+            self.set_option("fc_one_wave", on)
+        return on == 1
 
     @classmethod
     def from_config(cls, config: Mapping, state_dict: Mapping, device="cuda", sdf_size: int = 64):

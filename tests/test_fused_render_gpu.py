@@ -92,6 +92,81 @@ def test_trajectory_follows_the_two_launch_form(views, shape, use_graph):
     assert np.abs(hist[True][-1] - hist[True][0]).max() > 1e-3      # (something was optimised)
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_the_next_linear_stack_in_the_tails_launch_changes_no_number(use_graph):
+    """fc_in_tail: the tail's launch gets one workgroup per 256 outputs of the decoder's wide Linear layer; every one
+    repeats the latent's share of the tail and forms its slice for the NEXT decode (sdfr_loop_tail_fused(decoder_tape),
+    sdfr_decoder_forward_stage).  Same arithmetic on the same inputs: the trajectory must not move by a bit -- only the
+    float atomics of d/dSDF (both forms have them) can, so the comparison is made where they cannot: the FIRST iteration
+    bit for bit, the rest to the run-to-run spread of either form."""
+    s = _scene(1, 12)
+    hist = {}
+    for fc in (False, True):
+        loop = _loop(s, True, fc_in_tail=fc, graph_iterations=5)
+        assert loop.fc_in_tail == fc
+        runs = []
+        for _ in range(2):
+            h = []
+            loop(*s["init"], use_graph=use_graph, history=h)
+            torch.cuda.synchronize()
+            runs.append(S.history_array(h))
+        np.testing.assert_allclose(runs[1], runs[0], atol=2e-5, rtol=0)
+        hist[fc] = runs[0]
+    # iteration 1: Adam's first step is -lr sign(g) whatever the gradient's rounding; iteration 2 starts from the
+    # Linear-stack output the first tail left (fc_in_tail) or from a decode of the same latent: the same SDF
+    assert np.array_equal(hist[True][0], hist[False][0])
+    np.testing.assert_allclose(hist[True], hist[False], atol=2e-5, rtol=0)
+    assert np.abs(hist[True][-1, 8:] - hist[True][0, 8:]).max() > 1e-3     # the latent moved: later decodes differ
+
+
+def test_the_tails_linear_stack_output_is_the_decoders_bit_for_bit():
+    """after one iteration the tape's slot holds the wide layer's output for the UPDATED latent -- what a full decode of
+    that latent writes there"""
+    from sdfest_amd import _lib
+    L = _lib.lib()
+    s = _scene(1, 1)
+    loop = _loop(s, True, fc_in_tail=True)
+    loop(*s["init"], use_graph=False)
+    torch.cuda.synchronize()
+    n_fc = 8192
+    got = loop.tape.view(torch.float32).clone()
+    tape2 = torch.zeros_like(loop.tape)
+    rc = L.sdfr_decoder_forward_stage(s["decoder"]._h, loop.latent.data_ptr(), 1, 0, None, tape2.data_ptr(),
+                                      loop.ws_dec.data_ptr(), loop.ws_dec.numel(), None, 1)
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = tape2.view(torch.float32)
+    touched = ref != 0
+    assert int(touched.sum()) > n_fc // 8             # (ReLU'd outputs: a good share is positive)
+    assert torch.equal(got[touched], ref[touched])
+    # ... and the convolutional part from there equals the whole decode
+    out_a = torch.empty(64 ** 3, device="cuda"); out_b = torch.empty_like(out_a)
+    assert L.sdfr_decoder_forward_stage(s["decoder"]._h, None, 1, 0, out_a.data_ptr(), tape2.data_ptr(),
+                                        loop.ws_dec.data_ptr(), loop.ws_dec.numel(), None, 2) == 0
+    assert L.sdfr_decoder_forward(s["decoder"]._h, loop.latent.data_ptr(), 1, 0, out_b.data_ptr(), tape2.data_ptr(),
+                                  loop.ws_dec.data_ptr(), loop.ws_dec.numel(), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b)
+    assert L.sdfr_decoder_forward_stage(s["decoder"]._h, loop.latent.data_ptr(), 1, 0, out_a.data_ptr(), None,
+                                        loop.ws_dec.data_ptr(), loop.ws_dec.numel(), None, 2) != 0      # no tape
+    assert L.sdfr_decoder_forward_stage(s["decoder"]._h, loop.latent.data_ptr(), 1, 0, out_a.data_ptr(), tape2.data_ptr(),
+                                        loop.ws_dec.data_ptr(), loop.ws_dec.numel(), None, 4) != 0      # no such stage
+
+
+def test_decoders_without_a_narrow_linear_stack_keep_the_launch():
+    s = _scene(1, 1)
+    s["decoder"].set_option("fc_one_wave", 0)
+    try:
+        assert not s["decoder"].narrow_linear_stack()
+        loop = _loop(s, True)
+        assert loop.fused_render and not loop.fc_in_tail
+        with pytest.raises(ValueError, match="fc_in_tail"):
+            _loop(s, True, fc_in_tail=True)
+    finally:
+        s["decoder"].set_option("fc_one_wave", 1)
+    assert s["decoder"].narrow_linear_stack()
+
+
 def test_pose_only_run_is_reproducible_bit_for_bit():
     """no float atomic on the way to the pose: tile sums in a fixed order, the count a sum of integers"""
     s = _scene(2, 8)

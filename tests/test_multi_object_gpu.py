@@ -75,8 +75,17 @@ def test_rows_follow_the_single_object_loop(frame, shape_opt, use_graph):
     assert multi.step.tolist() == [7] * K and multi.counts.tolist() == masks.sum(dim=(1, 2)).tolist()
     moved = 0.0
     for k in range(K):
-        single = FusedRenderAndCompare(dec, cam, cfg, frames[k:k + 1].contiguous(), shape_optimization=shape_opt)
+        # (the single loop in its two-launch form: the K-object loop's kernels.  Its default for one view, the render
+        # pair as ONE launch, applies weight / count to sums instead of terms -- equal to rounding, asserted below)
+        single = FusedRenderAndCompare(dec, cam, cfg, frames[k:k + 1].contiguous(), shape_optimization=shape_opt,
+                                       fused_render=False)
         ref = single(p0[k:k + 1], q0[k:k + 1], s0[k:k + 1], z0[k:k + 1], use_graph=False)
+        if k == 0:
+            one = FusedRenderAndCompare(dec, cam, cfg, frames[k:k + 1].contiguous(), shape_optimization=shape_opt)
+            assert one.fused_render
+            for a, b, lr in zip(one(p0[k:k + 1], q0[k:k + 1], s0[k:k + 1], z0[k:k + 1], use_graph=False), ref,
+                                (1e-3, 1e-2, 1e-3, 1e-2)):
+                assert (a - b).abs().max().item() <= 0.01 * lr * 7
         got = [outs[0][0][k], outs[0][1][k], outs[0][2][k], outs[0][3][k]]
         # Adam's steps are ~lr (1e-3 position / scale, 1e-2 orientation / latent): 1 % of a step per iteration
         for name, a, b, lr in zip(("position", "orientation", "scale", "latent"), got, ref, (1e-3, 1e-2, 1e-3, 1e-2)):

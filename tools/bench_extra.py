@@ -614,7 +614,7 @@ def c5_config(hbm_peak):
             "final_position_error_mm": round(float((out[0] - sc["p_true"]).norm()) * 1e3, 3),
             "final_orientation_error_deg": round(float(np.degrees(2 * np.arccos(dot))), 3),
             "final_scale_error_rel": round(float(abs(out[2] - sc["s_true"]) / sc["s_true"]), 4),
-            "roofline": {"bound": "launch latency (14 dependent launches, profiles/r06_c5_loop_kernels.md); HBM figure for reference",
+            "roofline": {"bound": "launch latency (13 dependent launches, profiles/r06_c5_loop_kernels.md); HBM figure for reference",
                          "bytes_per_iteration": bytes_it, "achieved": round(bytes_it / (ms * 1e-3) / 1e9, 2),
                          "unit": "GB/s", "frac": round(bytes_it / (ms * 1e-3) / hbm_peak, 6)}}
 

@@ -12,9 +12,10 @@ from _loop_scene import c5_scene  # noqa: E402
 from sdfest_amd.pipeline import FusedRenderAndCompare  # noqa: E402
 
 
-def run(views, fused, n=7):
+def run(views, fused, n=7, shape=True, fc=None):
     s = c5_scene(views=views, max_iterations=50)
-    loop = FusedRenderAndCompare(s["decoder"], s["camera"], s["config"], s["targets"], form="tail", fused_render=fused)
+    loop = FusedRenderAndCompare(s["decoder"], s["camera"], s["config"], s["targets"], form="tail", fused_render=fused,
+                                 shape_optimization=shape, fc_in_tail=fc if fused else None)
     out = None
     for _ in range(3):
         out = loop(*s["init"], use_graph=True)
@@ -32,12 +33,15 @@ def run(views, fused, n=7):
 
 
 def main():
-    for views in (1, 2, 3):
+    for views, shape in ((1, True), (1, False), (2, False), (3, False)):
         res = {}
-        for fused in (False, True):
-            res[fused] = run(views, fused)
-            print(f"views {views} one launch {fused}: {res[fused][0]:.4f} ms per iteration", flush=True)
-        for a, b, name in zip(res[False][1], res[True][1], ("position", "orientation", "scale", "latent")):
+        for fused, fc in ((False, None), (True, False), (True, True)):
+            if fc and not shape:
+                continue
+            res[fused, fc] = run(views, fused, shape=shape, fc=fc)
+            print(f"views {views} shape optimisation {shape}: render pair as one launch {fused}, Linear stack in the tail's "
+                  f"launch {bool(fc)}: {res[fused, fc][0]:.4f} ms per iteration", flush=True)
+        for a, b, name in zip(res[False, None][1], res[True, False][1], ("position", "orientation", "scale", "latent")):
             print(f"   {name}: max |two launches - one| = {(a - b).abs().max().item():.3e}")
 
 
