@@ -262,3 +262,102 @@ def test_c_abi_argument_errors():
         s["decoder"]._h, loop.latent.data_ptr(), loop.tape.data_ptr(), plan._g_sdf_ring[0].data_ptr(), None,
         plan.view_count.data_ptr(), 1.0, loop.ws_dec.data_ptr(), loop.ws_dec.numel(), None, ctypes.byref(t_mid))
     assert rc != 0 and b"NULL" in L.sdfr_last_error()
+
+
+# ---- the C ABI call itself against the float64 oracle (ragged images, other grid sizes, off-centre intrinsics) --------
+
+def _oracle_step(sdf, pos, quat, isc, cam, tgt, points, offsets, thr, w_depth, w_pc, mode):
+    """float64: depth, the depth loss and its gradient image, the renderer's backward of it, and the point-cloud L1's
+    backward (losses.py:32-135 with the upstream gradient of simple_setup.py:144's mean of |value|) -- per view"""
+    import oracle
+    W, H, cx, cy, fx, fy = cam
+    B = len(pos)
+    depth = oracle.render_forward(sdf, pos, quat, isc, W, H, cx, cy, fx, fy, thr, dtype=np.float64)
+    loss, grad = oracle.depth_l1(depth, tgt, w_depth)
+    g_sdf = np.zeros_like(sdf, dtype=np.float64)
+    g_pose = np.zeros((B, 8))
+    for v in range(B):
+        gs, gp, gq, gi = oracle.render_backward(grad[v], depth[v], sdf, pos[v], quat[v], isc[v], cx, cy, fx, fy,
+                                                sdf_grad_mode=mode, dtype=np.float64)
+        g_sdf += gs
+        g_pose[v, 0:3], g_pose[v, 3:7], g_pose[v, 7] = gp.reshape(3), gq.reshape(4), float(np.ravel(gi)[0])
+    g_pc = np.zeros_like(g_sdf)
+    for v in range(B):
+        P = points[offsets[v]:offsets[v + 1]]
+        val = oracle.pc_loss_forward(P, pos[v], quat[v], 1.0 / isc[v], sdf, dtype=np.float64)
+        go = np.sign(val) * (w_pc / max(len(P), 1))
+        g_pc += oracle.pc_loss_backward(go, P, pos[v], quat[v], 1.0 / isc[v], sdf, dtype=np.float64)[0]
+    return depth, loss, g_sdf, g_pc, g_pose
+
+
+@pytest.mark.parametrize("R,W,H,B,mode,shape", [(64, 640, 480, 1, 0, True), (40, 150, 101, 1, 1, True),
+                                                (100, 97, 64, 1, 0, True), (64, 160, 120, 3, 0, False),
+                                                (33, 90, 50, 2, 1, False)])
+def test_one_launch_step_against_the_float64_oracle(R, W, H, B, mode, shape):
+    import oracle
+    from sdfest_amd import BatchRenderPlan, Camera, _lib
+    L = _lib.lib()
+    f = 0.55 * W
+    cx, cy = W / 2 + 3.25, H / 2 - 2.5                      # off-centre principal point
+    sdf = oracle.blobs_sdf(1, R=R)
+    pos, quat, isc = oracle.random_poses(B, seed=3, width=W, height=H, f=f)
+    rng = np.random.default_rng(11)
+    cam = (W, H, cx, cy, f, f)
+    tgt = oracle.render_forward(sdf, pos + rng.normal(0, 0.01, pos.shape).astype(np.float32), quat, isc, *cam, 0.005,
+                                dtype=np.float32)
+    tgt = np.where(rng.uniform(size=tgt.shape) < 0.1, 0.0, tgt).astype(np.float32)
+    # observed points in the camera frame: the back-projection of the targets (pointset_utils.depth_to_pointcloud :57-77)
+    pts, offs = [], [0]
+    for v in range(B):
+        p = oracle.depth_to_pointcloud(tgt[v], f, f, cx - 0.5, cy - 0.5, dtype=np.float32)
+        pts.append(p)
+        offs.append(offs[-1] + len(p))
+    points = np.concatenate(pts).astype(np.float32)
+    assert min(np.diff(offs)) > 50
+    w_depth, w_pc, thr = 1.0, 3.0, 0.005
+    ref_depth, ref_loss, ref_gsdf, ref_gpc, ref_pose = _oracle_step(sdf, pos, quat, isc, cam, tgt, points, offs, thr,
+                                                                    w_depth, w_pc, mode)
+    T = lambda a, dt=torch.float32: torch.tensor(np.ascontiguousarray(a), dtype=dt, device="cuda")
+    camera = Camera(W, H, f, f, cx, cy, pixel_center=0.5)
+    plan = BatchRenderPlan(R, B, camera, sdf_grad_mode=mode)
+    d_sdf, d_pos, d_quat, d_isc, d_tgt = T(sdf), T(pos), T(quat), T(isc), T(tgt)
+    d_scale = (1.0 / d_isc).contiguous()
+    d_pts, d_off = T(points), T(offs, torch.int32)
+    max_pts = int(max(np.diff(offs)))
+    ws_pc = torch.zeros(max(L.sdfr_pc_loss_backward_workspace_bytes(B, max_pts), 256), dtype=torch.uint8, device="cuda")
+    g_pc = torch.zeros((R, R, R), device="cuda") if shape else None
+    depth = plan.step_fused_l1_pc(d_sdf, d_pos, d_quat, d_isc, d_scale, thr, d_tgt, d_pts, d_off, max_pts, ws_pc,
+                                  pc_weight=w_pc, g_sdf=g_pc)
+    torch.cuda.synchronize()
+    # depth: the forward kernel's, bit for bit -- and the oracle's to float rounding
+    plain = BatchRenderPlan(R, B, camera).forward(d_sdf, d_pos, d_quat, d_isc, thr)
+    assert torch.equal(depth, plain)
+    hit = ref_depth > 0
+    assert (depth.cpu().numpy() > 0).sum() == hit.sum() or abs(int((depth > 0).sum()) - int(hit.sum())) <= 2
+    # the overlap counts: integers
+    cnt = plan.view_count.cpu().numpy().astype(np.float64)
+    ref_cnt = ((tgt > 0) & hit).sum(axis=(1, 2))
+    assert np.all(np.abs(cnt - ref_cnt) <= 2), (cnt, ref_cnt)
+    k = np.where(cnt > 0, w_depth / np.maximum(cnt, 1), 0.0)
+    if shape:
+        g = g_pc.cpu().numpy().astype(np.float64) + k[0] * plan.g_depth.cpu().numpy().astype(np.float64)
+        ref = ref_gsdf + ref_gpc
+        from helpers import check_sdf_grad
+        check_sdf_grad(g, ref, mode, int(hit.sum()), rel=1e-4, name=f"one launch R={R} {W}x{H}")
+    else:
+        assert float(plan.g_depth.abs().max()) == 0.0           # nobody asked for d/dSDF: nothing was added
+    # the tiles' pose sums, times k: the renderer's pose gradients
+    off = plan.partials_offset
+    ntx, nty = (W + 31) // 32, (H + 7) // 8
+    part = plan.workspace[off:off + B * ntx * nty * 32].view(torch.float32).view(B, nty * ntx, 8).cpu().numpy().astype(np.float64)
+    # (only the tiles of a view's rectangle are written; the plan's workspace starts zero-filled)
+    got_pose = part.sum(axis=1) * k[:, None]
+    scale = np.abs(ref_pose).max(axis=0) + 1e-12
+    # the fp32 bound of the sums: 1e-4 of the sum of the per-pixel magnitudes is what tests/test_render_gpu.py asserts;
+    # against each component's largest value over the views it stays well below 1e-3 on these scenes
+    assert np.all(np.abs(got_pose - ref_pose) <= 1e-3 * scale), (got_pose, ref_pose)
+    # the depth loss from the tiles' records
+    lo = L.sdfr_render_fused_tile_loss_offset(R, B, W, H)
+    rec = plan.workspace[lo:lo + B * ntx * nty * 32].view(torch.float32).view(B, nty * ntx, 8).cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(rec[:, :, 0].sum(axis=1) / np.maximum(cnt, 1), np.nan_to_num(ref_loss), rtol=2e-4, atol=1e-7)
+    np.testing.assert_array_equal(rec[:, :, 1].sum(axis=1), cnt)
