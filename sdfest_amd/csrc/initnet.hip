@@ -25,6 +25,8 @@ namespace {
 __device__ __forceinline__ float relu_nan(float v) { return (v != v) ? __int_as_float(0x7fc00000) : fmaxf(v, 0.0f); }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// (K = 128, the mug backbone's inner layers, as ONE chunk -- 66 KB of dynamic LDS, a run-time row stride -- was
+// measured: 13.8 -> 16.7 us per layer; the second chunk's four columns cost less than that)
 constexpr int kPtsPerBlock = 64, kColsPerBlock = 64, kChunk = 124;
 
 // Y = relu((X W^T + c) * s + t), optionally F_out = F_res + Y, and colmax[col] = max over the points.
