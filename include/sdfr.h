@@ -250,33 +250,35 @@ SDFR_API int sdfr_render_step_backward_l1_pc(
     long long g_sdf_view_stride, void* workspace, size_t workspace_bytes, float pc_weight, const float* points,
     const int* offsets, int max_view_points, const float* scale, void* pc_workspace, size_t pc_workspace_bytes,
     float* loss, float* loss_stats_out, int device, void* stream);
-/* ONE LAUNCH for the whole loss-fused step of 1 .. 3 views of the plain grid (sdfr_render_step_forward_l1 with the
+/* ONE LAUNCH for the whole loss-fused step of 1 .. 8 views of the plain grid (sdfr_render_step_forward_l1 with the
  * loss deferred + sdfr_render_step_backward_l1_pc): every image tile marches its rays and, while the depths are still
  * in registers, runs the backward of its hit pixels; the sampler's blocks run beside the tiles as before.  The depth
  * loss is a mean over a count that no tile knows before the launch ends, so the depth term is left UNSCALED, with
  * the bare sign of (estimate - observation) as its upstream gradient:
+ *   g_depth  float [B][R^3]   d/dSDF of view b's depth term, unscaled, ADDED to (every view has its own k)
+ *   g_sdf    float [R^3]      the point-cloud term of all views (its scale is known), ADDED to
+ *     (both NULL: nobody wants d/dSDF -- the tiles and the sampler's blocks then skip it)
  *   workspace (sdfr_render_step_workspace_bytes; offsets by the functions named)
- *     sdfr_render_fixed_volume_offset(R, B, W, H, 1)   float [R^3]   d/dSDF of the depth term, unscaled, ADDED to
  *     sdfr_render_partials_offset(R, B, W, H, 1)       the tiles' pose sums, unscaled (32 x 8-pixel tiles)
  *     sdfr_render_fused_view_count_offset(B, H)        float [B]     the views' overlap counts, ADDED to (integers
  *                                                      below 2^24 held in floats: exact in any order)
- *     behind the 64-bit volume: (sum |est - obs|, count) per tile, 8 floats apart
- *   g_sdf (nullable: nobody wants d/dSDF -- the tiles then skip it)  float [R^3]: the point-cloud term, ADDED to;
- *     with g_sdf, B = 1 (every view's depth term has its own k: one unscaled volume serves one view).
+ *     sdfr_render_fused_tile_loss_offset(R, B, W, H)   (sum |est - obs|, count) per tile, 8 floats apart
  * Nothing is zero-filled by this call: whoever consumes a sum clears it (sdfr_decoder_backward_latent_deferred_scaled
- * forms  k * depth volume + g_sdf,  k = weight / count, and clears both; sdfr_loop_tail_fused multiplies the pose
- * sums and resets the count) -- the volumes and the counts must be zero before the FIRST call.
+ * forms  g_sdf + sum_b k_b g_depth[b],  k_b = weight / count_b, and clears the volumes; sdfr_loop_tail_fused multiplies
+ * the pose sums and resets the counts) -- the volumes and the counts must be zero before the FIRST call.
  * depth equals sdfr_render_step_forward_l1's bit for bit; the gradients equal the two launches' up to rounding (k
- * multiplies sums instead of terms).  sdf_grad_mode: SDFR_SDF_GRAD_EXACT or _CUDA_COMPAT, no flags.  R <= 128.
+ * multiplies sums instead of terms).  d/dSDF goes to the volumes by float atomics directly (no LDS pre-sum: what a
+ * launch over a few views costs is the depth of a tile's chain of phases); from 3 views on the sampler's blocks, which
+ * share one volume, keep their run table.  sdf_grad_mode: SDFR_SDF_GRAD_EXACT or _CUDA_COMPAT, no flags.  R <= 128.
  * pos / quat / inv_scale / scale: the views' poses (scale = 1 / inv_scale, what the sampler takes). */
 SDFR_API size_t sdfr_render_fused_view_count_offset(int B, int H);
 SDFR_API size_t sdfr_render_fused_tile_loss_offset(int R, int B, int W, int H);   /* the (sum, count) tile records */
 SDFR_API int sdfr_render_step_fused_l1_pc(
     const float* sdf, int R, long long sdf_view_stride, const float* pos, const float* quat, const float* inv_scale,
     const float* scale, int B, int W, int H, float cx, float cy, float fx, float fy, float threshold,
-    const float* target, float* depth, int sdf_grad_mode, float* g_sdf, void* workspace, size_t workspace_bytes,
-    float pc_weight, const float* points, const int* offsets, int max_view_points, void* pc_workspace,
-    size_t pc_workspace_bytes, int device, void* stream);
+    const float* target, float* depth, int sdf_grad_mode, float* g_sdf, float* g_depth, void* workspace,
+    size_t workspace_bytes, float pc_weight, const float* points, const int* offsets, int max_view_points,
+    void* pc_workspace, size_t pc_workspace_bytes, int device, void* stream);
 /* sdfr_render_step_backward_l1 = sdfr_render_backward_l1 as the second half of a step begun by
  * sdfr_render_step_forward_l1 (no prologue launch, the forward's view records and rectangles; pos / quat / inv_scale
  * are not passed again) -- the loss-fused form of sdfr_render_step_backward.
@@ -454,15 +456,17 @@ SDFR_API int sdfr_decoder_backward_latent_deferred(const sdfr_decoder* decoder, 
 SDFR_API int sdfr_decoder_forward_stage(const sdfr_decoder* decoder, const float* z, int N, int enforce_tsdf,
                                float* out, float* tape, void* workspace, size_t workspace_bytes,
                                void* stream, int stages);
-/* sdfr_decoder_backward_latent_deferred for an incoming gradient in TWO volumes, one of them not yet normalised:
- *     grad = grad_out + k * grad_scaled,   k = count[0] > 0 ? weight / count[0] : 0     (count: a device float)
- * -- what sdfr_render_step_fused_l1_pc leaves: the point-cloud term, and the depth term before its division by the
- * view's overlap count.  The first launch of the VJP forms the sum as it loads (decoders whose first launch cannot,
- * get it from one small launch in front), and BOTH volumes are zero-filled once they have been read -- their
- * producer adds into them.  volume^3 a multiple of 4, both volumes 16-byte aligned. */
+/* sdfr_decoder_backward_latent_deferred for an incoming gradient in 1 + n_scaled volumes, n_scaled of them not yet
+ * normalised:
+ *     grad = grad_out + sum_v k_v * grad_scaled[v],   k_v = count[v] > 0 ? weight / count[v] : 0   (count: device floats)
+ * -- what sdfr_render_step_fused_l1_pc leaves: the point-cloud term, and every view's depth term before its division by
+ * the view's overlap count.  With one scaled volume the first launch of the VJP forms the sum as it loads (decoders
+ * whose first launch cannot, and n_scaled > 1, get it from one small launch in front), and ALL the volumes are
+ * zero-filled once they have been read -- their producer adds into them.  volume^3 a multiple of 4, the volumes
+ * 16-byte aligned, grad_scaled [n_scaled][volume^3], n_scaled <= 64. */
 SDFR_API int sdfr_decoder_backward_latent_deferred_scaled(const sdfr_decoder* decoder, const float* z, const float* tape,
-                                                 float* grad_out, float* grad_scaled, const float* count, float weight,
-                                                 void* workspace, size_t workspace_bytes, void* stream,
+                                                 float* grad_out, float* grad_scaled, int n_scaled, const float* count,
+                                                 float weight, void* workspace, size_t workspace_bytes, void* stream,
                                                  const float** t_mid);
 /* ... and for N latents (the K objects of a frame): *t_mid is [N][width of the wide layer's input]; sdfr_loop_tail_objects
  * finishes object k's product rule from row k. */

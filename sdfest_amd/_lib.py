@@ -34,8 +34,8 @@ SIGNATURES = {
                                                 c_int, c_int, c_int, c_f, c_f, c_f, c_f, c_int, c_fp, c_ll, c_fp, c_sz,
                                                 c_f, c_fp, c_fp, c_int, c_fp, c_fp, c_sz, c_fp, c_fp, c_int, c_fp]),
     "sdfr_render_step_fused_l1_pc": (c_int, [c_fp, c_int, c_ll, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_f, c_f, c_f,
-                                             c_f, c_f, c_fp, c_fp, c_int, c_fp, c_fp, c_sz, c_f, c_fp, c_fp, c_int, c_fp,
-                                             c_sz, c_int, c_fp]),
+                                             c_f, c_f, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_sz, c_f, c_fp, c_fp, c_int,
+                                             c_fp, c_sz, c_int, c_fp]),
     "sdfr_render_fused_view_count_offset": (c_sz, [c_int, c_int]),
     "sdfr_render_fused_tile_loss_offset": (c_sz, [c_int, c_int, c_int, c_int]),
     "sdfr_loop_tail_fused": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_f, c_f, c_f, c_f, c_int, c_fp, c_fp, c_int,
@@ -102,8 +102,8 @@ SIGNATURES = {
     "sdfr_decoder_backward_workspace_bytes": (c_sz, [c_fp, c_int]),
     "sdfr_decoder_backward_latent": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_sz, c_fp]),
     "sdfr_decoder_backward_latent_deferred": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_fp, c_fp]),
-    "sdfr_decoder_backward_latent_deferred_scaled": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_sz, c_fp,
-                                                             c_fp]),
+    "sdfr_decoder_backward_latent_deferred_scaled": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_f, c_fp, c_sz,
+                                                             c_fp, c_fp]),
     "sdfr_decoder_backward_latent_deferred_batch": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_sz, c_fp, c_fp]),
     "sdfr_pose_to_views": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_int, c_fp]),
     "sdfr_views_to_pose_grad": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,

@@ -1582,12 +1582,18 @@ __global__ __launch_bounds__(kBtMaxThreads) void resize3_backward_tiled_kernel(
 
 // g += k g2,  k = weight / cnt[0] (0 for a zero count): the scaled form's incoming gradients as one volume, for the
 // decoders whose first VJP launch is not the fused stage (which adds them on load)
-__global__ __launch_bounds__(256) void scaled_combine_kernel(float* __restrict__ g, const float* __restrict__ g2,
+// (nv volumes g2 [nv][n] with their counts: views 0, 1, ... in that order)
+__global__ __launch_bounds__(256) void scaled_combine_kernel(float* __restrict__ g, const float* __restrict__ g2, int nv,
                                                              const float* __restrict__ cnt, float weight, size_t n) {
-  const float c = cnt[0];
-  const float k = c > 0.0f ? weight / c : 0.0f;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) g[i] = fmaf(k, g2[i], g[i]);
+  if (i >= n) return;
+  float acc = g[i];
+  for (int v = 0; v < nv; ++v) {
+    const float c = cnt[v];
+    const float k = c > 0.0f ? weight / c : 0.0f;
+    acc = fmaf(k, g2[(size_t)v * n + i], acc);
+  }
+  g[i] = acc;
 }
 
 // Backward of the last (wide) Linear layer: t[n][i] = sum_o Wt[i][o] * g_last[n][o], one workgroup
@@ -1599,7 +1605,8 @@ __global__ __launch_bounds__(kFcBlock) void fc_last_backward_kernel(const float*
                                                                     const float* __restrict__ act,
                                                                     float* __restrict__ t_out,
                                                                     float* __restrict__ clear_a,
-                                                                    float* __restrict__ clear_b, int clear_vec) {
+                                                                    float* __restrict__ clear_b, int clear_vec,
+                                                                    int clear_b_volumes) {
   __shared__ float red[kFcBlock / 64];
   const int i = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
   // sdfr_decoder_backward_latent_deferred_scaled: the VJP's incoming gradient volumes were consumed by its first
@@ -1607,10 +1614,8 @@ __global__ __launch_bounds__(kFcBlock) void fc_last_backward_kernel(const float*
   if (clear_a) {
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     const int nthreads = (int)(gridDim.x * gridDim.y) * kFcBlock, me = ((int)blockIdx.y * (int)gridDim.x + i) * kFcBlock + tid;
-    for (int e = me; e < clear_vec; e += nthreads) {
-      reinterpret_cast<f32x4*>(clear_a)[e] = zero4;
-      if (clear_b) reinterpret_cast<f32x4*>(clear_b)[e] = zero4;
-    }
+    for (int e = me; e < clear_vec; e += nthreads) reinterpret_cast<f32x4*>(clear_a)[e] = zero4;
+    for (int e = me; e < clear_vec * clear_b_volumes; e += nthreads) reinterpret_cast<f32x4*>(clear_b)[e] = zero4;
   }
   const int l = d.n_fc - 1, win = d.width[l], wout = d.width[l + 1];
   const float* wt = params + d.w_off[l] + (size_t)i * wout;
@@ -2085,9 +2090,10 @@ VjpPlan vjp_stage_plan(const sdfr_decoder* d, int lc, int C, int n_in, int n_out
 
 // e_nin > 0: the stage's epilogue applies the z pass of the NEXT stage's transposed resize (nc -> e_nin)
 struct ScaledGrad {   // sdfr_decoder_backward_latent_deferred_scaled
-  float* g2;
-  const float* cnt;
+  float* g2;          // [n][volume]
+  const float* cnt;   // [n]
   float weight;
+  int n;
 };
 bool launch_vjp_stage(const sdfr_decoder* d, const VjpPlan& p, int lc, const float* g, int C, int n_in, int n_out,
                       const float* act, const float* mix_w, int mix_cout, int e_nin, float* dst, int N, hipStream_t st,
@@ -2802,7 +2808,8 @@ int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* ta
   int cur = 0;
   const float* g = grad_out;  // gradient w.r.t. the current tensor, [N][c][n^3]
   const size_t vox_in = (size_t)d->volume * d->volume * d->volume;
-  if (sg && (N != 1 || (vox_in & 3) || ((uintptr_t)grad_out & 15) || ((uintptr_t)sg->g2 & 15) || !sg->g2 || !sg->cnt))
+  if (sg && (N != 1 || sg->n < 1 || sg->n > 64 || (vox_in & 3) || ((uintptr_t)grad_out & 15) || ((uintptr_t)sg->g2 & 15) ||
+             !sg->g2 || !sg->cnt))
     return fail(SDFR_E_INVALID, "sdfr_decoder_backward_latent_deferred_scaled: one latent, 16-byte aligned volumes of a "
                 "multiple of 4 voxels");
 
@@ -3000,14 +3007,14 @@ int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* ta
   bool sg_in_stage = false;
   if (sg) {
     const int l = d->n_conv - 1;
-    if (l > 0 && out_n[l] == d->volume && d->conv_swap[l] && !d->conv_relu[l] && d->conv_k[l] == 1 && d->conv_cin[l] <= 4 &&
+    if (sg->n == 1 && l > 0 && out_n[l] == d->volume && d->conv_swap[l] && !d->conv_relu[l] && d->conv_k[l] == 1 && d->conv_cin[l] <= 4 &&
         !d->conv_swap[l - 1] && out_n[l - 1] == d->conv_prev[l] && d->conv_cout[l - 1] == d->conv_cin[l] &&
         d->conv_prev[l] != d->conv_in_size[l] && ((uintptr_t)sg->g2 & 15) == 0)
       sg_in_stage = vjp_stage_plan(d, l - 1, d->conv_cout[l], d->conv_prev[l], d->conv_in_size[l], d->conv_cin[l], N, 1,
                                    grad_out, true).ok;
     if (!sg_in_stage)
       hipLaunchKernelGGL(scaled_combine_kernel, dim3((unsigned)((vox_in + 255) / 256)), dim3(256), 0, st,
-                         const_cast<float*>(grad_out), sg->g2, sg->cnt, sg->weight, vox_in);
+                         const_cast<float*>(grad_out), sg->g2, sg->n, sg->cnt, sg->weight, vox_in);
   }
   int n = d->volume;
   if (out_n[d->n_conv - 1] != d->volume) {  // final resize
@@ -3059,7 +3066,7 @@ int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* ta
     if (mix) {
       const float* act_below = d->conv_relu[l - 1] ? tape + (size_t)N * d->tape_conv_off[l - 1] : nullptr;
       pend.plan = vjp_stage_plan(d, l - 1, co_n, prev, nin, ci_n, N, 1, g, g == grad_out);
-      if (sg && g == grad_out && pend.plan.ok != sg_in_stage)
+      if (sg && sg->n == 1 && g == grad_out && pend.plan.ok != sg_in_stage)
         return fail(SDFR_E_INVALID, "sdfr_decoder_backward_latent: the scaled form's first stage changed its mind (internal)");
       if (pend.plan.ok) {
         pend.on = true;
@@ -3156,7 +3163,7 @@ int decoder_backward_impl(const sdfr_decoder* d, const float* z, const float* ta
     else
       hipLaunchKernelGGL(fc_last_backward_kernel, dim3(win, N), dim3(kFcBlock), 0, st, d->d_params, fd, g, act_fc,
                          t_mid, sg ? const_cast<float*>(grad_out) : (float*)nullptr, sg ? sg->g2 : (float*)nullptr,
-                         (int)(vox_in / 4));
+                         (int)(vox_in / 4), sg ? sg->n : 0);
   }
   if (t_mid_out) *t_mid_out = t_mid;
   else if (decoder_fc_one_wave(d, fd))
@@ -3189,11 +3196,11 @@ extern "C" int sdfr_decoder_backward_latent_deferred_batch(const sdfr_decoder* d
 }
 
 extern "C" int sdfr_decoder_backward_latent_deferred_scaled(const sdfr_decoder* d, const float* z, const float* tape,
-                                                            float* grad_out, float* grad_scaled, const float* count,
-                                                            float weight, void* workspace, size_t workspace_bytes,
-                                                            void* stream, const float** t_mid) {
+                                                            float* grad_out, float* grad_scaled, int n_scaled,
+                                                            const float* count, float weight, void* workspace,
+                                                            size_t workspace_bytes, void* stream, const float** t_mid) {
   if (!t_mid || !grad_scaled || !count)
     return fail(SDFR_E_NULL, "sdfr_decoder_backward_latent_deferred_scaled: NULL pointer argument");
-  const ScaledGrad sg{grad_scaled, count, weight};
+  const ScaledGrad sg{grad_scaled, count, weight, n_scaled};
   return decoder_backward_impl(d, z, tape, grad_out, 1, nullptr, workspace, workspace_bytes, stream, t_mid, &sg);
 }

@@ -1350,9 +1350,9 @@ __global__ __launch_bounds__(kBlock) void render_backward_pc_kernel(
 // 8 x 8 patch per wave) and, while the depths are still in registers, runs the backward of its hit pixels
 // (backward_tile, REG).  What a tile cannot know is the view's overlap count -- the depth loss is a MEAN over pixels
 // every tile contributes to -- so the upstream gradient is the bare sign of (est - obs):
-//   * d/dSDF of the depth term goes UNSCALED into its own volume `g_depth` (the sampler's blocks add the point-cloud
-//     term, whose scale is known, into pa.g_sdf): the consumer forms  k g_depth + g_sdf,  k = weight / count
-//     (sdfr_decoder_backward_latent_deferred_scaled);
+//   * d/dSDF of the depth term goes UNSCALED into the view's own volume g_depth[b] (the sampler's blocks add the
+//     point-cloud term, whose scale is known, into pa.g_sdf): the consumer forms  g_sdf + sum_b k_b g_depth[b],
+//     k_b = weight / count_b  (sdfr_decoder_backward_latent_deferred_scaled);
 //   * the tile's pose sums are unscaled too, its (sum |est - obs|, count) pair lies in `tile_loss`, and the view's count
 //     is summed atomically in `view_cnt` (integers below 2^24 held in floats: exact whatever the order) -- the loop's
 //     tail multiplies and resets (sdfr_loop_tail_fused).
@@ -1360,7 +1360,9 @@ __global__ __launch_bounds__(kBlock) void render_backward_pc_kernel(
 // Nothing in this launch zero-fills: both volumes are cleared by their consumer (the decoder VJP's last launch).
 // The depth image is the forward's, bit for bit; the gradients differ from the two launches' in rounding only
 // (k is applied to sums instead of to terms).     grid (tiles x, pc_rows + tiles y, views)
-template <int RT, bool SDFG>
+// PCD: the sampler's blocks add straight to the (shared) point-cloud volume -- one or two views; more views collide
+// there, and their blocks pre-sum in the LDS run table as in the two-launch form.
+template <int RT, bool SDFG, bool PCD>
 __global__ __launch_bounds__(kBlock) void render_fused_l1_pc_kernel(
     const float* __restrict__ sdf, int R, long long sdf_view_stride, int W, int H, int ntx, int nty, float cx, float cy,
     float rfx, float rfy, float threshold, int vec_ok, float* __restrict__ depth, const float* __restrict__ target,
@@ -1373,7 +1375,7 @@ __global__ __launch_bounds__(kBlock) void render_fused_l1_pc_kernel(
   if ((int)blockIdx.y < pc_rows) {
     const int bx = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
     if (bx < (pa.groups > 0 ? pa.groups : pa.nblk))
-      pc_backward_block<RT, true, false, true, SDFG>(*reinterpret_cast<PcBackwardLds*>(raw), pa, bx, b);
+      pc_backward_block<RT, true, false, PCD, SDFG>(*reinterpret_cast<PcBackwardLds*>(raw), pa, bx, b);
     return;
   }
   const int tile_x = blockIdx.x, tile_y = (int)blockIdx.y - pc_rows;
@@ -1443,9 +1445,11 @@ __global__ __launch_bounds__(kBlock) void render_fused_l1_pc_kernel(
     }
   }
   if (inside) img[rp.row * W + rp.col] = rp.z;
+  // (every view its own unscaled volume: its k is its own)
   backward_tile<RT, 1, 1, SmallHash, true, false, true, SDFG>(
       *reinterpret_cast<BackwardLds<SmallHash>*>(raw), tile_x, tile_y, tile, b, LossArgs{}, nullptr, nullptr, sdf, R,
-      sdf_view_stride, &s, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_depth, 0, partials, rp);
+      sdf_view_stride, &s, W, H, cx, cy, rfx, rfy, sdf_grad_mode, g_depth, SDFG ? (long long)Rr * Rr * Rr : 0, partials,
+      rp);
 }
 
 // deterministic mode: the 64-bit fixed-point volume -> float (one rounding per voxel)
@@ -2147,18 +2151,18 @@ extern "C" size_t sdfr_render_fused_tile_loss_offset(int R, int B, int W, int H)
 extern "C" int sdfr_render_step_fused_l1_pc(
     const float* sdf, int R, long long sdf_view_stride, const float* pos, const float* quat, const float* inv_scale,
     const float* scale, int B, int W, int H, float cx, float cy, float fx, float fy, float threshold,
-    const float* target, float* depth, int sdf_grad_mode, float* g_sdf, void* workspace, size_t workspace_bytes,
-    float pc_weight, const float* points, const int* offsets, int max_view_points, void* pc_workspace,
-    size_t pc_workspace_bytes, int device, void* stream) {
+    const float* target, float* depth, int sdf_grad_mode, float* g_sdf, float* g_depth, void* workspace,
+    size_t workspace_bytes, float pc_weight, const float* points, const int* offsets, int max_view_points,
+    void* pc_workspace, size_t pc_workspace_bytes, int device, void* stream) {
   const char* fn = "sdfr_render_step_fused_l1_pc";
   if (int rc = check_common(R, B, W, H, fx, fy)) return rc;
-  if (B <= 0 || B > kInlineSetupMaxViews || W <= 0 || H <= 0 || max_view_points <= 0)
+  if (B <= 0 || B > SDFR_FUSED_MAX_VIEWS || W <= 0 || H <= 0 || max_view_points <= 0)
     return fail(SDFR_E_INVALID, "%s: 1 .. %d views of a non-empty image with observed points (B=%d W=%d H=%d points=%d)",
-                fn, kInlineSetupMaxViews, B, W, H, max_view_points);
-  if (g_sdf && B != 1)   // (one unscaled volume, one count: a second view's k would need a volume of its own)
-    return fail(SDFR_E_INVALID, "%s: d/dSDF (g_sdf) goes with ONE view, got %d", fn, B);
-  if (fixed_bytes(R) == 0 || cells_bytes(R) == 0)   // (the workspace regions the unscaled volume and the counts live in)
-    return fail(SDFR_E_INVALID, "%s: grids up to R = %d", fn, std::min(kDetMaxR, kPackedMaxR));
+                fn, SDFR_FUSED_MAX_VIEWS, B, W, H, max_view_points);
+  if ((g_sdf != nullptr) != (g_depth != nullptr))
+    return fail(SDFR_E_NULL, "%s: g_sdf and g_depth go together (both NULL: nobody wants d/dSDF)", fn);
+  if (cells_bytes(R) == 0)   // (the workspace region the counts live in)
+    return fail(SDFR_E_INVALID, "%s: grids up to R = %d", fn, kPackedMaxR);
   if (sdf_grad_mode != SDFR_SDF_GRAD_EXACT && sdf_grad_mode != SDFR_SDF_GRAD_CUDA_COMPAT)
     return fail(SDFR_E_INVALID, "%s: sdf_grad_mode %d (the weights only: no flags in the one-launch form)", fn,
                 sdf_grad_mode);
@@ -2181,27 +2185,34 @@ extern "C" int sdfr_render_step_fused_l1_pc(
   char* w = (char*)workspace;
   ViewSetup* setup = (ViewSetup*)w;
   float* partials = (float*)(w + step_partials_offset(R, B, H));
-  float* g_depth = (float*)((char*)partials + partials_bytes(B, W, H));   // (the deterministic mode's volume: not in use here)
   float* tile_loss = (float*)(w + step_loss_offset(R, B, W, H));
   float* view_cnt = (float*)(w + scratch_offset(B, H));                   // (the face records' place: the plain grid is marched)
   const int nblk = (max_view_points + kSamplerPts - 1) / kSamplerPts;
   float* pc_part = (float*)pc_workspace;
   const int groups = std::min(nblk, std::max(kSamplerMinGroups, (kSamplerGridTarget + B - 1) / B));
-  // (pose only: the sampler's blocks still need a volume to add into -- the depth term's, which nobody reads then)
+  // (pose only: SDFG = false, neither the tiles nor the sampler's blocks touch a volume)
   const PcBackwardArgs pa{nullptr, points, offsets, max_view_points, pos, quat, scale, sdf, R, sdf_view_stride,
-                          g_sdf ? g_sdf : g_depth, 0, pc_part, nblk, pc_weight, pc_part + (size_t)B * nblk * 8, groups};
+                          g_sdf, 0, pc_part, nblk, pc_weight, pc_part + (size_t)B * nblk * 8, groups};
   const int ntx = kSmallTile.nx(W), nty = kSmallTile.ny(H);
   const int pc_rows = (groups + ntx - 1) / ntx;
   const dim3 grid((unsigned)ntx, (unsigned)(nty + pc_rows), (unsigned)B);
   const float rfx = (float)(1.0 / (double)fx), rfy = (float)(1.0 / (double)fy);
   const int vec_ok = (W % 4 == 0) && ((uintptr_t)depth % 16 == 0);
   const InlineSetup in{pos, quat, inv_scale, fx, fy, setup, nullptr, 0};
-#define SDFR_LAUNCH_FUSED(RT, SDFG)                                                                              \
-  hipLaunchKernelGGL((render_fused_l1_pc_kernel<RT, SDFG>), grid, dim3(kBlock), 0, st, sdf, R, sdf_view_stride, W, H,  \
+#define SDFR_LAUNCH_FUSED(RT, SDFG, PCD)                                                                         \
+  hipLaunchKernelGGL((render_fused_l1_pc_kernel<RT, SDFG, PCD>), grid, dim3(kBlock), 0, st, sdf, R, sdf_view_stride, W, H,  \
                      ntx, nty, cx, cy, rfx, rfy, threshold, vec_ok, depth, target, in, sdf_grad_mode, g_depth,  \
                      partials, tile_loss, view_cnt, pc_rows, pa)
-  if (R == 64) { if (g_sdf) SDFR_LAUNCH_FUSED(64, true); else SDFR_LAUNCH_FUSED(64, false); }
-  else { if (g_sdf) SDFR_LAUNCH_FUSED(0, true); else SDFR_LAUNCH_FUSED(0, false); }
+  // (without d/dSDF the sampler's blocks send no atomics at all: their direct form is simply the shorter one)
+  const bool pcd = !g_sdf || B <= 2;
+#define SDFR_LAUNCH_FUSED_R(RT)                                                                                  \
+  do {                                                                                                           \
+    if (!g_sdf) SDFR_LAUNCH_FUSED(RT, false, true);                                                              \
+    else if (pcd) SDFR_LAUNCH_FUSED(RT, true, true);                                                             \
+    else SDFR_LAUNCH_FUSED(RT, true, false);                                                                     \
+  } while (0)
+  if (R == 64) SDFR_LAUNCH_FUSED_R(64); else SDFR_LAUNCH_FUSED_R(0);
+#undef SDFR_LAUNCH_FUSED_R
 #undef SDFR_LAUNCH_FUSED
   SDFR_HIP_TRY(hipGetLastError());
   return 0;

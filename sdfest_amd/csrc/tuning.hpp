@@ -53,6 +53,11 @@
 #ifndef SDFR_DENSE_CAP
 #define SDFR_DENSE_CAP 4608
 #endif
+// most views the loop's one-launch render step takes (every workgroup derives its view's record itself; every view
+// has its own unscaled d/dSDF volume).  The tail form of the loop ends at 7 views.
+#ifndef SDFR_FUSED_MAX_VIEWS
+#define SDFR_FUSED_MAX_VIEWS 8
+#endif
 // 1: the two-launch form's small-tile backward and its sampler blocks send d/dSDF straight to the volume's float
 // atomics, as the one-launch step always does (render_fused_l1_pc_kernel), instead of pre-summing in LDS.  Measured on
 // the C5 scene seen from V cameras, ms per iteration (tools/microbench/loop_forms.py): 2 views 0.1125 -> 0.1089, 4 views

@@ -516,6 +516,7 @@ class BatchRenderPlan:
         self._fixed_layout = None   # deterministic mode: which workspace layout holds the last int64 volume
         self._step_l1 = None        # the volume a forward_l1(prepare_backward=True) zero-filled
         self.partials_offset = 0    # where the last backward_l1_pc left its tile partials (sdfr_loop_tail)
+        self._g_depth = None        # step_fused_l1_pc: the views' unscaled depth-term volumes
         self.loss = torch.empty((B,), **f32)
         self.loss_stats = torch.empty((B, 2), **f32)
         # zero-filled once: the sync region's counter of prologue fall-backs (include/sdfr.h) then counts from 0
@@ -795,11 +796,12 @@ class BatchRenderPlan:
 
     def step_fused_l1_pc(self, sdf, pos, quat, inv_scale, scale, threshold: float, target, points, offsets,
                          max_view_points: int, pc_workspace, pc_weight: float = 1.0, g_sdf=None):
-        """``forward_l1(prepare_backward=True, defer_loss=True)`` and ``backward_l1_pc`` of at most 3 views as ONE launch
+        """``forward_l1(prepare_backward=True, defer_loss=True)`` and ``backward_l1_pc`` of at most 8 views as ONE launch
         (``sdfr_render_step_fused_l1_pc``): a tile runs the backward of its hit pixels while their depths are still
-        in registers.  The view's overlap count is not known inside the launch, so the depth term is left UNSCALED --
-        d/dSDF in a volume of the workspace (``g_depth``), the pose sums in the tile partials -- beside the count
-        (``view_count``); ``g_sdf`` (None: a loop that does not optimise the shape) receives the point-cloud term.
+        in registers.  A view's overlap count is not known inside the launch, so the depth term is left UNSCALED --
+        d/dSDF in the view's own volume (``g_depth`` (B,R,R,R), allocated at the first call that wants it), the pose sums
+        in the tile partials -- beside the count (``view_count``); ``g_sdf`` (None: a loop that does not optimise the shape:
+        no d/dSDF at all) receives the point-cloud term of all views.
         Nothing is zero-filled here: the consumer clears what it has read (``sdfr_decoder_backward_latent_deferred_scaled``,
         ``sdfr_loop_tail_fused``).  Returns the depth images."""
         self._step = None
@@ -809,6 +811,7 @@ class BatchRenderPlan:
             sdf.data_ptr(), self.R, self.sdf_stride, pos.data_ptr(), quat.data_ptr(), inv_scale.data_ptr(),
             scale.data_ptr(), self.B, self.W, self.H, self.cx, self.cy, self.fx, self.fy, threshold, target.data_ptr(),
             self.depth.data_ptr(), self.sdf_grad_mode, g_sdf.data_ptr() if g_sdf is not None else None,
+            self.g_depth.data_ptr() if g_sdf is not None else None,
             self.workspace.data_ptr(), self.workspace.numel(), pc_weight, points.data_ptr(),
             offsets.data_ptr() if offsets is not None else None, max_view_points, pc_workspace.data_ptr(),
             pc_workspace.numel(), self.device.index, _stream(self.device))
@@ -818,9 +821,10 @@ class BatchRenderPlan:
 
     @property
     def g_depth(self) -> torch.Tensor:
-        """the unscaled d/dSDF of the depth term that ``step_fused_l1_pc`` accumulates, (R,R,R) float32 in the workspace"""
-        off = self._L.sdfr_render_fixed_volume_offset(self.R, self.B, self.W, self.H, 1)
-        return self.workspace[off:off + self.R ** 3 * 4].view(torch.float32).view(self.R, self.R, self.R)
+        """the views' unscaled d/dSDF of the depth term that ``step_fused_l1_pc`` accumulates, (B,R,R,R) float32"""
+        if self._g_depth is None:
+            self._g_depth = torch.zeros((self.B, self.R, self.R, self.R), dtype=torch.float32, device=self.device)
+        return self._g_depth
 
     @property
     def view_count(self) -> torch.Tensor:

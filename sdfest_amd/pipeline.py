@@ -336,10 +336,10 @@ class FusedRenderAndCompare:
         platform is what ``self.graph_collective_error`` says afterwards (None: captured; a string: why not -- the loop
         then runs the two-graph form).  An experiment, off by default.
         fused_render: the render pair of an iteration as ONE launch (``sdfr_render_step_fused_l1_pc``: a tile runs the
-        backward of its hit pixels right behind their march; include/sdfr.h) -- for the tail form over ONE view (the
-        reference's own use: one call per detected object; up to 3 views when the shape is not optimised -- every view's
-        depth term has its own weight / count, and one unscaled d/dSDF volume serves one) of a grid up to 128^3, loss-fused,
-        with plain ``sdf_grad_mode`` weights; default: wherever that holds (C5: 0.110 -> 0.100 ms per iteration).  Depth
+        backward of its hit pixels right behind their march; include/sdfr.h) -- for the tail form (at most 7 views; every
+        view's depth term has its own weight / count and so its own unscaled d/dSDF volume) of a grid up to 128^3,
+        loss-fused, with plain ``sdf_grad_mode`` weights; default: where it measured faster (up to 4 views with shape
+        optimisation, any tail-form loop without; C5: 0.110 -> 0.100 ms per iteration).  Depth
         images bit for bit the two launches'; gradients equal up to rounding (the view's weight / count multiplies sums
         instead of terms), so the trajectory is the two-launch form's to ~1e-6.
         fc_in_tail (with fused_render and shape optimisation, for decoders whose Linear stack has narrow leading layers:
@@ -496,13 +496,16 @@ class FusedRenderAndCompare:
                                       self.L.sdfr_decoder_backward_workspace_bytes(decoder._h, 1), 256), **u8)
         self.ws_loss = torch.empty(max(self.L.sdfr_depth_l1_workspace_bytes(V, W, H), 256), **u8)
         self.ws_pc = torch.empty(max(self.L.sdfr_pc_loss_backward_workspace_bytes(V, self.max_pts), 256), **u8)
-        can_fuse = (self.merge_tail and not self.records_form and self.fuse_depth_loss and R <= 128
-                    and V <= (1 if self.shape_opt else 3)
+        can_fuse = (self.merge_tail and not self.records_form and self.fuse_depth_loss and R <= 128 and V <= 8
                     and self.max_pts > 0 and self.sdf_grad_mode in (0, 1) and 8 + self.Lz <= 256)
         if fused_render and not can_fuse:
-            raise ValueError("fused_render needs the tail form over ONE view (up to 3 without shape optimisation) of a "
-                             "grid up to 128^3, the loss-fused kernels and sdf_grad_mode 0 / 1")
-        self.fused_render = can_fuse if fused_render is None else bool(fused_render)
+            raise ValueError("fused_render needs the tail form over at most 8 views of a grid up to 128^3, the loss-fused "
+                             "kernels and sdf_grad_mode 0 / 1")
+        # (default: where it measured faster -- with shape optimisation up to 4 views: 1 view 0.111 -> 0.099 ms per
+        # iteration, 2: 0.112 -> 0.102, 3: 0.114 -> 0.107, 4: 0.119 -> 0.116, but 7: 0.126 -> 0.132 -- every view adds a
+        # megabyte to sum, to clear and to collide in; pose only, where no volume exists, wherever it applies)
+        auto = can_fuse and (V <= 4 or not self.shape_opt)
+        self.fused_render = auto if fused_render is None else bool(fused_render)
         can_fc = bool(self.fused_render and self.shape_opt and getattr(decoder, "narrow_linear_stack", lambda: False)())
         if fc_in_tail and not can_fc:
             raise ValueError("fc_in_tail needs fused_render, shape optimisation and a decoder with a narrow Linear stack")
@@ -581,8 +584,9 @@ class FusedRenderAndCompare:
 
     def _zero_fused_sums(self):
         """the volumes and counts ``sdfr_render_step_fused_l1_pc`` adds into (normally left at zero by their consumers)"""
-        self.plan._g_sdf_ring[0].zero_()
-        self.plan.g_depth.zero_()
+        if self.shape_opt:     # (a loop that does not optimise the shape has no d/dSDF volumes at all)
+            self.plan._g_sdf_ring[0].zero_()
+            self.plan.g_depth.zero_()
         self.plan.view_count.zero_()
         self._sums_open = False
 
@@ -791,7 +795,7 @@ class FusedRenderAndCompare:
             t_mid = ctypes.c_void_p()
             self.check(L.sdfr_decoder_backward_latent_deferred_scaled(
                 self.dec._h, self.latent.data_ptr(), self.tape.data_ptr(), g_pc.data_ptr(), plan.g_depth.data_ptr(),
-                ws + cnt_off, self.cfg["depth_weight"], self.ws_dec.data_ptr(), self.ws_dec.numel(), st,
+                self.V, ws + cnt_off, self.cfg["depth_weight"], self.ws_dec.data_ptr(), self.ws_dec.numel(), st,
                 ctypes.byref(t_mid)), "sdfr_decoder_backward_latent_deferred_scaled")
         con = self.pc_source is not None
         self.check(L.sdfr_loop_tail_fused(

@@ -1,6 +1,6 @@
 """GPU: seeded random configurations of the loop's one-launch render step (sdfr_render_step_fused_l1_pc) -- image sizes
 that are no multiple of a tile, odd grid resolutions up to 128, off-centre and anisotropic intrinsics, thresholds, objects
-from far away to filling the screen or off it, 1 .. 3 views, both d/dSDF weightings, holes in the observed images --
+from far away to filling the screen or off it, 1 .. 8 views, both d/dSDF weightings, holes in the observed images --
 against the TWO launches it replaces (sdfr_render_step_forward_l1 + sdfr_render_step_backward_l1_pc), which
 tests/test_render_fuzz_gpu.py / test_render_l1_gpu.py / test_pc_loss_gpu.py hold against the float64 oracle.
 
@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 def draw(seed):
     rng = np.random.default_rng(7000 + seed)
     R = int(rng.choice([8, 17, 32, 33, 64, 64, 100, 128]))
-    B = int(rng.choice([1, 1, 2, 3]))
+    B = int(rng.choice([1, 1, 2, 3, 5, 8]))
     W, H = int(rng.integers(17, 330)), int(rng.integers(9, 250))
     f = W * rng.uniform(0.45, 1.4)
     fx, fy = f, f * rng.uniform(0.8, 1.25)
@@ -31,7 +31,7 @@ def draw(seed):
     pos, quat, isc = oracle.random_poses(B, seed=seed, width=W, height=H, f=f)
     pos = (pos * rng.uniform(0.5, 1.3, (B, 1))).astype(np.float32)
     isc = (isc * rng.uniform(0.6, 2.5, B)).astype(np.float32)
-    if B == 3:
+    if B >= 3:
         pos[1, 0] += 50.0            # one object off screen: an empty rectangle, count 0
     sdf = oracle.blobs_sdf(int(rng.integers(0, 3)), R=R).astype(np.float32)
     return dict(R=R, B=B, W=W, H=H, fx=float(fx), fy=float(fy), cx=float(cx), cy=float(cy), thr=thr, pos=pos, quat=quat,
@@ -45,7 +45,7 @@ def test_random_configuration(seed):
     c = draw(seed)
     B, W, H, R, rng = c["B"], c["W"], c["H"], c["R"], c["rng"]
     mode = seed % 2
-    shape = B == 1                       # d/dSDF goes with one view
+    shape = seed % 3 != 2                # every third seed: nobody wants d/dSDF
     T = lambda a, dt=torch.float32: torch.tensor(np.ascontiguousarray(a), dtype=dt, device="cuda")
     camera = Camera(W, H, c["fx"], c["fy"], c["cx"], c["cy"], pixel_center=0.5)
     sdf, pos, quat, isc = T(c["sdf"]), T(c["pos"]), T(c["quat"]), T(c["isc"])
@@ -101,9 +101,7 @@ def test_random_configuration(seed):
     mag = np.abs(part(two)).sum(axis=1) + 1e-30                        # the fp32-summation yardstick: sum of |tile sums|
     assert np.all(np.abs(p_one - p_two) <= 1e-5 * mag), (seed, p_one, p_two)
     if shape:
-        g = g_pc.cpu().numpy().astype(np.float64) + k[0] * one.g_depth.cpu().numpy().astype(np.float64)
+        g = g_pc.cpu().numpy().astype(np.float64) + np.tensordot(k, one.g_depth.cpu().numpy().astype(np.float64), 1)
         ref = g_two.cpu().numpy().astype(np.float64)
         top = np.abs(ref).max()
         assert np.abs(g - ref).max() <= 1e-5 * top + 1e-30, (seed, np.abs(g - ref).max() / max(top, 1e-30))
-    else:
-        assert float(one.g_depth.abs().max()) == 0.0

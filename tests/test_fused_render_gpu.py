@@ -1,6 +1,6 @@
 """GPU: the render pair of a loop iteration as ONE launch (sdfr_render_step_fused_l1_pc -> sdfr_decoder_backward_latent_
-deferred_scaled -> sdfr_loop_tail_fused; FusedRenderAndCompare(fused_render=True), the default for one view -- up to 3
-when the shape is not optimised: every view's depth term has its own weight / count --) against
+deferred_scaled -> sdfr_loop_tail_fused; FusedRenderAndCompare(fused_render=True), the default of the tail form: up to 7
+views, every view's depth term with its own weight / count and its own unscaled volume) against
 the two launches it replaces (sdfr_render_step_forward_l1 + sdfr_render_step_backward_l1_pc), which the G7 goldens and
 the oracle pin (tests/test_loop_g7_gpu.py, tests/test_render_l1_gpu.py).
 
@@ -40,7 +40,7 @@ def _group_scale(g):
                     + ([np.abs(g[8:]).max()] * (len(g) - 8) if len(g) > 8 else []))
 
 
-@pytest.mark.parametrize("views,shape", [(1, True), (1, False), (2, False), (3, False)])
+@pytest.mark.parametrize("views,shape", [(1, True), (1, False), (2, True), (3, False), (4, True), (7, True)])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_first_gradient_equals_the_two_launch_form(views, shape, mode):
     """one eager iteration: the gradient vector Adam is given, the depth images, both loss values"""
@@ -57,8 +57,9 @@ def test_first_gradient_equals_the_two_launch_form(views, shape, mode):
         if fused:
             # the consumers cleared what they read: the next step adds into zeros
             assert float(loop.plan.view_count.abs().max()) == 0.0
-            assert float(loop.plan.g_depth.abs().max()) == 0.0
-            assert float(loop.plan._g_sdf_ring[0].abs().max()) == 0.0
+            if shape:
+                assert float(loop.plan.g_depth.abs().max()) == 0.0
+                assert float(loop.plan._g_sdf_ring[0].abs().max()) == 0.0
     assert torch.equal(got[True][1], got[False][1]), "depth images differ"
     g0, g1 = got[False][0], got[True][0]
     assert np.all(np.isfinite(g1)) and (np.abs(g0[8:]).max() > 0) == shape
@@ -70,7 +71,7 @@ def test_first_gradient_equals_the_two_launch_form(views, shape, mode):
     np.testing.assert_array_equal(got[True][3], got[False][3])           # point loss: the same blocks, the same order
 
 
-@pytest.mark.parametrize("views,shape", [(1, True), (1, False), (2, False), (3, False)])
+@pytest.mark.parametrize("views,shape", [(1, True), (1, False), (2, True), (3, False), (5, True)])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_trajectory_follows_the_two_launch_form(views, shape, use_graph):
     s = _scene(views, 12)
@@ -217,16 +218,21 @@ def test_an_object_out_of_sight_contributes_nothing():
 
 def test_which_loops_take_the_one_launch_form():
     from sdfest_amd.differentiable_renderer import BWD_SMALL_TILES, SDF_GRAD_DETERMINISTIC
-    s4 = _scene(4, 1)
-    assert _loop(_scene(1, 1), None).fused_render and not _loop(_scene(2, 1), None).fused_render
-    assert _loop(_scene(3, 1), None, shape_optimization=False).fused_render
-    assert not _loop(s4, None, shape_optimization=False).fused_render
-    with pytest.raises(ValueError, match="fused_render"):
-        _loop(s4, True, shape_optimization=False)
-    with pytest.raises(ValueError, match="fused_render"):
-        _loop(_scene(2, 1), True)
-    s = _scene(2, 1)
     from sdfest_amd.pipeline import FusedRenderAndCompare
+    assert _loop(_scene(1, 1), None).fused_render and _loop(_scene(4, 1), None).fused_render
+    assert not _loop(_scene(7, 1), None).fused_render and _loop(_scene(7, 1), True).fused_render      # (slower there: opt-in)
+    assert _loop(_scene(7, 1), None, shape_optimization=False).fused_render
+    s9 = S.build("many", iterations=1)
+    s9 = dict(s9, depth=s9["depth"][:9].contiguous(), cam_pos=s9["cam_pos"][:9].contiguous(),
+              cam_quat=s9["cam_quat"][:9].contiguous())
+    assert not _loop(s9, None).fused_render
+    with pytest.raises(ValueError, match="fused_render"):
+        _loop(s9, True)
+    s8 = dict(s9, depth=s9["depth"][:8].contiguous(), cam_pos=s9["cam_pos"][:8].contiguous(),
+              cam_quat=s9["cam_quat"][:8].contiguous())
+    auto8 = FusedRenderAndCompare(s8["decoder"], s8["camera"], s8["config"], s8["depth"], s8["cam_pos"], s8["cam_quat"])
+    assert auto8.records_form and not auto8.fused_render          # form="auto": the records form from 8 views on
+    s = _scene(2, 1)
     det = FusedRenderAndCompare(s["decoder"], s["camera"], s["config"], s["depth"], s["cam_pos"], s["cam_quat"],
                                 shape_optimization=False, sdf_grad_mode=SDF_GRAD_DETERMINISTIC | BWD_SMALL_TILES)
     assert not det.fused_render          # (the records form)
@@ -247,19 +253,19 @@ def test_c_abi_argument_errors():
         return L.sdfr_render_step_fused_l1_pc(
             sdf.data_ptr(), R, 0, loop.pos_c.data_ptr(), loop.quat_c.data_ptr(), loop.inv_scale.data_ptr(),
             loop.scale_v.data_ptr(), B, plan.W, plan.H, plan.cx, plan.cy, plan.fx, plan.fy, 0.005, loop.target.data_ptr(),
-            plan.depth.data_ptr(), mode, None, plan.workspace.data_ptr(),
+            plan.depth.data_ptr(), mode, None, None, plan.workspace.data_ptr(),
             plan.workspace.numel() if ws_bytes is None else ws_bytes, 3.0, loop.points.data_ptr(),
             loop.offsets.data_ptr(), pts, loop.ws_pc.data_ptr(), loop.ws_pc.numel(), 0, None)
 
     inv, wsp = -1, -3      # SDFR_E_INVALID, SDFR_E_WORKSPACE (include/sdfr.h)
-    assert call(B=4) == inv and b"views" in L.sdfr_last_error()
+    assert call(B=9) == inv and b"views" in L.sdfr_last_error()
     assert call(mode=0x100) == inv and b"sdf_grad_mode" in L.sdfr_last_error()
     assert call(R=256) == inv
     assert call(pts=0) == inv
     assert call(ws_bytes=1024) == wsp
     t_mid = ctypes.c_void_p()
     rc = L.sdfr_decoder_backward_latent_deferred_scaled(
-        s["decoder"]._h, loop.latent.data_ptr(), loop.tape.data_ptr(), plan._g_sdf_ring[0].data_ptr(), None,
+        s["decoder"]._h, loop.latent.data_ptr(), loop.tape.data_ptr(), plan._g_sdf_ring[0].data_ptr(), None, 1,
         plan.view_count.data_ptr(), 1.0, loop.ws_dec.data_ptr(), loop.ws_dec.numel(), None, ctypes.byref(t_mid))
     assert rc != 0 and b"NULL" in L.sdfr_last_error()
 
@@ -291,8 +297,8 @@ def _oracle_step(sdf, pos, quat, isc, cam, tgt, points, offsets, thr, w_depth, w
 
 
 @pytest.mark.parametrize("R,W,H,B,mode,shape", [(64, 640, 480, 1, 0, True), (40, 150, 101, 1, 1, True),
-                                                (100, 97, 64, 1, 0, True), (64, 160, 120, 3, 0, False),
-                                                (33, 90, 50, 2, 1, False)])
+                                                (100, 97, 64, 2, 0, True), (64, 160, 120, 3, 0, False),
+                                                (33, 90, 50, 2, 1, False), (64, 160, 120, 5, 1, True)])
 def test_one_launch_step_against_the_float64_oracle(R, W, H, B, mode, shape):
     import oracle
     from sdfest_amd import BatchRenderPlan, Camera, _lib
@@ -340,12 +346,10 @@ def test_one_launch_step_against_the_float64_oracle(R, W, H, B, mode, shape):
     assert np.all(np.abs(cnt - ref_cnt) <= 2), (cnt, ref_cnt)
     k = np.where(cnt > 0, w_depth / np.maximum(cnt, 1), 0.0)
     if shape:
-        g = g_pc.cpu().numpy().astype(np.float64) + k[0] * plan.g_depth.cpu().numpy().astype(np.float64)
+        g = g_pc.cpu().numpy().astype(np.float64) + np.tensordot(k, plan.g_depth.cpu().numpy().astype(np.float64), 1)
         ref = ref_gsdf + ref_gpc
         from helpers import check_sdf_grad
         check_sdf_grad(g, ref, mode, int(hit.sum()), rel=1e-4, name=f"one launch R={R} {W}x{H}")
-    else:
-        assert float(plan.g_depth.abs().max()) == 0.0           # nobody asked for d/dSDF: nothing was added
     # the tiles' pose sums, times k: the renderer's pose gradients
     off = plan.partials_offset
     ntx, nty = (W + 31) // 32, (H + 7) // 8

@@ -33,10 +33,10 @@ def run(views, fused, n=7, shape=True, fc=None):
 
 
 def main():
-    for views, shape in ((1, True), (1, False), (2, False), (3, False)):
+    for views, shape in ((1, True), (1, False), (2, True), (3, True), (4, True), (7, True), (3, False)):
         res = {}
         for fused, fc in ((False, None), (True, False), (True, True)):
-            if fc and not shape:
+            if fc and (not shape or views > 1):
                 continue
             res[fused, fc] = run(views, fused, shape=shape, fc=fc)
             print(f"views {views} shape optimisation {shape}: render pair as one launch {fused}, Linear stack in the tail's "
