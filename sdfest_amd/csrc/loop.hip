@@ -858,8 +858,8 @@ __global__ __launch_bounds__(256) void loop_tail_kernel(LoopTailArgs a_in) {
       fc_narrow_forward_one_wave(fc_lds, a.fc, lane);
     }
     __syncthreads();
-    // (the thread's column of the wide layer's weights preloaded at the kernel's start -- 64 loads per thread in front
-    // of everything else -- was measured: the tail 10.3 -> 13.6 us; they queue ahead of the loads the chain waits for)
+    // (the thread's column of the wide layer's weights preloaded into 64 registers -- at the kernel's start, or behind
+    // the chain's last load, under the Adam step -- was measured: the tail 10.3 -> 13.6 / 13.9 us)
     fc_wide_slice(a.dec_params, a.fc, fc_lds.a[a.fc.n_fc - 1], (int)blockIdx.x, a.fc_next);
     if (helper) return;
     // workgroup 0 stores the new state below: not before every other workgroup has read the old one
