@@ -200,11 +200,8 @@ class SDFPipeline:
                 prior_orientation_distribution = prior_orientation_distribution.unsqueeze(0)
         n_imgs = depth_images.shape[0]
         dev = self._dev
-        if camera_positions is None:
-            camera_positions = torch.zeros(n_imgs, 3, device=dev)
-        if camera_orientations is None:
-            camera_orientations = torch.zeros(n_imgs, 4, device=dev)
-            camera_orientations[:, 3] = 1.0
+        # (the default cameras -- the origin, the identity: :327-331 -- are left as None for ``rebind``, which writes them
+        # into the loop's own buffers; only the host-driven initialisation below needs them as tensors)
 
         loop = self._loop(n_imgs, shape_optimization)
         with torch.no_grad():
@@ -230,8 +227,9 @@ class SDFPipeline:
                     training_orientation_distribution)
             else:
                 latent_shape, position, scale, orientation = self._nn_init(
-                    depth_images, camera_positions, camera_orientations, prior_orientation_distribution,
-                    training_orientation_distribution)
+                    depth_images, loop.cam_pos_all if camera_positions is None else camera_positions,
+                    loop.cam_quat_all if camera_orientations is None else camera_orientations,
+                    prior_orientation_distribution, training_orientation_distribution)
             # :381-470
             position, orientation, scale, latent_shape = loop(position, orientation, scale, latent_shape)
             if resident is not None and resident.empty_views():
