@@ -267,9 +267,10 @@ SDFR_API int sdfr_render_step_backward_l1_pc(
  * forms  g_sdf + sum_b k_b g_depth[b],  k_b = weight / count_b, and clears the volumes; sdfr_loop_tail_fused multiplies
  * the pose sums and resets the counts) -- the volumes and the counts must be zero before the FIRST call.
  * depth equals sdfr_render_step_forward_l1's bit for bit; the gradients equal the two launches' up to rounding (k
- * multiplies sums instead of terms).  d/dSDF goes to the volumes by float atomics directly (no LDS pre-sum: what a
- * launch over a few views costs is the depth of a tile's chain of phases); from 3 views on the sampler's blocks, which
- * share one volume, keep their run table.  sdf_grad_mode: SDFR_SDF_GRAD_EXACT or _CUDA_COMPAT, no flags.  R <= 128.
+ * multiplies sums instead of terms).  A view whose observed point set is small (<= 6144 points, tuning.hpp) sends its
+ * d/dSDF to the volumes by float atomics directly (no LDS pre-sum: what a small object costs is the depth of a tile's
+ * chain of phases); larger ones, and the sampler's blocks of 3 and more views (they share one volume), pre-sum in their
+ * LDS tables as the two-launch form does.  sdf_grad_mode: SDFR_SDF_GRAD_EXACT or _CUDA_COMPAT, no flags.  R <= 128.
  * pos / quat / inv_scale / scale: the views' poses (scale = 1 / inv_scale, what the sampler takes). */
 SDFR_API size_t sdfr_render_fused_view_count_offset(int B, int H);
 SDFR_API size_t sdfr_render_fused_tile_loss_offset(int R, int B, int W, int H);   /* the (sum, count) tile records */

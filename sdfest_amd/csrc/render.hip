@@ -936,6 +936,7 @@ struct RegPixel {
   int row = 0, col = 0;
   float* tile_loss = nullptr;   // this tile's (sum, count)
   float* view_cnt = nullptr;    // the view's overlap count (atomic: integers below 2^24, exact in any order)
+  bool use_table = false;       // d/dSDF pre-summed in the tile's LDS table (a view of many pixels) or sent straight
 };
 template <int RT, int SX, int SY, typename Hash, bool LOSS, bool DET = false, bool REG = false, bool SDFG = true>
 __device__ __forceinline__ void backward_tile(
@@ -946,11 +947,13 @@ __device__ __forceinline__ void backward_tile(
     int sdf_grad_mode, float* __restrict__ g_sdf, long long g_sdf_view_stride,
     float* __restrict__ partials, const RegPixel& rp = RegPixel{}) {
   static_assert(!REG || (SX * SY == 1 && LOSS && !DET), "the register form: one pixel per thread, loss-fused");
-  // d/dSDF pre-summed in the tile's LDS table -- or, REG, straight to the volume's float atomics: a launch over one or
-  // a few views is a few hundred tiles with hit pixels, and what it takes is the depth of a tile's chain of phases
-  // (bounds pass, clear, adds, flush: three barriers and a table walk), not the number of atomics it sends: the loop's
-  // iteration 0.1042 -> 0.0970 ms without the table (tools/microbench/fused_render.py)
-  constexpr bool TABLE = SDFG && !REG && !(SDFR_SMALL_DIRECT && std::is_same<Hash, SmallHash>::value && !DET);
+  // d/dSDF pre-summed in the tile's LDS table -- or straight to the volume's float atomics.  REG (the loop's one-launch
+  // step) decides per VIEW (rp.use_table, workgroup-uniform): a small object is a few dozen tiles with hit pixels, and
+  // what they take is the depth of a tile's chain of phases (bounds pass, clear, adds, flush: three barriers and a table
+  // walk), not the number of atomics -- the C5 mug's 4 k pixels: 0.1042 -> 0.0970 ms per iteration without the table;
+  // an object that fills the image sends so many that they queue up on the volume -- 25 k pixels 0.119 -> 0.145 ms,
+  // 83 k: 0.135 -> 0.306 -- and keeps the table (tools/microbench/fused_render_close.py)
+  const bool TABLE = SDFG && (REG ? rp.use_table : !(SDFR_SMALL_DIRECT && std::is_same<Hash, SmallHash>::value && !DET));
   Hash& hash = lds.hash;
   float (*wave_part)[8] = lds.wave_part;
 
@@ -1372,10 +1375,16 @@ __global__ __launch_bounds__(kBlock) void render_fused_l1_pc_kernel(
   constexpr size_t kLdsBytes = kTileLds > sizeof(PcBackwardLds) ? kTileLds : sizeof(PcBackwardLds);
   __shared__ __attribute__((aligned(16))) unsigned char raw[kLdsBytes];
   const int b = blockIdx.z;
+  // straight atomics or the LDS tables: by the size of the view's observed point set -- its mask's pixels, which is
+  // what the estimate comes to cover (workgroup-uniform, one scalar load; backward_tile, TABLE)
+  const int n_obs = pa.offsets ? pa.offsets[b + 1] - pa.offsets[b] : pa.n_single;
+  const bool direct = n_obs <= SDFR_FUSED_DIRECT_MAX_POINTS;
   if ((int)blockIdx.y < pc_rows) {
     const int bx = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
-    if (bx < (pa.groups > 0 ? pa.groups : pa.nblk))
-      pc_backward_block<RT, true, false, PCD, SDFG>(*reinterpret_cast<PcBackwardLds*>(raw), pa, bx, b);
+    if (bx < (pa.groups > 0 ? pa.groups : pa.nblk)) {
+      if (PCD && direct) pc_backward_block<RT, true, false, true, SDFG>(*reinterpret_cast<PcBackwardLds*>(raw), pa, bx, b);
+      else pc_backward_block<RT, true, false, false, SDFG>(*reinterpret_cast<PcBackwardLds*>(raw), pa, bx, b);
+    }
     return;
   }
   const int tile_x = blockIdx.x, tile_y = (int)blockIdx.y - pc_rows;
@@ -1412,6 +1421,7 @@ __global__ __launch_bounds__(kBlock) void render_fused_l1_pc_kernel(
   rp.row = py0 + PF::oy(wave) + PF::y(lane);
   rp.tile_loss = tile_loss + tile * kLossRec;
   rp.view_cnt = view_cnt + b;
+  rp.use_table = !direct;
   const bool inside = (rp.col < W) && (rp.row < H);
   // the march: forward_tile's (plain grid, full cube), one pixel per lane
   if (overlaps(rc, px0 + PF::ox(wave), py0 + PF::oy(wave), PF::W, PF::H)) {

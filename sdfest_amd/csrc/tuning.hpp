@@ -58,6 +58,13 @@
 #ifndef SDFR_FUSED_MAX_VIEWS
 #define SDFR_FUSED_MAX_VIEWS 8
 #endif
+// the one-launch render step sends a view's d/dSDF straight to float atomics while the view's observed point set (its
+// mask's pixels) is at most this large, and through the LDS tables beyond (tools/microbench/fused_render_close.py: the
+// C5 mug at 0.5 m, 4 k pixels: straight 0.0995 ms per iteration against 0.1042 through the tables; 11 k pixels 0.117
+// against the two launches' 0.112; 25 k: 0.145 against 0.119; 83 k: 0.306 against 0.135)
+#ifndef SDFR_FUSED_DIRECT_MAX_POINTS
+#define SDFR_FUSED_DIRECT_MAX_POINTS 6144
+#endif
 // 1: the two-launch form's small-tile backward and its sampler blocks send d/dSDF straight to the volume's float
 // atomics, as the one-launch step always does (render_fused_l1_pc_kernel), instead of pre-summing in LDS.  Measured on
 // the C5 scene seen from V cameras, ms per iteration (tools/microbench/loop_forms.py): 2 views 0.1125 -> 0.1089, 4 views

@@ -18,7 +18,7 @@ OVERRIDES = {"SDFR_MACRO_SX": "2", "SDFR_MACRO_SY": "1", "SDFR_FWD_SX": "4", "SD
              "SDFR_DENSE_CAP": "3072", "SDFR_BWD_WAVES_PER_EU": "0", "SDFR_BT_LOADS": "6", "SDFR_BT_OUT": "4",
              "SDFR_BT_TILE": "4", "SDFR_BT_THREADS": "512", "SDFR_PC_GRID_TARGET": "2048", "SDFR_PC_MIN_GROUPS": "16",
              "SDFR_DIRECT_MIN_TILES": "128", "SDFR_DIRECT_MIN_TILES_FEW": "64", "SDFR_DIRECT_MIN_LATENTS_FEW": "4", "SDFR_FEW_MIX_LOG2": "20", "SDFR_RESIZE_TILED_MIN_ITEMS": "1024", "SDFR_INLINE_MAX_VIEWS": "4", "SDFR_SPLITK_MAX_LATENTS": "8",
-             "SDFR_SMALL_DIRECT": "1", "SDFR_FUSED_MAX_VIEWS": "4"}
+             "SDFR_SMALL_DIRECT": "1", "SDFR_FUSED_MAX_VIEWS": "4", "SDFR_FUSED_DIRECT_MAX_POINTS": "1000"}
 
 
 def test_every_tunable_is_listed_and_overridable():

@@ -365,3 +365,48 @@ def test_one_launch_step_against_the_float64_oracle(R, W, H, B, mode, shape):
     rec = plan.workspace[lo:lo + B * ntx * nty * 32].view(torch.float32).view(B, nty * ntx, 8).cpu().numpy().astype(np.float64)
     np.testing.assert_allclose(rec[:, :, 0].sum(axis=1) / np.maximum(cnt, 1), np.nan_to_num(ref_loss), rtol=2e-4, atol=1e-7)
     np.testing.assert_array_equal(rec[:, :, 1].sum(axis=1), cnt)
+
+
+# ---- an object that fills the image: the one-launch step pre-sums d/dSDF in the LDS tables (SDFR_FUSED_DIRECT_MAX_POINTS) --
+
+def _close_scene(iterations):
+    """the mug 0.17 m in front of a 320x240 camera: ~11 k observed pixels, above the bound of the straight atomics"""
+    from sdfest_amd import Camera, render_depth_gpu
+    dec, d = S.mug_decoder()
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device="cuda")
+    cam = Camera(320, 240, 200.0, 200.0, 160.0, 120.0, pixel_center=0.5)
+    p_true = np.array([0.005, -0.004, -0.17])
+    q_true = np.array([0.2, 0.6, -0.15, 0.75]); q_true /= np.linalg.norm(q_true)
+    s_true = 0.055
+    with torch.no_grad():
+        sdf = dec.decode(t(d["z"][9:10] * 0.5))[0, 0]
+        depth = render_depth_gpu(sdf, t(p_true), t(q_true), t(1.0 / s_true), None, None, None, 0.005, cam)[None].contiguous()
+    q0 = q_true + np.array([0.03, -0.02, 0.02, 0.0])
+    cfg = {"threshold": 0.005, "max_iterations": iterations, "depth_weight": 1.0, "pc_weight": 3.0}
+    return dict(decoder=dec, camera=cam, config=cfg, depth=depth, cam_pos=t([[0.0, 0.0, 0.0]]), cam_quat=t([[0.0, 0.0, 0.0, 1.0]]),
+                init=(t(p_true[None] + 0.003), t((q0 / np.linalg.norm(q0))[None]), t([0.057]),
+                      torch.zeros(1, int(d["latent_size"]), device="cuda")))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_an_object_that_fills_the_image_takes_the_tables(mode):
+    s = _close_scene(8)
+    n_obs = int((s["depth"] > 0).sum())
+    assert n_obs > 6144 + 2000, n_obs                   # (tuning.hpp: SDFR_FUSED_DIRECT_MAX_POINTS)
+    got, hist = {}, {}
+    for fused in (False, True):
+        loop = _loop(s, fused, sdf_grad_mode=mode)
+        h = []
+        loop(*s["init"], use_graph=False, history=h)
+        torch.cuda.synchronize()
+        hist[fused] = S.history_array(h)
+        one = _loop(s, fused, sdf_grad_mode=mode)
+        one.cfg = dict(one.cfg, max_iterations=1)
+        one(*s["init"], use_graph=False)
+        torch.cuda.synchronize()
+        got[fused] = (one.grads.cpu().numpy().astype(np.float64), one.plan.depth.clone())
+    assert torch.equal(got[True][1], got[False][1])
+    err = np.abs(got[True][0] - got[False][0]) / _group_scale(got[False][0])
+    assert err.max() < 1e-5, err
+    d = np.abs(hist[True] - hist[False])
+    assert d[:, :8].max() < 5e-6 and d[:, 8:].max() < 2e-4, (d[:, :8].max(), d[:, 8:].max())
