@@ -410,3 +410,34 @@ def test_an_object_that_fills_the_image_takes_the_tables(mode):
     assert err.max() < 1e-5, err
     d = np.abs(hist[True] - hist[False])
     assert d[:, :8].max() < 5e-6 and d[:, 8:].max() < 2e-4, (d[:, :8].max(), d[:, 8:].max())
+
+
+def test_rebinding_between_a_small_and_a_large_object_needs_no_capture():
+    """straight atomics or tables is decided inside the launch, from the observed point set's size on the device: the
+    captured graphs serve an object of any size (FusedRenderAndCompare.rebind)"""
+    big = _close_scene(6)
+    from sdfest_amd import render_depth_gpu
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float32), device="cuda")
+    with torch.no_grad():      # the same mug three times as far: a ninth of the pixels
+        sdf = big["decoder"].decode(torch.tensor(S.mug_decoder()[1]["z"][9:10] * 0.5, device="cuda"))[0, 0]
+        p_far = big["init"][0].clone()
+        p_far[0, 2] = -0.51
+        small_depth = render_depth_gpu(sdf, p_far[0], big["init"][1][0], 1.0 / big["init"][2][0], None, None, None, 0.005,
+                                       big["camera"])[None].contiguous()
+    assert int((small_depth > 0).sum()) < 6144 < int((big["depth"] > 0).sum())
+    small = dict(big, depth=small_depth, init=(p_far + 0.003,) + tuple(big["init"][1:]))
+    ref = {}
+    for name, s in (("big", big), ("small", small)):
+        loop = _loop(s, True)
+        ref[name] = [x.clone() for x in loop(*s["init"], use_graph=True)]
+    loop = _loop(big, True)
+    graphs = None
+    for name, s in (("big", big), ("small", small), ("big", big), ("small", small)):
+        loop.rebind(s["depth"], s["cam_pos"], s["cam_quat"])
+        out = loop(*s["init"], use_graph=True)
+        torch.cuda.synchronize()
+        for a, b, tol in zip(out, ref[name], (2e-6, 2e-5, 2e-6, 1e-4)):
+            assert (a - b).abs().max().item() <= tol, (name, a, b)
+        now = (id(loop.graph), id(loop.graph_many))
+        assert graphs in (None, now)
+        graphs = now
