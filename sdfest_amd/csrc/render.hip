@@ -1359,8 +1359,10 @@ __global__ __launch_bounds__(kBlock) void render_backward_pc_kernel(
 //   * the tile's pose sums are unscaled too, its (sum |est - obs|, count) pair lies in `tile_loss`, and the view's count
 //     is summed atomically in `view_cnt` (integers below 2^24 held in floats: exact whatever the order) -- the loop's
 //     tail multiplies and resets (sdfr_loop_tail_fused).
-// Neither the tiles nor the sampler's blocks pre-sum in LDS (backward_tile REG, pc_backward_block DIRECT).
-// Nothing in this launch zero-fills: both volumes are cleared by their consumer (the decoder VJP's last launch).
+// A view whose observed point set is small sends d/dSDF straight to the volumes' float atomics -- tiles and sampler blocks
+// alike; a larger one pre-sums in the LDS tables as the two launches do (`direct` below; backward_tile REG / TABLE,
+// pc_backward_block DIRECT).
+// Nothing in this launch zero-fills: the volumes are cleared by their consumer (the decoder VJP's last launch).
 // The depth image is the forward's, bit for bit; the gradients differ from the two launches' in rounding only
 // (k is applied to sums instead of to terms).     grid (tiles x, pc_rows + tiles y, views)
 // PCD: the sampler's blocks add straight to the (shared) point-cloud volume -- one or two views; more views collide

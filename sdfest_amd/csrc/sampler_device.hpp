@@ -99,8 +99,8 @@ struct PcBackwardLds {
 // 640x480 view, of which a mug fills ~60).  (Several blocks through ONE table, flushed once, was measured and
 // dropped: the block is a dependent chain and every block added to it costs its full length, profiles/r05_pc_rounds.md.)
 // DIRECT: every point's eight contributions go straight to the volume's float atomics -- no table, no block maximum,
-// two barriers less per block: for launches of a few dozen blocks (one view of the captured loop), where what a block
-// costs is the depth of its dependent chain and not the number of atomics it sends.
+// two barriers less per block: for launches of a few dozen blocks (a small object in one or two views of the captured
+// loop), where what a block costs is the depth of its dependent chain and not the number of atomics it sends.
 // SDFG = false: nobody wants d/dSDF (a loop that does not optimise the shape) -- pose sums and the loss only.
 template <int RT, bool L1, bool DET = false, bool DIRECT = false, bool SDFG = true>
 __device__ __forceinline__ void pc_backward_block(PcBackwardLds& lds, const PcBackwardArgs& a, int bx, int v) {

@@ -66,10 +66,11 @@
 #define SDFR_FUSED_DIRECT_MAX_POINTS 6144
 #endif
 // 1: the two-launch form's small-tile backward and its sampler blocks send d/dSDF straight to the volume's float
-// atomics, as the one-launch step always does (render_fused_l1_pc_kernel), instead of pre-summing in LDS.  Measured on
+// atomics, as the one-launch step does for small objects (render_fused_l1_pc_kernel), instead of pre-summing in LDS.  Measured on
 // the C5 scene seen from V cameras, ms per iteration (tools/microbench/loop_forms.py): 2 views 0.1125 -> 0.1089, 4 views
 // 0.1207 -> 0.1233, 8: 0.1330 -> 0.1499, 16: 0.1624 -> 0.1979; K objects side by side unchanged -- beyond a view or two
-// the atomics on a shared volume collide, so: 0
+// the atomics on a shared volume collide (and a stand-alone backward does not know how large its object is: BASELINE's C1,
+// 160x120, 26.3 -> 19.4 us per pair, but C2, 640x480 and a large object, 23.0 -> 33.1), so: 0
 #ifndef SDFR_SMALL_DIRECT
 #define SDFR_SMALL_DIRECT 0
 #endif
